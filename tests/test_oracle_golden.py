@@ -1,0 +1,159 @@
+"""The oracle (oracle/cpu_ref.py) pinned against outputs of the reference's own
+functions (tests/golden/*.npz, produced by oracle/make_golden.py) and against
+the known-answer values recorded in SURVEY.md section 8c."""
+import numpy as np
+import pytest
+
+from conftest import golden
+from oracle import cpu_ref
+
+STAGE_FILES = [
+    "stages_4x6x8_c64.npz", "stages_6x4x12_c64.npz", "stages_16x16x16_c64.npz",
+    "stages_32x32x32_c64.npz", "stages_16x32x64_c64.npz",
+    "stages_4x6x8_c128.npz", "stages_16x16x16_c128.npz", "stages_32x32x32_c128.npz",
+]
+
+
+@pytest.mark.parametrize("name", STAGE_FILES)
+def test_stages_bit_exact_through_symmetrize(name, default_power):
+    g = golden(name)
+    nx, ny, nz = (int(v) for v in g["shape"])
+    dtype = g["kspace"].dtype
+    spacing, seed = float(g["spacing"]), int(g["seed"])
+    k, Pk = default_power["k"], default_power["Pk"]
+
+    data = cpu_ref.fill_log10k(nx, ny, nz, spacing, dtype)
+    assert np.array_equal(data.real, g["log10k"])           # includes -inf at DC
+    assert np.isneginf(data.real[0, 0, 0]) and not data.imag.any()
+
+    cpu_ref.tabulate_sigmas(data, k, Pk, spacing)
+    assert np.array_equal(data.real, g["sigma"])
+    assert data.real[0, 0, 0] == 0
+
+    cpu_ref.randomize(data, seed=seed)
+    assert np.array_equal(data, g["randomized"])
+
+    cpu_ref.symmetrize_packed(data)
+    assert np.array_equal(data, g["kspace"])
+    assert cpu_ref.is_hermitian_packed(data)
+
+    delta = cpu_ref.c2r(data)
+    rms = float(g["rms"])
+    tol = 1e-6 if dtype == np.complex64 else 1e-13
+    assert np.max(np.abs(delta - g["delta"])) <= tol * rms
+    assert abs(np.std(delta) - rms) <= tol * rms
+    # f64-FFT-then-round variant (numpy 1.x behaviour) agrees within f32 FFT error
+    delta64 = cpu_ref.c2r(data, double_fft=True)
+    assert np.max(np.abs(delta64 - g["delta"])) <= 3e-6 * rms
+
+
+@pytest.mark.parametrize("n,tag", [(64, "c64"), (128, "c64"), (64, "c128"), (128, "c128")])
+def test_summary_grids(n, tag, default_power):
+    g = golden("summary_%d_%s.npz" % (n, tag))
+    dtype = np.complex64 if tag == "c64" else np.complex128
+    data = cpu_ref.generate_kspace(n, n, n, 2.5, default_power["k"], default_power["Pk"],
+                                   seed=123, dtype=dtype)
+    assert np.array_equal(data[:, :, 0], g["kspace_plane0"])
+    assert np.array_equal(data[:, :, n // 2], g["kspace_nyq"])
+    assert np.array_equal(data[::8, ::8, 1::7], g["kspace_sub"])
+    delta = cpu_ref.c2r(data)
+    rms = float(g["rms"])
+    tol = 2e-6 if tag == "c64" else 1e-13
+    assert np.max(np.abs(delta[::8, ::8, ::8] - g["sub"])) <= tol * rms
+    assert abs(np.std(delta) - rms) <= tol * rms
+    assert abs(delta.astype(np.float64).mean() - float(g["mean"])) < 1e-6
+
+
+def test_survey_known_answers(default_power):
+    """SURVEY.md 8c spot values (default P(k), spacing 2.5, seed 123, c64)."""
+    expect = {
+        64: ([-0.87743145, -2.2504132, -2.4692194, -1.7827865],
+             [-1.2413877, 0.30402526, 1.9525096, 3.7410448], 2.3093588),
+        128: ([-0.28138322, -0.53682196, 0.38453567, -1.8259681],
+              [-0.1237278, -2.8513167, -2.2769353, 3.2357025], 2.3160193),
+    }
+    for n, (first, last, std) in expect.items():
+        delta, rms = cpu_ref.generate_delta_field(n, n, n, 2.5, default_power["k"],
+                                                  default_power["Pk"], seed=123)
+        assert delta.dtype == np.float32 and delta.shape == (n, n, n)
+        assert np.allclose(delta[0, 0, :4], first, rtol=0, atol=5e-6)
+        assert np.allclose(delta[-1, -1, -4:], last, rtol=0, atol=5e-6)
+        assert abs(rms - std) < 5e-6
+    # at 32^3: sigma range and log10k range quoted in the survey
+    d = cpu_ref.fill_log10k(32, 32, 32, 2.5)
+    lk = d.real[np.isfinite(d.real)]
+    assert abs(lk.min() - (-1.10491)) < 1e-5 and abs(lk.max() - 0.33777) < 1e-5
+    cpu_ref.tabulate_sigmas(d, default_power["k"], default_power["Pk"], 2.5)
+    s = d.real[d.real > 0]
+    assert abs(s.min() - 106.334) < 1e-3 and abs(s.max() - 3025.888) < 1e-3
+
+
+def test_noise_stream_definition():
+    """MT19937 + polar restatement == numpy RandomState == golden fixture."""
+    g = golden("normals_seed123.npz")["normals"]
+    assert np.allclose(g[:4], [-1.0856306, 0.99734545, 0.2829785, -1.50629471], atol=1e-7)
+    assert np.array_equal(np.random.RandomState(123).normal(size=4096), g)
+    mine = cpu_ref.legacy_normals(123, 1500)
+    assert np.array_equal(mine, g[:1500])
+
+
+def test_smoothed_and_gaussian_tables(default_power):
+    g = golden("smoothed_16_c64.npz")
+    Pk = default_power["Pk"] * np.exp(-(default_power["k"] * float(g["smoothing"])) ** 2)
+    assert np.array_equal(Pk, g["smoothed_Pk"])                     # powertools.py:121
+    data = cpu_ref.generate_kspace(16, 16, 16, 2.5, default_power["k"], Pk, seed=123)
+    assert np.array_equal(data, g["kspace"])
+    g = golden("gaussian_16_c64.npz")                                # linear-k table (non-uniform in log k)
+    data = cpu_ref.generate_kspace(16, 16, 16, 2.5, g["k"], g["Pk"], seed=123)
+    assert np.array_equal(data, g["kspace"])
+    assert np.max(np.abs(cpu_ref.c2r(data) - g["delta"])) <= 1e-6 * float(g["rms"])
+
+
+def test_lognormal_matches_reference():
+    for tag, tol in (("f32", 0), ("f64", 0)):
+        g = golden("lognormal_%s.npz" % tag)
+        out = cpu_ref.lognormal(g["delta"].copy(), 0.3, sigma=2.5)
+        assert np.array_equal(out, g["out_scalar"])
+        out = cpu_ref.lognormal(g["delta"].copy(), g["growth_z"], sigma=g["sigma_vec"][()])
+        assert np.array_equal(out, g["out_vec"])
+        assert np.all(out > 0)
+
+
+def test_potential_matches_reference():
+    g = golden("potential_16_c64.npz")
+    pot = cpu_ref.potential_kspace(g["kspace"], 2.5)
+    assert np.array_equal(pot, g["potential"])
+    assert pot[0, 0, 0] == 0
+
+
+def test_r2c_matches_reference():
+    g = golden("r2c_8x16x32_f32.npz")
+    spec = cpu_ref.r2c(g["field"])
+    assert spec.dtype == np.complex64
+    assert np.allclose(spec, g["spectrum"], rtol=0, atol=1e-4)
+
+
+def test_variance_fixture_matches_analytic():
+    """tests/test_generate.py:24-62 through the reference: mean variance within
+    1 % of the analytic erf^3 expression."""
+    from scipy.special import erf
+    g = golden("variance_64.npz")
+    spacing, n = 2.5, 64
+    kmin, kmax, sigma = (2 * np.pi) / (spacing * n), np.pi / spacing, 2.5 * spacing
+    calc = 1.23 / (2 * np.pi) ** 1.5 / sigma ** 3 * (
+        erf(kmax * sigma / np.sqrt(2)) ** 3 - erf(kmin * sigma / np.sqrt(2)) ** 3)
+    assert abs(g["variances"].mean() - calc) < 0.01 * calc
+
+
+def test_philox_known_answer():
+    """Philox4x32-10 known-answer vectors from the Random123 distribution
+    (kat_vectors): counter/key all zero and all ones."""
+    w = cpu_ref.philox4x32_10(np.array([0], np.uint64), np.array([0], np.uint64), 0, 0)
+    assert [int(v[0]) for v in w] == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
+    ff = np.array([0xFFFFFFFFFFFFFFFF], np.uint64)
+    w = cpu_ref.philox4x32_10(ff, ff, 0xFFFFFFFF, 0xFFFFFFFF)
+    assert [int(v[0]) for v in w] == [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
+    re, im = cpu_ref.philox_normals(123, np.arange(200000, dtype=np.uint64))
+    for v in (re, im):
+        assert abs(v.mean()) < 0.01 and abs(v.std() - 1) < 0.01
+    assert abs(np.mean(re * im)) < 0.01
