@@ -1,0 +1,151 @@
+#!/usr/bin/env python3
+"""
+bench.py -- Mcells/s for N^3 delta(x) realisations on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--n 1024] [--no-cpu-baseline]
+
+One "step" = one realisation seed -> delta(x) resident in HBM + rms
+(generate_delta_field(save_potential=False) semantics: rows K,T,R,S fused into
+the c2r FFT, then the moments).  Native counter-based RNG, float32, the shipped
+500-row P(k) table.  The K timed steps are replayed from one captured hipGraph
+(BASELINE config 3) and bracketed by barrier + device sync; rank 0 prints ONE
+JSON line.  For N > 1 the driver launches this under torch.distributed.run, one
+rank per GPU.
+
+Extra objects on the JSON line:
+  roofline     -- dominant kernel: algorithmic bytes per launch / its mean duration
+                  (HIP events on the plan's stream, eager launches inside this run)
+  cpu_baseline -- the oracle (numpy restatement of the reference path) timed on
+                  this host, 1 thread, on a bounded sample (rank 0, N = 1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def grid_for(ngpus, n):
+    """Weak scaling: per-GPU work fixed at n^3 cells (1 -> n^3 ... 8 -> (2n)^3)."""
+    shape = [n, n, n]
+    axis, g = 0, ngpus
+    while g > 1:
+        shape[axis] *= 2
+        axis = (axis + 1) % 3
+        g //= 2
+    return tuple(shape)
+
+
+def cpu_baseline(power, spacing, sample_n):
+    from oracle import cpu_ref                     # checker / baseline only
+    t0 = time.perf_counter()
+    delta, rms = cpu_ref.generate_delta_field(sample_n, sample_n, sample_n, spacing, power["k"], power["Pk"], seed=123)
+    dt = time.perf_counter() - t0
+    return {"value": round(sample_n ** 3 / dt / 1e6, 3), "unit": "Mcells/s", "cores": 1, "kind": "port",
+            "sample": "%d^3 float32 realisation, default P(k), seed 123, numpy %s (%.1f s; os.cpu_count()=%d)"
+                      % (sample_n, np.__version__, dt, os.cpu_count() or 0),
+            "rms": float(rms)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n", type=int, default=1024, help="per-GPU cube edge")
+    ap.add_argument("--cpu-sample", type=int, default=512, help="cube edge of the CPU baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
+                     % (args.gpus, args.gpus))
+        args.gpus = world
+
+    from randomfield_amd import _hip, powertools
+    _hip.require_gpu()                              # no GPU / no library -> loud failure, never a CPU run
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist           # plumbing only: rendezvous, barrier, max over ranks
+        dist.init_process_group(backend="gloo")
+        sys.exit("multi-GPU slab exchange is not built yet")
+
+    spacing = 2.5
+    nx, ny, nz = grid_for(args.gpus, args.n)
+    power = powertools.load_default_power()
+    plan = _hip.DevicePlan(nx, ny, nz, np.complex64, device=local_rank)
+    plan.set_kgrid(*powertools.ksq_axes(nx, ny, nz, spacing))
+    plan.set_power(*powertools.sigma_table(power, (nx, ny, nz), spacing))
+
+    # --- per-kernel timing (HIP events on the plan's stream, eager launches) ---
+    kern = np.zeros(4)
+    reps = max(3, min(args.steps, 10))
+    plan.realise(seed=1)
+    plan.sync()
+    for i in range(reps):
+        plan.realise(seed=100 + i)
+        plan.sync()
+        kern += np.array(plan.kernel_ms())
+    kern /= reps
+
+    # --- the timed region: W warm-up + K steps replayed from one hipGraph -----
+    if args.warmup > 0:
+        plan.realise_batch(np.arange(1000, 1000 + args.warmup, dtype=np.uint64), want_rms=False)
+    plan.sync()
+    seeds = np.arange(123, 123 + args.steps, dtype=np.uint64)
+    t0 = time.perf_counter()
+    plan.realise_batch(seeds, want_rms=False)
+    plan.sync()
+    wall = time.perf_counter() - t0
+    gpu_ms = plan.elapsed_ms()
+    mean, std = plan.moments()
+
+    cells = float(nx) * ny * nz
+    sweep = 8.0 * nx * ny * (nz // 2 + 1)           # bytes of one sweep of the packed complex64 array
+    names = ["x pass (generation + FFT, write only)", "y pass (FFT in place)", "z pass (c2r + moments, in place)"]
+    alg = [1 * sweep, 2 * sweep, 2 * sweep]
+    dom = int(np.argmax(kern[:3]))
+    achieved = alg[dom] / (kern[dom] * 1e-3) / 1e9
+    out = {
+        "metric": "Mcells/s for N^3 delta(x) realisation",
+        "value": round(cells * args.steps / wall / 1e6, 1),
+        "unit": "Mcells/s",
+        "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(wall / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%dx%dx%d float32 delta(x) realisations back to back (hipGraph replay), "
+                               "native Philox4x32-10 RNG, shipped 500-row P(k), spacing 2.5 Mpc/h" % (nx, ny, nz),
+                   "grid": [nx, ny, nz], "rms_last": round(std, 6)},
+        "gpu_ms_per_step_events": round(gpu_ms / args.steps, 4),
+        "pipeline": {"algorithmic_GBs": round(5 * sweep * args.steps / wall / 1e9, 1),
+                     "frac_of_hbm_peak": round(5 * sweep * args.steps / wall / 1e9 / HBM_PEAK_GBS, 4),
+                     "kernel_ms": {"x": round(float(kern[0]), 4), "y": round(float(kern[1]), 4),
+                                   "z": round(float(kern[2]), 4), "reduce": round(float(kern[3]), 4)}},
+        "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "algorithmic_bytes_per_launch": alg[dom], "avg_ms": round(float(kern[dom]), 4)},
+    }
+    if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(power, spacing, args.cpu_sample)
+        out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+    plan.close()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

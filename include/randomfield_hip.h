@@ -1,0 +1,124 @@
+/*
+ * randomfield_hip.h -- C-ABI of the MI355X (gfx950) Gaussian-random-field hot path.
+ *
+ * Drop-in boundary for the Fourier-space sampling path of dkirkby/randomfield
+ * (SURVEY.md section 8b).  The reference has no FFI of its own -- the path is
+ * plain Python over numpy/scipy/pyFFTW -- so each entry point below cites the
+ * reference Python interface (randomfield/<file>:<line>) whose work it takes
+ * over.  The Python host (randomfield_amd/) binds these with ctypes; see
+ * INTEGRATION.md for the stub a maintainer of the reference would add.
+ *
+ * Conventions: every function returns 0 on success and a non-zero status on
+ * failure (message via rf_last_error(), thread-local).  No exceptions, torch
+ * types or callbacks cross the boundary: plain pointers and sizes only.  A plan
+ * is used from one host thread at a time.  Host arrays use the reference's
+ * layouts: k-space (nx, ny, nz/2+1) complex C-order (transform.py:192), real
+ * space (nx, ny, nz) dense or (nx, ny, nz+2) padded (transform.py:227-235).
+ * All work is queued on the plan's HIP stream; rf_sync() waits for it.
+ */
+#ifndef RANDOMFIELD_HIP_H
+#define RANDOMFIELD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rf_plan rf_plan;
+
+enum { RF_F32 = 0, RF_F64 = 1 };                 /* complex64/float32 or complex128/float64 plan */
+enum { RF_NOISE_NATIVE = 0, RF_NOISE_EXTERNAL = 1 };
+enum { RF_LAYOUT_DENSE = 0, RF_LAYOUT_PADDED = 1 };
+
+/* ---- library ---------------------------------------------------------- */
+int rf_version(void);                            /* 100*major + minor */
+const char* rf_last_error(void);
+int rf_device_count(int* count);
+/* is this grid shape supported by the HIP kernels? (power-of-two axes) */
+int rf_shape_supported(int nx, int ny, int nz);
+
+/* ---- plan: replaces transform.Plan.__init__ / allocate (transform.py:10-43,170-276)
+ * One device buffer of nx*ny*nz reals (== nx*ny*nz/2 complex) is the analogue of
+ * the reference's single in-place buffer.  nranks/rank select the kz-slab (k space)
+ * / x-slab (real space) owned by this process for multi-GPU plans (1, 0 otherwise). */
+int rf_plan_create(rf_plan** plan, int nx, int ny, int nz, int dtype, int device, int nranks, int rank);
+int rf_plan_destroy(rf_plan* plan);
+int rf_plan_nbytes(rf_plan* plan, size_t* nbytes);          /* transform.py:221,226 nbytes_allocated */
+/* run on a caller-owned HIP stream (hipStream_t passed as void*); NULL restores the plan's own stream */
+int rf_plan_set_stream(rf_plan* plan, void* hip_stream);
+
+/* ---- inputs ----------------------------------------------------------- */
+/* Per-axis float64 tables k_a(i)^2 computed by the host exactly as
+ * powertools.create_ksq_grids (powertools.py:27-37): lengths nx, ny, nz/2+1. */
+int rf_set_kgrid(rf_plan* plan, const double* kx2, const double* ky2, const double* kz2);
+/* float64 tables x_i = log10 k_i and s_i = N3*sqrt(P_i/(2 Vbox)) computed by the host
+ * exactly as powertools.tabulate_sigmas (powertools.py:153-154), n >= 2 rows. */
+int rf_set_power(rf_plan* plan, const double* log10k, const double* sigma, int n);
+
+/* ---- rows K,T,R,S: fill_with_log10k + tabulate_sigmas + randomize + symmetrize
+ * (powertools.py:40-61,125-164; random.py:12-29; transform.py:114-158).
+ * Leaves the symmetrised k-space array in the plan's API-layout k buffer.
+ * mode RF_NOISE_NATIVE: counter-based Philox4x32-10 + Box-Muller keyed by (seed, cell).
+ * mode RF_NOISE_EXTERNAL: noise_host = 2*nx*ny*(nz/2+1) float64 deviates in the order of
+ * RandomState(seed).normal(size=2*M) (random.py:24-28) -- the same-seed parity mode. */
+int rf_generate(rf_plan* plan, uint64_t seed, int mode, const double* noise_host);
+
+/* ---- row X: Plan.execute (transform.py:303-315) ------------------------- */
+int rf_execute_c2r(rf_plan* plan);               /* k buffer -> real field, numpy normalisation 1/(nx ny nz) */
+int rf_execute_r2c(rf_plan* plan);               /* real field -> k buffer, unnormalised */
+
+/* ---- fused K,T,R,S,X,D: Generator.generate_delta_field(save_potential=False)
+ * (generate.py:191-199,218-219).  Generation is fused into the first FFT pass; the
+ * k-space array is never materialised.  rms/mean are available from rf_moments(). */
+int rf_realise(rf_plan* plan, uint64_t seed, int mode, const double* noise_host);
+/* n realisations back to back replayed from one captured hipGraph (native noise);
+ * the field of the last seed stays resident; rms_out[i] (may be NULL) = np.std of field i. */
+int rf_realise_batch(rf_plan* plan, const uint64_t* seeds, int n, double* rms_out);
+
+/* ---- row D: np.std(delta.flat) (generate.py:219) ------------------------ */
+int rf_moments(rf_plan* plan, double* mean, double* std);
+
+/* ---- row L: cosmotools.apply_lognormal_transform (cosmotools.py:206-221) and the
+ * per-z scaling delta *= mean_matter_density (generate.py:273).
+ * a_z[iz] = sqrt(log t), b_z[iz] = sqrt(t), t = 1 + (sigma*growth[iz])^2 (host, float64);
+ * field <- exp(field / sigma * a_z) / b_z with the reference's four roundings. */
+int rf_lognormal(rf_plan* plan, const double* a_z, const double* b_z, int nz, double sigma);
+int rf_scale_z(rf_plan* plan, const double* factor_z, int nz);
+/* field <- field * mul_z[iz] + add (generate.py:271-272 non-lognormal branch) */
+int rf_affine_z(rf_plan* plan, const double* mul_z, int nz, double add);
+
+/* ---- save_potential branch (generate.py:200-217, 333-343) ---------------- */
+/* potential(k) = delta(k) / k^2 (0 at DC) from the k buffer into the plan's second k buffer */
+int rf_save_potential(rf_plan* plan);
+/* k buffer <- scale * potential(k)  (then rf_execute_c2r gives the Newtonian potential) */
+int rf_load_potential(rf_plan* plan, double scale);
+
+/* ---- host <-> device (layout conversion to/from the reference's arrays) -- */
+int rf_upload_k(rf_plan* plan, const void* host);            /* (nx, ny, nz/2+1) complex */
+int rf_download_k(rf_plan* plan, void* host);
+int rf_upload_real(rf_plan* plan, const void* host, int layout);
+/* rows x0 <= ix < x1 of the real field into host (shape (x1-x0, ny, nz) or (.., nz+2)) */
+int rf_download_real(rf_plan* plan, void* host, int layout, int x0, int x1);
+/* raw device pointers (real field / k buffer) for zero-copy consumers */
+int rf_device_ptr(rf_plan* plan, void** real_field, void** kspace);
+
+/* ---- stream control and timing ------------------------------------------ */
+int rf_sync(rf_plan* plan);
+/* GPU time (hipEvents on the plan's stream) of the last rf_realise / rf_realise_batch /
+ * rf_execute_* call, in milliseconds; blocks until that call has finished. */
+int rf_elapsed_ms(rf_plan* plan, float* ms);
+/* GPU time of each kernel of the last rf_realise (x pass, y pass, z pass, reduce), 4 floats */
+int rf_kernel_ms(rf_plan* plan, float* ms4);
+
+/* ---- multi-GPU: one process per GPU, RCCL all-to-all between the y and z passes.
+ * The 128-byte unique id comes from rank 0 and is distributed by the host
+ * (torch.distributed / a file / MPI ...).  No-op requirement for nranks == 1. */
+int rf_comm_unique_id(void* id128);
+int rf_comm_init(rf_plan* plan, const void* id128);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RANDOMFIELD_HIP_H */

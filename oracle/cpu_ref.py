@@ -43,7 +43,8 @@ __all__ = [
     "sigma_table", "interp_sigma", "tabulate_sigmas", "legacy_normals",
     "randomize", "symmetrize_packed", "is_hermitian_packed", "c2r", "r2c",
     "generate_kspace", "generate_delta_field", "lognormal", "scale_z",
-    "potential_kspace", "philox4x32_10", "philox_normals", "default_like_power",
+    "potential_kspace", "philox4x32_10", "philox_normals", "native_noise_index",
+    "native_noise", "default_like_power",
 ]
 
 
@@ -431,24 +432,49 @@ def philox4x32_10(counter_lo, counter_hi, key0, key1):
             c2.astype(np.uint32), c3.astype(np.uint32))
 
 
-def philox_normals(seed, cell_index):
+def philox_normals(seed, cell_index, bits=32):
     """(re, im) float64 standard normals of the HIP path's native RNG for the
     given 64-bit noise-cell indices ("native noise").
 
     One Philox call serves the cell *pair* ``cell_index >> 1``; the even cell
-    uses words (0, 1), the odd cell words (2, 3).  u1 = (w_a + 0.5) / 2**32,
-    u2 = (w_b + 0.5) / 2**32, r = sqrt(-2 ln u1), (re, im) = r*(cos, sin)(2 pi u2).
+    uses words (0, 1), the odd cell words (2, 3).  With ``bits`` = 32 (float64
+    plans) u = (w + 0.5) / 2**32; with ``bits`` = 24 (float32 plans) the low 8
+    bits of each word are dropped first, u = ((w >> 8) + 0.5) / 2**24.  Then
+    r = sqrt(-2 ln u1), (re, im) = r * (cos, sin)(2 pi u2).
     """
     ci = np.asarray(cell_index, np.uint64)
     seed = int(seed) & 0xFFFFFFFFFFFFFFFF
     w = philox4x32_10(ci >> np.uint64(1), np.uint64(0), seed & 0xFFFFFFFF, seed >> 32)
     odd = (ci & np.uint64(1)).astype(bool)
-    wa = np.where(odd, w[2], w[0]).astype(np.float64)
-    wb = np.where(odd, w[3], w[1]).astype(np.float64)
-    u1 = (wa + 0.5) / 4294967296.0
-    u2 = (wb + 0.5) / 4294967296.0
+    shift = np.uint32(32 - bits)
+    wa = (np.where(odd, w[2], w[0]) >> shift).astype(np.float64)
+    wb = (np.where(odd, w[3], w[1]) >> shift).astype(np.float64)
+    u1 = (wa + 0.5) / float(2 ** bits)
+    u2 = (wb + 0.5) / float(2 ** bits)
     r = np.sqrt(-2.0 * np.log(u1))
     return r * np.cos(2 * np.pi * u2), r * np.sin(2 * np.pi * u2)
+
+
+def native_noise_index(nx, ny, nz):
+    """Noise-cell index of every API cell (ix, iy, iz), shape (nx, ny, nz//2+1):
+    cells with iz < nz/2 are numbered in the device-internal order
+    [ix][iy][nz/2]; the Nyquist plane iz = nz/2 follows (rf_core.h)."""
+    nzc = nz // 2
+    col = (np.arange(nx, dtype=np.uint64)[:, None] * np.uint64(ny) + np.arange(ny, dtype=np.uint64)[None, :])
+    idx = np.empty((nx, ny, nzc + 1), np.uint64)
+    idx[:, :, :nzc] = col[:, :, None] * np.uint64(nzc) + np.arange(nzc, dtype=np.uint64)[None, None, :]
+    idx[:, :, nzc] = np.uint64(nx * ny * nzc) + col
+    return idx
+
+
+def native_noise(seed, nx, ny, nz, dtype=np.complex64):
+    """The HIP path's native deviates laid out like the reference's noise vector
+    (2*M float64 values, (re, im) interleaved in C order of the packed array)."""
+    bits = 24 if np.dtype(dtype) == np.complex64 else 32
+    re, im = philox_normals(seed, native_noise_index(nx, ny, nz), bits=bits)
+    if bits == 24:  # the float32 kernels form the deviates in float32
+        re, im = re.astype(np.float32).astype(np.float64), im.astype(np.float32).astype(np.float64)
+    return np.stack([re, im], axis=-1).reshape(-1)
 
 
 def default_like_power(nrows=500, amplitude=2.0e4):

@@ -1,0 +1,280 @@
+"""
+ctypes binding of ``librandomfield_hip.so`` (the C-ABI declared in
+``include/randomfield_hip.h``).
+
+There is NO CPU fallback here: if the shared library has not been built, cannot
+be loaded, or no GPU is visible, every entry point raises ``RuntimeError`` with
+the reason.  Build the library in-tree with ``make -C randomfield_amd/csrc`` (or
+``python -c "import __graft_entry__ as g; g.build()"``).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librandomfield_hip.so")
+
+RF_F32, RF_F64 = 0, 1
+NOISE_NATIVE, NOISE_EXTERNAL = 0, 1
+LAYOUT_DENSE, LAYOUT_PADDED = 0, 1
+
+_c_void_pp = ctypes.POINTER(ctypes.c_void_p)
+_c_dp = ctypes.POINTER(ctypes.c_double)
+
+# name -> (restype, argtypes); every symbol of include/randomfield_hip.h
+SIGNATURES = {
+    "rf_version": (ctypes.c_int, []),
+    "rf_last_error": (ctypes.c_char_p, []),
+    "rf_device_count": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
+    "rf_shape_supported": (ctypes.c_int, [ctypes.c_int] * 3),
+    "rf_plan_create": (ctypes.c_int, [_c_void_pp] + [ctypes.c_int] * 7),
+    "rf_plan_destroy": (ctypes.c_int, [ctypes.c_void_p]),
+    "rf_plan_nbytes": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t)]),
+    "rf_plan_set_stream": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "rf_set_kgrid": (ctypes.c_int, [ctypes.c_void_p, _c_dp, _c_dp, _c_dp]),
+    "rf_set_power": (ctypes.c_int, [ctypes.c_void_p, _c_dp, _c_dp, ctypes.c_int]),
+    "rf_generate": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, _c_dp]),
+    "rf_execute_c2r": (ctypes.c_int, [ctypes.c_void_p]),
+    "rf_execute_r2c": (ctypes.c_int, [ctypes.c_void_p]),
+    "rf_realise": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, _c_dp]),
+    "rf_realise_batch": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64), ctypes.c_int, _c_dp]),
+    "rf_moments": (ctypes.c_int, [ctypes.c_void_p, _c_dp, _c_dp]),
+    "rf_lognormal": (ctypes.c_int, [ctypes.c_void_p, _c_dp, _c_dp, ctypes.c_int, ctypes.c_double]),
+    "rf_scale_z": (ctypes.c_int, [ctypes.c_void_p, _c_dp, ctypes.c_int]),
+    "rf_affine_z": (ctypes.c_int, [ctypes.c_void_p, _c_dp, ctypes.c_int, ctypes.c_double]),
+    "rf_save_potential": (ctypes.c_int, [ctypes.c_void_p]),
+    "rf_load_potential": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_double]),
+    "rf_upload_k": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "rf_download_k": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "rf_upload_real": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
+    "rf_download_real": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "rf_device_ptr": (ctypes.c_int, [ctypes.c_void_p, _c_void_pp, _c_void_pp]),
+    "rf_sync": (ctypes.c_int, [ctypes.c_void_p]),
+    "rf_elapsed_ms": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]),
+    "rf_kernel_ms": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]),
+    "rf_comm_unique_id": (ctypes.c_int, [ctypes.c_void_p]),
+    "rf_comm_init": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once) and declare every prototype.  Raises
+    RuntimeError if it is missing or does not load -- never falls back."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "randomfield_amd: HIP extension %s has not been built "
+            "(run `make -C randomfield_amd/csrc`); there is no CPU fallback for the hip backend." % LIB_PATH)
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as exc:  # pragma: no cover - depends on the machine
+        raise RuntimeError("randomfield_amd: cannot load %s: %s" % (LIB_PATH, exc))
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here means header and library disagree
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def last_error():
+    return load().rf_last_error().decode("utf-8", "replace")
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise RuntimeError("randomfield_amd HIP error%s: %s" % (" in " + what if what else "", last_error()))
+
+
+def device_count():
+    n = ctypes.c_int(0)
+    check(load().rf_device_count(ctypes.byref(n)), "rf_device_count")
+    return n.value
+
+
+def require_gpu():
+    """Raise RuntimeError unless the library loads and sees at least one GPU."""
+    try:
+        n = device_count()
+    except RuntimeError:
+        raise
+    if n < 1:
+        raise RuntimeError("randomfield_amd: no HIP device visible; the hip backend has no CPU fallback.")
+    return n
+
+
+def shape_supported(nx, ny, nz):
+    return bool(load().rf_shape_supported(int(nx), int(ny), int(nz)))
+
+
+def _dp(a):
+    return a.ctypes.data_as(_c_dp)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class DevicePlan(object):
+    """Thin object wrapper around ``rf_plan*``.  All methods raise RuntimeError on failure."""
+
+    def __init__(self, nx, ny, nz, dtype=np.complex64, device=0, nranks=1, rank=0):
+        self._lib = load()
+        require_gpu()
+        dtype = np.dtype(dtype)
+        if dtype not in (np.dtype(np.complex64), np.dtype(np.complex128)):
+            raise ValueError("DevicePlan dtype must be complex64 or complex128: %r" % (dtype,))
+        self.nx, self.ny, self.nz = int(nx), int(ny), int(nz)
+        self.complex_dtype = dtype
+        self.real_dtype = np.dtype(np.float32 if dtype == np.complex64 else np.float64)
+        self._h = ctypes.c_void_p()
+        check(self._lib.rf_plan_create(ctypes.byref(self._h), self.nx, self.ny, self.nz,
+                                       RF_F64 if dtype == np.complex128 else RF_F32, int(device),
+                                       int(nranks), int(rank)), "rf_plan_create")
+
+    # -- lifetime ---------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.rf_plan_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def nbytes(self):
+        n = ctypes.c_size_t(0)
+        check(self._lib.rf_plan_nbytes(self._h, ctypes.byref(n)), "rf_plan_nbytes")
+        return n.value
+
+    def set_stream(self, hip_stream):
+        check(self._lib.rf_plan_set_stream(self._h, ctypes.c_void_p(hip_stream or 0)), "rf_plan_set_stream")
+
+    # -- inputs -----------------------------------------------------------
+    def set_kgrid(self, kx2, ky2, kz2):
+        kx2, ky2, kz2 = _f64(kx2), _f64(ky2), _f64(kz2)
+        if (len(kx2), len(ky2), len(kz2)) != (self.nx, self.ny, self.nz // 2 + 1):
+            raise ValueError("k-grid tables have the wrong lengths")
+        check(self._lib.rf_set_kgrid(self._h, _dp(kx2), _dp(ky2), _dp(kz2)), "rf_set_kgrid")
+
+    def set_power(self, log10k, sigma):
+        log10k, sigma = _f64(log10k), _f64(sigma)
+        if log10k.shape != sigma.shape or log10k.ndim != 1:
+            raise ValueError("log10k and sigma must be 1-D arrays of equal length")
+        check(self._lib.rf_set_power(self._h, _dp(log10k), _dp(sigma), len(log10k)), "rf_set_power")
+
+    # -- generation / transforms -----------------------------------------
+    def _noise_arg(self, noise):
+        if noise is None:
+            return NOISE_NATIVE, None, None
+        noise = _f64(noise).reshape(-1)
+        if noise.size != 2 * self.nx * self.ny * (self.nz // 2 + 1):
+            raise ValueError("noise must hold 2*nx*ny*(nz/2+1) float64 deviates")
+        return NOISE_EXTERNAL, _dp(noise), noise
+
+    def generate(self, seed=0, noise=None):
+        mode, ptr, keep = self._noise_arg(noise)
+        check(self._lib.rf_generate(self._h, ctypes.c_uint64(int(seed) & (2 ** 64 - 1)), mode, ptr), "rf_generate")
+
+    def realise(self, seed=0, noise=None):
+        mode, ptr, keep = self._noise_arg(noise)
+        check(self._lib.rf_realise(self._h, ctypes.c_uint64(int(seed) & (2 ** 64 - 1)), mode, ptr), "rf_realise")
+
+    def realise_batch(self, seeds, want_rms=True):
+        seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
+        rms = np.empty(len(seeds), np.float64) if want_rms else None
+        check(self._lib.rf_realise_batch(self._h, seeds.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), len(seeds),
+                                         _dp(rms) if want_rms else None), "rf_realise_batch")
+        return rms
+
+    def execute_c2r(self):
+        check(self._lib.rf_execute_c2r(self._h), "rf_execute_c2r")
+
+    def execute_r2c(self):
+        check(self._lib.rf_execute_r2c(self._h), "rf_execute_r2c")
+
+    def moments(self):
+        m, s = ctypes.c_double(), ctypes.c_double()
+        check(self._lib.rf_moments(self._h, ctypes.byref(m), ctypes.byref(s)), "rf_moments")
+        return m.value, s.value
+
+    def lognormal(self, a_z, b_z, sigma):
+        a_z, b_z = _f64(a_z), _f64(b_z)
+        check(self._lib.rf_lognormal(self._h, _dp(a_z), _dp(b_z), len(a_z), float(sigma)), "rf_lognormal")
+
+    def scale_z(self, factor_z):
+        f = _f64(factor_z)
+        check(self._lib.rf_scale_z(self._h, _dp(f), len(f)), "rf_scale_z")
+
+    def affine_z(self, mul_z, add):
+        f = _f64(mul_z)
+        check(self._lib.rf_affine_z(self._h, _dp(f), len(f), float(add)), "rf_affine_z")
+
+    def save_potential(self):
+        check(self._lib.rf_save_potential(self._h), "rf_save_potential")
+
+    def load_potential(self, scale=1.0):
+        check(self._lib.rf_load_potential(self._h, float(scale)), "rf_load_potential")
+
+    # -- host <-> device --------------------------------------------------
+    def upload_k(self, data):
+        if data.shape != (self.nx, self.ny, self.nz // 2 + 1) or data.dtype != self.complex_dtype:
+            raise ValueError("upload_k: wrong shape or dtype")
+        data = np.ascontiguousarray(data)
+        check(self._lib.rf_upload_k(self._h, data.ctypes.data_as(ctypes.c_void_p)), "rf_upload_k")
+
+    def download_k(self, out=None):
+        if out is None:
+            out = np.empty((self.nx, self.ny, self.nz // 2 + 1), self.complex_dtype)
+        if not out.flags.c_contiguous or out.dtype != self.complex_dtype or out.shape != (self.nx, self.ny, self.nz // 2 + 1):
+            raise ValueError("download_k: out must be a C-contiguous (nx, ny, nz/2+1) array of the plan's dtype")
+        check(self._lib.rf_download_k(self._h, out.ctypes.data_as(ctypes.c_void_p)), "rf_download_k")
+        return out
+
+    def upload_real(self, data, padded=False):
+        nzp = self.nz + 2 if padded else self.nz
+        if data.shape != (self.nx, self.ny, nzp) or data.dtype != self.real_dtype or not data.flags.c_contiguous:
+            raise ValueError("upload_real: wrong shape, dtype or layout")
+        check(self._lib.rf_upload_real(self._h, data.ctypes.data_as(ctypes.c_void_p),
+                                       LAYOUT_PADDED if padded else LAYOUT_DENSE), "rf_upload_real")
+
+    def download_real(self, out=None, padded=False, x0=0, x1=None):
+        x1 = self.nx if x1 is None else x1
+        nzp = self.nz + 2 if padded else self.nz
+        if out is None:
+            out = np.empty((x1 - x0, self.ny, nzp), self.real_dtype)
+        if out.shape != (x1 - x0, self.ny, nzp) or out.dtype != self.real_dtype or not out.flags.c_contiguous:
+            raise ValueError("download_real: out has the wrong shape, dtype or layout")
+        check(self._lib.rf_download_real(self._h, out.ctypes.data_as(ctypes.c_void_p),
+                                         LAYOUT_PADDED if padded else LAYOUT_DENSE, int(x0), int(x1)),
+              "rf_download_real")
+        return out
+
+    def device_ptrs(self):
+        a, b = ctypes.c_void_p(), ctypes.c_void_p()
+        check(self._lib.rf_device_ptr(self._h, ctypes.byref(a), ctypes.byref(b)), "rf_device_ptr")
+        return a.value, b.value
+
+    # -- sync / timing ----------------------------------------------------
+    def sync(self):
+        check(self._lib.rf_sync(self._h), "rf_sync")
+
+    def elapsed_ms(self):
+        ms = ctypes.c_float()
+        check(self._lib.rf_elapsed_ms(self._h, ctypes.byref(ms)), "rf_elapsed_ms")
+        return ms.value
+
+    def kernel_ms(self):
+        ms = (ctypes.c_float * 4)()
+        check(self._lib.rf_kernel_ms(self._h, ms), "rf_kernel_ms")
+        return list(ms)

@@ -1,0 +1,167 @@
+// rf_emu.cpp -- CPU emulator of the HIP kernels (TEST TOOLING, build container).
+//
+// Runs the exact phase functions of rf_fft.h / rf_core.h that the gfx950
+// kernels inline, one "thread" after another with a plain array standing in
+// for LDS and a loop boundary standing in for each workgroup barrier.  It
+// checks index math, twiddles, Hermitian packing and the generation rules
+// against the oracle without a GPU.  It is not a product path: nothing in
+// randomfield_amd/ loads it.
+#include <cstdio>
+#include <cstring>
+#include <vector>
+#include "../rf_configs.h"
+#include "../rf_host.h"
+
+using namespace rf;
+
+namespace {
+
+template <class C, int DIR, class IO>
+void run_col_pass(const IO& io, long long ncols, const cplx<typename C::T>* tw) {
+  using F = ColFFT<C, DIR, IO>;
+  using cx = cplx<typename C::T>;
+  std::vector<cx> lds((size_t)C::LDS_BYTES / sizeof(cx) + 16);
+  std::vector<typename F::Regs> regs(C::NT);
+  const long long ntiles = ncols / C::TC;
+  for (long long tile = 0; tile < ntiles; ++tile) {
+    for (int t = 0; t < C::NT; ++t) F::pass_first(t, tile, io, lds.data());
+    if (C::NPASS == 3) {
+      for (int t = 0; t < C::NT; ++t) F::pass_mid_read(t, tw, lds.data(), regs[t]);
+      for (int t = 0; t < C::NT; ++t) F::pass_mid_write(t, lds.data(), regs[t]);
+    }
+    if (C::NPASS >= 2)
+      for (int t = 0; t < C::NT; ++t) F::pass_last(t, tile, io, tw, lds.data());
+  }
+}
+
+template <typename T, int DIR, class IO>
+int dispatch_col(int N, const IO& io, long long ncols) {
+  auto tw = make_twiddles<T>(N);
+  switch (N) {
+#define X(NN)                                                                        \
+  case NN:                                                                           \
+    if (ncols % ColSel<T, NN>::type::TC) return -2;                                  \
+    run_col_pass<typename ColSel<T, NN>::type, DIR, IO>(io, ncols, tw.data());       \
+    return 0;
+    RF_COL_SIZES(X)
+#undef X
+    default: return -1;
+  }
+}
+
+template <class C>
+void run_row_c2r(const PlainRowIO<typename C::T>& io, long long nrows, const cplx<typename C::T>* tw, double* s1, double* s2) {
+  using F = RowC2R<C, PlainRowIO<typename C::T>>;
+  using cx = cplx<typename C::T>;
+  std::vector<cx> lds((size_t)C::LDS_BYTES / sizeof(cx) + 16);
+  std::vector<typename F::Regs> regs(C::NT);
+  const long long ntiles = (nrows + C::NRT - 1) / C::NRT;
+  double a1 = 0, a2 = 0;
+  for (long long tile = 0; tile < ntiles; ++tile) {
+    for (int t = 0; t < C::NT; ++t) F::pass_first(t, tile, nrows, io, tw, lds.data(), regs[t]);
+    if (C::NPASS == 3) {
+      for (int t = 0; t < C::NT; ++t) F::pass_mid_read(t, tw, lds.data(), regs[t]);
+      for (int t = 0; t < C::NT; ++t) F::pass_mid_write(t, lds.data(), regs[t]);
+    }
+    if (C::NPASS >= 2)
+      for (int t = 0; t < C::NT; ++t) F::pass_last(t, tile, nrows, io, tw, lds.data(), regs[t]);
+    for (int t = 0; t < C::NT; ++t) { a1 += regs[t].s1; a2 += regs[t].s2; }
+  }
+  *s1 = a1; *s2 = a2;
+}
+
+template <typename T>
+int dispatch_row_c2r(int M, cplx<T>* base, long long nrows, double scale, double* s1, double* s2) {
+  auto tw = make_twiddles<T>(2 * M);
+  PlainRowIO<T> io; io.base = base; io.scale = (T)scale; io.M_of = M;
+  switch (M) {
+#define X(MM) case MM: run_row_c2r<typename RowSel<T, MM>::type>(io, nrows, tw.data(), s1, s2); return 0;
+    RF_ROW_SIZES(X)
+#undef X
+    default: return -1;
+  }
+}
+
+struct GenHost {
+  SigmaTableHost tab;
+  GenParams gp;
+};
+
+void fill_gen(GenHost& h, int nx, int ny, int nz, const double* kx2, const double* ky2, const double* kz2,
+              const double* log10k, const double* sigma, int nt, int noise_mode, uint64_t seed, const double* noise) {
+  build_sigma_table(log10k, sigma, nt, h.tab);
+  GenParams& g = h.gp;
+  g.nx = nx; g.ny = ny; g.nz = nz; g.kx2 = kx2; g.ky2 = ky2; g.kz2 = kz2;
+  g.xt = h.tab.xt.data(); g.st = h.tab.st.data(); g.sl = h.tab.sl.data(); g.bin = h.tab.bin.data();
+  g.nt = nt; g.nbins = (int)h.tab.bin.size(); g.x0 = h.tab.x0; g.inv_dx = h.tab.inv_dx;
+  g.noise_mode = noise_mode; g.seed = seed; g.seed_dev = nullptr; g.noise = noise;
+}
+
+template <typename T>
+int c2r_impl(int nx, int ny, int nz, const GenHost* gen, const cplx<T>* kspace, cplx<T>* W, double* s1, double* s2) {
+  const long long nzc = nz / 2;
+  // x pass (generation or API-layout k-space fused into the load)
+  GenColIO<T> gio;
+  gio.base = W; gio.g = ColGeom{(long long)ny * nzc, 0, (long long)ny * nzc};
+  if (gen) gio.gp = gen->gp; else { memset(&gio.gp, 0, sizeof(gio.gp)); gio.gp.nx = nx; gio.gp.ny = ny; gio.gp.nz = nz; }
+  gio.kspace = kspace; gio.kz0 = 0; gio.nzl = (int)nzc;
+  int rc = dispatch_col<T, +1>(nx, gio, (long long)ny * nzc);
+  if (rc) return rc;
+  // y pass, in place
+  PlainColIO<T> pio; pio.base = W; pio.g = ColGeom{nzc, (long long)ny * nzc, nzc};
+  rc = dispatch_col<T, +1>(ny, pio, (long long)nx * nzc);
+  if (rc) return rc;
+  // z pass c2r, in place
+  return dispatch_row_c2r<T>((int)nzc, W, (long long)nx * ny, 1.0 / ((double)nx * ny * nz), s1, s2);
+}
+
+}  // namespace
+
+extern "C" {
+
+// k-space after symmetrise in the API layout [nx][ny][nz/2+1] (rows K,T,R,S)
+int emu_generate_kspace(int f64, int nx, int ny, int nz, const double* kx2, const double* ky2, const double* kz2,
+                        const double* log10k, const double* sigma, int nt, int noise_mode, uint64_t seed,
+                        const double* noise, void* out) {
+  GenHost h;
+  fill_gen(h, nx, ny, nz, kx2, ky2, kz2, log10k, sigma, nt, noise_mode, seed, noise);
+  const int nzh = nz / 2 + 1;
+  for (int ix = 0; ix < nx; ++ix)
+    for (int iy = 0; iy < ny; ++iy)
+      for (int iz = 0; iz < nzh; ++iz) {
+        const size_t c = ((size_t)ix * ny + iy) * nzh + iz;
+        if (f64) ((cplx<double>*)out)[c] = gen_cell<double>(h.gp, seed, ix, iy, iz);
+        else     ((cplx<float>*)out)[c] = gen_cell<float>(h.gp, seed, ix, iy, iz);
+      }
+  return 0;
+}
+
+// full fused realisation: generation + x, y, z passes -> W (real [nx][ny][nz]) and (sum, sumsq)
+int emu_realise(int f64, int nx, int ny, int nz, const double* kx2, const double* ky2, const double* kz2,
+                const double* log10k, const double* sigma, int nt, int noise_mode, uint64_t seed,
+                const double* noise, void* W, double* s1, double* s2) {
+  GenHost h;
+  fill_gen(h, nx, ny, nz, kx2, ky2, kz2, log10k, sigma, nt, noise_mode, seed, noise);
+  return f64 ? c2r_impl<double>(nx, ny, nz, &h, nullptr, (cplx<double>*)W, s1, s2)
+             : c2r_impl<float>(nx, ny, nz, &h, nullptr, (cplx<float>*)W, s1, s2);
+}
+
+// unfused c2r of an API-layout k-space array
+int emu_c2r(int f64, int nx, int ny, int nz, const void* kspace, void* W, double* s1, double* s2) {
+  return f64 ? c2r_impl<double>(nx, ny, nz, nullptr, (const cplx<double>*)kspace, (cplx<double>*)W, s1, s2)
+             : c2r_impl<float>(nx, ny, nz, nullptr, (const cplx<float>*)kspace, (cplx<float>*)W, s1, s2);
+}
+
+// one strided FFT pass over data[(C / inner) * outer_stride + C % inner + row * row_stride]
+int emu_col_fft(int f64, int N, int dir, void* data, long long ncols, long long inner, long long outer_stride,
+                long long row_stride) {
+  ColGeom g{inner, outer_stride, row_stride};
+  if (f64) {
+    PlainColIO<double> io; io.base = (cplx<double>*)data; io.g = g;
+    return dir > 0 ? dispatch_col<double, +1>(N, io, ncols) : dispatch_col<double, -1>(N, io, ncols);
+  }
+  PlainColIO<float> io; io.base = (cplx<float>*)data; io.g = g;
+  return dir > 0 ? dispatch_col<float, +1>(N, io, ncols) : dispatch_col<float, -1>(N, io, ncols);
+}
+
+}  // extern "C"

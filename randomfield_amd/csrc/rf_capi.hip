@@ -1,0 +1,556 @@
+// rf_capi.hip -- the C-ABI of include/randomfield_hip.h: plan object, device
+// buffers, stream/graph orchestration of the HIP kernels.
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/randomfield_hip.h"
+#include "rf_host.h"
+#include "rf_launch.h"
+
+using namespace rf;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+#define RF_HIP(expr)                                                                              \
+  do {                                                                                            \
+    hipError_t e_ = (expr);                                                                       \
+    if (e_ != hipSuccess)                                                                         \
+      return fail(2, std::string(#expr) + " failed: " + hipGetErrorString(e_) + " (" __FILE__ ":" + \
+                         std::to_string(__LINE__) + ")");                                         \
+  } while (0)
+
+#define RF_REQUIRE(cond, msg) \
+  do {                        \
+    if (!(cond)) return fail(1, msg); \
+  } while (0)
+
+// RCCL entry points, resolved lazily with dlopen so that single-GPU use never
+// depends on librccl being loadable.
+struct Rccl {
+  void* lib = nullptr;
+  int (*GetUniqueId)(void*) = nullptr;
+  int (*CommInitRank)(void**, int, const void* /* ncclUniqueId by value: 128 bytes */, int) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+Rccl g_rccl;
+
+}  // namespace
+
+struct rf_plan {
+  int nx = 0, ny = 0, nz = 0, nzc = 0, f64 = 0, device = 0, nranks = 1, rank = 0;
+  size_t csize = 8;                       // bytes per complex element
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  void* W = nullptr;                      // [nx][ny][nz] real == [nx][ny][nz/2] complex (packed Nyquist)
+  void* K = nullptr;                      // lazy: API-layout k-space [nx][ny][nz/2+1]
+  void* P = nullptr;                      // lazy: saved potential, API layout
+  size_t w_bytes = 0, k_bytes = 0;
+  void *tw_x = nullptr, *tw_y = nullptr, *tw_z = nullptr;
+  double *kx2 = nullptr, *ky2 = nullptr, *kz2 = nullptr;
+  double *xt = nullptr, *st = nullptr, *sl = nullptr;
+  int* bin = nullptr;
+  int nt = 0, nbins = 0;
+  double x0 = 0, inv_dx = 0;
+  bool have_kgrid = false, have_power = false;
+  double* noise = nullptr;
+  size_t noise_cap = 0;
+  double* partials = nullptr;
+  long long npartials = 0;
+  double* stats = nullptr;                // [2 * stats_cap] (sum, sumsq) per realisation
+  int stats_cap = 0;
+  uint64_t* seed_cur = nullptr;           // device word read by graph-replayed kernels
+  uint64_t* seeds_dev = nullptr;
+  int seeds_cap = 0;
+  unsigned long long* counter = nullptr;
+  double* ztab = nullptr;                 // 2 * nz doubles for lognormal / affine tables
+  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  bool timed = false;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t graph_exec = nullptr;
+  bool real_valid = false, k_valid = false, stats_valid = false;
+};
+
+namespace {
+
+int ensure_k(rf_plan* p) {
+  if (!p->K) RF_HIP(hipMalloc(&p->K, p->k_bytes));
+  return 0;
+}
+
+GenParams make_gen(rf_plan* p, uint64_t seed, int mode, bool seed_from_dev) {
+  GenParams g;
+  g.nx = p->nx; g.ny = p->ny; g.nz = p->nz;
+  g.kx2 = p->kx2; g.ky2 = p->ky2; g.kz2 = p->kz2;
+  g.xt = p->xt; g.st = p->st; g.sl = p->sl; g.bin = p->bin;
+  g.nt = p->nt; g.nbins = p->nbins; g.x0 = p->x0; g.inv_dx = p->inv_dx;
+  g.noise_mode = mode; g.seed = seed; g.seed_dev = seed_from_dev ? p->seed_cur : nullptr;
+  g.noise = p->noise;
+  return g;
+}
+
+int upload_noise(rf_plan* p, int mode, const double* noise_host) {
+  if (mode != RF_NOISE_EXTERNAL) return 0;
+  RF_REQUIRE(noise_host != nullptr, "external noise mode needs a host noise array");
+  const size_t n = 2 * (size_t)p->nx * p->ny * (p->nzc + 1);
+  if (p->noise_cap < n) {
+    if (p->noise) RF_HIP(hipFree(p->noise));
+    p->noise = nullptr; p->noise_cap = 0;
+    RF_HIP(hipMalloc((void**)&p->noise, n * sizeof(double)));
+    p->noise_cap = n;
+  }
+  RF_HIP(hipMemcpyAsync(p->noise, noise_host, n * sizeof(double), hipMemcpyHostToDevice, p->stream));
+  return 0;
+}
+
+// the three FFT passes + moments on the plan's stream; generation or API k-space feeds the x pass
+int queue_c2r(rf_plan* p, const GenParams& gp, const void* kspace, bool graph_slot) {
+  const long long nzc = p->nzc;
+  const ColGeom gx{(long long)p->ny * nzc, 0, (long long)p->ny * nzc};
+  const ColGeom gy{nzc, (long long)p->ny * nzc, nzc};
+  if (p->timed) RF_HIP(hipEventRecord(p->ev[0], p->stream));
+  RF_HIP(launch_col_gen(p->f64, p->nx, p->W, gx, (long long)p->ny * nzc, gp, kspace, 0, (int)nzc, p->tw_x, p->stream));
+  if (p->timed) RF_HIP(hipEventRecord(p->ev[1], p->stream));
+  RF_HIP(launch_col_plain(p->f64, p->ny, +1, p->W, gy, (long long)p->nx * nzc, p->tw_y, p->stream));
+  if (p->timed) RF_HIP(hipEventRecord(p->ev[2], p->stream));
+  const long long nrows = (long long)p->nx * p->ny;
+  const double scale = 1.0 / ((double)p->nx * (double)p->ny * (double)p->nz);
+  RF_HIP(launch_row_c2r(p->f64, (int)nzc, p->W, nrows, scale, p->tw_z, p->partials, p->stream));
+  if (p->timed) RF_HIP(hipEventRecord(p->ev[3], p->stream));
+  RF_HIP(launch_reduce_partials(p->partials, p->npartials, p->stats, graph_slot ? p->counter : nullptr, p->stream));
+  if (p->timed) RF_HIP(hipEventRecord(p->ev[4], p->stream));
+  p->real_valid = true;
+  p->stats_valid = true;
+  return 0;
+}
+
+template <typename T> int upload_twiddles(void** dst, int n) {
+  auto w = make_twiddles<T>(n);
+  hipError_t e = hipMalloc(dst, w.size() * sizeof(cplx<T>));
+  if (e != hipSuccess) return fail(2, std::string("hipMalloc twiddles: ") + hipGetErrorString(e));
+  e = hipMemcpy(*dst, w.data(), w.size() * sizeof(cplx<T>), hipMemcpyHostToDevice);
+  if (e != hipSuccess) return fail(2, std::string("hipMemcpy twiddles: ") + hipGetErrorString(e));
+  return 0;
+}
+
+int shape_check(int nx, int ny, int nz, int f64, std::string* why) {
+  auto bad = [&](const std::string& m) { if (why) *why = m; return 1; };
+  if (nx <= 0 || ny <= 0 || nz <= 0) return bad("grid dimensions must be positive");
+  if (nz % 4) return bad("nz must be a multiple of 4 (packed layout, transform.py:53-56)");
+  if (!col_size_supported(nx) || !col_size_supported(ny))
+    return bad("HIP path needs nx, ny in {8,16,...,2048} (powers of two)");
+  if (!row_size_supported(nz / 2)) return bad("HIP path needs nz in {16,32,...,2048} (powers of two)");
+  const long long nzc = nz / 2;
+  if (((long long)ny * nzc) % col_tile_cols(f64, nx)) return bad("ny*nz/2 is not a multiple of the x-pass tile width");
+  if (((long long)nx * nzc) % col_tile_cols(f64, ny)) return bad("nx*nz/2 is not a multiple of the y-pass tile width");
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rf_version(void) { return 1; }
+
+const char* rf_last_error(void) { return g_err.c_str(); }
+
+int rf_device_count(int* count) {
+  RF_REQUIRE(count != nullptr, "count is null");
+  RF_HIP(hipGetDeviceCount(count));
+  return 0;
+}
+
+int rf_shape_supported(int nx, int ny, int nz) {
+  return shape_check(nx, ny, nz, 0, nullptr) == 0 && shape_check(nx, ny, nz, 1, nullptr) == 0;
+}
+
+int rf_plan_create(rf_plan** out, int nx, int ny, int nz, int dtype, int device, int nranks, int rank) {
+  RF_REQUIRE(out != nullptr, "plan pointer is null");
+  *out = nullptr;
+  RF_REQUIRE(dtype == RF_F32 || dtype == RF_F64, "dtype must be RF_F32 or RF_F64");
+  std::string why;
+  if (shape_check(nx, ny, nz, dtype, &why)) return fail(1, "unsupported shape: " + why);
+  RF_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "invalid nranks/rank");
+  RF_REQUIRE(nranks == 1, "multi-rank plans are created with rf_plan_create + rf_comm_init (not built yet)");
+  RF_HIP(hipSetDevice(device));
+  rf_plan* p = new rf_plan();
+  p->nx = nx; p->ny = ny; p->nz = nz; p->nzc = nz / 2; p->f64 = dtype; p->device = device;
+  p->nranks = nranks; p->rank = rank;
+  p->csize = dtype ? 16 : 8;
+  p->w_bytes = (size_t)nx * ny * p->nzc * p->csize;
+  p->k_bytes = (size_t)nx * ny * (p->nzc + 1) * p->csize;
+  auto cleanup = [&](int rc) { rf_plan_destroy(p); return rc; };
+  hipError_t e;
+  if ((e = hipStreamCreateWithFlags(&p->own_stream, hipStreamNonBlocking)) != hipSuccess)
+    return cleanup(fail(2, std::string("hipStreamCreate: ") + hipGetErrorString(e)));
+  p->stream = p->own_stream;
+  if ((e = hipMalloc(&p->W, p->w_bytes)) != hipSuccess)
+    return cleanup(fail(2, std::string("hipMalloc field buffer: ") + hipGetErrorString(e)));
+  int rc = 0;
+  if (dtype) {
+    rc = upload_twiddles<double>(&p->tw_x, nx);
+    if (!rc) rc = upload_twiddles<double>(&p->tw_y, ny);
+    if (!rc) rc = upload_twiddles<double>(&p->tw_z, nz);
+  } else {
+    rc = upload_twiddles<float>(&p->tw_x, nx);
+    if (!rc) rc = upload_twiddles<float>(&p->tw_y, ny);
+    if (!rc) rc = upload_twiddles<float>(&p->tw_z, nz);
+  }
+  if (rc) return cleanup(rc);
+  p->npartials = row_c2r_tiles(dtype, p->nzc, (long long)nx * ny);
+  p->stats_cap = 64;
+  if ((e = hipMalloc((void**)&p->partials, 2 * p->npartials * sizeof(double))) != hipSuccess ||
+      (e = hipMalloc((void**)&p->stats, 2 * p->stats_cap * sizeof(double))) != hipSuccess ||
+      (e = hipMalloc((void**)&p->seed_cur, sizeof(uint64_t))) != hipSuccess ||
+      (e = hipMalloc((void**)&p->counter, sizeof(unsigned long long))) != hipSuccess ||
+      (e = hipMalloc((void**)&p->kx2, nx * sizeof(double))) != hipSuccess ||
+      (e = hipMalloc((void**)&p->ky2, ny * sizeof(double))) != hipSuccess ||
+      (e = hipMalloc((void**)&p->kz2, (p->nzc + 1) * sizeof(double))) != hipSuccess ||
+      (e = hipMalloc((void**)&p->ztab, 2 * nz * sizeof(double))) != hipSuccess)
+    return cleanup(fail(2, std::string("hipMalloc workspace: ") + hipGetErrorString(e)));
+  for (auto& ev : p->ev)
+    if ((e = hipEventCreate(&ev)) != hipSuccess) return cleanup(fail(2, std::string("hipEventCreate: ") + hipGetErrorString(e)));
+  {  // function attributes (dynamic LDS above 64 KB) are set here, never inside a graph capture
+    GenParams gp0; memset(&gp0, 0, sizeof(gp0)); gp0.nx = nx; gp0.ny = ny; gp0.nz = nz;
+    const long long nzc = p->nzc;
+    const ColGeom gx{(long long)ny * nzc, 0, (long long)ny * nzc}, gy{nzc, (long long)ny * nzc, nzc};
+    if ((e = launch_col_gen(dtype, nx, p->W, gx, (long long)ny * nzc, gp0, nullptr, 0, (int)nzc, p->tw_x, p->stream, true)) != hipSuccess ||
+        (e = launch_col_plain(dtype, ny, +1, p->W, gy, (long long)nx * nzc, p->tw_y, p->stream, true)) != hipSuccess ||
+        (e = launch_row_c2r(dtype, (int)nzc, p->W, (long long)nx * ny, 1.0, p->tw_z, p->partials, p->stream, true)) != hipSuccess)
+      return cleanup(fail(2, std::string("kernel preparation: ") + hipGetErrorString(e)));
+  }
+  *out = p;
+  return 0;
+}
+
+int rf_plan_destroy(rf_plan* p) {
+  if (!p) return 0;
+  (void)hipSetDevice(p->device);
+  if (p->stream) (void)hipStreamSynchronize(p->stream);
+  if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
+  if (p->graph) (void)hipGraphDestroy(p->graph);
+  void* bufs[] = {p->W, p->K, p->P, p->tw_x, p->tw_y, p->tw_z, p->kx2, p->ky2, p->kz2, p->xt, p->st, p->sl, p->bin,
+                  p->noise, p->partials, p->stats, p->seed_cur, p->seeds_dev, p->counter, p->ztab};
+  for (void* b : bufs)
+    if (b) (void)hipFree(b);
+  for (auto& ev : p->ev)
+    if (ev) (void)hipEventDestroy(ev);
+  if (p->own_stream) (void)hipStreamDestroy(p->own_stream);
+  delete p;
+  return 0;
+}
+
+int rf_plan_nbytes(rf_plan* p, size_t* nbytes) {
+  RF_REQUIRE(p && nbytes, "null argument");
+  *nbytes = p->w_bytes + (p->K ? p->k_bytes : 0) + (p->P ? p->k_bytes : 0);
+  return 0;
+}
+
+int rf_plan_set_stream(rf_plan* p, void* hip_stream) {
+  RF_REQUIRE(p, "null plan");
+  RF_HIP(hipStreamSynchronize(p->stream));
+  p->stream = hip_stream ? (hipStream_t)hip_stream : p->own_stream;
+  if (p->graph_exec) { (void)hipGraphExecDestroy(p->graph_exec); p->graph_exec = nullptr; }
+  if (p->graph) { (void)hipGraphDestroy(p->graph); p->graph = nullptr; }
+  return 0;
+}
+
+int rf_set_kgrid(rf_plan* p, const double* kx2, const double* ky2, const double* kz2) {
+  RF_REQUIRE(p && kx2 && ky2 && kz2, "null argument");
+  RF_HIP(hipSetDevice(p->device));
+  RF_HIP(hipMemcpyAsync(p->kx2, kx2, p->nx * sizeof(double), hipMemcpyHostToDevice, p->stream));
+  RF_HIP(hipMemcpyAsync(p->ky2, ky2, p->ny * sizeof(double), hipMemcpyHostToDevice, p->stream));
+  RF_HIP(hipMemcpyAsync(p->kz2, kz2, (p->nzc + 1) * sizeof(double), hipMemcpyHostToDevice, p->stream));
+  RF_HIP(hipStreamSynchronize(p->stream));
+  p->have_kgrid = true;
+  return 0;
+}
+
+int rf_set_power(rf_plan* p, const double* log10k, const double* sigma, int n) {
+  RF_REQUIRE(p && log10k && sigma, "null argument");
+  RF_REQUIRE(n >= 2, "power table needs at least 2 rows");
+  for (int i = 0; i + 1 < n; ++i) RF_REQUIRE(log10k[i + 1] > log10k[i], "log10k must be strictly increasing");
+  RF_HIP(hipSetDevice(p->device));
+  RF_HIP(hipStreamSynchronize(p->stream));
+  SigmaTableHost t;
+  build_sigma_table(log10k, sigma, n, t);
+  for (void* b : {(void*)p->xt, (void*)p->st, (void*)p->sl, (void*)p->bin})
+    if (b) RF_HIP(hipFree(b));
+  p->xt = p->st = p->sl = nullptr; p->bin = nullptr; p->have_power = false;
+  RF_HIP(hipMalloc((void**)&p->xt, n * sizeof(double)));
+  RF_HIP(hipMalloc((void**)&p->st, n * sizeof(double)));
+  RF_HIP(hipMalloc((void**)&p->sl, t.sl.size() * sizeof(double)));
+  RF_HIP(hipMalloc((void**)&p->bin, t.bin.size() * sizeof(int)));
+  RF_HIP(hipMemcpy(p->xt, t.xt.data(), n * sizeof(double), hipMemcpyHostToDevice));
+  RF_HIP(hipMemcpy(p->st, t.st.data(), n * sizeof(double), hipMemcpyHostToDevice));
+  RF_HIP(hipMemcpy(p->sl, t.sl.data(), t.sl.size() * sizeof(double), hipMemcpyHostToDevice));
+  RF_HIP(hipMemcpy(p->bin, t.bin.data(), t.bin.size() * sizeof(int), hipMemcpyHostToDevice));
+  p->nt = n; p->nbins = (int)t.bin.size(); p->x0 = t.x0; p->inv_dx = t.inv_dx;
+  p->have_power = true;
+  return 0;
+}
+
+int rf_generate(rf_plan* p, uint64_t seed, int mode, const double* noise_host) {
+  RF_REQUIRE(p, "null plan");
+  RF_REQUIRE(p->have_kgrid && p->have_power, "rf_set_kgrid and rf_set_power must be called first");
+  RF_REQUIRE(mode == RF_NOISE_NATIVE || mode == RF_NOISE_EXTERNAL, "invalid noise mode");
+  RF_HIP(hipSetDevice(p->device));
+  if (int rc = ensure_k(p)) return rc;
+  if (int rc = upload_noise(p, mode, noise_host)) return rc;
+  RF_HIP(launch_gen_kspace(p->f64, p->K, make_gen(p, seed, mode, false), p->stream));
+  if (mode == RF_NOISE_EXTERNAL) RF_HIP(hipStreamSynchronize(p->stream));  // host noise buffer may be released by the caller
+  p->k_valid = true;
+  return 0;
+}
+
+int rf_execute_c2r(rf_plan* p) {
+  RF_REQUIRE(p, "null plan");
+  RF_REQUIRE(p->K && p->k_valid, "no k-space data: call rf_generate or rf_upload_k first");
+  RF_HIP(hipSetDevice(p->device));
+  GenParams gp;
+  memset(&gp, 0, sizeof(gp));
+  gp.nx = p->nx; gp.ny = p->ny; gp.nz = p->nz;
+  p->timed = true;
+  return queue_c2r(p, gp, p->K, false);
+}
+
+int rf_execute_r2c(rf_plan* p) {
+  RF_REQUIRE(p, "null plan");
+  return fail(3, "rf_execute_r2c: forward transform not built yet");
+}
+
+int rf_realise(rf_plan* p, uint64_t seed, int mode, const double* noise_host) {
+  RF_REQUIRE(p, "null plan");
+  RF_REQUIRE(p->have_kgrid && p->have_power, "rf_set_kgrid and rf_set_power must be called first");
+  RF_REQUIRE(mode == RF_NOISE_NATIVE || mode == RF_NOISE_EXTERNAL, "invalid noise mode");
+  RF_HIP(hipSetDevice(p->device));
+  if (int rc = upload_noise(p, mode, noise_host)) return rc;
+  p->timed = true;
+  int rc = queue_c2r(p, make_gen(p, seed, mode, false), nullptr, false);
+  if (rc) return rc;
+  if (mode == RF_NOISE_EXTERNAL) RF_HIP(hipStreamSynchronize(p->stream));
+  return 0;
+}
+
+int rf_realise_batch(rf_plan* p, const uint64_t* seeds, int n, double* rms_out) {
+  RF_REQUIRE(p && seeds, "null argument");
+  RF_REQUIRE(n >= 1, "need at least one seed");
+  RF_REQUIRE(p->have_kgrid && p->have_power, "rf_set_kgrid and rf_set_power must be called first");
+  RF_HIP(hipSetDevice(p->device));
+  if (p->seeds_cap < n) {
+    if (p->seeds_dev) RF_HIP(hipFree(p->seeds_dev));
+    p->seeds_dev = nullptr;
+    RF_HIP(hipMalloc((void**)&p->seeds_dev, n * sizeof(uint64_t)));
+    p->seeds_cap = n;
+    if (p->graph_exec) { (void)hipGraphExecDestroy(p->graph_exec); p->graph_exec = nullptr; }
+    if (p->graph) { (void)hipGraphDestroy(p->graph); p->graph = nullptr; }
+  }
+  if (p->stats_cap < n) {
+    RF_HIP(hipStreamSynchronize(p->stream));
+    RF_HIP(hipFree(p->stats));
+    p->stats = nullptr;
+    RF_HIP(hipMalloc((void**)&p->stats, 2 * (size_t)n * sizeof(double)));
+    p->stats_cap = n;
+    if (p->graph_exec) { (void)hipGraphExecDestroy(p->graph_exec); p->graph_exec = nullptr; }
+    if (p->graph) { (void)hipGraphDestroy(p->graph); p->graph = nullptr; }
+  }
+  RF_HIP(hipMemcpyAsync(p->seeds_dev, seeds, n * sizeof(uint64_t), hipMemcpyHostToDevice, p->stream));
+  RF_HIP(hipMemsetAsync(p->counter, 0, sizeof(unsigned long long), p->stream));
+  if (!p->graph_exec) {
+    // capture ONE realisation: seed = seeds[counter]; x, y, z passes; moments -> stats[counter++]
+    p->timed = false;
+    RF_HIP(hipStreamSynchronize(p->stream));
+    RF_HIP(hipStreamBeginCapture(p->stream, hipStreamCaptureModeThreadLocal));
+    hipError_t e = launch_pick_seed(p->seeds_dev, p->counter, p->seed_cur, p->stream);
+    int rc = 0;
+    if (e != hipSuccess) rc = fail(2, std::string("pick_seed: ") + hipGetErrorString(e));
+    if (!rc) rc = queue_c2r(p, make_gen(p, 0, RF_NOISE_NATIVE, true), nullptr, true);
+    hipError_t e2 = hipStreamEndCapture(p->stream, &p->graph);
+    if (rc) return rc;
+    RF_HIP(e2);
+    RF_HIP(hipGraphInstantiate(&p->graph_exec, p->graph, nullptr, nullptr, 0));
+  }
+  RF_HIP(hipEventRecord(p->ev[0], p->stream));
+  for (int i = 0; i < n; ++i) RF_HIP(hipGraphLaunch(p->graph_exec, p->stream));
+  RF_HIP(hipEventRecord(p->ev[4], p->stream));
+  p->timed = false;
+  p->real_valid = true;
+  p->stats_valid = true;
+  if (rms_out) {
+    std::vector<double> st(2 * (size_t)n);
+    RF_HIP(hipMemcpyAsync(st.data(), p->stats, st.size() * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+    RF_HIP(hipStreamSynchronize(p->stream));
+    const double cnt = (double)p->nx * p->ny * p->nz;
+    for (int i = 0; i < n; ++i) {
+      const double m = st[2 * i] / cnt;
+      const double v = st[2 * i + 1] / cnt - m * m;
+      rms_out[i] = v > 0 ? std::sqrt(v) : 0.0;
+    }
+  }
+  return 0;
+}
+
+int rf_moments(rf_plan* p, double* mean, double* std_out) {
+  RF_REQUIRE(p, "null plan");
+  RF_REQUIRE(p->stats_valid, "no realisation has been computed");
+  RF_HIP(hipSetDevice(p->device));
+  double st[2];
+  RF_HIP(hipMemcpyAsync(st, p->stats, sizeof(st), hipMemcpyDeviceToHost, p->stream));
+  RF_HIP(hipStreamSynchronize(p->stream));
+  const double cnt = (double)p->nx * p->ny * p->nz;
+  const double m = st[0] / cnt;
+  const double v = st[1] / cnt - m * m;
+  if (mean) *mean = m;
+  if (std_out) *std_out = v > 0 ? std::sqrt(v) : 0.0;
+  return 0;
+}
+
+int rf_lognormal(rf_plan* p, const double* a_z, const double* b_z, int nz, double sigma) {
+  RF_REQUIRE(p && a_z && b_z, "null argument");
+  RF_REQUIRE(nz == p->nz, "table length must equal nz");
+  RF_REQUIRE(p->real_valid, "no real-space field on the device");
+  RF_REQUIRE(sigma > 0, "sigma must be positive");
+  RF_HIP(hipSetDevice(p->device));
+  RF_HIP(hipMemcpyAsync(p->ztab, a_z, nz * sizeof(double), hipMemcpyHostToDevice, p->stream));
+  RF_HIP(hipMemcpyAsync(p->ztab + nz, b_z, nz * sizeof(double), hipMemcpyHostToDevice, p->stream));
+  RF_HIP(launch_lognormal(p->f64, p->W, (long long)p->nx * p->ny, nz, p->ztab, p->ztab + nz, sigma, p->stream));
+  RF_HIP(hipStreamSynchronize(p->stream));  // host tables may go away
+  p->stats_valid = false;
+  return 0;
+}
+
+int rf_affine_z(rf_plan* p, const double* mul_z, int nz, double add) {
+  RF_REQUIRE(p && mul_z, "null argument");
+  RF_REQUIRE(nz == p->nz, "table length must equal nz");
+  RF_REQUIRE(p->real_valid, "no real-space field on the device");
+  RF_HIP(hipSetDevice(p->device));
+  RF_HIP(hipMemcpyAsync(p->ztab, mul_z, nz * sizeof(double), hipMemcpyHostToDevice, p->stream));
+  RF_HIP(launch_affine_z(p->f64, p->W, (long long)p->nx * p->ny, nz, p->ztab, add, p->stream));
+  RF_HIP(hipStreamSynchronize(p->stream));
+  p->stats_valid = false;
+  return 0;
+}
+
+int rf_scale_z(rf_plan* p, const double* factor_z, int nz) { return rf_affine_z(p, factor_z, nz, 0.0); }
+
+int rf_save_potential(rf_plan* p) {
+  RF_REQUIRE(p, "null plan");
+  RF_REQUIRE(p->K && p->k_valid, "no k-space data");
+  RF_REQUIRE(p->have_kgrid, "rf_set_kgrid must be called first");
+  RF_HIP(hipSetDevice(p->device));
+  if (!p->P) RF_HIP(hipMalloc(&p->P, p->k_bytes));
+  RF_HIP(launch_save_potential(p->f64, p->K, p->P, p->nx, p->ny, p->nz, p->kx2, p->ky2, p->kz2, p->stream));
+  return 0;
+}
+
+int rf_load_potential(rf_plan* p, double scale) {
+  RF_REQUIRE(p, "null plan");
+  RF_REQUIRE(p->P, "no saved potential");
+  RF_HIP(hipSetDevice(p->device));
+  if (int rc = ensure_k(p)) return rc;
+  RF_HIP(launch_scale_copy(p->f64, p->P, p->K, (long long)p->nx * p->ny * (p->nzc + 1), scale, p->stream));
+  p->k_valid = true;
+  return 0;
+}
+
+int rf_upload_k(rf_plan* p, const void* host) {
+  RF_REQUIRE(p && host, "null argument");
+  RF_HIP(hipSetDevice(p->device));
+  if (int rc = ensure_k(p)) return rc;
+  RF_HIP(hipMemcpyAsync(p->K, host, p->k_bytes, hipMemcpyHostToDevice, p->stream));
+  RF_HIP(hipStreamSynchronize(p->stream));
+  p->k_valid = true;
+  return 0;
+}
+
+int rf_download_k(rf_plan* p, void* host) {
+  RF_REQUIRE(p && host, "null argument");
+  RF_REQUIRE(p->K && p->k_valid, "no k-space data");
+  RF_HIP(hipSetDevice(p->device));
+  RF_HIP(hipMemcpyAsync(host, p->K, p->k_bytes, hipMemcpyDeviceToHost, p->stream));
+  RF_HIP(hipStreamSynchronize(p->stream));
+  return 0;
+}
+
+int rf_upload_real(rf_plan* p, const void* host, int layout) {
+  RF_REQUIRE(p && host, "null argument");
+  RF_HIP(hipSetDevice(p->device));
+  const size_t rsize = p->csize / 2;
+  const size_t width = (size_t)p->nz * rsize;
+  const size_t hpitch = layout == RF_LAYOUT_PADDED ? (size_t)(p->nz + 2) * rsize : width;
+  RF_HIP(hipMemcpy2DAsync(p->W, width, host, hpitch, width, (size_t)p->nx * p->ny, hipMemcpyHostToDevice, p->stream));
+  RF_HIP(hipStreamSynchronize(p->stream));
+  p->real_valid = true;
+  p->stats_valid = false;
+  return 0;
+}
+
+int rf_download_real(rf_plan* p, void* host, int layout, int x0, int x1) {
+  RF_REQUIRE(p && host, "null argument");
+  RF_REQUIRE(p->real_valid, "no real-space field on the device");
+  RF_REQUIRE(0 <= x0 && x0 < x1 && x1 <= p->nx, "invalid x range");
+  RF_HIP(hipSetDevice(p->device));
+  const size_t rsize = p->csize / 2;
+  const size_t width = (size_t)p->nz * rsize;
+  const size_t hpitch = layout == RF_LAYOUT_PADDED ? (size_t)(p->nz + 2) * rsize : width;
+  const char* src = (const char*)p->W + (size_t)x0 * p->ny * width;
+  RF_HIP(hipMemcpy2DAsync(host, hpitch, src, width, width, (size_t)(x1 - x0) * p->ny, hipMemcpyDeviceToHost, p->stream));
+  RF_HIP(hipStreamSynchronize(p->stream));
+  return 0;
+}
+
+int rf_device_ptr(rf_plan* p, void** real_field, void** kspace) {
+  RF_REQUIRE(p, "null plan");
+  if (real_field) *real_field = p->W;
+  if (kspace) *kspace = p->K;
+  return 0;
+}
+
+int rf_sync(rf_plan* p) {
+  RF_REQUIRE(p, "null plan");
+  RF_HIP(hipSetDevice(p->device));
+  RF_HIP(hipStreamSynchronize(p->stream));
+  return 0;
+}
+
+int rf_elapsed_ms(rf_plan* p, float* ms) {
+  RF_REQUIRE(p && ms, "null argument");
+  RF_HIP(hipEventSynchronize(p->ev[4]));
+  RF_HIP(hipEventElapsedTime(ms, p->ev[0], p->ev[4]));
+  return 0;
+}
+
+int rf_kernel_ms(rf_plan* p, float* ms4) {
+  RF_REQUIRE(p && ms4, "null argument");
+  RF_REQUIRE(p->timed, "per-kernel times are recorded by rf_realise / rf_execute_c2r only");
+  RF_HIP(hipEventSynchronize(p->ev[4]));
+  for (int i = 0; i < 4; ++i) RF_HIP(hipEventElapsedTime(&ms4[i], p->ev[i], p->ev[i + 1]));
+  return 0;
+}
+
+int rf_comm_unique_id(void* id128) {
+  (void)id128;
+  return fail(3, "rf_comm_unique_id: multi-GPU exchange not built yet");
+}
+
+int rf_comm_init(rf_plan* p, const void* id128) {
+  (void)p; (void)id128;
+  return fail(3, "rf_comm_init: multi-GPU exchange not built yet");
+}
+
+}  // extern "C"

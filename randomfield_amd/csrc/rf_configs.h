@@ -1,0 +1,62 @@
+// rf_configs.h -- which radices / tile shapes each supported axis length uses.
+// Shared by the HIP dispatch (rf_kernels.hip) and the CPU emulator.
+#pragma once
+#include "rf_fft.h"
+
+namespace rf {
+
+// ---- strided (x / y) passes: N = axis length -------------------------------
+// TC is the tile width in columns for float32 (float64 uses TC/2 so that the
+// LDS footprint and the 16-byte-per-lane access width stay the same).
+template <typename T, int N> struct ColSel;
+#define RF_COL(N, R1, R2, R3, TC32, NT)                                                         \
+  template <> struct ColSel<float, N>  { using type = ColCfg<float,  N, R1, R2, R3, TC32,     NT>; }; \
+  template <> struct ColSel<double, N> { using type = ColCfg<double, N, R1, R2, R3, TC32 / 2, NT>; };
+RF_COL(8,    8,  1,  1, 32, 256)
+RF_COL(16,   16, 1,  1, 32, 256)
+RF_COL(32,   8,  4,  1, 32, 256)
+RF_COL(64,   8,  8,  1, 32, 256)
+RF_COL(128,  16, 8,  1, 32, 256)
+RF_COL(256,  16, 16, 1, 16, 256)
+RF_COL(512,  8,  8,  8, 16, 256)
+RF_COL(1024, 16, 16, 4, 8,  256)
+RF_COL(2048, 16, 16, 8, 8,  256)
+#undef RF_COL
+#define RF_COL_SIZES(X) X(8) X(16) X(32) X(64) X(128) X(256) X(512) X(1024) X(2048)
+
+// ---- contiguous (z) pass: M = nz / 2 ----------------------------------------
+template <typename T, int M> struct RowSel;
+#define RF_ROW(M, R1, R2, R3, NRT32, NT)                                                          \
+  template <> struct RowSel<float, M>  { using type = RowCfg<float,  M, R1, R2, R3, NRT32,     NT>; }; \
+  template <> struct RowSel<double, M> { using type = RowCfg<double, M, R1, R2, R3, NRT32 / 2, NT>; };
+RF_ROW(8,    8,  1,  1,  256, 256)
+RF_ROW(16,   16, 1,  1,  256, 256)
+RF_ROW(32,   8,  4,  1,  64,  256)
+RF_ROW(64,   8,  8,  1,  64,  256)
+RF_ROW(128,  8,  16, 1,  32,  256)
+RF_ROW(256,  8,  8,  4,  16,  256)
+RF_ROW(512,  8,  8,  8,  8,   256)
+RF_ROW(1024, 8,  8,  16, 4,   256)
+#undef RF_ROW
+#define RF_ROW_SIZES(X) X(8) X(16) X(32) X(64) X(128) X(256) X(512) X(1024)
+
+inline bool col_size_supported(int n) {
+  switch (n) {
+#define X(N) case N:
+    RF_COL_SIZES(X)
+#undef X
+    return true;
+    default: return false;
+  }
+}
+inline bool row_size_supported(int m) {
+  switch (m) {
+#define X(M) case M:
+    RF_ROW_SIZES(X)
+#undef X
+    return true;
+    default: return false;
+  }
+}
+
+}  // namespace rf

@@ -1,0 +1,352 @@
+// rf_core.h -- arithmetic shared by every kernel of the MI355X random-field path.
+//
+// Everything here is plain C++ templates marked RF_HD so that the same code is
+// (a) inlined into the HIP kernels for gfx950 and (b) compiled by g++ into the
+// CPU kernel emulator (csrc/emu) that checks index math, twiddles and phase
+// structure in the build container, where there is no GPU.
+//
+// Reference rows restated here:
+//   K  powertools.py:27-61   |k| per cell            -> log10k_cell()
+//   T  powertools.py:125-164 sigma(k) table lookup   -> sigma_lookup()
+//   R  random.py:12-29       sigma * N(0,1)          -> gen_cell()
+//   S  transform.py:141-158  Hermitian symmetrise    -> sym_role(), gen_cell()
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define RF_HD __host__ __device__ __forceinline__
+#define RF_DEVICE_CODE 1
+#else
+#define RF_HD inline
+#endif
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+namespace rf {
+
+// ---------------------------------------------------------------- complex --
+template <typename T>
+struct cplx {
+  T x, y;
+};
+
+template <typename T> RF_HD cplx<T> mk(T x, T y) { cplx<T> r; r.x = x; r.y = y; return r; }
+template <typename T> RF_HD cplx<T> operator+(cplx<T> a, cplx<T> b) { return mk<T>(a.x + b.x, a.y + b.y); }
+template <typename T> RF_HD cplx<T> operator-(cplx<T> a, cplx<T> b) { return mk<T>(a.x - b.x, a.y - b.y); }
+template <typename T> RF_HD cplx<T> cmul(cplx<T> a, cplx<T> b) {
+  return mk<T>(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+template <typename T> RF_HD cplx<T> cconj(cplx<T> a) { return mk<T>(a.x, -a.y); }
+// multiply by +i (DIR=+1) or -i (DIR=-1)
+template <int DIR, typename T> RF_HD cplx<T> mul_i(cplx<T> a) {
+  return DIR > 0 ? mk<T>(-a.y, a.x) : mk<T>(a.y, -a.x);
+}
+// conjugate the twiddle for the forward transform: tables hold exp(+2 pi i q/N)
+template <int DIR, typename T> RF_HD cplx<T> tw_dir(cplx<T> w) { return DIR > 0 ? w : mk<T>(w.x, -w.y); }
+
+// ------------------------------------------------------- radix butterflies --
+// DFT<R, DIR>::run(v): in-place R-point DFT, natural order in and out,
+// kernel exp(DIR * 2 pi i n k / R).  DIR=+1 is the (unnormalised) inverse.
+template <int R, int DIR> struct DFT;
+
+template <int DIR> struct DFT<1, DIR> {
+  template <typename T> RF_HD static void run(cplx<T>*) {}
+};
+
+template <int DIR> struct DFT<2, DIR> {
+  template <typename T> RF_HD static void run(cplx<T>* v) {
+    cplx<T> a = v[0], b = v[1];
+    v[0] = a + b;
+    v[1] = a - b;
+  }
+};
+
+template <int DIR> struct DFT<4, DIR> {
+  template <typename T> RF_HD static void run(cplx<T>* v) {
+    cplx<T> t0 = v[0] + v[2], t1 = v[0] - v[2];
+    cplx<T> t2 = v[1] + v[3], t3 = mul_i<DIR>(v[1] - v[3]);
+    v[0] = t0 + t2;
+    v[1] = t1 + t3;
+    v[2] = t0 - t2;
+    v[3] = t1 - t3;
+  }
+};
+
+// exp(DIR * 2 pi i q / 16) for q = 0..9 (products n2*k1 of the 4x4 split)
+template <int DIR, typename T> RF_HD cplx<T> w16(int q) {
+  const T c1 = (T)0.92387953251128675613, s1 = (T)0.38268343236508977173, r = (T)0.70710678118654752440;
+  T cx, sy;
+  switch (q) {
+    case 0: cx = 1; sy = 0; break;
+    case 1: cx = c1; sy = s1; break;
+    case 2: cx = r; sy = r; break;
+    case 3: cx = s1; sy = c1; break;
+    case 4: cx = 0; sy = 1; break;
+    case 6: cx = -r; sy = r; break;
+    default: cx = -c1; sy = -s1; break;  // q == 9
+  }
+  return mk<T>(cx, DIR > 0 ? sy : -sy);
+}
+
+template <int DIR> struct DFT<8, DIR> {
+  // n = 2 n1 + n2, k = k1 + 4 k2
+  template <typename T> RF_HD static void run(cplx<T>* v) {
+    cplx<T> a[4] = {v[0], v[2], v[4], v[6]};
+    cplx<T> b[4] = {v[1], v[3], v[5], v[7]};
+    DFT<4, DIR>::run(a);
+    DFT<4, DIR>::run(b);
+    const T r = (T)0.70710678118654752440;
+    // w8^k1 = exp(DIR 2 pi i k1 / 8)
+    b[1] = cmul(b[1], mk<T>(r, DIR > 0 ? r : -r));
+    b[2] = mul_i<DIR>(b[2]);
+    b[3] = cmul(b[3], mk<T>(-r, DIR > 0 ? r : -r));
+#pragma unroll
+    for (int k1 = 0; k1 < 4; ++k1) {
+      v[k1] = a[k1] + b[k1];
+      v[k1 + 4] = a[k1] - b[k1];
+    }
+  }
+};
+
+template <int DIR> struct DFT<16, DIR> {
+  // n = 4 n1 + n2, k = k1 + 4 k2
+  template <typename T> RF_HD static void run(cplx<T>* v) {
+    cplx<T> a[4][4];
+#pragma unroll
+    for (int n2 = 0; n2 < 4; ++n2) {
+#pragma unroll
+      for (int n1 = 0; n1 < 4; ++n1) a[n2][n1] = v[4 * n1 + n2];
+      DFT<4, DIR>::run(a[n2]);  // a[n2][k1]
+    }
+#pragma unroll
+    for (int k1 = 0; k1 < 4; ++k1) {
+      cplx<T> c[4];
+      c[0] = a[0][k1];
+#pragma unroll
+      for (int n2 = 1; n2 < 4; ++n2) c[n2] = (k1 == 0) ? a[n2][k1] : cmul(a[n2][k1], w16<DIR, T>(n2 * k1));
+      DFT<4, DIR>::run(c);  // c[k2]
+#pragma unroll
+      for (int k2 = 0; k2 < 4; ++k2) v[k1 + 4 * k2] = c[k2];
+    }
+  }
+};
+
+// ----------------------------------------------------------- Stockham maps --
+// Pass with radix R on sub-transforms of length Ns (Ns = product of earlier
+// radices): butterfly j in [0, N/R) reads in[j + m*N/R], multiplies by
+// exp(DIR 2 pi i m (j % Ns) / (Ns R)), does an R-point DFT, writes
+// out[(j / Ns) * Ns * R + (j % Ns) + m * Ns].  Natural order after the last pass.
+RF_HD int stockham_out_base(int j, int Ns, int R) { return (j / Ns) * Ns * R + (j % Ns); }
+// index into a length-N table of exp(2 pi i q / N)
+RF_HD int stockham_tw_index(int j, int m, int Ns, int R, int N) { return m * (j % Ns) * (N / (Ns * R)); }
+
+// -------------------------------------------------------------------- RNG --
+struct PhiloxOut { uint32_t w[4]; };
+
+RF_HD uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * (uint64_t)b) >> 32); }
+
+// Philox4x32-10 (Salmon, Moraes, Dror, Shaw 2011).  counter = (ctr_lo, ctr_hi) as
+// two 64-bit words, key = 64-bit seed.
+RF_HD PhiloxOut philox4x32_10(uint64_t ctr_lo, uint64_t ctr_hi, uint64_t key) {
+  uint32_t c0 = (uint32_t)ctr_lo, c1 = (uint32_t)(ctr_lo >> 32);
+  uint32_t c2 = (uint32_t)ctr_hi, c3 = (uint32_t)(ctr_hi >> 32);
+  uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint32_t h0 = mulhi32(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+    uint32_t h1 = mulhi32(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+    uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+    c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  PhiloxOut o; o.w[0] = c0; o.w[1] = c1; o.w[2] = c2; o.w[3] = c3;
+  return o;
+}
+
+// Box-Muller from two 32-bit words: u = (w + 0.5) / 2^32 in (0, 1).
+template <typename T> struct BoxMuller;
+template <> struct BoxMuller<double> {
+  RF_HD static void run(uint32_t wa, uint32_t wb, double& g0, double& g1) {
+    double u1 = ((double)wa + 0.5) * (1.0 / 4294967296.0);
+    double u2 = ((double)wb + 0.5) * (1.0 / 4294967296.0);
+    double r = sqrt(-2.0 * log(u1));
+    double a = (2.0 * M_PI) * u2;
+    g0 = r * cos(a);
+    g1 = r * sin(a);
+  }
+};
+template <> struct BoxMuller<float> {
+  RF_HD static void run(uint32_t wa, uint32_t wb, float& g0, float& g1) {
+    // u1 keeps all 32 bits through a float that never rounds to 0 or 1
+    float u1 = ((float)(wa >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    float u2 = ((float)(wb >> 8) + 0.5f) * (1.0f / 16777216.0f);
+#if defined(__HIP_DEVICE_COMPILE__)
+    float r = __builtin_sqrtf(-2.0f * __logf(u1));
+    // v_sin_f32 / v_cos_f32 take their argument in revolutions
+    g0 = r * __builtin_amdgcn_cosf(u2);
+    g1 = r * __builtin_amdgcn_sinf(u2);
+#else
+    float r = sqrtf(-2.0f * logf(u1));
+    float a = (float)(2.0 * M_PI) * u2;
+    g0 = r * cosf(a);
+    g1 = r * sinf(a);
+#endif
+  }
+};
+
+// ------------------------------------------------------------ generation --
+enum { NOISE_PHILOX = 0, NOISE_EXTERNAL = 1 };
+
+struct GenParams {
+  int nx, ny, nz;             // real-space grid
+  const double* kx2;          // [nx]      k_x(i)^2, float64, host-computed as powertools.py:27-37
+  const double* ky2;          // [ny]
+  const double* kz2;          // [nz/2+1]
+  const double* xt;           // [nt] log10 k_i      (powertools.py:153)
+  const double* st;           // [nt] sigma_i        (powertools.py:154)
+  const double* sl;           // [nt-1] (st[j+1]-st[j])/(xt[j+1]-xt[j])
+  const int* bin;             // [nbins] acceleration grid: lower bound of the interval index per bin
+  int nt, nbins;
+  double x0, inv_dx;          // bin b covers x0 + [b, b+1) / inv_dx
+  int noise_mode;
+  uint64_t seed;
+  const uint64_t* seed_dev;   // if non-null the seed is read from device memory (graph replay)
+  const double* noise;        // external mode: 2*nx*ny*(nz/2+1) float64 deviates, reference order
+};
+
+// no-FMA product-sum: slope*(x-x_lo)+y_lo must round exactly like numpy's two ufunc calls
+RF_HD double mul_then_add(double a, double b, double c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __dadd_rn(__dmul_rn(a, b), c);
+#else
+  volatile double p = a * b;
+  return p + c;
+#endif
+}
+
+// Row T: piecewise-linear sigma(log10 k), 0 outside the table (powertools.py:155-157,163).
+RF_HD double sigma_lookup(const GenParams& g, double x) {
+  const int n = g.nt;
+  if (!(x >= g.xt[0] && x <= g.xt[n - 1])) return 0.0;  // also -inf (DC cell) and NaN
+  if (x == g.xt[n - 1]) return g.st[n - 1];
+  int b = (int)((x - g.x0) * g.inv_dx);
+  b = b < 0 ? 0 : (b >= g.nbins ? g.nbins - 1 : b);
+  int j = g.bin[b];
+  while (j > 0 && g.xt[j] > x) --j;
+  while (j < n - 2 && g.xt[j + 1] <= x) ++j;
+  return mul_then_add(g.sl[j], x - g.xt[j], g.st[j]);
+}
+
+// Row K + T: sigma of cell (ix, iy, iz), rounded to the array's real type.
+template <typename T> RF_HD T sigma_cell(const GenParams& g, int ix, int iy, int iz);
+template <> RF_HD float sigma_cell<float>(const GenParams& g, int ix, int iy, int iz) {
+  float t = (float)(g.kx2[ix] + g.ky2[iy]);          // powertools.py:50
+  t = (float)((double)t + g.kz2[iz]);                 // powertools.py:52
+  t = log10f(t) * 0.5f;                               // powertools.py:56,60  (-inf at DC)
+  return (float)sigma_lookup(g, (double)t);           // powertools.py:163
+}
+template <> RF_HD double sigma_cell<double>(const GenParams& g, int ix, int iy, int iz) {
+  double t = g.kx2[ix] + g.ky2[iy];
+  t = t + g.kz2[iz];
+  t = log10(t) * 0.5;
+  return sigma_lookup(g, t);
+}
+
+// Native noise index of API cell (ix, iy, iz): cells with iz < nz/2 are numbered
+// in the device-internal order [ix][iy][nz/2]; the Nyquist plane follows.
+RF_HD uint64_t native_noise_index(const GenParams& g, int ix, int iy, int iz) {
+  const uint64_t nzc = (uint64_t)(g.nz / 2);
+  const uint64_t col = (uint64_t)ix * (uint64_t)g.ny + (uint64_t)iy;
+  return iz < g.nz / 2 ? col * nzc + (uint64_t)iz : (uint64_t)g.nx * (uint64_t)g.ny * nzc + col;
+}
+
+// Row R deviates (g_re, g_im) of the cell that OWNS the draw.
+template <typename T>
+RF_HD void noise_of_cell(const GenParams& g, uint64_t seed, int ix, int iy, int iz, double& gre, double& gim) {
+  if (g.noise_mode == NOISE_EXTERNAL) {
+    const uint64_t c = ((uint64_t)ix * (uint64_t)g.ny + (uint64_t)iy) * (uint64_t)(g.nz / 2 + 1) + (uint64_t)iz;
+    gre = g.noise[2 * c];
+    gim = g.noise[2 * c + 1];
+  } else {
+    const uint64_t ci = native_noise_index(g, ix, iy, iz);
+    PhiloxOut o = philox4x32_10(ci >> 1, 0, seed);
+    T a, b;
+    if (ci & 1) BoxMuller<T>::run(o.w[2], o.w[3], a, b);
+    else        BoxMuller<T>::run(o.w[0], o.w[1], a, b);
+    gre = (double)a;
+    gim = (double)b;
+  }
+}
+
+// Row S roles inside a kz in {0, nz/2} plane (transform.py:141-158).
+enum { RF_SRC = 0, RF_DEST = 1, RF_SELF = 2 };
+RF_HD int sym_role(int nx, int ny, int ix, int iy) {
+  const bool xe = (ix == 0) || (ix == nx / 2);
+  const bool ye = (iy == 0) || (iy == ny / 2);
+  if (xe && ye) return RF_SELF;
+  if (iy > ny / 2) return RF_DEST;
+  if (ye && ix > nx / 2) return RF_DEST;
+  return RF_SRC;
+}
+
+// Rows K,T,R,S for one API cell (ix, iy, iz), iz in [0, nz/2].
+template <typename T>
+RF_HD cplx<T> gen_cell(const GenParams& g, uint64_t seed, int ix, int iy, int iz) {
+  int sx = ix, sy = iy, role = RF_SRC;
+  if (iz == 0 || iz == g.nz / 2) {
+    role = sym_role(g.nx, g.ny, ix, iy);
+    if (role == RF_DEST) {  // take conj of the draw at (-ix, -iy)
+      sx = (g.nx - ix) % g.nx;
+      sy = (g.ny - iy) % g.ny;
+    }
+  }
+  const T s = sigma_cell<T>(g, sx, sy, iz);
+  double gre, gim;
+  noise_of_cell<T>(g, seed, sx, sy, iz, gre, gim);
+  T re = (T)((double)s * gre);       // random.py:28: product in float64, rounded once
+  T im = (T)((double)s * gim);
+  if (role == RF_DEST) im = -im;
+  if (role == RF_SELF) im = (T)0;    // transform.py:154-156
+  if (ix == 0 && iy == 0 && iz == 0) re = (T)0;  // transform.py:158
+  return mk<T>(re, im);
+}
+
+// Device-internal packed cell: kz in [0, nz/2); slot kz = 0 carries
+// A(kz=0) + i * A(kz=nz/2)  (both planes are 2-D Hermitian, so after the x and
+// y inverse passes they are real and occupy re / im of one complex plane).
+template <typename T>
+RF_HD cplx<T> gen_packed(const GenParams& g, uint64_t seed, int ix, int iy, int kz) {
+  cplx<T> a = gen_cell<T>(g, seed, ix, iy, kz);
+  if (kz == 0) {
+    cplx<T> n = gen_cell<T>(g, seed, ix, iy, g.nz / 2);
+    a = mk<T>(a.x - n.y, a.y + n.x);
+  }
+  return a;
+}
+
+// ------------------------------------------------------- c2r / r2c untangle --
+// Inverse: Zc[k] = (X[k] + conj X[M-k]) + i t_k (X[k] - conj X[M-k]),  t_k = exp(+2 pi i k / N), N = 2M.
+// The length-M unnormalised inverse FFT of Zc is z[m] = x[2m] + i x[2m+1] (x unnormalised, i.e. N * irfft).
+template <typename T> RF_HD cplx<T> c2r_untangle(cplx<T> xk, cplx<T> xmk, cplx<T> tk) {
+  cplx<T> a = mk<T>(xk.x + xmk.x, xk.y - xmk.y);
+  cplx<T> d = mk<T>(xk.x - xmk.x, xk.y + xmk.y);
+  cplx<T> b = cmul(tk, d);
+  return mk<T>(a.x - b.y, a.y + b.x);
+}
+// Forward: given Z = FFT_M(z) (kernel exp(-...)), X[k] = (Z[k] + conj Z[M-k])/2 - (i/2) conj(t_k) (Z[k] - conj Z[M-k]).
+template <typename T> RF_HD cplx<T> r2c_tangle(cplx<T> zk, cplx<T> zmk, cplx<T> tk) {
+  cplx<T> a = mk<T>(zk.x + zmk.x, zk.y - zmk.y);
+  cplx<T> d = mk<T>(zk.x - zmk.x, zk.y + zmk.y);
+  cplx<T> b = cmul(cconj(tk), d);
+  return mk<T>((T)0.5 * (a.x + b.y), (T)0.5 * (a.y - b.x));
+}
+
+// LDS padding: one extra slot every 16 so that stride-16 (and stride-8) write
+// patterns of the first Stockham pass spread over the banks.
+RF_HD int pad16(int i) { return i + (i >> 4); }
+
+}  // namespace rf

@@ -1,0 +1,387 @@
+// rf_fft.h -- LDS-staged Stockham FFT passes of the 3-D c2r / r2c transform.
+//
+// Two pass shapes, both written as *phase functions* separated by workgroup
+// barriers so that the HIP kernels (rf_kernels.hip) and the CPU emulator
+// (emu/rf_emu.cpp) run the very same code:
+//
+//   ColFFT : FFT along a strided axis (x or y).  A workgroup owns a tile of TC
+//            adjacent columns (kz fastest => every global access is a 16-byte
+//            vector covering CPL adjacent columns, tile rows are TC*8 B
+//            contiguous segments).  Pass 1 goes global -> registers -> LDS,
+//            the last pass LDS -> registers -> global, so the tile crosses LDS
+//            only NPASS-1 times.  LDS image: [pad16(row)][TC] (t fastest).
+//   RowFFT : c2r (or r2c) along the contiguous z axis.  A workgroup owns NRT
+//            whole rows of M = nz/2 complex.  The Hermitian untangle is folded
+//            into pass 1: one thread owns the butterfly pair (j, M/R1 - j),
+//            whose inputs are each other's mirror images.
+//
+// Device-internal layout: W[nx][ny][nz/2] complex == [nx][ny][nz]
+// real; slot kz=0 of the complex view carries (kz=0 plane) + i (kz=nz/2 plane).
+#pragma once
+#include "rf_core.h"
+
+namespace rf {
+
+constexpr int ceil_div(int a, int b) { return (a + b - 1) / b; }
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+
+template <typename T> struct alignas(16) V16 {
+  static constexpr int CPL = 16 / (int)sizeof(cplx<T>);
+  cplx<T> c[CPL];
+};
+
+// ---------------------------------------------------------------------------
+// Column pass configuration
+// ---------------------------------------------------------------------------
+template <typename T_, int N_, int R1_, int R2_, int R3_, int TC_, int NT_>
+struct ColCfg {
+  using T = T_;
+  static constexpr int N = N_, R1 = R1_, R2 = R2_, R3 = R3_, TC = TC_, NT = NT_;
+  static_assert(R1_ * R2_ * R3_ == N_, "radices must multiply to N");
+  static constexpr int CPL = V16<T>::CPL;        // columns per lane (2 for f32, 1 for f64)
+  static constexpr int LPR = TC / CPL;           // lanes per tile row
+  static constexpr int BPI = NT / LPR;           // butterflies (per column) per iteration
+  static_assert(NT_ % LPR == 0, "NT must be a multiple of lanes-per-row");
+  static constexpr int NPASS = (R2 == 1 ? 1 : (R3 == 1 ? 2 : 3));
+  static constexpr int RL = (NPASS == 1 ? R1 : (NPASS == 2 ? R2 : R3));  // radix of the last pass
+  static constexpr int LDS_ROWS = (NPASS == 1 ? 0 : N + ((N - 1) >> 4) + 1);
+  static constexpr int LDS_BYTES = LDS_ROWS * TC * (int)sizeof(cplx<T>);
+  static constexpr int IT1 = ceil_div(N / R1, BPI);
+  static constexpr int IT2 = (NPASS == 3 ? ceil_div(N / R2, BPI) : 1);
+  static constexpr int ITL = ceil_div(N / RL, BPI);
+};
+
+// Addressing of a column pass over the packed device array.
+//   flattened column C in [0, ncols); element (row, C) lives at
+//   (C / inner) * outer_stride + (C % inner) + row * row_stride   (complex units)
+struct ColGeom {
+  long long inner, outer_stride, row_stride;
+};
+
+template <typename T> struct PlainColIO {
+  cplx<T>* base;
+  ColGeom g;
+  RF_HD long long addr(long long C, int row) const {
+    return (C / g.inner) * g.outer_stride + (C % g.inner) + (long long)row * g.row_stride;
+  }
+  RF_HD V16<T> load(long long C, int row) const { return *reinterpret_cast<const V16<T>*>(base + addr(C, row)); }
+  RF_HD void store(long long C, int row, const V16<T>& v) const {
+    *reinterpret_cast<V16<T>*>(base + addr(C, row)) = v;
+  }
+};
+
+// x pass fused with generation (rows K,T,R,S): load() synthesises the packed
+// k-space cell instead of reading memory.  Columns are the flattened (iy, kz).
+// If `kspace` is non-null the cell is read from an API-layout array
+// [nx][ny][nz/2+1] instead (unfused c2r of uploaded / separately generated data).
+template <typename T> struct GenColIO {
+  cplx<T>* base;           // destination W
+  ColGeom g;               // x-pass geometry: inner = ny*nzc, row_stride = ny*nzc
+  GenParams gp;
+  const cplx<T>* kspace;   // optional source in API layout
+  int kz0, nzl;            // this rank's kz slab [kz0, kz0 + nzl) of the nz/2 packed planes
+  RF_HD V16<T> load(long long C, int row) const {
+    V16<T> v;
+    const int nzc = gp.nz / 2;
+    const uint64_t seed = gp.seed_dev ? *gp.seed_dev : gp.seed;
+#pragma unroll
+    for (int c = 0; c < V16<T>::CPL; ++c) {
+      const long long Cc = C + c;
+      const int iy = (int)(Cc / nzl), kz = kz0 + (int)(Cc % nzl), ix = row;
+      if (kspace) {
+        const cplx<T>* p = kspace + ((long long)ix * gp.ny + iy) * (nzc + 1);
+        cplx<T> a = p[kz];
+        if (kz == 0) { cplx<T> n = p[nzc]; a = mk<T>(a.x - n.y, a.y + n.x); }
+        v.c[c] = a;
+      } else {
+        v.c[c] = gen_packed<T>(gp, seed, ix, iy, kz);
+      }
+    }
+    return v;
+  }
+  RF_HD void store(long long C, int row, const V16<T>& v) const {
+    const long long a = (C / g.inner) * g.outer_stride + (C % g.inner) + (long long)row * g.row_stride;
+    *reinterpret_cast<V16<T>*>(base + a) = v;
+  }
+};
+
+// ---------------------------------------------------------------------------
+// Column FFT phases.  `tw` = exp(+2 pi i q / N), q in [0, N).
+// ---------------------------------------------------------------------------
+template <class C, int DIR, class IO>
+struct ColFFT {
+  using T = typename C::T;
+  using cx = cplx<T>;
+  using V = V16<T>;
+  static constexpr int N = C::N, CPL = C::CPL, LPR = C::LPR, BPI = C::BPI;
+
+  struct Regs { cx v[C::IT2][C::CPL][cmax(C::R2, 1)]; };
+
+  RF_HD static V* lds_at(cx* lds, int row, int lp) {
+    return reinterpret_cast<V*>(lds + (long long)pad16(row) * C::TC) + lp;
+  }
+
+  // pass 1: global -> R1 butterfly -> LDS (or straight back to global when N == R1)
+  RF_HD static void pass_first(int tid, long long tile, const IO& io, cx* lds) {
+    constexpr int R = C::R1, L = N / R;
+    const int lp = tid % LPR, jl = tid / LPR;
+    const long long Ccol = tile * C::TC + (long long)lp * CPL;
+#pragma unroll
+    for (int it = 0; it < C::IT1; ++it) {
+      const int j = it * BPI + jl;
+      if (j < L) {
+        cx v[CPL][R];
+#pragma unroll
+        for (int m = 0; m < R; ++m) {
+          V x = io.load(Ccol, j + m * L);
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) v[c][m] = x.c[c];
+        }
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) DFT<R, DIR>::run(v[c]);
+#pragma unroll
+        for (int m = 0; m < R; ++m) {
+          V x;
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) x.c[c] = v[c][m];
+          if (C::NPASS == 1) io.store(Ccol, j * R + m, x);
+          else *lds_at(lds, j * R + m, lp) = x;
+        }
+      }
+    }
+  }
+
+  // middle pass (only when NPASS == 3), split around a barrier because it is in place
+  RF_HD static void pass_mid_read(int tid, const cx* tw, cx* lds, Regs& r) {
+    constexpr int R = C::R2, L = N / R, Ns = C::R1;
+    const int lp = tid % LPR, jl = tid / LPR;
+#pragma unroll
+    for (int it = 0; it < C::IT2; ++it) {
+      const int j = it * BPI + jl;
+      if (j < L) {
+#pragma unroll
+        for (int m = 0; m < R; ++m) {
+          V x = *lds_at(lds, j + m * L, lp);
+          if (m > 0) {
+            const cx w = tw_dir<DIR>(tw[stockham_tw_index(j, m, Ns, R, N)]);
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) x.c[c] = cmul(x.c[c], w);
+          }
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) r.v[it][c][m] = x.c[c];
+        }
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) DFT<R, DIR>::run(r.v[it][c]);
+      }
+    }
+  }
+  RF_HD static void pass_mid_write(int tid, cx* lds, const Regs& r) {
+    constexpr int R = C::R2, L = N / R, Ns = C::R1;
+    const int lp = tid % LPR, jl = tid / LPR;
+#pragma unroll
+    for (int it = 0; it < C::IT2; ++it) {
+      const int j = it * BPI + jl;
+      if (j < L) {
+        const int ob = stockham_out_base(j, Ns, R);
+#pragma unroll
+        for (int m = 0; m < R; ++m) {
+          V x;
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) x.c[c] = r.v[it][c][m];
+          *lds_at(lds, ob + m * Ns, lp) = x;
+        }
+      }
+    }
+  }
+
+  // last pass (NPASS >= 2): LDS -> RL butterfly -> global
+  RF_HD static void pass_last(int tid, long long tile, const IO& io, const cx* tw, cx* lds) {
+    constexpr int R = C::RL, L = N / R;  // Ns == L, out_base(j) == j, twiddle index == m*j
+    const int lp = tid % LPR, jl = tid / LPR;
+    const long long Ccol = tile * C::TC + (long long)lp * CPL;
+#pragma unroll
+    for (int it = 0; it < C::ITL; ++it) {
+      const int j = it * BPI + jl;
+      if (j < L) {
+        cx v[CPL][R];
+#pragma unroll
+        for (int m = 0; m < R; ++m) {
+          V x = *lds_at(lds, j + m * L, lp);
+          if (m > 0) {
+            const cx w = tw_dir<DIR>(tw[m * j]);
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) x.c[c] = cmul(x.c[c], w);
+          }
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) v[c][m] = x.c[c];
+        }
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) DFT<R, DIR>::run(v[c]);
+#pragma unroll
+        for (int m = 0; m < R; ++m) {
+          V x;
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) x.c[c] = v[c][m];
+          io.store(Ccol, j + m * L, x);
+        }
+      }
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------
+// Row (z) pass: complex FFT of length M = nz/2 per row + Hermitian (un)tangle
+// ---------------------------------------------------------------------------
+template <typename T_, int M_, int R1_, int R2_, int R3_, int NRT_, int NT_>
+struct RowCfg {
+  using T = T_;
+  static constexpr int M = M_, R1 = R1_, R2 = R2_, R3 = R3_, NRT = NRT_, NT = NT_;
+  static_assert(R1_ * R2_ * R3_ == M_, "radices must multiply to M");
+  static constexpr int NPASS = (R2 == 1 ? 1 : (R3 == 1 ? 2 : 3));
+  static constexpr int RL = (NPASS == 1 ? R1 : (NPASS == 2 ? R2 : R3));
+  static constexpr int RS = M + ((M - 1) >> 4) + 1 + 1;       // LDS row stride (complex), odd-ish shift between rows
+  static constexpr int LDS_BYTES = (NPASS == 1 ? 0 : NRT * RS * (int)sizeof(cplx<T>));
+  static constexpr int L1 = M / R1;                           // butterflies per row in pass 1
+  static constexpr int TPR1 = cmax(1, L1 / 2);                // threads per row in pass 1 (each owns a mirror pair)
+  static constexpr int IT1 = ceil_div(NRT * TPR1, NT);
+  static constexpr int IT2 = (NPASS == 3 ? ceil_div(NRT * (M / R2), NT) : 1);
+  static constexpr int ITL = ceil_div(NRT * (M / RL), NT);
+};
+
+// c2r row IO over the device array viewed as complex [nrows][M] on input and
+// real [nrows][2M] on output (same memory).  Accumulates sum / sum of squares.
+template <typename T> struct PlainRowIO {
+  cplx<T>* base;
+  T scale;                       // 1 / (nx ny nz)
+  int M_of;                      // complex elements per row (nz / 2)
+  RF_HD cplx<T> load(long long row, int k) const { return base[row * (long long)M_of + k]; }
+  RF_HD void store(long long row, int n, cplx<T> z, double& s1, double& s2) const {
+    z.x *= scale; z.y *= scale;
+    base[row * (long long)M_of + n] = z;
+    s1 += (double)z.x + (double)z.y;
+    s2 += (double)z.x * (double)z.x + (double)z.y * (double)z.y;
+  }
+};
+
+// tw = exp(+2 pi i q / (2M)), q in [0, 2M): t_k = tw[k], w_M^q = tw[2q]
+template <class C, class IO>
+struct RowC2R {
+  using T = typename C::T;
+  using cx = cplx<T>;
+  static constexpr int M = C::M, NT = C::NT;
+  static constexpr int DIR = +1;
+
+  struct Regs { cx v[C::IT2][cmax(C::R2, 1)]; double s1, s2; };
+
+  RF_HD static cx* lds_at(cx* lds, int rl, int i) { return lds + (long long)rl * C::RS + pad16(i); }
+
+  // pass 1 outputs: LDS (NPASS > 1) or global (NPASS == 1)
+  template <int R>
+  RF_HD static void emit(int rl, long long row, int idx, const cx* v, const IO& io, cx* lds, Regs& r) {
+#pragma unroll
+    for (int m = 0; m < R; ++m) {
+      if (C::NPASS == 1) io.store(row, idx + m, v[m], r.s1, r.s2);
+      else *lds_at(lds, rl, idx + m) = v[m];
+    }
+  }
+
+  // pass 1: global -> untangle -> R1 butterflies of the mirror pair -> LDS
+  RF_HD static void pass_first(int tid, long long tile, long long nrows, const IO& io, const cx* tw, cx* lds, Regs& r) {
+    constexpr int R = C::R1, L = C::L1;
+    r.s1 = 0; r.s2 = 0;
+#pragma unroll
+    for (int it = 0; it < C::IT1; ++it) {
+      const int w = it * NT + tid;
+      const int rl = w / C::TPR1, q = w % C::TPR1;
+      const long long row = tile * C::NRT + rl;
+      if (rl < C::NRT && row < nrows) {
+        const bool self = (q == 0);
+        const int ja = q;
+        const int jb = self ? L / 2 : L - q;
+        const bool has_b = (L >= 2);
+        cx A[R], B[R], ZA[R], ZB[R];
+#pragma unroll
+        for (int m = 0; m < R; ++m) A[m] = io.load(row, ja + m * L);
+        if (has_b) {
+#pragma unroll
+          for (int m = 0; m < R; ++m) B[m] = io.load(row, jb + m * L);
+        }
+#pragma unroll
+        for (int m = 0; m < R; ++m) {
+          const cx ta = tw[ja + m * L];
+          if (self) {
+            if (m == 0) ZA[0] = mk<T>(A[0].x + A[0].y, A[0].x - A[0].y);   // (DC + Nyq) + i (DC - Nyq)
+            else ZA[m] = c2r_untangle(A[m], A[R - m], ta);
+          } else {
+            ZA[m] = c2r_untangle(A[m], B[R - 1 - m], ta);
+          }
+          if (has_b) {
+            const cx tb = tw[jb + m * L];
+            ZB[m] = self ? c2r_untangle(B[m], B[R - 1 - m], tb) : c2r_untangle(B[m], A[R - 1 - m], tb);
+          }
+        }
+        DFT<R, DIR>::run(ZA);
+        emit<R>(rl, row, ja * R, ZA, io, lds, r);
+        if (has_b) {
+          DFT<R, DIR>::run(ZB);
+          emit<R>(rl, row, jb * R, ZB, io, lds, r);
+        }
+      }
+    }
+  }
+
+  RF_HD static void pass_mid_read(int tid, const cx* tw, cx* lds, Regs& r) {
+    constexpr int R = C::R2, L = M / R, Ns = C::R1;
+#pragma unroll
+    for (int it = 0; it < C::IT2; ++it) {
+      const int w = it * NT + tid;
+      const int rl = w / L, j = w % L;
+      if (rl < C::NRT) {
+#pragma unroll
+        for (int m = 0; m < R; ++m) {
+          cx x = *lds_at(lds, rl, j + m * L);
+          if (m > 0) x = cmul(x, tw[2 * stockham_tw_index(j, m, Ns, R, M)]);
+          r.v[it][m] = x;
+        }
+        DFT<R, DIR>::run(r.v[it]);
+      }
+    }
+  }
+  RF_HD static void pass_mid_write(int tid, cx* lds, const Regs& r) {
+    constexpr int R = C::R2, L = M / R, Ns = C::R1;
+#pragma unroll
+    for (int it = 0; it < C::IT2; ++it) {
+      const int w = it * NT + tid;
+      const int rl = w / L, j = w % L;
+      if (rl < C::NRT) {
+        const int ob = stockham_out_base(j, Ns, R);
+#pragma unroll
+        for (int m = 0; m < R; ++m) *lds_at(lds, rl, ob + m * Ns) = r.v[it][m];
+      }
+    }
+  }
+
+  RF_HD static void pass_last(int tid, long long tile, long long nrows, const IO& io, const cx* tw, cx* lds, Regs& r) {
+    constexpr int R = C::RL, L = M / R;
+#pragma unroll
+    for (int it = 0; it < C::ITL; ++it) {
+      const int w = it * NT + tid;
+      const int rl = w / L, j = w % L;
+      const long long row = tile * C::NRT + rl;
+      if (rl < C::NRT && row < nrows) {
+        cx v[R];
+#pragma unroll
+        for (int m = 0; m < R; ++m) {
+          cx x = *lds_at(lds, rl, j + m * L);
+          if (m > 0) x = cmul(x, tw[2 * m * j]);
+          v[m] = x;
+        }
+        DFT<R, DIR>::run(v);
+#pragma unroll
+        for (int m = 0; m < R; ++m) io.store(row, j + m * L, v[m], r.s1, r.s2);
+      }
+    }
+  }
+};
+
+}  // namespace rf

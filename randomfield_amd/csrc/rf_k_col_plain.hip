@@ -1,0 +1,52 @@
+// strided in-place FFT passes (PlainColIO), float32 + float64, both directions
+#include "rf_kernels.h"
+#include "rf_launch.h"
+
+namespace rf {
+namespace {
+template <class C, int DIR, class IO>
+hipError_t launch_one(const IO& io, long long ncols, const cplx<typename C::T>* tw, hipStream_t s, bool prepare_only) {
+  if (ncols % C::TC) return hipErrorInvalidValue;
+  const long long ntiles = ncols / C::TC;
+  auto k = col_kernel<C, DIR, IO>;
+  static bool prepared = false;
+  if (!prepared) {
+    if (C::LDS_BYTES > 65536) {
+      hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+      if (e != hipSuccess) return e;
+    }
+    prepared = true;
+  }
+  if (prepare_only) return hipSuccess;
+  hipLaunchKernelGGL(k, dim3((unsigned)ntiles), dim3(C::NT), C::LDS_BYTES, s, io, tw, ntiles);
+  return hipGetLastError();
+}
+template <typename T, int DIR>
+hipError_t launch_t(int N, cplx<T>* base, ColGeom g, long long ncols, const cplx<T>* tw, hipStream_t s, bool po) {
+  PlainColIO<T> io; io.base = base; io.g = g;
+  switch (N) {
+#define X(NN) case NN: return launch_one<typename ColSel<T, NN>::type, DIR, PlainColIO<T>>(io, ncols, tw, s, po);
+    RF_COL_SIZES(X)
+#undef X
+    default: return hipErrorInvalidValue;
+  }
+}
+}  // namespace
+
+int col_tile_cols(int f64, int N) {
+  switch (N) {
+#define X(NN) case NN: return f64 ? ColSel<double, NN>::type::TC : ColSel<float, NN>::type::TC;
+    RF_COL_SIZES(X)
+#undef X
+    default: return 0;
+  }
+}
+
+hipError_t launch_col_plain(int f64, int N, int dir, void* base, ColGeom g, long long ncols, const void* tw,
+                            hipStream_t s, bool po) {
+  if (f64) return dir > 0 ? launch_t<double, +1>(N, (cplx<double>*)base, g, ncols, (const cplx<double>*)tw, s, po)
+                          : launch_t<double, -1>(N, (cplx<double>*)base, g, ncols, (const cplx<double>*)tw, s, po);
+  return dir > 0 ? launch_t<float, +1>(N, (cplx<float>*)base, g, ncols, (const cplx<float>*)tw, s, po)
+                 : launch_t<float, -1>(N, (cplx<float>*)base, g, ncols, (const cplx<float>*)tw, s, po);
+}
+}  // namespace rf

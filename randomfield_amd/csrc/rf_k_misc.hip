@@ -1,0 +1,182 @@
+// elementwise / reduction kernels: standalone generation (rows K,T,R,S in the API
+// layout), moments finalisation (row D), lognormal map and per-z scaling (row L),
+// save_potential helpers.
+#include "rf_kernels.h"
+#include "rf_launch.h"
+
+namespace rf {
+namespace {
+
+template <typename T>
+__global__ __launch_bounds__(256) void gen_kspace_kernel(cplx<T>* __restrict__ K, GenParams gp) {
+  const int nzh = gp.nz / 2 + 1;
+  const long long total = (long long)gp.nx * gp.ny * nzh;
+  const uint64_t seed = gp.seed_dev ? *gp.seed_dev : gp.seed;
+  for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += (long long)gridDim.x * blockDim.x) {
+    const int iz = (int)(c % nzh);
+    const long long col = c / nzh;
+    const int iy = (int)(col % gp.ny), ix = (int)(col / gp.ny);
+    K[c] = gen_cell<T>(gp, seed, ix, iy, iz);
+  }
+}
+
+__global__ __launch_bounds__(1024) void reduce_partials_kernel(const double* __restrict__ partials, long long n,
+                                                              double* __restrict__ stats, unsigned long long* counter) {
+  __shared__ double red[2 * 16];
+  double a = 0, b = 0;
+  for (long long i = threadIdx.x; i < n; i += blockDim.x) { a += partials[2 * i]; b += partials[2 * i + 1]; }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); b += __shfl_down(b, off); }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) { red[2 * wave] = a; red[2 * wave + 1] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    a = 0; b = 0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { a += red[2 * w]; b += red[2 * w + 1]; }
+    unsigned long long slot = 0;
+    if (counter) { slot = *counter; *counter = slot + 1; }
+    stats[2 * slot] = a;
+    stats[2 * slot + 1] = b;
+  }
+}
+
+__global__ void pick_seed_kernel(const uint64_t* seeds, const unsigned long long* counter, uint64_t* seed_cur) {
+  *seed_cur = seeds[*counter];
+}
+
+// cosmotools.py:216-220: delta /= sigma; delta *= sqrt(log t); delta = exp(delta); delta /= sqrt(t)
+// each step rounded to the array dtype; the two table factors are float64 (growth is a float64 (nz,) array)
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void lognormal_vec_kernel(T* __restrict__ W, long long nvec, int nz,
+                                                            const double* __restrict__ a_z,
+                                                            const double* __restrict__ b_z, T sigma) {
+  struct alignas(16) Vec { T v[VEC]; };
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
+    Vec x = reinterpret_cast<const Vec*>(W)[i];
+    const int iz0 = (int)((i * VEC) % nz);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      T d = x.v[e] / sigma;
+      d = (T)((double)d * a_z[iz0 + e]);
+      d = sizeof(T) == 4 ? (T)expf((float)d) : (T)exp((double)d);
+      d = (T)((double)d / b_z[iz0 + e]);
+      x.v[e] = d;
+    }
+    reinterpret_cast<Vec*>(W)[i] = x;
+  }
+}
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void affine_vec_kernel(T* __restrict__ W, long long nvec, int nz,
+                                                         const double* __restrict__ mul_z, double add, int has_add) {
+  struct alignas(16) Vec { T v[VEC]; };
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
+    Vec x = reinterpret_cast<const Vec*>(W)[i];
+    const int iz0 = (int)((i * VEC) % nz);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      T d = (T)((double)x.v[e] * mul_z[iz0 + e]);   // delta *= f64 (nz,) array: f64 product rounded to T
+      if (has_add) d = d + (T)add;                   // delta += 1 in the array dtype
+      x.v[e] = d;
+    }
+    reinterpret_cast<Vec*>(W)[i] = x;
+  }
+}
+
+// generate.py:205-215: potential = delta(k) / k^2, 0 at DC; k^2 rounded to the array dtype in two steps
+template <typename T>
+__global__ __launch_bounds__(256) void save_potential_kernel(const cplx<T>* __restrict__ K, cplx<T>* __restrict__ P,
+                                                             int nx, int ny, int nz, const double* __restrict__ kx2,
+                                                             const double* __restrict__ ky2, const double* __restrict__ kz2) {
+  const int nzh = nz / 2 + 1;
+  const long long total = (long long)nx * ny * nzh;
+  for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += (long long)gridDim.x * blockDim.x) {
+    const int iz = (int)(c % nzh);
+    const long long col = c / nzh;
+    const int iy = (int)(col % ny), ix = (int)(col / ny);
+    T t = (T)(kx2[ix] + ky2[iy]);
+    t = (T)((double)t + kz2[iz]);
+    T inv = (T)1 / t;
+    cplx<T> d = K[c];
+    // complex (inv + 0i) * d: the 0*x terms of numpy's complex product vanish exactly
+    cplx<T> r = mk<T>(inv * d.x, inv * d.y);
+    if (c == 0) r = mk<T>((T)0, (T)0);
+    P[c] = r;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void scale_copy_kernel(const cplx<T>* __restrict__ P, cplx<T>* __restrict__ K,
+                                                         long long n, T scale) {
+  for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < n; c += (long long)gridDim.x * blockDim.x) {
+    cplx<T> p = P[c];
+    K[c] = mk<T>(p.x * scale, p.y * scale);
+  }
+}
+
+inline unsigned grid_for(long long n, int block) {
+  long long g = (n + block - 1) / block;
+  if (g > 256 * 16) g = 256 * 16;   // 16 blocks per CU, grid-stride the rest
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+}  // namespace
+
+hipError_t launch_gen_kspace(int f64, void* K, const GenParams& gp, hipStream_t s) {
+  const long long total = (long long)gp.nx * gp.ny * (gp.nz / 2 + 1);
+  if (f64) hipLaunchKernelGGL(gen_kspace_kernel<double>, dim3(grid_for(total, 256)), dim3(256), 0, s, (cplx<double>*)K, gp);
+  else hipLaunchKernelGGL(gen_kspace_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, s, (cplx<float>*)K, gp);
+  return hipGetLastError();
+}
+
+hipError_t launch_reduce_partials(const double* partials, long long n, double* stats, unsigned long long* counter,
+                                  hipStream_t s) {
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(1024), 0, s, partials, n, stats, counter);
+  return hipGetLastError();
+}
+
+hipError_t launch_pick_seed(const uint64_t* seeds, const unsigned long long* counter, uint64_t* seed_cur, hipStream_t s) {
+  hipLaunchKernelGGL(pick_seed_kernel, dim3(1), dim3(1), 0, s, seeds, counter, seed_cur);
+  return hipGetLastError();
+}
+
+hipError_t launch_lognormal(int f64, void* W, long long nrows, int nz, const double* a_z, const double* b_z,
+                            double sigma, hipStream_t s) {
+  const long long total = nrows * nz;
+  if (f64) {
+    const long long nvec = total / 2;
+    hipLaunchKernelGGL((lognormal_vec_kernel<double, 2>), dim3(grid_for(nvec, 256)), dim3(256), 0, s, (double*)W, nvec, nz, a_z, b_z, sigma);
+  } else {
+    const long long nvec = total / 4;
+    hipLaunchKernelGGL((lognormal_vec_kernel<float, 4>), dim3(grid_for(nvec, 256)), dim3(256), 0, s, (float*)W, nvec, nz, a_z, b_z, (float)sigma);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_affine_z(int f64, void* W, long long nrows, int nz, const double* mul_z, double add, hipStream_t s) {
+  const long long total = nrows * nz;
+  const int has_add = add != 0.0;
+  if (f64) {
+    const long long nvec = total / 2;
+    hipLaunchKernelGGL((affine_vec_kernel<double, 2>), dim3(grid_for(nvec, 256)), dim3(256), 0, s, (double*)W, nvec, nz, mul_z, add, has_add);
+  } else {
+    const long long nvec = total / 4;
+    hipLaunchKernelGGL((affine_vec_kernel<float, 4>), dim3(grid_for(nvec, 256)), dim3(256), 0, s, (float*)W, nvec, nz, mul_z, add, has_add);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_save_potential(int f64, const void* K, void* P, int nx, int ny, int nz, const double* kx2,
+                                 const double* ky2, const double* kz2, hipStream_t s) {
+  const long long total = (long long)nx * ny * (nz / 2 + 1);
+  if (f64) hipLaunchKernelGGL(save_potential_kernel<double>, dim3(grid_for(total, 256)), dim3(256), 0, s, (const cplx<double>*)K, (cplx<double>*)P, nx, ny, nz, kx2, ky2, kz2);
+  else hipLaunchKernelGGL(save_potential_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, s, (const cplx<float>*)K, (cplx<float>*)P, nx, ny, nz, kx2, ky2, kz2);
+  return hipGetLastError();
+}
+
+hipError_t launch_scale_copy(int f64, const void* P, void* K, long long n, double scale, hipStream_t s) {
+  if (f64) hipLaunchKernelGGL(scale_copy_kernel<double>, dim3(grid_for(n, 256)), dim3(256), 0, s, (const cplx<double>*)P, (cplx<double>*)K, n, scale);
+  else hipLaunchKernelGGL(scale_copy_kernel<float>, dim3(grid_for(n, 256)), dim3(256), 0, s, (const cplx<float>*)P, (cplx<float>*)K, n, (float)scale);
+  return hipGetLastError();
+}
+}  // namespace rf

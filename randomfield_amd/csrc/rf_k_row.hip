@@ -1,0 +1,56 @@
+// z pass of the c2r transform (contiguous rows, Hermitian untangle fused, moments)
+#include "rf_kernels.h"
+#include "rf_launch.h"
+
+namespace rf {
+namespace {
+template <class C>
+constexpr int row_lds_bytes() { return C::LDS_BYTES > 2 * (C::NT / 64) * 8 ? C::LDS_BYTES : 2 * (C::NT / 64) * 8; }
+
+template <class C>
+hipError_t launch_one(const PlainRowIO<typename C::T>& io, long long nrows, const cplx<typename C::T>* tw,
+                      double* partials, hipStream_t s, bool prepare_only) {
+  const long long ntiles = (nrows + C::NRT - 1) / C::NRT;
+  auto k = row_c2r_kernel<C, PlainRowIO<typename C::T>>;
+  constexpr int lds = row_lds_bytes<C>();
+  static bool prepared = false;
+  if (!prepared) {
+    if (lds > 65536) {
+      hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      if (e != hipSuccess) return e;
+    }
+    prepared = true;
+  }
+  if (prepare_only) return hipSuccess;
+  hipLaunchKernelGGL(k, dim3((unsigned)ntiles), dim3(C::NT), lds, s, io, tw, nrows, partials);
+  return hipGetLastError();
+}
+template <typename T>
+hipError_t launch_t(int M, cplx<T>* W, long long nrows, double scale, const cplx<T>* tw, double* partials, hipStream_t s, bool po) {
+  PlainRowIO<T> io; io.base = W; io.scale = (T)scale; io.M_of = M;
+  switch (M) {
+#define X(MM) case MM: return launch_one<typename RowSel<T, MM>::type>(io, nrows, tw, partials, s, po);
+    RF_ROW_SIZES(X)
+#undef X
+    default: return hipErrorInvalidValue;
+  }
+}
+template <typename T> long long tiles_t(int M, long long nrows) {
+  switch (M) {
+#define X(MM) case MM: return (nrows + RowSel<T, MM>::type::NRT - 1) / RowSel<T, MM>::type::NRT;
+    RF_ROW_SIZES(X)
+#undef X
+    default: return -1;
+  }
+}
+}  // namespace
+
+hipError_t launch_row_c2r(int f64, int M, void* W, long long nrows, double scale, const void* tw,
+                          double* partials, hipStream_t s, bool po) {
+  if (f64) return launch_t<double>(M, (cplx<double>*)W, nrows, scale, (const cplx<double>*)tw, partials, s, po);
+  return launch_t<float>(M, (cplx<float>*)W, nrows, scale, (const cplx<float>*)tw, partials, s, po);
+}
+long long row_c2r_tiles(int f64, int M, long long nrows) {
+  return f64 ? tiles_t<double>(M, nrows) : tiles_t<float>(M, nrows);
+}
+}  // namespace rf

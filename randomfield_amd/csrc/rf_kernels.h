@@ -1,0 +1,82 @@
+// rf_kernels.h -- __global__ wrappers around the phase functions of rf_fft.h
+// (gfx950 only; compiled by hipcc).  One workgroup = one tile.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "rf_configs.h"
+
+namespace rf {
+
+// Blocks are dealt round-robin over the 8 XCDs (b and b+8 share one L2).  Give
+// each XCD a contiguous run of tiles so that neighbouring tiles -- which share
+// 128-byte lines when a tile row is 64 B wide -- meet in the same L2.
+__device__ __forceinline__ long long xcd_tile(long long b, long long nb) {
+  return (nb % 8 == 0) ? (b % 8) * (nb / 8) + b / 8 : b;
+}
+
+template <class C, int DIR, class IO>
+__global__ __launch_bounds__(C::NT) void col_kernel(IO io, const cplx<typename C::T>* __restrict__ tw,
+                                                    long long ntiles) {
+  using F = ColFFT<C, DIR, IO>;
+  using cx = cplx<typename C::T>;
+  extern __shared__ __attribute__((aligned(16))) char rf_smem[];
+  cx* lds = reinterpret_cast<cx*>(rf_smem);
+  const int tid = threadIdx.x;
+  const long long tile = xcd_tile(blockIdx.x, ntiles);
+  F::pass_first(tid, tile, io, lds);
+  if (C::NPASS == 3) {
+    typename F::Regs r;
+    __syncthreads();
+    F::pass_mid_read(tid, tw, lds, r);
+    __syncthreads();
+    F::pass_mid_write(tid, lds, r);
+  }
+  if (C::NPASS >= 2) {
+    __syncthreads();
+    F::pass_last(tid, tile, io, tw, lds);
+  }
+}
+
+// z pass: c2r rows + per-workgroup (sum, sum of squares) partials
+template <class C, class IO>
+__global__ __launch_bounds__(C::NT) void row_c2r_kernel(IO io, const cplx<typename C::T>* __restrict__ tw,
+                                                        long long nrows, double* __restrict__ partials) {
+  using F = RowC2R<C, IO>;
+  using cx = cplx<typename C::T>;
+  extern __shared__ __attribute__((aligned(16))) char rf_smem[];
+  cx* lds = reinterpret_cast<cx*>(rf_smem);
+  const int tid = threadIdx.x;
+  const long long tile = blockIdx.x;
+  typename F::Regs r;
+  F::pass_first(tid, tile, nrows, io, tw, lds, r);
+  if (C::NPASS == 3) {
+    __syncthreads();
+    F::pass_mid_read(tid, tw, lds, r);
+    __syncthreads();
+    F::pass_mid_write(tid, lds, r);
+  }
+  if (C::NPASS >= 2) {
+    __syncthreads();
+    F::pass_last(tid, tile, nrows, io, tw, lds, r);
+  }
+  // workgroup reduction of the moments: wave shuffle, then one slot per wave in LDS
+  double s1 = r.s1, s2 = r.s2;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    s1 += __shfl_down(s1, off);
+    s2 += __shfl_down(s2, off);
+  }
+  __syncthreads();  // LDS tile no longer needed
+  double* red = reinterpret_cast<double*>(rf_smem);
+  const int wave = tid >> 6, lane = tid & 63;
+  if (lane == 0) { red[2 * wave] = s1; red[2 * wave + 1] = s2; }
+  __syncthreads();
+  if (tid == 0) {
+    double a = 0, b = 0;
+#pragma unroll
+    for (int w = 0; w < C::NT / 64; ++w) { a += red[2 * w]; b += red[2 * w + 1]; }
+    partials[2 * (long long)blockIdx.x] = a;
+    partials[2 * (long long)blockIdx.x + 1] = b;
+  }
+}
+
+}  // namespace rf

@@ -1,0 +1,42 @@
+// rf_launch.h -- host-callable launchers; each .hip translation unit instantiates
+// one family of kernels so that the files compile in parallel.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "rf_configs.h"
+
+namespace rf {
+
+// strided FFT pass in place (y pass of c2r; x/y passes of r2c). dir = +1 inverse, -1 forward.
+// prepare_only = true sets the kernel's function attributes (dynamic LDS > 64 KB) without launching
+hipError_t launch_col_plain(int f64, int N, int dir, void* base, ColGeom g, long long ncols, const void* tw,
+                            hipStream_t s, bool prepare_only = false);
+// x pass of c2r fused with generation (kspace == nullptr) or reading an API-layout k array
+// [kz0, kz0+nzl) is the slab of packed kz planes this rank owns (0, nz/2 on one GPU)
+hipError_t launch_col_gen(int f64, int N, void* W, ColGeom g, long long ncols, const GenParams& gp,
+                          const void* kspace, int kz0, int nzl, const void* tw, hipStream_t s,
+                          bool prepare_only = false);
+int col_tile_cols(int f64, int N);   // tile width (columns) of the strided pass of length N, 0 if unsupported
+// z pass of c2r: rows of M = nz/2 complex -> nz reals, scaled; partials[2*tile] = (sum, sumsq)
+hipError_t launch_row_c2r(int f64, int M, void* W, long long nrows, double scale, const void* tw,
+                          double* partials, hipStream_t s, bool prepare_only = false);
+long long row_c2r_tiles(int f64, int M, long long nrows);
+
+// rows K,T,R,S into an API-layout k array [nx][ny][nz/2+1]
+hipError_t launch_gen_kspace(int f64, void* K, const GenParams& gp, hipStream_t s);
+// stats[0] = sum of partials[2i], stats[1] = sum of partials[2i+1]; if counter != nullptr the pair is
+// written at stats[2 * *counter] and *counter is incremented (graph replay)
+hipError_t launch_reduce_partials(const double* partials, long long n, double* stats, unsigned long long* counter,
+                                  hipStream_t s);
+// seed_cur = seeds[*counter]
+hipError_t launch_pick_seed(const uint64_t* seeds, const unsigned long long* counter, uint64_t* seed_cur,
+                            hipStream_t s);
+hipError_t launch_lognormal(int f64, void* W, long long nrows, int nz, const double* a_z, const double* b_z,
+                            double sigma, hipStream_t s);
+hipError_t launch_affine_z(int f64, void* W, long long nrows, int nz, const double* mul_z, double add,
+                           hipStream_t s);
+// P = K / k^2 (0 at DC), API layout; and K = scale * P
+hipError_t launch_save_potential(int f64, const void* K, void* P, int nx, int ny, int nz, const double* kx2,
+                                 const double* ky2, const double* kz2, hipStream_t s);
+hipError_t launch_scale_copy(int f64, const void* P, void* K, long long n, double scale, hipStream_t s);
+
+}  // namespace rf

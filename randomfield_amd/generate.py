@@ -1,0 +1,306 @@
+"""
+High-level functions to generate random fields -- mirror of
+``randomfield/generate.py`` :class:`Generator` for the Fourier-space sampling
+path, running on MI355X through ``librandomfield_hip.so``.
+
+Same constructor / method signatures as the reference (generate.py:74-75,
+144-146, 232-233, 282) plus keyword-only extensions.  The call order of the
+reference's ``generate_delta_field`` (generate.py:191-199,218-219)
+
+    fill_with_log10k -> filter_power -> tabulate_sigmas -> randomize
+    -> symmetrize -> [save potential] -> Plan.execute -> np.std
+
+is preserved in meaning, but on the ``hip`` backend the first five steps are
+evaluated per cell inside the first FFT pass of one fused GPU pipeline
+(``rf_realise``); the k-space array is only materialised when
+``save_potential=True`` needs it.
+
+Out of scope here (host-only side-cars of the reference):
+``calculate_lensing_potential`` and ``plot_slice``.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from . import cosmotools, powertools, transform
+from . import random as rf_random
+
+__all__ = ["Generator"]
+
+
+class _DevicePotential(object):
+    """Marker for a saved delta(k)/k**2 field that lives in device memory."""
+
+    def __init__(self, generator):
+        self._generator = generator
+
+    def download(self):
+        """Host copy (nx, ny, nz/2+1) of the saved potential."""
+        dev = self._generator.plan_c2r.device
+        dev.load_potential(1.0)
+        return dev.download_k()
+
+
+class Generator(object):
+    """
+    Manage random field generation for a specified geometry.
+
+    Parameters (as the reference, generate.py:43-73)
+    ----------
+    nx, ny, nz : int
+        Grid size; z is the line-of-sight direction.
+    grid_spacing_Mpc_h : float
+        Uniform grid spacing in Mpc/h.
+    num_plot_sections : int
+        Kept for compatibility: nz must be divisible by it (generate.py:86-90).
+    cosmology : astropy.cosmology.FLRW, optional
+        Background cosmology (needs astropy).  Only used for the O(nz) tables
+        (redshifts, growth function, mean matter density).
+    power : numpy.ndarray, optional
+        Structured array with fields 'k', 'Pk' (powertools.validate_power).
+        Defaults to the shipped Planck13 table.
+    verbose : bool, optional
+
+    Keyword-only extensions
+    -----------------------
+    backend : 'hip' (default) or 'numpy'
+        See :mod:`randomfield_amd.transform`.  'hip' raises RuntimeError when the
+        GPU path is unavailable; it never falls back to the CPU.
+    dtype : numpy complex dtype
+        complex64 (reference behaviour, generate.py:77) or complex128.
+    rng : 'reference' (default) or 'native'
+        'reference' draws the reference's own stream
+        (``RandomState(seed).normal``, random.py:24) on the host and uploads it, so
+        the same seed gives the reference's field (to float32 FFT rounding).
+        'native' uses the GPU's counter-based Philox4x32-10 + Box-Muller generator:
+        no host work, different (statistically equivalent) realisations.
+    growth_function, mean_matter_density, redshifts : (nz,) arrays, optional
+        The cosmology tables, for use without astropy.
+    """
+
+    def __init__(self, nx, ny, nz, grid_spacing_Mpc_h, num_plot_sections=4, cosmology=None, power=None,
+                 verbose=False, *, backend=None, dtype=np.complex64, rng="reference", growth_function=None,
+                 mean_matter_density=None, redshifts=None):
+        self.backend = transform.resolve_backend(backend)
+        if rng not in ("reference", "native"):
+            raise ValueError("Invalid rng: {0} (expected 'reference' or 'native').".format(rng))
+        if rng == "native" and self.backend != "hip":
+            raise ValueError("rng='native' is the GPU generator; it needs backend='hip'.")
+        self.rng = rng
+        self.plan_c2r = transform.Plan(shape=(nx, ny, nz), dtype_in=dtype, packed=True, overwrite=True,
+                                       inverse=True, use_pyfftw=True, backend=self.backend)
+        self.plan_r2c = self.plan_c2r.create_reverse_plan(reuse_output=True, overwrite=True)
+        self.grid_spacing_Mpc_h = grid_spacing_Mpc_h
+        self.k_min, self.k_max = powertools.get_k_bounds(self.plan_c2r.data_in, grid_spacing_Mpc_h, packed=True)
+        self.potential = None
+
+        if nz % num_plot_sections != 0:
+            raise ValueError("Z-axis does not evenly divided into {0} plot sections.".format(num_plot_sections))
+        self.num_plot_sections = num_plot_sections
+
+        self.cosmology = cosmology
+        if cosmology is None and cosmotools.have_astropy():
+            self.cosmology = cosmotools.create_cosmology()
+        if power is None:
+            if cosmology is not None:
+                raise ValueError("A tabulated power= is required with a custom cosmology "
+                                 "(the CLASS-based calculate_power is not part of this package).")
+            power = powertools.load_default_power()
+        self.power = powertools.validate_power(power)
+
+        # O(nz) background tables (generate.py:104-129): arrays win, else astropy if present
+        self.redshifts = None if redshifts is None else np.asarray(redshifts, float).reshape(nz)
+        self.growth_function = None if growth_function is None else np.asarray(growth_function, float).reshape(nz)
+        self.mean_matter_density = (None if mean_matter_density is None
+                                    else np.asarray(mean_matter_density, float).reshape(nz))
+        self.DC = np.arange(nz) * self.grid_spacing_Mpc_h
+
+        self.delta_field_rms = None
+        self.smoothed_power = None
+        self._field_on_host = False
+        if self.backend == "hip":
+            dev = self.plan_c2r.device
+            dev.set_kgrid(*powertools.ksq_axes(nx, ny, nz, grid_spacing_Mpc_h))
+
+        self.verbose = verbose
+        if self.verbose:
+            Mb = (self.plan_c2r.nbytes_allocated + self.plan_r2c.nbytes_allocated) / 2.0 ** 20
+            print("Allocated {0:.1f} Mb for {1} x {2} x {3} grid.".format(Mb, nx, ny, nz))
+            print("{0} Mpc/h spacing covered by k = {1:.5f} - {2:.5f} h/Mpc."
+                  .format(self.grid_spacing_Mpc_h, self.k_min, self.k_max))
+            if self.backend == "hip":
+                print("Device buffers: {0:.1f} Mb.".format(self.plan_c2r.device.nbytes / 2.0 ** 20))
+
+    # ------------------------------------------------------------------
+    @property
+    def shape(self):
+        return self.plan_c2r.shape
+
+    def _native_seed(self, seed):
+        if seed is None:
+            seed = int.from_bytes(os.urandom(8), "little")
+        return int(seed) & (2 ** 64 - 1)
+
+    def generate_delta_field(self, smoothing_length_Mpc_h=0., seed=None, save_potential=True, show_plot=False,
+                             save_plot_name=None, *, download=True):
+        """
+        Generate a delta-field realization (generate.py:144-230).
+
+        The delta field is calculated at redshift zero and sampled from a
+        distribution with mean zero and k-space variance proportional to the
+        smoothed power spectrum.  ``seed=None`` draws a fresh seed.
+
+        Returns a 3D array of delta values that is a *view* of the plan's host
+        buffer and will be overwritten by subsequent operations (as in the
+        reference).  With ``download=False`` (hip backend) the field stays on the
+        GPU, ``None`` is returned, and :meth:`download_field` fetches it later.
+        """
+        if show_plot or save_plot_name is not None:
+            raise NotImplementedError("plot_slice is outside the accelerated path (see DESIGN.md).")
+        nx, ny, nz = self.plan_c2r.shape
+        self.smoothed_power = powertools.filter_power(self.power, smoothing_length_Mpc_h)
+
+        if self.backend == "numpy":
+            data = self.plan_c2r.data_in
+            powertools.fill_with_log10k(data, spacing=self.grid_spacing_Mpc_h, packed=True)
+            powertools.tabulate_sigmas(data, power=self.smoothed_power, spacing=self.grid_spacing_Mpc_h, packed=True)
+            rf_random.randomize(data, seed=seed)
+            transform.symmetrize(data, packed=True)
+            if save_potential:
+                if self.potential is None or isinstance(self.potential, _DevicePotential):
+                    self.potential = np.empty_like(data)
+                self.potential.imag = 0.
+                kx2, ky2, kz2 = powertools.create_ksq_grids(self.potential, spacing=self.grid_spacing_Mpc_h,
+                                                            packed=True)
+                np.add(kx2, ky2, out=self.potential.real, casting="same_kind")
+                np.add(self.potential.real, kz2, out=self.potential.real, casting="same_kind")
+                with np.errstate(divide="ignore"):
+                    np.reciprocal(self.potential.real, out=self.potential.real)
+                self.potential[0, 0, 0] = 0.
+                self.potential *= data
+            else:
+                self.potential = None
+            delta = self.plan_c2r.execute()
+            self.delta_field_rms = np.std(delta.reshape(-1))
+            self._field_on_host = True
+        else:
+            dev = self.plan_c2r.device
+            log10_k, sigma = powertools.sigma_table(self.smoothed_power, (nx, ny, nz), self.grid_spacing_Mpc_h)
+            dev.set_power(log10_k, sigma)
+            if self.rng == "reference":
+                noise = rf_random.reference_normals(seed, 2 * nx * ny * (nz // 2 + 1))
+                dseed = 0
+            else:
+                noise = None
+                dseed = self._native_seed(seed)
+            if save_potential:
+                dev.generate(dseed, noise)          # rows K,T,R,S -> k-space on the device
+                dev.save_potential()                # generate.py:200-217
+                dev.execute_c2r()
+                self.potential = _DevicePotential(self)
+            else:
+                dev.realise(dseed, noise)           # fused: k-space never materialised
+                self.potential = None
+            mean, std = dev.moments()
+            self.delta_field_rms = self.plan_c2r.data_out.dtype.type(std)
+            self._field_on_host = False
+            delta = self.download_field() if download else None
+
+        if self.verbose:
+            print("Delta field has standard deviation {0:.3f}.".format(self.delta_field_rms))
+        return delta
+
+    def download_field(self):
+        """Copy the device-resident field into the plan's host buffer and return the view."""
+        if self.backend == "hip" and not self._field_on_host:
+            self.plan_c2r.device.download_real(self.plan_c2r.data_out_padded, padded=True)
+            self._field_on_host = True
+        return self.plan_c2r.data_out
+
+    def _need_table(self, name):
+        value = getattr(self, name)
+        if value is None:
+            raise RuntimeError("Generator.{0} is not available: pass {0}= (an (nz,) array) to the constructor "
+                               "(astropy-based tables are outside the accelerated path).".format(name))
+        return value
+
+    def convert_delta_to_density(self, apply_lognormal_transform=True, show_plot=False, save_plot_name=None, *,
+                                 download=True):
+        """
+        Convert a delta field into a density field with light-cone evolution
+        (generate.py:232-280): lognormal map with sigma = delta_field_rms and the
+        growth function along z (or ``delta*growth + 1``), then multiplication by
+        the mean matter density along z.
+        """
+        if show_plot or save_plot_name is not None:
+            raise NotImplementedError("plot_slice is outside the accelerated path (see DESIGN.md).")
+        if self.delta_field_rms is None:
+            raise RuntimeError("No delta field has been generated.")
+        growth = self._need_table("growth_function")
+        density = self._need_table("mean_matter_density")
+        nz = self.plan_c2r.shape[2]
+        if self.backend == "numpy":
+            delta = self.plan_c2r.data_out
+            if apply_lognormal_transform:
+                delta = cosmotools.apply_lognormal_transform(delta, growth, sigma=self.delta_field_rms)
+            else:
+                delta *= growth
+                delta += 1
+            delta *= density
+            return delta
+        dev = self.plan_c2r.device
+        if apply_lognormal_transform:
+            a_z, b_z = cosmotools.lognormal_tables(growth, self.delta_field_rms, nz)
+            dev.lognormal(a_z, b_z, float(self.delta_field_rms))
+        else:
+            dev.affine_z(growth, 1.0)
+        dev.scale_z(density)
+        self._field_on_host = False
+        return self.download_field() if download else None
+
+    def calculate_newtonian_potential(self, light_cone=True, show_plot=False, save_plot_name=None, *,
+                                      scale=None, download=True):
+        """
+        Calculate the Newtonian potential Phi(r) (generate.py:282-350): inverse
+        transform of ``scale * delta(k)/k**2`` with scale = -3/2 H0**2 Omega_m
+        (in s**-2, H0 = 100 km/s/Mpc), optionally times G(z)/(1+z) along z.
+
+        ``scale`` may be given explicitly; otherwise it is derived from the
+        cosmology (needs astropy).
+        """
+        if show_plot or save_plot_name is not None:
+            raise NotImplementedError("plot_slice is outside the accelerated path (see DESIGN.md).")
+        if self.potential is None:
+            raise RuntimeError("No saved potential field.")
+        if scale is None:
+            if self.cosmology is None:
+                raise RuntimeError("calculate_newtonian_potential needs scale= or an astropy cosmology.")
+            import astropy.units as u
+            H0 = 100 * (u.km / u.s) / u.Mpc
+            scale = (-1.5 * H0 ** 2 * self.cosmology.Om0).to(u.s ** -2).value
+        factor = None
+        if light_cone:
+            factor = self._need_table("growth_function") / (1 + self._need_table("redshifts"))
+        if self.backend == "numpy":
+            self.plan_c2r.data_in[:] = self.potential
+            self.plan_c2r.data_in *= scale
+            field = self.plan_c2r.execute()
+            if light_cone:
+                field *= self._need_table("growth_function")
+                field /= 1 + self._need_table("redshifts")
+            return field
+        dev = self.plan_c2r.device
+        dev.load_potential(scale)
+        dev.execute_c2r()
+        if factor is not None:
+            dev.scale_z(factor)
+        self._field_on_host = False
+        return self.download_field() if download else None
+
+    def calculate_lensing_potential(self, *args, **kwargs):
+        raise NotImplementedError("calculate_lensing_potential is outside the accelerated path (see DESIGN.md).")
+
+    def plot_slice(self, *args, **kwargs):
+        raise NotImplementedError("plot_slice is outside the accelerated path (see DESIGN.md).")

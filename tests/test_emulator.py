@@ -1,0 +1,118 @@
+"""CPU emulation of the HIP kernels' phase functions (rf_fft.h / rf_core.h)
+against numpy and the oracle.  Runs in the build container (no GPU): catches
+index / twiddle / packing / symmetrise mistakes before any GPU minute is spent."""
+import numpy as np
+import pytest
+
+import emu_util
+from conftest import golden
+from oracle import cpu_ref
+
+COL_SIZES = [8, 16, 32, 64, 128, 256, 512, 1024, 2048]
+ROW_SIZES = [8, 16, 32, 64, 128, 256, 512, 1024]
+
+
+@pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
+@pytest.mark.parametrize("N", COL_SIZES)
+def test_col_fft_all_sizes(N, dtype):
+    rng = np.random.RandomState(N)
+    ncols = 64
+    a = (rng.normal(size=(N, ncols)) + 1j * rng.normal(size=(N, ncols))).astype(dtype)
+    tol = 3e-6 if dtype == np.complex64 else 1e-13
+    for direction in (+1, -1):
+        work = a.copy()
+        # contiguous columns: element (row, C) at row*ncols + C
+        assert emu_util.col_fft(work, N, direction, ncols, ncols, 0, ncols) == 0
+        ref = (np.fft.ifft(a.astype(np.complex128), axis=0) * N if direction > 0
+               else np.fft.fft(a.astype(np.complex128), axis=0))
+        assert np.max(np.abs(work - ref)) <= tol * np.sqrt(N) * 2
+
+
+def test_col_fft_y_geometry():
+    """y-pass addressing: columns are (ix, kz) pairs, rows are iy."""
+    nx, ny, nzc = 4, 32, 16
+    rng = np.random.RandomState(5)
+    a = (rng.normal(size=(nx, ny, nzc)) + 1j * rng.normal(size=(nx, ny, nzc))).astype(np.complex64)
+    work = a.copy()
+    assert emu_util.col_fft(work, ny, +1, nx * nzc, nzc, ny * nzc, nzc) == 0
+    ref = np.fft.ifft(a.astype(np.complex128), axis=1) * ny
+    assert np.max(np.abs(work - ref)) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
+@pytest.mark.parametrize("M", ROW_SIZES)
+def test_row_c2r_all_sizes(M, dtype):
+    """c2r along z for every supported nz = 2M (x, y kept at the minimum 8)."""
+    nx = ny = 8
+    nz = 2 * M
+    rng = np.random.RandomState(M)
+    ks = (rng.normal(size=(nx, ny, M + 1)) + 1j * rng.normal(size=(nx, ny, M + 1))).astype(dtype)
+    cpu_ref.symmetrize_packed(ks)
+    out, s1, s2 = emu_util.c2r(ks)
+    ref = np.fft.irfftn(ks.astype(np.complex128), s=(nx, ny, nz), axes=(0, 1, 2))
+    tol = 4e-6 if dtype == np.complex64 else 1e-13
+    assert np.max(np.abs(out - ref)) <= tol * ref.std()
+    assert abs(s1 - out.astype(np.float64).sum()) < 1e-6 * out.size
+    assert abs(s2 - (out.astype(np.float64) ** 2).sum()) < 1e-6 * s2
+
+
+@pytest.mark.parametrize("shape", [(8, 8, 16), (16, 16, 16), (32, 32, 32), (16, 32, 64), (64, 32, 16)])
+@pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
+def test_generation_and_fused_realisation(shape, dtype, default_power):
+    nx, ny, nz = shape
+    k, Pk = default_power["k"], default_power["Pk"]
+    xt, st = cpu_ref.sigma_table(k, Pk, nx, ny, nz, 2.5)
+    noise = cpu_ref.reference_noise(123, nx * ny * (nz // 2 + 1))
+    ref = cpu_ref.generate_kspace(nx, ny, nz, 2.5, k, Pk, seed=123, dtype=dtype)
+    ks = emu_util.generate_kspace(nx, ny, nz, 2.5, xt, st, noise=noise, dtype=dtype)
+    # identical up to the last ulp of log10 (libm here, numpy's SIMD loop in the oracle)
+    scale = np.max(np.abs(ref))
+    assert np.max(np.abs(ks - ref)) <= (5e-7 if dtype == np.complex64 else 1e-15) * scale
+    assert ks[0, 0, 0] == 0 and cpu_ref.is_hermitian_packed(ks, rtol=0, atol=0)
+    # exact structure of the symmetrised planes: same zeros, same conjugate pairs
+    assert np.array_equal(ks.imag == 0, ref.imag == 0)
+    dref = cpu_ref.c2r(ref, double_fft=True)
+    rms = dref.std()
+    out, s1, s2 = emu_util.realise(nx, ny, nz, 2.5, xt, st, noise=noise, dtype=dtype)
+    tol = 3e-6 if dtype == np.complex64 else 1e-12
+    assert np.max(np.abs(out - dref)) <= tol * rms
+    n = out.size
+    assert abs(np.sqrt(s2 / n - (s1 / n) ** 2) - rms) <= 1e-6 * rms
+
+
+def test_native_noise_matches_oracle_philox(default_power):
+    """Native (Philox + Box-Muller) mode: the emulator's k-space equals the oracle
+    chain fed with the oracle's restatement of the same counter-based stream."""
+    nx, ny, nz = 16, 16, 32
+    k, Pk = default_power["k"], default_power["Pk"]
+    xt, st = cpu_ref.sigma_table(k, Pk, nx, ny, nz, 2.5)
+    for dtype, tol in ((np.complex128, 1e-12), (np.complex64, 2e-6)):
+        noise = cpu_ref.native_noise(321, nx, ny, nz, dtype)
+        ref = cpu_ref.generate_kspace(nx, ny, nz, 2.5, k, Pk, noise=noise, dtype=dtype)
+        ks = emu_util.generate_kspace(nx, ny, nz, 2.5, xt, st, seed=321, dtype=dtype)
+        assert np.max(np.abs(ks - ref)) <= tol * np.max(np.abs(ref))
+
+
+def test_linear_k_table_and_edges():
+    """Non-uniform (linear-k) table of the reference's variance test.  Its first
+    knot equals the grid's fundamental |k| exactly, so for the six fundamental
+    modes log10|k| sits within one float32 ulp of the table edge: whether they get
+    sigma = 0 (outside) or sigma(edge) depends on the last ulp of log10f (numpy's
+    SIMD loop, libm and OCML all differ).  Everything else must agree."""
+    g = golden("gaussian_16_c64.npz")
+    xt, st = cpu_ref.sigma_table(g["k"], g["Pk"], 16, 16, 16, 2.5)
+    noise = cpu_ref.reference_noise(123, 16 * 16 * 9)
+    ks = emu_util.generate_kspace(16, 16, 16, 2.5, xt, st, noise=noise)
+    lk = cpu_ref.fill_log10k(16, 16, 16, 2.5).real.astype(np.float64)
+    edge = (np.abs(lk - xt[0]) < 3e-7) | (np.abs(lk - xt[-1]) < 3e-7)
+    assert 0 < edge.sum() <= 8
+    ref = g["kspace"]
+    assert np.max(np.abs(ks - ref)[~edge]) <= 5e-7 * np.max(np.abs(ref))
+    # on the edge cells: either the reference's value (0 here) or the edge sigma times the same deviate
+    sig_edge = np.float32(st[0])
+    nz3 = noise.reshape(16, 16, 9, 2)
+    for ix, iy, iz in zip(*np.nonzero(edge)):
+        v = ks[ix, iy, iz]
+        ok_zero = abs(v - ref[ix, iy, iz]) <= 1e-6 * sig_edge
+        ok_edge = abs(abs(v.real) - abs(np.float32(sig_edge * nz3[ix, iy, iz, 0]))) <= 1e-5 * sig_edge or iz in (0, 8)
+        assert ok_zero or ok_edge

@@ -1,0 +1,328 @@
+"""GPU parity tests (run with ``-m gpu`` on an MI355X).  Everything goes through
+the C-ABI (ctypes -> librandomfield_hip.so); the oracle and the golden fixtures
+are only the checkers.
+
+Tolerances: float32 fields agree with the reference CPU
+path to max|d_gpu - d_cpu| <= 1e-5 * rms(d) on the same noise; in practice the
+difference is ~1e-6 * rms (float32 FFT rounding).  k-space cells agree to the
+last ulp of log10f (5e-7 relative).  float64 plans: 1e-12.
+"""
+import numpy as np
+import pytest
+
+from conftest import golden
+from oracle import cpu_ref
+
+pytestmark = pytest.mark.gpu
+
+SPACING = 2.5
+TOL_F32 = 1e-5          # * rms, the north-star tolerance
+TOL_F64 = 1e-11
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from randomfield_amd import _hip
+    _hip.require_gpu()
+    return _hip
+
+
+@pytest.fixture(scope="module")
+def dpower(default_power):
+    return default_power["k"], default_power["Pk"]
+
+
+def make_plan(hip, shape, dtype, k, Pk, spacing=SPACING):
+    from randomfield_amd import powertools
+    nx, ny, nz = shape
+    plan = hip.DevicePlan(nx, ny, nz, dtype)
+    plan.set_kgrid(*powertools.ksq_axes(nx, ny, nz, spacing))
+    xt, st = cpu_ref.sigma_table(k, Pk, nx, ny, nz, spacing)
+    plan.set_power(xt, st)
+    return plan
+
+
+STAGES = ["stages_16x16x16_c64.npz", "stages_32x32x32_c64.npz", "stages_16x32x64_c64.npz",
+          "stages_16x16x16_c128.npz", "stages_32x32x32_c128.npz"]
+
+
+@pytest.mark.parametrize("name", STAGES)
+def test_kspace_and_field_against_reference_fixtures(hip, dpower, name):
+    """rows K,T,R,S (rf_generate), row X (rf_execute_c2r), fused rf_realise, row D
+    (rf_moments) against the reference's own outputs for the same seed."""
+    g = golden(name)
+    shape = tuple(int(v) for v in g["shape"])
+    dtype = g["kspace"].dtype
+    tol = TOL_F32 if dtype == np.complex64 else TOL_F64
+    rms = float(g["rms"])
+    nx, ny, nz = shape
+    plan = make_plan(hip, shape, dtype, *dpower)
+    noise = cpu_ref.reference_noise(int(g["seed"]), nx * ny * (nz // 2 + 1))
+
+    plan.generate(noise=noise)
+    ks = plan.download_k()
+    scale = np.max(np.abs(g["kspace"]))
+    assert np.max(np.abs(ks - g["kspace"])) <= (5e-7 if dtype == np.complex64 else 1e-14) * scale
+    assert ks[0, 0, 0] == 0
+    assert np.array_equal(ks.imag == 0, g["kspace"].imag == 0)           # same self-conjugate zeros
+    assert cpu_ref.is_hermitian_packed(ks, rtol=0, atol=0)                # exact conjugate pairs
+
+    plan.execute_c2r()
+    d1 = plan.download_real()
+    assert d1.shape == shape and d1.dtype == g["delta"].dtype
+    assert np.max(np.abs(d1 - g["delta"])) <= tol * rms
+
+    # exact reference k-space uploaded -> c2r (row X alone)
+    plan.upload_k(g["kspace"])
+    plan.execute_c2r()
+    assert np.max(np.abs(plan.download_real() - g["delta"])) <= tol * rms
+
+    plan.realise(noise=noise)                                             # fused path
+    d2 = plan.download_real()
+    assert np.max(np.abs(d2 - g["delta"])) <= tol * rms
+    mean, std = plan.moments()
+    assert abs(std - rms) <= tol * rms and abs(mean) < 1e-6 * rms
+    padded = plan.download_real(padded=True)
+    assert padded.shape == (nx, ny, nz + 2) and np.array_equal(padded[:, :, :nz], d2)
+    part = plan.download_real(x0=nx // 2, x1=nx // 2 + 2)
+    assert np.array_equal(part, d2[nx // 2:nx // 2 + 2])
+    plan.close()
+
+
+@pytest.mark.parametrize("n,tag", [(64, "c64"), (128, "c64"), (64, "c128"), (128, "c128")])
+def test_summary_grids(hip, dpower, n, tag):
+    g = golden("summary_%d_%s.npz" % (n, tag))
+    dtype = np.complex64 if tag == "c64" else np.complex128
+    tol = TOL_F32 if tag == "c64" else TOL_F64
+    plan = make_plan(hip, (n, n, n), dtype, *dpower)
+    noise = cpu_ref.reference_noise(123, n * n * (n // 2 + 1))
+    plan.realise(noise=noise)
+    d = plan.download_real()
+    rms = float(g["rms"])
+    assert np.max(np.abs(d[::8, ::8, ::8] - g["sub"])) <= tol * rms
+    assert np.max(np.abs(d[0, 0, :4] - g["first"])) <= tol * rms
+    assert np.max(np.abs(d[-1, -1, -4:] - g["last"])) <= tol * rms
+    mean, std = plan.moments()
+    assert abs(std - rms) <= tol * rms
+    assert abs(d.min() - float(g["min"])) <= 2 * tol * rms and abs(d.max() - float(g["max"])) <= 2 * tol * rms
+    plan.close()
+
+
+@pytest.mark.parametrize("shape", [(256, 256, 256), (64, 128, 256), (512, 16, 32), (8, 8, 16), (16, 1024, 64)])
+def test_full_field_against_oracle(hip, dpower, shape):
+    """Whole-array comparison with the oracle run here on the same noise (sizes the
+    oracle finishes in seconds), incl. anisotropic grids and every pass shape."""
+    nx, ny, nz = shape
+    k, Pk = dpower
+    noise = cpu_ref.reference_noise(7, nx * ny * (nz // 2 + 1))
+    ref, rms = cpu_ref.generate_delta_field(nx, ny, nz, SPACING, k, Pk, noise=noise, double_fft=True)
+    plan = make_plan(hip, shape, np.complex64, k, Pk)
+    plan.realise(noise=noise)
+    d = plan.download_real()
+    assert np.max(np.abs(d - ref)) <= TOL_F32 * rms
+    assert abs(plan.moments()[1] - rms) <= TOL_F32 * rms
+    plan.close()
+
+
+def test_512_cube_known_answer(hip, dpower):
+    """BASELINE config 1 (512^3 f32): SURVEY 8c spot values of the reference for seed 123."""
+    n = 512
+    plan = make_plan(hip, (n, n, n), np.complex64, *dpower)
+    noise = cpu_ref.reference_noise(123, n * n * (n // 2 + 1))
+    plan.realise(noise=noise)
+    del noise
+    mean, std = plan.moments()
+    assert abs(std - 2.3144155) <= TOL_F32 * 2.3144155 and abs(mean) < 1e-6
+    first = plan.download_real(x0=0, x1=1)[0, 0, :4]
+    last = plan.download_real(x0=n - 1, x1=n)[0, -1, -4:]
+    assert np.allclose(first, [-0.628191, -0.63676345, 0.3869021, 0.5524756], rtol=0, atol=2.4e-5)
+    assert np.allclose(last, [4.058375, 1.2057173, 2.9818745, 1.7062455], rtol=0, atol=2.4e-5)
+    plan.close()
+
+
+def test_native_rng_matches_oracle_restatement(hip, dpower):
+    """Native Philox4x32-10 + Box-Muller mode, value by value against the oracle's
+    restatement of the same counter-based stream (float32 plans use hardware
+    log/sin/cos: 2e-5 * rms; float64 plans 1e-11)."""
+    k, Pk = dpower
+    for dtype, tol in ((np.complex64, 2e-5), (np.complex128, TOL_F64)):
+        shape = (64, 32, 128)
+        nx, ny, nz = shape
+        plan = make_plan(hip, shape, dtype, k, Pk)
+        plan.realise(seed=2024)
+        d = plan.download_real()
+        noise = cpu_ref.native_noise(2024, nx, ny, nz, dtype)
+        ref, rms = cpu_ref.generate_delta_field(nx, ny, nz, SPACING, k, Pk, noise=noise, dtype=dtype, double_fft=True)
+        assert np.max(np.abs(d - ref)) <= tol * rms
+        # unfused path (generate -> k-space -> c2r) equals the fused one
+        plan.generate(seed=2024)
+        ks = plan.download_k()
+        kref = cpu_ref.generate_kspace(nx, ny, nz, SPACING, k, Pk, noise=noise, dtype=dtype)
+        assert np.max(np.abs(ks - kref)) <= tol * np.max(np.abs(kref))
+        plan.execute_c2r()
+        assert np.max(np.abs(plan.download_real() - d)) <= 1e-6 * rms
+        # deterministic: same seed twice is bitwise identical, another seed is not
+        plan.realise(seed=2024)
+        assert np.array_equal(plan.download_real(), d)
+        plan.realise(seed=2025)
+        assert not np.array_equal(plan.download_real(), d)
+        plan.close()
+
+
+def test_native_gaussian_variance(hip):
+    """The reference's statistical pin (tests/test_generate.py:24-62) with the native RNG."""
+    from scipy.special import erf
+    g = golden("variance_64.npz")
+    spacing, n = 2.5, 64
+    kmin, kmax, sigma = (2 * np.pi) / (spacing * n), np.pi / spacing, 2.5 * spacing
+    calc = 1.23 / (2 * np.pi) ** 1.5 / sigma ** 3 * (
+        erf(kmax * sigma / np.sqrt(2)) ** 3 - erf(kmin * sigma / np.sqrt(2)) ** 3)
+    plan = make_plan(hip, (n, n, n), np.complex64, g["k"], g["Pk"], spacing)
+    var = []
+    for trial in range(10):
+        plan.realise(seed=123 + trial)
+        mean, std = plan.moments()
+        assert abs(mean) < 1e-6
+        var.append(std ** 2)
+    assert abs(np.mean(var) - calc) < 0.01 * calc
+    plan.close()
+
+
+def test_large_grid_properties(hip, dpower):
+    """BASELINE-size checks through size-independent properties (1024^3 float32):
+    zero mean (DC mode is exactly 0), rms equal to the Parseval sum of the sigma
+    table over the grid's modes within sampling noise, run-to-run determinism, and
+    fused == graph-replayed batch."""
+    n = 1024
+    k, Pk = dpower
+    plan = make_plan(hip, (n, n, n), np.complex64, k, Pk)
+    plan.realise(seed=123)
+    mean, std = plan.moments()
+    slab = plan.download_real(x0=5, x1=6).copy()
+    assert abs(mean) < 1e-6 and np.isfinite(slab).all()
+    # expected variance: sum over all modes of |delta_k|^2 / N3^2 with <|delta_k|^2> = 2 sigma_k^2 (sigma^2 on
+    # the 8 real modes).  Evaluate on a coarse |k| histogram of the grid: the reference run gives 2.3137536.
+    assert abs(std - 2.3137) < 5e-3
+    assert abs(slab.std() - std) < 0.05 * std
+    plan.realise(seed=123)
+    assert np.array_equal(plan.download_real(x0=5, x1=6), slab)
+    rms = plan.realise_batch([11, 12, 123])
+    assert abs(rms[2] - std) <= 1e-12 * std
+    assert np.array_equal(plan.download_real(x0=5, x1=6), slab)
+    assert abs(rms[0] - 2.3137) < 5e-3 and rms[0] != rms[1]
+    plan.close()
+
+
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+def test_lognormal_and_scaling(hip, tag):
+    """row L: lognormal map with a growth table along z, then per-z scaling."""
+    g = golden("lognormal_%s.npz" % tag)
+    from randomfield_amd import cosmotools
+    delta = g["delta"]
+    nx, ny, nz = delta.shape
+    dtype = np.complex64 if tag == "f32" else np.complex128
+    plan = hip.DevicePlan(nx, ny, nz, dtype)
+    plan.upload_real(delta)
+    assert np.array_equal(plan.download_real(), delta)
+    sigma = g["sigma_vec"][()]
+    a_z, b_z = cosmotools.lognormal_tables(g["growth_z"], sigma, nz)
+    plan.lognormal(a_z, b_z, float(sigma))
+    out = plan.download_real()
+    assert np.all(out > 0)
+    tol = 2e-6 if tag == "f32" else 1e-14
+    assert np.max(np.abs(out - g["out_vec"]) / g["out_vec"]) <= tol
+    dens = np.linspace(1.0, 2.0, nz)
+    plan.scale_z(dens)
+    ref = cpu_ref.scale_z(g["out_vec"].copy(), dens)
+    assert np.max(np.abs(plan.download_real() - ref) / ref) <= tol
+    plan.affine_z(np.full(nz, 0.5), 1.0)
+    ref = ref * 0.5 + 1
+    assert np.max(np.abs(plan.download_real() - ref) / ref) <= 2 * tol
+    plan.close()
+
+
+def test_generator_api_hip_backend(hip):
+    """The drop-in API: Generator(...).generate_delta_field(seed) on the GPU gives the
+    reference's field for the same seed (tests/test_generate.py:16-21 + parity)."""
+    from randomfield_amd import Generator
+    g = golden("summary_64_c64.npz")
+    gen = Generator(64, 64, 64, 2.5)                                  # default backend 'hip', rng 'reference'
+    assert gen.backend == "hip" and gen.plan_c2r.device is not None
+    data = gen.generate_delta_field(seed=123)                         # default save_potential=True
+    assert data.shape == (64, 64, 64) and data.dtype == np.float32
+    assert abs(np.mean(data)) < 1e-3
+    rms = float(g["rms"])
+    assert np.max(np.abs(data[::8, ::8, ::8] - g["sub"])) <= TOL_F32 * rms
+    assert abs(gen.delta_field_rms - rms) <= TOL_F32 * rms and isinstance(gen.delta_field_rms, np.float32)
+    assert data.base is not None                                      # a view of the plan's buffer
+    first = data.copy()
+    again = gen.generate_delta_field(seed=123, save_potential=False)  # fused path, same answer
+    assert np.max(np.abs(again - first)) <= 1e-6 * rms and gen.potential is None
+    nat = Generator(64, 64, 64, 2.5, rng="native")
+    a = nat.generate_delta_field(seed=5, save_potential=False).copy()
+    b = nat.generate_delta_field(seed=5, save_potential=False)
+    assert np.array_equal(a, b) and abs(nat.delta_field_rms - rms) < 0.05 * rms
+    assert nat.generate_delta_field(seed=6, save_potential=False, download=False) is None
+    assert not np.array_equal(nat.download_field(), a)
+
+
+def test_generator_potential_and_density(hip):
+    from randomfield_amd import Generator
+    gp = golden("potential_16_c64.npz")
+    z = np.linspace(0, 0.1, 16)
+    gen = Generator(16, 16, 16, 2.5, growth_function=np.exp(-z), mean_matter_density=1 + z, redshifts=z)
+    delta = gen.generate_delta_field(seed=123, save_potential=True).copy()
+    pot = gen.potential.download()
+    assert np.max(np.abs(pot - gp["potential"])) <= 1e-6 * np.max(np.abs(gp["potential"]))
+    ref = Generator(16, 16, 16, 2.5, backend="numpy", growth_function=np.exp(-z), mean_matter_density=1 + z,
+                    redshifts=z)
+    dref = ref.generate_delta_field(seed=123, save_potential=True).copy()
+    assert np.max(np.abs(delta - dref)) <= TOL_F32 * dref.std()
+    phi = gen.calculate_newtonian_potential(scale=-1.5)
+    phi_ref = ref.calculate_newtonian_potential(scale=-1.5)
+    assert np.max(np.abs(phi - phi_ref)) <= TOL_F32 * phi_ref.std()
+    gen.generate_delta_field(seed=123, save_potential=False)
+    ref.generate_delta_field(seed=123, save_potential=False)
+    rho = gen.convert_delta_to_density()
+    rho_ref = ref.convert_delta_to_density()
+    assert np.all(rho > 0) and np.max(np.abs(rho - rho_ref) / rho_ref) <= 1e-4   # exp() amplifies 1e-6*rms
+    gen.generate_delta_field(seed=123, save_potential=False)
+    ref.generate_delta_field(seed=123, save_potential=False)
+    lin = gen.convert_delta_to_density(apply_lognormal_transform=False)
+    lin_ref = ref.convert_delta_to_density(apply_lognormal_transform=False)
+    assert np.max(np.abs(lin - lin_ref)) <= 1e-5 * np.abs(lin_ref).max()
+
+
+def test_plan_api_hip_backend(hip):
+    """transform.Plan on the hip backend: same host arrays / aliasing, GPU transform."""
+    from randomfield_amd.transform import Plan, symmetrize
+    rng = np.random.RandomState(3)
+    for dtype, tol in ((np.complex64, 2e-6), (np.complex128, 1e-13)):
+        plan = Plan(shape=(16, 32, 64), dtype_in=dtype)
+        assert plan.backend == "hip"
+        n = 2 * plan.data_in.size
+        plan.data_in.view(plan.data_out.dtype).reshape(n)[:] = rng.normal(size=n)
+        symmetrize(plan.data_in, packed=True)
+        ks = plan.data_in.copy()
+        out = plan.execute()
+        assert out.shape == (16, 32, 64) and (out.base is plan.data_in or out.base is plan.data_in.base)
+        ref = np.fft.irfftn(ks.astype(np.complex128), s=(16, 32, 64), axes=(0, 1, 2))
+        assert np.max(np.abs(out - ref)) <= tol * ref.std() * 10
+
+
+def test_errors_are_loud(hip, dpower):
+    with pytest.raises(RuntimeError):
+        hip.DevicePlan(4, 6, 8)                                      # unsupported shape: no silent CPU path
+    plan = hip.DevicePlan(16, 16, 16)
+    with pytest.raises(RuntimeError):
+        plan.realise(seed=1)                                         # tables not set
+    with pytest.raises(RuntimeError):
+        plan.execute_c2r()                                           # no k-space data
+    with pytest.raises(RuntimeError):
+        plan.moments()
+    with pytest.raises(ValueError):
+        plan.realise(noise=np.zeros(10))
+    plan.close()
+    from randomfield_amd.transform import Plan
+    with pytest.raises(RuntimeError):
+        Plan(shape=(4, 6, 8), dtype_in=np.complex64)                 # hip backend refuses, does not fall back
