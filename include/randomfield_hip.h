@@ -46,6 +46,10 @@ int rf_shape_supported(int nx, int ny, int nz);
 int rf_plan_create(rf_plan** plan, int nx, int ny, int nz, int dtype, int device, int nranks, int rank);
 int rf_plan_destroy(rf_plan* plan);
 int rf_plan_nbytes(rf_plan* plan, size_t* nbytes);          /* transform.py:221,226 nbytes_allocated */
+/* plan options.  RF_FLAG_EXACT_GENERATION = 1 makes native-noise float32 realisations use the
+ * reference's exact float64 rounding chain for |k| and sigma(k) instead of the fast float32 one. */
+enum { RF_FLAG_EXACT_GENERATION = 1 };
+int rf_plan_set_flag(rf_plan* plan, int flag, int value);
 /* run on a caller-owned HIP stream (hipStream_t passed as void*); NULL restores the plan's own stream */
 int rf_plan_set_stream(rf_plan* plan, void* hip_stream);
 

@@ -34,6 +34,7 @@ SIGNATURES = {
     "rf_plan_destroy": (ctypes.c_int, [ctypes.c_void_p]),
     "rf_plan_nbytes": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t)]),
     "rf_plan_set_stream": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "rf_plan_set_flag": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
     "rf_set_kgrid": (ctypes.c_int, [ctypes.c_void_p, _c_dp, _c_dp, _c_dp]),
     "rf_set_power": (ctypes.c_int, [ctypes.c_void_p, _c_dp, _c_dp, ctypes.c_int]),
     "rf_generate": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, _c_dp]),
@@ -156,6 +157,10 @@ class DevicePlan(object):
         n = ctypes.c_size_t(0)
         check(self._lib.rf_plan_nbytes(self._h, ctypes.byref(n)), "rf_plan_nbytes")
         return n.value
+
+    def set_exact_generation(self, on=True):
+        """Native-noise float32 realisations with the reference's exact float64 chain (slower)."""
+        check(self._lib.rf_plan_set_flag(self._h, 1, int(bool(on))), "rf_plan_set_flag")
 
     def set_stream(self, hip_stream):
         check(self._lib.rf_plan_set_stream(self._h, ctypes.c_void_p(hip_stream or 0)), "rf_plan_set_stream")

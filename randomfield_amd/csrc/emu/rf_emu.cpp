@@ -115,9 +115,40 @@ int c2r_impl(int nx, int ny, int nz, const GenHost* gen, const cplx<T>* kspace, 
   return dispatch_row_c2r<T>((int)nzc, W, (long long)nx * ny, 1.0 / ((double)nx * ny * nz), s1, s2);
 }
 
+int realise_fast_impl(int nx, int ny, int nz, const GenHost& h, uint64_t seed, double spacing_k_lo, double spacing_k_hi,
+                      cplx<float>* W, double* s1, double* s2) {
+  const long long nzc = nz / 2;
+  std::vector<float> kx2(nx), ky2(ny), kz2(nzc + 1);
+  for (int i = 0; i < nx; ++i) kx2[i] = (float)h.gp.kx2[i];
+  for (int i = 0; i < ny; ++i) ky2[i] = (float)h.gp.ky2[i];
+  for (int i = 0; i <= nzc; ++i) kz2[i] = (float)h.gp.kz2[i];
+  std::vector<FastRec> rec;
+  FastGenColIO io;
+  io.base = W; io.g = ColGeom{(long long)ny * nzc, 0, (long long)ny * nzc}; io.kz0 = 0; io.nzl = (int)nzc;
+  FastGenParams& f = io.gp;
+  if (!build_fast_records(h.tab, spacing_k_lo, spacing_k_hi, rec, f.x0, f.inv_dx, f.xmin, f.xmax)) return -3;
+  f.nx = nx; f.ny = ny; f.nz = nz; f.kx2 = kx2.data(); f.ky2 = ky2.data(); f.kz2 = kz2.data();
+  f.rec = rec.data(); f.nbins = (int)rec.size(); f.seed = seed; f.seed_dev = nullptr;
+  int rc = dispatch_col<float, +1>(nx, io, (long long)ny * nzc);
+  if (rc) return rc;
+  PlainColIO<float> pio; pio.base = W; pio.g = ColGeom{nzc, (long long)ny * nzc, nzc};
+  rc = dispatch_col<float, +1>(ny, pio, (long long)nx * nzc);
+  if (rc) return rc;
+  return dispatch_row_c2r<float>((int)nzc, W, (long long)nx * ny, 1.0 / ((double)nx * ny * nz), s1, s2);
+}
+
 }  // namespace
 
 extern "C" {
+
+// fused realisation with the fast float32 native generation; [xlo, xhi] = log10 k range of the grid (padded)
+int emu_realise_fast(int nx, int ny, int nz, const double* kx2, const double* ky2, const double* kz2,
+                     const double* log10k, const double* sigma, int nt, uint64_t seed, double xlo, double xhi,
+                     void* W, double* s1, double* s2) {
+  GenHost h;
+  fill_gen(h, nx, ny, nz, kx2, ky2, kz2, log10k, sigma, nt, 0, seed, nullptr);
+  return realise_fast_impl(nx, ny, nz, h, seed, xlo, xhi, (cplx<float>*)W, s1, s2);
+}
 
 // k-space after symmetrise in the API layout [nx][ny][nz/2+1] (rows K,T,R,S)
 int emu_generate_kspace(int f64, int nx, int ny, int nz, const double* kx2, const double* ky2, const double* kz2,

@@ -68,6 +68,14 @@ struct rf_plan {
   int nt = 0, nbins = 0;
   double x0 = 0, inv_dx = 0;
   bool have_kgrid = false, have_power = false;
+  // fast float32 native generation: float copies of the k^2 tables + per-bin sigma records
+  float *kx2f = nullptr, *ky2f = nullptr, *kz2f = nullptr;
+  FastRec* frec = nullptr;
+  int fnbins = 0;
+  float fx0 = 0, finv_dx = 0, fxmin = 0, fxmax = 0;
+  bool have_fast = false, exact_gen = false;
+  std::vector<double> h_kx2, h_ky2, h_kz2;   // host copies (k range of the grid for the fast records)
+  SigmaTableHost h_tab;
   double* noise = nullptr;
   size_t noise_cap = 0;
   double* partials = nullptr;
@@ -118,13 +126,50 @@ int upload_noise(rf_plan* p, int mode, const double* noise_host) {
   return 0;
 }
 
+FastGenParams make_fast(rf_plan* p, uint64_t seed, bool seed_from_dev) {
+  FastGenParams f;
+  f.nx = p->nx; f.ny = p->ny; f.nz = p->nz;
+  f.kx2 = p->kx2f; f.ky2 = p->ky2f; f.kz2 = p->kz2f;
+  f.rec = p->frec; f.nbins = p->fnbins; f.x0 = p->fx0; f.inv_dx = p->finv_dx; f.xmin = p->fxmin; f.xmax = p->fxmax;
+  f.seed = seed; f.seed_dev = seed_from_dev ? p->seed_cur : nullptr;
+  return f;
+}
+
+// (re)build the fast-path records once both the k grid and the power table are known
+int build_fast(rf_plan* p) {
+  p->have_fast = false;
+  if (p->f64 || !p->have_kgrid || !p->have_power) return 0;
+  double kmax2 = 0, kmin2 = 1e300;
+  auto scan = [&](const std::vector<double>& a) { for (double v : a) if (v > 0 && v < kmin2) kmin2 = v; };
+  scan(p->h_kx2); scan(p->h_ky2); scan(p->h_kz2);
+  auto mx = [](const std::vector<double>& a) { double m = 0; for (double v : a) m = v > m ? v : m; return m; };
+  kmax2 = mx(p->h_kx2) + mx(p->h_ky2) + mx(p->h_kz2);
+  if (!(kmin2 < 1e300) || !(kmax2 > 0)) return 0;
+  std::vector<FastRec> rec;
+  if (!build_fast_records(p->h_tab, 0.5 * std::log10(kmin2) - 0.01, 0.5 * std::log10(kmax2) + 0.01, rec, p->fx0,
+                          p->finv_dx, p->fxmin, p->fxmax))
+    return 0;   // knots too dense for the per-bin records: the exact kernel is used instead
+  if (p->frec) RF_HIP(hipFree(p->frec));
+  p->frec = nullptr;
+  RF_HIP(hipMalloc((void**)&p->frec, rec.size() * sizeof(FastRec)));
+  RF_HIP(hipMemcpy(p->frec, rec.data(), rec.size() * sizeof(FastRec), hipMemcpyHostToDevice));
+  p->fnbins = (int)rec.size();
+  p->have_fast = true;
+  return 0;
+}
+
 // the three FFT passes + moments on the plan's stream; generation or API k-space feeds the x pass
 int queue_c2r(rf_plan* p, const GenParams& gp, const void* kspace, bool graph_slot) {
   const long long nzc = p->nzc;
   const ColGeom gx{(long long)p->ny * nzc, 0, (long long)p->ny * nzc};
   const ColGeom gy{nzc, (long long)p->ny * nzc, nzc};
   if (p->timed) RF_HIP(hipEventRecord(p->ev[0], p->stream));
-  RF_HIP(launch_col_gen(p->f64, p->nx, p->W, gx, (long long)p->ny * nzc, gp, kspace, 0, (int)nzc, p->tw_x, p->stream));
+  const bool fast = !kspace && gp.noise_mode == NOISE_PHILOX && p->have_fast && !p->exact_gen;
+  if (fast)
+    RF_HIP(launch_col_fastgen(p->nx, p->W, gx, (long long)p->ny * nzc, make_fast(p, gp.seed, gp.seed_dev != nullptr), 0,
+                              (int)nzc, p->tw_x, p->stream));
+  else
+    RF_HIP(launch_col_gen(p->f64, p->nx, p->W, gx, (long long)p->ny * nzc, gp, kspace, 0, (int)nzc, p->tw_x, p->stream));
   if (p->timed) RF_HIP(hipEventRecord(p->ev[1], p->stream));
   RF_HIP(launch_col_plain(p->f64, p->ny, +1, p->W, gy, (long long)p->nx * nzc, p->tw_y, p->stream));
   if (p->timed) RF_HIP(hipEventRecord(p->ev[2], p->stream));
@@ -221,6 +266,9 @@ int rf_plan_create(rf_plan** out, int nx, int ny, int nz, int dtype, int device,
       (e = hipMalloc((void**)&p->kx2, nx * sizeof(double))) != hipSuccess ||
       (e = hipMalloc((void**)&p->ky2, ny * sizeof(double))) != hipSuccess ||
       (e = hipMalloc((void**)&p->kz2, (p->nzc + 1) * sizeof(double))) != hipSuccess ||
+      (e = hipMalloc((void**)&p->kx2f, nx * sizeof(float))) != hipSuccess ||
+      (e = hipMalloc((void**)&p->ky2f, ny * sizeof(float))) != hipSuccess ||
+      (e = hipMalloc((void**)&p->kz2f, (p->nzc + 1) * sizeof(float))) != hipSuccess ||
       (e = hipMalloc((void**)&p->ztab, 2 * nz * sizeof(double))) != hipSuccess)
     return cleanup(fail(2, std::string("hipMalloc workspace: ") + hipGetErrorString(e)));
   for (auto& ev : p->ev)
@@ -229,7 +277,9 @@ int rf_plan_create(rf_plan** out, int nx, int ny, int nz, int dtype, int device,
     GenParams gp0; memset(&gp0, 0, sizeof(gp0)); gp0.nx = nx; gp0.ny = ny; gp0.nz = nz;
     const long long nzc = p->nzc;
     const ColGeom gx{(long long)ny * nzc, 0, (long long)ny * nzc}, gy{nzc, (long long)ny * nzc, nzc};
+    FastGenParams fp0; memset(&fp0, 0, sizeof(fp0)); fp0.nx = nx; fp0.ny = ny; fp0.nz = nz;
     if ((e = launch_col_gen(dtype, nx, p->W, gx, (long long)ny * nzc, gp0, nullptr, 0, (int)nzc, p->tw_x, p->stream, true)) != hipSuccess ||
+        (!dtype && (e = launch_col_fastgen(nx, p->W, gx, (long long)ny * nzc, fp0, 0, (int)nzc, p->tw_x, p->stream, true)) != hipSuccess) ||
         (e = launch_col_plain(dtype, ny, +1, p->W, gy, (long long)nx * nzc, p->tw_y, p->stream, true)) != hipSuccess ||
         (e = launch_row_c2r(dtype, (int)nzc, p->W, (long long)nx * ny, 1.0, p->tw_z, p->partials, p->stream, true)) != hipSuccess)
       return cleanup(fail(2, std::string("kernel preparation: ") + hipGetErrorString(e)));
@@ -245,7 +295,8 @@ int rf_plan_destroy(rf_plan* p) {
   if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
   if (p->graph) (void)hipGraphDestroy(p->graph);
   void* bufs[] = {p->W, p->K, p->P, p->tw_x, p->tw_y, p->tw_z, p->kx2, p->ky2, p->kz2, p->xt, p->st, p->sl, p->bin,
-                  p->noise, p->partials, p->stats, p->seed_cur, p->seeds_dev, p->counter, p->ztab};
+                  p->noise, p->partials, p->stats, p->seed_cur, p->seeds_dev, p->counter, p->ztab, p->kx2f, p->ky2f,
+                  p->kz2f, p->frec};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   for (auto& ev : p->ev)
@@ -258,6 +309,16 @@ int rf_plan_destroy(rf_plan* p) {
 int rf_plan_nbytes(rf_plan* p, size_t* nbytes) {
   RF_REQUIRE(p && nbytes, "null argument");
   *nbytes = p->w_bytes + (p->K ? p->k_bytes : 0) + (p->P ? p->k_bytes : 0);
+  return 0;
+}
+
+int rf_plan_set_flag(rf_plan* p, int flag, int value) {
+  RF_REQUIRE(p, "null plan");
+  RF_REQUIRE(flag == RF_FLAG_EXACT_GENERATION, "unknown flag");
+  RF_HIP(hipStreamSynchronize(p->stream));
+  p->exact_gen = value != 0;
+  if (p->graph_exec) { (void)hipGraphExecDestroy(p->graph_exec); p->graph_exec = nullptr; }
+  if (p->graph) { (void)hipGraphDestroy(p->graph); p->graph = nullptr; }
   return 0;
 }
 
@@ -277,8 +338,18 @@ int rf_set_kgrid(rf_plan* p, const double* kx2, const double* ky2, const double*
   RF_HIP(hipMemcpyAsync(p->ky2, ky2, p->ny * sizeof(double), hipMemcpyHostToDevice, p->stream));
   RF_HIP(hipMemcpyAsync(p->kz2, kz2, (p->nzc + 1) * sizeof(double), hipMemcpyHostToDevice, p->stream));
   RF_HIP(hipStreamSynchronize(p->stream));
+  p->h_kx2.assign(kx2, kx2 + p->nx); p->h_ky2.assign(ky2, ky2 + p->ny); p->h_kz2.assign(kz2, kz2 + p->nzc + 1);
+  std::vector<float> f;
+  auto up = [&](float* dst, const double* src, int n) {
+    f.resize(n);
+    for (int i = 0; i < n; ++i) f[i] = (float)src[i];
+    return hipMemcpy(dst, f.data(), n * sizeof(float), hipMemcpyHostToDevice);
+  };
+  RF_HIP(up(p->kx2f, kx2, p->nx));
+  RF_HIP(up(p->ky2f, ky2, p->ny));
+  RF_HIP(up(p->kz2f, kz2, p->nzc + 1));
   p->have_kgrid = true;
-  return 0;
+  return build_fast(p);
 }
 
 int rf_set_power(rf_plan* p, const double* log10k, const double* sigma, int n) {
@@ -302,7 +373,8 @@ int rf_set_power(rf_plan* p, const double* log10k, const double* sigma, int n) {
   RF_HIP(hipMemcpy(p->bin, t.bin.data(), t.bin.size() * sizeof(int), hipMemcpyHostToDevice));
   p->nt = n; p->nbins = (int)t.bin.size(); p->x0 = t.x0; p->inv_dx = t.inv_dx;
   p->have_power = true;
-  return 0;
+  p->h_tab = t;
+  return build_fast(p);
 }
 
 int rf_generate(rf_plan* p, uint64_t seed, int mode, const double* noise_host) {

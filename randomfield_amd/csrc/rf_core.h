@@ -328,6 +328,101 @@ RF_HD cplx<T> gen_packed(const GenParams& g, uint64_t seed, int ix, int iy, int 
   return a;
 }
 
+// ------------------------------------------------- fast native generation --
+// float32 plans with the native RNG do rows K,T,R,S entirely in float32: the
+// values are this repo's own definition (checked against the oracle's
+// restatement of the same stream to ~1e-6), so the reference's float64
+// rounding chain -- which only matters for same-noise parity -- is not needed.
+struct FastRec {          // 32 bytes per bin of the uniform acceleration grid in x = log10 k
+  float xs;               // knot inside the bin (+inf if none): piece A left of it, piece B right
+  float xa, sa, sla;      // piece A: sigma = sa + sla * (x - xa)
+  float xb, sb, slb;      // piece B
+  float pad;
+};
+
+struct FastGenParams {
+  int nx, ny, nz;
+  const float* kx2;       // float32 copies of the k^2 axis tables
+  const float* ky2;
+  const float* kz2;
+  const FastRec* rec;
+  int nbins;
+  float x0, inv_dx, xmin, xmax;
+  uint64_t seed;
+  const uint64_t* seed_dev;
+};
+
+RF_HD float fast_log2(float t) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_logf(t);   // v_log_f32
+#else
+  return log2f(t);
+#endif
+}
+
+RF_HD float fast_sigma(const FastGenParams& g, float t /* |k|^2 */) {
+  const float x = 0.15051499783199060f * fast_log2(t);   // 0.5 * log10(2) * log2(k^2) = log10 |k|
+  if (!(x >= g.xmin && x <= g.xmax)) return 0.0f;        // also t == 0 (-inf) and NaN
+  int b = (int)((x - g.x0) * g.inv_dx);
+  b = b < 0 ? 0 : (b >= g.nbins ? g.nbins - 1 : b);
+  const FastRec r = g.rec[b];
+  const bool left = x < r.xs;
+  const float xr = left ? r.xa : r.xb, sr = left ? r.sa : r.sb, sl = left ? r.sla : r.slb;
+  return sr + sl * (x - xr);
+}
+
+// two adjacent packed cells (ix, iy, kz) and (ix, iy, kz + 1), kz even: ONE Philox call
+RF_HD void fast_gen_pair(const FastGenParams& g, uint64_t seed, int ix, int iy, int kz, cplx<float>& c0,
+                         cplx<float>& c1) {
+  const int nzc = g.nz / 2;
+  const float kxy = g.kx2[ix] + g.ky2[iy];
+  const uint64_t col = (uint64_t)ix * (uint64_t)g.ny + (uint64_t)iy;
+  const uint64_t ci = col * (uint64_t)nzc + (uint64_t)kz;      // even
+  const PhiloxOut o = philox4x32_10(ci >> 1, 0, seed);
+  float g0, g1;
+  // odd cell kz + 1: always an ordinary (non-symmetrised) cell
+  {
+    const float s = fast_sigma(g, kxy + g.kz2[kz + 1]);
+    BoxMuller<float>::run(o.w[2], o.w[3], g0, g1);
+    c1 = mk<float>(s * g0, s * g1);
+  }
+  if (kz != 0) {
+    const float s = fast_sigma(g, kxy + g.kz2[kz]);
+    BoxMuller<float>::run(o.w[0], o.w[1], g0, g1);
+    c0 = mk<float>(s * g0, s * g1);
+    return;
+  }
+  // slot kz = 0: (plane kz=0) + i (plane kz=nz/2), each Hermitian-symmetrised (rf_core gen_cell rules)
+  const int role = sym_role(g.nx, g.ny, ix, iy);
+  int sx = ix, sy = iy;
+  if (role == RF_DEST) { sx = (g.nx - ix) % g.nx; sy = (g.ny - iy) % g.ny; }
+  const float kxy_s = g.kx2[sx] + g.ky2[sy];
+  const uint64_t scol = (uint64_t)sx * (uint64_t)g.ny + (uint64_t)sy;
+  cplx<float> a, n;
+  {
+    const float s = fast_sigma(g, kxy_s + g.kz2[0]);
+    if (role == RF_DEST) {
+      const PhiloxOut os = philox4x32_10((scol * (uint64_t)nzc) >> 1, 0, seed);
+      BoxMuller<float>::run(os.w[0], os.w[1], g0, g1);
+    } else {
+      BoxMuller<float>::run(o.w[0], o.w[1], g0, g1);
+    }
+    a = mk<float>(s * g0, s * g1);
+  }
+  {
+    const float s = fast_sigma(g, kxy_s + g.kz2[nzc]);
+    const uint64_t cn = (uint64_t)g.nx * (uint64_t)g.ny * (uint64_t)nzc + scol;
+    const PhiloxOut on = philox4x32_10(cn >> 1, 0, seed);
+    if (cn & 1) BoxMuller<float>::run(on.w[2], on.w[3], g0, g1);
+    else        BoxMuller<float>::run(on.w[0], on.w[1], g0, g1);
+    n = mk<float>(s * g0, s * g1);
+  }
+  if (role == RF_DEST) { a.y = -a.y; n.y = -n.y; }
+  if (role == RF_SELF) { a.y = 0.0f; n.y = 0.0f; }
+  if (ix == 0 && iy == 0) a.x = 0.0f;
+  c0 = mk<float>(a.x - n.y, a.y + n.x);
+}
+
 // ------------------------------------------------------- c2r / r2c untangle --
 // Inverse: Zc[k] = (X[k] + conj X[M-k]) + i t_k (X[k] - conj X[M-k]),  t_k = exp(+2 pi i k / N), N = 2M.
 // The length-M unnormalised inverse FFT of Zc is z[m] = x[2m] + i x[2m+1] (x unnormalised, i.e. N * irfft).

@@ -105,6 +105,25 @@ template <typename T> struct GenColIO {
   }
 };
 
+// x pass fused with the fast float32 native generation (one Philox call per lane load)
+struct FastGenColIO {
+  cplx<float>* base;
+  ColGeom g;
+  FastGenParams gp;
+  int kz0, nzl;
+  RF_HD V16<float> load(long long C, int row) const {
+    V16<float> v;
+    const uint64_t seed = gp.seed_dev ? *gp.seed_dev : gp.seed;
+    const int iy = (int)(C / nzl), kz = kz0 + (int)(C % nzl);
+    fast_gen_pair(gp, seed, row, iy, kz, v.c[0], v.c[1]);
+    return v;
+  }
+  RF_HD void store(long long C, int row, const V16<float>& v) const {
+    const long long a = (C / g.inner) * g.outer_stride + (C % g.inner) + (long long)row * g.row_stride;
+    *reinterpret_cast<V16<float>*>(base + a) = v;
+  }
+};
+
 // ---------------------------------------------------------------------------
 // Column FFT phases.  `tw` = exp(+2 pi i q / N), q in [0, N).
 // ---------------------------------------------------------------------------

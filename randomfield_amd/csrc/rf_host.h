@@ -1,6 +1,7 @@
 // rf_host.h -- host-side table preparation shared by the C-ABI library and the
 // CPU emulator (plain C++, no HIP).
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <vector>
 #include "rf_core.h"
@@ -31,6 +32,46 @@ inline void build_sigma_table(const double* log10k, const double* sigma, int n, 
     while (j + 1 < n - 1 && t.xt[j + 1] <= edge) ++j;
     t.bin[b] = j;
   }
+}
+
+// Per-bin records of the fast float32 sigma lookup, restricted to [xlo, xhi] (the
+// grid's own log10 k range, padded).  Returns false if no bin count up to 65536
+// separates the knots (more than one knot per bin) -- the caller then uses the
+// exact kernel.
+inline bool build_fast_records(const SigmaTableHost& t, double xlo, double xhi, std::vector<FastRec>& rec,
+                               float& x0, float& inv_dx, float& xmin, float& xmax) {
+  const int n = (int)t.xt.size();
+  xlo = std::max(xlo, t.xt[0]);
+  xhi = std::min(xhi, t.xt[n - 1]);
+  if (!(xhi > xlo)) return false;
+  for (int nbins = 512; nbins <= 65536; nbins *= 2) {
+    const double dx = (xhi - xlo) / nbins;
+    rec.assign(nbins, FastRec());
+    bool ok = true;
+    int j = 0;
+    for (int b = 0; b < nbins && ok; ++b) {
+      const double e0 = xlo + b * dx, e1 = xlo + (b + 1) * dx;
+      while (j + 1 < n - 1 && t.xt[j + 1] <= e0) ++j;          // interval containing e0
+      FastRec& r = rec[b];
+      const int ja = j;
+      int jb = j;
+      r.xs = INFINITY;
+      if (ja + 1 < n - 1 && t.xt[ja + 1] < e1) {                 // a knot inside the bin
+        jb = ja + 1;
+        r.xs = (float)t.xt[jb];
+        if (jb + 1 < n - 1 && t.xt[jb + 1] < e1) ok = false;     // a second one: need finer bins
+      }
+      r.xa = (float)t.xt[ja]; r.sa = (float)t.st[ja]; r.sla = (float)t.sl[ja];
+      r.xb = (float)t.xt[jb]; r.sb = (float)t.st[jb]; r.slb = (float)t.sl[jb];
+      r.pad = 0.0f;
+    }
+    if (ok) {
+      x0 = (float)xlo; inv_dx = (float)(1.0 / dx);
+      xmin = (float)t.xt[0]; xmax = (float)t.xt[n - 1];
+      return true;
+    }
+  }
+  return false;
 }
 
 // exp(+2 pi i q / n), q in [0, n), evaluated in double

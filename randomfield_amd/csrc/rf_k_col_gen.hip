@@ -34,6 +34,17 @@ hipError_t launch_t(int N, cplx<T>* W, ColGeom g, long long ncols, const GenPara
 }
 }  // namespace
 
+hipError_t launch_col_fastgen(int N, void* W, ColGeom g, long long ncols, const FastGenParams& gp, int kz0, int nzl,
+                              const void* tw, hipStream_t s, bool po) {
+  FastGenColIO io; io.base = (cplx<float>*)W; io.g = g; io.gp = gp; io.kz0 = kz0; io.nzl = nzl;
+  switch (N) {
+#define X(NN) case NN: return launch_one<typename ColSel<float, NN>::type, FastGenColIO>(io, ncols, (const cplx<float>*)tw, s, po);
+    RF_COL_SIZES(X)
+#undef X
+    default: return hipErrorInvalidValue;
+  }
+}
+
 hipError_t launch_col_gen(int f64, int N, void* W, ColGeom g, long long ncols, const GenParams& gp,
                           const void* kspace, int kz0, int nzl, const void* tw, hipStream_t s, bool po) {
   if (f64) return launch_t<double>(N, (cplx<double>*)W, g, ncols, gp, (const cplx<double>*)kspace, kz0, nzl, (const cplx<double>*)tw, s, po);
