@@ -18,9 +18,9 @@ RF_COL(32,   8,  4,  1, 32, 256)
 RF_COL(64,   8,  8,  1, 32, 256)
 RF_COL(128,  16, 8,  1, 32, 256)
 RF_COL(256,  16, 16, 1, 16, 256)
-RF_COL(512,  8,  8,  8, 16, 256)
-RF_COL(1024, 16, 16, 4, 8,  256)
-RF_COL(2048, 16, 16, 8, 8,  256)
+RF_COL(512,  8,  8,  8, 16, 512)
+RF_COL(1024, 8,  16, 8, 8,  512)
+RF_COL(2048, 8,  16, 16, 8, 1024)
 #undef RF_COL
 #define RF_COL_SIZES(X) X(8) X(16) X(32) X(64) X(128) X(256) X(512) X(1024) X(2048)
 

@@ -157,8 +157,11 @@ RF_HD PhiloxOut philox4x32_10(uint64_t ctr_lo, uint64_t ctr_hi, uint64_t key) {
   uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
-    uint32_t h0 = mulhi32(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
-    uint32_t h1 = mulhi32(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+    // one 32x32->64 product each (v_mad_u64_u32), not separate mul_lo / mul_hi
+    const uint64_t p0 = (uint64_t)0xD2511F53u * (uint64_t)c0;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * (uint64_t)c2;
+    const uint32_t h0 = (uint32_t)(p0 >> 32), l0 = (uint32_t)p0;
+    const uint32_t h1 = (uint32_t)(p1 >> 32), l1 = (uint32_t)p1;
     uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
     c0 = n0; c1 = l1; c2 = n2; c3 = l0;
     k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
@@ -371,56 +374,47 @@ RF_HD float fast_sigma(const FastGenParams& g, float t /* |k|^2 */) {
   return sr + sl * (x - xr);
 }
 
-// two adjacent packed cells (ix, iy, kz) and (ix, iy, kz + 1), kz even: ONE Philox call
+// two adjacent packed cells (ix, iy, kz) and (ix, iy, kz + 1), kz even: ONE Philox call.
+// Branch-free: for kz == 0 the first cell is provisional and fast_fix_kz0() replaces it.
 RF_HD void fast_gen_pair(const FastGenParams& g, uint64_t seed, int ix, int iy, int kz, cplx<float>& c0,
                          cplx<float>& c1) {
   const int nzc = g.nz / 2;
   const float kxy = g.kx2[ix] + g.ky2[iy];
-  const uint64_t col = (uint64_t)ix * (uint64_t)g.ny + (uint64_t)iy;
-  const uint64_t ci = col * (uint64_t)nzc + (uint64_t)kz;      // even
+  const uint64_t ci = ((uint64_t)ix * (uint64_t)g.ny + (uint64_t)iy) * (uint64_t)nzc + (uint64_t)kz;   // even
   const PhiloxOut o = philox4x32_10(ci >> 1, 0, seed);
   float g0, g1;
-  // odd cell kz + 1: always an ordinary (non-symmetrised) cell
-  {
-    const float s = fast_sigma(g, kxy + g.kz2[kz + 1]);
-    BoxMuller<float>::run(o.w[2], o.w[3], g0, g1);
-    c1 = mk<float>(s * g0, s * g1);
-  }
-  if (kz != 0) {
-    const float s = fast_sigma(g, kxy + g.kz2[kz]);
-    BoxMuller<float>::run(o.w[0], o.w[1], g0, g1);
-    c0 = mk<float>(s * g0, s * g1);
-    return;
-  }
-  // slot kz = 0: (plane kz=0) + i (plane kz=nz/2), each Hermitian-symmetrised (rf_core gen_cell rules)
+  const float s0 = fast_sigma(g, kxy + g.kz2[kz]);
+  const float s1 = fast_sigma(g, kxy + g.kz2[kz + 1]);
+  BoxMuller<float>::run(o.w[0], o.w[1], g0, g1);
+  c0 = mk<float>(s0 * g0, s0 * g1);
+  BoxMuller<float>::run(o.w[2], o.w[3], g0, g1);
+  c1 = mk<float>(s1 * g0, s1 * g1);
+}
+
+// slot kz = 0 of column (ix, iy): (plane kz=0) + i (plane kz=nz/2), each Hermitian-symmetrised
+// by the rules of gen_cell() (transform.py:141-158)
+RF_HD cplx<float> fast_fix_kz0(const FastGenParams& g, uint64_t seed, int ix, int iy) {
+  const int nzc = g.nz / 2;
   const int role = sym_role(g.nx, g.ny, ix, iy);
   int sx = ix, sy = iy;
   if (role == RF_DEST) { sx = (g.nx - ix) % g.nx; sy = (g.ny - iy) % g.ny; }
   const float kxy_s = g.kx2[sx] + g.ky2[sy];
   const uint64_t scol = (uint64_t)sx * (uint64_t)g.ny + (uint64_t)sy;
-  cplx<float> a, n;
-  {
-    const float s = fast_sigma(g, kxy_s + g.kz2[0]);
-    if (role == RF_DEST) {
-      const PhiloxOut os = philox4x32_10((scol * (uint64_t)nzc) >> 1, 0, seed);
-      BoxMuller<float>::run(os.w[0], os.w[1], g0, g1);
-    } else {
-      BoxMuller<float>::run(o.w[0], o.w[1], g0, g1);
-    }
-    a = mk<float>(s * g0, s * g1);
-  }
-  {
-    const float s = fast_sigma(g, kxy_s + g.kz2[nzc]);
-    const uint64_t cn = (uint64_t)g.nx * (uint64_t)g.ny * (uint64_t)nzc + scol;
-    const PhiloxOut on = philox4x32_10(cn >> 1, 0, seed);
-    if (cn & 1) BoxMuller<float>::run(on.w[2], on.w[3], g0, g1);
-    else        BoxMuller<float>::run(on.w[0], on.w[1], g0, g1);
-    n = mk<float>(s * g0, s * g1);
-  }
+  float g0, g1;
+  const float s0 = fast_sigma(g, kxy_s + g.kz2[0]);
+  const PhiloxOut os = philox4x32_10((scol * (uint64_t)nzc) >> 1, 0, seed);
+  BoxMuller<float>::run(os.w[0], os.w[1], g0, g1);
+  cplx<float> a = mk<float>(s0 * g0, s0 * g1);
+  const float sn = fast_sigma(g, kxy_s + g.kz2[nzc]);
+  const uint64_t cn = (uint64_t)g.nx * (uint64_t)g.ny * (uint64_t)nzc + scol;
+  const PhiloxOut on = philox4x32_10(cn >> 1, 0, seed);
+  if (cn & 1) BoxMuller<float>::run(on.w[2], on.w[3], g0, g1);
+  else        BoxMuller<float>::run(on.w[0], on.w[1], g0, g1);
+  cplx<float> n = mk<float>(sn * g0, sn * g1);
   if (role == RF_DEST) { a.y = -a.y; n.y = -n.y; }
   if (role == RF_SELF) { a.y = 0.0f; n.y = 0.0f; }
   if (ix == 0 && iy == 0) a.x = 0.0f;
-  c0 = mk<float>(a.x - n.y, a.y + n.x);
+  return mk<float>(a.x - n.y, a.y + n.x);
 }
 
 // ------------------------------------------------------- c2r / r2c untangle --

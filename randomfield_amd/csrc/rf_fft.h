@@ -9,7 +9,8 @@
 //            vector covering CPL adjacent columns, tile rows are TC*8 B
 //            contiguous segments).  Pass 1 goes global -> registers -> LDS,
 //            the last pass LDS -> registers -> global, so the tile crosses LDS
-//            only NPASS-1 times.  LDS image: [pad16(row)][TC] (t fastest).
+//            only NPASS-1 times.  LDS image: [padded row][TC] (t fastest); the middle
+//            (LDS-only) pass works one column per lane so that all threads stay busy.
 //   RowFFT : c2r (or r2c) along the contiguous z axis.  A workgroup owns NRT
 //            whole rows of M = nz/2 complex.  The Hermitian untangle is folded
 //            into pass 1: one thread owns the butterfly pair (j, M/R1 - j),
@@ -38,17 +39,21 @@ struct ColCfg {
   using T = T_;
   static constexpr int N = N_, R1 = R1_, R2 = R2_, R3 = R3_, TC = TC_, NT = NT_;
   static_assert(R1_ * R2_ * R3_ == N_, "radices must multiply to N");
-  static constexpr int CPL = V16<T>::CPL;        // columns per lane (2 for f32, 1 for f64)
-  static constexpr int LPR = TC / CPL;           // lanes per tile row
-  static constexpr int BPI = NT / LPR;           // butterflies (per column) per iteration
-  static_assert(NT_ % LPR == 0, "NT must be a multiple of lanes-per-row");
+  static constexpr int CPL = V16<T>::CPL;        // columns per lane in the global-memory passes (16 B per lane)
+  static constexpr int LPR = TC / CPL;           // lanes per tile row in those passes
+  static constexpr int BPI = NT / LPR;           // butterflies (per column) per iteration, first / last pass
+  static constexpr int BPM = NT / TC;            // butterflies per iteration in the middle pass (1 column per lane)
+  static_assert(NT_ % TC_ == 0, "NT must be a multiple of the tile width");
   static constexpr int NPASS = (R2 == 1 ? 1 : (R3 == 1 ? 2 : 3));
   static constexpr int RL = (NPASS == 1 ? R1 : (NPASS == 2 ? R2 : R3));  // radix of the last pass
-  static constexpr int LDS_ROWS = (NPASS == 1 ? 0 : N + ((N - 1) >> 4) + 1);
+  // LDS image [padded row][TC]: one pad row after every R1 rows, so that the stride-R1
+  // row pattern written by pass 1 walks through the banks
+  static constexpr int LDS_ROWS = (NPASS == 1 ? 0 : N + N / R1);
   static constexpr int LDS_BYTES = LDS_ROWS * TC * (int)sizeof(cplx<T>);
   static constexpr int IT1 = ceil_div(N / R1, BPI);
-  static constexpr int IT2 = (NPASS == 3 ? ceil_div(N / R2, BPI) : 1);
+  static constexpr int IT2 = (NPASS == 3 ? ceil_div(N / R2, BPM) : 1);
   static constexpr int ITL = ceil_div(N / RL, BPI);
+  RF_HD static int prow(int r) { return r + r / R1; }
 };
 
 // Addressing of a column pass over the packed device array.
@@ -68,6 +73,7 @@ template <typename T> struct PlainColIO {
   RF_HD void store(long long C, int row, const V16<T>& v) const {
     *reinterpret_cast<V16<T>*>(base + addr(C, row)) = v;
   }
+  template <int R> RF_HD void fix(long long, int, int, cplx<T> (*)[R]) const {}
 };
 
 // x pass fused with generation (rows K,T,R,S): load() synthesises the packed
@@ -103,6 +109,7 @@ template <typename T> struct GenColIO {
     const long long a = (C / g.inner) * g.outer_stride + (C % g.inner) + (long long)row * g.row_stride;
     *reinterpret_cast<V16<T>*>(base + a) = v;
   }
+  template <int R> RF_HD void fix(long long, int, int, cplx<T> (*)[R]) const {}
 };
 
 // x pass fused with the fast float32 native generation (one Philox call per lane load)
@@ -117,6 +124,18 @@ struct FastGenColIO {
     const int iy = (int)(C / nzl), kz = kz0 + (int)(C % nzl);
     fast_gen_pair(gp, seed, row, iy, kz, v.c[0], v.c[1]);
     return v;
+  }
+  // after the R loads of one butterfly (rows j + m*L): the lane that owns slot kz = 0 replaces its
+  // provisional cells by the packed, symmetrised (kz=0, kz=nz/2) pair -- one branch per butterfly
+  template <int R> RF_HD void fix(long long C, int j, int L, cplx<float> (*v)[R]) const {
+#ifndef RF_NO_FIX
+    if (kz0 + (int)(C % nzl) == 0) {
+      const uint64_t seed = gp.seed_dev ? *gp.seed_dev : gp.seed;
+      const int iy = (int)(C / nzl);
+#pragma unroll
+      for (int m = 0; m < R; ++m) v[0][m] = fast_fix_kz0(gp, seed, j + m * L, iy);
+    }
+#endif
   }
   RF_HD void store(long long C, int row, const V16<float>& v) const {
     const long long a = (C / g.inner) * g.outer_stride + (C % g.inner) + (long long)row * g.row_stride;
@@ -134,11 +153,12 @@ struct ColFFT {
   using V = V16<T>;
   static constexpr int N = C::N, CPL = C::CPL, LPR = C::LPR, BPI = C::BPI;
 
-  struct Regs { cx v[C::IT2][C::CPL][cmax(C::R2, 1)]; };
+  struct Regs { cx v[C::IT2][cmax(C::R2, 1)]; };
 
   RF_HD static V* lds_at(cx* lds, int row, int lp) {
-    return reinterpret_cast<V*>(lds + (long long)pad16(row) * C::TC) + lp;
+    return reinterpret_cast<V*>(lds + (long long)C::prow(row) * C::TC) + lp;
   }
+  RF_HD static cx* lds_col(cx* lds, int row, int t) { return lds + (long long)C::prow(row) * C::TC + t; }
 
   // pass 1: global -> R1 butterfly -> LDS (or straight back to global when N == R1)
   RF_HD static void pass_first(int tid, long long tile, const IO& io, cx* lds) {
@@ -156,6 +176,7 @@ struct ColFFT {
 #pragma unroll
           for (int c = 0; c < CPL; ++c) v[c][m] = x.c[c];
         }
+        io.template fix<R>(Ccol, j, L, v);
 #pragma unroll
         for (int c = 0; c < CPL; ++c) DFT<R, DIR>::run(v[c]);
 #pragma unroll
@@ -170,45 +191,35 @@ struct ColFFT {
     }
   }
 
-  // middle pass (only when NPASS == 3), split around a barrier because it is in place
+  // middle pass (only when NPASS == 3): in place, so split around a barrier.  One column per
+  // lane (8-byte LDS accesses): twice the threads of the 16-byte passes stay busy.
   RF_HD static void pass_mid_read(int tid, const cx* tw, cx* lds, Regs& r) {
     constexpr int R = C::R2, L = N / R, Ns = C::R1;
-    const int lp = tid % LPR, jl = tid / LPR;
+    const int t = tid % C::TC, jl = tid / C::TC;
 #pragma unroll
     for (int it = 0; it < C::IT2; ++it) {
-      const int j = it * BPI + jl;
+      const int j = it * C::BPM + jl;
       if (j < L) {
 #pragma unroll
         for (int m = 0; m < R; ++m) {
-          V x = *lds_at(lds, j + m * L, lp);
-          if (m > 0) {
-            const cx w = tw_dir<DIR>(tw[stockham_tw_index(j, m, Ns, R, N)]);
-#pragma unroll
-            for (int c = 0; c < CPL; ++c) x.c[c] = cmul(x.c[c], w);
-          }
-#pragma unroll
-          for (int c = 0; c < CPL; ++c) r.v[it][c][m] = x.c[c];
+          cx x = *lds_col(lds, j + m * L, t);
+          if (m > 0) x = cmul(x, tw_dir<DIR>(tw[stockham_tw_index(j, m, Ns, R, N)]));
+          r.v[it][m] = x;
         }
-#pragma unroll
-        for (int c = 0; c < CPL; ++c) DFT<R, DIR>::run(r.v[it][c]);
+        DFT<R, DIR>::run(r.v[it]);
       }
     }
   }
   RF_HD static void pass_mid_write(int tid, cx* lds, const Regs& r) {
     constexpr int R = C::R2, L = N / R, Ns = C::R1;
-    const int lp = tid % LPR, jl = tid / LPR;
+    const int t = tid % C::TC, jl = tid / C::TC;
 #pragma unroll
     for (int it = 0; it < C::IT2; ++it) {
-      const int j = it * BPI + jl;
+      const int j = it * C::BPM + jl;
       if (j < L) {
         const int ob = stockham_out_base(j, Ns, R);
 #pragma unroll
-        for (int m = 0; m < R; ++m) {
-          V x;
-#pragma unroll
-          for (int c = 0; c < CPL; ++c) x.c[c] = r.v[it][c][m];
-          *lds_at(lds, ob + m * Ns, lp) = x;
-        }
+        for (int m = 0; m < R; ++m) *lds_col(lds, ob + m * Ns, t) = r.v[it][m];
       }
     }
   }
