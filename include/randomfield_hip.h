@@ -80,6 +80,8 @@ int rf_realise(rf_plan* plan, uint64_t seed, int mode, const double* noise_host)
 /* n realisations back to back replayed from one captured hipGraph (native noise);
  * the field of the last seed stays resident; rms_out[i] (may be NULL) = np.std of field i. */
 int rf_realise_batch(rf_plan* plan, const uint64_t* seeds, int n, double* rms_out);
+/* capture + instantiate the n-realisation graph now (otherwise the first rf_realise_batch(n) does it) */
+int rf_realise_batch_prepare(rf_plan* plan, int n);
 
 /* ---- row D: np.std(delta.flat) (generate.py:219) ------------------------ */
 int rf_moments(rf_plan* plan, double* mean, double* std);

@@ -42,6 +42,7 @@ SIGNATURES = {
     "rf_execute_r2c": (ctypes.c_int, [ctypes.c_void_p]),
     "rf_realise": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, _c_dp]),
     "rf_realise_batch": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64), ctypes.c_int, _c_dp]),
+    "rf_realise_batch_prepare": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "rf_moments": (ctypes.c_int, [ctypes.c_void_p, _c_dp, _c_dp]),
     "rf_lognormal": (ctypes.c_int, [ctypes.c_void_p, _c_dp, _c_dp, ctypes.c_int, ctypes.c_double]),
     "rf_scale_z": (ctypes.c_int, [ctypes.c_void_p, _c_dp, ctypes.c_int]),
@@ -201,6 +202,9 @@ class DevicePlan(object):
         check(self._lib.rf_realise_batch(self._h, seeds.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), len(seeds),
                                          _dp(rms) if want_rms else None), "rf_realise_batch")
         return rms
+
+    def realise_batch_prepare(self, n):
+        check(self._lib.rf_realise_batch_prepare(self._h, int(n)), "rf_realise_batch_prepare")
 
     def execute_c2r(self):
         check(self._lib.rf_execute_c2r(self._h), "rf_execute_c2r")

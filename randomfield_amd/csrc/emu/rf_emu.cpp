@@ -17,31 +17,37 @@ using namespace rf;
 namespace {
 
 template <class C, int DIR, class IO>
-void run_col_pass(const IO& io, long long ncols, const cplx<typename C::T>* tw) {
+void run_col_pass(const IO& io_in, long long ncols, const cplx<typename C::T>* tw) {
   using F = ColFFT<C, DIR, IO>;
   using cx = cplx<typename C::T>;
-  std::vector<cx> lds((size_t)C::LDS_BYTES / sizeof(cx) + 16);
+  std::vector<cx> lds((size_t)(C::LDS_BYTES + IO::LDS_EXTRA) / sizeof(cx) + 16);
   std::vector<typename F::Regs> regs(C::NT);
+  std::vector<IO> ios(C::NT, io_in);             // every "thread" has its own copy of the kernel argument
   const long long ntiles = ncols / C::TC;
   for (long long tile = 0; tile < ntiles; ++tile) {
-    for (int t = 0; t < C::NT; ++t) F::pass_first(t, tile, io, lds.data());
+    const cx* ltw = tw;
+    if (F::HAS_PROLOGUE) {
+      for (int t = 0; t < C::NT; ++t) F::prologue(t, ios[t], tw, lds.data());
+      if (C::NPASS >= 2) ltw = F::lds_tw(lds.data());
+    }
+    for (int t = 0; t < C::NT; ++t) F::pass_first(t, tile, ios[t], lds.data());
     if (C::NPASS == 3) {
-      for (int t = 0; t < C::NT; ++t) F::pass_mid_read(t, tw, lds.data(), regs[t]);
+      for (int t = 0; t < C::NT; ++t) F::pass_mid_read(t, ltw, lds.data(), regs[t]);
       for (int t = 0; t < C::NT; ++t) F::pass_mid_write(t, lds.data(), regs[t]);
     }
     if (C::NPASS >= 2)
-      for (int t = 0; t < C::NT; ++t) F::pass_last(t, tile, io, tw, lds.data());
+      for (int t = 0; t < C::NT; ++t) F::pass_last(t, tile, ios[t], ltw, lds.data());
   }
 }
 
-template <typename T, int DIR, class IO>
+template <typename T, int DIR, class IO, template <typename, int> class SEL = ColSel>
 int dispatch_col(int N, const IO& io, long long ncols) {
   auto tw = make_twiddles<T>(N);
   switch (N) {
 #define X(NN)                                                                        \
   case NN:                                                                           \
-    if (ncols % ColSel<T, NN>::type::TC) return -2;                                  \
-    run_col_pass<typename ColSel<T, NN>::type, DIR, IO>(io, ncols, tw.data());       \
+    if (ncols % SEL<T, NN>::type::TC) return -2;                                     \
+    run_col_pass<typename SEL<T, NN>::type, DIR, IO>(io, ncols, tw.data());          \
     return 0;
     RF_COL_SIZES(X)
 #undef X
@@ -105,7 +111,7 @@ int c2r_impl(int nx, int ny, int nz, const GenHost* gen, const cplx<T>* kspace, 
   gio.base = W; gio.g = ColGeom{(long long)ny * nzc, 0, (long long)ny * nzc};
   if (gen) gio.gp = gen->gp; else { memset(&gio.gp, 0, sizeof(gio.gp)); gio.gp.nx = nx; gio.gp.ny = ny; gio.gp.nz = nz; }
   gio.kspace = kspace; gio.kz0 = 0; gio.nzl = (int)nzc;
-  int rc = dispatch_col<T, +1>(nx, gio, (long long)ny * nzc);
+  int rc = dispatch_col<T, +1, GenColIO<T>, GenSel>(nx, gio, (long long)ny * nzc);
   if (rc) return rc;
   // y pass, in place
   PlainColIO<T> pio; pio.base = W; pio.g = ColGeom{nzc, (long long)ny * nzc, nzc};
@@ -115,21 +121,23 @@ int c2r_impl(int nx, int ny, int nz, const GenHost* gen, const cplx<T>* kspace, 
   return dispatch_row_c2r<T>((int)nzc, W, (long long)nx * ny, 1.0 / ((double)nx * ny * nz), s1, s2);
 }
 
-int realise_fast_impl(int nx, int ny, int nz, const GenHost& h, uint64_t seed, double spacing_k_lo, double spacing_k_hi,
+int realise_fast_impl(int nx, int ny, int nz, const GenHost& h, uint64_t seed, double xlo, double xhi, double dkx,
                       cplx<float>* W, double* s1, double* s2) {
   const long long nzc = nz / 2;
-  std::vector<float> kx2(nx), ky2(ny), kz2(nzc + 1);
-  for (int i = 0; i < nx; ++i) kx2[i] = (float)h.gp.kx2[i];
+  std::vector<float> ky2(ny), kz2(nzc + 1);
   for (int i = 0; i < ny; ++i) ky2[i] = (float)h.gp.ky2[i];
   for (int i = 0; i <= nzc; ++i) kz2[i] = (float)h.gp.kz2[i];
   std::vector<FastRec> rec;
   FastGenColIO io;
-  io.base = W; io.g = ColGeom{(long long)ny * nzc, 0, (long long)ny * nzc}; io.kz0 = 0; io.nzl = (int)nzc;
+  io.base = W; io.g = ColGeom{(long long)ny * nzc, 0, (long long)ny * nzc}; io.kz0 = 0; io.nzl = (int)nzc; io.rec = nullptr;
   FastGenParams& f = io.gp;
-  if (!build_fast_records(h.tab, spacing_k_lo, spacing_k_hi, rec, f.x0, f.inv_dx, f.xmin, f.xmax)) return -3;
-  f.nx = nx; f.ny = ny; f.nz = nz; f.kx2 = kx2.data(); f.ky2 = ky2.data(); f.kz2 = kz2.data();
-  f.rec = rec.data(); f.nbins = (int)rec.size(); f.seed = seed; f.seed_dev = nullptr;
-  int rc = dispatch_col<float, +1>(nx, io, (long long)ny * nzc);
+  double x0, dx;
+  if (!build_fast_records(h.tab, xlo, xhi, rec, x0, dx)) return -3;
+  f.nx = nx; f.ny = ny; f.nz = nz; f.dkx = (float)dkx; f.ky2 = ky2.data(); f.kz2 = kz2.data();
+  f.rec = rec.data(); f.nbins = (int)rec.size();
+  f.u_scale = (float)(0.5 * std::log10(2.0) / dx); f.u_off = (float)(-x0 / dx);
+  f.seed = seed; f.seed_dev = nullptr;
+  int rc = dispatch_col<float, +1, FastGenColIO, GenSel>(nx, io, (long long)ny * nzc);
   if (rc) return rc;
   PlainColIO<float> pio; pio.base = W; pio.g = ColGeom{nzc, (long long)ny * nzc, nzc};
   rc = dispatch_col<float, +1>(ny, pio, (long long)nx * nzc);
@@ -144,10 +152,10 @@ extern "C" {
 // fused realisation with the fast float32 native generation; [xlo, xhi] = log10 k range of the grid (padded)
 int emu_realise_fast(int nx, int ny, int nz, const double* kx2, const double* ky2, const double* kz2,
                      const double* log10k, const double* sigma, int nt, uint64_t seed, double xlo, double xhi,
-                     void* W, double* s1, double* s2) {
+                     double dkx, void* W, double* s1, double* s2) {
   GenHost h;
   fill_gen(h, nx, ny, nz, kx2, ky2, kz2, log10k, sigma, nt, 0, seed, nullptr);
-  return realise_fast_impl(nx, ny, nz, h, seed, xlo, xhi, (cplx<float>*)W, s1, s2);
+  return realise_fast_impl(nx, ny, nz, h, seed, xlo, xhi, dkx, (cplx<float>*)W, s1, s2);
 }
 
 // k-space after symmetrise in the API layout [nx][ny][nz/2+1] (rows K,T,R,S)

@@ -3,7 +3,9 @@
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -69,10 +71,10 @@ struct rf_plan {
   double x0 = 0, inv_dx = 0;
   bool have_kgrid = false, have_power = false;
   // fast float32 native generation: float copies of the k^2 tables + per-bin sigma records
-  float *kx2f = nullptr, *ky2f = nullptr, *kz2f = nullptr;
+  float *ky2f = nullptr, *kz2f = nullptr;
   FastRec* frec = nullptr;
   int fnbins = 0;
-  float fx0 = 0, finv_dx = 0, fxmin = 0, fxmax = 0;
+  float fdkx = 0, fu_scale = 0, fu_off = 0;
   bool have_fast = false, exact_gen = false;
   std::vector<double> h_kx2, h_ky2, h_kz2;   // host copies (k range of the grid for the fast records)
   SigmaTableHost h_tab;
@@ -89,12 +91,23 @@ struct rf_plan {
   double* ztab = nullptr;                 // 2 * nz doubles for lognormal / affine tables
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   bool timed = false;
-  hipGraph_t graph = nullptr;
-  hipGraphExec_t graph_exec = nullptr;
+  struct BatchGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };
+  std::map<int, BatchGraph> graphs;       // captured batch graphs, keyed by the number of realisations
   bool real_valid = false, k_valid = false, stats_valid = false;
+  int slab_planes = 0;
+  void* cur = nullptr;                    // buffer holding the current real-space field
+  int stats_slot = 0;                     // which (sum, sumsq) pair of `stats` belongs to the current field                    // x-planes per y/z slab (0 = whole grid in one launch pair)
 };
 
 namespace {
+
+void drop_graphs(rf_plan* p) {
+  for (auto& kv : p->graphs) {
+    if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+    if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
+  }
+  p->graphs.clear();
+}
 
 int ensure_k(rf_plan* p) {
   if (!p->K) RF_HIP(hipMalloc(&p->K, p->k_bytes));
@@ -126,12 +139,12 @@ int upload_noise(rf_plan* p, int mode, const double* noise_host) {
   return 0;
 }
 
-FastGenParams make_fast(rf_plan* p, uint64_t seed, bool seed_from_dev) {
+FastGenParams make_fast(rf_plan* p, uint64_t seed, bool seed_from_dev, const uint64_t* seed_ptr) {
   FastGenParams f;
   f.nx = p->nx; f.ny = p->ny; f.nz = p->nz;
-  f.kx2 = p->kx2f; f.ky2 = p->ky2f; f.kz2 = p->kz2f;
-  f.rec = p->frec; f.nbins = p->fnbins; f.x0 = p->fx0; f.inv_dx = p->finv_dx; f.xmin = p->fxmin; f.xmax = p->fxmax;
-  f.seed = seed; f.seed_dev = seed_from_dev ? p->seed_cur : nullptr;
+  f.dkx = p->fdkx; f.ky2 = p->ky2f; f.kz2 = p->kz2f;
+  f.rec = p->frec; f.nbins = p->fnbins; f.u_scale = p->fu_scale; f.u_off = p->fu_off;
+  f.seed = seed; f.seed_dev = seed_from_dev ? seed_ptr : nullptr;
   return f;
 }
 
@@ -146,9 +159,19 @@ int build_fast(rf_plan* p) {
   kmax2 = mx(p->h_kx2) + mx(p->h_ky2) + mx(p->h_kz2);
   if (!(kmin2 < 1e300) || !(kmax2 > 0)) return 0;
   std::vector<FastRec> rec;
-  if (!build_fast_records(p->h_tab, 0.5 * std::log10(kmin2) - 0.01, 0.5 * std::log10(kmax2) + 0.01, rec, p->fx0,
-                          p->finv_dx, p->fxmin, p->fxmax))
+  double x0, dx;
+  if (!build_fast_records(p->h_tab, 0.5 * std::log10(kmin2) - 0.01, 0.5 * std::log10(kmax2) + 0.01, rec, x0, dx))
     return 0;   // knots too dense for the per-bin records: the exact kernel is used instead
+  // the fast kernel forms kx arithmetically: kx(i) = dkx * signed index; needs a uniform fftfreq-style x axis
+  if (p->nx < 2 || !(p->h_kx2[1] > 0)) return 0;
+  p->fdkx = (float)std::sqrt(p->h_kx2[1]);
+  for (int i = 0; i < p->nx; ++i) {
+    const double j = i < p->nx / 2 ? i : i - p->nx;
+    const double want = j * j * p->h_kx2[1];
+    if (std::fabs(p->h_kx2[i] - want) > 1e-9 * (want + 1e-300)) return 0;   // not a regular grid: exact kernel
+  }
+  p->fu_scale = (float)(0.5 * std::log10(2.0) / dx);
+  p->fu_off = (float)(-x0 / dx);
   if (p->frec) RF_HIP(hipFree(p->frec));
   p->frec = nullptr;
   RF_HIP(hipMalloc((void**)&p->frec, rec.size() * sizeof(FastRec)));
@@ -158,27 +181,49 @@ int build_fast(rf_plan* p) {
   return 0;
 }
 
-// the three FFT passes + moments on the plan's stream; generation or API k-space feeds the x pass
-int queue_c2r(rf_plan* p, const GenParams& gp, const void* kspace, bool graph_slot) {
+// x pass (generation or API k-space fused into its load) into buffer W on stream sx
+int queue_x(rf_plan* p, const GenParams& gp, const void* kspace, void* W, hipStream_t sx) {
   const long long nzc = p->nzc;
   const ColGeom gx{(long long)p->ny * nzc, 0, (long long)p->ny * nzc};
-  const ColGeom gy{nzc, (long long)p->ny * nzc, nzc};
-  if (p->timed) RF_HIP(hipEventRecord(p->ev[0], p->stream));
   const bool fast = !kspace && gp.noise_mode == NOISE_PHILOX && p->have_fast && !p->exact_gen;
   if (fast)
-    RF_HIP(launch_col_fastgen(p->nx, p->W, gx, (long long)p->ny * nzc, make_fast(p, gp.seed, gp.seed_dev != nullptr), 0,
-                              (int)nzc, p->tw_x, p->stream));
+    RF_HIP(launch_col_fastgen(p->nx, W, gx, (long long)p->ny * nzc, make_fast(p, gp.seed, gp.seed_dev != nullptr, gp.seed_dev), 0,
+                              (int)nzc, p->tw_x, sx));
   else
-    RF_HIP(launch_col_gen(p->f64, p->nx, p->W, gx, (long long)p->ny * nzc, gp, kspace, 0, (int)nzc, p->tw_x, p->stream));
-  if (p->timed) RF_HIP(hipEventRecord(p->ev[1], p->stream));
-  RF_HIP(launch_col_plain(p->f64, p->ny, +1, p->W, gy, (long long)p->nx * nzc, p->tw_y, p->stream));
-  if (p->timed) RF_HIP(hipEventRecord(p->ev[2], p->stream));
-  const long long nrows = (long long)p->nx * p->ny;
+    RF_HIP(launch_col_gen(p->f64, p->nx, W, gx, (long long)p->ny * nzc, gp, kspace, 0, (int)nzc, p->tw_x, sx));
+  return 0;
+}
+
+// y pass, z pass and the moments of buffer W on stream s; stats go to stats_out[0..1]
+int queue_yz(rf_plan* p, void* W, hipStream_t s, double* stats_out, bool timed) {
+  const long long nzc = p->nzc;
+  const ColGeom gy{nzc, (long long)p->ny * nzc, nzc};
   const double scale = 1.0 / ((double)p->nx * (double)p->ny * (double)p->nz);
-  RF_HIP(launch_row_c2r(p->f64, (int)nzc, p->W, nrows, scale, p->tw_z, p->partials, p->stream));
-  if (p->timed) RF_HIP(hipEventRecord(p->ev[3], p->stream));
-  RF_HIP(launch_reduce_partials(p->partials, p->npartials, p->stats, graph_slot ? p->counter : nullptr, p->stream));
-  if (p->timed) RF_HIP(hipEventRecord(p->ev[4], p->stream));
+  const int S = p->slab_planes > 0 && p->slab_planes < p->nx ? p->slab_planes : p->nx;
+  const long long tiles_per_row_block = row_c2r_tiles(p->f64, (int)nzc, (long long)S * p->ny);
+  for (int x0 = 0; x0 < p->nx; x0 += S) {
+    const int sx = x0 + S <= p->nx ? S : p->nx - x0;
+    char* base = (char*)W + (size_t)x0 * p->ny * nzc * p->csize;
+    RF_HIP(launch_col_plain(p->f64, p->ny, +1, base, gy, (long long)sx * nzc, p->tw_y, s));
+    if (timed && S == p->nx) RF_HIP(hipEventRecord(p->ev[2], s));
+    RF_HIP(launch_row_c2r(p->f64, (int)nzc, base, (long long)sx * p->ny, scale, p->tw_z,
+                          p->partials + 2 * (x0 / S) * tiles_per_row_block, s));
+  }
+  if (timed && S != p->nx) RF_HIP(hipEventRecord(p->ev[2], s));   // y and z interleaved: no split
+  if (timed) RF_HIP(hipEventRecord(p->ev[3], s));
+  RF_HIP(launch_reduce_partials(p->partials, p->npartials, stats_out, nullptr, s));
+  if (timed) RF_HIP(hipEventRecord(p->ev[4], s));
+  return 0;
+}
+
+// one realisation / transform on the plan's stream into the primary buffer
+int queue_c2r(rf_plan* p, const GenParams& gp, const void* kspace) {
+  if (p->timed) RF_HIP(hipEventRecord(p->ev[0], p->stream));
+  if (int rc = queue_x(p, gp, kspace, p->W, p->stream)) return rc;
+  if (p->timed) RF_HIP(hipEventRecord(p->ev[1], p->stream));
+  if (int rc = queue_yz(p, p->W, p->stream, p->stats, p->timed)) return rc;
+  p->cur = p->W;
+  p->stats_slot = 0;
   p->real_valid = true;
   p->stats_valid = true;
   return 0;
@@ -257,7 +302,21 @@ int rf_plan_create(rf_plan** out, int nx, int ny, int nz, int dtype, int device,
     if (!rc) rc = upload_twiddles<float>(&p->tw_z, nz);
   }
   if (rc) return cleanup(rc);
-  p->npartials = row_c2r_tiles(dtype, p->nzc, (long long)nx * ny);
+  {
+    // optional experiment: y/z passes slab by slab so that a slab's y output could stay in the 256 MiB
+    // Infinity Cache for the z pass; RANDOMFIELD_SLAB_MB=<MiB> enables it
+    double slab_mb = 0.0;   // measured on MI355X: slabs never won (launch tails; z pass is not HBM-bound) -> off
+    if (const char* e = getenv("RANDOMFIELD_SLAB_MB")) slab_mb = atof(e);
+    const double plane_mb = (double)ny * p->nzc * p->csize / 1048576.0;
+    int S = slab_mb > 0 ? (int)(slab_mb / plane_mb) : 0;
+    if (S < 1 || (double)nx * plane_mb <= 2 * slab_mb) S = 0;      // small grids: one launch pair
+    if (S > 0) { int q = 1; while (q * 2 <= S) q *= 2; S = q; }    // power of two so that it divides nx
+    p->slab_planes = S;
+  }
+  {
+    const int S = p->slab_planes > 0 ? p->slab_planes : nx;
+    p->npartials = row_c2r_tiles(dtype, p->nzc, (long long)S * ny) * ((nx + S - 1) / S);
+  }
   p->stats_cap = 64;
   if ((e = hipMalloc((void**)&p->partials, 2 * p->npartials * sizeof(double))) != hipSuccess ||
       (e = hipMalloc((void**)&p->stats, 2 * p->stats_cap * sizeof(double))) != hipSuccess ||
@@ -266,7 +325,6 @@ int rf_plan_create(rf_plan** out, int nx, int ny, int nz, int dtype, int device,
       (e = hipMalloc((void**)&p->kx2, nx * sizeof(double))) != hipSuccess ||
       (e = hipMalloc((void**)&p->ky2, ny * sizeof(double))) != hipSuccess ||
       (e = hipMalloc((void**)&p->kz2, (p->nzc + 1) * sizeof(double))) != hipSuccess ||
-      (e = hipMalloc((void**)&p->kx2f, nx * sizeof(float))) != hipSuccess ||
       (e = hipMalloc((void**)&p->ky2f, ny * sizeof(float))) != hipSuccess ||
       (e = hipMalloc((void**)&p->kz2f, (p->nzc + 1) * sizeof(float))) != hipSuccess ||
       (e = hipMalloc((void**)&p->ztab, 2 * nz * sizeof(double))) != hipSuccess)
@@ -292,10 +350,9 @@ int rf_plan_destroy(rf_plan* p) {
   if (!p) return 0;
   (void)hipSetDevice(p->device);
   if (p->stream) (void)hipStreamSynchronize(p->stream);
-  if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
-  if (p->graph) (void)hipGraphDestroy(p->graph);
+  drop_graphs(p);
   void* bufs[] = {p->W, p->K, p->P, p->tw_x, p->tw_y, p->tw_z, p->kx2, p->ky2, p->kz2, p->xt, p->st, p->sl, p->bin,
-                  p->noise, p->partials, p->stats, p->seed_cur, p->seeds_dev, p->counter, p->ztab, p->kx2f, p->ky2f,
+                  p->noise, p->partials, p->stats, p->seed_cur, p->seeds_dev, p->counter, p->ztab, p->ky2f,
                   p->kz2f, p->frec};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -317,8 +374,7 @@ int rf_plan_set_flag(rf_plan* p, int flag, int value) {
   RF_REQUIRE(flag == RF_FLAG_EXACT_GENERATION, "unknown flag");
   RF_HIP(hipStreamSynchronize(p->stream));
   p->exact_gen = value != 0;
-  if (p->graph_exec) { (void)hipGraphExecDestroy(p->graph_exec); p->graph_exec = nullptr; }
-  if (p->graph) { (void)hipGraphDestroy(p->graph); p->graph = nullptr; }
+  drop_graphs(p);
   return 0;
 }
 
@@ -326,8 +382,7 @@ int rf_plan_set_stream(rf_plan* p, void* hip_stream) {
   RF_REQUIRE(p, "null plan");
   RF_HIP(hipStreamSynchronize(p->stream));
   p->stream = hip_stream ? (hipStream_t)hip_stream : p->own_stream;
-  if (p->graph_exec) { (void)hipGraphExecDestroy(p->graph_exec); p->graph_exec = nullptr; }
-  if (p->graph) { (void)hipGraphDestroy(p->graph); p->graph = nullptr; }
+  drop_graphs(p);
   return 0;
 }
 
@@ -345,7 +400,6 @@ int rf_set_kgrid(rf_plan* p, const double* kx2, const double* ky2, const double*
     for (int i = 0; i < n; ++i) f[i] = (float)src[i];
     return hipMemcpy(dst, f.data(), n * sizeof(float), hipMemcpyHostToDevice);
   };
-  RF_HIP(up(p->kx2f, kx2, p->nx));
   RF_HIP(up(p->ky2f, ky2, p->ny));
   RF_HIP(up(p->kz2f, kz2, p->nzc + 1));
   p->have_kgrid = true;
@@ -398,7 +452,7 @@ int rf_execute_c2r(rf_plan* p) {
   memset(&gp, 0, sizeof(gp));
   gp.nx = p->nx; gp.ny = p->ny; gp.nz = p->nz;
   p->timed = true;
-  return queue_c2r(p, gp, p->K, false);
+  return queue_c2r(p, gp, p->K);
 }
 
 int rf_execute_r2c(rf_plan* p) {
@@ -413,56 +467,77 @@ int rf_realise(rf_plan* p, uint64_t seed, int mode, const double* noise_host) {
   RF_HIP(hipSetDevice(p->device));
   if (int rc = upload_noise(p, mode, noise_host)) return rc;
   p->timed = true;
-  int rc = queue_c2r(p, make_gen(p, seed, mode, false), nullptr, false);
+  int rc = queue_c2r(p, make_gen(p, seed, mode, false), nullptr);
   if (rc) return rc;
   if (mode == RF_NOISE_EXTERNAL) RF_HIP(hipStreamSynchronize(p->stream));
   return 0;
 }
 
-int rf_realise_batch(rf_plan* p, const uint64_t* seeds, int n, double* rms_out) {
-  RF_REQUIRE(p && seeds, "null argument");
+// issue the n realisations of a batch on the plan's stream (under stream capture)
+static int batch_issue(rf_plan* p, int n) {
+  for (int i = 0; i < n; ++i) {
+    GenParams gp = make_gen(p, 0, RF_NOISE_NATIVE, true);
+    gp.seed_dev = p->seeds_dev + i;
+    if (int rc = queue_x(p, gp, nullptr, p->W, p->stream)) return rc;
+    if (int rc = queue_yz(p, p->W, p->stream, p->stats + 2 * i, false)) return rc;
+  }
+  return 0;
+}
+
+// Capture the whole batch as ONE graph: realisation i reads seed[i] from device memory and leaves its
+// (sum, sumsq) in stats[2i].  (Two-stream pipelining of consecutive realisations was measured on
+// MI355X and gave nothing: an x-pass and a y-pass kernel do not co-execute profitably -- DESIGN.md.)
+static int batch_prepare(rf_plan* p, int n) {
   RF_REQUIRE(n >= 1, "need at least one seed");
   RF_REQUIRE(p->have_kgrid && p->have_power, "rf_set_kgrid and rf_set_power must be called first");
   RF_HIP(hipSetDevice(p->device));
-  if (p->seeds_cap < n) {
+  if (p->seeds_cap < n || p->stats_cap < n) {
+    // device arrays are baked into the captured graphs: grow them (generously) and start over
+    RF_HIP(hipStreamSynchronize(p->stream));
+    drop_graphs(p);
+    const int cap = n > 64 ? n : 64;
     if (p->seeds_dev) RF_HIP(hipFree(p->seeds_dev));
     p->seeds_dev = nullptr;
-    RF_HIP(hipMalloc((void**)&p->seeds_dev, n * sizeof(uint64_t)));
-    p->seeds_cap = n;
-    if (p->graph_exec) { (void)hipGraphExecDestroy(p->graph_exec); p->graph_exec = nullptr; }
-    if (p->graph) { (void)hipGraphDestroy(p->graph); p->graph = nullptr; }
-  }
-  if (p->stats_cap < n) {
-    RF_HIP(hipStreamSynchronize(p->stream));
-    RF_HIP(hipFree(p->stats));
+    RF_HIP(hipMalloc((void**)&p->seeds_dev, cap * sizeof(uint64_t)));
+    p->seeds_cap = cap;
+    if (p->stats) RF_HIP(hipFree(p->stats));
     p->stats = nullptr;
-    RF_HIP(hipMalloc((void**)&p->stats, 2 * (size_t)n * sizeof(double)));
-    p->stats_cap = n;
-    if (p->graph_exec) { (void)hipGraphExecDestroy(p->graph_exec); p->graph_exec = nullptr; }
-    if (p->graph) { (void)hipGraphDestroy(p->graph); p->graph = nullptr; }
+    RF_HIP(hipMalloc((void**)&p->stats, 2 * (size_t)cap * sizeof(double)));
+    p->stats_cap = cap;
   }
+  if (p->graphs.count(n)) return 0;
+  const bool timed_save = p->timed;
+  p->timed = false;
+  RF_HIP(hipStreamSynchronize(p->stream));
+  rf_plan::BatchGraph bg;
+  RF_HIP(hipStreamBeginCapture(p->stream, hipStreamCaptureModeThreadLocal));
+  const int rc = batch_issue(p, n);
+  hipError_t e2 = hipStreamEndCapture(p->stream, &bg.graph);
+  p->timed = timed_save;
+  if (rc) return rc;
+  RF_HIP(e2);
+  RF_HIP(hipGraphInstantiate(&bg.exec, bg.graph, nullptr, nullptr, 0));
+  p->graphs[n] = bg;
+  return 0;
+}
+
+int rf_realise_batch_prepare(rf_plan* p, int n) {
+  RF_REQUIRE(p, "null plan");
+  return batch_prepare(p, n);
+}
+
+int rf_realise_batch(rf_plan* p, const uint64_t* seeds, int n, double* rms_out) {
+  RF_REQUIRE(p && seeds, "null argument");
+  if (int rc = batch_prepare(p, n)) return rc;
   RF_HIP(hipMemcpyAsync(p->seeds_dev, seeds, n * sizeof(uint64_t), hipMemcpyHostToDevice, p->stream));
-  RF_HIP(hipMemsetAsync(p->counter, 0, sizeof(unsigned long long), p->stream));
-  if (!p->graph_exec) {
-    // capture ONE realisation: seed = seeds[counter]; x, y, z passes; moments -> stats[counter++]
-    p->timed = false;
-    RF_HIP(hipStreamSynchronize(p->stream));
-    RF_HIP(hipStreamBeginCapture(p->stream, hipStreamCaptureModeThreadLocal));
-    hipError_t e = launch_pick_seed(p->seeds_dev, p->counter, p->seed_cur, p->stream);
-    int rc = 0;
-    if (e != hipSuccess) rc = fail(2, std::string("pick_seed: ") + hipGetErrorString(e));
-    if (!rc) rc = queue_c2r(p, make_gen(p, 0, RF_NOISE_NATIVE, true), nullptr, true);
-    hipError_t e2 = hipStreamEndCapture(p->stream, &p->graph);
-    if (rc) return rc;
-    RF_HIP(e2);
-    RF_HIP(hipGraphInstantiate(&p->graph_exec, p->graph, nullptr, nullptr, 0));
-  }
   RF_HIP(hipEventRecord(p->ev[0], p->stream));
-  for (int i = 0; i < n; ++i) RF_HIP(hipGraphLaunch(p->graph_exec, p->stream));
+  RF_HIP(hipGraphLaunch(p->graphs[n].exec, p->stream));
   RF_HIP(hipEventRecord(p->ev[4], p->stream));
+  p->cur = p->W;
   p->timed = false;
   p->real_valid = true;
   p->stats_valid = true;
+  p->stats_slot = n - 1;
   if (rms_out) {
     std::vector<double> st(2 * (size_t)n);
     RF_HIP(hipMemcpyAsync(st.data(), p->stats, st.size() * sizeof(double), hipMemcpyDeviceToHost, p->stream));
@@ -482,7 +557,7 @@ int rf_moments(rf_plan* p, double* mean, double* std_out) {
   RF_REQUIRE(p->stats_valid, "no realisation has been computed");
   RF_HIP(hipSetDevice(p->device));
   double st[2];
-  RF_HIP(hipMemcpyAsync(st, p->stats, sizeof(st), hipMemcpyDeviceToHost, p->stream));
+  RF_HIP(hipMemcpyAsync(st, p->stats + 2 * p->stats_slot, sizeof(st), hipMemcpyDeviceToHost, p->stream));
   RF_HIP(hipStreamSynchronize(p->stream));
   const double cnt = (double)p->nx * p->ny * p->nz;
   const double m = st[0] / cnt;
@@ -500,7 +575,7 @@ int rf_lognormal(rf_plan* p, const double* a_z, const double* b_z, int nz, doubl
   RF_HIP(hipSetDevice(p->device));
   RF_HIP(hipMemcpyAsync(p->ztab, a_z, nz * sizeof(double), hipMemcpyHostToDevice, p->stream));
   RF_HIP(hipMemcpyAsync(p->ztab + nz, b_z, nz * sizeof(double), hipMemcpyHostToDevice, p->stream));
-  RF_HIP(launch_lognormal(p->f64, p->W, (long long)p->nx * p->ny, nz, p->ztab, p->ztab + nz, sigma, p->stream));
+  RF_HIP(launch_lognormal(p->f64, p->cur, (long long)p->nx * p->ny, nz, p->ztab, p->ztab + nz, sigma, p->stream));
   RF_HIP(hipStreamSynchronize(p->stream));  // host tables may go away
   p->stats_valid = false;
   return 0;
@@ -512,7 +587,7 @@ int rf_affine_z(rf_plan* p, const double* mul_z, int nz, double add) {
   RF_REQUIRE(p->real_valid, "no real-space field on the device");
   RF_HIP(hipSetDevice(p->device));
   RF_HIP(hipMemcpyAsync(p->ztab, mul_z, nz * sizeof(double), hipMemcpyHostToDevice, p->stream));
-  RF_HIP(launch_affine_z(p->f64, p->W, (long long)p->nx * p->ny, nz, p->ztab, add, p->stream));
+  RF_HIP(launch_affine_z(p->f64, p->cur, (long long)p->nx * p->ny, nz, p->ztab, add, p->stream));
   RF_HIP(hipStreamSynchronize(p->stream));
   p->stats_valid = false;
   return 0;
@@ -567,6 +642,7 @@ int rf_upload_real(rf_plan* p, const void* host, int layout) {
   const size_t hpitch = layout == RF_LAYOUT_PADDED ? (size_t)(p->nz + 2) * rsize : width;
   RF_HIP(hipMemcpy2DAsync(p->W, width, host, hpitch, width, (size_t)p->nx * p->ny, hipMemcpyHostToDevice, p->stream));
   RF_HIP(hipStreamSynchronize(p->stream));
+  p->cur = p->W;
   p->real_valid = true;
   p->stats_valid = false;
   return 0;
@@ -580,7 +656,7 @@ int rf_download_real(rf_plan* p, void* host, int layout, int x0, int x1) {
   const size_t rsize = p->csize / 2;
   const size_t width = (size_t)p->nz * rsize;
   const size_t hpitch = layout == RF_LAYOUT_PADDED ? (size_t)(p->nz + 2) * rsize : width;
-  const char* src = (const char*)p->W + (size_t)x0 * p->ny * width;
+  const char* src = (const char*)p->cur + (size_t)x0 * p->ny * width;
   RF_HIP(hipMemcpy2DAsync(host, hpitch, src, width, width, (size_t)(x1 - x0) * p->ny, hipMemcpyDeviceToHost, p->stream));
   RF_HIP(hipStreamSynchronize(p->stream));
   return 0;
@@ -588,7 +664,7 @@ int rf_download_real(rf_plan* p, void* host, int layout, int x0, int x1) {
 
 int rf_device_ptr(rf_plan* p, void** real_field, void** kspace) {
   RF_REQUIRE(p, "null plan");
-  if (real_field) *real_field = p->W;
+  if (real_field) *real_field = p->cur ? p->cur : p->W;
   if (kspace) *kspace = p->K;
   return 0;
 }

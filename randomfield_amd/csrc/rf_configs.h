@@ -19,9 +19,14 @@ RF_COL(64,   8,  8,  1, 32, 256)
 RF_COL(128,  16, 8,  1, 32, 256)
 RF_COL(256,  16, 16, 1, 16, 256)
 RF_COL(512,  8,  8,  8, 16, 512)
-RF_COL(1024, 8,  16, 8, 8,  512)
+RF_COL(1024, 16, 8,  8, 8,  512)
 RF_COL(2048, 8,  16, 16, 8, 1024)
 #undef RF_COL
+// fused-generation x pass: same tiles, radices chosen for register pressure (generation happens
+// in pass 1, so a small first radix keeps the live set low)
+template <typename T, int N> struct GenSel { using type = typename ColSel<T, N>::type; };
+template <> struct GenSel<float, 1024> { using type = ColCfg<float, 1024, 8, 16, 8, 8, 512>; };
+template <> struct GenSel<double, 1024> { using type = ColCfg<double, 1024, 8, 16, 8, 4, 512>; };
 #define RF_COL_SIZES(X) X(8) X(16) X(32) X(64) X(128) X(256) X(512) X(1024) X(2048)
 
 // ---- contiguous (z) pass: M = nz / 2 ----------------------------------------
@@ -35,7 +40,7 @@ RF_ROW(32,   8,  4,  1,  64,  256)
 RF_ROW(64,   8,  8,  1,  64,  256)
 RF_ROW(128,  8,  16, 1,  32,  256)
 RF_ROW(256,  8,  8,  4,  16,  256)
-RF_ROW(512,  8,  8,  8,  8,   256)
+RF_ROW(512,  16, 8,  4,  16,  256)
 RF_ROW(1024, 8,  8,  16, 4,   256)
 #undef RF_ROW
 #define RF_ROW_SIZES(X) X(8) X(16) X(32) X(64) X(128) X(256) X(512) X(1024)

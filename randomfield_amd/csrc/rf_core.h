@@ -336,24 +336,25 @@ RF_HD cplx<T> gen_packed(const GenParams& g, uint64_t seed, int ix, int iy, int 
 // values are this repo's own definition (checked against the oracle's
 // restatement of the same stream to ~1e-6), so the reference's float64
 // rounding chain -- which only matters for same-noise parity -- is not needed.
-struct FastRec {          // 32 bytes per bin of the uniform acceleration grid in x = log10 k
-  float xs;               // knot inside the bin (+inf if none): piece A left of it, piece B right
-  float xa, sa, sla;      // piece A: sigma = sa + sla * (x - xa)
-  float xb, sb, slb;      // piece B
-  float pad;
-};
+struct FastRec {          // 16 bytes per bin of the uniform acceleration grid in x = log10 k
+  float v0;               // sigma at the bin's left edge
+  float sa;               // slope of the piece at the left edge, per bin width
+  float fs;               // position of the knot inside the bin in bin units (>= 1 if none)
+  float ds;               // slope change at the knot, per bin width
+};                        // sigma(f) = v0 + sa * f + ds * max(f - fs, 0),  f in [0, 1) the position inside the bin
 
 struct FastGenParams {
   int nx, ny, nz;
-  const float* kx2;       // float32 copies of the k^2 axis tables
-  const float* ky2;
+  float dkx;              // kx(i) = dkx * signed index  (2 pi / (nx spacing))
+  const float* ky2;       // float32 copies of the k^2 axis tables
   const float* kz2;
-  const FastRec* rec;
+  const FastRec* rec;     // global copy of the records; the kernels stage them in LDS when nbins <= FAST_LDS_BINS
   int nbins;
-  float x0, inv_dx, xmin, xmax;
+  float u_scale, u_off;   // bin coordinate u = log2(k^2) * u_scale + u_off
   uint64_t seed;
   const uint64_t* seed_dev;
 };
+enum { FAST_LDS_BINS = 512 };
 
 RF_HD float fast_log2(float t) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -363,49 +364,57 @@ RF_HD float fast_log2(float t) {
 #endif
 }
 
-RF_HD float fast_sigma(const FastGenParams& g, float t /* |k|^2 */) {
-  const float x = 0.15051499783199060f * fast_log2(t);   // 0.5 * log10(2) * log2(k^2) = log10 |k|
-  if (!(x >= g.xmin && x <= g.xmax)) return 0.0f;        // also t == 0 (-inf) and NaN
-  int b = (int)((x - g.x0) * g.inv_dx);
-  b = b < 0 ? 0 : (b >= g.nbins ? g.nbins - 1 : b);
-  const FastRec r = g.rec[b];
-  const bool left = x < r.xs;
-  const float xr = left ? r.xa : r.xb, sr = left ? r.sa : r.sb, sl = left ? r.sla : r.slb;
-  return sr + sl * (x - xr);
+// rec points at the records (LDS or global)
+RF_HD float fast_sigma(const FastGenParams& g, const FastRec* rec, float t /* |k|^2 */) {
+  float u = fast_log2(t) * g.u_scale + g.u_off;          // (log10|k| - x0) / dx
+  u = fmaxf(u, 0.0f);                                    // also t == 0 (-inf) and NaN
+  u = fminf(u, (float)g.nbins - 0.001f);
+  const int b = (int)u;
+  const float f = u - (float)b;
+  const FastRec r = rec[b];
+  const float d = fmaxf(f - r.fs, 0.0f);
+  return (r.v0 + r.sa * f) + r.ds * d;
 }
 
-// two adjacent packed cells (ix, iy, kz) and (ix, iy, kz + 1), kz even: ONE Philox call.
-// Branch-free: for kz == 0 the first cell is provisional and fast_fix_kz0() replaces it.
-RF_HD void fast_gen_pair(const FastGenParams& g, uint64_t seed, int ix, int iy, int kz, cplx<float>& c0,
-                         cplx<float>& c1) {
+// AB: development-only ablation mask (1: no Philox, 2: no sigma lookup, 4: no Box-Muller); 0 in the product
+RF_HD float fast_kx2(const FastGenParams& g, int ix) {
+  const float kx = (float)(ix < g.nx / 2 ? ix : ix - g.nx) * g.dkx;
+  return kx * kx;
+}
+
+template <int AB = 0>
+RF_HD void fast_gen_pair(const FastGenParams& g, const FastRec* rec, uint64_t seed, int ix, int iy, int kz,
+                         cplx<float>& c0, cplx<float>& c1) {
   const int nzc = g.nz / 2;
-  const float kxy = g.kx2[ix] + g.ky2[iy];
+  const float kxy = fast_kx2(g, ix) + g.ky2[iy];
   const uint64_t ci = ((uint64_t)ix * (uint64_t)g.ny + (uint64_t)iy) * (uint64_t)nzc + (uint64_t)kz;   // even
-  const PhiloxOut o = philox4x32_10(ci >> 1, 0, seed);
+  PhiloxOut o;
+  if (AB & 1) { o.w[0] = (uint32_t)ci; o.w[1] = (uint32_t)ci * 3u; o.w[2] = (uint32_t)ci * 5u; o.w[3] = (uint32_t)ci * 7u; }
+  else o = philox4x32_10(ci >> 1, 0, seed);
   float g0, g1;
-  const float s0 = fast_sigma(g, kxy + g.kz2[kz]);
-  const float s1 = fast_sigma(g, kxy + g.kz2[kz + 1]);
-  BoxMuller<float>::run(o.w[0], o.w[1], g0, g1);
+  const float s0 = (AB & 2) ? kxy + g.kz2[kz] : fast_sigma(g, rec, kxy + g.kz2[kz]);
+  const float s1 = (AB & 2) ? kxy + g.kz2[kz + 1] : fast_sigma(g, rec, kxy + g.kz2[kz + 1]);
+  if (AB & 4) { g0 = (float)o.w[0]; g1 = (float)o.w[1]; } else BoxMuller<float>::run(o.w[0], o.w[1], g0, g1);
   c0 = mk<float>(s0 * g0, s0 * g1);
-  BoxMuller<float>::run(o.w[2], o.w[3], g0, g1);
+  if (AB & 4) { g0 = (float)o.w[2]; g1 = (float)o.w[3]; } else BoxMuller<float>::run(o.w[2], o.w[3], g0, g1);
   c1 = mk<float>(s1 * g0, s1 * g1);
 }
 
 // slot kz = 0 of column (ix, iy): (plane kz=0) + i (plane kz=nz/2), each Hermitian-symmetrised
 // by the rules of gen_cell() (transform.py:141-158)
-RF_HD cplx<float> fast_fix_kz0(const FastGenParams& g, uint64_t seed, int ix, int iy) {
+RF_HD cplx<float> fast_fix_kz0(const FastGenParams& g, const FastRec* rec, uint64_t seed, int ix, int iy) {
   const int nzc = g.nz / 2;
   const int role = sym_role(g.nx, g.ny, ix, iy);
   int sx = ix, sy = iy;
   if (role == RF_DEST) { sx = (g.nx - ix) % g.nx; sy = (g.ny - iy) % g.ny; }
-  const float kxy_s = g.kx2[sx] + g.ky2[sy];
+  const float kxy_s = fast_kx2(g, sx) + g.ky2[sy];
   const uint64_t scol = (uint64_t)sx * (uint64_t)g.ny + (uint64_t)sy;
   float g0, g1;
-  const float s0 = fast_sigma(g, kxy_s + g.kz2[0]);
+  const float s0 = fast_sigma(g, rec, kxy_s + g.kz2[0]);
   const PhiloxOut os = philox4x32_10((scol * (uint64_t)nzc) >> 1, 0, seed);
   BoxMuller<float>::run(os.w[0], os.w[1], g0, g1);
   cplx<float> a = mk<float>(s0 * g0, s0 * g1);
-  const float sn = fast_sigma(g, kxy_s + g.kz2[nzc]);
+  const float sn = fast_sigma(g, rec, kxy_s + g.kz2[nzc]);
   const uint64_t cn = (uint64_t)g.nx * (uint64_t)g.ny * (uint64_t)nzc + scol;
   const PhiloxOut on = philox4x32_10(cn >> 1, 0, seed);
   if (cn & 1) BoxMuller<float>::run(on.w[2], on.w[3], g0, g1);
@@ -413,7 +422,7 @@ RF_HD cplx<float> fast_fix_kz0(const FastGenParams& g, uint64_t seed, int ix, in
   cplx<float> n = mk<float>(sn * g0, sn * g1);
   if (role == RF_DEST) { a.y = -a.y; n.y = -n.y; }
   if (role == RF_SELF) { a.y = 0.0f; n.y = 0.0f; }
-  if (ix == 0 && iy == 0) a.x = 0.0f;
+  if (ix == 0 && iy == 0) a = mk<float>(0.0f, 0.0f);     // DC mode (its sigma lookup is meaningless)
   return mk<float>(a.x - n.y, a.y + n.x);
 }
 

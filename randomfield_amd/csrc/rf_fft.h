@@ -46,14 +46,16 @@ struct ColCfg {
   static_assert(NT_ % TC_ == 0, "NT must be a multiple of the tile width");
   static constexpr int NPASS = (R2 == 1 ? 1 : (R3 == 1 ? 2 : 3));
   static constexpr int RL = (NPASS == 1 ? R1 : (NPASS == 2 ? R2 : R3));  // radix of the last pass
-  // LDS image [padded row][TC]: one pad row after every R1 rows, so that the stride-R1
-  // row pattern written by pass 1 walks through the banks
-  static constexpr int LDS_ROWS = (NPASS == 1 ? 0 : N + N / R1);
-  static constexpr int LDS_BYTES = LDS_ROWS * TC * (int)sizeof(cplx<T>);
+  // LDS image [row ^ swizzle][TC] -- no padding: bit 0 of the row is flipped by bit log2(R1), so the
+  // stride-R1 rows written by pass 1 alternate between the two 128-byte bank halves while runs of
+  // consecutive rows stay conflict free.  Behind the tile: the twiddle table, then the IO's tables.
+  static constexpr int TILE_BYTES = (NPASS == 1 ? 0 : N * TC * (int)sizeof(cplx<T>));
+  static constexpr int TW_BYTES = (NPASS == 1 ? 0 : N * (int)sizeof(cplx<T>));
+  static constexpr int LDS_BYTES = TILE_BYTES + TW_BYTES;      // + IO::LDS_EXTRA, added by the launcher
   static constexpr int IT1 = ceil_div(N / R1, BPI);
   static constexpr int IT2 = (NPASS == 3 ? ceil_div(N / R2, BPM) : 1);
   static constexpr int ITL = ceil_div(N / RL, BPI);
-  RF_HD static int prow(int r) { return r + r / R1; }
+  RF_HD static int prow(int r) { return r ^ ((r / R1) & 1); }
 };
 
 // Addressing of a column pass over the packed device array.
@@ -73,7 +75,12 @@ template <typename T> struct PlainColIO {
   RF_HD void store(long long C, int row, const V16<T>& v) const {
     *reinterpret_cast<V16<T>*>(base + addr(C, row)) = v;
   }
-  template <int R> RF_HD void fix(long long, int, int, cplx<T> (*)[R]) const {}
+  static constexpr int FIX_MODE = 0;
+  RF_HD bool needs_fix(long long) const { return false; }
+  RF_HD cplx<T> fix_value(long long, int) const { return cplx<T>(); }
+  static constexpr int LDS_EXTRA = 0;
+  RF_HD void prologue(int, int, void*) {}
+  RF_HD static void sched_fence() {}      // loads of one butterfly are meant to be issued back to back
 };
 
 // x pass fused with generation (rows K,T,R,S): load() synthesises the packed
@@ -109,39 +116,61 @@ template <typename T> struct GenColIO {
     const long long a = (C / g.inner) * g.outer_stride + (C % g.inner) + (long long)row * g.row_stride;
     *reinterpret_cast<V16<T>*>(base + a) = v;
   }
-  template <int R> RF_HD void fix(long long, int, int, cplx<T> (*)[R]) const {}
+  static constexpr int FIX_MODE = 0;
+  RF_HD bool needs_fix(long long) const { return false; }
+  RF_HD cplx<T> fix_value(long long, int) const { return cplx<T>(); }
+  static constexpr int LDS_EXTRA = 0;
+  RF_HD void prologue(int, int, void*) {}
+  RF_HD static void sched_fence() {}
 };
 
 // x pass fused with the fast float32 native generation (one Philox call per lane load)
-struct FastGenColIO {
+// FIX: 1 = this kernel repairs the kz = 0 slot (rolled loop through LDS); 0 = it does not (the tiles that
+// hold kz = 0 are then re-run by a FIX = 1 launch).  An out-of-line call was measured 3x slower (scratch).
+template <int AB = 0, int FIX = 1>
+struct FastGenColIOT {
   cplx<float>* base;
   ColGeom g;
   FastGenParams gp;
   int kz0, nzl;
+  const FastRec* rec;      // set by prologue(): LDS copy of the sigma records (or the global one)
+  static constexpr int LDS_EXTRA = FAST_LDS_BINS * (int)sizeof(FastRec);
+  // keep the compiler from interleaving all R generation bodies of a butterfly (register blow-up)
+  RF_HD static void sched_fence() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+  }
+  // stage the sigma records in LDS (every thread copies its share; the kernel barriers afterwards)
+  RF_HD void prologue(int tid, int nthreads, void* lds_extra) {
+    rec = gp.rec;
+    if (gp.nbins <= FAST_LDS_BINS) {
+      FastRec* l = reinterpret_cast<FastRec*>(lds_extra);
+      for (int i = tid; i < gp.nbins; i += nthreads) l[i] = gp.rec[i];
+      rec = l;
+    }
+  }
   RF_HD V16<float> load(long long C, int row) const {
     V16<float> v;
     const uint64_t seed = gp.seed_dev ? *gp.seed_dev : gp.seed;
     const int iy = (int)(C / nzl), kz = kz0 + (int)(C % nzl);
-    fast_gen_pair(gp, seed, row, iy, kz, v.c[0], v.c[1]);
+    fast_gen_pair<AB>(gp, rec, seed, row, iy, kz, v.c[0], v.c[1]);
     return v;
   }
-  // after the R loads of one butterfly (rows j + m*L): the lane that owns slot kz = 0 replaces its
-  // provisional cells by the packed, symmetrised (kz=0, kz=nz/2) pair -- one branch per butterfly
-  template <int R> RF_HD void fix(long long C, int j, int L, cplx<float> (*v)[R]) const {
-#ifndef RF_NO_FIX
-    if (kz0 + (int)(C % nzl) == 0) {
-      const uint64_t seed = gp.seed_dev ? *gp.seed_dev : gp.seed;
-      const int iy = (int)(C / nzl);
-#pragma unroll
-      for (int m = 0; m < R; ++m) v[0][m] = fast_fix_kz0(gp, seed, j + m * L, iy);
-    }
-#endif
+  // the lane that owns slot kz = 0 replaces its provisional first cell of every row by the packed,
+  // symmetrised (kz=0, kz=nz/2) pair (cold path: one lane in four of one tile in nz/16)
+  static constexpr int FIX_MODE = FIX;
+  RF_HD bool needs_fix(long long C) const { return FIX != 0 && kz0 + (int)(C % nzl) == 0; }
+  RF_HD cplx<float> fix_value(long long C, int row) const {
+    const uint64_t seed = gp.seed_dev ? *gp.seed_dev : gp.seed;
+    return fast_fix_kz0(gp, rec, seed, row, (int)(C / nzl));
   }
   RF_HD void store(long long C, int row, const V16<float>& v) const {
     const long long a = (C / g.inner) * g.outer_stride + (C % g.inner) + (long long)row * g.row_stride;
     *reinterpret_cast<V16<float>*>(base + a) = v;
   }
 };
+using FastGenColIO = FastGenColIOT<0, 1>;
 
 // ---------------------------------------------------------------------------
 // Column FFT phases.  `tw` = exp(+2 pi i q / N), q in [0, N).
@@ -160,6 +189,20 @@ struct ColFFT {
   }
   RF_HD static cx* lds_col(cx* lds, int row, int t) { return lds + (long long)C::prow(row) * C::TC + t; }
 
+  // LDS carve: [tile][twiddles][IO tables]
+  RF_HD static cx* lds_tw(cx* lds) { return lds + C::TILE_BYTES / (int)sizeof(cx); }
+  RF_HD static void* lds_io(cx* lds) { return lds + (C::TILE_BYTES + C::TW_BYTES) / (int)sizeof(cx); }
+  static constexpr bool HAS_PROLOGUE = (C::NPASS >= 2) || (IO::LDS_EXTRA > 0);
+
+  // prologue: stage the twiddle table (and the IO's own tables) in LDS; a barrier follows
+  RF_HD static void prologue(int tid, IO& io, const cx* tw, cx* lds) {
+    if (C::NPASS >= 2) {
+      cx* l = lds_tw(lds);
+      for (int i = tid; i < N; i += C::NT) l[i] = tw[i];
+    }
+    io.prologue(tid, C::NT, lds_io(lds));
+  }
+
   // pass 1: global -> R1 butterfly -> LDS (or straight back to global when N == R1)
   RF_HD static void pass_first(int tid, long long tile, const IO& io, cx* lds) {
     constexpr int R = C::R1, L = N / R;
@@ -175,8 +218,21 @@ struct ColFFT {
           V x = io.load(Ccol, j + m * L);
 #pragma unroll
           for (int c = 0; c < CPL; ++c) v[c][m] = x.c[c];
+          IO::sched_fence();
         }
-        io.template fix<R>(Ccol, j, L, v);
+        if (IO::FIX_MODE != 0 && io.needs_fix(Ccol)) {
+          if (C::NPASS == 1) {
+#pragma unroll
+            for (int m = 0; m < R; ++m) v[0][m] = io.fix_value(Ccol, j + m * L);
+          } else {
+            // rolled loop (one copy of the body); values are parked in this thread's own, still unused
+            // LDS output slots and read back with static register indices
+#pragma unroll 1
+            for (int m = 0; m < R; ++m) lds_at(lds, j * R + m, lp)->c[0] = io.fix_value(Ccol, j + m * L);
+#pragma unroll
+            for (int m = 0; m < R; ++m) v[0][m] = lds_at(lds, j * R + m, lp)->c[0];
+          }
+        }
 #pragma unroll
         for (int c = 0; c < CPL; ++c) DFT<R, DIR>::run(v[c]);
 #pragma unroll

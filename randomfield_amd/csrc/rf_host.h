@@ -34,18 +34,22 @@ inline void build_sigma_table(const double* log10k, const double* sigma, int n, 
   }
 }
 
-// Per-bin records of the fast float32 sigma lookup, restricted to [xlo, xhi] (the
-// grid's own log10 k range, padded).  Returns false if no bin count up to 65536
-// separates the knots (more than one knot per bin) -- the caller then uses the
-// exact kernel.
+// Per-bin records of the fast float32 sigma lookup over [xlo, xhi] (the grid's own log10 k range,
+// padded).  Tries the smallest power-of-two bin count >= 128 with at most one knot per bin (so that
+// the records fit LDS when possible); false if even 65536 bins do not separate the knots -- the
+// caller then uses the exact kernel.
 inline bool build_fast_records(const SigmaTableHost& t, double xlo, double xhi, std::vector<FastRec>& rec,
-                               float& x0, float& inv_dx, float& xmin, float& xmax) {
+                               double& x0, double& dx) {
   const int n = (int)t.xt.size();
+  // cells outside the table get sigma = 0 (powertools.py:155-157): when the requested range reaches a
+  // table edge, one all-zero guard bin is put beyond it (x below / above clamps into it)
+  const bool guard_lo = xlo <= t.xt[0], guard_hi = xhi >= t.xt[n - 1];
   xlo = std::max(xlo, t.xt[0]);
   xhi = std::min(xhi, t.xt[n - 1]);
   if (!(xhi > xlo)) return false;
-  for (int nbins = 512; nbins <= 65536; nbins *= 2) {
-    const double dx = (xhi - xlo) / nbins;
+  auto sigma_at = [&](double x, int j) { return t.sl[j] * (x - t.xt[j]) + t.st[j]; };
+  for (int nbins = 126; nbins <= 65536; nbins = (nbins + 2) * 2 - 2) {   // +2 guard bins stay within 2^k
+    dx = (xhi - xlo) / nbins;
     rec.assign(nbins, FastRec());
     bool ok = true;
     int j = 0;
@@ -53,21 +57,20 @@ inline bool build_fast_records(const SigmaTableHost& t, double xlo, double xhi, 
       const double e0 = xlo + b * dx, e1 = xlo + (b + 1) * dx;
       while (j + 1 < n - 1 && t.xt[j + 1] <= e0) ++j;          // interval containing e0
       FastRec& r = rec[b];
-      const int ja = j;
-      int jb = j;
-      r.xs = INFINITY;
-      if (ja + 1 < n - 1 && t.xt[ja + 1] < e1) {                 // a knot inside the bin
-        jb = ja + 1;
-        r.xs = (float)t.xt[jb];
-        if (jb + 1 < n - 1 && t.xt[jb + 1] < e1) ok = false;     // a second one: need finer bins
+      r.v0 = (float)sigma_at(e0, j);
+      r.sa = (float)(t.sl[j] * dx);
+      r.fs = 2.0f;
+      r.ds = 0.0f;
+      if (j + 1 < n - 1 && t.xt[j + 1] < e1) {                   // a knot inside the bin
+        r.fs = (float)((t.xt[j + 1] - e0) / dx);
+        r.ds = (float)((t.sl[j + 1] - t.sl[j]) * dx);
+        if (j + 2 < n - 1 && t.xt[j + 2] < e1) ok = false;       // a second one: need finer bins
       }
-      r.xa = (float)t.xt[ja]; r.sa = (float)t.st[ja]; r.sla = (float)t.sl[ja];
-      r.xb = (float)t.xt[jb]; r.sb = (float)t.st[jb]; r.slb = (float)t.sl[jb];
-      r.pad = 0.0f;
     }
     if (ok) {
-      x0 = (float)xlo; inv_dx = (float)(1.0 / dx);
-      xmin = (float)t.xt[0]; xmax = (float)t.xt[n - 1];
+      x0 = xlo;
+      if (guard_lo) { rec.insert(rec.begin(), FastRec{0.0f, 0.0f, 2.0f, 0.0f}); x0 -= dx; }
+      if (guard_hi) rec.push_back(FastRec{0.0f, 0.0f, 2.0f, 0.0f});
       return true;
     }
   }

@@ -4,21 +4,24 @@
 
 namespace rf {
 namespace {
+// runs tiles  b * tile_mul + tile_add,  b in [0, ntiles)
 template <class C, class IO>
-hipError_t launch_one(const IO& io, long long ncols, const cplx<typename C::T>* tw, hipStream_t s, bool prepare_only) {
+hipError_t launch_one(const IO& io, long long ncols, const cplx<typename C::T>* tw, hipStream_t s, bool prepare_only,
+                      long long ntiles_sub = -1, long long tile_mul = 1, long long tile_add = 0) {
   if (ncols % C::TC) return hipErrorInvalidValue;
-  const long long ntiles = ncols / C::TC;
+  const long long ntiles = ntiles_sub >= 0 ? ntiles_sub : ncols / C::TC;
   auto k = col_kernel<C, +1, IO>;
+  constexpr int lds_bytes = C::LDS_BYTES + IO::LDS_EXTRA;
   static bool prepared = false;
   if (!prepared) {
-    if (C::LDS_BYTES > 65536) {
-      hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    if (lds_bytes > 65536) {
+      hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
       if (e != hipSuccess) return e;
     }
     prepared = true;
   }
   if (prepare_only) return hipSuccess;
-  hipLaunchKernelGGL(k, dim3((unsigned)ntiles), dim3(C::NT), C::LDS_BYTES, s, io, tw, ntiles);
+  hipLaunchKernelGGL(k, dim3((unsigned)ntiles), dim3(C::NT), lds_bytes, s, io, tw, ntiles, tile_mul, tile_add);
   return hipGetLastError();
 }
 template <typename T>
@@ -26,7 +29,7 @@ hipError_t launch_t(int N, cplx<T>* W, ColGeom g, long long ncols, const GenPara
                     int kz0, int nzl, const cplx<T>* tw, hipStream_t s, bool po) {
   GenColIO<T> io; io.base = W; io.g = g; io.gp = gp; io.kspace = kspace; io.kz0 = kz0; io.nzl = nzl;
   switch (N) {
-#define X(NN) case NN: return launch_one<typename ColSel<T, NN>::type, GenColIO<T>>(io, ncols, tw, s, po);
+#define X(NN) case NN: return launch_one<typename GenSel<T, NN>::type, GenColIO<T>>(io, ncols, tw, s, po);
     RF_COL_SIZES(X)
 #undef X
     default: return hipErrorInvalidValue;
@@ -34,11 +37,30 @@ hipError_t launch_t(int N, cplx<T>* W, ColGeom g, long long ncols, const GenPara
 }
 }  // namespace
 
+// Fast float32 generation.  The kernel WITHOUT the kz = 0 repair runs over every tile; the tiles that
+// contain the kz = 0 slot (one per iy when a tile is narrower than a kz row) are then re-run by the
+// kernel WITH the repair, which carries the extra register pressure only where it is needed.
+template <class C>
+hipError_t launch_fast_one(const FastGenParams& gp, cplx<float>* W, ColGeom g, long long ncols, int kz0, int nzl,
+                           const cplx<float>* tw, hipStream_t s, bool po) {
+  FastGenColIOT<0, 0> io0; io0.base = W; io0.g = g; io0.gp = gp; io0.kz0 = kz0; io0.nzl = nzl; io0.rec = nullptr;
+  FastGenColIOT<0, 1> io1; io1.base = W; io1.g = g; io1.gp = gp; io1.kz0 = kz0; io1.nzl = nzl; io1.rec = nullptr;
+  const bool split = nzl > C::TC && nzl % C::TC == 0;
+  if (po) {
+    hipError_t e = launch_one<C, FastGenColIOT<0, 0>>(io0, ncols, tw, s, true);
+    return e != hipSuccess ? e : launch_one<C, FastGenColIOT<0, 1>>(io1, ncols, tw, s, true);
+  }
+  if (!split) return launch_one<C, FastGenColIOT<0, 1>>(io1, ncols, tw, s, false);
+  hipError_t e = launch_one<C, FastGenColIOT<0, 0>>(io0, ncols, tw, s, false);
+  if (e != hipSuccess || kz0 != 0) return e;                 // only the slab that owns kz = 0 needs the repair
+  const long long tiles_per_iy = nzl / C::TC;
+  return launch_one<C, FastGenColIOT<0, 1>>(io1, ncols, tw, s, false, ncols / nzl, tiles_per_iy, 0);
+}
+
 hipError_t launch_col_fastgen(int N, void* W, ColGeom g, long long ncols, const FastGenParams& gp, int kz0, int nzl,
                               const void* tw, hipStream_t s, bool po) {
-  FastGenColIO io; io.base = (cplx<float>*)W; io.g = g; io.gp = gp; io.kz0 = kz0; io.nzl = nzl;
   switch (N) {
-#define X(NN) case NN: return launch_one<typename ColSel<float, NN>::type, FastGenColIO>(io, ncols, (const cplx<float>*)tw, s, po);
+#define X(NN) case NN: return launch_fast_one<typename GenSel<float, NN>::type>(gp, (cplx<float>*)W, g, ncols, kz0, nzl, (const cplx<float>*)tw, s, po);
     RF_COL_SIZES(X)
 #undef X
     default: return hipErrorInvalidValue;

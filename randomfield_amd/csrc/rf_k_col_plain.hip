@@ -9,16 +9,17 @@ hipError_t launch_one(const IO& io, long long ncols, const cplx<typename C::T>* 
   if (ncols % C::TC) return hipErrorInvalidValue;
   const long long ntiles = ncols / C::TC;
   auto k = col_kernel<C, DIR, IO>;
+  constexpr int lds_bytes = C::LDS_BYTES + IO::LDS_EXTRA;
   static bool prepared = false;
   if (!prepared) {
-    if (C::LDS_BYTES > 65536) {
-      hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    if (lds_bytes > 65536) {
+      hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
       if (e != hipSuccess) return e;
     }
     prepared = true;
   }
   if (prepare_only) return hipSuccess;
-  hipLaunchKernelGGL(k, dim3((unsigned)ntiles), dim3(C::NT), C::LDS_BYTES, s, io, tw, ntiles);
+  hipLaunchKernelGGL(k, dim3((unsigned)ntiles), dim3(C::NT), lds_bytes, s, io, tw, ntiles, 1LL, 0LL);
   return hipGetLastError();
 }
 template <typename T, int DIR>

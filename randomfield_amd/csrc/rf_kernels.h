@@ -13,26 +13,43 @@ __device__ __forceinline__ long long xcd_tile(long long b, long long nb) {
   return (nb % 8 == 0) ? (b % 8) * (nb / 8) + b / 8 : b;
 }
 
+// waves per SIMD the register allocator must leave room for: as many workgroups per CU as the LDS
+// footprint admits (160 KiB), capped at 4 waves/SIMD (128 VGPRs) so radix-16 butterflies never spill
+template <class C, class IO>
+constexpr int col_min_waves() {
+  constexpr int lds = C::LDS_BYTES + IO::LDS_EXTRA;
+  constexpr int blocks = lds > 0 ? (163840 / lds > 0 ? 163840 / lds : 1) : 8;
+  constexpr int w = blocks * C::NT / 256;
+  return w < 1 ? 1 : (w > 4 ? 4 : w);
+}
+
 template <class C, int DIR, class IO>
-__global__ __launch_bounds__(C::NT) void col_kernel(IO io, const cplx<typename C::T>* __restrict__ tw,
-                                                    long long ntiles) {
+__global__ __launch_bounds__(C::NT, (col_min_waves<C, IO>())) void col_kernel(IO io, const cplx<typename C::T>* __restrict__ tw,
+                                                                           long long ntiles, long long tile_mul,
+                                                                           long long tile_add) {
   using F = ColFFT<C, DIR, IO>;
   using cx = cplx<typename C::T>;
   extern __shared__ __attribute__((aligned(16))) char rf_smem[];
   cx* lds = reinterpret_cast<cx*>(rf_smem);
   const int tid = threadIdx.x;
-  const long long tile = xcd_tile(blockIdx.x, ntiles);
+  const long long tile = xcd_tile(blockIdx.x, ntiles) * tile_mul + tile_add;   // (1, 0) unless a tile subset is run
+  const cx* ltw = tw;
+  if (F::HAS_PROLOGUE) {
+    F::prologue(tid, io, tw, lds);          // twiddles (+ the IO's tables) -> LDS
+    if (C::NPASS >= 2) ltw = F::lds_tw(lds);
+    if (IO::LDS_EXTRA > 0) __syncthreads(); // pass 1 reads the IO tables; the twiddles are first read after the next barrier
+  }
   F::pass_first(tid, tile, io, lds);
   if (C::NPASS == 3) {
     typename F::Regs r;
     __syncthreads();
-    F::pass_mid_read(tid, tw, lds, r);
+    F::pass_mid_read(tid, ltw, lds, r);
     __syncthreads();
     F::pass_mid_write(tid, lds, r);
   }
   if (C::NPASS >= 2) {
     __syncthreads();
-    F::pass_last(tid, tile, io, tw, lds);
+    F::pass_last(tid, tile, io, ltw, lds);
   }
 }
 

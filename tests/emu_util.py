@@ -96,7 +96,7 @@ def realise_fast(nx, ny, nz, spacing, log10k, sigma, seed):
     out = np.empty((nx, ny, nz), np.float32)
     s1, s2 = ctypes.c_double(), ctypes.c_double()
     rc = lib().emu_realise_fast(nx, ny, nz, *args[:6], ctypes.c_uint64(seed), ctypes.c_double(xlo),
-                                ctypes.c_double(xhi), out.ctypes.data_as(ctypes.c_void_p), ctypes.byref(s1),
-                                ctypes.byref(s2))
+                                ctypes.c_double(xhi), ctypes.c_double(k0 / nx),
+                                out.ctypes.data_as(ctypes.c_void_p), ctypes.byref(s1), ctypes.byref(s2))
     assert rc == 0, rc
     return out, s1.value, s2.value
