@@ -122,6 +122,18 @@ def main():
         names[1], alg[1] = "y+z passes (FFT in place, slab-interleaved) ", 4 * sweep
     dom = int(np.argmax(kern[:3]))
     achieved = alg[dom] / (kern[dom] * 1e-3) / 1e9
+    # HBM bytes per launch of that kernel from the committed rocprofv3 --pmc passes (profiles/), if they
+    # were taken on this grid; bench.py itself cannot run the profiler
+    traffic = None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
+        key = ["FastGenColIOT<0, 0>", "PlainColIO", "row_c2r_kernel"][dom]
+        if (nx, ny, nz) == (1024, 1024, 1024) and args.gpus == 1:
+            for name, v in tj["kernels"].items():
+                if key in name:
+                    traffic = v["total"]
+    except Exception:
+        traffic = None
     out = {
         "metric": "Mcells/s for N^3 delta(x) realisation",
         "value": round(cells * args.steps / wall / 1e6, 1),
@@ -139,7 +151,7 @@ def main():
                      "kernel_ms": {"x": round(float(kern[0]), 4), "y": round(float(kern[1]), 4),
                                    "z": round(float(kern[2]), 4), "reduce": round(float(kern[3]), 4)}},
         "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "algorithmic_bytes_per_launch": alg[dom], "avg_ms": round(float(kern[dom]), 4)},
     }
     if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
