@@ -2,7 +2,7 @@
 """
 bench.py -- Mcells/s for N^3 delta(x) realisations on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--n 1024] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--edge 1024] [--no-cpu-baseline]
 
 One "step" = one realisation seed -> delta(x) resident in HBM + rms
 (generate_delta_field(save_potential=False) semantics: rows K,T,R,S fused into
@@ -55,14 +55,67 @@ def cpu_baseline(power, spacing, sample_n):
             "rms": float(rms)}
 
 
+def main_multi(args, rank, world, local_rank, shape, power, spacing):
+    """N > 1: one process per GPU, kz-slab / x-slab decomposition with one RCCL all-to-all per realisation.
+    No torch in these processes: the unique id travels through a file, barriers and the max over ranks
+    through RCCL (randomfield_amd/slab.py)."""
+    from randomfield_amd import powertools, slab
+    nx, ny, nz = shape
+    dplan = slab.DistributedPlan(nx, ny, nz, np.complex64, device=local_rank, rank=rank, world=world)
+    plan = dplan.plan
+    plan.set_kgrid(*powertools.ksq_axes(nx, ny, nz, spacing))
+    plan.set_power(*powertools.sigma_table(power, (nx, ny, nz), spacing))
+    for i in range(max(args.warmup, 1)):
+        plan.realise(seed=1000 + i)
+    plan.sync()
+    dplan.barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        plan.realise(seed=123 + i)
+    plan.sync()
+    dplan.barrier()
+    wall = time.perf_counter() - t0
+    kern = np.array(plan.kernel_ms())                  # last step: x, y, exchange+z, all-reduce
+    wall = float(dplan.allreduce([wall], op="max")[0])
+    mean, std = plan.moments()
+    cells = float(nx) * ny * nz
+    sweep = 8.0 * nx * ny * (nz // 2 + 1)
+    xgmi_bytes = (world - 1) / world * sweep / world     # all-to-all egress per GPU
+    out = {
+        "metric": "Mcells/s for N^3 delta(x) realisation",
+        "value": round(cells * args.steps / wall / 1e6, 1), "unit": "Mcells/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(wall / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%dx%dx%d float32 delta(x) realisations, kz-slab/x-slab decomposition over %d GPUs, "
+                               "one RCCL all-to-all per realisation, native Philox4x32-10 RNG, shipped 500-row P(k)"
+                               % (nx, ny, nz, world), "grid": [nx, ny, nz], "rms_last": round(std, 6)},
+        "pipeline": {"algorithmic_GBs": round(5 * sweep * args.steps / wall / 1e9, 1),
+                     "frac_of_hbm_peak": round(5 * sweep * args.steps / wall / 1e9 / (HBM_PEAK_GBS * world), 4),
+                     "kernel_ms_rank0_last_step": {"x": round(float(kern[0]), 4), "y": round(float(kern[1]), 4),
+                                                   "exchange+z": round(float(kern[2]), 4),
+                                                   "allreduce": round(float(kern[3]), 4)},
+                     "xgmi_egress_bytes_per_gpu": xgmi_bytes},
+        "roofline": {"bound": "hbm", "kernel": "whole pipeline (5 sweeps) over %d GPUs" % world,
+                     "achieved": round(5 * sweep * args.steps / wall / 1e9, 1), "peak": HBM_PEAK_GBS * world,
+                     "unit": "GB/s", "frac": round(5 * sweep * args.steps / wall / 1e9 / (HBM_PEAK_GBS * world), 4),
+                     "traffic": None},
+    }
+    dplan.barrier()
+    plan.close()
+    if rank == 0:
+        print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--n", type=int, default=1024, help="per-GPU cube edge")
+    ap.add_argument("--edge", type=int, default=1024, help="per-GPU cube edge")
     ap.add_argument("--cpu-sample", type=int, default=512, help="cube edge of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-multi", action="store_true", help="debug: run the N>1 code path with one rank")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -77,15 +130,11 @@ def main():
     from randomfield_amd import _hip, powertools
     _hip.require_gpu()                              # no GPU / no library -> loud failure, never a CPU run
 
-    dist = None
-    if world > 1:
-        import torch.distributed as dist           # plumbing only: rendezvous, barrier, max over ranks
-        dist.init_process_group(backend="gloo")
-        sys.exit("multi-GPU slab exchange is not built yet")
-
     spacing = 2.5
-    nx, ny, nz = grid_for(args.gpus, args.n)
+    nx, ny, nz = grid_for(args.gpus, args.edge)
     power = powertools.load_default_power()
+    if world > 1 or args.force_multi:
+        return main_multi(args, rank, world, local_rank, (nx, ny, nz), power, spacing)
     plan = _hip.DevicePlan(nx, ny, nz, np.complex64, device=local_rank)
     plan.set_kgrid(*powertools.ksq_axes(nx, ny, nz, spacing))
     plan.set_power(*powertools.sigma_table(power, (nx, ny, nz), spacing))

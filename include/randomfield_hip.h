@@ -123,6 +123,17 @@ int rf_kernel_ms(rf_plan* plan, float* ms4);
  * (torch.distributed / a file / MPI ...).  No-op requirement for nranks == 1. */
 int rf_comm_unique_id(void* id128);
 int rf_comm_init(rf_plan* plan, const void* id128);
+/* host-side all-reduce of 1 or 2 doubles over the plan's communicator (op 0 = sum, 1 = max), after all
+ * queued work of the plan: doubles as a barrier.  With one rank it only synchronises the stream. */
+int rf_comm_allreduce_f64(rf_plan* plan, double* inout, int n, int op);
+/* The slab pipeline in separate steps, for tests and custom exchanges: forward = generation + x and y
+ * passes on this rank's kz slab; backward = z pass on this rank's x slab + local (sum, sumsq).
+ * rf_slab_exchange_local performs the all-to-all between n "virtual ranks" that live on ONE device
+ * (plain device copies, no RCCL): it checks layouts and kernels where only one GPU is available. */
+int rf_slab_forward(rf_plan* plan, uint64_t seed, int mode, const double* noise_host);
+int rf_slab_exchange_local(rf_plan** plans, int n);
+int rf_slab_backward(rf_plan* plan);
+int rf_slab_stats(rf_plan* plan, double* sum, double* sumsq);
 
 #ifdef __cplusplus
 }

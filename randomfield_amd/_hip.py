@@ -59,6 +59,11 @@ SIGNATURES = {
     "rf_kernel_ms": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]),
     "rf_comm_unique_id": (ctypes.c_int, [ctypes.c_void_p]),
     "rf_comm_init": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "rf_comm_allreduce_f64": (ctypes.c_int, [ctypes.c_void_p, _c_dp, ctypes.c_int, ctypes.c_int]),
+    "rf_slab_forward": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, _c_dp]),
+    "rf_slab_exchange_local": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int]),
+    "rf_slab_backward": (ctypes.c_int, [ctypes.c_void_p]),
+    "rf_slab_stats": (ctypes.c_int, [ctypes.c_void_p, _c_dp, _c_dp]),
 }
 
 _lib = None
@@ -134,6 +139,8 @@ class DevicePlan(object):
         if dtype not in (np.dtype(np.complex64), np.dtype(np.complex128)):
             raise ValueError("DevicePlan dtype must be complex64 or complex128: %r" % (dtype,))
         self.nx, self.ny, self.nz = int(nx), int(ny), int(nz)
+        self.nranks, self.rank = int(nranks), int(rank)
+        self.nx_local = self.nx // self.nranks          # x planes of the real-space field held by this rank
         self.complex_dtype = dtype
         self.real_dtype = np.dtype(np.float32 if dtype == np.complex64 else np.float64)
         self._h = ctypes.c_void_p()
@@ -258,7 +265,8 @@ class DevicePlan(object):
                                        LAYOUT_PADDED if padded else LAYOUT_DENSE), "rf_upload_real")
 
     def download_real(self, out=None, padded=False, x0=0, x1=None):
-        x1 = self.nx if x1 is None else x1
+        """Rows x0 <= ix < x1 (local plane indices on multi-GPU plans) of the real-space field."""
+        x1 = self.nx_local if x1 is None else x1
         nzp = self.nz + 2 if padded else self.nz
         if out is None:
             out = np.empty((x1 - x0, self.ny, nzp), self.real_dtype)
@@ -272,6 +280,44 @@ class DevicePlan(object):
     def device_ptrs(self):
         a, b = ctypes.c_void_p(), ctypes.c_void_p()
         check(self._lib.rf_device_ptr(self._h, ctypes.byref(a), ctypes.byref(b)), "rf_device_ptr")
+        return a.value, b.value
+
+    # -- multi-GPU -------------------------------------------------------
+    @staticmethod
+    def comm_unique_id():
+        """128-byte RCCL unique id (call on rank 0, hand to every rank's comm_init)."""
+        buf = ctypes.create_string_buffer(128)
+        check(load().rf_comm_unique_id(buf), "rf_comm_unique_id")
+        return buf.raw
+
+    def comm_init(self, unique_id):
+        buf = ctypes.create_string_buffer(bytes(unique_id), 128)
+        check(self._lib.rf_comm_init(self._h, buf), "rf_comm_init")
+
+    def allreduce(self, values, op="sum"):
+        """All-reduce 1 or 2 host doubles over the plan's RCCL communicator (also a barrier)."""
+        a = np.ascontiguousarray(np.atleast_1d(values), dtype=np.float64).copy()
+        check(self._lib.rf_comm_allreduce_f64(self._h, _dp(a), len(a), 0 if op == "sum" else 1), "rf_comm_allreduce_f64")
+        return a
+
+    def barrier(self):
+        self.allreduce([0.0])
+
+    def slab_forward(self, seed=0, noise=None):
+        mode, ptr, keep = self._noise_arg(noise)
+        check(self._lib.rf_slab_forward(self._h, ctypes.c_uint64(int(seed) & (2 ** 64 - 1)), mode, ptr), "rf_slab_forward")
+
+    @staticmethod
+    def slab_exchange_local(plans):
+        arr = (ctypes.c_void_p * len(plans))(*[p._h.value for p in plans])
+        check(load().rf_slab_exchange_local(arr, len(plans)), "rf_slab_exchange_local")
+
+    def slab_backward(self):
+        check(self._lib.rf_slab_backward(self._h), "rf_slab_backward")
+
+    def slab_stats(self):
+        a, b = ctypes.c_double(), ctypes.c_double()
+        check(self._lib.rf_slab_stats(self._h, ctypes.byref(a), ctypes.byref(b)), "rf_slab_stats")
         return a.value, b.value
 
     # -- sync / timing ----------------------------------------------------

@@ -9,6 +9,8 @@
 #include <string>
 #include <vector>
 
+#include <rccl/rccl.h>
+
 #include "../../include/randomfield_hip.h"
 #include "rf_host.h"
 #include "rf_launch.h"
@@ -37,26 +39,63 @@ int fail(int code, const std::string& msg) {
     if (!(cond)) return fail(1, msg); \
   } while (0)
 
-// RCCL entry points, resolved lazily with dlopen so that single-GPU use never
-// depends on librccl being loadable.
+// RCCL entry points, resolved lazily with dlopen so that single-GPU use never depends on librccl
+// being loadable (types and enums come from <rccl/rccl.h>, no link-time dependency).
 struct Rccl {
   void* lib = nullptr;
-  int (*GetUniqueId)(void*) = nullptr;
-  int (*CommInitRank)(void**, int, const void* /* ncclUniqueId by value: 128 bytes */, int) = nullptr;
-  int (*CommDestroy)(void*) = nullptr;
-  int (*GroupStart)() = nullptr;
-  int (*GroupEnd)() = nullptr;
-  int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
-  int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
-  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
-  const char* (*GetErrorString)(int) = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 Rccl g_rccl;
+
+int load_rccl() {
+  if (g_rccl.lib) return 0;
+  // If an RCCL is already in the process (e.g. the one bundled with PyTorch, which comes with its own HIP /
+  // HSA runtime) it must be THAT one: a second librccl would talk to a second, uninitialised HSA runtime.
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"};
+  void* h = nullptr;
+  for (const char* n : names) { h = dlopen(n, RTLD_NOW | RTLD_NOLOAD); if (h) break; }
+  if (!h)
+    for (const char* n : names) { h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+  if (!h) return fail(4, std::string("cannot load librccl: ") + dlerror());
+#define RF_SYM(field, name)                                                        \
+  g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(h, name));         \
+  if (!g_rccl.field) return fail(4, std::string("librccl lacks ") + name);
+  RF_SYM(GetUniqueId, "ncclGetUniqueId")
+  RF_SYM(CommInitRank, "ncclCommInitRank")
+  RF_SYM(CommDestroy, "ncclCommDestroy")
+  RF_SYM(GroupStart, "ncclGroupStart")
+  RF_SYM(GroupEnd, "ncclGroupEnd")
+  RF_SYM(Send, "ncclSend")
+  RF_SYM(Recv, "ncclRecv")
+  RF_SYM(AllReduce, "ncclAllReduce")
+  RF_SYM(GetErrorString, "ncclGetErrorString")
+#undef RF_SYM
+  g_rccl.lib = h;
+  return 0;
+}
+
+#define RF_NCCL(expr)                                                                                   \
+  do {                                                                                                  \
+    ncclResult_t r_ = (expr);                                                                           \
+    if (r_ != ncclSuccess)                                                                              \
+      return fail(5, std::string(#expr) + " failed: " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "?")); \
+  } while (0)
 
 }  // namespace
 
 struct rf_plan {
   int nx = 0, ny = 0, nz = 0, nzc = 0, f64 = 0, device = 0, nranks = 1, rank = 0;
+  int nxl = 0, nzl = 0, kz0 = 0;          // this rank's x-slab height, kz-slab width and first kz plane
+  void* R = nullptr;                      // receive buffer of the all-to-all (multi-rank plans only)
+  ncclComm_t comm = nullptr;
   size_t csize = 8;                       // bytes per complex element
   hipStream_t own_stream = nullptr, stream = nullptr;
   void* W = nullptr;                      // [nx][ny][nz] real == [nx][ny][nz/2] complex (packed Nyquist)
@@ -183,14 +222,51 @@ int build_fast(rf_plan* p) {
 
 // x pass (generation or API k-space fused into its load) into buffer W on stream sx
 int queue_x(rf_plan* p, const GenParams& gp, const void* kspace, void* W, hipStream_t sx) {
-  const long long nzc = p->nzc;
-  const ColGeom gx{(long long)p->ny * nzc, 0, (long long)p->ny * nzc};
+  const long long nzl = p->nzl;     // kz planes held by this rank (nz/2 on one GPU)
+  const ColGeom gx{(long long)p->ny * nzl, 0, (long long)p->ny * nzl};
   const bool fast = !kspace && gp.noise_mode == NOISE_PHILOX && p->have_fast && !p->exact_gen;
   if (fast)
-    RF_HIP(launch_col_fastgen(p->nx, W, gx, (long long)p->ny * nzc, make_fast(p, gp.seed, gp.seed_dev != nullptr, gp.seed_dev), 0,
-                              (int)nzc, p->tw_x, sx));
+    RF_HIP(launch_col_fastgen(p->nx, W, gx, (long long)p->ny * nzl, make_fast(p, gp.seed, gp.seed_dev != nullptr, gp.seed_dev),
+                              p->kz0, (int)nzl, p->tw_x, sx));
   else
-    RF_HIP(launch_col_gen(p->f64, p->nx, W, gx, (long long)p->ny * nzc, gp, kspace, 0, (int)nzc, p->tw_x, sx));
+    RF_HIP(launch_col_gen(p->f64, p->nx, W, gx, (long long)p->ny * nzl, gp, kspace, p->kz0, (int)nzl, p->tw_x, sx));
+  return 0;
+}
+
+// multi-rank: y pass on the local kz slab [nx][ny][nzl]
+int queue_y_slab(rf_plan* p, hipStream_t s) {
+  const long long nzl = p->nzl;
+  const ColGeom gy{nzl, (long long)p->ny * nzl, nzl};
+  RF_HIP(launch_col_plain(p->f64, p->ny, +1, p->W, gy, (long long)p->nx * nzl, p->tw_y, s));
+  return 0;
+}
+
+// multi-rank: z pass on the local x slab, rows gathered from the P received blocks in R; output
+// (dense real [nxl][ny][nz]) into W, then the local (sum, sumsq)
+int queue_z_slab(rf_plan* p, hipStream_t s) {
+  const long long nrows = (long long)p->nxl * p->ny;
+  const double scale = 1.0 / ((double)p->nx * (double)p->ny * (double)p->nz);
+  RF_HIP(launch_row_c2r_gather(p->f64, p->nzc, p->R, p->W, nrows, scale, p->nzl, nrows * p->nzl, p->tw_z, p->partials, s));
+  RF_HIP(launch_reduce_partials(p->partials, p->npartials, p->stats, nullptr, s));
+  p->cur = p->W;
+  p->stats_slot = 0;
+  p->real_valid = true;
+  return 0;
+}
+
+// multi-rank: the single all-to-all between the y and z passes.  Rank g sends to rank h the block
+// [x in slab h][all y][kz in slab g], which is contiguous in W because x is the slowest axis.
+int queue_exchange_rccl(rf_plan* p, hipStream_t s) {
+  RF_REQUIRE(p->comm != nullptr, "rf_comm_init has not been called on this multi-rank plan");
+  const size_t blk = (size_t)p->nxl * p->ny * p->nzl * p->csize;
+  RF_HIP(hipMemcpyAsync((char*)p->R + p->rank * blk, (char*)p->W + p->rank * blk, blk, hipMemcpyDeviceToDevice, s));
+  RF_NCCL(g_rccl.GroupStart());
+  for (int h = 0; h < p->nranks; ++h) {
+    if (h == p->rank) continue;
+    RF_NCCL(g_rccl.Send((char*)p->W + h * blk, blk, ncclUint8, h, p->comm, s));
+    RF_NCCL(g_rccl.Recv((char*)p->R + h * blk, blk, ncclUint8, h, p->comm, s));
+  }
+  RF_NCCL(g_rccl.GroupEnd());
   return 0;
 }
 
@@ -221,6 +297,18 @@ int queue_c2r(rf_plan* p, const GenParams& gp, const void* kspace) {
   if (p->timed) RF_HIP(hipEventRecord(p->ev[0], p->stream));
   if (int rc = queue_x(p, gp, kspace, p->W, p->stream)) return rc;
   if (p->timed) RF_HIP(hipEventRecord(p->ev[1], p->stream));
+  if (p->nranks > 1) {
+    if (int rc = queue_y_slab(p, p->stream)) return rc;
+    if (p->timed) RF_HIP(hipEventRecord(p->ev[2], p->stream));
+    if (int rc = queue_exchange_rccl(p, p->stream)) return rc;
+    if (int rc = queue_z_slab(p, p->stream)) return rc;
+    if (p->timed) RF_HIP(hipEventRecord(p->ev[3], p->stream));
+    // global (sum, sumsq): one 2-double all-reduce
+    RF_NCCL(g_rccl.AllReduce(p->stats, p->stats, 2, ncclFloat64, ncclSum, p->comm, p->stream));
+    if (p->timed) RF_HIP(hipEventRecord(p->ev[4], p->stream));
+    p->stats_valid = true;
+    return 0;
+  }
   if (int rc = queue_yz(p, p->W, p->stream, p->stats, p->timed)) return rc;
   p->cur = p->W;
   p->stats_slot = 0;
@@ -238,7 +326,7 @@ template <typename T> int upload_twiddles(void** dst, int n) {
   return 0;
 }
 
-int shape_check(int nx, int ny, int nz, int f64, std::string* why) {
+int shape_check(int nx, int ny, int nz, int f64, std::string* why, int nranks = 1) {
   auto bad = [&](const std::string& m) { if (why) *why = m; return 1; };
   if (nx <= 0 || ny <= 0 || nz <= 0) return bad("grid dimensions must be positive");
   if (nz % 4) return bad("nz must be a multiple of 4 (packed layout, transform.py:53-56)");
@@ -246,8 +334,11 @@ int shape_check(int nx, int ny, int nz, int f64, std::string* why) {
     return bad("HIP path needs nx, ny in {8,16,...,2048} (powers of two)");
   if (!row_size_supported(nz / 2)) return bad("HIP path needs nz in {16,32,...,2048} (powers of two)");
   const long long nzc = nz / 2;
-  if (((long long)ny * nzc) % col_tile_cols(f64, nx)) return bad("ny*nz/2 is not a multiple of the x-pass tile width");
-  if (((long long)nx * nzc) % col_tile_cols(f64, ny)) return bad("nx*nz/2 is not a multiple of the y-pass tile width");
+  if (nranks > 1 && (nx % nranks || nzc % nranks || (nzc / nranks) % 2))
+    return bad("nx and nz/2 must be divisible by the number of ranks (and nz/(2*ranks) must be even)");
+  const long long nzl = nzc / nranks;
+  if (((long long)ny * nzl) % col_tile_cols(f64, nx)) return bad("ny*nz/(2*ranks) is not a multiple of the x-pass tile width");
+  if (((long long)nx * nzl) % col_tile_cols(f64, ny)) return bad("nx*nz/(2*ranks) is not a multiple of the y-pass tile width");
   return 0;
 }
 
@@ -274,22 +365,22 @@ int rf_plan_create(rf_plan** out, int nx, int ny, int nz, int dtype, int device,
   *out = nullptr;
   RF_REQUIRE(dtype == RF_F32 || dtype == RF_F64, "dtype must be RF_F32 or RF_F64");
   std::string why;
-  if (shape_check(nx, ny, nz, dtype, &why)) return fail(1, "unsupported shape: " + why);
   RF_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "invalid nranks/rank");
-  RF_REQUIRE(nranks == 1, "multi-rank plans are created with rf_plan_create + rf_comm_init (not built yet)");
+  if (shape_check(nx, ny, nz, dtype, &why, nranks)) return fail(1, "unsupported shape: " + why);
   RF_HIP(hipSetDevice(device));
   rf_plan* p = new rf_plan();
   p->nx = nx; p->ny = ny; p->nz = nz; p->nzc = nz / 2; p->f64 = dtype; p->device = device;
   p->nranks = nranks; p->rank = rank;
   p->csize = dtype ? 16 : 8;
-  p->w_bytes = (size_t)nx * ny * p->nzc * p->csize;
+  p->nxl = nx / nranks; p->nzl = p->nzc / nranks; p->kz0 = rank * p->nzl;
+  p->w_bytes = (size_t)nx * ny * p->nzl * p->csize;       // == nxl * ny * nzc: the local share of the field
   p->k_bytes = (size_t)nx * ny * (p->nzc + 1) * p->csize;
   auto cleanup = [&](int rc) { rf_plan_destroy(p); return rc; };
   hipError_t e;
   if ((e = hipStreamCreateWithFlags(&p->own_stream, hipStreamNonBlocking)) != hipSuccess)
     return cleanup(fail(2, std::string("hipStreamCreate: ") + hipGetErrorString(e)));
   p->stream = p->own_stream;
-  if ((e = hipMalloc(&p->W, p->w_bytes)) != hipSuccess)
+  if ((e = hipMalloc(&p->W, p->w_bytes)) != hipSuccess || (nranks > 1 && (e = hipMalloc(&p->R, p->w_bytes)) != hipSuccess))
     return cleanup(fail(2, std::string("hipMalloc field buffer: ") + hipGetErrorString(e)));
   int rc = 0;
   if (dtype) {
@@ -313,7 +404,10 @@ int rf_plan_create(rf_plan** out, int nx, int ny, int nz, int dtype, int device,
     if (S > 0) { int q = 1; while (q * 2 <= S) q *= 2; S = q; }    // power of two so that it divides nx
     p->slab_planes = S;
   }
-  {
+  if (nranks > 1) {
+    p->slab_planes = 0;
+    p->npartials = row_c2r_tiles(dtype, p->nzc, (long long)p->nxl * ny);
+  } else {
     const int S = p->slab_planes > 0 ? p->slab_planes : nx;
     p->npartials = row_c2r_tiles(dtype, p->nzc, (long long)S * ny) * ((nx + S - 1) / S);
   }
@@ -333,13 +427,15 @@ int rf_plan_create(rf_plan** out, int nx, int ny, int nz, int dtype, int device,
     if ((e = hipEventCreate(&ev)) != hipSuccess) return cleanup(fail(2, std::string("hipEventCreate: ") + hipGetErrorString(e)));
   {  // function attributes (dynamic LDS above 64 KB) are set here, never inside a graph capture
     GenParams gp0; memset(&gp0, 0, sizeof(gp0)); gp0.nx = nx; gp0.ny = ny; gp0.nz = nz;
-    const long long nzc = p->nzc;
-    const ColGeom gx{(long long)ny * nzc, 0, (long long)ny * nzc}, gy{nzc, (long long)ny * nzc, nzc};
+    const long long nzc = p->nzc, nzl = p->nzl;
+    const ColGeom gx{(long long)ny * nzl, 0, (long long)ny * nzl}, gy{nzl, (long long)ny * nzl, nzl};
     FastGenParams fp0; memset(&fp0, 0, sizeof(fp0)); fp0.nx = nx; fp0.ny = ny; fp0.nz = nz;
-    if ((e = launch_col_gen(dtype, nx, p->W, gx, (long long)ny * nzc, gp0, nullptr, 0, (int)nzc, p->tw_x, p->stream, true)) != hipSuccess ||
-        (!dtype && (e = launch_col_fastgen(nx, p->W, gx, (long long)ny * nzc, fp0, 0, (int)nzc, p->tw_x, p->stream, true)) != hipSuccess) ||
-        (e = launch_col_plain(dtype, ny, +1, p->W, gy, (long long)nx * nzc, p->tw_y, p->stream, true)) != hipSuccess ||
-        (e = launch_row_c2r(dtype, (int)nzc, p->W, (long long)nx * ny, 1.0, p->tw_z, p->partials, p->stream, true)) != hipSuccess)
+    if ((e = launch_col_gen(dtype, nx, p->W, gx, (long long)ny * nzl, gp0, nullptr, 0, (int)nzl, p->tw_x, p->stream, true)) != hipSuccess ||
+        (!dtype && (e = launch_col_fastgen(nx, p->W, gx, (long long)ny * nzl, fp0, 0, (int)nzl, p->tw_x, p->stream, true)) != hipSuccess) ||
+        (e = launch_col_plain(dtype, ny, +1, p->W, gy, (long long)nx * nzl, p->tw_y, p->stream, true)) != hipSuccess ||
+        (e = launch_row_c2r(dtype, (int)nzc, p->W, (long long)p->nxl * ny, 1.0, p->tw_z, p->partials, p->stream, true)) != hipSuccess ||
+        (nranks > 1 && (e = launch_row_c2r_gather(dtype, (int)nzc, p->R, p->W, (long long)p->nxl * ny, 1.0, (int)nzl, (long long)p->nxl * ny * nzl,
+                                                  p->tw_z, p->partials, p->stream, true)) != hipSuccess))
       return cleanup(fail(2, std::string("kernel preparation: ") + hipGetErrorString(e)));
   }
   *out = p;
@@ -351,7 +447,8 @@ int rf_plan_destroy(rf_plan* p) {
   (void)hipSetDevice(p->device);
   if (p->stream) (void)hipStreamSynchronize(p->stream);
   drop_graphs(p);
-  void* bufs[] = {p->W, p->K, p->P, p->tw_x, p->tw_y, p->tw_z, p->kx2, p->ky2, p->kz2, p->xt, p->st, p->sl, p->bin,
+  if (p->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(p->comm);
+  void* bufs[] = {p->W, p->R, p->K, p->P, p->tw_x, p->tw_y, p->tw_z, p->kx2, p->ky2, p->kz2, p->xt, p->st, p->sl, p->bin,
                   p->noise, p->partials, p->stats, p->seed_cur, p->seeds_dev, p->counter, p->ztab, p->ky2f,
                   p->kz2f, p->frec};
   for (void* b : bufs)
@@ -365,7 +462,7 @@ int rf_plan_destroy(rf_plan* p) {
 
 int rf_plan_nbytes(rf_plan* p, size_t* nbytes) {
   RF_REQUIRE(p && nbytes, "null argument");
-  *nbytes = p->w_bytes + (p->K ? p->k_bytes : 0) + (p->P ? p->k_bytes : 0);
+  *nbytes = p->w_bytes + (p->R ? p->w_bytes : 0) + (p->K ? p->k_bytes : 0) + (p->P ? p->k_bytes : 0);
   return 0;
 }
 
@@ -433,6 +530,7 @@ int rf_set_power(rf_plan* p, const double* log10k, const double* sigma, int n) {
 
 int rf_generate(rf_plan* p, uint64_t seed, int mode, const double* noise_host) {
   RF_REQUIRE(p, "null plan");
+  RF_REQUIRE(p->nranks == 1, "k-space buffer operations are single-GPU only");
   RF_REQUIRE(p->have_kgrid && p->have_power, "rf_set_kgrid and rf_set_power must be called first");
   RF_REQUIRE(mode == RF_NOISE_NATIVE || mode == RF_NOISE_EXTERNAL, "invalid noise mode");
   RF_HIP(hipSetDevice(p->device));
@@ -446,6 +544,7 @@ int rf_generate(rf_plan* p, uint64_t seed, int mode, const double* noise_host) {
 
 int rf_execute_c2r(rf_plan* p) {
   RF_REQUIRE(p, "null plan");
+  RF_REQUIRE(p->nranks == 1, "k-space buffer operations are single-GPU only");
   RF_REQUIRE(p->K && p->k_valid, "no k-space data: call rf_generate or rf_upload_k first");
   RF_HIP(hipSetDevice(p->device));
   GenParams gp;
@@ -489,6 +588,7 @@ static int batch_issue(rf_plan* p, int n) {
 // MI355X and gave nothing: an x-pass and a y-pass kernel do not co-execute profitably -- DESIGN.md.)
 static int batch_prepare(rf_plan* p, int n) {
   RF_REQUIRE(n >= 1, "need at least one seed");
+  RF_REQUIRE(p->nranks == 1, "graph-captured batches are single-GPU; loop rf_realise on multi-GPU plans");
   RF_REQUIRE(p->have_kgrid && p->have_power, "rf_set_kgrid and rf_set_power must be called first");
   RF_HIP(hipSetDevice(p->device));
   if (p->seeds_cap < n || p->stats_cap < n) {
@@ -575,7 +675,7 @@ int rf_lognormal(rf_plan* p, const double* a_z, const double* b_z, int nz, doubl
   RF_HIP(hipSetDevice(p->device));
   RF_HIP(hipMemcpyAsync(p->ztab, a_z, nz * sizeof(double), hipMemcpyHostToDevice, p->stream));
   RF_HIP(hipMemcpyAsync(p->ztab + nz, b_z, nz * sizeof(double), hipMemcpyHostToDevice, p->stream));
-  RF_HIP(launch_lognormal(p->f64, p->cur, (long long)p->nx * p->ny, nz, p->ztab, p->ztab + nz, sigma, p->stream));
+  RF_HIP(launch_lognormal(p->f64, p->cur, (long long)p->nxl * p->ny, nz, p->ztab, p->ztab + nz, sigma, p->stream));
   RF_HIP(hipStreamSynchronize(p->stream));  // host tables may go away
   p->stats_valid = false;
   return 0;
@@ -587,7 +687,7 @@ int rf_affine_z(rf_plan* p, const double* mul_z, int nz, double add) {
   RF_REQUIRE(p->real_valid, "no real-space field on the device");
   RF_HIP(hipSetDevice(p->device));
   RF_HIP(hipMemcpyAsync(p->ztab, mul_z, nz * sizeof(double), hipMemcpyHostToDevice, p->stream));
-  RF_HIP(launch_affine_z(p->f64, p->cur, (long long)p->nx * p->ny, nz, p->ztab, add, p->stream));
+  RF_HIP(launch_affine_z(p->f64, p->cur, (long long)p->nxl * p->ny, nz, p->ztab, add, p->stream));
   RF_HIP(hipStreamSynchronize(p->stream));
   p->stats_valid = false;
   return 0;
@@ -597,6 +697,7 @@ int rf_scale_z(rf_plan* p, const double* factor_z, int nz) { return rf_affine_z(
 
 int rf_save_potential(rf_plan* p) {
   RF_REQUIRE(p, "null plan");
+  RF_REQUIRE(p->nranks == 1, "k-space buffer operations are single-GPU only");
   RF_REQUIRE(p->K && p->k_valid, "no k-space data");
   RF_REQUIRE(p->have_kgrid, "rf_set_kgrid must be called first");
   RF_HIP(hipSetDevice(p->device));
@@ -607,6 +708,7 @@ int rf_save_potential(rf_plan* p) {
 
 int rf_load_potential(rf_plan* p, double scale) {
   RF_REQUIRE(p, "null plan");
+  RF_REQUIRE(p->nranks == 1, "k-space buffer operations are single-GPU only");
   RF_REQUIRE(p->P, "no saved potential");
   RF_HIP(hipSetDevice(p->device));
   if (int rc = ensure_k(p)) return rc;
@@ -617,6 +719,7 @@ int rf_load_potential(rf_plan* p, double scale) {
 
 int rf_upload_k(rf_plan* p, const void* host) {
   RF_REQUIRE(p && host, "null argument");
+  RF_REQUIRE(p->nranks == 1, "k-space buffer operations are single-GPU only");
   RF_HIP(hipSetDevice(p->device));
   if (int rc = ensure_k(p)) return rc;
   RF_HIP(hipMemcpyAsync(p->K, host, p->k_bytes, hipMemcpyHostToDevice, p->stream));
@@ -636,6 +739,7 @@ int rf_download_k(rf_plan* p, void* host) {
 
 int rf_upload_real(rf_plan* p, const void* host, int layout) {
   RF_REQUIRE(p && host, "null argument");
+  RF_REQUIRE(p->nranks == 1, "rf_upload_real is single-GPU only");
   RF_HIP(hipSetDevice(p->device));
   const size_t rsize = p->csize / 2;
   const size_t width = (size_t)p->nz * rsize;
@@ -651,7 +755,7 @@ int rf_upload_real(rf_plan* p, const void* host, int layout) {
 int rf_download_real(rf_plan* p, void* host, int layout, int x0, int x1) {
   RF_REQUIRE(p && host, "null argument");
   RF_REQUIRE(p->real_valid, "no real-space field on the device");
-  RF_REQUIRE(0 <= x0 && x0 < x1 && x1 <= p->nx, "invalid x range");
+  RF_REQUIRE(0 <= x0 && x0 < x1 && x1 <= p->nxl, "invalid x range (multi-GPU plans hold nx/ranks local planes)");
   RF_HIP(hipSetDevice(p->device));
   const size_t rsize = p->csize / 2;
   const size_t width = (size_t)p->nz * rsize;
@@ -692,13 +796,94 @@ int rf_kernel_ms(rf_plan* p, float* ms4) {
 }
 
 int rf_comm_unique_id(void* id128) {
-  (void)id128;
-  return fail(3, "rf_comm_unique_id: multi-GPU exchange not built yet");
+  RF_REQUIRE(id128, "null argument");
+  if (int rc = load_rccl()) return rc;
+  ncclUniqueId id;
+  RF_NCCL(g_rccl.GetUniqueId(&id));
+  memcpy(id128, &id, sizeof(id));
+  return 0;
 }
 
 int rf_comm_init(rf_plan* p, const void* id128) {
-  (void)p; (void)id128;
-  return fail(3, "rf_comm_init: multi-GPU exchange not built yet");
+  RF_REQUIRE(p && id128, "null argument");
+  RF_REQUIRE(p->comm == nullptr, "communicator already initialised");
+  if (int rc = load_rccl()) return rc;
+  RF_HIP(hipSetDevice(p->device));
+  // RCCL inspects hipGetLastError(): make sure no stale (non-sticky) error of an earlier call is pending
+  {
+    hipError_t stale = hipGetLastError();
+    if (stale != hipSuccess && getenv("RANDOMFIELD_DEBUG"))
+      fprintf(stderr, "rf_comm_init: cleared stale HIP error: %s\n", hipGetErrorString(stale));
+  }
+  ncclUniqueId id;
+  memcpy(&id, id128, sizeof(id));
+  RF_NCCL(g_rccl.CommInitRank(&p->comm, p->nranks, id, p->rank));
+  // one tiny collective now: a broken communicator should fail here, not inside a timed region
+  RF_HIP(hipMemsetAsync(p->stats, 0, 2 * sizeof(double), p->stream));
+  RF_NCCL(g_rccl.AllReduce(p->stats, p->stats, 2, ncclFloat64, ncclSum, p->comm, p->stream));
+  RF_HIP(hipStreamSynchronize(p->stream));
+  return 0;
+}
+
+int rf_comm_allreduce_f64(rf_plan* p, double* inout, int n, int op) {
+  RF_REQUIRE(p && inout, "null argument");
+  RF_REQUIRE(n >= 1 && n <= 2, "n must be 1 or 2");
+  RF_REQUIRE(op == 0 || op == 1, "op must be 0 (sum) or 1 (max)");
+  RF_HIP(hipSetDevice(p->device));
+  if (p->nranks == 1 || !p->comm) { RF_HIP(hipStreamSynchronize(p->stream)); return 0; }
+  // scratch: the two doubles behind the moments pair (stats has at least 128 slots)
+  double* d = p->stats + 2 * (p->stats_cap - 1);
+  RF_HIP(hipMemcpyAsync(d, inout, n * sizeof(double), hipMemcpyHostToDevice, p->stream));
+  RF_NCCL(g_rccl.AllReduce(d, d, n, ncclFloat64, op == 0 ? ncclSum : ncclMax, p->comm, p->stream));
+  RF_HIP(hipMemcpyAsync(inout, d, n * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+  RF_HIP(hipStreamSynchronize(p->stream));
+  return 0;
+}
+
+/* ---- slab pipeline in separate steps (tests / custom exchanges) ------------------------------- */
+int rf_slab_forward(rf_plan* p, uint64_t seed, int mode, const double* noise_host) {
+  RF_REQUIRE(p, "null plan");
+  RF_REQUIRE(p->nranks > 1, "rf_slab_* are for multi-rank plans");
+  RF_REQUIRE(p->have_kgrid && p->have_power, "rf_set_kgrid and rf_set_power must be called first");
+  RF_HIP(hipSetDevice(p->device));
+  if (int rc = upload_noise(p, mode, noise_host)) return rc;
+  if (int rc = queue_x(p, make_gen(p, seed, mode, false), nullptr, p->W, p->stream)) return rc;
+  if (int rc = queue_y_slab(p, p->stream)) return rc;
+  RF_HIP(hipStreamSynchronize(p->stream));
+  return 0;
+}
+
+int rf_slab_exchange_local(rf_plan** plans, int n) {
+  RF_REQUIRE(plans && n >= 1, "null argument");
+  for (int g = 0; g < n; ++g) {
+    RF_REQUIRE(plans[g] && plans[g]->nranks == n && plans[g]->rank == g, "plans must be ranks 0..n-1 of one n-rank job");
+    RF_REQUIRE(plans[g]->device == plans[0]->device, "virtual ranks must live on one device");
+    RF_HIP(hipStreamSynchronize(plans[g]->stream));
+  }
+  const rf_plan* p0 = plans[0];
+  const size_t blk = (size_t)p0->nxl * p0->ny * p0->nzl * p0->csize;
+  for (int g = 0; g < n; ++g)        // sender g, receiver h: block h of W_g -> block g of R_h
+    for (int h = 0; h < n; ++h)
+      RF_HIP(hipMemcpy((char*)plans[h]->R + g * blk, (char*)plans[g]->W + h * blk, blk, hipMemcpyDeviceToDevice));
+  return 0;
+}
+
+int rf_slab_backward(rf_plan* p) {
+  RF_REQUIRE(p, "null plan");
+  RF_REQUIRE(p->nranks > 1, "rf_slab_* are for multi-rank plans");
+  RF_HIP(hipSetDevice(p->device));
+  if (int rc = queue_z_slab(p, p->stream)) return rc;
+  RF_HIP(hipStreamSynchronize(p->stream));
+  return 0;
+}
+
+int rf_slab_stats(rf_plan* p, double* sum, double* sumsq) {
+  RF_REQUIRE(p && sum && sumsq, "null argument");
+  double st[2];
+  RF_HIP(hipMemcpyAsync(st, p->stats, sizeof(st), hipMemcpyDeviceToHost, p->stream));
+  RF_HIP(hipStreamSynchronize(p->stream));
+  *sum = st[0]; *sumsq = st[1];
+  return 0;
 }
 
 }  // extern "C"

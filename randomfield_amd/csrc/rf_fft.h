@@ -349,6 +349,29 @@ template <typename T> struct PlainRowIO {
   }
 };
 
+// z pass of a slab-decomposed (multi-GPU) plan: this rank owns nxl x-planes.  After the all-to-all
+// the receive buffer holds P blocks [src rank g][nxl][ny][nzl]; row (x, y) is gathered from its P
+// segments of nzl = nz/(2P) complex (1 KiB each at 2048^3 / 8 GPUs) -- no separate local transpose.
+// Output goes to a different buffer (the send buffer, free by then): dense real [nxl][ny][nz].
+template <typename T> struct GatherRowIO {
+  const cplx<T>* src;
+  cplx<T>* dst;
+  T scale;
+  int M_of;                      // nz / 2
+  int nzl;                       // kz planes per source rank
+  long long seg_stride;          // complex elements between two source blocks = nxl * ny * nzl
+  RF_HD cplx<T> load(long long row, int k) const {
+    const int g = k / nzl, kk = k - g * nzl;
+    return src[(long long)g * seg_stride + row * (long long)nzl + kk];
+  }
+  RF_HD void store(long long row, int n, cplx<T> z, double& s1, double& s2) const {
+    z.x *= scale; z.y *= scale;
+    dst[row * (long long)M_of + n] = z;
+    s1 += (double)z.x + (double)z.y;
+    s2 += (double)z.x * (double)z.x + (double)z.y * (double)z.y;
+  }
+};
+
 // tw = exp(+2 pi i q / (2M)), q in [0, 2M): t_k = tw[k], w_M^q = tw[2q]
 template <class C, class IO>
 struct RowC2R {

@@ -7,11 +7,11 @@ namespace {
 template <class C>
 constexpr int row_lds_bytes() { return C::LDS_BYTES > 2 * (C::NT / 64) * 8 ? C::LDS_BYTES : 2 * (C::NT / 64) * 8; }
 
-template <class C>
-hipError_t launch_one(const PlainRowIO<typename C::T>& io, long long nrows, const cplx<typename C::T>* tw,
+template <class C, class IO>
+hipError_t launch_one(const IO& io, long long nrows, const cplx<typename C::T>* tw,
                       double* partials, hipStream_t s, bool prepare_only) {
   const long long ntiles = (nrows + C::NRT - 1) / C::NRT;
-  auto k = row_c2r_kernel<C, PlainRowIO<typename C::T>>;
+  auto k = row_c2r_kernel<C, IO>;
   constexpr int lds = row_lds_bytes<C>();
   static bool prepared = false;
   if (!prepared) {
@@ -29,7 +29,18 @@ template <typename T>
 hipError_t launch_t(int M, cplx<T>* W, long long nrows, double scale, const cplx<T>* tw, double* partials, hipStream_t s, bool po) {
   PlainRowIO<T> io; io.base = W; io.scale = (T)scale; io.M_of = M;
   switch (M) {
-#define X(MM) case MM: return launch_one<typename RowSel<T, MM>::type>(io, nrows, tw, partials, s, po);
+#define X(MM) case MM: return launch_one<typename RowSel<T, MM>::type, PlainRowIO<T>>(io, nrows, tw, partials, s, po);
+    RF_ROW_SIZES(X)
+#undef X
+    default: return hipErrorInvalidValue;
+  }
+}
+template <typename T>
+hipError_t launch_gather_t(int M, const cplx<T>* src, cplx<T>* dst, long long nrows, double scale, int nzl,
+                           long long seg_stride, const cplx<T>* tw, double* partials, hipStream_t s, bool po) {
+  GatherRowIO<T> io; io.src = src; io.dst = dst; io.scale = (T)scale; io.M_of = M; io.nzl = nzl; io.seg_stride = seg_stride;
+  switch (M) {
+#define X(MM) case MM: return launch_one<typename RowSel<T, MM>::type, GatherRowIO<T>>(io, nrows, tw, partials, s, po);
     RF_ROW_SIZES(X)
 #undef X
     default: return hipErrorInvalidValue;
@@ -49,6 +60,11 @@ hipError_t launch_row_c2r(int f64, int M, void* W, long long nrows, double scale
                           double* partials, hipStream_t s, bool po) {
   if (f64) return launch_t<double>(M, (cplx<double>*)W, nrows, scale, (const cplx<double>*)tw, partials, s, po);
   return launch_t<float>(M, (cplx<float>*)W, nrows, scale, (const cplx<float>*)tw, partials, s, po);
+}
+hipError_t launch_row_c2r_gather(int f64, int M, const void* src, void* dst, long long nrows, double scale, int nzl,
+                                 long long seg_stride, const void* tw, double* partials, hipStream_t s, bool po) {
+  if (f64) return launch_gather_t<double>(M, (const cplx<double>*)src, (cplx<double>*)dst, nrows, scale, nzl, seg_stride, (const cplx<double>*)tw, partials, s, po);
+  return launch_gather_t<float>(M, (const cplx<float>*)src, (cplx<float>*)dst, nrows, scale, nzl, seg_stride, (const cplx<float>*)tw, partials, s, po);
 }
 long long row_c2r_tiles(int f64, int M, long long nrows) {
   return f64 ? tiles_t<double>(M, nrows) : tiles_t<float>(M, nrows);

@@ -22,6 +22,10 @@ int col_tile_cols(int f64, int N);   // tile width (columns) of the strided pass
 // z pass of c2r: rows of M = nz/2 complex -> nz reals, scaled; partials[2*tile] = (sum, sumsq)
 hipError_t launch_row_c2r(int f64, int M, void* W, long long nrows, double scale, const void* tw,
                           double* partials, hipStream_t s, bool prepare_only = false);
+// z pass of a slab-decomposed plan: rows gathered from P received blocks of nzl kz planes each
+hipError_t launch_row_c2r_gather(int f64, int M, const void* src, void* dst, long long nrows, double scale, int nzl,
+                                 long long seg_stride, const void* tw, double* partials, hipStream_t s,
+                                 bool prepare_only = false);
 long long row_c2r_tiles(int f64, int M, long long nrows);
 
 // rows K,T,R,S into an API-layout k array [nx][ny][nz/2+1]

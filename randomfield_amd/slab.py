@@ -1,0 +1,137 @@
+"""
+Multi-GPU slab decomposition of the hot path: one process per GPU.
+
+k space is split by kz slabs -- with the Nyquist plane packed into slot kz = 0 there are exactly nz/2
+planes, so rank r owns planes [r*nzl, (r+1)*nzl), nzl = nz/(2P).  Generation and the x and y passes are
+local.  ONE all-to-all then moves block [x in slab h][all y][kz in slab g] from rank g to rank h, after
+which rank h owns the x slab [h*nxl, (h+1)*nxl), nxl = nx/P, runs the z pass on rows gathered from the P
+received blocks and holds delta[x in its slab].  The rms needs one 2-double all-reduce.
+
+This module holds the layout arithmetic (shared by the C library's design, the tests and bench.py) and
+the process plumbing.  The GPU path needs no torch: rank 0's RCCL unique id reaches the other ranks of
+the (single-node) job through a small file, and barriers / reductions of timings go through RCCL itself.
+All collectives are issued by ``librandomfield_hip.so`` on the plan's HIP stream.  (``torch.distributed``
+with gloo is used by the CPU tests only.)
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+__all__ = ["slab_layout", "exchange_blocks", "gather_rows", "exchange_unique_id", "init_process_group",
+           "DistributedPlan"]
+
+
+def slab_layout(nx, ny, nz, nranks, rank):
+    """Sizes and offsets of rank ``rank``'s slabs."""
+    nzc = nz // 2
+    if nx % nranks or nzc % nranks or (nzc // nranks) % 2:
+        raise ValueError("nx and nz/2 must be divisible by the number of ranks (nz/(2*ranks) even)")
+    nxl, nzl = nx // nranks, nzc // nranks
+    return dict(nxl=nxl, nzl=nzl, x0=rank * nxl, kz0=rank * nzl, nzc=nzc,
+                block_elems=nxl * ny * nzl, local_elems=nx * ny * nzl)
+
+
+def exchange_blocks(local_k, nranks):
+    """Split a rank's post-y-pass array [nx][ny][nzl] into the P send blocks [nxl][ny][nzl]
+    (block h goes to rank h).  x is the slowest axis, so the blocks are contiguous slices."""
+    nx = local_k.shape[0]
+    nxl = nx // nranks
+    return [local_k[h * nxl:(h + 1) * nxl] for h in range(nranks)]
+
+
+def gather_rows(recv_blocks):
+    """Assemble the z-pass input [nxl][ny][nz/2] of a rank from its P received blocks
+    (block g holds the kz planes of rank g's slab)."""
+    return np.concatenate(recv_blocks, axis=2)
+
+
+def _rendezvous_path():
+    """A file name every rank of one launch agrees on: the ranks of `torch.distributed.run` are children
+    of the same agent process, so (parent pid, MASTER_PORT) identifies the launch on this node."""
+    port = os.environ.get("MASTER_PORT", "0")
+    run_id = os.environ.get("TORCHELASTIC_RUN_ID", "none")
+    return os.path.join(os.environ.get("TMPDIR", "/tmp"), "randomfield_uid_%d_%s_%s" % (os.getppid(), port, run_id))
+
+
+def exchange_unique_id(rank, world, make_uid, timeout=300.0):
+    """Hand rank 0's RCCL unique id to every rank of a single-node job WITHOUT importing torch
+    (a process that loads PyTorch's bundled ROCm runtime next to the system one is asking for trouble).
+    Rank 0 writes the 128 bytes atomically; the others poll for the file."""
+    import time
+    path = _rendezvous_path()
+    if world == 1:
+        return make_uid()
+    if rank == 0:
+        uid = make_uid()
+        tmp = path + ".tmp%d" % os.getpid()
+        with open(tmp, "wb") as f:
+            f.write(uid)
+        os.replace(tmp, path)
+        return uid
+    t0 = time.time()
+    while True:
+        try:
+            with open(path, "rb") as f:
+                uid = f.read()
+            if len(uid) == 128:
+                return uid
+        except OSError:
+            pass
+        if time.time() - t0 > timeout:
+            raise RuntimeError("timed out waiting for the RCCL unique id at %s" % path)
+        time.sleep(0.02)
+
+
+def init_process_group():
+    """Join the job described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torch.distributed.run).
+    Returns (dist, rank, world, local_rank).  gloo: only tiny host-side messages go through it.
+    (Used by the CPU tests; the GPU path needs no torch at all -- see DistributedPlan.)"""
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    return dist, rank, world, local_rank
+
+
+def broadcast_bytes(dist, payload, src=0):
+    """Broadcast a bytes object from rank ``src`` over torch.distributed (CPU tests)."""
+    box = [payload if dist.get_rank() == src else None]
+    dist.broadcast_object_list(box, src=src)
+    return box[0]
+
+
+class DistributedPlan(object):
+    """One rank's share of a multi-GPU plan: DevicePlan(nranks, rank) + RCCL communicator.
+
+    Reads RANK / WORLD_SIZE / LOCAL_RANK from the environment (as set by ``torch.distributed.run``).
+    After construction ``barrier()`` and ``allreduce()`` go through RCCL on the plan's stream."""
+
+    def __init__(self, nx, ny, nz, dtype=np.complex64, device=None, rank=None, world=None):
+        from . import _hip
+        self.rank = int(os.environ.get("RANK", "0")) if rank is None else rank
+        self.world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else world
+        local_rank = int(os.environ.get("LOCAL_RANK", str(self.rank)))
+        self.layout = slab_layout(nx, ny, nz, self.world, self.rank)
+        self.plan = _hip.DevicePlan(nx, ny, nz, dtype, device=local_rank if device is None else device,
+                                    nranks=self.world, rank=self.rank)
+        if self.world > 1:
+            uid = exchange_unique_id(self.rank, self.world, _hip.DevicePlan.comm_unique_id)
+            self.plan.comm_init(uid)          # collective: every rank calls it; ends with a tiny all-reduce
+            self.plan.barrier()
+            if self.rank == 0:
+                try:
+                    os.remove(_rendezvous_path())
+                except OSError:
+                    pass
+
+    def barrier(self):
+        self.plan.barrier()
+
+    def allreduce(self, values, op="sum"):
+        return self.plan.allreduce(values, op)

@@ -1,0 +1,128 @@
+"""world_size-2 gloo test (CPU): the multi-GPU path's rendezvous, unique-id hand-off and, above all,
+the slab / all-to-all block layout.  Each rank computes its kz slab with the oracle, runs the x and y
+inverse transforms locally, exchanges the blocks defined in randomfield_amd/slab.py with a real
+all_to_all over gloo, gathers its rows and runs the z c2r -- and must end up with exactly its x slab of
+the single-process field."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+# torch is imported lazily inside the tests: a `-m gpu` run must not load PyTorch's bundled ROCm runtime
+# into the process next to the system one (RCCL then fails to initialise)
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, shape, out_dir):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from oracle import cpu_ref
+    from randomfield_amd import slab
+    d, r, w, lr = slab.init_process_group()
+    assert (r, w) == (rank, world)
+    # unique-id hand-off (a stand-in payload: no RCCL on the CPU)
+    uid = slab.broadcast_bytes(d, bytes(range(128)) if rank == 0 else None, src=0)
+    assert uid == bytes(range(128))
+
+    nx, ny, nz = shape
+    lay = slab.slab_layout(nx, ny, nz, world, rank)
+    pw = np.load(os.path.join(ROOT, "tests", "golden", "default_power.npz"))
+    noise = cpu_ref.reference_noise(11, nx * ny * (nz // 2 + 1))
+    full_k = cpu_ref.generate_kspace(nx, ny, nz, 2.5, pw["k"], pw["Pk"], noise=noise, dtype=np.complex128)
+    nzc = nz // 2
+    packed = full_k[:, :, :nzc].copy()
+    packed[:, :, 0] = full_k[:, :, 0] + 1j * full_k[:, :, nzc]          # device-internal packing of DC/Nyquist planes
+    mine = packed[:, :, lay["kz0"]:lay["kz0"] + lay["nzl"]]             # this rank's kz slab
+    mine = np.fft.ifft(np.fft.ifft(mine, axis=0), axis=1) * (nx * ny)   # x and y passes (unnormalised)
+    # THE exchange: grouped point-to-point sends/receives, block h -> rank h (what the library does with
+    # ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd; the own block is a local copy)
+    send = [torch.from_numpy(np.ascontiguousarray(b).view(np.float64)) for b in slab.exchange_blocks(mine, world)]
+    recv = [torch.empty_like(send[0]) for _ in range(world)]
+    recv[rank].copy_(send[rank])
+    ops = []
+    for h in range(world):
+        if h != rank:
+            ops.append(dist.P2POp(dist.isend, send[h], h))
+            ops.append(dist.P2POp(dist.irecv, recv[h], h))
+    for req in dist.batch_isend_irecv(ops):
+        req.wait()
+    rows = slab.gather_rows([t.numpy().view(np.complex128) for t in recv])   # [nxl][ny][nz/2]
+    assert rows.shape == (lay["nxl"], ny, nzc)
+    half = np.empty((lay["nxl"], ny, nzc + 1), np.complex128)            # unpack slot 0 -> DC and Nyquist elements
+    half[:, :, :nzc] = rows
+    half[:, :, 0] = rows[:, :, 0].real
+    half[:, :, nzc] = rows[:, :, 0].imag
+    delta = np.fft.irfft(half, n=nz, axis=2) / (nx * ny)
+    # global rms through a 2-double all-reduce
+    st = torch.tensor([delta.sum(), (delta ** 2).sum()], dtype=torch.float64)
+    dist.all_reduce(st)
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), delta=delta, stats=st.numpy(), x0=lay["x0"])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2])
+def test_slab_exchange_two_processes(tmp_path, world):
+    pytest.importorskip("torch")
+    import torch.multiprocessing as mp
+    from oracle import cpu_ref
+    shape = (8, 8, 16)
+    mp.spawn(_worker, args=(world, _free_port(), shape, str(tmp_path)), nprocs=world, join=True)
+    nx, ny, nz = shape
+    pw = np.load(os.path.join(ROOT, "tests", "golden", "default_power.npz"))
+    noise = cpu_ref.reference_noise(11, nx * ny * (nz // 2 + 1))
+    ref, rms = cpu_ref.generate_delta_field(nx, ny, nz, 2.5, pw["k"], pw["Pk"], noise=noise, dtype=np.complex128)
+    for r in range(world):
+        g = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
+        x0 = int(g["x0"])
+        assert np.allclose(g["delta"], ref[x0:x0 + nx // world], rtol=0, atol=1e-12 * rms)
+        n = ref.size
+        assert abs(np.sqrt(g["stats"][1] / n - (g["stats"][0] / n) ** 2) - rms) < 1e-12 * rms
+
+
+def test_unique_id_file_handoff(tmp_path, monkeypatch):
+    """The torch-free unique-id hand-off used on the GPU path: rank 0 writes, the others read."""
+    import threading
+    from randomfield_amd import slab
+    monkeypatch.setenv("TMPDIR", str(tmp_path))
+    monkeypatch.setenv("MASTER_PORT", "12345")
+    payload = bytes(range(128))
+    got = {}
+
+    def reader(r):
+        got[r] = slab.exchange_unique_id(r, 3, lambda: b"wrong" * 30, timeout=20)
+
+    threads = [threading.Thread(target=reader, args=(r,)) for r in (1, 2)]
+    for t in threads:
+        t.start()
+    assert slab.exchange_unique_id(0, 3, lambda: payload) == payload
+    for t in threads:
+        t.join()
+    assert got == {1: payload, 2: payload}
+    assert slab.exchange_unique_id(0, 1, lambda: payload) == payload
+
+
+def test_slab_layout_rules():
+    from randomfield_amd import slab
+    lay = slab.slab_layout(2048, 2048, 2048, 8, 3)
+    assert lay["nxl"] == 256 and lay["nzl"] == 128 and lay["kz0"] == 384 and lay["x0"] == 768
+    assert lay["block_elems"] * 8 == 256 * 2048 * 128 * 8 == 536870912          # 537 MB per pair
+    assert lay["local_elems"] == 2048 * 2048 * 128
+    with pytest.raises(ValueError):
+        slab.slab_layout(16, 16, 16, 3, 0)
+    with pytest.raises(ValueError):
+        slab.slab_layout(16, 16, 16, 8, 0)           # nz/2 = 8 planes over 8 ranks: 1 plane each (odd)
