@@ -31,17 +31,18 @@ template <> struct GenSel<double, 1024> { using type = ColCfg<double, 1024, 8, 1
 
 // ---- contiguous (z) pass: M = nz / 2 ----------------------------------------
 template <typename T, int M> struct RowSel;
-#define RF_ROW(M, R1, R2, R3, NRT32, NT)                                                          \
-  template <> struct RowSel<float, M>  { using type = RowCfg<float,  M, R1, R2, R3, NRT32,     NT>; }; \
-  template <> struct RowSel<double, M> { using type = RowCfg<double, M, R1, R2, R3, NRT32 / 2, NT>; };
-RF_ROW(8,    8,  1,  1,  256, 256)
-RF_ROW(16,   16, 1,  1,  256, 256)
-RF_ROW(32,   8,  4,  1,  64,  256)
-RF_ROW(64,   8,  8,  1,  64,  256)
-RF_ROW(128,  8,  16, 1,  32,  256)
-RF_ROW(256,  8,  8,  4,  16,  256)
-RF_ROW(512,  16, 8,  4,  16,  256)
-RF_ROW(1024, 8,  8,  16, 4,   256)
+// float32 and float64 get their own radices: a float64 butterfly pair of radix 16 needs 256+ VGPRs
+#define RF_ROW(M, R1, R2, R3, NRT32, D1, D2, D3, NRT64, NT)                                        \
+  template <> struct RowSel<float, M>  { using type = RowCfg<float,  M, R1, R2, R3, NRT32, NT>; }; \
+  template <> struct RowSel<double, M> { using type = RowCfg<double, M, D1, D2, D3, NRT64, NT>; };
+RF_ROW(8,    8,  1,  1,  256, 8,  1,  1,  128, 256)
+RF_ROW(16,   16, 1,  1,  256, 8,  2,  1,  64,  256)
+RF_ROW(32,   8,  4,  1,  64,  8,  4,  1,  32,  256)
+RF_ROW(64,   8,  8,  1,  64,  8,  8,  1,  32,  256)
+RF_ROW(128,  8,  16, 1,  32,  8,  4,  4,  16,  256)
+RF_ROW(256,  8,  8,  4,  16,  8,  8,  4,  8,   256)
+RF_ROW(512,  16, 8,  4,  16,  8,  8,  8,  8,   256)
+RF_ROW(1024, 8,  8,  16, 4,   8,  8,  16, 2,   256)
 #undef RF_ROW
 #define RF_ROW_SIZES(X) X(8) X(16) X(32) X(64) X(128) X(256) X(512) X(1024)
 

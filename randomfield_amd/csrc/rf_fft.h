@@ -81,6 +81,7 @@ template <typename T> struct PlainColIO {
   static constexpr int LDS_EXTRA = 0;
   RF_HD void prologue(int, int, void*) {}
   RF_HD static void sched_fence() {}      // loads of one butterfly are meant to be issued back to back
+  static constexpr bool ROLLED_LOAD = false;
 };
 
 // x pass fused with generation (rows K,T,R,S): load() synthesises the packed
@@ -122,6 +123,9 @@ template <typename T> struct GenColIO {
   static constexpr int LDS_EXTRA = 0;
   RF_HD void prologue(int, int, void*) {}
   RF_HD static void sched_fence() {}
+  // the exact-chain generation body (float64 lookups, libm-grade log10 / sin / cos) is far too big to be
+  // replicated R times: the load loop stays rolled and parks its values in the thread's own LDS slots
+  static constexpr bool ROLLED_LOAD = true;
 };
 
 // x pass fused with the fast float32 native generation (one Philox call per lane load)
@@ -159,6 +163,7 @@ struct FastGenColIOT {
   }
   // the lane that owns slot kz = 0 replaces its provisional first cell of every row by the packed,
   // symmetrised (kz=0, kz=nz/2) pair (cold path: one lane in four of one tile in nz/16)
+  static constexpr bool ROLLED_LOAD = false;
   static constexpr int FIX_MODE = FIX;
   RF_HD bool needs_fix(long long C) const { return FIX != 0 && kz0 + (int)(C % nzl) == 0; }
   RF_HD cplx<float> fix_value(long long C, int row) const {
@@ -213,12 +218,23 @@ struct ColFFT {
       const int j = it * BPI + jl;
       if (j < L) {
         cx v[CPL][R];
+        if (IO::ROLLED_LOAD && C::NPASS > 1) {
+#pragma unroll 1
+          for (int m = 0; m < R; ++m) *lds_at(lds, j * R + m, lp) = io.load(Ccol, j + m * L);
 #pragma unroll
-        for (int m = 0; m < R; ++m) {
-          V x = io.load(Ccol, j + m * L);
+          for (int m = 0; m < R; ++m) {
+            V x = *lds_at(lds, j * R + m, lp);
 #pragma unroll
-          for (int c = 0; c < CPL; ++c) v[c][m] = x.c[c];
-          IO::sched_fence();
+            for (int c = 0; c < CPL; ++c) v[c][m] = x.c[c];
+          }
+        } else {
+#pragma unroll
+          for (int m = 0; m < R; ++m) {
+            V x = io.load(Ccol, j + m * L);
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) v[c][m] = x.c[c];
+            IO::sched_fence();
+          }
         }
         if (IO::FIX_MODE != 0 && io.needs_fix(Ccol)) {
           if (C::NPASS == 1) {

@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Timings of the other BASELINE.json configurations (development tool): 512^3 single realisation (config 1),
+1024^3 float64 + lognormal map (config 4/5), 2048^3 on one GPU.  Prints one JSON line per case."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from randomfield_amd import _hip, cosmotools, powertools   # noqa: E402
+
+
+def run(n, dtype, lognormal=False, reps=5):
+    spacing = 2.5
+    power = powertools.load_default_power()
+    plan = _hip.DevicePlan(n, n, n, dtype)
+    plan.set_kgrid(*powertools.ksq_axes(n, n, n, spacing))
+    plan.set_power(*powertools.sigma_table(power, (n, n, n), spacing))
+    plan.realise(seed=1)
+    plan.sync()
+    times, kern = [], np.zeros(4)
+    growth = np.exp(-0.5 * np.arange(n) / n)
+    for i in range(reps):
+        plan.sync()
+        t0 = time.perf_counter()
+        plan.realise(seed=10 + i)
+        if lognormal:
+            mean, std = plan.moments()
+            a_z, b_z = cosmotools.lognormal_tables(growth, std, n)
+            plan.lognormal(a_z, b_z, std)
+        plan.sync()
+        times.append(time.perf_counter() - t0)
+        if not lognormal:
+            kern += np.array(plan.kernel_ms())
+    t = float(np.median(times))
+    itemsize = 8 if dtype == np.complex64 else 16
+    sweep = itemsize * n * n * (n // 2 + 1)
+    alg = 5 * sweep + (2 * (itemsize // 2) * n ** 3 if lognormal else 0)
+    out = {"case": "%d^3 %s%s" % (n, "f32" if dtype == np.complex64 else "f64", " + lognormal" if lognormal else ""),
+           "ms": round(t * 1e3, 3), "Mcells_s": round(n ** 3 / t / 1e6, 1), "algorithmic_GBs": round(alg / t / 1e9, 1),
+           "frac_hbm_peak": round(alg / t / 8e12, 4)}
+    if not lognormal:
+        out["kernel_ms"] = [round(float(v), 3) for v in kern / reps]
+    plan.close()
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    run(512, np.complex64)
+    run(1024, np.complex64)
+    run(1024, np.complex128)
+    run(1024, np.complex128, lognormal=True)
+    run(2048, np.complex64, reps=3)
