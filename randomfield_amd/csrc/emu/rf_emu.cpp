@@ -88,6 +88,61 @@ int dispatch_row_c2r(int M, cplx<T>* base, long long nrows, double scale, double
   }
 }
 
+template <class C>
+void run_row_r2c(const PlainRowFwdIO<typename C::T>& io, long long nrows, const cplx<typename C::T>* tw) {
+  using F = RowR2C<C, PlainRowFwdIO<typename C::T>>;
+  using cx = cplx<typename C::T>;
+  std::vector<cx> lds((size_t)C::LDS_BYTES / sizeof(cx) + 16);
+  std::vector<typename F::Regs> regs(C::NT);
+  const long long ntiles = (nrows + C::NRT - 1) / C::NRT;
+  for (long long tile = 0; tile < ntiles; ++tile) {
+    if (C::NPASS >= 2) for (int t = 0; t < C::NT; ++t) F::pass_first(t, tile, nrows, io, lds.data());
+    if (C::NPASS == 3) {
+      for (int t = 0; t < C::NT; ++t) F::pass_mid_read(t, tw, lds.data(), regs[t]);
+      for (int t = 0; t < C::NT; ++t) F::pass_mid_write(t, lds.data(), regs[t]);
+    }
+    // every thread reads all its LDS inputs before any thread stores (stores go to global memory only)
+    for (int t = 0; t < C::NT; ++t) F::pass_last(t, tile, nrows, io, tw, lds.data());
+  }
+}
+
+template <typename T>
+int dispatch_row_r2c(int M, cplx<T>* base, long long nrows) {
+  auto tw = make_twiddles<T>(2 * M);
+  PlainRowFwdIO<T> io; io.base = base; io.M_of = M;
+  switch (M) {
+#define X(MM) case MM: run_row_r2c<typename RowSel<T, MM>::type>(io, nrows, tw.data()); return 0;
+    RF_ROW_SIZES(X)
+#undef X
+    default: return -1;
+  }
+}
+
+template <typename T>
+int r2c_impl(int nx, int ny, int nz, const T* field, cplx<T>* K) {
+  const long long nzc = nz / 2;
+  std::vector<cplx<T>> W((size_t)nx * ny * nzc);
+  memcpy(W.data(), field, W.size() * sizeof(cplx<T>));
+  int rc = dispatch_row_r2c<T>((int)nzc, W.data(), (long long)nx * ny);
+  if (rc) return rc;
+  PlainColIO<T> yio; yio.base = W.data(); yio.g = ColGeom{nzc, (long long)ny * nzc, nzc};
+  rc = dispatch_col<T, -1>(ny, yio, (long long)nx * nzc);
+  if (rc) return rc;
+  PlainColIO<T> xio; xio.base = W.data(); xio.g = ColGeom{(long long)ny * nzc, 0, (long long)ny * nzc};
+  rc = dispatch_col<T, -1>(nx, xio, (long long)ny * nzc);
+  if (rc) return rc;
+  const int nzh = (int)nzc + 1;
+  for (int ix = 0; ix < nx; ++ix)
+    for (int iy = 0; iy < ny; ++iy) {
+      const long long col = (long long)ix * ny + iy, mcol = (long long)((nx - ix) % nx) * ny + (ny - iy) % ny;
+      for (int iz = 1; iz < nzc; ++iz) K[col * nzh + iz] = W[col * nzc + iz];
+      const cplx<T> a = W[col * nzc], b = W[mcol * nzc];
+      K[col * nzh] = mk<T>((T)0.5 * (a.x + b.x), (T)0.5 * (a.y - b.y));
+      K[col * nzh + nzc] = mk<T>((T)0.5 * (a.y + b.y), (T)0.5 * (b.x - a.x));
+    }
+  return 0;
+}
+
 struct GenHost {
   SigmaTableHost tab;
   GenParams gp;
@@ -189,6 +244,12 @@ int emu_realise(int f64, int nx, int ny, int nz, const double* kx2, const double
 int emu_c2r(int f64, int nx, int ny, int nz, const void* kspace, void* W, double* s1, double* s2) {
   return f64 ? c2r_impl<double>(nx, ny, nz, nullptr, (const cplx<double>*)kspace, (cplx<double>*)W, s1, s2)
              : c2r_impl<float>(nx, ny, nz, nullptr, (const cplx<float>*)kspace, (cplx<float>*)W, s1, s2);
+}
+
+// forward r2c of a dense real field [nx][ny][nz] into the API k layout [nx][ny][nz/2+1]
+int emu_r2c(int f64, int nx, int ny, int nz, const void* field, void* K) {
+  return f64 ? r2c_impl<double>(nx, ny, nz, (const double*)field, (cplx<double>*)K)
+             : r2c_impl<float>(nx, ny, nz, (const float*)field, (cplx<float>*)K);
 }
 
 // one strided FFT pass over data[(C / inner) * outer_stride + C % inner + row * row_stride]

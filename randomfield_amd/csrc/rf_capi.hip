@@ -434,6 +434,9 @@ int rf_plan_create(rf_plan** out, int nx, int ny, int nz, int dtype, int device,
         (!dtype && (e = launch_col_fastgen(nx, p->W, gx, (long long)ny * nzl, fp0, 0, (int)nzl, p->tw_x, p->stream, true)) != hipSuccess) ||
         (e = launch_col_plain(dtype, ny, +1, p->W, gy, (long long)nx * nzl, p->tw_y, p->stream, true)) != hipSuccess ||
         (e = launch_row_c2r(dtype, (int)nzc, p->W, (long long)p->nxl * ny, 1.0, p->tw_z, p->partials, p->stream, true)) != hipSuccess ||
+        (e = launch_row_r2c(dtype, (int)nzc, p->W, (long long)p->nxl * ny, p->tw_z, p->stream, true)) != hipSuccess ||
+        (e = launch_col_plain(dtype, ny, -1, p->W, gy, (long long)nx * nzl, p->tw_y, p->stream, true)) != hipSuccess ||
+        (e = launch_col_plain(dtype, nx, -1, p->W, gx, (long long)ny * nzl, p->tw_x, p->stream, true)) != hipSuccess ||
         (nranks > 1 && (e = launch_row_c2r_gather(dtype, (int)nzc, p->R, p->W, (long long)p->nxl * ny, 1.0, (int)nzl, (long long)p->nxl * ny * nzl,
                                                   p->tw_z, p->partials, p->stream, true)) != hipSuccess))
       return cleanup(fail(2, std::string("kernel preparation: ") + hipGetErrorString(e)));
@@ -556,7 +559,23 @@ int rf_execute_c2r(rf_plan* p) {
 
 int rf_execute_r2c(rf_plan* p) {
   RF_REQUIRE(p, "null plan");
-  return fail(3, "rf_execute_r2c: forward transform not built yet");
+  RF_REQUIRE(p->nranks == 1, "rf_execute_r2c is single-GPU only");
+  RF_REQUIRE(p->real_valid && p->cur == p->W, "no real-space field on the device: call rf_upload_real (or a c2r) first");
+  RF_HIP(hipSetDevice(p->device));
+  if (int rc = ensure_k(p)) return rc;
+  const long long nzc = p->nzc;
+  const ColGeom gx{(long long)p->ny * nzc, 0, (long long)p->ny * nzc}, gy{nzc, (long long)p->ny * nzc, nzc};
+  RF_HIP(hipEventRecord(p->ev[0], p->stream));
+  RF_HIP(launch_row_r2c(p->f64, (int)nzc, p->W, (long long)p->nx * p->ny, p->tw_z, p->stream));     // z, in place
+  RF_HIP(launch_col_plain(p->f64, p->ny, -1, p->W, gy, (long long)p->nx * nzc, p->tw_y, p->stream));   // y forward
+  RF_HIP(launch_col_plain(p->f64, p->nx, -1, p->W, gx, (long long)p->ny * nzc, p->tw_x, p->stream));   // x forward
+  RF_HIP(launch_unpack_kspace(p->f64, p->W, p->K, p->nx, p->ny, p->nz, p->stream));
+  RF_HIP(hipEventRecord(p->ev[4], p->stream));
+  p->timed = false;
+  p->real_valid = false;      // the field buffer now holds packed k space
+  p->stats_valid = false;
+  p->k_valid = true;
+  return 0;
 }
 
 int rf_realise(rf_plan* p, uint64_t seed, int mode, const double* noise_host) {

@@ -151,12 +151,13 @@ RF_HD uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a 
 
 // Philox4x32-10 (Salmon, Moraes, Dror, Shaw 2011).  counter = (ctr_lo, ctr_hi) as
 // two 64-bit words, key = 64-bit seed.
-RF_HD PhiloxOut philox4x32_10(uint64_t ctr_lo, uint64_t ctr_hi, uint64_t key) {
+template <int ROUNDS = 10>
+RF_HD PhiloxOut philox4x32(uint64_t ctr_lo, uint64_t ctr_hi, uint64_t key) {
   uint32_t c0 = (uint32_t)ctr_lo, c1 = (uint32_t)(ctr_lo >> 32);
   uint32_t c2 = (uint32_t)ctr_hi, c3 = (uint32_t)(ctr_hi >> 32);
   uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
 #pragma unroll
-  for (int r = 0; r < 10; ++r) {
+  for (int r = 0; r < ROUNDS; ++r) {
     // one 32x32->64 product each (v_mad_u64_u32), not separate mul_lo / mul_hi
     const uint64_t p0 = (uint64_t)0xD2511F53u * (uint64_t)c0;
     const uint64_t p1 = (uint64_t)0xCD9E8D57u * (uint64_t)c2;
@@ -169,6 +170,7 @@ RF_HD PhiloxOut philox4x32_10(uint64_t ctr_lo, uint64_t ctr_hi, uint64_t key) {
   PhiloxOut o; o.w[0] = c0; o.w[1] = c1; o.w[2] = c2; o.w[3] = c3;
   return o;
 }
+RF_HD PhiloxOut philox4x32_10(uint64_t ctr_lo, uint64_t ctr_hi, uint64_t key) { return philox4x32<10>(ctr_lo, ctr_hi, key); }
 
 // Box-Muller from two 32-bit words: u = (w + 0.5) / 2^32 in (0, 1).
 template <typename T> struct BoxMuller;
@@ -390,6 +392,7 @@ RF_HD void fast_gen_pair(const FastGenParams& g, const FastRec* rec, uint64_t se
   const uint64_t ci = ((uint64_t)ix * (uint64_t)g.ny + (uint64_t)iy) * (uint64_t)nzc + (uint64_t)kz;   // even
   PhiloxOut o;
   if (AB & 1) { o.w[0] = (uint32_t)ci; o.w[1] = (uint32_t)ci * 3u; o.w[2] = (uint32_t)ci * 5u; o.w[3] = (uint32_t)ci * 7u; }
+  else if (AB & 8) o = philox4x32<7>(ci >> 1, 0, seed);   // timing experiment only
   else o = philox4x32_10(ci >> 1, 0, seed);
   float g0, g1;
   const float s0 = (AB & 2) ? kxy + g.kz2[kz] : fast_sigma(g, rec, kxy + g.kz2[kz]);

@@ -509,4 +509,134 @@ struct RowC2R {
   }
 };
 
+// ---------------------------------------------------------------------------
+// Forward row pass: r2c along z (transform.py:199-206,270 -- np.fft.rfftn's last axis)
+// ---------------------------------------------------------------------------
+// The real row x[0..nz) is viewed as M = nz/2 complex z[m] = x[2m] + i x[2m+1]; Z = FFT_M(z) (forward);
+// X[k] = (Z[k] + conj Z[M-k])/2 - (i/2) conj(t_k) (Z[k] - conj Z[M-k]).  The tangle needs the mirror
+// pair (k, M-k) of the FFT *output*, so the LAST pass gives one thread the butterfly pair (j, L - j)
+// (the mirror image of RowC2R's first pass).  Output in place: M complex per row, element 0 packs
+// (X[0], X[M]) -- both are real.
+template <typename T> struct PlainRowFwdIO {
+  cplx<T>* base;
+  int M_of;
+  RF_HD cplx<T> load(long long row, int k) const { return base[row * (long long)M_of + k]; }
+  RF_HD void store(long long row, int k, cplx<T> z) const { base[row * (long long)M_of + k] = z; }
+};
+
+template <class C, class IO>
+struct RowR2C {
+  using T = typename C::T;
+  using cx = cplx<T>;
+  static constexpr int M = C::M, NT = C::NT;
+  static constexpr int DIR = -1;
+  // the paired LAST pass needs L/2 threads per row (or 1)
+  static constexpr int LL = M / C::RL;
+  static constexpr int TPRL = cmax(1, LL / 2);
+  static constexpr int ITF = ceil_div(C::NRT * (M / C::R1), NT);
+  static constexpr int ITLP = ceil_div(C::NRT * TPRL, NT);
+
+  struct Regs { cx v[C::IT2][cmax(C::R2, 1)]; };
+
+  RF_HD static cx* lds_at(cx* lds, int rl, int i) { return lds + (long long)rl * C::RS + pad16(i); }
+
+  // pass 1 (only when NPASS >= 2): global -> R1 butterfly -> LDS
+  RF_HD static void pass_first(int tid, long long tile, long long nrows, const IO& io, cx* lds) {
+    constexpr int R = C::R1, L = M / R;
+#pragma unroll
+    for (int it = 0; it < ITF; ++it) {
+      const int w = it * NT + tid;
+      const int rl = w / L, j = w % L;
+      const long long row = tile * C::NRT + rl;
+      if (rl < C::NRT && row < nrows) {
+        cx v[R];
+#pragma unroll
+        for (int m = 0; m < R; ++m) v[m] = io.load(row, j + m * L);
+        DFT<R, DIR>::run(v);
+#pragma unroll
+        for (int m = 0; m < R; ++m) *lds_at(lds, rl, j * R + m) = v[m];
+      }
+    }
+  }
+
+  RF_HD static void pass_mid_read(int tid, const cx* tw, cx* lds, Regs& r) {
+    constexpr int R = C::R2, L = M / R, Ns = C::R1;
+#pragma unroll
+    for (int it = 0; it < C::IT2; ++it) {
+      const int w = it * NT + tid;
+      const int rl = w / L, j = w % L;
+      if (rl < C::NRT) {
+#pragma unroll
+        for (int m = 0; m < R; ++m) {
+          cx x = *lds_at(lds, rl, j + m * L);
+          if (m > 0) x = cmul(x, cconj(tw[2 * stockham_tw_index(j, m, Ns, R, M)]));
+          r.v[it][m] = x;
+        }
+        DFT<R, DIR>::run(r.v[it]);
+      }
+    }
+  }
+  RF_HD static void pass_mid_write(int tid, cx* lds, const Regs& r) {
+    constexpr int R = C::R2, L = M / R, Ns = C::R1;
+#pragma unroll
+    for (int it = 0; it < C::IT2; ++it) {
+      const int w = it * NT + tid;
+      const int rl = w / L, j = w % L;
+      if (rl < C::NRT) {
+        const int ob = stockham_out_base(j, Ns, R);
+#pragma unroll
+        for (int m = 0; m < R; ++m) *lds_at(lds, rl, ob + m * Ns) = r.v[it][m];
+      }
+    }
+  }
+
+  // last pass: (LDS | global when NPASS == 1) -> RL butterflies of the mirror pair -> tangle -> global
+  RF_HD static void pass_last(int tid, long long tile, long long nrows, const IO& io, const cx* tw, cx* lds) {
+    constexpr int R = C::RL, L = LL;
+#pragma unroll
+    for (int it = 0; it < ITLP; ++it) {
+      const int w = it * NT + tid;
+      const int rl = w / TPRL, q = w % TPRL;
+      const long long row = tile * C::NRT + rl;
+      if (rl < C::NRT && row < nrows) {
+        const bool self = (q == 0);
+        const int ja = q, jb = self ? L / 2 : L - q;
+        const bool has_b = (L >= 2);
+        cx A[R], B[R];
+#pragma unroll
+        for (int m = 0; m < R; ++m) {
+          cx x = (C::NPASS == 1) ? io.load(row, ja + m * L) : *lds_at(lds, rl, ja + m * L);
+          if (C::NPASS > 1 && m > 0) x = cmul(x, cconj(tw[2 * m * ja]));
+          A[m] = x;
+        }
+        DFT<R, DIR>::run(A);                      // A[m] = Z[ja + m L]
+        if (has_b) {
+#pragma unroll
+          for (int m = 0; m < R; ++m) {
+            cx x = (C::NPASS == 1) ? io.load(row, jb + m * L) : *lds_at(lds, rl, jb + m * L);
+            if (C::NPASS > 1 && m > 0) x = cmul(x, cconj(tw[2 * m * jb]));
+            B[m] = x;
+          }
+          DFT<R, DIR>::run(B);                    // B[m] = Z[jb + m L]
+        }
+        // mirror of k = ja + m L is M - k = jb + (R-1-m) L  (ja >= 1); for ja = 0: (R - m) L, and k = 0 <-> M
+#pragma unroll
+        for (int m = 0; m < R; ++m) {
+          const int ka = ja + m * L;
+          if (self) {
+            if (m == 0) io.store(row, 0, mk<T>(A[0].x + A[0].y, A[0].x - A[0].y));   // (X[0], X[M]) packed
+            else io.store(row, ka, r2c_tangle(A[m], A[R - m], tw[ka]));
+          } else {
+            io.store(row, ka, r2c_tangle(A[m], B[R - 1 - m], tw[ka]));
+          }
+          if (has_b) {
+            const int kb = jb + m * L;
+            io.store(row, kb, self ? r2c_tangle(B[m], B[R - 1 - m], tw[kb]) : r2c_tangle(B[m], A[R - 1 - m], tw[kb]));
+          }
+        }
+      }
+    }
+  }
+};
+
 }  // namespace rf

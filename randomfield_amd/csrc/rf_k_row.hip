@@ -46,6 +46,33 @@ hipError_t launch_gather_t(int M, const cplx<T>* src, cplx<T>* dst, long long nr
     default: return hipErrorInvalidValue;
   }
 }
+template <class C>
+hipError_t launch_fwd_one(const PlainRowFwdIO<typename C::T>& io, long long nrows, const cplx<typename C::T>* tw, hipStream_t s, bool po) {
+  const long long ntiles = (nrows + C::NRT - 1) / C::NRT;
+  auto k = row_r2c_kernel<C, PlainRowFwdIO<typename C::T>>;
+  constexpr int lds = C::LDS_BYTES > 64 ? C::LDS_BYTES : 64;
+  static bool prepared = false;
+  if (!prepared) {
+    if (lds > 65536) {
+      hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      if (e != hipSuccess) return e;
+    }
+    prepared = true;
+  }
+  if (po) return hipSuccess;
+  hipLaunchKernelGGL(k, dim3((unsigned)ntiles), dim3(C::NT), lds, s, io, tw, nrows);
+  return hipGetLastError();
+}
+template <typename T>
+hipError_t launch_fwd_t(int M, cplx<T>* W, long long nrows, const cplx<T>* tw, hipStream_t s, bool po) {
+  PlainRowFwdIO<T> io; io.base = W; io.M_of = M;
+  switch (M) {
+#define X(MM) case MM: return launch_fwd_one<typename RowSel<T, MM>::type>(io, nrows, tw, s, po);
+    RF_ROW_SIZES(X)
+#undef X
+    default: return hipErrorInvalidValue;
+  }
+}
 template <typename T> long long tiles_t(int M, long long nrows) {
   switch (M) {
 #define X(MM) case MM: return (nrows + RowSel<T, MM>::type::NRT - 1) / RowSel<T, MM>::type::NRT;
@@ -65,6 +92,10 @@ hipError_t launch_row_c2r_gather(int f64, int M, const void* src, void* dst, lon
                                  long long seg_stride, const void* tw, double* partials, hipStream_t s, bool po) {
   if (f64) return launch_gather_t<double>(M, (const cplx<double>*)src, (cplx<double>*)dst, nrows, scale, nzl, seg_stride, (const cplx<double>*)tw, partials, s, po);
   return launch_gather_t<float>(M, (const cplx<float>*)src, (cplx<float>*)dst, nrows, scale, nzl, seg_stride, (const cplx<float>*)tw, partials, s, po);
+}
+hipError_t launch_row_r2c(int f64, int M, void* W, long long nrows, const void* tw, hipStream_t s, bool po) {
+  if (f64) return launch_fwd_t<double>(M, (cplx<double>*)W, nrows, (const cplx<double>*)tw, s, po);
+  return launch_fwd_t<float>(M, (cplx<float>*)W, nrows, (const cplx<float>*)tw, s, po);
 }
 long long row_c2r_tiles(int f64, int M, long long nrows) {
   return f64 ? tiles_t<double>(M, nrows) : tiles_t<float>(M, nrows);

@@ -96,4 +96,25 @@ __global__ __launch_bounds__(C::NT) void row_c2r_kernel(IO io, const cplx<typena
   }
 }
 
+// forward z pass: r2c rows in place
+template <class C, class IO>
+__global__ __launch_bounds__(C::NT) void row_r2c_kernel(IO io, const cplx<typename C::T>* __restrict__ tw, long long nrows) {
+  using F = RowR2C<C, IO>;
+  using cx = cplx<typename C::T>;
+  extern __shared__ __attribute__((aligned(16))) char rf_smem[];
+  cx* lds = reinterpret_cast<cx*>(rf_smem);
+  const int tid = threadIdx.x;
+  const long long tile = blockIdx.x;
+  if (C::NPASS >= 2) F::pass_first(tid, tile, nrows, io, lds);
+  if (C::NPASS == 3) {
+    typename F::Regs r;
+    __syncthreads();
+    F::pass_mid_read(tid, tw, lds, r);
+    __syncthreads();
+    F::pass_mid_write(tid, lds, r);
+  }
+  if (C::NPASS >= 2) __syncthreads();
+  F::pass_last(tid, tile, nrows, io, tw, lds);
+}
+
 }  // namespace rf

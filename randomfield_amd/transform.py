@@ -175,13 +175,14 @@ class Plan(object):
     With the ``hip`` backend ``execute()`` uploads ``data_in``, runs the
     transform on the GPU and downloads the result into ``data_out`` (the host
     copies are the price of the numpy-array API; device-resident use goes through
-    :class:`randomfield_amd.generate.Generator` or :attr:`device`).  A packed
-    inverse (c2r) transform assumes Hermitian input in the kz = 0 and kz = nz/2
-    planes, as FFTW's multi-dimensional c2r does.
+    :class:`randomfield_amd.generate.Generator` or :attr:`device`).  Packed inverse
+    (c2r) and forward (r2c) plans run on the GPU; a c2r transform assumes Hermitian
+    input in the kz = 0 and kz = nz/2 planes, as FFTW's multi-dimensional c2r does
+    (see DESIGN.md).
     """
 
     def __init__(self, shape, dtype_in=None, data_in=None, overwrite=True, inverse=True, packed=True,
-                 use_pyfftw=True, backend=None):
+                 use_pyfftw=True, backend=None, _device=None):
         try:
             nx, ny, nz = shape
         except (TypeError, ValueError):
@@ -255,8 +256,6 @@ class Plan(object):
             _hip.require_gpu()           # raises: library missing / no GPU
             if not packed:
                 raise RuntimeError("hip backend: unpacked (c2c) transforms are not built; use backend='numpy'.")
-            if not inverse:
-                raise RuntimeError("hip backend: forward (r2c) transforms are not built yet; use backend='numpy'.")
             cdtype = dtype_in if inverse else dtype_out
             if np.dtype(cdtype) not in (np.dtype(np.complex64), np.dtype(np.complex128)):
                 raise RuntimeError("hip backend supports complex64 / complex128 only: {0}.".format(cdtype))
@@ -264,7 +263,9 @@ class Plan(object):
                 raise RuntimeError(
                     "hip backend: shape {0} is not supported (power-of-two axes, nx, ny in 8..2048, nz in "
                     "16..2048); use backend='numpy' explicitly for this shape.".format(tuple(shape)))
-            self.device = _hip.DevicePlan(nx, ny, nz, cdtype)
+            # a reverse plan that shares our memory also shares our device plan (one device buffer, as the
+            # reference's pair of plans shares one host buffer)
+            self.device = _device if _device is not None else _hip.DevicePlan(nx, ny, nz, cdtype)
         else:
             if inverse:
                 self.transformer = np.fft.irfftn if packed else np.fft.ifftn
@@ -291,24 +292,28 @@ class Plan(object):
         else:
             data_in = None
             dtype_in = self.data_out.dtype
-        backend = self.backend
-        if backend == "hip" and (not inverse or not self.packed):
-            # the forward / unpacked directions are host-side (numpy) plans until the r2c kernels land
-            backend = "numpy"
         return Plan(shape=self.shape, dtype_in=dtype_in, data_in=data_in, overwrite=overwrite, inverse=inverse,
-                    packed=self.packed, use_pyfftw=self.use_pyfftw, backend=backend)
+                    packed=self.packed, use_pyfftw=self.use_pyfftw, backend=self.backend,
+                    _device=self.device if self.backend == "hip" else None)
 
     def execute(self):
         """Run the transform; returns ``data_out`` (transform.py:303-315)."""
         if self.backend == "hip":
-            nx, ny, nz = self.shape
             dev = self.device
-            dev.upload_k(self.data_in)
-            dev.execute_c2r()
-            if self.overwrite:
-                dev.download_real(self.data_out_padded, padded=True)
+            if self.inverse:
+                dev.upload_k(np.ascontiguousarray(self.data_in))
+                dev.execute_c2r()
+                if self.overwrite:
+                    dev.download_real(self.data_out_padded, padded=True)
+                else:
+                    dev.download_real(self.data_out, padded=False)
             else:
-                dev.download_real(self.data_out, padded=False)
+                if self.overwrite:
+                    dev.upload_real(self.data_in_padded, padded=True)
+                else:
+                    dev.upload_real(np.ascontiguousarray(self.data_in), padded=False)
+                dev.execute_r2c()
+                dev.download_k(self.data_out)
             return self.data_out
         if self.packed and self.inverse:
             nx, ny, nz = self.shape

@@ -100,3 +100,14 @@ def realise_fast(nx, ny, nz, spacing, log10k, sigma, seed):
                                 out.ctypes.data_as(ctypes.c_void_p), ctypes.byref(s1), ctypes.byref(s2))
     assert rc == 0, rc
     return out, s1.value, s2.value
+
+
+def r2c(field):
+    nx, ny, nz = field.shape
+    ct = np.complex64 if field.dtype == np.float32 else np.complex128
+    out = np.empty((nx, ny, nz // 2 + 1), ct)
+    f = np.ascontiguousarray(field)
+    rc = lib().emu_r2c(int(ct == np.complex128), nx, ny, nz, f.ctypes.data_as(ctypes.c_void_p),
+                       out.ctypes.data_as(ctypes.c_void_p))
+    assert rc == 0, rc
+    return out

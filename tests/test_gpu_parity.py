@@ -408,3 +408,67 @@ def test_slab_float64_and_rccl_single_rank(hip, dpower):
     one.realise(seed=3)
     assert np.array_equal(one.download_real(), ref)
     one.close()
+
+
+@pytest.mark.parametrize("shape", [(8, 8, 16), (16, 32, 64), (64, 64, 64), (32, 128, 256), (256, 16, 1024)])
+def test_forward_r2c_against_numpy(hip, shape):
+    """rf_execute_r2c (transform.py:199-206,270): forward, unnormalised, API k layout; and c2r(r2c(x)) = x."""
+    rng = np.random.RandomState(9)
+    for dtype, ct, tol in ((np.float32, np.complex64, 3e-6), (np.float64, np.complex128, 1e-13)):
+        nx, ny, nz = shape
+        f = rng.normal(size=shape).astype(dtype)
+        plan = hip.DevicePlan(nx, ny, nz, ct)
+        plan.upload_real(f)
+        plan.execute_r2c()
+        spec = plan.download_k()
+        ref = np.fft.rfftn(f.astype(np.float64), axes=(0, 1, 2))
+        assert spec.shape == (nx, ny, nz // 2 + 1) and spec.dtype == ct
+        assert np.max(np.abs(spec - ref)) <= tol * np.sqrt(f.size) * 3
+        assert cpu_ref.is_hermitian_packed(spec, rtol=0, atol=tol * np.sqrt(f.size) * 3)
+        plan.execute_c2r()                                              # k buffer -> real field
+        assert np.max(np.abs(plan.download_real() - f)) <= 10 * tol
+        plan.close()
+    g = golden("r2c_8x16x32_f32.npz")
+    plan = hip.DevicePlan(8, 16, 32, np.complex64)
+    plan.upload_real(g["field"])
+    plan.execute_r2c()
+    assert np.allclose(plan.download_k(), g["spectrum"], rtol=0, atol=1e-4)       # the reference's own rfftn output
+    plan.close()
+
+
+def test_round_trip_at_full_size(hip, dpower):
+    """Size-independent property at BASELINE size: r2c(c2r(K)) reproduces the generated k space and
+    c2r(r2c(delta)) the field (1024^3 float32, values compared on slabs / planes)."""
+    n = 1024
+    k, Pk = dpower
+    plan = make_plan(hip, (n, n, n), np.complex64, k, Pk)
+    plan.realise(seed=5)
+    mean, std = plan.moments()
+    slab = plan.download_real(x0=100, x1=101).copy()
+    plan.execute_r2c()                                                   # delta(x) -> delta(k)
+    plan.execute_c2r()                                                   # and back
+    back = plan.download_real(x0=100, x1=101)
+    assert np.max(np.abs(back - slab)) <= 2e-5 * std
+    m2, s2 = plan.moments()
+    assert abs(s2 - std) <= 1e-5 * std
+    plan.close()
+
+
+def test_plan_r2c_and_reverse_on_device(hip):
+    """transform.Plan forward plans and create_reverse_plan on the hip backend (tests/test_transform.py:270-298)."""
+    from randomfield_amd.transform import Plan
+    rng = np.random.RandomState(4)
+    shape = (16, 16, 32)
+    for ftype in (np.float32, np.float64):
+        for overwrite in (True, False):
+            plan_f = Plan(shape=shape, dtype_in=ftype, inverse=False, packed=True, overwrite=overwrite)
+            assert plan_f.backend == "hip"
+            plan_r = plan_f.create_reverse_plan(reuse_output=True, overwrite=True)
+            assert plan_r.device is plan_f.device and plan_r.nbytes_allocated == 0
+            plan_f.data_in[:] = rng.normal(size=shape)
+            original = np.copy(plan_f.data_in)
+            spec = plan_f.execute()
+            assert np.allclose(spec, np.fft.rfftn(original.astype(np.float64), axes=(0, 1, 2)), rtol=0,
+                               atol=2e-4 if ftype == np.float32 else 1e-10)
+            result = plan_r.execute()
+            assert np.allclose(original, result, atol=1e-5 if ftype == np.float32 else 1e-12)

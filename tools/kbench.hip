@@ -200,7 +200,8 @@ int main(int argc, char** argv) {
       report(nm, bench_fastgen<C>(t, W, tw, fp), sweep);                                              \
     }
     GEN(8, 16, 8, 8, 512)
-#define ABL(AB, label) { using C = ColCfg<float, 1024, 8, 16, 8, 8, 512>; report(label, bench_fastgen<C, AB>(t, W, tw, fp), sweep); }
+#define ABL(AB, label) { using C = ColCfg<float, 1024, 8, 16, 8, 8, 512>; report(label, bench_fastgen<C, AB, 0>(t, W, tw, fp), sweep); }
+    ABL(8, "  variant: Philox4x32-7 instead of -10")
     ABL(1, "  ablation: no Philox")
     ABL(2, "  ablation: no sigma lookup")
     ABL(4, "  ablation: no Box-Muller")
