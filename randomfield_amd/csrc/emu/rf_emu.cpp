@@ -20,7 +20,7 @@ template <class C, int DIR, class IO>
 void run_col_pass(const IO& io_in, long long ncols, const cplx<typename C::T>* tw) {
   using F = ColFFT<C, DIR, IO>;
   using cx = cplx<typename C::T>;
-  std::vector<cx> lds((size_t)(C::LDS_BYTES + IO::LDS_EXTRA) / sizeof(cx) + 16);
+  std::vector<cx> lds((size_t)(C::LDS_BYTES + IO::LDS_EXTRA) / sizeof(cx));   // exactly the kernel's dynamic LDS
   std::vector<typename F::Regs> regs(C::NT);
   std::vector<IO> ios(C::NT, io_in);             // every "thread" has its own copy of the kernel argument
   const long long ntiles = ncols / C::TC;
@@ -59,7 +59,7 @@ template <class C>
 void run_row_c2r(const PlainRowIO<typename C::T>& io, long long nrows, const cplx<typename C::T>* tw, double* s1, double* s2) {
   using F = RowC2R<C, PlainRowIO<typename C::T>>;
   using cx = cplx<typename C::T>;
-  std::vector<cx> lds((size_t)C::LDS_BYTES / sizeof(cx) + 16);
+  std::vector<cx> lds((size_t)C::LDS_BYTES / sizeof(cx));
   std::vector<typename F::Regs> regs(C::NT);
   const long long ntiles = (nrows + C::NRT - 1) / C::NRT;
   double a1 = 0, a2 = 0;
@@ -92,7 +92,7 @@ template <class C>
 void run_row_r2c(const PlainRowFwdIO<typename C::T>& io, long long nrows, const cplx<typename C::T>* tw) {
   using F = RowR2C<C, PlainRowFwdIO<typename C::T>>;
   using cx = cplx<typename C::T>;
-  std::vector<cx> lds((size_t)C::LDS_BYTES / sizeof(cx) + 16);
+  std::vector<cx> lds((size_t)C::LDS_BYTES / sizeof(cx));
   std::vector<typename F::Regs> regs(C::NT);
   const long long ntiles = (nrows + C::NRT - 1) / C::NRT;
   for (long long tile = 0; tile < ntiles; ++tile) {
