@@ -179,9 +179,16 @@ template <> struct BoxMuller<double> {
     double u1 = ((double)wa + 0.5) * (1.0 / 4294967296.0);
     double u2 = ((double)wb + 0.5) * (1.0 / 4294967296.0);
     double r = sqrt(-2.0 * log(u1));
+#if defined(__HIP_DEVICE_COMPILE__)
+    double sn, cs;
+    sincospi(2.0 * u2, &sn, &cs);       // no Payne-Hanek style reduction: the argument is an exact multiple of pi
+    g0 = r * cs;
+    g1 = r * sn;
+#else
     double a = (2.0 * M_PI) * u2;
     g0 = r * cos(a);
     g1 = r * sin(a);
+#endif
   }
 };
 template <> struct BoxMuller<float> {
