@@ -201,6 +201,7 @@ int build_fast(rf_plan* p) {
   double x0, dx;
   if (!build_fast_records(p->h_tab, 0.5 * std::log10(kmin2) - 0.01, 0.5 * std::log10(kmax2) + 0.01, rec, x0, dx))
     return 0;   // knots too dense for the per-bin records: the exact kernel is used instead
+  if ((int)rec.size() > FAST_LDS_BINS) return 0;   // the records must fit the kernel's LDS table
   // the fast kernel forms kx arithmetically: kx(i) = dkx * signed index; needs a uniform fftfreq-style x axis
   if (p->nx < 2 || !(p->h_kx2[1] > 0)) return 0;
   p->fdkx = (float)std::sqrt(p->h_kx2[1]);

@@ -197,7 +197,9 @@ template <> struct BoxMuller<float> {
     float u1 = ((float)(wa >> 8) + 0.5f) * (1.0f / 16777216.0f);
     float u2 = ((float)(wb >> 8) + 0.5f) * (1.0f / 16777216.0f);
 #if defined(__HIP_DEVICE_COMPILE__)
-    float r = __builtin_sqrtf(-2.0f * __logf(u1));
+    // raw v_log_f32 / v_sqrt_f32: u1 >= 2^-25 and -2 ln u1 in (0, 35) are normal numbers, so the
+    // denormal fix-ups of logf / sqrtf are not needed.  -2 ln u = (-2 ln 2) log2 u
+    float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));
     // v_sin_f32 / v_cos_f32 take their argument in revolutions
     g0 = r * __builtin_amdgcn_cosf(u2);
     g1 = r * __builtin_amdgcn_sinf(u2);
@@ -387,7 +389,8 @@ RF_HD float fast_sigma(const FastGenParams& g, const FastRec* rec, float t /* |k
 
 // AB: development-only ablation mask (1: no Philox, 2: no sigma lookup, 4: no Box-Muller); 0 in the product
 RF_HD float fast_kx2(const FastGenParams& g, int ix) {
-  const float kx = (float)(ix < g.nx / 2 ? ix : ix - g.nx) * g.dkx;
+  // signed fftfreq index without a select: nx is a power of two, so (ix & nx/2) is 0 or nx/2
+  const float kx = (float)(ix - 2 * (ix & (g.nx >> 1))) * g.dkx;
   return kx * kx;
 }
 

@@ -80,7 +80,7 @@ template <typename T> struct PlainColIO {
   RF_HD cplx<T> fix_value(long long, int) const { return cplx<T>(); }
   static constexpr int LDS_EXTRA = 0;
   RF_HD void prologue(int, int, void*) {}
-  RF_HD static void sched_fence() {}      // loads of one butterfly are meant to be issued back to back
+  RF_HD static void sched_fence(int = 0) {}      // loads of one butterfly are meant to be issued back to back
   static constexpr bool ROLLED_LOAD = false;
 };
 
@@ -122,7 +122,7 @@ template <typename T> struct GenColIO {
   RF_HD cplx<T> fix_value(long long, int) const { return cplx<T>(); }
   static constexpr int LDS_EXTRA = 0;
   RF_HD void prologue(int, int, void*) {}
-  RF_HD static void sched_fence() {}
+  RF_HD static void sched_fence(int = 0) {}
   // the exact-chain generation body (float64 lookups, libm-grade log10 / sin / cos) is far too big to be
   // replicated R times: the load loop stays rolled and parks its values in the thread's own LDS slots
   static constexpr bool ROLLED_LOAD = true;
@@ -139,20 +139,23 @@ struct FastGenColIOT {
   int kz0, nzl;
   const FastRec* rec;      // set by prologue(): LDS copy of the sigma records (or the global one)
   static constexpr int LDS_EXTRA = FAST_LDS_BINS * (int)sizeof(FastRec);
-  // keep the compiler from interleaving all R generation bodies of a butterfly (register blow-up)
-  RF_HD static void sched_fence() {
+  // keep the compiler from interleaving all R generation bodies of a butterfly (register blow-up);
+  // RF_FENCE_EVERY = 0 disables it, k > 0 fences after every k-th row (timing experiments)
+#ifndef RF_FENCE_EVERY
+#define RF_FENCE_EVERY 0
+#endif
+  RF_HD static void sched_fence(int m = 0) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    __builtin_amdgcn_sched_barrier(0);
+    if (RF_FENCE_EVERY > 0 && (m % (RF_FENCE_EVERY > 0 ? RF_FENCE_EVERY : 1)) == (RF_FENCE_EVERY > 0 ? RF_FENCE_EVERY - 1 : 0)) __builtin_amdgcn_sched_barrier(0);
 #endif
   }
   // stage the sigma records in LDS (every thread copies its share; the kernel barriers afterwards)
+  // (the host only selects this kernel when nbins <= FAST_LDS_BINS, so `rec` is always an LDS pointer
+  // and the lookups compile to ds_read_b128, not flat loads)
   RF_HD void prologue(int tid, int nthreads, void* lds_extra) {
-    rec = gp.rec;
-    if (gp.nbins <= FAST_LDS_BINS) {
-      FastRec* l = reinterpret_cast<FastRec*>(lds_extra);
-      for (int i = tid; i < gp.nbins; i += nthreads) l[i] = gp.rec[i];
-      rec = l;
-    }
+    FastRec* l = reinterpret_cast<FastRec*>(lds_extra);
+    for (int i = tid; i < gp.nbins && i < FAST_LDS_BINS; i += nthreads) l[i] = gp.rec[i];
+    rec = l;
   }
   RF_HD V16<float> load(long long C, int row) const {
     V16<float> v;
@@ -233,7 +236,7 @@ struct ColFFT {
             V x = io.load(Ccol, j + m * L);
 #pragma unroll
             for (int c = 0; c < CPL; ++c) v[c][m] = x.c[c];
-            IO::sched_fence();
+            IO::sched_fence(m);
           }
         }
         if (IO::FIX_MODE != 0 && io.needs_fix(Ccol)) {
