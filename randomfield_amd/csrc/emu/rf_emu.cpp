@@ -64,13 +64,15 @@ void run_row_c2r(const PlainRowIO<typename C::T>& io, long long nrows, const cpl
   const long long ntiles = (nrows + C::NRT - 1) / C::NRT;
   double a1 = 0, a2 = 0;
   for (long long tile = 0; tile < ntiles; ++tile) {
-    for (int t = 0; t < C::NT; ++t) F::pass_first(t, tile, nrows, io, tw, lds.data(), regs[t]);
+    for (int t = 0; t < C::NT; ++t) F::prologue(t, tw, lds.data());
+    const cx* ltw = F::lds_tw(lds.data());
+    for (int t = 0; t < C::NT; ++t) F::pass_first(t, tile, nrows, io, ltw, lds.data(), regs[t]);
     if (C::NPASS == 3) {
-      for (int t = 0; t < C::NT; ++t) F::pass_mid_read(t, tw, lds.data(), regs[t]);
+      for (int t = 0; t < C::NT; ++t) F::pass_mid_read(t, ltw, lds.data(), regs[t]);
       for (int t = 0; t < C::NT; ++t) F::pass_mid_write(t, lds.data(), regs[t]);
     }
     if (C::NPASS >= 2)
-      for (int t = 0; t < C::NT; ++t) F::pass_last(t, tile, nrows, io, tw, lds.data(), regs[t]);
+      for (int t = 0; t < C::NT; ++t) F::pass_last(t, tile, nrows, io, ltw, lds.data(), regs[t]);
     for (int t = 0; t < C::NT; ++t) { a1 += regs[t].s1; a2 += regs[t].s2; }
   }
   *s1 = a1; *s2 = a2;
@@ -96,13 +98,15 @@ void run_row_r2c(const PlainRowFwdIO<typename C::T>& io, long long nrows, const 
   std::vector<typename F::Regs> regs(C::NT);
   const long long ntiles = (nrows + C::NRT - 1) / C::NRT;
   for (long long tile = 0; tile < ntiles; ++tile) {
+    for (int t = 0; t < C::NT; ++t) F::prologue(t, tw, lds.data());
+    const cx* ltw = F::lds_tw(lds.data());
     if (C::NPASS >= 2) for (int t = 0; t < C::NT; ++t) F::pass_first(t, tile, nrows, io, lds.data());
     if (C::NPASS == 3) {
-      for (int t = 0; t < C::NT; ++t) F::pass_mid_read(t, tw, lds.data(), regs[t]);
+      for (int t = 0; t < C::NT; ++t) F::pass_mid_read(t, ltw, lds.data(), regs[t]);
       for (int t = 0; t < C::NT; ++t) F::pass_mid_write(t, lds.data(), regs[t]);
     }
     // every thread reads all its LDS inputs before any thread stores (stores go to global memory only)
-    for (int t = 0; t < C::NT; ++t) F::pass_last(t, tile, nrows, io, tw, lds.data());
+    for (int t = 0; t < C::NT; ++t) F::pass_last(t, tile, nrows, io, ltw, lds.data());
   }
 }
 

@@ -248,7 +248,7 @@ int queue_z_slab(rf_plan* p, hipStream_t s) {
   const long long nrows = (long long)p->nxl * p->ny;
   const double scale = 1.0 / ((double)p->nx * (double)p->ny * (double)p->nz);
   RF_HIP(launch_row_c2r_gather(p->f64, p->nzc, p->R, p->W, nrows, scale, p->nzl, nrows * p->nzl, p->tw_z, p->partials, s));
-  RF_HIP(launch_reduce_partials(p->partials, p->npartials, p->stats, nullptr, s));
+  RF_HIP(launch_reduce_partials(p->partials, p->npartials, p->stats, p->partials + 2 * p->npartials, s));
   p->cur = p->W;
   p->stats_slot = 0;
   p->real_valid = true;
@@ -288,7 +288,7 @@ int queue_yz(rf_plan* p, void* W, hipStream_t s, double* stats_out, bool timed) 
   }
   if (timed && S != p->nx) RF_HIP(hipEventRecord(p->ev[2], s));   // y and z interleaved: no split
   if (timed) RF_HIP(hipEventRecord(p->ev[3], s));
-  RF_HIP(launch_reduce_partials(p->partials, p->npartials, stats_out, nullptr, s));
+  RF_HIP(launch_reduce_partials(p->partials, p->npartials, stats_out, p->partials + 2 * p->npartials, s));
   if (timed) RF_HIP(hipEventRecord(p->ev[4], s));
   return 0;
 }
@@ -413,7 +413,7 @@ int rf_plan_create(rf_plan** out, int nx, int ny, int nz, int dtype, int device,
     p->npartials = row_c2r_tiles(dtype, p->nzc, (long long)S * ny) * ((nx + S - 1) / S);
   }
   p->stats_cap = 64;
-  if ((e = hipMalloc((void**)&p->partials, 2 * p->npartials * sizeof(double))) != hipSuccess ||
+  if ((e = hipMalloc((void**)&p->partials, (2 * p->npartials + 512) * sizeof(double))) != hipSuccess ||
       (e = hipMalloc((void**)&p->stats, 2 * p->stats_cap * sizeof(double))) != hipSuccess ||
       (e = hipMalloc((void**)&p->seed_cur, sizeof(uint64_t))) != hipSuccess ||
       (e = hipMalloc((void**)&p->counter, sizeof(unsigned long long))) != hipSuccess ||

@@ -41,8 +41,8 @@ RF_ROW(32,   8,  4,  1,  64,  8,  4,  1,  32,  256)
 RF_ROW(64,   8,  8,  1,  64,  8,  8,  1,  32,  256)
 RF_ROW(128,  8,  16, 1,  32,  8,  4,  4,  16,  256)
 RF_ROW(256,  8,  8,  4,  16,  8,  8,  4,  8,   256)
-RF_ROW(512,  16, 8,  4,  16,  8,  8,  8,  8,   256)
-RF_ROW(1024, 8,  8,  16, 4,   8,  8,  16, 2,   256)
+RF_ROW(512,  8,  8,  8,  8,   8,  8,  8,  4,   256)
+RF_ROW(1024, 8,  16, 8,  4,   8,  8,  16, 2,   256)
 #undef RF_ROW
 #define RF_ROW_SIZES(X) X(8) X(16) X(32) X(64) X(128) X(256) X(512) X(1024)
 

@@ -345,7 +345,9 @@ struct RowCfg {
   static constexpr int NPASS = (R2 == 1 ? 1 : (R3 == 1 ? 2 : 3));
   static constexpr int RL = (NPASS == 1 ? R1 : (NPASS == 2 ? R2 : R3));
   static constexpr int RS = M + ((M - 1) >> 4) + 1 + 1;       // LDS row stride (complex), odd-ish shift between rows
-  static constexpr int LDS_BYTES = (NPASS == 1 ? 0 : NRT * RS * (int)sizeof(cplx<T>));
+  static constexpr int TILE_BYTES = (NPASS == 1 ? 0 : NRT * RS * (int)sizeof(cplx<T>));
+  static constexpr int TW_BYTES = 2 * M * (int)sizeof(cplx<T>);    // twiddle table exp(2 pi i q / 2M), staged behind the tile
+  static constexpr int LDS_BYTES = TILE_BYTES + TW_BYTES;
   static constexpr int L1 = M / R1;                           // butterflies per row in pass 1
   static constexpr int TPR1 = cmax(1, L1 / 2);                // threads per row in pass 1 (each owns a mirror pair)
   static constexpr int IT1 = ceil_div(NRT * TPR1, NT);
@@ -402,6 +404,12 @@ struct RowC2R {
   struct Regs { cx v[C::IT2][cmax(C::R2, 1)]; double s1, s2; };
 
   RF_HD static cx* lds_at(cx* lds, int rl, int i) { return lds + (long long)rl * C::RS + pad16(i); }
+  RF_HD static cx* lds_tw(cx* lds) { return lds + C::TILE_BYTES / (int)sizeof(cx); }
+  // prologue: stage the twiddle table in LDS (a barrier follows)
+  RF_HD static void prologue(int tid, const cx* tw, cx* lds) {
+    cx* l = lds_tw(lds);
+    for (int i = tid; i < 2 * M; i += NT) l[i] = tw[i];
+  }
 
   // pass 1 outputs: LDS (NPASS > 1) or global (NPASS == 1)
   template <int R>
@@ -542,6 +550,11 @@ struct RowR2C {
   struct Regs { cx v[C::IT2][cmax(C::R2, 1)]; };
 
   RF_HD static cx* lds_at(cx* lds, int rl, int i) { return lds + (long long)rl * C::RS + pad16(i); }
+  RF_HD static cx* lds_tw(cx* lds) { return lds + C::TILE_BYTES / (int)sizeof(cx); }
+  RF_HD static void prologue(int tid, const cx* tw, cx* lds) {
+    cx* l = lds_tw(lds);
+    for (int i = tid; i < 2 * M; i += NT) l[i] = tw[i];
+  }
 
   // pass 1 (only when NPASS >= 2): global -> R1 butterfly -> LDS
   RF_HD static void pass_first(int tid, long long tile, long long nrows, const IO& io, cx* lds) {

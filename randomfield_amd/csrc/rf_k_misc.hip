@@ -20,11 +20,13 @@ __global__ __launch_bounds__(256) void gen_kspace_kernel(cplx<T>* __restrict__ K
   }
 }
 
-__global__ __launch_bounds__(1024) void reduce_partials_kernel(const double* __restrict__ partials, long long n,
-                                                              double* __restrict__ stats, unsigned long long* counter) {
-  __shared__ double red[2 * 16];
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const double* __restrict__ partials, long long n,
+                                                             double* __restrict__ out, long long chunk) {
+  // block b sums pairs [b*chunk, min(n, (b+1)*chunk)) -> out[2b], out[2b+1]; fixed order: deterministic
+  __shared__ double red[2 * 4];
+  const long long lo = (long long)blockIdx.x * chunk, hi = lo + chunk < n ? lo + chunk : n;
   double a = 0, b = 0;
-  for (long long i = threadIdx.x; i < n; i += blockDim.x) { a += partials[2 * i]; b += partials[2 * i + 1]; }
+  for (long long i = lo + threadIdx.x; i < hi; i += blockDim.x) { a += partials[2 * i]; b += partials[2 * i + 1]; }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); b += __shfl_down(b, off); }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -33,10 +35,8 @@ __global__ __launch_bounds__(1024) void reduce_partials_kernel(const double* __r
   if (threadIdx.x == 0) {
     a = 0; b = 0;
     for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { a += red[2 * w]; b += red[2 * w + 1]; }
-    unsigned long long slot = 0;
-    if (counter) { slot = *counter; *counter = slot + 1; }
-    stats[2 * slot] = a;
-    stats[2 * slot + 1] = b;
+    out[2 * (long long)blockIdx.x] = a;
+    out[2 * (long long)blockIdx.x + 1] = b;
   }
 }
 
@@ -156,9 +156,16 @@ hipError_t launch_unpack_kspace(int f64, const void* W, void* K, int nx, int ny,
   return hipGetLastError();
 }
 
-hipError_t launch_reduce_partials(const double* partials, long long n, double* stats, unsigned long long* counter,
-                                  hipStream_t s) {
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(1024), 0, s, partials, n, stats, counter);
+// two levels: 256 blocks reduce chunks of the partials into `scratch` (2*256 doubles), one block finishes
+hipError_t launch_reduce_partials(const double* partials, long long n, double* stats, double* scratch, hipStream_t s) {
+  const int nb = n > 4096 ? 256 : 1;
+  if (nb == 1) {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, s, partials, n, stats, n);
+    return hipGetLastError();
+  }
+  const long long chunk = (n + nb - 1) / nb;
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(nb), dim3(256), 0, s, partials, n, scratch, chunk);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, s, (const double*)scratch, (long long)nb, stats, (long long)nb);
   return hipGetLastError();
 }
 

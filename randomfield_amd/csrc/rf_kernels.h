@@ -64,16 +64,19 @@ __global__ __launch_bounds__(C::NT) void row_c2r_kernel(IO io, const cplx<typena
   const int tid = threadIdx.x;
   const long long tile = blockIdx.x;
   typename F::Regs r;
-  F::pass_first(tid, tile, nrows, io, tw, lds, r);
+  F::prologue(tid, tw, lds);                 // twiddles -> LDS
+  const cx* ltw = F::lds_tw(lds);
+  __syncthreads();
+  F::pass_first(tid, tile, nrows, io, ltw, lds, r);
   if (C::NPASS == 3) {
     __syncthreads();
-    F::pass_mid_read(tid, tw, lds, r);
+    F::pass_mid_read(tid, ltw, lds, r);
     __syncthreads();
     F::pass_mid_write(tid, lds, r);
   }
   if (C::NPASS >= 2) {
     __syncthreads();
-    F::pass_last(tid, tile, nrows, io, tw, lds, r);
+    F::pass_last(tid, tile, nrows, io, ltw, lds, r);
   }
   // workgroup reduction of the moments: wave shuffle, then one slot per wave in LDS
   double s1 = r.s1, s2 = r.s2;
@@ -105,16 +108,18 @@ __global__ __launch_bounds__(C::NT) void row_r2c_kernel(IO io, const cplx<typena
   cx* lds = reinterpret_cast<cx*>(rf_smem);
   const int tid = threadIdx.x;
   const long long tile = blockIdx.x;
+  F::prologue(tid, tw, lds);                 // twiddles -> LDS
+  const cx* ltw = F::lds_tw(lds);
   if (C::NPASS >= 2) F::pass_first(tid, tile, nrows, io, lds);
   if (C::NPASS == 3) {
     typename F::Regs r;
     __syncthreads();
-    F::pass_mid_read(tid, tw, lds, r);
+    F::pass_mid_read(tid, ltw, lds, r);
     __syncthreads();
     F::pass_mid_write(tid, lds, r);
   }
-  if (C::NPASS >= 2) __syncthreads();
-  F::pass_last(tid, tile, nrows, io, tw, lds);
+  __syncthreads();
+  F::pass_last(tid, tile, nrows, io, ltw, lds);
 }
 
 }  // namespace rf

@@ -35,10 +35,8 @@ long long row_c2r_tiles(int f64, int M, long long nrows);
 
 // rows K,T,R,S into an API-layout k array [nx][ny][nz/2+1]
 hipError_t launch_gen_kspace(int f64, void* K, const GenParams& gp, hipStream_t s);
-// stats[0] = sum of partials[2i], stats[1] = sum of partials[2i+1]; if counter != nullptr the pair is
-// written at stats[2 * *counter] and *counter is incremented (graph replay)
-hipError_t launch_reduce_partials(const double* partials, long long n, double* stats, unsigned long long* counter,
-                                  hipStream_t s);
+// stats[0] = sum of partials[2i], stats[1] = sum of partials[2i+1]  (two levels through `scratch`, 512 doubles)
+hipError_t launch_reduce_partials(const double* partials, long long n, double* stats, double* scratch, hipStream_t s);
 // seed_cur = seeds[*counter]
 hipError_t launch_pick_seed(const uint64_t* seeds, const unsigned long long* counter, uint64_t* seed_cur,
                             hipStream_t s);

@@ -102,10 +102,10 @@ float bench_fastgen(Timer& t, cplx<float>* W, const cplx<float>* tw, const FastG
 template <class C>
 float bench_row(Timer& t, cplx<float>* W, const cplx<float>* tw, double* partials) {
   PlainRowIO<float> io;
-  io.base = W; io.scale = 1.0f; io.M_of = NZ / 2;   // scale 1 keeps repeated in-place runs finite-ish
-  const long long nrows = (long long)NX * NY, ntiles = (nrows + C::NRT - 1) / C::NRT;
+  io.base = W; io.scale = 1.0f; io.M_of = C::M;   // scale 1 keeps repeated in-place runs finite-ish
+  const long long nrows = (long long)NX * NY * (NZ / 2) / C::M, ntiles = (nrows + C::NRT - 1) / C::NRT;
   auto k = row_c2r_kernel<C, PlainRowIO<float>>;
-  const int lds = C::LDS_BYTES > 64 ? C::LDS_BYTES : 64;
+  const int lds = C::LDS_BYTES > 64 ? C::LDS_BYTES : 64;   // tile + twiddles
   if (lds > 65536) CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   return t.run([&]() { hipLaunchKernelGGL(k, dim3((unsigned)ntiles), dim3(C::NT), lds, 0, io, tw, nrows, partials); });
 }
@@ -271,10 +271,32 @@ int main(int argc, char** argv) {
   auto twzh = make_twiddles<float>(1024);
   cplx<float>* twz = tw;
   ROW(8, 8, 8, 8, 256)
+  ROW(8, 8, 8, 16, 256)
   ROW(16, 8, 4, 16, 256)
-  ROW(16, 8, 4, 16, 512)
   ROW(16, 8, 4, 8, 256)
-  ROW(16, 16, 2, 16, 256)
+  ROW(8, 16, 4, 16, 256)
   ROW(16, 4, 8, 16, 256)
+  ROW(16, 8, 4, 16, 512)
+  // rows of nz = 2048 (M = 1024): the z pass of the 8-GPU 2048^3 job; same number of cells
+  {
+    auto tw2h = make_twiddles<float>(2048);
+    cplx<float>* tw2;
+    CK(hipMalloc((void**)&tw2, tw2h.size() * 8));
+    CK(hipMemcpy(tw2, tw2h.data(), tw2h.size() * 8, hipMemcpyHostToDevice));
+#define ROW2(R1, R2, R3, NRT, NT)                                                                  \
+  {                                                                                                  \
+    using C = RowCfg<float, 1024, R1, R2, R3, NRT, NT>;                                              \
+    char nm[128];                                                                                    \
+    snprintf(nm, sizeof nm, "z pass M=1024 radix %2d,%2d,%2d NRT=%2d NT=%4d LDS=%6d", R1, R2, R3, NRT, NT, C::LDS_BYTES); \
+    report(nm, bench_row<C>(t, W, tw2, partials), 2 * sweep);                                        \
+  }
+    ROW2(8, 8, 16, 4, 256)
+    ROW2(8, 16, 8, 4, 256)
+    ROW2(16, 8, 8, 4, 256)
+    ROW2(8, 8, 16, 8, 256)
+    ROW2(16, 8, 8, 8, 256)
+    ROW2(16, 16, 4, 8, 256)
+    ROW2(8, 16, 8, 8, 512)
+  }
   return 0;
 }
