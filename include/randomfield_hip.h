@@ -47,8 +47,10 @@ int rf_plan_create(rf_plan** plan, int nx, int ny, int nz, int dtype, int device
 int rf_plan_destroy(rf_plan* plan);
 int rf_plan_nbytes(rf_plan* plan, size_t* nbytes);          /* transform.py:221,226 nbytes_allocated */
 /* plan options.  RF_FLAG_EXACT_GENERATION = 1 makes native-noise float32 realisations use the
- * reference's exact float64 rounding chain for |k| and sigma(k) instead of the fast float32 one. */
-enum { RF_FLAG_EXACT_GENERATION = 1 };
+ * reference's exact float64 rounding chain for |k| and sigma(k) instead of the fast float32 one.
+ * RF_FLAG_FORCE_SLAB_PATH = 2 routes a single-rank plan through the multi-GPU slab pipeline (y pass on the
+ * slab, exchange = copy of the own block, gathering z pass, pipelined batches): a test hook. */
+enum { RF_FLAG_EXACT_GENERATION = 1, RF_FLAG_FORCE_SLAB_PATH = 2 };
 int rf_plan_set_flag(rf_plan* plan, int flag, int value);
 /* run on a caller-owned HIP stream (hipStream_t passed as void*); NULL restores the plan's own stream */
 int rf_plan_set_stream(rf_plan* plan, void* hip_stream);
@@ -77,8 +79,10 @@ int rf_execute_r2c(rf_plan* plan);               /* real field -> k buffer, unno
  * (generate.py:191-199,218-219).  Generation is fused into the first FFT pass; the
  * k-space array is never materialised.  rms/mean are available from rf_moments(). */
 int rf_realise(rf_plan* plan, uint64_t seed, int mode, const double* noise_host);
-/* n realisations back to back replayed from one captured hipGraph (native noise);
- * the field of the last seed stays resident; rms_out[i] (may be NULL) = np.std of field i. */
+/* n realisations back to back (native noise); the field of the last seed stays resident; rms_out[i]
+ * (may be NULL) = np.std of field i.  Single-GPU plans replay one captured hipGraph.  Multi-GPU plans
+ * pipeline instead: realisation i+1's generation / x / y passes run on the compute stream while
+ * realisation i's all-to-all is in flight on a second stream (two buffer pairs). */
 int rf_realise_batch(rf_plan* plan, const uint64_t* seeds, int n, double* rms_out);
 /* capture + instantiate the n-realisation graph now (otherwise the first rf_realise_batch(n) does it) */
 int rf_realise_batch_prepare(rf_plan* plan, int n);

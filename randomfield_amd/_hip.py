@@ -170,6 +170,10 @@ class DevicePlan(object):
         """Native-noise float32 realisations with the reference's exact float64 chain (slower)."""
         check(self._lib.rf_plan_set_flag(self._h, 1, int(bool(on))), "rf_plan_set_flag")
 
+    def set_force_slab_path(self, on=True):
+        """Route this single-rank plan through the multi-GPU slab pipeline (test hook)."""
+        check(self._lib.rf_plan_set_flag(self._h, 2, int(bool(on))), "rf_plan_set_flag")
+
     def set_stream(self, hip_stream):
         check(self._lib.rf_plan_set_stream(self._h, ctypes.c_void_p(hip_stream or 0)), "rf_plan_set_stream")
 

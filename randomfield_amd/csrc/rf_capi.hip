@@ -94,7 +94,11 @@ int load_rccl() {
 struct rf_plan {
   int nx = 0, ny = 0, nz = 0, nzc = 0, f64 = 0, device = 0, nranks = 1, rank = 0;
   int nxl = 0, nzl = 0, kz0 = 0;          // this rank's x-slab height, kz-slab width and first kz plane
-  void* R = nullptr;                      // receive buffer of the all-to-all (multi-rank plans only)
+  void* R = nullptr;                      // receive buffer of the all-to-all (slab-path plans only)
+  void *W2 = nullptr, *R2 = nullptr;      // second buffer pair of pipelined slab batches
+  hipStream_t comm_stream = nullptr;      // exchange stream of pipelined slab batches
+  hipEvent_t pev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // fwd[2], exch[2], z[2]
+  bool force_slab = false;                // single-rank plan routed through the slab pipeline (tests)
   ncclComm_t comm = nullptr;
   size_t csize = 8;                       // bytes per complex element
   hipStream_t own_stream = nullptr, stream = nullptr;
@@ -235,39 +239,94 @@ int queue_x(rf_plan* p, const GenParams& gp, const void* kspace, void* W, hipStr
 }
 
 // multi-rank: y pass on the local kz slab [nx][ny][nzl]
-int queue_y_slab(rf_plan* p, hipStream_t s) {
+int queue_y_slab(rf_plan* p, void* W, hipStream_t s) {
   const long long nzl = p->nzl;
   const ColGeom gy{nzl, (long long)p->ny * nzl, nzl};
-  RF_HIP(launch_col_plain(p->f64, p->ny, +1, p->W, gy, (long long)p->nx * nzl, p->tw_y, s));
+  RF_HIP(launch_col_plain(p->f64, p->ny, +1, W, gy, (long long)p->nx * nzl, p->tw_y, s));
   return 0;
 }
 
 // multi-rank: z pass on the local x slab, rows gathered from the P received blocks in R; output
 // (dense real [nxl][ny][nz]) into W, then the local (sum, sumsq)
-int queue_z_slab(rf_plan* p, hipStream_t s) {
+int queue_z_slab(rf_plan* p, const void* R, void* W, double* stats_out, hipStream_t s) {
   const long long nrows = (long long)p->nxl * p->ny;
   const double scale = 1.0 / ((double)p->nx * (double)p->ny * (double)p->nz);
-  RF_HIP(launch_row_c2r_gather(p->f64, p->nzc, p->R, p->W, nrows, scale, p->nzl, nrows * p->nzl, p->tw_z, p->partials, s));
-  RF_HIP(launch_reduce_partials(p->partials, p->npartials, p->stats, p->partials + 2 * p->npartials, s));
-  p->cur = p->W;
-  p->stats_slot = 0;
+  RF_HIP(launch_row_c2r_gather(p->f64, p->nzc, R, W, nrows, scale, p->nzl, nrows * p->nzl, p->tw_z, p->partials, s));
+  RF_HIP(launch_reduce_partials(p->partials, p->npartials, stats_out, p->partials + 2 * p->npartials, s));
+  p->cur = W;
   p->real_valid = true;
   return 0;
 }
 
 // multi-rank: the single all-to-all between the y and z passes.  Rank g sends to rank h the block
 // [x in slab h][all y][kz in slab g], which is contiguous in W because x is the slowest axis.
-int queue_exchange_rccl(rf_plan* p, hipStream_t s) {
-  RF_REQUIRE(p->comm != nullptr, "rf_comm_init has not been called on this multi-rank plan");
+int queue_exchange_rccl(rf_plan* p, const void* W, void* R, hipStream_t s) {
+  RF_REQUIRE(p->nranks == 1 || p->comm != nullptr, "rf_comm_init has not been called on this multi-rank plan");
   const size_t blk = (size_t)p->nxl * p->ny * p->nzl * p->csize;
-  RF_HIP(hipMemcpyAsync((char*)p->R + p->rank * blk, (char*)p->W + p->rank * blk, blk, hipMemcpyDeviceToDevice, s));
+  RF_HIP(hipMemcpyAsync((char*)R + p->rank * blk, (const char*)W + p->rank * blk, blk, hipMemcpyDeviceToDevice, s));
+  if (p->nranks == 1) return 0;        // forced slab path of a single-rank plan: the own block is everything
   RF_NCCL(g_rccl.GroupStart());
   for (int h = 0; h < p->nranks; ++h) {
     if (h == p->rank) continue;
-    RF_NCCL(g_rccl.Send((char*)p->W + h * blk, blk, ncclUint8, h, p->comm, s));
-    RF_NCCL(g_rccl.Recv((char*)p->R + h * blk, blk, ncclUint8, h, p->comm, s));
+    RF_NCCL(g_rccl.Send((const char*)W + h * blk, blk, ncclUint8, h, p->comm, s));
+    RF_NCCL(g_rccl.Recv((char*)R + h * blk, blk, ncclUint8, h, p->comm, s));
   }
   RF_NCCL(g_rccl.GroupEnd());
+  return 0;
+}
+
+// Pipelined batch on the slab path: realisation i+1's generation + x + y passes (compute stream) run
+// while realisation i's all-to-all is in flight (exchange stream); two (send, receive) buffer pairs.
+//   compute: x,y(0) | x,y(1)   z(0) | x,y(2)   z(1) | ...            (in order on p->stream)
+//   exchange:        | exch(0)       | exch(1)       | ...            (in order on p->comm_stream)
+// z(i) waits for exch(i); exch(i) waits for x,y(i) and -- because it overwrites R[i%2] -- for z(i-2).
+// One all-reduce of all n (sum, sumsq) pairs at the end.
+int slab_batch(rf_plan* p, const uint64_t* seeds, int n) {
+  if (!p->W2) {
+    RF_HIP(hipMalloc(&p->W2, p->w_bytes));
+    RF_HIP(hipMalloc(&p->R2, p->w_bytes));
+    RF_HIP(hipStreamCreateWithFlags(&p->comm_stream, hipStreamNonBlocking));
+    for (auto& e : p->pev) RF_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  if (p->stats_cap < n) {
+    RF_HIP(hipStreamSynchronize(p->stream));
+    drop_graphs(p);
+    if (p->stats) RF_HIP(hipFree(p->stats));
+    p->stats = nullptr;
+    RF_HIP(hipMalloc((void**)&p->stats, 2 * (size_t)(n + 64) * sizeof(double)));
+    p->stats_cap = n + 64;
+  }
+  void* Wb[2] = {p->W, p->W2};
+  void* Rb[2] = {p->R, p->R2};
+  hipEvent_t *ev_fwd = p->pev, *ev_exch = p->pev + 2, *ev_z = p->pev + 4;
+  hipStream_t A = p->stream, C = p->comm_stream;
+  RF_HIP(hipEventRecord(p->ev[0], A));
+  for (int i = 0; i <= n; ++i) {
+    if (i < n) {
+      const int b = i & 1;
+      if (int rc = queue_x(p, make_gen(p, seeds[i], RF_NOISE_NATIVE, false), nullptr, Wb[b], A)) return rc;
+      if (int rc = queue_y_slab(p, Wb[b], A)) return rc;
+      RF_HIP(hipEventRecord(ev_fwd[b], A));
+      RF_HIP(hipStreamWaitEvent(C, ev_fwd[b], 0));
+      if (i >= 2) RF_HIP(hipStreamWaitEvent(C, ev_z[b], 0));          // R[b] still being read by z(i-2)?
+      if (int rc = queue_exchange_rccl(p, Wb[b], Rb[b], C)) return rc;
+      RF_HIP(hipEventRecord(ev_exch[b], C));
+    }
+    if (i >= 1) {
+      const int pb = (i - 1) & 1;
+      RF_HIP(hipStreamWaitEvent(A, ev_exch[pb], 0));
+      if (int rc = queue_z_slab(p, Rb[pb], Wb[pb], p->stats + 2 * (i - 1), A)) return rc;
+      RF_HIP(hipEventRecord(ev_z[pb], A));
+    }
+  }
+  if (p->nranks > 1)
+    RF_NCCL(g_rccl.AllReduce(p->stats, p->stats, 2 * (size_t)n, ncclFloat64, ncclSum, p->comm, A));
+  RF_HIP(hipEventRecord(p->ev[4], A));
+  p->cur = Wb[(n - 1) & 1];
+  p->stats_slot = n - 1;
+  p->timed = false;
+  p->real_valid = true;
+  p->stats_valid = true;
   return 0;
 }
 
@@ -298,15 +357,16 @@ int queue_c2r(rf_plan* p, const GenParams& gp, const void* kspace) {
   if (p->timed) RF_HIP(hipEventRecord(p->ev[0], p->stream));
   if (int rc = queue_x(p, gp, kspace, p->W, p->stream)) return rc;
   if (p->timed) RF_HIP(hipEventRecord(p->ev[1], p->stream));
-  if (p->nranks > 1) {
-    if (int rc = queue_y_slab(p, p->stream)) return rc;
+  if (p->nranks > 1 || p->force_slab) {
+    if (int rc = queue_y_slab(p, p->W, p->stream)) return rc;
     if (p->timed) RF_HIP(hipEventRecord(p->ev[2], p->stream));
-    if (int rc = queue_exchange_rccl(p, p->stream)) return rc;
-    if (int rc = queue_z_slab(p, p->stream)) return rc;
+    if (int rc = queue_exchange_rccl(p, p->W, p->R, p->stream)) return rc;
+    if (int rc = queue_z_slab(p, p->R, p->W, p->stats, p->stream)) return rc;
     if (p->timed) RF_HIP(hipEventRecord(p->ev[3], p->stream));
     // global (sum, sumsq): one 2-double all-reduce
-    RF_NCCL(g_rccl.AllReduce(p->stats, p->stats, 2, ncclFloat64, ncclSum, p->comm, p->stream));
+    if (p->nranks > 1) RF_NCCL(g_rccl.AllReduce(p->stats, p->stats, 2, ncclFloat64, ncclSum, p->comm, p->stream));
     if (p->timed) RF_HIP(hipEventRecord(p->ev[4], p->stream));
+    p->stats_slot = 0;
     p->stats_valid = true;
     return 0;
   }
@@ -438,7 +498,7 @@ int rf_plan_create(rf_plan** out, int nx, int ny, int nz, int dtype, int device,
         (e = launch_row_r2c(dtype, (int)nzc, p->W, (long long)p->nxl * ny, p->tw_z, p->stream, true)) != hipSuccess ||
         (e = launch_col_plain(dtype, ny, -1, p->W, gy, (long long)nx * nzl, p->tw_y, p->stream, true)) != hipSuccess ||
         (e = launch_col_plain(dtype, nx, -1, p->W, gx, (long long)ny * nzl, p->tw_x, p->stream, true)) != hipSuccess ||
-        (nranks > 1 && (e = launch_row_c2r_gather(dtype, (int)nzc, p->R, p->W, (long long)p->nxl * ny, 1.0, (int)nzl, (long long)p->nxl * ny * nzl,
+        ((e = launch_row_c2r_gather(dtype, (int)nzc, p->W, p->W, (long long)p->nxl * ny, 1.0, (int)nzl, (long long)p->nxl * ny * nzl,
                                                   p->tw_z, p->partials, p->stream, true)) != hipSuccess))
       return cleanup(fail(2, std::string("kernel preparation: ") + hipGetErrorString(e)));
   }
@@ -452,7 +512,9 @@ int rf_plan_destroy(rf_plan* p) {
   if (p->stream) (void)hipStreamSynchronize(p->stream);
   drop_graphs(p);
   if (p->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(p->comm);
-  void* bufs[] = {p->W, p->R, p->K, p->P, p->tw_x, p->tw_y, p->tw_z, p->kx2, p->ky2, p->kz2, p->xt, p->st, p->sl, p->bin,
+  if (p->comm_stream) { (void)hipStreamSynchronize(p->comm_stream); (void)hipStreamDestroy(p->comm_stream); }
+  for (auto& e : p->pev) if (e) (void)hipEventDestroy(e);
+  void* bufs[] = {p->W, p->R, p->W2, p->R2, p->K, p->P, p->tw_x, p->tw_y, p->tw_z, p->kx2, p->ky2, p->kz2, p->xt, p->st, p->sl, p->bin,
                   p->noise, p->partials, p->stats, p->seed_cur, p->seeds_dev, p->counter, p->ztab, p->ky2f,
                   p->kz2f, p->frec};
   for (void* b : bufs)
@@ -466,14 +528,21 @@ int rf_plan_destroy(rf_plan* p) {
 
 int rf_plan_nbytes(rf_plan* p, size_t* nbytes) {
   RF_REQUIRE(p && nbytes, "null argument");
-  *nbytes = p->w_bytes + (p->R ? p->w_bytes : 0) + (p->K ? p->k_bytes : 0) + (p->P ? p->k_bytes : 0);
+  *nbytes = p->w_bytes * (1 + (p->R ? 1 : 0) + (p->W2 ? 2 : 0)) + (p->K ? p->k_bytes : 0) + (p->P ? p->k_bytes : 0);
   return 0;
 }
 
 int rf_plan_set_flag(rf_plan* p, int flag, int value) {
   RF_REQUIRE(p, "null plan");
-  RF_REQUIRE(flag == RF_FLAG_EXACT_GENERATION, "unknown flag");
+  RF_REQUIRE(flag == RF_FLAG_EXACT_GENERATION || flag == RF_FLAG_FORCE_SLAB_PATH, "unknown flag");
   RF_HIP(hipStreamSynchronize(p->stream));
+  if (flag == RF_FLAG_FORCE_SLAB_PATH) {
+    RF_REQUIRE(p->nranks == 1, "RF_FLAG_FORCE_SLAB_PATH is for single-rank plans");
+    if (value && !p->R) RF_HIP(hipMalloc(&p->R, p->w_bytes));
+    p->force_slab = value != 0;
+    drop_graphs(p);
+    return 0;
+  }
   p->exact_gen = value != 0;
   drop_graphs(p);
   return 0;
@@ -643,11 +712,29 @@ static int batch_prepare(rf_plan* p, int n) {
 
 int rf_realise_batch_prepare(rf_plan* p, int n) {
   RF_REQUIRE(p, "null plan");
+  if (p->nranks > 1 || p->force_slab) return 0;     // slab batches are not graph-captured
   return batch_prepare(p, n);
 }
 
 int rf_realise_batch(rf_plan* p, const uint64_t* seeds, int n, double* rms_out) {
   RF_REQUIRE(p && seeds, "null argument");
+  RF_REQUIRE(n >= 1, "need at least one seed");
+  if (p->nranks > 1 || p->force_slab) {
+    RF_REQUIRE(p->have_kgrid && p->have_power, "rf_set_kgrid and rf_set_power must be called first");
+    RF_HIP(hipSetDevice(p->device));
+    if (int rc = slab_batch(p, seeds, n)) return rc;
+    if (rms_out) {
+      std::vector<double> st(2 * (size_t)n);
+      RF_HIP(hipMemcpyAsync(st.data(), p->stats, st.size() * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+      RF_HIP(hipStreamSynchronize(p->stream));
+      const double cnt = (double)p->nx * p->ny * p->nz;
+      for (int i = 0; i < n; ++i) {
+        const double m = st[2 * i] / cnt, v = st[2 * i + 1] / cnt - m * m;
+        rms_out[i] = v > 0 ? std::sqrt(v) : 0.0;
+      }
+    }
+    return 0;
+  }
   if (int rc = batch_prepare(p, n)) return rc;
   RF_HIP(hipMemcpyAsync(p->seeds_dev, seeds, n * sizeof(uint64_t), hipMemcpyHostToDevice, p->stream));
   RF_HIP(hipEventRecord(p->ev[0], p->stream));
@@ -868,7 +955,7 @@ int rf_slab_forward(rf_plan* p, uint64_t seed, int mode, const double* noise_hos
   RF_HIP(hipSetDevice(p->device));
   if (int rc = upload_noise(p, mode, noise_host)) return rc;
   if (int rc = queue_x(p, make_gen(p, seed, mode, false), nullptr, p->W, p->stream)) return rc;
-  if (int rc = queue_y_slab(p, p->stream)) return rc;
+  if (int rc = queue_y_slab(p, p->W, p->stream)) return rc;
   RF_HIP(hipStreamSynchronize(p->stream));
   return 0;
 }
@@ -892,7 +979,8 @@ int rf_slab_backward(rf_plan* p) {
   RF_REQUIRE(p, "null plan");
   RF_REQUIRE(p->nranks > 1, "rf_slab_* are for multi-rank plans");
   RF_HIP(hipSetDevice(p->device));
-  if (int rc = queue_z_slab(p, p->stream)) return rc;
+  if (int rc = queue_z_slab(p, p->R, p->W, p->stats, p->stream)) return rc;
+  p->stats_slot = 0;
   RF_HIP(hipStreamSynchronize(p->stream));
   return 0;
 }

@@ -472,3 +472,31 @@ def test_plan_r2c_and_reverse_on_device(hip):
                                atol=2e-4 if ftype == np.float32 else 1e-10)
             result = plan_r.execute()
             assert np.allclose(original, result, atol=1e-5 if ftype == np.float32 else 1e-12)
+
+
+@pytest.mark.parametrize("shape", [(64, 64, 64), (128, 32, 256)])
+def test_pipelined_slab_batch_matches_plain_path(hip, dpower, shape):
+    """The multi-GPU code path (slab y pass, exchange, gathering z pass) and its software-pipelined batch
+    (two streams, two buffer pairs, events) run on ONE rank (the exchange degenerates to a copy of the own
+    block): every realisation's rms and the resident final field must equal the plain single-GPU path."""
+    k, Pk = dpower
+    seeds = [3, 4, 5, 6, 7]
+    plain = make_plan(hip, shape, np.complex64, k, Pk)
+    rms_ref = plain.realise_batch(seeds)
+    last_ref = plain.download_real()
+    slab = make_plan(hip, shape, np.complex64, k, Pk)
+    slab.set_force_slab_path(True)
+    slab.realise(seed=seeds[-1])
+    std = plain.moments()[1]
+    assert np.max(np.abs(slab.download_real() - last_ref)) <= 1e-6 * std
+    assert abs(slab.moments()[1] - std) <= 1e-7 * std
+    for n in (1, 2, 5):                                          # odd and even counts end in different buffers
+        rms = slab.realise_batch(seeds[:n])
+        assert np.allclose(rms, rms_ref[:n], rtol=1e-7, atol=0)
+        plain.realise(seed=seeds[n - 1])
+        assert np.max(np.abs(slab.download_real() - plain.download_real())) <= 1e-6 * std
+        assert abs(slab.moments()[1] - rms_ref[n - 1]) <= 1e-7 * std
+    rms2 = slab.realise_batch(seeds)                              # buffers / events are reusable
+    assert np.allclose(rms2, rms_ref, rtol=1e-7, atol=0)
+    slab.close()
+    plain.close()
