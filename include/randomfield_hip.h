@@ -29,7 +29,7 @@ extern "C" {
 typedef struct rf_plan rf_plan;
 
 enum { RF_F32 = 0, RF_F64 = 1 };                 /* complex64/float32 or complex128/float64 plan */
-enum { RF_NOISE_NATIVE = 0, RF_NOISE_EXTERNAL = 1 };
+enum { RF_NOISE_NATIVE = 0, RF_NOISE_EXTERNAL = 1, RF_NOISE_RESIDENT = 2 };
 enum { RF_LAYOUT_DENSE = 0, RF_LAYOUT_PADDED = 1 };
 
 /* ---- library ---------------------------------------------------------- */
@@ -68,8 +68,23 @@ int rf_set_power(rf_plan* plan, const double* log10k, const double* sigma, int n
  * Leaves the symmetrised k-space array in the plan's API-layout k buffer.
  * mode RF_NOISE_NATIVE: counter-based Philox4x32-10 + Box-Muller keyed by (seed, cell).
  * mode RF_NOISE_EXTERNAL: noise_host = 2*nx*ny*(nz/2+1) float64 deviates in the order of
- * RandomState(seed).normal(size=2*M) (random.py:24-28) -- the same-seed parity mode. */
+ * RandomState(seed).normal(size=2*M) (random.py:24-28) -- the same-seed parity mode.
+ * mode RF_NOISE_RESIDENT: the deviates already in the plan's device buffer (rf_noise_mt19937 or a
+ * previous external-noise call). */
 int rf_generate(rf_plan* plan, uint64_t seed, int mode, const double* noise_host);
+
+/* ---- on-GPU replay of the reference's noise stream: np.random.RandomState(seed).normal(size=2*M)
+ * (random.py:24-28) = MT19937 + legacy polar method, filled into the plan's device noise buffer in the
+ * reference's order; afterwards rf_generate / rf_realise with mode RF_NOISE_RESIDENT use it (same-seed
+ * parity without drawing 2*M deviates on the host and uploading them).
+ * rf_mt_set_jump: positions of the set coefficients of t^(L*2^k) mod phi(t), k < nlevels, L =
+ * 624*blocks_per_segment words (computed by randomfield_amd/mt19937.py); pos is nlevels x stride uint16.
+ * rf_noise_mt19937: state624 = the generator's initial state (init_genrand(seed)); *accepted (may be NULL)
+ * receives the number of accepted polar attempts that were generated. */
+int rf_mt_set_jump(rf_plan* plan, int nlevels, const uint16_t* pos, const int* npos, int stride, int blocks_per_segment);
+int rf_noise_mt19937(rf_plan* plan, const uint32_t* state624, unsigned long long* accepted);
+/* copy deviates [first, first+count) of the device noise buffer to the host (tests) */
+int rf_download_noise(rf_plan* plan, double* host, unsigned long long first, unsigned long long count);
 
 /* ---- row X: Plan.execute (transform.py:303-315) ------------------------- */
 int rf_execute_c2r(rf_plan* plan);               /* k buffer -> real field, numpy normalisation 1/(nx ny nz) */

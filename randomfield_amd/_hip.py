@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librandomfield_hip.so")
 
 RF_F32, RF_F64 = 0, 1
-NOISE_NATIVE, NOISE_EXTERNAL = 0, 1
+NOISE_NATIVE, NOISE_EXTERNAL, NOISE_RESIDENT = 0, 1, 2
 LAYOUT_DENSE, LAYOUT_PADDED = 0, 1
 
 _c_void_pp = ctypes.POINTER(ctypes.c_void_p)
@@ -38,6 +38,11 @@ SIGNATURES = {
     "rf_set_kgrid": (ctypes.c_int, [ctypes.c_void_p, _c_dp, _c_dp, _c_dp]),
     "rf_set_power": (ctypes.c_int, [ctypes.c_void_p, _c_dp, _c_dp, ctypes.c_int]),
     "rf_generate": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, _c_dp]),
+    "rf_mt_set_jump": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_uint16),
+                                      ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_int]),
+    "rf_noise_mt19937": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32),
+                                        ctypes.POINTER(ctypes.c_ulonglong)]),
+    "rf_download_noise": (ctypes.c_int, [ctypes.c_void_p, _c_dp, ctypes.c_ulonglong, ctypes.c_ulonglong]),
     "rf_execute_c2r": (ctypes.c_int, [ctypes.c_void_p]),
     "rf_execute_r2c": (ctypes.c_int, [ctypes.c_void_p]),
     "rf_realise": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, _c_dp]),
@@ -191,7 +196,39 @@ class DevicePlan(object):
         check(self._lib.rf_set_power(self._h, _dp(log10k), _dp(sigma), len(log10k)), "rf_set_power")
 
     # -- generation / transforms -----------------------------------------
+    # -- the reference's noise stream generated on the GPU --------------------
+    def reference_noise(self, seed):
+        """Fill the device noise buffer with ``RandomState(seed).normal(size=2*M)`` (MT19937 + polar
+        method replayed on the GPU; integer seeds < 2**32).  Afterwards pass ``noise='resident'``."""
+        from . import mt19937
+        if not getattr(self, "_mt_ready", False):
+            polys = mt19937.jump_polynomials(20)
+            pos = [mt19937.set_bit_positions(p) for p in polys]
+            stride = max(len(q) for q in pos)
+            table = np.zeros((len(pos), stride), np.uint16)
+            for i, q in enumerate(pos):
+                table[i, :len(q)] = q
+            npos = np.array([len(q) for q in pos], np.int32)
+            check(self._lib.rf_mt_set_jump(self._h, len(pos), table.ctypes.data_as(ctypes.POINTER(ctypes.c_uint16)),
+                                           npos.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), stride,
+                                           mt19937.SEGMENT_BLOCKS), "rf_mt_set_jump")
+            self._mt_ready = True
+        state = np.ascontiguousarray(mt19937.init_genrand(int(seed)), np.uint32)
+        acc = ctypes.c_ulonglong(0)
+        check(self._lib.rf_noise_mt19937(self._h, state.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)),
+                                         ctypes.byref(acc)), "rf_noise_mt19937")
+        return acc.value
+
+    def download_noise(self, first=0, count=None):
+        total = 2 * self.nx * self.ny * (self.nz // 2 + 1)
+        count = total - first if count is None else count
+        out = np.empty(count, np.float64)
+        check(self._lib.rf_download_noise(self._h, _dp(out), int(first), int(count)), "rf_download_noise")
+        return out
+
     def _noise_arg(self, noise):
+        if isinstance(noise, str) and noise == "resident":
+            return NOISE_RESIDENT, None, None
         if noise is None:
             return NOISE_NATIVE, None, None
         noise = _f64(noise).reshape(-1)

@@ -123,14 +123,20 @@ struct rf_plan {
   SigmaTableHost h_tab;
   double* noise = nullptr;
   size_t noise_cap = 0;
+  bool noise_resident = false;            // the device noise buffer holds a full set of deviates
+  // MT19937 replay (rf_noise_mt19937): jump-polynomial bit positions per tree level, scratch
+  uint16_t* mt_pos = nullptr;
+  std::vector<int> mt_npos;
+  int mt_stride = 0, mt_bps = 0;          // positions per level (padded), blocks of 624 words per segment
+  uint32_t *mt_states = nullptr, *mt_seq = nullptr;
+  unsigned long long *mt_counts = nullptr, *mt_offsets = nullptr;
+  size_t mt_states_cap = 0, mt_seq_cap = 0, mt_seg_cap = 0;
   double* partials = nullptr;
   long long npartials = 0;
   double* stats = nullptr;                // [2 * stats_cap] (sum, sumsq) per realisation
   int stats_cap = 0;
-  uint64_t* seed_cur = nullptr;           // device word read by graph-replayed kernels
   uint64_t* seeds_dev = nullptr;
   int seeds_cap = 0;
-  unsigned long long* counter = nullptr;
   double* ztab = nullptr;                 // 2 * nz doubles for lognormal / affine tables
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   bool timed = false;
@@ -163,22 +169,33 @@ GenParams make_gen(rf_plan* p, uint64_t seed, int mode, bool seed_from_dev) {
   g.kx2 = p->kx2; g.ky2 = p->ky2; g.kz2 = p->kz2;
   g.xt = p->xt; g.st = p->st; g.sl = p->sl; g.bin = p->bin;
   g.nt = p->nt; g.nbins = p->nbins; g.x0 = p->x0; g.inv_dx = p->inv_dx;
-  g.noise_mode = mode; g.seed = seed; g.seed_dev = seed_from_dev ? p->seed_cur : nullptr;
+  g.noise_mode = (mode == RF_NOISE_RESIDENT) ? (int)RF_NOISE_EXTERNAL : mode; g.seed = seed; g.seed_dev = nullptr; (void)seed_from_dev;   // graph batches point seed_dev at seeds_dev[i]
   g.noise = p->noise;
   return g;
 }
 
-int upload_noise(rf_plan* p, int mode, const double* noise_host) {
-  if (mode != RF_NOISE_EXTERNAL) return 0;
-  RF_REQUIRE(noise_host != nullptr, "external noise mode needs a host noise array");
+int ensure_noise(rf_plan* p) {
   const size_t n = 2 * (size_t)p->nx * p->ny * (p->nzc + 1);
   if (p->noise_cap < n) {
     if (p->noise) RF_HIP(hipFree(p->noise));
-    p->noise = nullptr; p->noise_cap = 0;
+    p->noise = nullptr; p->noise_cap = 0; p->noise_resident = false;
     RF_HIP(hipMalloc((void**)&p->noise, n * sizeof(double)));
     p->noise_cap = n;
   }
+  return 0;
+}
+
+int upload_noise(rf_plan* p, int mode, const double* noise_host) {
+  if (mode == RF_NOISE_RESIDENT) {
+    RF_REQUIRE(p->noise_resident, "no deviates resident on the device: call rf_noise_mt19937 (or an external-noise run) first");
+    return 0;
+  }
+  if (mode != RF_NOISE_EXTERNAL) return 0;
+  RF_REQUIRE(noise_host != nullptr, "external noise mode needs a host noise array");
+  if (int rc = ensure_noise(p)) return rc;
+  const size_t n = 2 * (size_t)p->nx * p->ny * (p->nzc + 1);
   RF_HIP(hipMemcpyAsync(p->noise, noise_host, n * sizeof(double), hipMemcpyHostToDevice, p->stream));
+  p->noise_resident = true;
   return 0;
 }
 
@@ -475,8 +492,6 @@ int rf_plan_create(rf_plan** out, int nx, int ny, int nz, int dtype, int device,
   p->stats_cap = 64;
   if ((e = hipMalloc((void**)&p->partials, (2 * p->npartials + 512) * sizeof(double))) != hipSuccess ||
       (e = hipMalloc((void**)&p->stats, 2 * p->stats_cap * sizeof(double))) != hipSuccess ||
-      (e = hipMalloc((void**)&p->seed_cur, sizeof(uint64_t))) != hipSuccess ||
-      (e = hipMalloc((void**)&p->counter, sizeof(unsigned long long))) != hipSuccess ||
       (e = hipMalloc((void**)&p->kx2, nx * sizeof(double))) != hipSuccess ||
       (e = hipMalloc((void**)&p->ky2, ny * sizeof(double))) != hipSuccess ||
       (e = hipMalloc((void**)&p->kz2, (p->nzc + 1) * sizeof(double))) != hipSuccess ||
@@ -515,7 +530,7 @@ int rf_plan_destroy(rf_plan* p) {
   if (p->comm_stream) { (void)hipStreamSynchronize(p->comm_stream); (void)hipStreamDestroy(p->comm_stream); }
   for (auto& e : p->pev) if (e) (void)hipEventDestroy(e);
   void* bufs[] = {p->W, p->R, p->W2, p->R2, p->K, p->P, p->tw_x, p->tw_y, p->tw_z, p->kx2, p->ky2, p->kz2, p->xt, p->st, p->sl, p->bin,
-                  p->noise, p->partials, p->stats, p->seed_cur, p->seeds_dev, p->counter, p->ztab, p->ky2f,
+                  p->noise, p->mt_pos, p->mt_states, p->mt_seq, p->mt_counts, p->mt_offsets, p->partials, p->stats, p->seeds_dev, p->ztab, p->ky2f,
                   p->kz2f, p->frec};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -605,7 +620,7 @@ int rf_generate(rf_plan* p, uint64_t seed, int mode, const double* noise_host) {
   RF_REQUIRE(p, "null plan");
   RF_REQUIRE(p->nranks == 1, "k-space buffer operations are single-GPU only");
   RF_REQUIRE(p->have_kgrid && p->have_power, "rf_set_kgrid and rf_set_power must be called first");
-  RF_REQUIRE(mode == RF_NOISE_NATIVE || mode == RF_NOISE_EXTERNAL, "invalid noise mode");
+  RF_REQUIRE(mode == RF_NOISE_NATIVE || mode == RF_NOISE_EXTERNAL || mode == RF_NOISE_RESIDENT, "invalid noise mode");
   RF_HIP(hipSetDevice(p->device));
   if (int rc = ensure_k(p)) return rc;
   if (int rc = upload_noise(p, mode, noise_host)) return rc;
@@ -651,7 +666,7 @@ int rf_execute_r2c(rf_plan* p) {
 int rf_realise(rf_plan* p, uint64_t seed, int mode, const double* noise_host) {
   RF_REQUIRE(p, "null plan");
   RF_REQUIRE(p->have_kgrid && p->have_power, "rf_set_kgrid and rf_set_power must be called first");
-  RF_REQUIRE(mode == RF_NOISE_NATIVE || mode == RF_NOISE_EXTERNAL, "invalid noise mode");
+  RF_REQUIRE(mode == RF_NOISE_NATIVE || mode == RF_NOISE_EXTERNAL || mode == RF_NOISE_RESIDENT, "invalid noise mode");
   RF_HIP(hipSetDevice(p->device));
   if (int rc = upload_noise(p, mode, noise_host)) return rc;
   p->timed = true;
@@ -899,6 +914,94 @@ int rf_kernel_ms(rf_plan* p, float* ms4) {
   RF_REQUIRE(p->timed, "per-kernel times are recorded by rf_realise / rf_execute_c2r only");
   RF_HIP(hipEventSynchronize(p->ev[4]));
   for (int i = 0; i < 4; ++i) RF_HIP(hipEventElapsedTime(&ms4[i], p->ev[i], p->ev[i + 1]));
+  return 0;
+}
+
+int rf_mt_set_jump(rf_plan* p, int nlevels, const uint16_t* pos, const int* npos, int stride, int blocks_per_segment) {
+  RF_REQUIRE(p && pos && npos, "null argument");
+  RF_REQUIRE(nlevels >= 1 && stride >= 1 && blocks_per_segment >= 1, "invalid jump table");
+  RF_HIP(hipSetDevice(p->device));
+  RF_HIP(hipStreamSynchronize(p->stream));
+  if (p->mt_pos) RF_HIP(hipFree(p->mt_pos));
+  p->mt_pos = nullptr;
+  RF_HIP(hipMalloc((void**)&p->mt_pos, (size_t)nlevels * stride * sizeof(uint16_t)));
+  RF_HIP(hipMemcpy(p->mt_pos, pos, (size_t)nlevels * stride * sizeof(uint16_t), hipMemcpyHostToDevice));
+  p->mt_npos.assign(npos, npos + nlevels);
+  p->mt_stride = stride;
+  p->mt_bps = blocks_per_segment;
+  return 0;
+}
+
+int rf_noise_mt19937(rf_plan* p, const uint32_t* state624, unsigned long long* accepted) {
+  RF_REQUIRE(p && state624, "null argument");
+  RF_REQUIRE(p->nranks == 1, "rf_noise_mt19937 is single-GPU only");
+  RF_REQUIRE(p->mt_pos && !p->mt_npos.empty(), "rf_mt_set_jump must be called first");
+  RF_HIP(hipSetDevice(p->device));
+  if (int rc = ensure_noise(p)) return rc;
+  const unsigned long long ncells = (unsigned long long)p->nx * p->ny * (p->nzc + 1);
+  // polar attempts to generate: acceptance pi/4, margin of 10 sigma + 1024 (mt19937.attempts_needed)
+  const double pa = 0.78539816339744830962;
+  const unsigned long long attempts = (unsigned long long)std::ceil((double)ncells / pa + 10.0 * std::sqrt((double)ncells * (1 - pa)) / pa + 1024.0);
+  const long long total_blocks = (long long)((4 * attempts + 623) / 624);
+  const int nseg = (int)((total_blocks + p->mt_bps - 1) / p->mt_bps);
+  int levels = 0;
+  while ((1 << levels) < nseg) ++levels;
+  RF_REQUIRE(levels <= (int)p->mt_npos.size(), "grid too large for the uploaded jump table");
+  const size_t nstates = (size_t)1 << levels;
+  if (p->mt_states_cap < nstates) {
+    if (p->mt_states) RF_HIP(hipFree(p->mt_states));
+    p->mt_states = nullptr;
+    RF_HIP(hipMalloc((void**)&p->mt_states, nstates * 624 * sizeof(uint32_t)));
+    p->mt_states_cap = nstates;
+  }
+  const size_t chunk = nstates / 2 < 512 ? (nstates / 2 ? nstates / 2 : 1) : 512;      // sources expanded per launch
+  if (p->mt_seq_cap < chunk) {
+    if (p->mt_seq) RF_HIP(hipFree(p->mt_seq));
+    p->mt_seq = nullptr;
+    RF_HIP(hipMalloc((void**)&p->mt_seq, chunk * (size_t)mt_seq_words() * sizeof(uint32_t)));
+    p->mt_seq_cap = chunk;
+  }
+  if (p->mt_seg_cap < (size_t)nseg + 1) {
+    if (p->mt_counts) RF_HIP(hipFree(p->mt_counts));
+    if (p->mt_offsets) RF_HIP(hipFree(p->mt_offsets));
+    p->mt_counts = p->mt_offsets = nullptr;
+    RF_HIP(hipMalloc((void**)&p->mt_counts, ((size_t)nseg + 1) * sizeof(unsigned long long)));
+    RF_HIP(hipMalloc((void**)&p->mt_offsets, ((size_t)nseg + 1) * sizeof(unsigned long long)));
+    p->mt_seg_cap = (size_t)nseg + 1;
+  }
+  hipStream_t s = p->stream;
+  RF_HIP(hipMemcpyAsync(p->mt_states, state624, 624 * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+  // jump tree: level k turns the states of segments [0, 2^k) into those of [2^k, 2^(k+1)) (distance 2^k segments)
+  for (int k = 0; k < levels; ++k) {
+    const long long nsrc_all = 1LL << k;
+    long long ndst_all = (long long)nseg - nsrc_all;
+    if (ndst_all > nsrc_all) ndst_all = nsrc_all;
+    for (long long s0 = 0; s0 < ndst_all; s0 += (long long)chunk) {
+      const int cnt = (int)((ndst_all - s0) < (long long)chunk ? (ndst_all - s0) : (long long)chunk);
+      RF_HIP(launch_mt_expand(p->mt_states + (size_t)s0 * 624, p->mt_seq, cnt, s));
+      RF_HIP(launch_mt_combine(p->mt_seq, p->mt_pos + (size_t)k * p->mt_stride, p->mt_npos[k],
+                               p->mt_states + (size_t)(nsrc_all + s0) * 624, cnt, s));
+    }
+  }
+  RF_HIP(launch_mt_polar(false, p->mt_states, nseg, p->mt_bps, total_blocks, p->mt_counts, nullptr, nullptr, ncells, s));
+  RF_HIP(launch_mt_scan(p->mt_counts, p->mt_offsets, nseg, s));
+  unsigned long long total = 0;
+  RF_HIP(hipMemcpyAsync(&total, p->mt_offsets + nseg, sizeof(total), hipMemcpyDeviceToHost, s));
+  RF_HIP(hipStreamSynchronize(s));
+  if (accepted) *accepted = total;
+  RF_REQUIRE(total >= ncells, "MT19937 replay: not enough accepted polar attempts (increase the margin)");
+  RF_HIP(launch_mt_polar(true, p->mt_states, nseg, p->mt_bps, total_blocks, p->mt_counts, p->mt_offsets, p->noise, ncells, s));
+  p->noise_resident = true;
+  return 0;
+}
+
+int rf_download_noise(rf_plan* p, double* host, unsigned long long first, unsigned long long count) {
+  RF_REQUIRE(p && host, "null argument");
+  RF_REQUIRE(p->noise_resident, "no deviates resident on the device");
+  RF_REQUIRE(first + count <= 2ull * p->nx * p->ny * (p->nzc + 1), "range outside the noise buffer");
+  RF_HIP(hipSetDevice(p->device));
+  RF_HIP(hipMemcpyAsync(host, p->noise + first, count * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+  RF_HIP(hipStreamSynchronize(p->stream));
   return 0;
 }
 

@@ -232,13 +232,27 @@ struct GenParams {
   const double* noise;        // external mode: 2*nx*ny*(nz/2+1) float64 deviates, reference order
 };
 
-// no-FMA product-sum: slope*(x-x_lo)+y_lo must round exactly like numpy's two ufunc calls
+// no-FMA arithmetic: these must round exactly like numpy's separate ufunc calls / numpy's C code built
+// without FMA.  (hipcc contracts a*b+c by default and its __dmul_rn/__dadd_rn are plain operators, so the
+// contraction is switched off by pragma; the host build parks the product in a volatile.)
 RF_HD double mul_then_add(double a, double b, double c) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  return __dadd_rn(__dmul_rn(a, b), c);
+#if defined(__clang__)
+#pragma clang fp contract(off)
+  const double p = a * b;
+  return p + c;
 #else
   volatile double p = a * b;
   return p + c;
+#endif
+}
+RF_HD double sum_of_squares(double a, double b) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+  const double p = a * a, q = b * b;
+  return p + q;
+#else
+  volatile double p = a * a, q = b * b;
+  return p + q;
 #endif
 }
 

@@ -40,10 +40,6 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const double* __re
   }
 }
 
-__global__ void pick_seed_kernel(const uint64_t* seeds, const unsigned long long* counter, uint64_t* seed_cur) {
-  *seed_cur = seeds[*counter];
-}
-
 // cosmotools.py:216-220: delta /= sigma; delta *= sqrt(log t); delta = exp(delta); delta /= sqrt(t)
 // each step rounded to the array dtype; the two table factors are float64 (growth is a float64 (nz,) array)
 template <typename T, int VEC>
@@ -166,11 +162,6 @@ hipError_t launch_reduce_partials(const double* partials, long long n, double* s
   const long long chunk = (n + nb - 1) / nb;
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(nb), dim3(256), 0, s, partials, n, scratch, chunk);
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, s, (const double*)scratch, (long long)nb, stats, (long long)nb);
-  return hipGetLastError();
-}
-
-hipError_t launch_pick_seed(const uint64_t* seeds, const unsigned long long* counter, uint64_t* seed_cur, hipStream_t s) {
-  hipLaunchKernelGGL(pick_seed_kernel, dim3(1), dim3(1), 0, s, seeds, counter, seed_cur);
   return hipGetLastError();
 }
 

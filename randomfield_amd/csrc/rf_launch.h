@@ -37,9 +37,6 @@ long long row_c2r_tiles(int f64, int M, long long nrows);
 hipError_t launch_gen_kspace(int f64, void* K, const GenParams& gp, hipStream_t s);
 // stats[0] = sum of partials[2i], stats[1] = sum of partials[2i+1]  (two levels through `scratch`, 512 doubles)
 hipError_t launch_reduce_partials(const double* partials, long long n, double* stats, double* scratch, hipStream_t s);
-// seed_cur = seeds[*counter]
-hipError_t launch_pick_seed(const uint64_t* seeds, const unsigned long long* counter, uint64_t* seed_cur,
-                            hipStream_t s);
 hipError_t launch_lognormal(int f64, void* W, long long nrows, int nz, const double* a_z, const double* b_z,
                             double sigma, hipStream_t s);
 hipError_t launch_affine_z(int f64, void* W, long long nrows, int nz, const double* mul_z, double add,
@@ -48,5 +45,14 @@ hipError_t launch_affine_z(int f64, void* W, long long nrows, int nz, const doub
 hipError_t launch_save_potential(int f64, const void* K, void* P, int nx, int ny, int nz, const double* kx2,
                                  const double* ky2, const double* kz2, hipStream_t s);
 hipError_t launch_scale_copy(int f64, const void* P, void* K, long long n, double scale, hipStream_t s);
+
+// on-GPU replay of RandomState(seed).normal (rf_k_mt.hip)
+hipError_t launch_mt_expand(const uint32_t* states, uint32_t* seq, int nsrc, hipStream_t s);
+hipError_t launch_mt_combine(const uint32_t* seq, const uint16_t* pos, int npos, uint32_t* states_dst, int ndst, hipStream_t s);
+hipError_t launch_mt_polar(bool fill, const uint32_t* states, int nseg, int blocks_per_segment, long long total_blocks,
+                           unsigned long long* counts, const unsigned long long* offsets, double* noise,
+                           unsigned long long ncells, hipStream_t s);
+hipError_t launch_mt_scan(const unsigned long long* counts, unsigned long long* offsets, int n, hipStream_t s);
+int mt_seq_words();
 
 }  // namespace rf

@@ -71,9 +71,10 @@ class Generator(object):
     dtype : numpy complex dtype
         complex64 (reference behaviour, generate.py:77) or complex128.
     rng : 'reference' (default) or 'native'
-        'reference' draws the reference's own stream
-        (``RandomState(seed).normal``, random.py:24) on the host and uploads it, so
-        the same seed gives the reference's field (to float32 FFT rounding).
+        'reference' draws the reference's own stream (``RandomState(seed).normal``,
+        random.py:24) -- replayed on the GPU (MT19937 with jump-ahead + polar method)
+        for integer seeds -- so the same seed gives the reference's field (to float32
+        FFT rounding).
         'native' uses the GPU's counter-based Philox4x32-10 + Box-Muller generator:
         no host work, different (statistically equivalent) realisations.
     growth_function, mean_matter_density, redshifts : (nz,) arrays, optional
@@ -190,7 +191,13 @@ class Generator(object):
             log10_k, sigma = powertools.sigma_table(self.smoothed_power, (nx, ny, nz), self.grid_spacing_Mpc_h)
             dev.set_power(log10_k, sigma)
             if self.rng == "reference":
-                noise = rf_random.reference_normals(seed, 2 * nx * ny * (nz // 2 + 1))
+                if seed is None:
+                    seed = int.from_bytes(os.urandom(4), "little")      # RandomState(None) seeds itself from the OS
+                if isinstance(seed, (int, np.integer)) and 0 <= int(seed) < 2 ** 32:
+                    dev.reference_noise(int(seed))                      # MT19937 + polar method replayed on the GPU
+                    noise = "resident"
+                else:                                                   # array seeds etc.: draw on the host, upload
+                    noise = rf_random.reference_normals(seed, 2 * nx * ny * (nz // 2 + 1))
                 dseed = 0
             else:
                 noise = None

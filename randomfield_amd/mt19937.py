@@ -1,0 +1,239 @@
+"""
+Jump-ahead support for replaying ``numpy.random.RandomState(seed).normal`` (MT19937 + the legacy polar
+method, the stream ``randomfield.random.randomize`` draws -- random.py:24-28) on the GPU.
+
+MT19937 is a linear recurrence over GF(2): the sequence of state words x_n satisfies
+x_{n+J} = XOR_{j : g_j = 1} x_{n+j} for every n, where g(t) = t^J mod phi(t) and phi is the
+characteristic (minimal) polynomial of the generator, of degree 19937.  So the state J words ahead is an
+XOR-combination of 19937 + 623 consecutive sequence words -- embarrassingly parallel on a GPU, no
+sequential Horner scheme.  This module computes, on the host and once,
+
+* phi (Berlekamp-Massey on one output bit of the generator), and
+* the jump polynomials g_k = t^(L * 2^k) mod phi for a fixed segment length L (in words),
+
+as Python integers (bit i = coefficient of t^i); the GPU library receives the positions of their set bits.
+A binary tree of such jumps turns the seed state into the start states of 2^K consecutive segments.
+
+Also here: the legacy seeding ``init_genrand`` (numpy's ``RandomState(int)``) and small numpy reference
+implementations used by the tests.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+N, M_ = 624, 397
+DEGREE = 19937
+SEGMENT_BLOCKS = 1024                 # blocks of 624 words per segment
+SEGMENT_WORDS = SEGMENT_BLOCKS * N    # L: 638 976 words = 159 744 polar attempts per segment
+_CACHE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "mt19937_jump_L%d.npz" % SEGMENT_WORDS)
+
+_UPPER, _LOWER, _MATRIX_A = 0x80000000, 0x7FFFFFFF, 0x9908B0DF
+
+
+def init_genrand(seed):
+    """Initial 624-word state of numpy's legacy ``RandomState(seed)`` for an integer seed
+    (Knuth's multiplier 1812433253, as in the original mt19937ar.c)."""
+    mt = np.empty(N, np.uint32)
+    s = int(seed) & 0xFFFFFFFF
+    for i in range(N):
+        mt[i] = s
+        s = (1812433253 * (s ^ (s >> 30)) + i + 1) & 0xFFFFFFFF
+    return mt
+
+
+def next_block(mt):
+    """Regenerate the state: words x_{p+624 .. p+1247} from x_{p .. p+623} (vectorised in the three
+    dependency-free chunks of the recurrence).  Returns a new array."""
+    mt = mt.astype(np.uint64)
+    new = np.empty(N, np.uint64)
+
+    def f(a, b, c):
+        y = (a & _UPPER) | (b & _LOWER)
+        return c ^ (y >> np.uint64(1)) ^ np.where(y & np.uint64(1), np.uint64(_MATRIX_A), np.uint64(0))
+
+    new[:227] = f(mt[:227], mt[1:228], mt[397:624])
+    new[227:454] = f(mt[227:454], mt[228:455], new[:227])
+    new[454:623] = f(mt[454:623], mt[455:624], new[227:396])
+    new[623] = f(mt[623], new[0], new[396])
+    return new.astype(np.uint32)
+
+
+def sequence(state, nwords):
+    """x_p .. x_{p+nwords-1} given the state (x_p .. x_{p+623})."""
+    out = [np.asarray(state, np.uint32)]
+    have = N
+    while have < nwords:
+        out.append(next_block(out[-1]))
+        have += N
+    return np.concatenate(out)[:nwords]
+
+
+def temper(y):
+    y = np.asarray(y, np.uint32).copy()
+    y ^= y >> np.uint32(11)
+    y ^= (y << np.uint32(7)) & np.uint32(0x9D2C5680)
+    y ^= (y << np.uint32(15)) & np.uint32(0xEFC60000)
+    y ^= y >> np.uint32(18)
+    return y
+
+
+# ----------------------------------------------------------------- GF(2)[t] on python integers
+
+def _berlekamp_massey(bits):
+    """Minimal polynomial of a binary sequence (list of 0/1), as an int: bit i = coefficient of t^i of the
+    *connection* polynomial C (s_n = XOR_{i>=1} C_i s_{n-i})."""
+    n = len(bits)
+    s = 0
+    for i, b in enumerate(bits):
+        if b:
+            s |= 1 << i
+    C, B, L, m = 1, 1, 0, 1
+    for i in range(n):
+        # discrepancy d = s_i + sum_{j=1..L} C_j s_{i-j}  ==  parity of (C reversed against the window)
+        window = (s >> (i - L)) & ((1 << (L + 1)) - 1) if i >= L else None
+        # compute with bit tricks: sum_j C_j s_{i-j}, j = 0..L
+        d = 0
+        if window is not None:
+            # reverse C over L+1 bits and AND with window
+            rc = int(format(C, "0%db" % (L + 1))[::-1], 2) if C.bit_length() <= L + 1 else None
+            d = bin(rc & window).count("1") & 1
+        if d == 0:
+            m += 1
+        elif 2 * L <= i:
+            T = C
+            C ^= B << m
+            L = i + 1 - L
+            B = T
+            m = 1
+        else:
+            C ^= B << m
+            m += 1
+    return C, L
+
+
+def characteristic_polynomial():
+    """phi(t) of MT19937 as an int (degree 19937): the reversed connection polynomial of the sequence
+    formed by one bit of the state words."""
+    seq = sequence(init_genrand(5489), 2 * DEGREE + 64)
+    bits = [int(v) & 1 for v in seq >> np.uint32(1)]        # bit 1 of every state word
+    C, L = _berlekamp_massey_fast(bits)
+    if L != DEGREE:
+        raise RuntimeError("unexpected linear complexity %d" % L)
+    # connection polynomial C(t) = sum C_i t^i with s_n = XOR_{i=1..L} C_i s_{n-i}; the characteristic
+    # polynomial is phi(t) = t^L C(1/t)
+    phi = 0
+    for i in range(L + 1):
+        if (C >> i) & 1:
+            phi |= 1 << (L - i)
+    return phi
+
+
+def _berlekamp_massey_fast(bits):
+    """Berlekamp-Massey with the sequence kept bit-REVERSED so that the discrepancy is one AND + popcount."""
+    n = len(bits)
+    # R holds s_{i}, s_{i-1}, ... in ascending bit positions: bit j of R = s_{i-j}
+    R = 0
+    C, B, L, m = 1, 1, 0, 1
+    for i in range(n):
+        R = (R << 1) | bits[i]
+        d = bin(C & R).count("1") & 1                      # sum_{j=0..L} C_j s_{i-j}
+        if d == 0:
+            m += 1
+        elif 2 * L <= i:
+            T = C
+            C ^= B << m
+            L = i + 1 - L
+            B = T
+            m = 1
+        else:
+            C ^= B << m
+            m += 1
+    return C, L
+
+
+_SPREAD = None
+
+
+def _square(p):
+    """p(t)^2 over GF(2): spread the bits apart (bytewise table)."""
+    global _SPREAD
+    if _SPREAD is None:
+        _SPREAD = []
+        for b in range(256):
+            v = 0
+            for k in range(8):
+                if (b >> k) & 1:
+                    v |= 1 << (2 * k)
+            _SPREAD.append(v)
+    raw = p.to_bytes((p.bit_length() + 7) // 8 or 1, "little")
+    out = bytearray(2 * len(raw))
+    for i, b in enumerate(raw):
+        v = _SPREAD[b]
+        out[2 * i] = v & 0xFF
+        out[2 * i + 1] = v >> 8
+    return int.from_bytes(out, "little")
+
+
+def _mod(p, phi, deg):
+    """p mod phi (phi of degree deg)."""
+    while p.bit_length() > deg:
+        p ^= phi << (p.bit_length() - 1 - deg)
+    return p
+
+
+def power_of_t(J, phi, deg=DEGREE):
+    """t^J mod phi by left-to-right square-and-multiply."""
+    g = 1
+    for bit in bin(J)[2:]:
+        g = _mod(_square(g), phi, deg)
+        if bit == "1":
+            g = _mod(g << 1, phi, deg)
+    return g
+
+
+def jump_polynomials(nlevels=20, cache=True):
+    """g_k = t^(SEGMENT_WORDS * 2^k) mod phi for k < nlevels, as a (nlevels, 624) uint32 array of
+    coefficient bits (word w, bit b = coefficient of t^(32 w + b)).  Cached next to the package data."""
+    if cache and os.path.exists(_CACHE):
+        arr = np.load(_CACHE)["polys"]
+        if arr.shape[0] >= nlevels:
+            return arr[:nlevels]
+    phi = characteristic_polynomial()
+    g = power_of_t(SEGMENT_WORDS, phi)
+    rows = []
+    for _ in range(nlevels):
+        rows.append(np.frombuffer(g.to_bytes(N * 4, "little"), dtype="<u4").astype(np.uint32))
+        g = _mod(_square(g), phi, DEGREE)
+    arr = np.stack(rows)
+    if cache:
+        try:
+            np.savez_compressed(_CACHE, polys=arr)
+        except OSError:
+            pass
+    return arr
+
+
+def set_bit_positions(poly_words):
+    """Positions j of the set coefficient bits of one jump polynomial (ascending uint16 array)."""
+    bits = np.unpackbits(np.asarray(poly_words, "<u4").view(np.uint8), bitorder="little")
+    return np.nonzero(bits)[0].astype(np.uint16)
+
+
+def jump_state(state, poly_words):
+    """numpy reference of the jump: state J words ahead = XOR-combination of sequence words."""
+    pos = set_bit_positions(poly_words).astype(np.int64)
+    seq = sequence(state, DEGREE + N + 1)
+    out = np.zeros(N, np.uint32)
+    idx = np.arange(N)
+    for j in pos:
+        out ^= seq[idx + j]
+    return out
+
+
+def attempts_needed(ncells):
+    """Polar attempts to generate so that at least ncells are accepted (acceptance pi/4), with a margin
+    of 10 standard deviations plus a constant."""
+    p = np.pi / 4
+    return int(np.ceil(ncells / p + 10.0 * np.sqrt(ncells * (1 - p)) / p + 1024))

@@ -140,6 +140,25 @@ def test_512_cube_known_answer(hip, dpower):
     plan.close()
 
 
+def test_1024_cube_known_answer_generator_reference_rng(hip):
+    """BASELINE headline config (1024^3 f32) through the Generator API with the default rng='reference':
+    the MT19937 + polar stream of seed 123 is replayed on the GPU (no host deviates), and the field must
+    reproduce the reference's SURVEY 8c spot values (first = delta[0,0,:4], last = delta[-1,-1,-4:], std)."""
+    from randomfield_amd import Generator
+    n = 1024
+    gen = Generator(n, n, n, SPACING, backend="hip")
+    assert gen.rng == "reference"
+    gen.generate_delta_field(seed=123, download=False)
+    # the reference's own float32 np.std over 2^30 values carries ~5e-6 relative accumulation error
+    assert abs(float(gen.delta_field_rms) - 2.3137536) <= TOL_F32 * 2.3137536
+    dev = gen.plan_c2r.device
+    first = dev.download_real(x0=0, x1=1)[0, 0, :4]
+    last = dev.download_real(x0=n - 1, x1=n)[0, -1, -4:]
+    assert np.allclose(first, [1.1417141, 0.06940198, 0.947284, -1.5216146], rtol=0, atol=2.4e-5)
+    assert np.allclose(last, [-0.7602967, -6.768864, -1.6377747, -0.7990725], rtol=0, atol=2.4e-5)
+    dev.close()
+
+
 def test_native_rng_matches_oracle_restatement(hip, dpower):
     """Native Philox4x32-10 + Box-Muller mode, value by value against the oracle's
     restatement of the same counter-based stream (float32 plans use hardware
@@ -500,3 +519,29 @@ def test_pipelined_slab_batch_matches_plain_path(hip, dpower, shape):
     assert np.allclose(rms2, rms_ref, rtol=1e-7, atol=0)
     slab.close()
     plain.close()
+
+
+@pytest.mark.parametrize("shape,seed", [((16, 16, 16), 123), ((64, 64, 64), 123), ((128, 128, 256), 7), ((256, 256, 256), 2024)])
+def test_mt19937_replay_matches_numpy(hip, dpower, shape, seed):
+    """On-GPU replay of np.random.RandomState(seed).normal(size=2*M) (random.py:24-28): MT19937 with jump-ahead
+    by t^J mod phi(t), polar rejection with count / scan / fill.  The integer stream is exact; the deviates are
+    bit-identical except where the device's double log()/sqrt() round differently from libm's (about 1 %
+    of the values, at most 2 ulp): <= 1e-15 relative.  (r2 itself must round like numpy's C code -- two
+    products and a sum, no FMA -- or cells with r2 near 1 amplify a 1-ulp difference to ~1e-9.)"""
+    nx, ny, nz = shape
+    k, Pk = dpower
+    plan = make_plan(hip, shape, np.complex64, k, Pk)
+    accepted = plan.reference_noise(seed)
+    ncells = nx * ny * (nz // 2 + 1)
+    assert accepted >= ncells
+    got = plan.download_noise()
+    ref = cpu_ref.reference_noise(seed, ncells)
+    assert got.shape == ref.shape
+    assert np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1e-300)) <= 1e-15
+    assert np.mean(got == ref) > 0.95                                   # mostly bit-identical
+    # and the field generated from it is the reference's field for that seed
+    plan.realise(noise="resident")
+    d = plan.download_real()
+    dref, rms = cpu_ref.generate_delta_field(nx, ny, nz, SPACING, k, Pk, seed=seed)
+    assert np.max(np.abs(d - dref)) <= TOL_F32 * rms
+    plan.close()

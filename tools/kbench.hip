@@ -259,6 +259,48 @@ int main(int argc, char** argv) {
     }
   }
 
+  // --- spatial split with CU masks: x pass on `nx_cu` CUs per XCD, y pass on the other CUs, concurrently
+  {
+    cplx<float>* W3;
+    CK(hipMalloc((void**)&W3, ncplx * 8));
+    CK(hipMemset(W3, 0, ncplx * 8));
+    using C = ColCfg<float, 1024, 8, 16, 8, 8, 512>;
+    using CY = ColCfg<float, 1024, 16, 8, 8, 8, 512>;
+    PlainColIO<float> yio; yio.base = W3; yio.g = ColGeom{nzc, (long long)NY * nzc, nzc};
+    const long long yt = (long long)NX * nzc / CY::TC;
+    auto ky = col_kernel<CY, +1, PlainColIO<float>>;
+    CK(hipFuncSetAttribute((const void*)ky, hipFuncAttributeMaxDynamicSharedMemorySize, CY::LDS_BYTES));
+    FastGenColIOT<0, 0> xio; xio.rec = nullptr; xio.base = W; xio.g = ColGeom{(long long)NY * nzc, 0, (long long)NY * nzc}; xio.gp = g_fp; xio.kz0 = 0; xio.nzl = (int)nzc;
+    auto kx = col_kernel<C, +1, FastGenColIOT<0, 0>>;
+    constexpr int xl = C::LDS_BYTES + FastGenColIOT<0, 0>::LDS_EXTRA;
+    CK(hipFuncSetAttribute((const void*)kx, hipFuncAttributeMaxDynamicSharedMemorySize, xl));
+    const long long xt = (long long)NY * nzc / C::TC;
+    for (int nx_cu : {8, 12, 16, 20}) {
+      // CU numbering: assume 32 consecutive bits per XCD (8 XCDs); x gets the low nx_cu bits of each group
+      uint32_t mx[8], my[8];
+      for (int x = 0; x < 8; ++x) { mx[x] = (nx_cu >= 32) ? 0xFFFFFFFFu : ((1u << nx_cu) - 1u); my[x] = ~mx[x]; }
+      hipStream_t sx, sy;
+      if (hipExtStreamCreateWithCUMask(&sx, 8, mx) != hipSuccess || hipExtStreamCreateWithCUMask(&sy, 8, my) != hipSuccess) { printf("CU mask streams not available\n"); break; }
+      for (int rep = 0; rep < 2; ++rep) {
+        CK(hipDeviceSynchronize());
+        auto t0 = std::chrono::high_resolution_clock::now();
+        hipLaunchKernelGGL(kx, dim3((unsigned)xt), dim3(C::NT), xl, sx, xio, tw, xt, 1LL, 0LL);
+        hipLaunchKernelGGL(ky, dim3((unsigned)yt), dim3(CY::NT), CY::LDS_BYTES, sy, yio, tw, yt, 1LL, 0LL);
+        CK(hipDeviceSynchronize());
+        auto t1 = std::chrono::high_resolution_clock::now();
+        hipLaunchKernelGGL(kx, dim3((unsigned)xt), dim3(C::NT), xl, sx, xio, tw, xt, 1LL, 0LL);
+        CK(hipDeviceSynchronize());
+        auto t2 = std::chrono::high_resolution_clock::now();
+        hipLaunchKernelGGL(ky, dim3((unsigned)yt), dim3(CY::NT), CY::LDS_BYTES, sy, yio, tw, yt, 1LL, 0LL);
+        CK(hipDeviceSynchronize());
+        auto t3 = std::chrono::high_resolution_clock::now();
+        auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        printf("CU split x:%2d/32 y:%2d/32 per XCD: together %.3f ms; x alone (masked) %.3f; y alone (masked) %.3f\n", nx_cu, 32 - nx_cu, ms(t0, t1), ms(t1, t2), ms(t2, t3));
+      }
+      CK(hipStreamDestroy(sx)); CK(hipStreamDestroy(sy));
+    }
+  }
+
   // --- row pass variants
   CK(hipMemset(W, 0, ncplx * 8));
 #define ROW(R1, R2, R3, NRT, NT)                                                                   \
