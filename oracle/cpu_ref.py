@@ -438,19 +438,30 @@ def philox_normals(seed, cell_index, bits=32):
 
     One Philox call serves the cell *pair* ``cell_index >> 1``; the even cell
     uses words (0, 1), the odd cell words (2, 3).  With ``bits`` = 32 (float64
-    plans) u = (w + 0.5) / 2**32; with ``bits`` = 24 (float32 plans) the low 8
-    bits of each word are dropped first, u = ((w >> 8) + 0.5) / 2**24.  Then
-    r = sqrt(-2 ln u1), (re, im) = r * (cos, sin)(2 pi u2).
+    plans) u = (w + 0.5) / 2**32 in float64.  With ``bits`` = 24 (float32 plans,
+    24-bit significands) the kernels convert each word to float32 (round to
+    nearest even) and form u1 = fma(float32(w), 2**-32, 2**-33) with ONE rounding
+    (so the radius keeps its resolution in the tail, down to u1 = 2**-33), and
+    u2 = float32(w) * 2**-32.  Then r = sqrt(-2 ln u1),
+    (re, im) = r * (cos, sin)(2 pi u2) (BoxMuller<float> in rf_core.h).
     """
     ci = np.asarray(cell_index, np.uint64)
     seed = int(seed) & 0xFFFFFFFFFFFFFFFF
     w = philox4x32_10(ci >> np.uint64(1), np.uint64(0), seed & 0xFFFFFFFF, seed >> 32)
     odd = (ci & np.uint64(1)).astype(bool)
-    shift = np.uint32(32 - bits)
-    wa = (np.where(odd, w[2], w[0]) >> shift).astype(np.float64)
-    wb = (np.where(odd, w[3], w[1]) >> shift).astype(np.float64)
-    u1 = (wa + 0.5) / float(2 ** bits)
-    u2 = (wb + 0.5) / float(2 ** bits)
+    wa = np.where(odd, w[2], w[0])
+    wb = np.where(odd, w[3], w[1])
+    if bits == 32:
+        u1 = (wa.astype(np.float64) + 0.5) / float(2 ** 32)
+        u2 = (wb.astype(np.float64) + 0.5) / float(2 ** 32)
+    elif bits == 24:
+        fa = wa.astype(np.float32).astype(np.float64)            # v_cvt_f32_u32
+        fb = wb.astype(np.float32).astype(np.float64)
+        # the float64 expression is exact (<= 34 significant bits), so one rounding to float32 = the fma
+        u1 = (fa * 2.0 ** -32 + 2.0 ** -33).astype(np.float32).astype(np.float64)
+        u2 = fb * 2.0 ** -32                                     # exact scaling
+    else:
+        raise ValueError("bits must be 24 or 32")
     r = np.sqrt(-2.0 * np.log(u1))
     return r * np.cos(2 * np.pi * u2), r * np.sin(2 * np.pi * u2)
 

@@ -151,6 +151,25 @@ RF_HD uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a 
 
 // Philox4x32-10 (Salmon, Moraes, Dror, Shaw 2011).  counter = (ctr_lo, ctr_hi) as
 // two 64-bit words, key = 64-bit seed.
+// A workgroup-uniform 64-bit value pinned to scalar registers: keeps the compiler from re-associating
+// (lane part) + (uniform part) sums back into per-lane 64-bit multiplies.
+RF_HD uint64_t pin_uniform(uint64_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)x), hi = __builtin_amdgcn_readfirstlane((uint32_t)(x >> 32));
+  return ((uint64_t)hi << 32) | lo;
+#else
+  return x;
+#endif
+}
+
+RF_HD uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);      // one v_bitop3_b32 instead of two v_xor_b32
+#else
+  return a ^ b ^ c;
+#endif
+}
+
 template <int ROUNDS = 10>
 RF_HD PhiloxOut philox4x32(uint64_t ctr_lo, uint64_t ctr_hi, uint64_t key) {
   uint32_t c0 = (uint32_t)ctr_lo, c1 = (uint32_t)(ctr_lo >> 32);
@@ -163,7 +182,7 @@ RF_HD PhiloxOut philox4x32(uint64_t ctr_lo, uint64_t ctr_hi, uint64_t key) {
     const uint64_t p1 = (uint64_t)0xCD9E8D57u * (uint64_t)c2;
     const uint32_t h0 = (uint32_t)(p0 >> 32), l0 = (uint32_t)p0;
     const uint32_t h1 = (uint32_t)(p1 >> 32), l1 = (uint32_t)p1;
-    uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+    uint32_t n0 = xor3(h1, c1, k0), n2 = xor3(h0, c3, k1);
     c0 = n0; c1 = l1; c2 = n2; c3 = l0;
     k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
   }
@@ -193,12 +212,14 @@ template <> struct BoxMuller<double> {
 };
 template <> struct BoxMuller<float> {
   RF_HD static void run(uint32_t wa, uint32_t wb, float& g0, float& g1) {
-    // u1 keeps all 32 bits through a float that never rounds to 0 or 1
-    float u1 = ((float)(wa >> 8) + 0.5f) * (1.0f / 16777216.0f);
-    float u2 = ((float)(wb >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    // u1 = (w + 1/2) / 2^32 formed as ONE fused multiply-add of float(w): the float keeps 24 significant
+    // bits at any magnitude, so the radius resolves the tail down to u1 = 2^-33 (6.7 sigma); u1 is never 0
+    // (it may round to exactly 1, giving radius 0).  u2 = float(w) / 2^32 in [0, 1] revolutions.
+    const float u1 = fmaf((float)wa, 1.0f / 4294967296.0f, 1.0f / 8589934592.0f);
+    const float u2 = (float)wb * (1.0f / 4294967296.0f);
 #if defined(__HIP_DEVICE_COMPILE__)
-    // raw v_log_f32 / v_sqrt_f32: u1 >= 2^-25 and -2 ln u1 in (0, 35) are normal numbers, so the
-    // denormal fix-ups of logf / sqrtf are not needed.  -2 ln u = (-2 ln 2) log2 u
+    // raw v_log_f32 / v_sqrt_f32: u1 >= 2^-33 and -2 ln u1 in [0, 46) need no denormal fix-ups.
+    // -2 ln u = (-2 ln 2) log2 u
     float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));
     // v_sin_f32 / v_cos_f32 take their argument in revolutions
     g0 = r * __builtin_amdgcn_cosf(u2);
@@ -392,39 +413,54 @@ RF_HD float fast_log2(float t) {
 // rec points at the records (LDS or global)
 RF_HD float fast_sigma(const FastGenParams& g, const FastRec* rec, float t /* |k|^2 */) {
   float u = fast_log2(t) * g.u_scale + g.u_off;          // (log10|k| - x0) / dx
-  u = fmaxf(u, 0.0f);                                    // also t == 0 (-inf) and NaN
-  u = fminf(u, (float)g.nbins - 0.001f);
+  const float hi = (float)g.nbins - 0.001f;
+#if defined(__HIP_DEVICE_COMPILE__)
+  u = __builtin_amdgcn_fmed3f(u, 0.0f, hi);              // clamp; t == 0 gives -inf -> bin 0 (a guard bin)
+  const float f = __builtin_amdgcn_fractf(u);
+#else
+  u = fminf(fmaxf(u, 0.0f), hi);
+  const float f = u - floorf(u);
+#endif
   const int b = (int)u;
-  const float f = u - (float)b;
   const FastRec r = rec[b];
   const float d = fmaxf(f - r.fs, 0.0f);
   return (r.v0 + r.sa * f) + r.ds * d;
 }
 
-// AB: development-only ablation mask (1: no Philox, 2: no sigma lookup, 4: no Box-Muller); 0 in the product
+// signed fftfreq index of ix without a select: nx is a power of two, so (ix & nx/2) is 0 or nx/2
+RF_HD int fast_signed_index(int ix, int nx) { return ix - 2 * (ix & (nx >> 1)); }
 RF_HD float fast_kx2(const FastGenParams& g, int ix) {
-  // signed fftfreq index without a select: nx is a power of two, so (ix & nx/2) is 0 or nx/2
-  const float kx = (float)(ix - 2 * (ix & (g.nx >> 1))) * g.dkx;
+  const float kx = (float)fast_signed_index(ix, g.nx) * g.dkx;
   return kx * kx;
 }
 
+// Philox counter of the cell pair (kz even, kz + 1) of column (ix, iy): half the native noise index
+RF_HD uint64_t fast_pair_counter(const FastGenParams& g, int ix, int iy, int kz) {
+  return (((uint64_t)ix * (uint64_t)g.ny + (uint64_t)iy) * (uint64_t)(g.nz / 2) + (uint64_t)kz) >> 1;
+}
+
+// AB: development-only ablation mask (1: no Philox, 2: no sigma lookup, 4: no Box-Muller); 0 in the product.
+// The two packed cells kz, kz + 1 of one column from ONE Philox call: k^2 = kxy + kz2a / kz2b.
 template <int AB = 0>
-RF_HD void fast_gen_pair(const FastGenParams& g, const FastRec* rec, uint64_t seed, int ix, int iy, int kz,
-                         cplx<float>& c0, cplx<float>& c1) {
-  const int nzc = g.nz / 2;
-  const float kxy = fast_kx2(g, ix) + g.ky2[iy];
-  const uint64_t ci = ((uint64_t)ix * (uint64_t)g.ny + (uint64_t)iy) * (uint64_t)nzc + (uint64_t)kz;   // even
+RF_HD void fast_gen_pair_at(const FastGenParams& g, const FastRec* rec, uint64_t seed, uint64_t ctr, float kxy,
+                            float kz2a, float kz2b, cplx<float>& c0, cplx<float>& c1) {
   PhiloxOut o;
-  if (AB & 1) { o.w[0] = (uint32_t)ci; o.w[1] = (uint32_t)ci * 3u; o.w[2] = (uint32_t)ci * 5u; o.w[3] = (uint32_t)ci * 7u; }
-  else if (AB & 8) o = philox4x32<7>(ci >> 1, 0, seed);   // timing experiment only
-  else o = philox4x32_10(ci >> 1, 0, seed);
+  if (AB & 1) { o.w[0] = (uint32_t)ctr; o.w[1] = (uint32_t)ctr * 3u; o.w[2] = (uint32_t)ctr * 5u; o.w[3] = (uint32_t)ctr * 7u; }
+  else if (AB & 8) o = philox4x32<7>(ctr, 0, seed);   // timing experiment only
+  else o = philox4x32_10(ctr, 0, seed);
   float g0, g1;
-  const float s0 = (AB & 2) ? kxy + g.kz2[kz] : fast_sigma(g, rec, kxy + g.kz2[kz]);
-  const float s1 = (AB & 2) ? kxy + g.kz2[kz + 1] : fast_sigma(g, rec, kxy + g.kz2[kz + 1]);
+  const float s0 = (AB & 2) ? kxy + kz2a : fast_sigma(g, rec, kxy + kz2a);
+  const float s1 = (AB & 2) ? kxy + kz2b : fast_sigma(g, rec, kxy + kz2b);
   if (AB & 4) { g0 = (float)o.w[0]; g1 = (float)o.w[1]; } else BoxMuller<float>::run(o.w[0], o.w[1], g0, g1);
   c0 = mk<float>(s0 * g0, s0 * g1);
   if (AB & 4) { g0 = (float)o.w[2]; g1 = (float)o.w[3]; } else BoxMuller<float>::run(o.w[2], o.w[3], g0, g1);
   c1 = mk<float>(s1 * g0, s1 * g1);
+}
+template <int AB = 0>
+RF_HD void fast_gen_pair(const FastGenParams& g, const FastRec* rec, uint64_t seed, int ix, int iy, int kz,
+                         cplx<float>& c0, cplx<float>& c1) {
+  fast_gen_pair_at<AB>(g, rec, seed, fast_pair_counter(g, ix, iy, kz), fast_kx2(g, ix) + g.ky2[iy], g.kz2[kz], g.kz2[kz + 1],
+                       c0, c1);
 }
 
 // slot kz = 0 of column (ix, iy): (plane kz=0) + i (plane kz=nz/2), each Hermitian-symmetrised

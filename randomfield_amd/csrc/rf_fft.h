@@ -61,23 +61,26 @@ struct ColCfg {
 // Addressing of a column pass over the packed device array.
 //   flattened column C in [0, ncols); element (row, C) lives at
 //   (C / inner) * outer_stride + (C % inner) + row * row_stride   (complex units)
+// The IO calls name a cell as (C, rb, ro): row = rb + ro with rb the lane's butterfly index and ro = m * L
+// the same for all lanes.  So an address splits into a lane part that does not depend on m (a common
+// subexpression of the R unrolled accesses) and a workgroup-uniform part (scalar ALU).
 struct ColGeom {
   long long inner, outer_stride, row_stride;
+  RF_HD long long lane_part(long long C, int rb) const {
+    return (C / inner) * outer_stride + (C % inner) + (long long)rb * row_stride;
+  }
+  RF_HD long long uniform_part(int ro) const { return (long long)ro * row_stride; }
 };
 
 template <typename T> struct PlainColIO {
   cplx<T>* base;
   ColGeom g;
-  RF_HD long long addr(long long C, int row) const {
-    return (C / g.inner) * g.outer_stride + (C % g.inner) + (long long)row * g.row_stride;
-  }
-  RF_HD V16<T> load(long long C, int row) const { return *reinterpret_cast<const V16<T>*>(base + addr(C, row)); }
-  RF_HD void store(long long C, int row, const V16<T>& v) const {
-    *reinterpret_cast<V16<T>*>(base + addr(C, row)) = v;
-  }
+  RF_HD cplx<T>* at(long long C, int rb, int ro) const { return (base + g.uniform_part(ro)) + g.lane_part(C, rb); }
+  RF_HD V16<T> load(long long C, int rb, int ro) const { return *reinterpret_cast<const V16<T>*>(at(C, rb, ro)); }
+  RF_HD void store(long long C, int rb, int ro, const V16<T>& v) const { *reinterpret_cast<V16<T>*>(at(C, rb, ro)) = v; }
   static constexpr int FIX_MODE = 0;
   RF_HD bool needs_fix(long long) const { return false; }
-  RF_HD cplx<T> fix_value(long long, int) const { return cplx<T>(); }
+  RF_HD cplx<T> fix_value(long long, int, int) const { return cplx<T>(); }
   static constexpr int LDS_EXTRA = 0;
   RF_HD void prologue(int, int, void*) {}
   RF_HD static void sched_fence(int = 0) {}      // loads of one butterfly are meant to be issued back to back
@@ -94,14 +97,15 @@ template <typename T> struct GenColIO {
   GenParams gp;
   const cplx<T>* kspace;   // optional source in API layout
   int kz0, nzl;            // this rank's kz slab [kz0, kz0 + nzl) of the nz/2 packed planes
-  RF_HD V16<T> load(long long C, int row) const {
+  RF_HD V16<T> load(long long C, int rb, int ro) const {
     V16<T> v;
     const int nzc = gp.nz / 2;
     const uint64_t seed = gp.seed_dev ? *gp.seed_dev : gp.seed;
+    const int ix = rb + ro;
 #pragma unroll
     for (int c = 0; c < V16<T>::CPL; ++c) {
       const long long Cc = C + c;
-      const int iy = (int)(Cc / nzl), kz = kz0 + (int)(Cc % nzl), ix = row;
+      const int iy = (int)(Cc / nzl), kz = kz0 + (int)(Cc % nzl);
       if (kspace) {
         const cplx<T>* p = kspace + ((long long)ix * gp.ny + iy) * (nzc + 1);
         cplx<T> a = p[kz];
@@ -113,13 +117,12 @@ template <typename T> struct GenColIO {
     }
     return v;
   }
-  RF_HD void store(long long C, int row, const V16<T>& v) const {
-    const long long a = (C / g.inner) * g.outer_stride + (C % g.inner) + (long long)row * g.row_stride;
-    *reinterpret_cast<V16<T>*>(base + a) = v;
+  RF_HD void store(long long C, int rb, int ro, const V16<T>& v) const {
+    *reinterpret_cast<V16<T>*>((base + g.uniform_part(ro)) + g.lane_part(C, rb)) = v;
   }
   static constexpr int FIX_MODE = 0;
   RF_HD bool needs_fix(long long) const { return false; }
-  RF_HD cplx<T> fix_value(long long, int) const { return cplx<T>(); }
+  RF_HD cplx<T> fix_value(long long, int, int) const { return cplx<T>(); }
   static constexpr int LDS_EXTRA = 0;
   RF_HD void prologue(int, int, void*) {}
   RF_HD static void sched_fence(int = 0) {}
@@ -157,11 +160,20 @@ struct FastGenColIOT {
     for (int i = tid; i < gp.nbins && i < FAST_LDS_BINS; i += nthreads) l[i] = gp.rec[i];
     rec = l;
   }
-  RF_HD V16<float> load(long long C, int row) const {
+  // Cell pair (kz, kz + 1) of column (ix = rb + ro, iy).  What does not depend on m (= ro / L) is a common
+  // subexpression of the R unrolled loads, and what does not depend on the lane runs on the scalar ALU: the
+  // Philox counter is (lane part) + (uniform part), two vector adds per load instead of a 64-bit multiply chain.
+  RF_HD V16<float> load(long long C, int rb, int ro) const {
     V16<float> v;
     const uint64_t seed = gp.seed_dev ? *gp.seed_dev : gp.seed;
-    const int iy = (int)(C / nzl), kz = kz0 + (int)(C % nzl);
-    fast_gen_pair<AB>(gp, rec, seed, row, iy, kz, v.c[0], v.c[1]);
+    const int iy = (int)(C / nzl), kz = kz0 + (int)(C % nzl);                          // lane, m-invariant
+    const uint64_t half_plane = ((uint64_t)gp.ny * (uint64_t)(gp.nz / 2)) >> 1;        // counters per unit of ix
+    const uint64_t ctr_l = (uint64_t)rb * half_plane + (((uint64_t)iy * (uint64_t)(gp.nz / 2) + (uint64_t)kz) >> 1);
+    const uint64_t ctr_u = pin_uniform((uint64_t)ro * half_plane);
+    // signed fftfreq index: rb < L <= nx/2, so the wrap depends on ro alone
+    const int ro_s = ro >= (gp.nx >> 1) ? ro - gp.nx : ro;
+    const float kx = (float)(rb + ro_s) * gp.dkx;
+    fast_gen_pair_at<AB>(gp, rec, seed, ctr_l + ctr_u, kx * kx + gp.ky2[iy], gp.kz2[kz], gp.kz2[kz + 1], v.c[0], v.c[1]);
     return v;
   }
   // the lane that owns slot kz = 0 replaces its provisional first cell of every row by the packed,
@@ -169,13 +181,12 @@ struct FastGenColIOT {
   static constexpr bool ROLLED_LOAD = false;
   static constexpr int FIX_MODE = FIX;
   RF_HD bool needs_fix(long long C) const { return FIX != 0 && kz0 + (int)(C % nzl) == 0; }
-  RF_HD cplx<float> fix_value(long long C, int row) const {
+  RF_HD cplx<float> fix_value(long long C, int rb, int ro) const {
     const uint64_t seed = gp.seed_dev ? *gp.seed_dev : gp.seed;
-    return fast_fix_kz0(gp, rec, seed, row, (int)(C / nzl));
+    return fast_fix_kz0(gp, rec, seed, rb + ro, (int)(C / nzl));
   }
-  RF_HD void store(long long C, int row, const V16<float>& v) const {
-    const long long a = (C / g.inner) * g.outer_stride + (C % g.inner) + (long long)row * g.row_stride;
-    *reinterpret_cast<V16<float>*>(base + a) = v;
+  RF_HD void store(long long C, int rb, int ro, const V16<float>& v) const {
+    *reinterpret_cast<V16<float>*>((base + g.uniform_part(ro)) + g.lane_part(C, rb)) = v;
   }
 };
 using FastGenColIO = FastGenColIOT<0, 1>;
@@ -223,7 +234,7 @@ struct ColFFT {
         cx v[CPL][R];
         if (IO::ROLLED_LOAD && C::NPASS > 1) {
 #pragma unroll 1
-          for (int m = 0; m < R; ++m) *lds_at(lds, j * R + m, lp) = io.load(Ccol, j + m * L);
+          for (int m = 0; m < R; ++m) *lds_at(lds, j * R + m, lp) = io.load(Ccol, j, m * L);
 #pragma unroll
           for (int m = 0; m < R; ++m) {
             V x = *lds_at(lds, j * R + m, lp);
@@ -233,7 +244,7 @@ struct ColFFT {
         } else {
 #pragma unroll
           for (int m = 0; m < R; ++m) {
-            V x = io.load(Ccol, j + m * L);
+            V x = io.load(Ccol, j, m * L);
 #pragma unroll
             for (int c = 0; c < CPL; ++c) v[c][m] = x.c[c];
             IO::sched_fence(m);
@@ -242,12 +253,12 @@ struct ColFFT {
         if (IO::FIX_MODE != 0 && io.needs_fix(Ccol)) {
           if (C::NPASS == 1) {
 #pragma unroll
-            for (int m = 0; m < R; ++m) v[0][m] = io.fix_value(Ccol, j + m * L);
+            for (int m = 0; m < R; ++m) v[0][m] = io.fix_value(Ccol, j, m * L);
           } else {
             // rolled loop (one copy of the body); values are parked in this thread's own, still unused
             // LDS output slots and read back with static register indices
 #pragma unroll 1
-            for (int m = 0; m < R; ++m) lds_at(lds, j * R + m, lp)->c[0] = io.fix_value(Ccol, j + m * L);
+            for (int m = 0; m < R; ++m) lds_at(lds, j * R + m, lp)->c[0] = io.fix_value(Ccol, j, m * L);
 #pragma unroll
             for (int m = 0; m < R; ++m) v[0][m] = lds_at(lds, j * R + m, lp)->c[0];
           }
@@ -259,7 +270,7 @@ struct ColFFT {
           V x;
 #pragma unroll
           for (int c = 0; c < CPL; ++c) x.c[c] = v[c][m];
-          if (C::NPASS == 1) io.store(Ccol, j * R + m, x);
+          if (C::NPASS == 1) io.store(Ccol, j * R, m, x);
           else *lds_at(lds, j * R + m, lp) = x;
         }
       }
@@ -327,7 +338,7 @@ struct ColFFT {
           V x;
 #pragma unroll
           for (int c = 0; c < CPL; ++c) x.c[c] = v[c][m];
-          io.store(Ccol, j + m * L, x);
+          io.store(Ccol, j, m * L, x);
         }
       }
     }

@@ -1,0 +1,66 @@
+"""Host-side mathematics of the MT19937 replay (randomfield_amd/mt19937.py): seeding, the recurrence, the
+characteristic polynomial and the jump polynomials the GPU library is fed with.  No GPU needed."""
+import numpy as np
+import pytest
+
+from randomfield_amd import mt19937 as mt
+
+
+def _same_state(a, b):
+    """MT19937 states are equal when all words agree except the unused low 31 bits of word 0."""
+    a, b = np.asarray(a, np.uint32), np.asarray(b, np.uint32)
+    return np.array_equal(a[1:], b[1:]) and ((int(a[0]) ^ int(b[0])) & 0x80000000) == 0
+
+
+@pytest.mark.parametrize("seed", [0, 1, 123, 2 ** 32 - 1])
+def test_seeding_matches_numpy(seed):
+    assert np.array_equal(mt.init_genrand(seed), np.random.RandomState(seed).get_state()[1])
+
+
+def test_sequence_and_tempering_match_numpy_raw_words():
+    n = 5 * mt.N
+    raw = np.frombuffer(np.random.RandomState(42).bytes(4 * n), dtype="<u4")
+    seq = mt.sequence(mt.init_genrand(42), n + mt.N)
+    assert np.array_equal(mt.temper(seq[mt.N:]), raw)         # outputs are the tempered words of the NEXT blocks
+
+
+@pytest.fixture(scope="module")
+def phi():
+    return mt.characteristic_polynomial()
+
+
+def test_characteristic_polynomial(phi):
+    assert phi.bit_length() - 1 == mt.DEGREE == 19937
+    assert bin(phi).count("1") == 135                          # Matsumoto & Nishimura 1998, table II
+    # phi annihilates the sequence of any bit of the state words
+    seq = mt.sequence(mt.init_genrand(99), mt.DEGREE + 700)
+    pos = np.nonzero(np.array([(phi >> i) & 1 for i in range(mt.DEGREE + 1)]))[0]
+    for n in (1, 17, 600):
+        assert np.bitwise_xor.reduce(seq[n + pos]) == 0
+
+
+def test_cached_jump_polynomials_are_powers_of_t(phi):
+    polys = mt.jump_polynomials(16)
+    g = mt.power_of_t(mt.SEGMENT_WORDS, phi)
+    for k in range(16):
+        assert np.array_equal(np.frombuffer(g.to_bytes(mt.N * 4, "little"), dtype="<u4"), polys[k]), k
+        g = mt._mod(mt._square(g), phi, mt.DEGREE)
+
+
+def test_jump_equals_stepping():
+    polys = mt.jump_polynomials(3)
+    st = mt.init_genrand(123)
+    seq = mt.sequence(st, 3 * mt.SEGMENT_WORDS + mt.N)
+    one = mt.jump_state(st, polys[0])
+    assert _same_state(one, seq[mt.SEGMENT_WORDS:mt.SEGMENT_WORDS + mt.N])
+    two = mt.jump_state(st, polys[1])
+    assert _same_state(two, seq[2 * mt.SEGMENT_WORDS:2 * mt.SEGMENT_WORDS + mt.N])
+    assert _same_state(mt.jump_state(one, polys[0]), two)
+    assert _same_state(mt.jump_state(one, polys[1]), seq[3 * mt.SEGMENT_WORDS:])
+
+
+def test_attempts_margin():
+    for ncells in (1, 4096, 10 ** 6, 2 ** 29 + 2 ** 20):
+        need = mt.attempts_needed(ncells)
+        p = np.pi / 4
+        assert (need * p - ncells) / np.sqrt(need * p * (1 - p)) > 9.0     # > 9 sigma of head-room
