@@ -143,7 +143,8 @@ struct rf_plan {
   struct BatchGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };
   std::map<int, BatchGraph> graphs;       // captured batch graphs, keyed by the number of realisations
   bool real_valid = false, k_valid = false, stats_valid = false;
-  int slab_planes = 0;
+  unsigned* fused_ctrl = nullptr;      // work queue + per-chunk counters of the fused x+y kernel, then the sticky abort flag
+  bool fused_ok = false;               // fused x+y kernel available for this shape (and not disabled by RANDOMFIELD_FUSED=0)
   void* cur = nullptr;                    // buffer holding the current real-space field
   int stats_slot = 0;                     // which (sum, sumsq) pair of `stats` belongs to the current field                    // x-planes per y/z slab (0 = whole grid in one launch pair)
 };
@@ -255,11 +256,27 @@ int queue_x(rf_plan* p, const GenParams& gp, const void* kspace, void* W, hipStr
   return 0;
 }
 
-// multi-rank: y pass on the local kz slab [nx][ny][nzl]
-int queue_y_slab(rf_plan* p, void* W, hipStream_t s) {
+// x pass (generation) + y pass of buffer W on stream s.  When the fast float32 generation applies and the shape
+// has a fused instantiation, both run in ONE persistent kernel (rf_fused.h); otherwise as two launches.
+// Records ev[1] (after x) and ev[2] (after y) when `timed`; with the fused kernel ev[1] is recorded at the start.
+int queue_xy(rf_plan* p, const GenParams& gp, const void* kspace, void* W, hipStream_t s, bool timed) {
   const long long nzl = p->nzl;
+  const ColGeom gx{(long long)p->ny * nzl, 0, (long long)p->ny * nzl};
   const ColGeom gy{nzl, (long long)p->ny * nzl, nzl};
+  const bool fast = !kspace && gp.noise_mode == NOISE_PHILOX && p->have_fast && !p->exact_gen;
+  if (fast && p->fused_ok && p->fnbins <= FAST_LDS_BINS - 1 && nzl % col_tile_cols(0, p->nx) == 0 && nzl % 16 == 0) {   // whole 128-byte lines per item
+    if (timed) RF_HIP(hipEventRecord(p->ev[1], s));
+    const FastGenParams fp = make_fast(p, gp.seed, gp.seed_dev != nullptr, gp.seed_dev);
+    RF_HIP(launch_col_fastgen_kz0(p->nx, W, gx, (long long)p->ny * nzl, fp, p->kz0, (int)nzl, p->tw_x, s));   // kz = 0 tiles, with the repair
+    RF_HIP(launch_xy_fused(p->nx, W, gx, gy, fp, p->kz0, (int)nzl, p->nx, p->ny, p->tw_x, p->fused_ctrl, p->fused_ctrl + fused_ctrl_words(),
+                           p->kz0 == 0, s));
+    if (timed) RF_HIP(hipEventRecord(p->ev[2], s));
+    return 0;
+  }
+  if (int rc = queue_x(p, gp, kspace, W, s)) return rc;
+  if (timed) RF_HIP(hipEventRecord(p->ev[1], s));
   RF_HIP(launch_col_plain(p->f64, p->ny, +1, W, gy, (long long)p->nx * nzl, p->tw_y, s));
+  if (timed) RF_HIP(hipEventRecord(p->ev[2], s));
   return 0;
 }
 
@@ -321,8 +338,7 @@ int slab_batch(rf_plan* p, const uint64_t* seeds, int n) {
   for (int i = 0; i <= n; ++i) {
     if (i < n) {
       const int b = i & 1;
-      if (int rc = queue_x(p, make_gen(p, seeds[i], RF_NOISE_NATIVE, false), nullptr, Wb[b], A)) return rc;
-      if (int rc = queue_y_slab(p, Wb[b], A)) return rc;
+      if (int rc = queue_xy(p, make_gen(p, seeds[i], RF_NOISE_NATIVE, false), nullptr, Wb[b], A, false)) return rc;
       RF_HIP(hipEventRecord(ev_fwd[b], A));
       RF_HIP(hipStreamWaitEvent(C, ev_fwd[b], 0));
       if (i >= 2) RF_HIP(hipStreamWaitEvent(C, ev_z[b], 0));          // R[b] still being read by z(i-2)?
@@ -347,22 +363,10 @@ int slab_batch(rf_plan* p, const uint64_t* seeds, int n) {
   return 0;
 }
 
-// y pass, z pass and the moments of buffer W on stream s; stats go to stats_out[0..1]
-int queue_yz(rf_plan* p, void* W, hipStream_t s, double* stats_out, bool timed) {
-  const long long nzc = p->nzc;
-  const ColGeom gy{nzc, (long long)p->ny * nzc, nzc};
+// z pass and the moments of buffer W on stream s; stats go to stats_out[0..1]
+int queue_z(rf_plan* p, void* W, hipStream_t s, double* stats_out, bool timed) {
   const double scale = 1.0 / ((double)p->nx * (double)p->ny * (double)p->nz);
-  const int S = p->slab_planes > 0 && p->slab_planes < p->nx ? p->slab_planes : p->nx;
-  const long long tiles_per_row_block = row_c2r_tiles(p->f64, (int)nzc, (long long)S * p->ny);
-  for (int x0 = 0; x0 < p->nx; x0 += S) {
-    const int sx = x0 + S <= p->nx ? S : p->nx - x0;
-    char* base = (char*)W + (size_t)x0 * p->ny * nzc * p->csize;
-    RF_HIP(launch_col_plain(p->f64, p->ny, +1, base, gy, (long long)sx * nzc, p->tw_y, s));
-    if (timed && S == p->nx) RF_HIP(hipEventRecord(p->ev[2], s));
-    RF_HIP(launch_row_c2r(p->f64, (int)nzc, base, (long long)sx * p->ny, scale, p->tw_z,
-                          p->partials + 2 * (x0 / S) * tiles_per_row_block, s));
-  }
-  if (timed && S != p->nx) RF_HIP(hipEventRecord(p->ev[2], s));   // y and z interleaved: no split
+  RF_HIP(launch_row_c2r(p->f64, (int)p->nzc, W, (long long)p->nx * p->ny, scale, p->tw_z, p->partials, s));
   if (timed) RF_HIP(hipEventRecord(p->ev[3], s));
   RF_HIP(launch_reduce_partials(p->partials, p->npartials, stats_out, p->partials + 2 * p->npartials, s));
   if (timed) RF_HIP(hipEventRecord(p->ev[4], s));
@@ -372,11 +376,8 @@ int queue_yz(rf_plan* p, void* W, hipStream_t s, double* stats_out, bool timed) 
 // one realisation / transform on the plan's stream into the primary buffer
 int queue_c2r(rf_plan* p, const GenParams& gp, const void* kspace) {
   if (p->timed) RF_HIP(hipEventRecord(p->ev[0], p->stream));
-  if (int rc = queue_x(p, gp, kspace, p->W, p->stream)) return rc;
-  if (p->timed) RF_HIP(hipEventRecord(p->ev[1], p->stream));
+  if (int rc = queue_xy(p, gp, kspace, p->W, p->stream, p->timed)) return rc;
   if (p->nranks > 1 || p->force_slab) {
-    if (int rc = queue_y_slab(p, p->W, p->stream)) return rc;
-    if (p->timed) RF_HIP(hipEventRecord(p->ev[2], p->stream));
     if (int rc = queue_exchange_rccl(p, p->W, p->R, p->stream)) return rc;
     if (int rc = queue_z_slab(p, p->R, p->W, p->stats, p->stream)) return rc;
     if (p->timed) RF_HIP(hipEventRecord(p->ev[3], p->stream));
@@ -387,7 +388,7 @@ int queue_c2r(rf_plan* p, const GenParams& gp, const void* kspace) {
     p->stats_valid = true;
     return 0;
   }
-  if (int rc = queue_yz(p, p->W, p->stream, p->stats, p->timed)) return rc;
+  if (int rc = queue_z(p, p->W, p->stream, p->stats, p->timed)) return rc;
   p->cur = p->W;
   p->stats_slot = 0;
   p->real_valid = true;
@@ -471,23 +472,14 @@ int rf_plan_create(rf_plan** out, int nx, int ny, int nz, int dtype, int device,
     if (!rc) rc = upload_twiddles<float>(&p->tw_z, nz);
   }
   if (rc) return cleanup(rc);
+  p->npartials = nranks > 1 ? row_c2r_tiles(dtype, p->nzc, (long long)p->nxl * ny) : row_c2r_tiles(dtype, p->nzc, (long long)nx * ny);
   {
-    // optional experiment: y/z passes slab by slab so that a slab's y output could stay in the 256 MiB
-    // Infinity Cache for the z pass; RANDOMFIELD_SLAB_MB=<MiB> enables it
-    double slab_mb = 0.0;   // measured on MI355X: slabs never won (launch tails; z pass is not HBM-bound) -> off
-    if (const char* e = getenv("RANDOMFIELD_SLAB_MB")) slab_mb = atof(e);
-    const double plane_mb = (double)ny * p->nzc * p->csize / 1048576.0;
-    int S = slab_mb > 0 ? (int)(slab_mb / plane_mb) : 0;
-    if (S < 1 || (double)nx * plane_mb <= 2 * slab_mb) S = 0;      // small grids: one launch pair
-    if (S > 0) { int q = 1; while (q * 2 <= S) q *= 2; S = q; }    // power of two so that it divides nx
-    p->slab_planes = S;
-  }
-  if (nranks > 1) {
-    p->slab_planes = 0;
-    p->npartials = row_c2r_tiles(dtype, p->nzc, (long long)p->nxl * ny);
-  } else {
-    const int S = p->slab_planes > 0 ? p->slab_planes : nx;
-    p->npartials = row_c2r_tiles(dtype, p->nzc, (long long)S * ny) * ((nx + S - 1) / S);
+    const char* env = getenv("RANDOMFIELD_FUSED");
+    p->fused_ok = !dtype && xy_fused_supported(nx, ny) && env && atoi(env) == 1;   // experiment: opt-in only
+    if (p->fused_ok) {
+      if ((e = hipMalloc((void**)&p->fused_ctrl, (fused_ctrl_words() + 1) * sizeof(unsigned))) != hipSuccess) return cleanup(fail(2, std::string("hipMalloc fused control block: ") + hipGetErrorString(e)));
+      if ((e = hipMemset(p->fused_ctrl, 0, (fused_ctrl_words() + 1) * sizeof(unsigned))) != hipSuccess) return cleanup(fail(2, std::string("hipMemset fused control block: ") + hipGetErrorString(e)));
+    }
   }
   p->stats_cap = 64;
   if ((e = hipMalloc((void**)&p->partials, (2 * p->npartials + 512) * sizeof(double))) != hipSuccess ||
@@ -508,6 +500,7 @@ int rf_plan_create(rf_plan** out, int nx, int ny, int nz, int dtype, int device,
     FastGenParams fp0; memset(&fp0, 0, sizeof(fp0)); fp0.nx = nx; fp0.ny = ny; fp0.nz = nz;
     if ((e = launch_col_gen(dtype, nx, p->W, gx, (long long)ny * nzl, gp0, nullptr, 0, (int)nzl, p->tw_x, p->stream, true)) != hipSuccess ||
         (!dtype && (e = launch_col_fastgen(nx, p->W, gx, (long long)ny * nzl, fp0, 0, (int)nzl, p->tw_x, p->stream, true)) != hipSuccess) ||
+        (p->fused_ok && (e = launch_xy_fused(nx, p->W, gx, gy, fp0, 0, (int)nzl, nx, ny, p->tw_x, p->fused_ctrl, p->fused_ctrl + fused_ctrl_words(), 0, p->stream, true)) != hipSuccess) ||
         (e = launch_col_plain(dtype, ny, +1, p->W, gy, (long long)nx * nzl, p->tw_y, p->stream, true)) != hipSuccess ||
         (e = launch_row_c2r(dtype, (int)nzc, p->W, (long long)p->nxl * ny, 1.0, p->tw_z, p->partials, p->stream, true)) != hipSuccess ||
         (e = launch_row_r2c(dtype, (int)nzc, p->W, (long long)p->nxl * ny, p->tw_z, p->stream, true)) != hipSuccess ||
@@ -531,7 +524,7 @@ int rf_plan_destroy(rf_plan* p) {
   for (auto& e : p->pev) if (e) (void)hipEventDestroy(e);
   void* bufs[] = {p->W, p->R, p->W2, p->R2, p->K, p->P, p->tw_x, p->tw_y, p->tw_z, p->kx2, p->ky2, p->kz2, p->xt, p->st, p->sl, p->bin,
                   p->noise, p->mt_pos, p->mt_states, p->mt_seq, p->mt_counts, p->mt_offsets, p->partials, p->stats, p->seeds_dev, p->ztab, p->ky2f,
-                  p->kz2f, p->frec};
+                  p->kz2f, p->frec, p->fused_ctrl};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   for (auto& ev : p->ev)
@@ -681,8 +674,8 @@ static int batch_issue(rf_plan* p, int n) {
   for (int i = 0; i < n; ++i) {
     GenParams gp = make_gen(p, 0, RF_NOISE_NATIVE, true);
     gp.seed_dev = p->seeds_dev + i;
-    if (int rc = queue_x(p, gp, nullptr, p->W, p->stream)) return rc;
-    if (int rc = queue_yz(p, p->W, p->stream, p->stats + 2 * i, false)) return rc;
+    if (int rc = queue_xy(p, gp, nullptr, p->W, p->stream, false)) return rc;
+    if (int rc = queue_z(p, p->W, p->stream, p->stats + 2 * i, false)) return rc;
   }
   return 0;
 }
@@ -774,6 +767,22 @@ int rf_realise_batch(rf_plan* p, const uint64_t* seeds, int n, double* rms_out) 
   return 0;
 }
 
+// the fused x+y kernel bounds its dependency waits; a timeout leaves a sticky flag instead of a hung GPU
+static int check_fused_abort(rf_plan* p) {
+  if (!p->fused_ok) return 0;
+  unsigned flag = 0;
+  RF_HIP(hipMemcpyAsync(&flag, p->fused_ctrl + fused_ctrl_words(), sizeof(flag), hipMemcpyDeviceToHost, p->stream));
+  RF_HIP(hipStreamSynchronize(p->stream));
+  if (flag != 0 && getenv("RANDOMFIELD_FUSED_DEBUG")) {
+    std::vector<unsigned> c(fused_ctrl_words());
+    (void)hipMemcpy(c.data(), p->fused_ctrl, c.size() * sizeof(unsigned), hipMemcpyDeviceToHost);
+    for (int i = 0; i < 70 && 4 * i + 3 < (int)c.size(); ++i)
+      fprintf(stderr, "[fused] chunk %2d: done %5u xmask %04x flushed %04x\n", i, c[4 * i], c[4 * i + 1], c[4 * i + 2]);
+  }
+  RF_REQUIRE(flag == 0, "fused x+y kernel: a dependency wait timed out (results are invalid); set RANDOMFIELD_FUSED=0 to use separate passes");
+  return 0;
+}
+
 int rf_moments(rf_plan* p, double* mean, double* std_out) {
   RF_REQUIRE(p, "null plan");
   RF_REQUIRE(p->stats_valid, "no realisation has been computed");
@@ -781,6 +790,7 @@ int rf_moments(rf_plan* p, double* mean, double* std_out) {
   double st[2];
   RF_HIP(hipMemcpyAsync(st, p->stats + 2 * p->stats_slot, sizeof(st), hipMemcpyDeviceToHost, p->stream));
   RF_HIP(hipStreamSynchronize(p->stream));
+  if (int rc = check_fused_abort(p)) return rc;
   const double cnt = (double)p->nx * p->ny * p->nz;
   const double m = st[0] / cnt;
   const double v = st[1] / cnt - m * m;
@@ -899,7 +909,7 @@ int rf_sync(rf_plan* p) {
   RF_REQUIRE(p, "null plan");
   RF_HIP(hipSetDevice(p->device));
   RF_HIP(hipStreamSynchronize(p->stream));
-  return 0;
+  return check_fused_abort(p);
 }
 
 int rf_elapsed_ms(rf_plan* p, float* ms) {
@@ -1057,8 +1067,7 @@ int rf_slab_forward(rf_plan* p, uint64_t seed, int mode, const double* noise_hos
   RF_REQUIRE(p->have_kgrid && p->have_power, "rf_set_kgrid and rf_set_power must be called first");
   RF_HIP(hipSetDevice(p->device));
   if (int rc = upload_noise(p, mode, noise_host)) return rc;
-  if (int rc = queue_x(p, make_gen(p, seed, mode, false), nullptr, p->W, p->stream)) return rc;
-  if (int rc = queue_y_slab(p, p->W, p->stream)) return rc;
+  if (int rc = queue_xy(p, make_gen(p, seed, mode, false), nullptr, p->W, p->stream, false)) return rc;
   RF_HIP(hipStreamSynchronize(p->stream));
   return 0;
 }
