@@ -143,8 +143,6 @@ struct rf_plan {
   struct BatchGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };
   std::map<int, BatchGraph> graphs;       // captured batch graphs, keyed by the number of realisations
   bool real_valid = false, k_valid = false, stats_valid = false;
-  unsigned* fused_ctrl = nullptr;      // work queue + per-chunk counters of the fused x+y kernel, then the sticky abort flag
-  bool fused_ok = false;               // fused x+y kernel available for this shape (and not disabled by RANDOMFIELD_FUSED=0)
   void* cur = nullptr;                    // buffer holding the current real-space field
   int stats_slot = 0;                     // which (sum, sumsq) pair of `stats` belongs to the current field                    // x-planes per y/z slab (0 = whole grid in one launch pair)
 };
@@ -256,23 +254,11 @@ int queue_x(rf_plan* p, const GenParams& gp, const void* kspace, void* W, hipStr
   return 0;
 }
 
-// x pass (generation) + y pass of buffer W on stream s.  When the fast float32 generation applies and the shape
-// has a fused instantiation, both run in ONE persistent kernel (rf_fused.h); otherwise as two launches.
-// Records ev[1] (after x) and ev[2] (after y) when `timed`; with the fused kernel ev[1] is recorded at the start.
+// x pass (generation or API k-space fused into its load) + y pass of buffer W on stream s.
+// Records ev[1] (after x) and ev[2] (after y) when `timed`.
 int queue_xy(rf_plan* p, const GenParams& gp, const void* kspace, void* W, hipStream_t s, bool timed) {
   const long long nzl = p->nzl;
-  const ColGeom gx{(long long)p->ny * nzl, 0, (long long)p->ny * nzl};
   const ColGeom gy{nzl, (long long)p->ny * nzl, nzl};
-  const bool fast = !kspace && gp.noise_mode == NOISE_PHILOX && p->have_fast && !p->exact_gen;
-  if (fast && p->fused_ok && p->fnbins <= FAST_LDS_BINS - 1 && nzl % col_tile_cols(0, p->nx) == 0 && nzl % 16 == 0) {   // whole 128-byte lines per item
-    if (timed) RF_HIP(hipEventRecord(p->ev[1], s));
-    const FastGenParams fp = make_fast(p, gp.seed, gp.seed_dev != nullptr, gp.seed_dev);
-    RF_HIP(launch_col_fastgen_kz0(p->nx, W, gx, (long long)p->ny * nzl, fp, p->kz0, (int)nzl, p->tw_x, s));   // kz = 0 tiles, with the repair
-    RF_HIP(launch_xy_fused(p->nx, W, gx, gy, fp, p->kz0, (int)nzl, p->nx, p->ny, p->tw_x, p->fused_ctrl, p->fused_ctrl + fused_ctrl_words(),
-                           p->kz0 == 0, s));
-    if (timed) RF_HIP(hipEventRecord(p->ev[2], s));
-    return 0;
-  }
   if (int rc = queue_x(p, gp, kspace, W, s)) return rc;
   if (timed) RF_HIP(hipEventRecord(p->ev[1], s));
   RF_HIP(launch_col_plain(p->f64, p->ny, +1, W, gy, (long long)p->nx * nzl, p->tw_y, s));
@@ -473,14 +459,6 @@ int rf_plan_create(rf_plan** out, int nx, int ny, int nz, int dtype, int device,
   }
   if (rc) return cleanup(rc);
   p->npartials = nranks > 1 ? row_c2r_tiles(dtype, p->nzc, (long long)p->nxl * ny) : row_c2r_tiles(dtype, p->nzc, (long long)nx * ny);
-  {
-    const char* env = getenv("RANDOMFIELD_FUSED");
-    p->fused_ok = !dtype && xy_fused_supported(nx, ny) && env && atoi(env) == 1;   // experiment: opt-in only
-    if (p->fused_ok) {
-      if ((e = hipMalloc((void**)&p->fused_ctrl, (fused_ctrl_words() + 1) * sizeof(unsigned))) != hipSuccess) return cleanup(fail(2, std::string("hipMalloc fused control block: ") + hipGetErrorString(e)));
-      if ((e = hipMemset(p->fused_ctrl, 0, (fused_ctrl_words() + 1) * sizeof(unsigned))) != hipSuccess) return cleanup(fail(2, std::string("hipMemset fused control block: ") + hipGetErrorString(e)));
-    }
-  }
   p->stats_cap = 64;
   if ((e = hipMalloc((void**)&p->partials, (2 * p->npartials + 512) * sizeof(double))) != hipSuccess ||
       (e = hipMalloc((void**)&p->stats, 2 * p->stats_cap * sizeof(double))) != hipSuccess ||
@@ -500,7 +478,6 @@ int rf_plan_create(rf_plan** out, int nx, int ny, int nz, int dtype, int device,
     FastGenParams fp0; memset(&fp0, 0, sizeof(fp0)); fp0.nx = nx; fp0.ny = ny; fp0.nz = nz;
     if ((e = launch_col_gen(dtype, nx, p->W, gx, (long long)ny * nzl, gp0, nullptr, 0, (int)nzl, p->tw_x, p->stream, true)) != hipSuccess ||
         (!dtype && (e = launch_col_fastgen(nx, p->W, gx, (long long)ny * nzl, fp0, 0, (int)nzl, p->tw_x, p->stream, true)) != hipSuccess) ||
-        (p->fused_ok && (e = launch_xy_fused(nx, p->W, gx, gy, fp0, 0, (int)nzl, nx, ny, p->tw_x, p->fused_ctrl, p->fused_ctrl + fused_ctrl_words(), 0, p->stream, true)) != hipSuccess) ||
         (e = launch_col_plain(dtype, ny, +1, p->W, gy, (long long)nx * nzl, p->tw_y, p->stream, true)) != hipSuccess ||
         (e = launch_row_c2r(dtype, (int)nzc, p->W, (long long)p->nxl * ny, 1.0, p->tw_z, p->partials, p->stream, true)) != hipSuccess ||
         (e = launch_row_r2c(dtype, (int)nzc, p->W, (long long)p->nxl * ny, p->tw_z, p->stream, true)) != hipSuccess ||
@@ -524,7 +501,7 @@ int rf_plan_destroy(rf_plan* p) {
   for (auto& e : p->pev) if (e) (void)hipEventDestroy(e);
   void* bufs[] = {p->W, p->R, p->W2, p->R2, p->K, p->P, p->tw_x, p->tw_y, p->tw_z, p->kx2, p->ky2, p->kz2, p->xt, p->st, p->sl, p->bin,
                   p->noise, p->mt_pos, p->mt_states, p->mt_seq, p->mt_counts, p->mt_offsets, p->partials, p->stats, p->seeds_dev, p->ztab, p->ky2f,
-                  p->kz2f, p->frec, p->fused_ctrl};
+                  p->kz2f, p->frec};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   for (auto& ev : p->ev)
@@ -767,22 +744,6 @@ int rf_realise_batch(rf_plan* p, const uint64_t* seeds, int n, double* rms_out) 
   return 0;
 }
 
-// the fused x+y kernel bounds its dependency waits; a timeout leaves a sticky flag instead of a hung GPU
-static int check_fused_abort(rf_plan* p) {
-  if (!p->fused_ok) return 0;
-  unsigned flag = 0;
-  RF_HIP(hipMemcpyAsync(&flag, p->fused_ctrl + fused_ctrl_words(), sizeof(flag), hipMemcpyDeviceToHost, p->stream));
-  RF_HIP(hipStreamSynchronize(p->stream));
-  if (flag != 0 && getenv("RANDOMFIELD_FUSED_DEBUG")) {
-    std::vector<unsigned> c(fused_ctrl_words());
-    (void)hipMemcpy(c.data(), p->fused_ctrl, c.size() * sizeof(unsigned), hipMemcpyDeviceToHost);
-    for (int i = 0; i < 70 && 4 * i + 3 < (int)c.size(); ++i)
-      fprintf(stderr, "[fused] chunk %2d: done %5u xmask %04x flushed %04x\n", i, c[4 * i], c[4 * i + 1], c[4 * i + 2]);
-  }
-  RF_REQUIRE(flag == 0, "fused x+y kernel: a dependency wait timed out (results are invalid); set RANDOMFIELD_FUSED=0 to use separate passes");
-  return 0;
-}
-
 int rf_moments(rf_plan* p, double* mean, double* std_out) {
   RF_REQUIRE(p, "null plan");
   RF_REQUIRE(p->stats_valid, "no realisation has been computed");
@@ -790,7 +751,6 @@ int rf_moments(rf_plan* p, double* mean, double* std_out) {
   double st[2];
   RF_HIP(hipMemcpyAsync(st, p->stats + 2 * p->stats_slot, sizeof(st), hipMemcpyDeviceToHost, p->stream));
   RF_HIP(hipStreamSynchronize(p->stream));
-  if (int rc = check_fused_abort(p)) return rc;
   const double cnt = (double)p->nx * p->ny * p->nz;
   const double m = st[0] / cnt;
   const double v = st[1] / cnt - m * m;
@@ -909,7 +869,7 @@ int rf_sync(rf_plan* p) {
   RF_REQUIRE(p, "null plan");
   RF_HIP(hipSetDevice(p->device));
   RF_HIP(hipStreamSynchronize(p->stream));
-  return check_fused_abort(p);
+  return 0;
 }
 
 int rf_elapsed_ms(rf_plan* p, float* ms) {

@@ -132,10 +132,9 @@ template <typename T> struct GenColIO {
 };
 
 // x pass fused with the fast float32 native generation (one Philox call per lane load)
-// WT: 1 = results are stored write-through at agent scope (fused x+y kernel).
 // FIX: 1 = this kernel repairs the kz = 0 slot (rolled loop through LDS); 0 = it does not (the tiles that
 // hold kz = 0 are then re-run by a FIX = 1 launch).  An out-of-line call was measured 3x slower (scratch).
-template <int AB = 0, int FIX = 1, int WT = 0>
+template <int AB = 0, int FIX = 1>
 struct FastGenColIOT {
   cplx<float>* base;
   ColGeom g;
@@ -187,18 +186,7 @@ struct FastGenColIOT {
     return fast_fix_kz0(gp, rec, seed, rb + ro, (int)(C / nzl));
   }
   RF_HD void store(long long C, int rb, int ro, const V16<float>& v) const {
-    V16<float>* dst = reinterpret_cast<V16<float>*>((base + g.uniform_part(ro)) + g.lane_part(C, rb));
-#if defined(__HIP_DEVICE_COMPILE__)
-    if (WT) {
-      // agent-scope write-through store: the data is visible to every XCD once vmcnt reaches 0, without
-      // a buffer_wbl2 (which writes back the whole L2) -- used by the fused x+y kernel (rf_fused.h)
-      typedef float f4 __attribute__((ext_vector_type(4)));
-      const f4 d = {v.c[0].x, v.c[0].y, v.c[1].x, v.c[1].y};
-      asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(dst), "v"(d) : "memory");
-      return;
-    }
-#endif
-    *dst = v;
+    *reinterpret_cast<V16<float>*>((base + g.uniform_part(ro)) + g.lane_part(C, rb)) = v;
   }
 };
 using FastGenColIO = FastGenColIOT<0, 1>;

@@ -57,26 +57,6 @@ hipError_t launch_fast_one(const FastGenParams& gp, cplx<float>* W, ColGeom g, l
   return launch_one<C, FastGenColIOT<0, 1>>(io1, ncols, tw, s, false, ncols / nzl, tiles_per_iy, 0);
 }
 
-// the repairing kernel over the tiles that hold slot kz = 0 only (tile kzt = 0 of every iy)
-template <class C>
-hipError_t launch_fast_kz0(const FastGenParams& gp, cplx<float>* W, ColGeom g, long long ncols, int kz0, int nzl,
-                           const cplx<float>* tw, hipStream_t s) {
-  if (kz0 != 0) return hipSuccess;
-  if (nzl % C::TC) return hipErrorInvalidValue;
-  FastGenColIOT<0, 1> io1; io1.base = W; io1.g = g; io1.gp = gp; io1.kz0 = kz0; io1.nzl = nzl; io1.rec = nullptr;
-  return launch_one<C, FastGenColIOT<0, 1>>(io1, ncols, tw, s, false, ncols / nzl, nzl / C::TC, 0);
-}
-
-hipError_t launch_col_fastgen_kz0(int N, void* W, ColGeom g, long long ncols, const FastGenParams& gp, int kz0, int nzl,
-                                  const void* tw, hipStream_t s) {
-  switch (N) {
-#define X(NN) case NN: return launch_fast_kz0<typename GenSel<float, NN>::type>(gp, (cplx<float>*)W, g, ncols, kz0, nzl, (const cplx<float>*)tw, s);
-    RF_COL_SIZES(X)
-#undef X
-    default: return hipErrorInvalidValue;
-  }
-}
-
 hipError_t launch_col_fastgen(int N, void* W, ColGeom g, long long ncols, const FastGenParams& gp, int kz0, int nzl,
                               const void* tw, hipStream_t s, bool po) {
   switch (N) {

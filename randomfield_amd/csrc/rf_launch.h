@@ -18,16 +18,6 @@ hipError_t launch_col_gen(int f64, int N, void* W, ColGeom g, long long ncols, c
 // x pass fused with the fast float32 native generation
 hipError_t launch_col_fastgen(int N, void* W, ColGeom g, long long ncols, const FastGenParams& gp, int kz0, int nzl,
                               const void* tw, hipStream_t s, bool prepare_only = false);
-// generation x pass + y pass in one persistent kernel (rf_fused.h); float32 fast generation, nx == ny only.
-// skip_kz0_tile: the tiles that hold slot kz = 0 were already produced by launch_col_fastgen_kz0 on this stream
-// ctrl: fused_ctrl_words() unsigned words (zeroed by the launcher on the stream), abort_flag: one sticky word
-bool xy_fused_supported(int nx, int ny);
-int fused_ctrl_words();
-hipError_t launch_xy_fused(int N, void* W, ColGeom gx, ColGeom gy, const FastGenParams& gp, int kz0, int nzl, int nx, int ny,
-                           const void* tw, unsigned* ctrl, unsigned* abort_flag, int skip_kz0_tile, hipStream_t s, bool prepare_only = false);
-// only the tiles that hold slot kz = 0 (with the Hermitian repair), for the fused kernel; no-op unless kz0 == 0
-hipError_t launch_col_fastgen_kz0(int N, void* W, ColGeom g, long long ncols, const FastGenParams& gp, int kz0, int nzl,
-                                  const void* tw, hipStream_t s);
 int col_tile_cols(int f64, int N);   // tile width (columns) of the strided pass of length N, 0 if unsupported
 // z pass of c2r: rows of M = nz/2 complex -> nz reals, scaled; partials[2*tile] = (sum, sumsq)
 hipError_t launch_row_c2r(int f64, int M, void* W, long long nrows, double scale, const void* tw,
