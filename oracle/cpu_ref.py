@@ -441,9 +441,10 @@ def philox_normals(seed, cell_index, bits=32):
     plans) u = (w + 0.5) / 2**32 in float64.  With ``bits`` = 24 (float32 plans,
     24-bit significands) the kernels convert each word to float32 (round to
     nearest even) and form u1 = fma(float32(w), 2**-32, 2**-33) with ONE rounding
-    (so the radius keeps its resolution in the tail, down to u1 = 2**-33), and
-    u2 = float32(w) * 2**-32.  Then r = sqrt(-2 ln u1),
-    (re, im) = r * (cos, sin)(2 pi u2) (BoxMuller<float> in rf_core.h).
+    (so the radius keeps its resolution in the tail, down to u1 = 2**-33); the
+    angle uses the top 23 bits of its word, u2 = (w >> 9) / 2**23.  Then
+    r = sqrt(-2 ln u1), (re, im) = r * (cos, sin)(2 pi u2) (BoxMuller<float> in
+    rf_core.h).
     """
     ci = np.asarray(cell_index, np.uint64)
     seed = int(seed) & 0xFFFFFFFFFFFFFFFF
@@ -456,10 +457,9 @@ def philox_normals(seed, cell_index, bits=32):
         u2 = (wb.astype(np.float64) + 0.5) / float(2 ** 32)
     elif bits == 24:
         fa = wa.astype(np.float32).astype(np.float64)            # v_cvt_f32_u32
-        fb = wb.astype(np.float32).astype(np.float64)
         # the float64 expression is exact (<= 34 significant bits), so one rounding to float32 = the fma
         u1 = (fa * 2.0 ** -32 + 2.0 ** -33).astype(np.float32).astype(np.float64)
-        u2 = fb * 2.0 ** -32                                     # exact scaling
+        u2 = (wb >> np.uint32(9)).astype(np.float64) * 2.0 ** -23   # exact
     else:
         raise ValueError("bits must be 24 or 32")
     r = np.sqrt(-2.0 * np.log(u1))

@@ -211,26 +211,29 @@ template <> struct BoxMuller<double> {
   }
 };
 template <> struct BoxMuller<float> {
-  RF_HD static void run(uint32_t wa, uint32_t wb, float& g0, float& g1) {
-    // u1 = (w + 1/2) / 2^32 formed as ONE fused multiply-add of float(w): the float keeps 24 significant
-    // bits at any magnitude, so the radius resolves the tail down to u1 = 2^-33 (6.7 sigma); u1 is never 0
-    // (it may round to exactly 1, giving radius 0).  u2 = float(w) / 2^32 in [0, 1] revolutions.
+  // (g0, g1) = scale * N(0,1) pair.
+  // u1 = (w + 1/2) / 2^32 formed as ONE fused multiply-add of float(w): the float keeps 24 significant bits at
+  // any magnitude, so the radius resolves the tail down to u1 = 2^-33 (6.7 sigma); u1 is never 0 (it may round
+  // to exactly 1, giving radius 0).  The angle uses the top 23 bits of its word: u2 = (w >> 9) / 2^23 revolutions.
+  RF_HD static void run_scaled(uint32_t wa, uint32_t wb, float scale, float& g0, float& g1) {
     const float u1 = fmaf((float)wa, 1.0f / 4294967296.0f, 1.0f / 8589934592.0f);
-    const float u2 = (float)wb * (1.0f / 4294967296.0f);
 #if defined(__HIP_DEVICE_COMPILE__)
     // raw v_log_f32 / v_sqrt_f32: u1 >= 2^-33 and -2 ln u1 in [0, 46) need no denormal fix-ups.
     // -2 ln u = (-2 ln 2) log2 u
-    float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));
-    // v_sin_f32 / v_cos_f32 take their argument in revolutions
-    g0 = r * __builtin_amdgcn_cosf(u2);
-    g1 = r * __builtin_amdgcn_sinf(u2);
+    const float r = scale * __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));
+    // the float with exponent 0 and mantissa w >> 9 is 1 + u2 (one v_alignbit_b32); v_sin_f32 / v_cos_f32 take
+    // their argument in revolutions and reduce it themselves
+    const float rev = __uint_as_float(__builtin_amdgcn_alignbit(0x7Fu, wb, 9));
+    g0 = r * __builtin_amdgcn_cosf(rev);
+    g1 = r * __builtin_amdgcn_sinf(rev);
 #else
-    float r = sqrtf(-2.0f * logf(u1));
-    float a = (float)(2.0 * M_PI) * u2;
+    const float r = scale * sqrtf(-2.0f * logf(u1));
+    const float a = (float)(2.0 * M_PI) * ((float)(wb >> 9) * (1.0f / 8388608.0f));
     g0 = r * cosf(a);
     g1 = r * sinf(a);
 #endif
   }
+  RF_HD static void run(uint32_t wa, uint32_t wb, float& g0, float& g1) { run_scaled(wa, wb, 1.0f, g0, g1); }
 };
 
 // ------------------------------------------------------------ generation --
@@ -451,10 +454,10 @@ RF_HD void fast_gen_pair_at(const FastGenParams& g, const FastRec* rec, uint64_t
   float g0, g1;
   const float s0 = (AB & 2) ? kxy + kz2a : fast_sigma(g, rec, kxy + kz2a);
   const float s1 = (AB & 2) ? kxy + kz2b : fast_sigma(g, rec, kxy + kz2b);
-  if (AB & 4) { g0 = (float)o.w[0]; g1 = (float)o.w[1]; } else BoxMuller<float>::run(o.w[0], o.w[1], g0, g1);
-  c0 = mk<float>(s0 * g0, s0 * g1);
-  if (AB & 4) { g0 = (float)o.w[2]; g1 = (float)o.w[3]; } else BoxMuller<float>::run(o.w[2], o.w[3], g0, g1);
-  c1 = mk<float>(s1 * g0, s1 * g1);
+  if (AB & 4) { g0 = s0 * (float)o.w[0]; g1 = s0 * (float)o.w[1]; } else BoxMuller<float>::run_scaled(o.w[0], o.w[1], s0, g0, g1);
+  c0 = mk<float>(g0, g1);
+  if (AB & 4) { g0 = s1 * (float)o.w[2]; g1 = s1 * (float)o.w[3]; } else BoxMuller<float>::run_scaled(o.w[2], o.w[3], s1, g0, g1);
+  c1 = mk<float>(g0, g1);
 }
 template <int AB = 0>
 RF_HD void fast_gen_pair(const FastGenParams& g, const FastRec* rec, uint64_t seed, int ix, int iy, int kz,
@@ -475,14 +478,14 @@ RF_HD cplx<float> fast_fix_kz0(const FastGenParams& g, const FastRec* rec, uint6
   float g0, g1;
   const float s0 = fast_sigma(g, rec, kxy_s + g.kz2[0]);
   const PhiloxOut os = philox4x32_10((scol * (uint64_t)nzc) >> 1, 0, seed);
-  BoxMuller<float>::run(os.w[0], os.w[1], g0, g1);
-  cplx<float> a = mk<float>(s0 * g0, s0 * g1);
+  BoxMuller<float>::run_scaled(os.w[0], os.w[1], s0, g0, g1);
+  cplx<float> a = mk<float>(g0, g1);
   const float sn = fast_sigma(g, rec, kxy_s + g.kz2[nzc]);
   const uint64_t cn = (uint64_t)g.nx * (uint64_t)g.ny * (uint64_t)nzc + scol;
   const PhiloxOut on = philox4x32_10(cn >> 1, 0, seed);
-  if (cn & 1) BoxMuller<float>::run(on.w[2], on.w[3], g0, g1);
-  else        BoxMuller<float>::run(on.w[0], on.w[1], g0, g1);
-  cplx<float> n = mk<float>(sn * g0, sn * g1);
+  if (cn & 1) BoxMuller<float>::run_scaled(on.w[2], on.w[3], sn, g0, g1);
+  else        BoxMuller<float>::run_scaled(on.w[0], on.w[1], sn, g0, g1);
+  cplx<float> n = mk<float>(g0, g1);
   if (role == RF_DEST) { a.y = -a.y; n.y = -n.y; }
   if (role == RF_SELF) { a.y = 0.0f; n.y = 0.0f; }
   if (ix == 0 && iy == 0) a = mk<float>(0.0f, 0.0f);     // DC mode (its sigma lookup is meaningless)

@@ -7,7 +7,7 @@ namespace {
 // runs tiles  b * tile_mul + tile_add,  b in [0, ntiles)
 template <class C, class IO>
 hipError_t launch_one(const IO& io, long long ncols, const cplx<typename C::T>* tw, hipStream_t s, bool prepare_only,
-                      long long ntiles_sub = -1, long long tile_mul = 1, long long tile_add = 0) {
+                      long long ntiles_sub = -1, long long tile_mul = 1, long long tile_add = 0, int skip_period = 0) {
   if (ncols % C::TC) return hipErrorInvalidValue;
   const long long ntiles = ntiles_sub >= 0 ? ntiles_sub : ncols / C::TC;
   auto k = col_kernel<C, +1, IO>;
@@ -21,7 +21,7 @@ hipError_t launch_one(const IO& io, long long ncols, const cplx<typename C::T>* 
     prepared = true;
   }
   if (prepare_only) return hipSuccess;
-  hipLaunchKernelGGL(k, dim3((unsigned)ntiles), dim3(C::NT), lds_bytes, s, io, tw, ntiles, tile_mul, tile_add);
+  hipLaunchKernelGGL(k, dim3((unsigned)ntiles), dim3(C::NT), lds_bytes, s, io, tw, ntiles, tile_mul, tile_add, skip_period);
   return hipGetLastError();
 }
 template <typename T>
@@ -37,9 +37,9 @@ hipError_t launch_t(int N, cplx<T>* W, ColGeom g, long long ncols, const GenPara
 }
 }  // namespace
 
-// Fast float32 generation.  The kernel WITHOUT the kz = 0 repair runs over every tile; the tiles that
-// contain the kz = 0 slot (one per iy when a tile is narrower than a kz row) are then re-run by the
-// kernel WITH the repair, which carries the extra register pressure only where it is needed.
+// Fast float32 generation.  The tiles that contain the kz = 0 slot (one per iy when a tile is narrower than a
+// kz row) are run by the kernel WITH the Hermitian repair, which carries the extra register pressure only where
+// it is needed; every other tile by the kernel WITHOUT it (skip_period = tiles per iy).
 template <class C>
 hipError_t launch_fast_one(const FastGenParams& gp, cplx<float>* W, ColGeom g, long long ncols, int kz0, int nzl,
                            const cplx<float>* tw, hipStream_t s, bool po) {
@@ -51,10 +51,12 @@ hipError_t launch_fast_one(const FastGenParams& gp, cplx<float>* W, ColGeom g, l
     return e != hipSuccess ? e : launch_one<C, FastGenColIOT<0, 1>>(io1, ncols, tw, s, true);
   }
   if (!split) return launch_one<C, FastGenColIOT<0, 1>>(io1, ncols, tw, s, false);
-  hipError_t e = launch_one<C, FastGenColIOT<0, 0>>(io0, ncols, tw, s, false);
-  if (e != hipSuccess || kz0 != 0) return e;                 // only the slab that owns kz = 0 needs the repair
-  const long long tiles_per_iy = nzl / C::TC;
-  return launch_one<C, FastGenColIOT<0, 1>>(io1, ncols, tw, s, false, ncols / nzl, tiles_per_iy, 0);
+  const long long tiles_per_iy = nzl / C::TC, ntiles = ncols / C::TC;
+  if (kz0 != 0) return launch_one<C, FastGenColIOT<0, 0>>(io0, ncols, tw, s, false);   // only the slab that owns kz = 0 needs the repair
+  // first the (few) tiles that hold slot kz = 0, with the repair; then every other tile without it
+  hipError_t e = launch_one<C, FastGenColIOT<0, 1>>(io1, ncols, tw, s, false, ncols / nzl, tiles_per_iy, 0);
+  if (e != hipSuccess || tiles_per_iy >= (1LL << 30) || ntiles >= (1LL << 31)) return e != hipSuccess ? e : hipErrorInvalidValue;
+  return launch_one<C, FastGenColIOT<0, 0>>(io0, ncols, tw, s, false, ntiles - ntiles / tiles_per_iy, 1, 0, (int)tiles_per_iy);
 }
 
 hipError_t launch_col_fastgen(int N, void* W, ColGeom g, long long ncols, const FastGenParams& gp, int kz0, int nzl,

@@ -19,7 +19,7 @@ hipError_t launch_one(const IO& io, long long ncols, const cplx<typename C::T>* 
     prepared = true;
   }
   if (prepare_only) return hipSuccess;
-  hipLaunchKernelGGL(k, dim3((unsigned)ntiles), dim3(C::NT), lds_bytes, s, io, tw, ntiles, 1LL, 0LL);
+  hipLaunchKernelGGL(k, dim3((unsigned)ntiles), dim3(C::NT), lds_bytes, s, io, tw, ntiles, 1LL, 0LL, 0);
   return hipGetLastError();
 }
 template <typename T, int DIR>

@@ -26,13 +26,17 @@ constexpr int col_min_waves() {
 template <class C, int DIR, class IO>
 __global__ __launch_bounds__(C::NT, (col_min_waves<C, IO>())) void col_kernel(IO io, const cplx<typename C::T>* __restrict__ tw,
                                                                            long long ntiles, long long tile_mul,
-                                                                           long long tile_add) {
+                                                                           long long tile_add, int skip_period) {
   using F = ColFFT<C, DIR, IO>;
   using cx = cplx<typename C::T>;
   extern __shared__ __attribute__((aligned(16))) char rf_smem[];
   cx* lds = reinterpret_cast<cx*>(rf_smem);
   const int tid = threadIdx.x;
-  const long long tile = xcd_tile(blockIdx.x, ntiles) * tile_mul + tile_add;   // (1, 0) unless a tile subset is run
+  long long tile = xcd_tile(blockIdx.x, ntiles) * tile_mul + tile_add;          // (1, 0) unless a tile subset is run
+  if (skip_period > 0) {                                                          // all tiles except those = 0 mod skip_period
+    const unsigned t = (unsigned)tile;
+    tile = (long long)(t + t / (unsigned)(skip_period - 1) + 1u);
+  }
   const cx* ltw = tw;
   if (F::HAS_PROLOGUE) {
     F::prologue(tid, io, tw, lds);          // twiddles (+ the IO's tables) -> LDS

@@ -83,7 +83,7 @@ float bench_col(Timer& t, cplx<float>* W, const cplx<float>* tw, bool ypass) {
   const long long ntiles = ncols / C::TC;
   auto k = col_kernel<C, +1, PlainColIO<float>>;
   if (C::LDS_BYTES > 65536) CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
-  return t.run([&]() { hipLaunchKernelGGL(k, dim3((unsigned)ntiles), dim3(C::NT), C::LDS_BYTES, 0, io, tw, ntiles, 1LL, 0LL); });
+  return t.run([&]() { hipLaunchKernelGGL(k, dim3((unsigned)ntiles), dim3(C::NT), C::LDS_BYTES, 0, io, tw, ntiles, 1LL, 0LL, 0); });
 }
 
 template <class C, int AB = 0, int FIX = 1>
@@ -96,7 +96,7 @@ float bench_fastgen(Timer& t, cplx<float>* W, const cplx<float>* tw, const FastG
   auto k = col_kernel<C, +1, FastGenColIOT<AB, FIX>>;
   constexpr int lds = C::LDS_BYTES + FastGenColIOT<AB, FIX>::LDS_EXTRA;
   if (lds > 65536) CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  return t.run([&]() { hipLaunchKernelGGL(k, dim3((unsigned)ntiles), dim3(C::NT), lds, 0, io, tw, ntiles, 1LL, 0LL); });
+  return t.run([&]() { hipLaunchKernelGGL(k, dim3((unsigned)ntiles), dim3(C::NT), lds, 0, io, tw, ntiles, 1LL, 0LL, 0); });
 }
 
 template <class C>
