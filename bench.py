@@ -143,7 +143,7 @@ def main():
     plan.set_power(*powertools.sigma_table(power, (nx, ny, nz), spacing))
 
     # --- per-kernel timing (HIP events on the plan's stream, eager launches) ---
-    kern = np.zeros(4)
+    kern = np.zeros(5)
     reps = max(3, min(args.steps, 10))
     plan.realise(seed=1)
     plan.sync()
@@ -168,10 +168,11 @@ def main():
 
     cells = float(nx) * ny * nz
     sweep = 8.0 * nx * ny * (nz // 2 + 1)           # bytes of one sweep of the packed complex64 array
+    # kern = [x main kernel, y, z, reduce, x launch over the kz = 0 tiles]; the x pass writes one sweep, of which the
+    # main kernel writes all tiles but one per ky row
     names = ["x pass (generation + FFT, write only)", "y pass (FFT in place)", "z pass (c2r + moments, in place)"]
-    alg = [1 * sweep, 2 * sweep, 2 * sweep]
-    if kern[2] < 1e-3:      # y and z passes interleaved slab by slab (Infinity-Cache reuse): timed together
-        names[1], alg[1] = "y+z passes (FFT in place, slab-interleaved) ", 4 * sweep
+    x_share = 1.0 - (8.0 / (nz // 2) if kern[4] > 0 and nz // 2 > 8 else 0.0)
+    alg = [x_share * sweep, 2 * sweep, 2 * sweep]
     dom = int(np.argmax(kern[:3]))
     achieved = alg[dom] / (kern[dom] * 1e-3) / 1e9
     # HBM bytes per launch of that kernel from the committed rocprofv3 --pmc passes (profiles/), if they
@@ -201,7 +202,10 @@ def main():
         "pipeline": {"algorithmic_GBs": round(5 * sweep * args.steps / wall / 1e9, 1),
                      "frac_of_hbm_peak": round(5 * sweep * args.steps / wall / 1e9 / HBM_PEAK_GBS, 4),
                      "kernel_ms": {"x": round(float(kern[0]), 4), "y": round(float(kern[1]), 4),
-                                   "z": round(float(kern[2]), 4), "reduce": round(float(kern[3]), 4)}},
+                                   "z": round(float(kern[2]), 4), "reduce": round(float(kern[3]), 4),
+                                   "x_kz0_tiles": round(float(kern[4]), 4)},
+                     "kernel_frac_of_hbm_peak": {k: round(alg[i] / (kern[i] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                                                 for i, k in enumerate(("x", "y", "z"))}},
         "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "algorithmic_bytes_per_launch": alg[dom], "avg_ms": round(float(kern[dom]), 4)},

@@ -134,8 +134,9 @@ int rf_sync(rf_plan* plan);
 /* GPU time (hipEvents on the plan's stream) of the last rf_realise / rf_realise_batch /
  * rf_execute_* call, in milliseconds; blocks until that call has finished. */
 int rf_elapsed_ms(rf_plan* plan, float* ms);
-/* GPU time of each kernel of the last rf_realise (x pass, y pass, z pass, reduce), 4 floats */
-int rf_kernel_ms(rf_plan* plan, float* ms4);
+/* GPU time of each kernel of the last rf_realise, 5 floats: x pass (main kernel), y pass, z pass, reduce,
+ * and the small x-pass launch that repairs the kz = 0 tiles (0 when the x pass is a single launch) */
+int rf_kernel_ms(rf_plan* plan, float* ms5);
 
 /* ---- multi-GPU: one process per GPU, RCCL all-to-all between the y and z passes.
  * The 128-byte unique id comes from rank 0 and is distributed by the host

@@ -371,6 +371,6 @@ class DevicePlan(object):
         return ms.value
 
     def kernel_ms(self):
-        ms = (ctypes.c_float * 4)()
+        ms = (ctypes.c_float * 5)()      # x (main kernel), y, z, reduce, x kz=0 repair launch
         check(self._lib.rf_kernel_ms(self._h, ms), "rf_kernel_ms")
         return list(ms)

@@ -42,7 +42,7 @@ hipError_t launch_t(int N, cplx<T>* W, ColGeom g, long long ncols, const GenPara
 // it is needed; every other tile by the kernel WITHOUT it (skip_period = tiles per iy).
 template <class C>
 hipError_t launch_fast_one(const FastGenParams& gp, cplx<float>* W, ColGeom g, long long ncols, int kz0, int nzl,
-                           const cplx<float>* tw, hipStream_t s, bool po) {
+                           const cplx<float>* tw, hipStream_t s, bool po, hipEvent_t after_repair) {
   FastGenColIOT<0, 0> io0; io0.base = W; io0.g = g; io0.gp = gp; io0.kz0 = kz0; io0.nzl = nzl; io0.rec = nullptr;
   FastGenColIOT<0, 1> io1; io1.base = W; io1.g = g; io1.gp = gp; io1.kz0 = kz0; io1.nzl = nzl; io1.rec = nullptr;
   const bool split = nzl > C::TC && nzl % C::TC == 0;
@@ -56,13 +56,14 @@ hipError_t launch_fast_one(const FastGenParams& gp, cplx<float>* W, ColGeom g, l
   // first the (few) tiles that hold slot kz = 0, with the repair; then every other tile without it
   hipError_t e = launch_one<C, FastGenColIOT<0, 1>>(io1, ncols, tw, s, false, ncols / nzl, tiles_per_iy, 0);
   if (e != hipSuccess || tiles_per_iy >= (1LL << 30) || ntiles >= (1LL << 31)) return e != hipSuccess ? e : hipErrorInvalidValue;
+  if (after_repair && (e = hipEventRecord(after_repair, s)) != hipSuccess) return e;
   return launch_one<C, FastGenColIOT<0, 0>>(io0, ncols, tw, s, false, ntiles - ntiles / tiles_per_iy, 1, 0, (int)tiles_per_iy);
 }
 
 hipError_t launch_col_fastgen(int N, void* W, ColGeom g, long long ncols, const FastGenParams& gp, int kz0, int nzl,
-                              const void* tw, hipStream_t s, bool po) {
+                              const void* tw, hipStream_t s, bool po, hipEvent_t after_repair) {
   switch (N) {
-#define X(NN) case NN: return launch_fast_one<typename GenSel<float, NN>::type>(gp, (cplx<float>*)W, g, ncols, kz0, nzl, (const cplx<float>*)tw, s, po);
+#define X(NN) case NN: return launch_fast_one<typename GenSel<float, NN>::type>(gp, (cplx<float>*)W, g, ncols, kz0, nzl, (const cplx<float>*)tw, s, po, after_repair);
     RF_COL_SIZES(X)
 #undef X
     default: return hipErrorInvalidValue;

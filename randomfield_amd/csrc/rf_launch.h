@@ -16,8 +16,9 @@ hipError_t launch_col_gen(int f64, int N, void* W, ColGeom g, long long ncols, c
                           const void* kspace, int kz0, int nzl, const void* tw, hipStream_t s,
                           bool prepare_only = false);
 // x pass fused with the fast float32 native generation
+// (when the kz = 0 tiles run as a separate repairing launch first, `after_repair` is recorded between the two)
 hipError_t launch_col_fastgen(int N, void* W, ColGeom g, long long ncols, const FastGenParams& gp, int kz0, int nzl,
-                              const void* tw, hipStream_t s, bool prepare_only = false);
+                              const void* tw, hipStream_t s, bool prepare_only = false, hipEvent_t after_repair = nullptr);
 int col_tile_cols(int f64, int N);   // tile width (columns) of the strided pass of length N, 0 if unsupported
 // z pass of c2r: rows of M = nz/2 complex -> nz reals, scaled; partials[2*tile] = (sum, sumsq)
 hipError_t launch_row_c2r(int f64, int M, void* W, long long nrows, double scale, const void* tw,

@@ -20,7 +20,7 @@ def run(n, dtype, lognormal=False, reps=5):
     plan.set_power(*powertools.sigma_table(power, (n, n, n), spacing))
     plan.realise(seed=1)
     plan.sync()
-    times, kern = [], np.zeros(4)
+    times, kern = [], np.zeros(5)
     growth = np.exp(-0.5 * np.arange(n) / n)
     for i in range(reps):
         plan.sync()
