@@ -180,14 +180,15 @@ int c2r_impl(int nx, int ny, int nz, const GenHost* gen, const cplx<T>* kspace, 
   return dispatch_row_c2r<T>((int)nzc, W, (long long)nx * ny, 1.0 / ((double)nx * ny * nz), s1, s2);
 }
 
+template <typename T, class IO>
 int realise_fast_impl(int nx, int ny, int nz, const GenHost& h, uint64_t seed, double xlo, double xhi, double dkx,
-                      cplx<float>* W, double* s1, double* s2) {
+                      cplx<T>* W, double* s1, double* s2) {
   const long long nzc = nz / 2;
   std::vector<float> ky2(ny), kz2(nzc + 1);
   for (int i = 0; i < ny; ++i) ky2[i] = (float)h.gp.ky2[i];
   for (int i = 0; i <= nzc; ++i) kz2[i] = (float)h.gp.kz2[i];
   std::vector<FastRec> rec;
-  FastGenColIO io;
+  IO io;
   io.base = W; io.g = ColGeom{(long long)ny * nzc, 0, (long long)ny * nzc}; io.kz0 = 0; io.nzl = (int)nzc; io.rec = nullptr;
   FastGenParams& f = io.gp;
   double x0, dx;
@@ -196,25 +197,27 @@ int realise_fast_impl(int nx, int ny, int nz, const GenHost& h, uint64_t seed, d
   f.rec = rec.data(); f.nbins = (int)rec.size();
   f.u_scale = (float)(0.5 * std::log10(2.0) / dx); f.u_off = (float)(-x0 / dx);
   f.seed = seed; f.seed_dev = nullptr;
-  int rc = dispatch_col<float, +1, FastGenColIO, GenSel>(nx, io, (long long)ny * nzc);
+  int rc = dispatch_col<T, +1, IO, GenSel>(nx, io, (long long)ny * nzc);
   if (rc) return rc;
-  PlainColIO<float> pio; pio.base = W; pio.g = ColGeom{nzc, (long long)ny * nzc, nzc};
-  rc = dispatch_col<float, +1>(ny, pio, (long long)nx * nzc);
+  PlainColIO<T> pio; pio.base = W; pio.g = ColGeom{nzc, (long long)ny * nzc, nzc};
+  rc = dispatch_col<T, +1>(ny, pio, (long long)nx * nzc);
   if (rc) return rc;
-  return dispatch_row_c2r<float>((int)nzc, W, (long long)nx * ny, 1.0 / ((double)nx * ny * nz), s1, s2);
+  return dispatch_row_c2r<T>((int)nzc, W, (long long)nx * ny, 1.0 / ((double)nx * ny * nz), s1, s2);
 }
 
 }  // namespace
 
 extern "C" {
 
-// fused realisation with the fast float32 native generation; [xlo, xhi] = log10 k range of the grid (padded)
-int emu_realise_fast(int nx, int ny, int nz, const double* kx2, const double* ky2, const double* kz2,
+// fused realisation with the fast native generation (float32 arithmetic; f64 != 0: float64 plan, values widened);
+// [xlo, xhi] = log10 k range of the grid (padded)
+int emu_realise_fast(int f64, int nx, int ny, int nz, const double* kx2, const double* ky2, const double* kz2,
                      const double* log10k, const double* sigma, int nt, uint64_t seed, double xlo, double xhi,
                      double dkx, void* W, double* s1, double* s2) {
   GenHost h;
   fill_gen(h, nx, ny, nz, kx2, ky2, kz2, log10k, sigma, nt, 0, seed, nullptr);
-  return realise_fast_impl(nx, ny, nz, h, seed, xlo, xhi, dkx, (cplx<float>*)W, s1, s2);
+  if (f64) return realise_fast_impl<double, FastGenColIO64<1>>(nx, ny, nz, h, seed, xlo, xhi, dkx, (cplx<double>*)W, s1, s2);
+  return realise_fast_impl<float, FastGenColIO>(nx, ny, nz, h, seed, xlo, xhi, dkx, (cplx<float>*)W, s1, s2);
 }
 
 // k-space after symmetrise in the API layout [nx][ny][nz/2+1] (rows K,T,R,S)

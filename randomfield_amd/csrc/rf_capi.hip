@@ -211,7 +211,7 @@ FastGenParams make_fast(rf_plan* p, uint64_t seed, bool seed_from_dev, const uin
 // (re)build the fast-path records once both the k grid and the power table are known
 int build_fast(rf_plan* p) {
   p->have_fast = false;
-  if (p->f64 || !p->have_kgrid || !p->have_power) return 0;
+  if (!p->have_kgrid || !p->have_power) return 0;
   double kmax2 = 0, kmin2 = 1e300;
   auto scan = [&](const std::vector<double>& a) { for (double v : a) if (v > 0 && v < kmin2) kmin2 = v; };
   scan(p->h_kx2); scan(p->h_ky2); scan(p->h_kz2);
@@ -249,7 +249,7 @@ int queue_x(rf_plan* p, const GenParams& gp, const void* kspace, void* W, hipStr
   const bool fast = !kspace && gp.noise_mode == NOISE_PHILOX && p->have_fast && !p->exact_gen;
   if (timed) { RF_HIP(hipEventRecord(p->ev[5], sx)); p->repair_timed = fast; }   // overwritten by the launcher if it splits
   if (fast)
-    RF_HIP(launch_col_fastgen(p->nx, W, gx, (long long)p->ny * nzl, make_fast(p, gp.seed, gp.seed_dev != nullptr, gp.seed_dev),
+    RF_HIP(launch_col_fastgen(p->f64, p->nx, W, gx, (long long)p->ny * nzl, make_fast(p, gp.seed, gp.seed_dev != nullptr, gp.seed_dev),
                               p->kz0, (int)nzl, p->tw_x, sx, false, timed ? p->ev[5] : nullptr));
   else
     RF_HIP(launch_col_gen(p->f64, p->nx, W, gx, (long long)p->ny * nzl, gp, kspace, p->kz0, (int)nzl, p->tw_x, sx));
@@ -479,7 +479,7 @@ int rf_plan_create(rf_plan** out, int nx, int ny, int nz, int dtype, int device,
     const ColGeom gx{(long long)ny * nzl, 0, (long long)ny * nzl}, gy{nzl, (long long)ny * nzl, nzl};
     FastGenParams fp0; memset(&fp0, 0, sizeof(fp0)); fp0.nx = nx; fp0.ny = ny; fp0.nz = nz;
     if ((e = launch_col_gen(dtype, nx, p->W, gx, (long long)ny * nzl, gp0, nullptr, 0, (int)nzl, p->tw_x, p->stream, true)) != hipSuccess ||
-        (!dtype && (e = launch_col_fastgen(nx, p->W, gx, (long long)ny * nzl, fp0, 0, (int)nzl, p->tw_x, p->stream, true)) != hipSuccess) ||
+        (e = launch_col_fastgen(dtype, nx, p->W, gx, (long long)ny * nzl, fp0, 0, (int)nzl, p->tw_x, p->stream, true)) != hipSuccess ||
         (e = launch_col_plain(dtype, ny, +1, p->W, gy, (long long)nx * nzl, p->tw_y, p->stream, true)) != hipSuccess ||
         (e = launch_row_c2r(dtype, (int)nzc, p->W, (long long)p->nxl * ny, 1.0, p->tw_z, p->partials, p->stream, true)) != hipSuccess ||
         (e = launch_row_r2c(dtype, (int)nzc, p->W, (long long)p->nxl * ny, p->tw_z, p->stream, true)) != hipSuccess ||

@@ -466,6 +466,16 @@ RF_HD void fast_gen_pair(const FastGenParams& g, const FastRec* rec, uint64_t se
                        c0, c1);
 }
 
+// One packed cell with native noise index ci (float64 plans: one complex128 per lane, so the two cells of a Philox
+// pair sit in neighbouring lanes; each lane runs the pair's call and keeps its own half).
+RF_HD cplx<float> fast_gen_one(const FastGenParams& g, const FastRec* rec, uint64_t seed, uint64_t ci, float k2) {
+  const PhiloxOut o = philox4x32_10(ci >> 1, 0, seed);
+  const bool odd = (ci & 1u) != 0;
+  float g0, g1;
+  BoxMuller<float>::run_scaled(odd ? o.w[2] : o.w[0], odd ? o.w[3] : o.w[1], fast_sigma(g, rec, k2), g0, g1);
+  return mk<float>(g0, g1);
+}
+
 // slot kz = 0 of column (ix, iy): (plane kz=0) + i (plane kz=nz/2), each Hermitian-symmetrised
 // by the rules of gen_cell() (transform.py:141-158)
 RF_HD cplx<float> fast_fix_kz0(const FastGenParams& g, const FastRec* rec, uint64_t seed, int ix, int iy) {

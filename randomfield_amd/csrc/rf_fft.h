@@ -191,6 +191,49 @@ struct FastGenColIOT {
 };
 using FastGenColIO = FastGenColIOT<0, 1>;
 
+// The same fast generation for float64 plans (native generator only: parity / reference-noise mode keeps the exact
+// float64 chain of GenColIO).  The deviates and sigma are formed in float32 -- hardware log / sin / cos, LDS
+// records -- and widened; the transform itself is float64.  One complex128 per lane (CPL = 1).
+template <int FIX = 1>
+struct FastGenColIO64 {
+  cplx<double>* base;
+  ColGeom g;
+  FastGenParams gp;
+  int kz0, nzl;
+  const FastRec* rec;
+  static constexpr int LDS_EXTRA = FAST_LDS_BINS * (int)sizeof(FastRec);
+  RF_HD static void sched_fence(int = 0) {}
+  RF_HD void prologue(int tid, int nthreads, void* lds_extra) {
+    FastRec* l = reinterpret_cast<FastRec*>(lds_extra);
+    for (int i = tid; i < gp.nbins && i < FAST_LDS_BINS; i += nthreads) l[i] = gp.rec[i];
+    rec = l;
+  }
+  RF_HD V16<double> load(long long C, int rb, int ro) const {
+    const uint64_t seed = gp.seed_dev ? *gp.seed_dev : gp.seed;
+    const int iy = (int)(C / nzl), kz = kz0 + (int)(C % nzl);                          // lane, m-invariant
+    const uint64_t plane = (uint64_t)gp.ny * (uint64_t)(gp.nz / 2);                    // noise cells per unit of ix
+    const uint64_t ci_l = (uint64_t)rb * plane + (uint64_t)iy * (uint64_t)(gp.nz / 2) + (uint64_t)kz;
+    const uint64_t ci_u = pin_uniform((uint64_t)ro * plane);
+    const int ro_s = ro >= (gp.nx >> 1) ? ro - gp.nx : ro;
+    const float kx = (float)(rb + ro_s) * gp.dkx;
+    const cplx<float> c = fast_gen_one(gp, rec, seed, ci_l + ci_u, kx * kx + gp.ky2[iy] + gp.kz2[kz]);
+    V16<double> v;
+    v.c[0] = mk<double>((double)c.x, (double)c.y);
+    return v;
+  }
+  static constexpr bool ROLLED_LOAD = false;
+  static constexpr int FIX_MODE = FIX;
+  RF_HD bool needs_fix(long long C) const { return FIX != 0 && kz0 + (int)(C % nzl) == 0; }
+  RF_HD cplx<double> fix_value(long long C, int rb, int ro) const {
+    const uint64_t seed = gp.seed_dev ? *gp.seed_dev : gp.seed;
+    const cplx<float> c = fast_fix_kz0(gp, rec, seed, rb + ro, (int)(C / nzl));
+    return mk<double>((double)c.x, (double)c.y);
+  }
+  RF_HD void store(long long C, int rb, int ro, const V16<double>& v) const {
+    *reinterpret_cast<V16<double>*>((base + g.uniform_part(ro)) + g.lane_part(C, rb)) = v;
+  }
+};
+
 // ---------------------------------------------------------------------------
 // Column FFT phases.  `tw` = exp(+2 pi i q / N), q in [0, N).
 // ---------------------------------------------------------------------------

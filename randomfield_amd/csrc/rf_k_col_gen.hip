@@ -40,30 +40,38 @@ hipError_t launch_t(int N, cplx<T>* W, ColGeom g, long long ncols, const GenPara
 // Fast float32 generation.  The tiles that contain the kz = 0 slot (one per iy when a tile is narrower than a
 // kz row) are run by the kernel WITH the Hermitian repair, which carries the extra register pressure only where
 // it is needed; every other tile by the kernel WITHOUT it (skip_period = tiles per iy).
-template <class C>
-hipError_t launch_fast_one(const FastGenParams& gp, cplx<float>* W, ColGeom g, long long ncols, int kz0, int nzl,
-                           const cplx<float>* tw, hipStream_t s, bool po, hipEvent_t after_repair) {
-  FastGenColIOT<0, 0> io0; io0.base = W; io0.g = g; io0.gp = gp; io0.kz0 = kz0; io0.nzl = nzl; io0.rec = nullptr;
-  FastGenColIOT<0, 1> io1; io1.base = W; io1.g = g; io1.gp = gp; io1.kz0 = kz0; io1.nzl = nzl; io1.rec = nullptr;
+template <class C, class IO0, class IO1, class CT>
+hipError_t launch_fast_one(const FastGenParams& gp, CT* W, ColGeom g, long long ncols, int kz0, int nzl,
+                           const CT* tw, hipStream_t s, bool po, hipEvent_t after_repair) {
+  IO0 io0; io0.base = W; io0.g = g; io0.gp = gp; io0.kz0 = kz0; io0.nzl = nzl; io0.rec = nullptr;
+  IO1 io1; io1.base = W; io1.g = g; io1.gp = gp; io1.kz0 = kz0; io1.nzl = nzl; io1.rec = nullptr;
   const bool split = nzl > C::TC && nzl % C::TC == 0;
   if (po) {
-    hipError_t e = launch_one<C, FastGenColIOT<0, 0>>(io0, ncols, tw, s, true);
-    return e != hipSuccess ? e : launch_one<C, FastGenColIOT<0, 1>>(io1, ncols, tw, s, true);
+    hipError_t e = launch_one<C, IO0>(io0, ncols, tw, s, true);
+    return e != hipSuccess ? e : launch_one<C, IO1>(io1, ncols, tw, s, true);
   }
-  if (!split) return launch_one<C, FastGenColIOT<0, 1>>(io1, ncols, tw, s, false);
+  if (!split) return launch_one<C, IO1>(io1, ncols, tw, s, false);
   const long long tiles_per_iy = nzl / C::TC, ntiles = ncols / C::TC;
-  if (kz0 != 0) return launch_one<C, FastGenColIOT<0, 0>>(io0, ncols, tw, s, false);   // only the slab that owns kz = 0 needs the repair
+  if (kz0 != 0) return launch_one<C, IO0>(io0, ncols, tw, s, false);   // only the slab that owns kz = 0 needs the repair
   // first the (few) tiles that hold slot kz = 0, with the repair; then every other tile without it
-  hipError_t e = launch_one<C, FastGenColIOT<0, 1>>(io1, ncols, tw, s, false, ncols / nzl, tiles_per_iy, 0);
+  hipError_t e = launch_one<C, IO1>(io1, ncols, tw, s, false, ncols / nzl, tiles_per_iy, 0);
   if (e != hipSuccess || tiles_per_iy >= (1LL << 30) || ntiles >= (1LL << 31)) return e != hipSuccess ? e : hipErrorInvalidValue;
   if (after_repair && (e = hipEventRecord(after_repair, s)) != hipSuccess) return e;
-  return launch_one<C, FastGenColIOT<0, 0>>(io0, ncols, tw, s, false, ntiles - ntiles / tiles_per_iy, 1, 0, (int)tiles_per_iy);
+  return launch_one<C, IO0>(io0, ncols, tw, s, false, ntiles - ntiles / tiles_per_iy, 1, 0, (int)tiles_per_iy);
 }
 
-hipError_t launch_col_fastgen(int N, void* W, ColGeom g, long long ncols, const FastGenParams& gp, int kz0, int nzl,
+hipError_t launch_col_fastgen(int f64, int N, void* W, ColGeom g, long long ncols, const FastGenParams& gp, int kz0, int nzl,
                               const void* tw, hipStream_t s, bool po, hipEvent_t after_repair) {
+  if (f64) {
+    switch (N) {
+#define X(NN) case NN: return launch_fast_one<typename GenSel<double, NN>::type, FastGenColIO64<0>, FastGenColIO64<1>, cplx<double>>(gp, (cplx<double>*)W, g, ncols, kz0, nzl, (const cplx<double>*)tw, s, po, after_repair);
+      RF_COL_SIZES(X)
+#undef X
+      default: return hipErrorInvalidValue;
+    }
+  }
   switch (N) {
-#define X(NN) case NN: return launch_fast_one<typename GenSel<float, NN>::type>(gp, (cplx<float>*)W, g, ncols, kz0, nzl, (const cplx<float>*)tw, s, po, after_repair);
+#define X(NN) case NN: return launch_fast_one<typename GenSel<float, NN>::type, FastGenColIOT<0, 0>, FastGenColIOT<0, 1>, cplx<float>>(gp, (cplx<float>*)W, g, ncols, kz0, nzl, (const cplx<float>*)tw, s, po, after_repair);
     RF_COL_SIZES(X)
 #undef X
     default: return hipErrorInvalidValue;

@@ -15,9 +15,9 @@ hipError_t launch_col_plain(int f64, int N, int dir, void* base, ColGeom g, long
 hipError_t launch_col_gen(int f64, int N, void* W, ColGeom g, long long ncols, const GenParams& gp,
                           const void* kspace, int kz0, int nzl, const void* tw, hipStream_t s,
                           bool prepare_only = false);
-// x pass fused with the fast float32 native generation
+// x pass fused with the fast native generation (float32 arithmetic; float64 plans widen the result)
 // (when the kz = 0 tiles run as a separate repairing launch first, `after_repair` is recorded between the two)
-hipError_t launch_col_fastgen(int N, void* W, ColGeom g, long long ncols, const FastGenParams& gp, int kz0, int nzl,
+hipError_t launch_col_fastgen(int f64, int N, void* W, ColGeom g, long long ncols, const FastGenParams& gp, int kz0, int nzl,
                               const void* tw, hipStream_t s, bool prepare_only = false, hipEvent_t after_repair = nullptr);
 int col_tile_cols(int f64, int N);   // tile width (columns) of the strided pass of length N, 0 if unsupported
 // z pass of c2r: rows of M = nz/2 complex -> nz reals, scaled; partials[2*tile] = (sum, sumsq)

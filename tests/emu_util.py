@@ -87,16 +87,17 @@ def col_fft(data, N, direction, ncols, inner, outer_stride, row_stride):
     return rc
 
 
-def realise_fast(nx, ny, nz, spacing, log10k, sigma, seed):
-    """Fused realisation with the fast float32 native generation path."""
+def realise_fast(nx, ny, nz, spacing, log10k, sigma, seed, dtype=np.float32):
+    """Fused realisation with the fast native generation path (float32 arithmetic; a float64
+    plan widens the generated values and transforms in double precision)."""
     args, keep = _gen_args(nx, ny, nz, spacing, log10k, sigma, seed, None)
     k0 = 2 * np.pi / spacing
     xlo = np.log10(k0 / max(nx, ny, nz)) - 0.01
     xhi = np.log10(k0 * np.sqrt(3) / 2) + 0.01
-    out = np.empty((nx, ny, nz), np.float32)
+    out = np.empty((nx, ny, nz), dtype)
     s1, s2 = ctypes.c_double(), ctypes.c_double()
-    rc = lib().emu_realise_fast(nx, ny, nz, *args[:6], ctypes.c_uint64(seed), ctypes.c_double(xlo),
-                                ctypes.c_double(xhi), ctypes.c_double(k0 / nx),
+    rc = lib().emu_realise_fast(int(np.dtype(dtype) == np.float64), nx, ny, nz, *args[:6], ctypes.c_uint64(seed),
+                                ctypes.c_double(xlo), ctypes.c_double(xhi), ctypes.c_double(k0 / nx),
                                 out.ctypes.data_as(ctypes.c_void_p), ctypes.byref(s1), ctypes.byref(s2))
     assert rc == 0, rc
     return out, s1.value, s2.value

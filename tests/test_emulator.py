@@ -130,6 +130,13 @@ def test_fast_native_generation_matches_oracle(shape, default_power):
     noise = cpu_ref.native_noise(99, nx, ny, nz, np.complex64)
     ref, rms = cpu_ref.generate_delta_field(nx, ny, nz, 2.5, k, Pk, noise=noise, double_fft=True)
     assert np.max(np.abs(out - ref)) <= 2e-5 * rms      # float32 Box-Muller angle rounding dominates
+    # float64 plans use the same float32 generation, widened: equal to the float32 plan up to FFT rounding, and
+    # within the same tolerance of the oracle's float64 restatement of the stream
+    out64, t1, t2 = emu_util.realise_fast(nx, ny, nz, 2.5, xt, st, seed=99, dtype=np.float64)
+    assert np.max(np.abs(out64 - out)) <= 2e-6 * rms
+    noise64 = cpu_ref.native_noise(99, nx, ny, nz, np.complex128)
+    ref64, rms64 = cpu_ref.generate_delta_field(nx, ny, nz, 2.5, k, Pk, noise=noise64, dtype=np.complex128)
+    assert np.max(np.abs(out64 - ref64)) <= 2e-5 * rms64
     # a linear-k Gaussian table (non-uniform in log k, many knots per decade at high k); its first knot is
     # put below the grid's fundamental mode so that no cell sits on the table edge (see the test above)
     if shape == (64, 64, 64):

@@ -161,8 +161,10 @@ def test_1024_cube_known_answer_generator_reference_rng(hip):
 
 def test_native_rng_matches_oracle_restatement(hip, dpower):
     """Native Philox4x32-10 + Box-Muller mode, value by value against the oracle's
-    restatement of the same counter-based stream (float32 plans use hardware
-    log/sin/cos: 2e-5 * rms; float64 plans 1e-11)."""
+    restatement of the same counter-based stream.  The default (fast) generation
+    forms sigma and the deviates with float32 hardware log / sin / cos on float32
+    AND float64 plans: 2e-5 * rms.  The exact-chain flavour on a float64 plan
+    reproduces the float64 restatement to 1e-11."""
     k, Pk = dpower
     for dtype, tol in ((np.complex64, 2e-5), (np.complex128, TOL_F64)):
         shape = (64, 32, 128)
@@ -172,7 +174,7 @@ def test_native_rng_matches_oracle_restatement(hip, dpower):
         d = plan.download_real()
         noise = cpu_ref.native_noise(2024, nx, ny, nz, dtype)
         ref, rms = cpu_ref.generate_delta_field(nx, ny, nz, SPACING, k, Pk, noise=noise, dtype=dtype, double_fft=True)
-        assert np.max(np.abs(d - ref)) <= tol * rms
+        assert np.max(np.abs(d - ref)) <= 2e-5 * rms
         # unfused path (generate -> k-space -> c2r) equals the fused one
         plan.generate(seed=2024)
         ks = plan.download_k()
@@ -352,7 +354,7 @@ def test_errors_are_loud(hip, dpower):
         Plan(shape=(4, 6, 8), dtype_in=np.complex64)                 # hip backend refuses, does not fall back
 
 
-def _virtual_rank_field(hip, shape, dtype, k, Pk, nranks, seed=None, noise=None):
+def _virtual_rank_field(hip, shape, dtype, k, Pk, nranks, seed=None, noise=None, exact=False):
     """Run the slab pipeline with `nranks` virtual ranks on one device: forward (generation + x + y on the
     kz slab), all-to-all by device copies, backward (z pass on the x slab); returns the assembled field
     and the global (sum, sumsq)."""
@@ -363,6 +365,7 @@ def _virtual_rank_field(hip, shape, dtype, k, Pk, nranks, seed=None, noise=None)
         p = hip.DevicePlan(nx, ny, nz, dtype, nranks=nranks, rank=r)
         p.set_kgrid(*powertools.ksq_axes(nx, ny, nz, SPACING))
         p.set_power(*cpu_ref.sigma_table(k, Pk, nx, ny, nz, SPACING))
+        p.set_exact_generation(exact)
         plans.append(p)
     for p in plans:
         p.slab_forward(seed=seed or 0, noise=noise)
@@ -414,7 +417,15 @@ def test_slab_float64_and_rccl_single_rank(hip, dpower):
     one.realise(seed=3)
     ref = one.download_real()
     field, s1, s2 = _virtual_rank_field(hip, shape, np.complex128, k, Pk, 4, seed=3)
-    assert np.max(np.abs(field - ref)) <= 1e-13 * ref.std()
+    # the default (fast) generation works in float32: kernel instantiations may contract multiply-adds differently
+    assert np.max(np.abs(field - ref)) <= 1e-6 * ref.std()
+    # with the exact float64 chain the decomposition is invariant to double-precision rounding
+    one.set_exact_generation(True)
+    one.realise(seed=3)
+    ref_exact = one.download_real()
+    field, s1, s2 = _virtual_rank_field(hip, shape, np.complex128, k, Pk, 4, seed=3, exact=True)
+    assert np.max(np.abs(field - ref_exact)) <= 1e-13 * ref_exact.std()
+    one.set_exact_generation(False)
     # the RCCL library loads, a communicator initialises and a collective runs (1 rank: all a 1-GPU box allows)
     import sys
     if "torch" in sys.modules:
