@@ -90,6 +90,16 @@ int rf_download_noise(rf_plan* plan, double* host, unsigned long long first, uns
 int rf_execute_c2r(rf_plan* plan);               /* k buffer -> real field, numpy normalisation 1/(nx ny nz) */
 int rf_execute_r2c(rf_plan* plan);               /* real field -> k buffer, unnormalised */
 
+/* ---- unpacked complex-to-complex plans: Plan(packed=False) (transform.py:207-213,266-270; the reference's
+ * tests/test_transform.py:180-298).  One device buffer [nx][ny][nz] complex, transformed in place.
+ * nx, ny powers of two in [8, 2048], nz in [8, 1024].  Only rf_upload_c / rf_download_c / rf_execute_c2c,
+ * rf_sync, rf_elapsed_ms, rf_plan_set_stream, rf_plan_nbytes, rf_device_ptr and rf_plan_destroy apply. */
+int rf_plan_create_c2c(rf_plan** plan, int nx, int ny, int nz, int dtype, int device);
+int rf_upload_c(rf_plan* plan, const void* host);     /* [nx][ny][nz] complex64 / complex128, C order */
+int rf_download_c(rf_plan* plan, void* host);
+/* direction = -1: forward, unnormalised (np.fft.fftn); +1: inverse with numpy's 1/(nx ny nz) (np.fft.ifftn) */
+int rf_execute_c2c(rf_plan* plan, int direction);
+
 /* ---- fused K,T,R,S,X,D: Generator.generate_delta_field(save_potential=False)
  * (generate.py:191-199,218-219).  Generation is fused into the first FFT pass; the
  * k-space array is never materialised.  rms/mean are available from rf_moments(). */

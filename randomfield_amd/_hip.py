@@ -45,6 +45,10 @@ SIGNATURES = {
     "rf_download_noise": (ctypes.c_int, [ctypes.c_void_p, _c_dp, ctypes.c_ulonglong, ctypes.c_ulonglong]),
     "rf_execute_c2r": (ctypes.c_int, [ctypes.c_void_p]),
     "rf_execute_r2c": (ctypes.c_int, [ctypes.c_void_p]),
+    "rf_plan_create_c2c": (ctypes.c_int, [_c_void_pp] + [ctypes.c_int] * 5),
+    "rf_upload_c": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "rf_download_c": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "rf_execute_c2c": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "rf_realise": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, _c_dp]),
     "rf_realise_batch": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64), ctypes.c_int, _c_dp]),
     "rf_realise_batch_prepare": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
@@ -137,7 +141,9 @@ def _f64(a):
 class DevicePlan(object):
     """Thin object wrapper around ``rf_plan*``.  All methods raise RuntimeError on failure."""
 
-    def __init__(self, nx, ny, nz, dtype=np.complex64, device=0, nranks=1, rank=0):
+    def __init__(self, nx, ny, nz, dtype=np.complex64, device=0, nranks=1, rank=0, unpacked=False):
+        """``unpacked=True`` makes a complex-to-complex plan over the full (nx, ny, nz) complex array
+        (``transform.Plan(packed=False)``): only ``upload_c`` / ``execute_c2c`` / ``download_c`` apply."""
         self._lib = load()
         require_gpu()
         dtype = np.dtype(dtype)
@@ -149,9 +155,36 @@ class DevicePlan(object):
         self.complex_dtype = dtype
         self.real_dtype = np.dtype(np.float32 if dtype == np.complex64 else np.float64)
         self._h = ctypes.c_void_p()
+        self.unpacked = bool(unpacked)
+        if self.unpacked:
+            if nranks != 1:
+                raise ValueError("unpacked c2c plans are single-GPU")
+            check(self._lib.rf_plan_create_c2c(ctypes.byref(self._h), self.nx, self.ny, self.nz,
+                                               RF_F64 if dtype == np.complex128 else RF_F32, int(device)),
+                  "rf_plan_create_c2c")
+            return
         check(self._lib.rf_plan_create(ctypes.byref(self._h), self.nx, self.ny, self.nz,
                                        RF_F64 if dtype == np.complex128 else RF_F32, int(device),
                                        int(nranks), int(rank)), "rf_plan_create")
+
+    # -- unpacked complex-to-complex plans -----------------------------------
+    def upload_c(self, data):
+        data = np.ascontiguousarray(data, self.complex_dtype)
+        if data.shape != (self.nx, self.ny, self.nz):
+            raise ValueError("expected a complex array of shape %r" % ((self.nx, self.ny, self.nz),))
+        check(self._lib.rf_upload_c(self._h, data.ctypes.data_as(ctypes.c_void_p)), "rf_upload_c")
+
+    def download_c(self, out=None):
+        if out is None:
+            out = np.empty((self.nx, self.ny, self.nz), self.complex_dtype)
+        if out.shape != (self.nx, self.ny, self.nz) or out.dtype != self.complex_dtype or not out.flags.c_contiguous:
+            raise ValueError("out must be a C-contiguous %s array of shape %r" % (self.complex_dtype, (self.nx, self.ny, self.nz)))
+        check(self._lib.rf_download_c(self._h, out.ctypes.data_as(ctypes.c_void_p)), "rf_download_c")
+        return out
+
+    def execute_c2c(self, inverse):
+        """In place: ``inverse=True`` is np.fft.ifftn (1/N), ``False`` np.fft.fftn."""
+        check(self._lib.rf_execute_c2c(self._h, 1 if inverse else -1), "rf_execute_c2c")
 
     # -- lifetime ---------------------------------------------------------
     def close(self):

@@ -147,6 +147,50 @@ int r2c_impl(int nx, int ny, int nz, const T* field, cplx<T>* K) {
   return 0;
 }
 
+template <class C, int DIR>
+void run_row_c2c(const ScaledRowIO<typename C::T>& io, long long nrows, const cplx<typename C::T>* tw) {
+  using F = RowC2C<C, DIR, ScaledRowIO<typename C::T>>;
+  using cx = cplx<typename C::T>;
+  std::vector<cx> lds((size_t)C::LDS_BYTES / sizeof(cx) + 1);
+  std::vector<typename F::Regs> regs(C::NT);
+  const long long ntiles = (nrows + C::NRT - 1) / C::NRT;
+  for (long long tile = 0; tile < ntiles; ++tile) {
+    for (int t = 0; t < C::NT; ++t) F::prologue(t, tw, lds.data());
+    const cx* ltw = F::lds_tw(lds.data());
+    for (int t = 0; t < C::NT; ++t) F::pass_first(t, tile, nrows, io, lds.data());
+    if (C::NPASS == 3) {
+      for (int t = 0; t < C::NT; ++t) F::pass_mid_read(t, ltw, lds.data(), regs[t]);
+      for (int t = 0; t < C::NT; ++t) F::pass_mid_write(t, lds.data(), regs[t]);
+    }
+    if (C::NPASS >= 2)
+      for (int t = 0; t < C::NT; ++t) F::pass_last(t, tile, nrows, io, ltw, lds.data());
+  }
+}
+
+template <typename T, int DIR>
+int dispatch_row_c2c(int M, cplx<T>* base, long long nrows, double scale) {
+  auto tw = make_twiddles<T>(M);
+  ScaledRowIO<T> io; io.base = base; io.M_of = M; io.scale = (T)scale;
+  switch (M) {
+#define X(MM) case MM: run_row_c2c<typename RowSel<T, MM>::type, DIR>(io, nrows, tw.data()); return 0;
+    RF_ROW_SIZES(X)
+#undef X
+    default: return -1;
+  }
+}
+
+// unpacked c2c in place on data[nx][ny][nz] (same pass order as rf_execute_c2c)
+template <typename T, int DIR>
+int c2c_impl(int nx, int ny, int nz, cplx<T>* W) {
+  PlainColIO<T> xio; xio.base = W; xio.g = ColGeom{(long long)ny * nz, 0, (long long)ny * nz};
+  int rc = dispatch_col<T, DIR>(nx, xio, (long long)ny * nz);
+  if (rc) return rc;
+  PlainColIO<T> yio; yio.base = W; yio.g = ColGeom{nz, (long long)ny * nz, nz};
+  rc = dispatch_col<T, DIR>(ny, yio, (long long)nx * nz);
+  if (rc) return rc;
+  return dispatch_row_c2c<T, DIR>(nz, W, (long long)nx * ny, DIR > 0 ? 1.0 / ((double)nx * ny * nz) : 1.0);
+}
+
 struct GenHost {
   SigmaTableHost tab;
   GenParams gp;
@@ -257,6 +301,12 @@ int emu_c2r(int f64, int nx, int ny, int nz, const void* kspace, void* W, double
 int emu_r2c(int f64, int nx, int ny, int nz, const void* field, void* K) {
   return f64 ? r2c_impl<double>(nx, ny, nz, (const double*)field, (cplx<double>*)K)
              : r2c_impl<float>(nx, ny, nz, (const float*)field, (cplx<float>*)K);
+}
+
+// unpacked complex-to-complex transform in place: dir = +1 inverse (1/N), -1 forward
+int emu_c2c(int f64, int nx, int ny, int nz, int dir, void* data) {
+  if (f64) return dir > 0 ? c2c_impl<double, +1>(nx, ny, nz, (cplx<double>*)data) : c2c_impl<double, -1>(nx, ny, nz, (cplx<double>*)data);
+  return dir > 0 ? c2c_impl<float, +1>(nx, ny, nz, (cplx<float>*)data) : c2c_impl<float, -1>(nx, ny, nz, (cplx<float>*)data);
 }
 
 // one strided FFT pass over data[(C / inner) * outer_stride + C % inner + row * row_stride]

@@ -140,6 +140,7 @@ struct rf_plan {
   double* ztab = nullptr;                 // 2 * nz doubles for lognormal / affine tables
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // start, after x, y, z, reduce; [5] = after the kz = 0 repair launch
   bool repair_timed = false;
+  bool unpacked = false;               // c2c plan: W is the full [nx][ny][nz] complex array, only rf_*_c / rf_execute_c2c apply
   bool timed = false;
   struct BatchGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };
   std::map<int, BatchGraph> graphs;       // captured batch graphs, keyed by the number of realisations
@@ -493,6 +494,80 @@ int rf_plan_create(rf_plan** out, int nx, int ny, int nz, int dtype, int device,
   return 0;
 }
 
+// Unpacked c2c plan (transform.py:207-213,266-270): one buffer [nx][ny][nz] complex, transformed in place.
+int rf_plan_create_c2c(rf_plan** out, int nx, int ny, int nz, int dtype, int device) {
+  RF_REQUIRE(out != nullptr, "plan pointer is null");
+  *out = nullptr;
+  RF_REQUIRE(dtype == RF_F32 || dtype == RF_F64, "dtype must be RF_F32 or RF_F64");
+  if (!col_size_supported(nx) || !col_size_supported(ny) || !row_size_supported(nz))
+    return fail(1, "unsupported shape for a c2c plan: nx, ny must be powers of two in [8, 2048], nz in [8, 1024]");
+  const int tcx = col_tile_cols(dtype, nx), tcy = col_tile_cols(dtype, ny);
+  if (((long long)ny * nz) % tcx || ((long long)nx * nz) % tcy) return fail(1, "unsupported shape for a c2c plan: too few columns for a tile");
+  RF_HIP(hipSetDevice(device));
+  rf_plan* p = new rf_plan();
+  p->nx = nx; p->ny = ny; p->nz = nz; p->nzc = nz / 2; p->f64 = dtype; p->device = device;
+  p->nranks = 1; p->rank = 0; p->csize = dtype ? 16 : 8; p->nxl = nx; p->nzl = p->nzc; p->kz0 = 0;
+  p->unpacked = true;
+  p->w_bytes = (size_t)nx * ny * nz * p->csize;
+  p->k_bytes = 0;
+  auto cleanup = [&](int rc) { rf_plan_destroy(p); return rc; };
+  hipError_t e;
+  if ((e = hipStreamCreateWithFlags(&p->own_stream, hipStreamNonBlocking)) != hipSuccess)
+    return cleanup(fail(2, std::string("hipStreamCreate: ") + hipGetErrorString(e)));
+  p->stream = p->own_stream;
+  if ((e = hipMalloc(&p->W, p->w_bytes)) != hipSuccess) return cleanup(fail(2, std::string("hipMalloc field buffer: ") + hipGetErrorString(e)));
+  int rc = dtype ? upload_twiddles<double>(&p->tw_x, nx) : upload_twiddles<float>(&p->tw_x, nx);
+  if (!rc) rc = dtype ? upload_twiddles<double>(&p->tw_y, ny) : upload_twiddles<float>(&p->tw_y, ny);
+  if (!rc) rc = dtype ? upload_twiddles<double>(&p->tw_z, nz) : upload_twiddles<float>(&p->tw_z, nz);
+  if (rc) return cleanup(rc);
+  for (auto& ev : p->ev)
+    if ((e = hipEventCreate(&ev)) != hipSuccess) return cleanup(fail(2, std::string("hipEventCreate: ") + hipGetErrorString(e)));
+  const ColGeom gx{(long long)ny * nz, 0, (long long)ny * nz}, gy{nz, (long long)ny * nz, nz};
+  for (int dir = -1; dir <= 1; dir += 2)
+    if ((e = launch_row_c2c(dtype, nz, dir, p->W, (long long)nx * ny, 1.0, p->tw_z, p->stream, true)) != hipSuccess ||
+        (e = launch_col_plain(dtype, ny, dir, p->W, gy, (long long)nx * nz, p->tw_y, p->stream, true)) != hipSuccess ||
+        (e = launch_col_plain(dtype, nx, dir, p->W, gx, (long long)ny * nz, p->tw_x, p->stream, true)) != hipSuccess)
+      return cleanup(fail(2, std::string("kernel preparation: ") + hipGetErrorString(e)));
+  *out = p;
+  return 0;
+}
+
+int rf_upload_c(rf_plan* p, const void* host) {
+  RF_REQUIRE(p && host, "null argument");
+  RF_REQUIRE(p->unpacked, "rf_upload_c is for plans made by rf_plan_create_c2c");
+  RF_HIP(hipSetDevice(p->device));
+  RF_HIP(hipMemcpyAsync(p->W, host, p->w_bytes, hipMemcpyHostToDevice, p->stream));
+  RF_HIP(hipStreamSynchronize(p->stream));
+  return 0;
+}
+
+int rf_download_c(rf_plan* p, void* host) {
+  RF_REQUIRE(p && host, "null argument");
+  RF_REQUIRE(p->unpacked, "rf_download_c is for plans made by rf_plan_create_c2c");
+  RF_HIP(hipSetDevice(p->device));
+  RF_HIP(hipMemcpyAsync(host, p->W, p->w_bytes, hipMemcpyDeviceToHost, p->stream));
+  RF_HIP(hipStreamSynchronize(p->stream));
+  return 0;
+}
+
+// direction = -1: forward, unnormalised (np.fft.fftn); +1: inverse with numpy's 1/(nx ny nz) (np.fft.ifftn)
+int rf_execute_c2c(rf_plan* p, int direction) {
+  RF_REQUIRE(p, "null plan");
+  RF_REQUIRE(p->unpacked, "rf_execute_c2c is for plans made by rf_plan_create_c2c");
+  RF_REQUIRE(direction == 1 || direction == -1, "direction must be +1 (inverse) or -1 (forward)");
+  RF_HIP(hipSetDevice(p->device));
+  const long long nz = p->nz;
+  const ColGeom gx{(long long)p->ny * nz, 0, (long long)p->ny * nz}, gy{nz, (long long)p->ny * nz, nz};
+  const double scale = direction > 0 ? 1.0 / ((double)p->nx * (double)p->ny * (double)p->nz) : 1.0;
+  RF_HIP(hipEventRecord(p->ev[0], p->stream));
+  RF_HIP(launch_col_plain(p->f64, p->nx, direction, p->W, gx, (long long)p->ny * nz, p->tw_x, p->stream));
+  RF_HIP(launch_col_plain(p->f64, p->ny, direction, p->W, gy, (long long)p->nx * nz, p->tw_y, p->stream));
+  RF_HIP(launch_row_c2c(p->f64, (int)nz, direction, p->W, (long long)p->nx * p->ny, scale, p->tw_z, p->stream));
+  RF_HIP(hipEventRecord(p->ev[4], p->stream));
+  p->timed = false;
+  return 0;
+}
+
 int rf_plan_destroy(rf_plan* p) {
   if (!p) return 0;
   (void)hipSetDevice(p->device);
@@ -521,6 +596,7 @@ int rf_plan_nbytes(rf_plan* p, size_t* nbytes) {
 
 int rf_plan_set_flag(rf_plan* p, int flag, int value) {
   RF_REQUIRE(p, "null plan");
+  RF_REQUIRE(!p->unpacked, "this call does not apply to an unpacked c2c plan");
   RF_REQUIRE(flag == RF_FLAG_EXACT_GENERATION || flag == RF_FLAG_FORCE_SLAB_PATH, "unknown flag");
   RF_HIP(hipStreamSynchronize(p->stream));
   if (flag == RF_FLAG_FORCE_SLAB_PATH) {
@@ -545,6 +621,7 @@ int rf_plan_set_stream(rf_plan* p, void* hip_stream) {
 
 int rf_set_kgrid(rf_plan* p, const double* kx2, const double* ky2, const double* kz2) {
   RF_REQUIRE(p && kx2 && ky2 && kz2, "null argument");
+  RF_REQUIRE(!p->unpacked, "this call does not apply to an unpacked c2c plan");
   RF_HIP(hipSetDevice(p->device));
   RF_HIP(hipMemcpyAsync(p->kx2, kx2, p->nx * sizeof(double), hipMemcpyHostToDevice, p->stream));
   RF_HIP(hipMemcpyAsync(p->ky2, ky2, p->ny * sizeof(double), hipMemcpyHostToDevice, p->stream));
@@ -565,6 +642,7 @@ int rf_set_kgrid(rf_plan* p, const double* kx2, const double* ky2, const double*
 
 int rf_set_power(rf_plan* p, const double* log10k, const double* sigma, int n) {
   RF_REQUIRE(p && log10k && sigma, "null argument");
+  RF_REQUIRE(!p->unpacked, "this call does not apply to an unpacked c2c plan");
   RF_REQUIRE(n >= 2, "power table needs at least 2 rows");
   for (int i = 0; i + 1 < n; ++i) RF_REQUIRE(log10k[i + 1] > log10k[i], "log10k must be strictly increasing");
   RF_HIP(hipSetDevice(p->device));
@@ -590,6 +668,7 @@ int rf_set_power(rf_plan* p, const double* log10k, const double* sigma, int n) {
 
 int rf_generate(rf_plan* p, uint64_t seed, int mode, const double* noise_host) {
   RF_REQUIRE(p, "null plan");
+  RF_REQUIRE(!p->unpacked, "this call does not apply to an unpacked c2c plan");
   RF_REQUIRE(p->nranks == 1, "k-space buffer operations are single-GPU only");
   RF_REQUIRE(p->have_kgrid && p->have_power, "rf_set_kgrid and rf_set_power must be called first");
   RF_REQUIRE(mode == RF_NOISE_NATIVE || mode == RF_NOISE_EXTERNAL || mode == RF_NOISE_RESIDENT, "invalid noise mode");
@@ -604,6 +683,7 @@ int rf_generate(rf_plan* p, uint64_t seed, int mode, const double* noise_host) {
 
 int rf_execute_c2r(rf_plan* p) {
   RF_REQUIRE(p, "null plan");
+  RF_REQUIRE(!p->unpacked, "this call does not apply to an unpacked c2c plan");
   RF_REQUIRE(p->nranks == 1, "k-space buffer operations are single-GPU only");
   RF_REQUIRE(p->K && p->k_valid, "no k-space data: call rf_generate or rf_upload_k first");
   RF_HIP(hipSetDevice(p->device));
@@ -616,6 +696,7 @@ int rf_execute_c2r(rf_plan* p) {
 
 int rf_execute_r2c(rf_plan* p) {
   RF_REQUIRE(p, "null plan");
+  RF_REQUIRE(!p->unpacked, "this call does not apply to an unpacked c2c plan");
   RF_REQUIRE(p->nranks == 1, "rf_execute_r2c is single-GPU only");
   RF_REQUIRE(p->real_valid && p->cur == p->W, "no real-space field on the device: call rf_upload_real (or a c2r) first");
   RF_HIP(hipSetDevice(p->device));
@@ -637,6 +718,7 @@ int rf_execute_r2c(rf_plan* p) {
 
 int rf_realise(rf_plan* p, uint64_t seed, int mode, const double* noise_host) {
   RF_REQUIRE(p, "null plan");
+  RF_REQUIRE(!p->unpacked, "this call does not apply to an unpacked c2c plan");
   RF_REQUIRE(p->have_kgrid && p->have_power, "rf_set_kgrid and rf_set_power must be called first");
   RF_REQUIRE(mode == RF_NOISE_NATIVE || mode == RF_NOISE_EXTERNAL || mode == RF_NOISE_RESIDENT, "invalid noise mode");
   RF_HIP(hipSetDevice(p->device));
@@ -699,12 +781,14 @@ static int batch_prepare(rf_plan* p, int n) {
 
 int rf_realise_batch_prepare(rf_plan* p, int n) {
   RF_REQUIRE(p, "null plan");
+  RF_REQUIRE(!p->unpacked, "this call does not apply to an unpacked c2c plan");
   if (p->nranks > 1 || p->force_slab) return 0;     // slab batches are not graph-captured
   return batch_prepare(p, n);
 }
 
 int rf_realise_batch(rf_plan* p, const uint64_t* seeds, int n, double* rms_out) {
   RF_REQUIRE(p && seeds, "null argument");
+  RF_REQUIRE(!p->unpacked, "this call does not apply to an unpacked c2c plan");
   RF_REQUIRE(n >= 1, "need at least one seed");
   if (p->nranks > 1 || p->force_slab) {
     RF_REQUIRE(p->have_kgrid && p->have_power, "rf_set_kgrid and rf_set_power must be called first");
@@ -748,6 +832,7 @@ int rf_realise_batch(rf_plan* p, const uint64_t* seeds, int n, double* rms_out) 
 
 int rf_moments(rf_plan* p, double* mean, double* std_out) {
   RF_REQUIRE(p, "null plan");
+  RF_REQUIRE(!p->unpacked, "this call does not apply to an unpacked c2c plan");
   RF_REQUIRE(p->stats_valid, "no realisation has been computed");
   RF_HIP(hipSetDevice(p->device));
   double st[2];
@@ -763,6 +848,7 @@ int rf_moments(rf_plan* p, double* mean, double* std_out) {
 
 int rf_lognormal(rf_plan* p, const double* a_z, const double* b_z, int nz, double sigma) {
   RF_REQUIRE(p && a_z && b_z, "null argument");
+  RF_REQUIRE(!p->unpacked, "this call does not apply to an unpacked c2c plan");
   RF_REQUIRE(nz == p->nz, "table length must equal nz");
   RF_REQUIRE(p->real_valid, "no real-space field on the device");
   RF_REQUIRE(sigma > 0, "sigma must be positive");
@@ -777,6 +863,7 @@ int rf_lognormal(rf_plan* p, const double* a_z, const double* b_z, int nz, doubl
 
 int rf_affine_z(rf_plan* p, const double* mul_z, int nz, double add) {
   RF_REQUIRE(p && mul_z, "null argument");
+  RF_REQUIRE(!p->unpacked, "this call does not apply to an unpacked c2c plan");
   RF_REQUIRE(nz == p->nz, "table length must equal nz");
   RF_REQUIRE(p->real_valid, "no real-space field on the device");
   RF_HIP(hipSetDevice(p->device));
@@ -791,6 +878,7 @@ int rf_scale_z(rf_plan* p, const double* factor_z, int nz) { return rf_affine_z(
 
 int rf_save_potential(rf_plan* p) {
   RF_REQUIRE(p, "null plan");
+  RF_REQUIRE(!p->unpacked, "this call does not apply to an unpacked c2c plan");
   RF_REQUIRE(p->nranks == 1, "k-space buffer operations are single-GPU only");
   RF_REQUIRE(p->K && p->k_valid, "no k-space data");
   RF_REQUIRE(p->have_kgrid, "rf_set_kgrid must be called first");
@@ -802,6 +890,7 @@ int rf_save_potential(rf_plan* p) {
 
 int rf_load_potential(rf_plan* p, double scale) {
   RF_REQUIRE(p, "null plan");
+  RF_REQUIRE(!p->unpacked, "this call does not apply to an unpacked c2c plan");
   RF_REQUIRE(p->nranks == 1, "k-space buffer operations are single-GPU only");
   RF_REQUIRE(p->P, "no saved potential");
   RF_HIP(hipSetDevice(p->device));
@@ -813,6 +902,7 @@ int rf_load_potential(rf_plan* p, double scale) {
 
 int rf_upload_k(rf_plan* p, const void* host) {
   RF_REQUIRE(p && host, "null argument");
+  RF_REQUIRE(!p->unpacked, "this call does not apply to an unpacked c2c plan");
   RF_REQUIRE(p->nranks == 1, "k-space buffer operations are single-GPU only");
   RF_HIP(hipSetDevice(p->device));
   if (int rc = ensure_k(p)) return rc;
@@ -824,6 +914,7 @@ int rf_upload_k(rf_plan* p, const void* host) {
 
 int rf_download_k(rf_plan* p, void* host) {
   RF_REQUIRE(p && host, "null argument");
+  RF_REQUIRE(!p->unpacked, "this call does not apply to an unpacked c2c plan");
   RF_REQUIRE(p->K && p->k_valid, "no k-space data");
   RF_HIP(hipSetDevice(p->device));
   RF_HIP(hipMemcpyAsync(host, p->K, p->k_bytes, hipMemcpyDeviceToHost, p->stream));
@@ -833,6 +924,7 @@ int rf_download_k(rf_plan* p, void* host) {
 
 int rf_upload_real(rf_plan* p, const void* host, int layout) {
   RF_REQUIRE(p && host, "null argument");
+  RF_REQUIRE(!p->unpacked, "this call does not apply to an unpacked c2c plan");
   RF_REQUIRE(p->nranks == 1, "rf_upload_real is single-GPU only");
   RF_HIP(hipSetDevice(p->device));
   const size_t rsize = p->csize / 2;
@@ -848,6 +940,7 @@ int rf_upload_real(rf_plan* p, const void* host, int layout) {
 
 int rf_download_real(rf_plan* p, void* host, int layout, int x0, int x1) {
   RF_REQUIRE(p && host, "null argument");
+  RF_REQUIRE(!p->unpacked, "this call does not apply to an unpacked c2c plan");
   RF_REQUIRE(p->real_valid, "no real-space field on the device");
   RF_REQUIRE(0 <= x0 && x0 < x1 && x1 <= p->nxl, "invalid x range (multi-GPU plans hold nx/ranks local planes)");
   RF_HIP(hipSetDevice(p->device));
@@ -883,6 +976,7 @@ int rf_elapsed_ms(rf_plan* p, float* ms) {
 
 int rf_kernel_ms(rf_plan* p, float* ms5) {
   RF_REQUIRE(p && ms5, "null argument");
+  RF_REQUIRE(!p->unpacked, "this call does not apply to an unpacked c2c plan");
   RF_REQUIRE(p->timed, "per-kernel times are recorded by rf_realise / rf_execute_c2r only");
   RF_HIP(hipEventSynchronize(p->ev[4]));
   for (int i = 0; i < 4; ++i) RF_HIP(hipEventElapsedTime(&ms5[i], p->ev[i], p->ev[i + 1]));
@@ -898,6 +992,7 @@ int rf_kernel_ms(rf_plan* p, float* ms5) {
 
 int rf_mt_set_jump(rf_plan* p, int nlevels, const uint16_t* pos, const int* npos, int stride, int blocks_per_segment) {
   RF_REQUIRE(p && pos && npos, "null argument");
+  RF_REQUIRE(!p->unpacked, "this call does not apply to an unpacked c2c plan");
   RF_REQUIRE(nlevels >= 1 && stride >= 1 && blocks_per_segment >= 1, "invalid jump table");
   RF_HIP(hipSetDevice(p->device));
   RF_HIP(hipStreamSynchronize(p->stream));
@@ -913,6 +1008,7 @@ int rf_mt_set_jump(rf_plan* p, int nlevels, const uint16_t* pos, const int* npos
 
 int rf_noise_mt19937(rf_plan* p, const uint32_t* state624, unsigned long long* accepted) {
   RF_REQUIRE(p && state624, "null argument");
+  RF_REQUIRE(!p->unpacked, "this call does not apply to an unpacked c2c plan");
   RF_REQUIRE(p->nranks == 1, "rf_noise_mt19937 is single-GPU only");
   RF_REQUIRE(p->mt_pos && !p->mt_npos.empty(), "rf_mt_set_jump must be called first");
   RF_HIP(hipSetDevice(p->device));
@@ -976,6 +1072,7 @@ int rf_noise_mt19937(rf_plan* p, const uint32_t* state624, unsigned long long* a
 
 int rf_download_noise(rf_plan* p, double* host, unsigned long long first, unsigned long long count) {
   RF_REQUIRE(p && host, "null argument");
+  RF_REQUIRE(!p->unpacked, "this call does not apply to an unpacked c2c plan");
   RF_REQUIRE(p->noise_resident, "no deviates resident on the device");
   RF_REQUIRE(first + count <= 2ull * p->nx * p->ny * (p->nzc + 1), "range outside the noise buffer");
   RF_HIP(hipSetDevice(p->device));
@@ -995,6 +1092,7 @@ int rf_comm_unique_id(void* id128) {
 
 int rf_comm_init(rf_plan* p, const void* id128) {
   RF_REQUIRE(p && id128, "null argument");
+  RF_REQUIRE(!p->unpacked, "this call does not apply to an unpacked c2c plan");
   RF_REQUIRE(p->comm == nullptr, "communicator already initialised");
   if (int rc = load_rccl()) return rc;
   RF_HIP(hipSetDevice(p->device));
@@ -1016,6 +1114,7 @@ int rf_comm_init(rf_plan* p, const void* id128) {
 
 int rf_comm_allreduce_f64(rf_plan* p, double* inout, int n, int op) {
   RF_REQUIRE(p && inout, "null argument");
+  RF_REQUIRE(!p->unpacked, "this call does not apply to an unpacked c2c plan");
   RF_REQUIRE(n >= 1 && n <= 2, "n must be 1 or 2");
   RF_REQUIRE(op == 0 || op == 1, "op must be 0 (sum) or 1 (max)");
   RF_HIP(hipSetDevice(p->device));
@@ -1032,6 +1131,7 @@ int rf_comm_allreduce_f64(rf_plan* p, double* inout, int n, int op) {
 /* ---- slab pipeline in separate steps (tests / custom exchanges) ------------------------------- */
 int rf_slab_forward(rf_plan* p, uint64_t seed, int mode, const double* noise_host) {
   RF_REQUIRE(p, "null plan");
+  RF_REQUIRE(!p->unpacked, "this call does not apply to an unpacked c2c plan");
   RF_REQUIRE(p->nranks > 1, "rf_slab_* are for multi-rank plans");
   RF_REQUIRE(p->have_kgrid && p->have_power, "rf_set_kgrid and rf_set_power must be called first");
   RF_HIP(hipSetDevice(p->device));
@@ -1058,6 +1158,7 @@ int rf_slab_exchange_local(rf_plan** plans, int n) {
 
 int rf_slab_backward(rf_plan* p) {
   RF_REQUIRE(p, "null plan");
+  RF_REQUIRE(!p->unpacked, "this call does not apply to an unpacked c2c plan");
   RF_REQUIRE(p->nranks > 1, "rf_slab_* are for multi-rank plans");
   RF_HIP(hipSetDevice(p->device));
   if (int rc = queue_z_slab(p, p->R, p->W, p->stats, p->stream)) return rc;
@@ -1068,6 +1169,7 @@ int rf_slab_backward(rf_plan* p) {
 
 int rf_slab_stats(rf_plan* p, double* sum, double* sumsq) {
   RF_REQUIRE(p && sum && sumsq, "null argument");
+  RF_REQUIRE(!p->unpacked, "this call does not apply to an unpacked c2c plan");
   double st[2];
   RF_HIP(hipMemcpyAsync(st, p->stats, sizeof(st), hipMemcpyDeviceToHost, p->stream));
   RF_HIP(hipStreamSynchronize(p->stream));

@@ -709,4 +709,112 @@ struct RowR2C {
   }
 };
 
+// ---------------------------------------------------------------------------
+// Plain complex row pass (unpacked c2c plans, transform.py:207-213,266-270): FFT of length M = nz along
+// the contiguous axis, either direction.  tw = exp(+2 pi i q / M), q in [0, M) (conjugated for DIR = -1).
+// ---------------------------------------------------------------------------
+template <typename T> struct ScaledRowIO {
+  cplx<T>* base;
+  int M_of;                      // complex elements per row (nz)
+  T scale;                       // 1 (forward) or 1 / (nx ny nz) (inverse, numpy normalisation)
+  RF_HD cplx<T> load(long long row, int k) const { return base[row * (long long)M_of + k]; }
+  RF_HD void store(long long row, int k, cplx<T> z) const {
+    z.x *= scale; z.y *= scale;
+    base[row * (long long)M_of + k] = z;
+  }
+};
+
+template <class C, int DIR_, class IO>
+struct RowC2C {
+  using T = typename C::T;
+  using cx = cplx<T>;
+  static constexpr int M = C::M, NT = C::NT, DIR = DIR_;
+  static constexpr int ITF = ceil_div(C::NRT * (M / C::R1), NT);
+
+  struct Regs { cx v[C::IT2][cmax(C::R2, 1)]; };
+
+  RF_HD static cx* lds_at(cx* lds, int rl, int i) { return lds + (long long)rl * C::RS + pad16(i); }
+  RF_HD static cx* lds_tw(cx* lds) { return lds + C::TILE_BYTES / (int)sizeof(cx); }
+  RF_HD static void prologue(int tid, const cx* tw, cx* lds) {
+    cx* l = lds_tw(lds);
+    for (int i = tid; i < M; i += NT) l[i] = tw[i];
+  }
+
+  // pass 1: global -> R1 butterfly -> LDS (or straight back to global when M == R1)
+  RF_HD static void pass_first(int tid, long long tile, long long nrows, const IO& io, cx* lds) {
+    constexpr int R = C::R1, L = M / R;
+#pragma unroll
+    for (int it = 0; it < ITF; ++it) {
+      const int w = it * NT + tid;
+      const int rl = w / L, j = w % L;
+      const long long row = tile * C::NRT + rl;
+      if (rl < C::NRT && row < nrows) {
+        cx v[R];
+#pragma unroll
+        for (int m = 0; m < R; ++m) v[m] = io.load(row, j + m * L);
+        DFT<R, DIR>::run(v);
+#pragma unroll
+        for (int m = 0; m < R; ++m) {
+          if (C::NPASS == 1) io.store(row, j * R + m, v[m]);
+          else *lds_at(lds, rl, j * R + m) = v[m];
+        }
+      }
+    }
+  }
+
+  RF_HD static void pass_mid_read(int tid, const cx* tw, cx* lds, Regs& r) {
+    constexpr int R = C::R2, L = M / R, Ns = C::R1;
+#pragma unroll
+    for (int it = 0; it < C::IT2; ++it) {
+      const int w = it * NT + tid;
+      const int rl = w / L, j = w % L;
+      if (rl < C::NRT) {
+#pragma unroll
+        for (int m = 0; m < R; ++m) {
+          cx x = *lds_at(lds, rl, j + m * L);
+          if (m > 0) x = cmul(x, tw_dir<DIR>(tw[stockham_tw_index(j, m, Ns, R, M)]));
+          r.v[it][m] = x;
+        }
+        DFT<R, DIR>::run(r.v[it]);
+      }
+    }
+  }
+  RF_HD static void pass_mid_write(int tid, cx* lds, const Regs& r) {
+    constexpr int R = C::R2, L = M / R, Ns = C::R1;
+#pragma unroll
+    for (int it = 0; it < C::IT2; ++it) {
+      const int w = it * NT + tid;
+      const int rl = w / L, j = w % L;
+      if (rl < C::NRT) {
+        const int ob = stockham_out_base(j, Ns, R);
+#pragma unroll
+        for (int m = 0; m < R; ++m) *lds_at(lds, rl, ob + m * Ns) = r.v[it][m];
+      }
+    }
+  }
+
+  // last pass (NPASS >= 2): LDS -> RL butterfly -> global
+  RF_HD static void pass_last(int tid, long long tile, long long nrows, const IO& io, const cx* tw, cx* lds) {
+    constexpr int R = C::RL, L = M / R;
+#pragma unroll
+    for (int it = 0; it < C::ITL; ++it) {
+      const int w = it * NT + tid;
+      const int rl = w / L, j = w % L;
+      const long long row = tile * C::NRT + rl;
+      if (rl < C::NRT && row < nrows) {
+        cx v[R];
+#pragma unroll
+        for (int m = 0; m < R; ++m) {
+          cx x = *lds_at(lds, rl, j + m * L);
+          if (m > 0) x = cmul(x, tw_dir<DIR>(tw[m * j]));
+          v[m] = x;
+        }
+        DFT<R, DIR>::run(v);
+#pragma unroll
+        for (int m = 0; m < R; ++m) io.store(row, j + m * L, v[m]);
+      }
+    }
+  }
+};
+
 }  // namespace rf

@@ -126,4 +126,29 @@ __global__ __launch_bounds__(C::NT) void row_r2c_kernel(IO io, const cplx<typena
   F::pass_last(tid, tile, nrows, io, ltw, lds);
 }
 
+// unpacked c2c row pass (either direction), in place
+template <class C, int DIR, class IO>
+__global__ __launch_bounds__(C::NT) void row_c2c_kernel(IO io, const cplx<typename C::T>* __restrict__ tw, long long nrows) {
+  using F = RowC2C<C, DIR, IO>;
+  using cx = cplx<typename C::T>;
+  extern __shared__ __attribute__((aligned(16))) char rf_smem[];
+  cx* lds = reinterpret_cast<cx*>(rf_smem);
+  const int tid = threadIdx.x;
+  const long long tile = blockIdx.x;
+  F::prologue(tid, tw, lds);                 // twiddles -> LDS (first read after the next barrier)
+  const cx* ltw = F::lds_tw(lds);
+  F::pass_first(tid, tile, nrows, io, lds);
+  if (C::NPASS == 3) {
+    typename F::Regs r;
+    __syncthreads();
+    F::pass_mid_read(tid, ltw, lds, r);
+    __syncthreads();
+    F::pass_mid_write(tid, lds, r);
+  }
+  if (C::NPASS >= 2) {
+    __syncthreads();
+    F::pass_last(tid, tile, nrows, io, ltw, lds);
+  }
+}
+
 }  // namespace rf

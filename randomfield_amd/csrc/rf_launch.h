@@ -30,6 +30,10 @@ hipError_t launch_row_c2r_gather(int f64, int M, const void* src, void* dst, lon
 // forward z pass (r2c rows, in place: nz reals -> nz/2 complex with (X[0], X[nz/2]) packed in element 0)
 hipError_t launch_row_r2c(int f64, int M, void* W, long long nrows, const void* tw, hipStream_t s,
                           bool prepare_only = false);
+// contiguous-axis pass of an unpacked c2c plan: rows of M = nz complex, in place; dir = +1 inverse (scaled), -1 forward;
+// tw = exp(2 pi i q / M), q in [0, M)
+hipError_t launch_row_c2c(int f64, int M, int dir, void* W, long long nrows, double scale, const void* tw, hipStream_t s,
+                          bool prepare_only = false);
 // packed device array [nx][ny][nz/2] -> API layout [nx][ny][nz/2+1] (separates the kz = 0 and nz/2 planes)
 hipError_t launch_unpack_kspace(int f64, const void* W, void* K, int nx, int ny, int nz, hipStream_t s);
 long long row_c2r_tiles(int f64, int M, long long nrows);

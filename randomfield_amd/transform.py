@@ -33,6 +33,10 @@ __all__ = ["allocate", "expanded_shape", "scalar_type", "complex_type", "is_herm
            "resolve_backend"]
 
 
+def _is_pow2(n):
+    return n > 0 and (n & (n - 1)) == 0
+
+
 def resolve_backend(backend=None):
     """'hip' or 'numpy' from the keyword, then $RANDOMFIELD_BACKEND, then 'hip'."""
     if backend is None:
@@ -176,9 +180,9 @@ class Plan(object):
     transform on the GPU and downloads the result into ``data_out`` (the host
     copies are the price of the numpy-array API; device-resident use goes through
     :class:`randomfield_amd.generate.Generator` or :attr:`device`).  Packed inverse
-    (c2r) and forward (r2c) plans run on the GPU; a c2r transform assumes Hermitian
-    input in the kz = 0 and kz = nz/2 planes, as FFTW's multi-dimensional c2r does
-    (see DESIGN.md).
+    (c2r) and forward (r2c) plans and unpacked complex-to-complex plans (both directions)
+    run on the GPU; a c2r transform assumes Hermitian input in the kz = 0 and kz = nz/2
+    planes, as FFTW's multi-dimensional c2r does.
     """
 
     def __init__(self, shape, dtype_in=None, data_in=None, overwrite=True, inverse=True, packed=True,
@@ -254,18 +258,22 @@ class Plan(object):
         if self.backend == "hip":
             from . import _hip
             _hip.require_gpu()           # raises: library missing / no GPU
-            if not packed:
-                raise RuntimeError("hip backend: unpacked (c2c) transforms are not built; use backend='numpy'.")
-            cdtype = dtype_in if inverse else dtype_out
+            cdtype = dtype_in if (inverse or not packed) else dtype_out
             if np.dtype(cdtype) not in (np.dtype(np.complex64), np.dtype(np.complex128)):
                 raise RuntimeError("hip backend supports complex64 / complex128 only: {0}.".format(cdtype))
-            if not _hip.shape_supported(nx, ny, nz):
+            if packed:
+                if not _hip.shape_supported(nx, ny, nz):
+                    raise RuntimeError(
+                        "hip backend: shape {0} is not supported (power-of-two axes, nx, ny in 8..2048, nz in "
+                        "16..2048); use backend='numpy' explicitly for this shape.".format(tuple(shape)))
+            elif not (_is_pow2(nx) and _is_pow2(ny) and _is_pow2(nz) and 8 <= nx <= 2048 and 8 <= ny <= 2048
+                      and 8 <= nz <= 1024):
                 raise RuntimeError(
-                    "hip backend: shape {0} is not supported (power-of-two axes, nx, ny in 8..2048, nz in "
-                    "16..2048); use backend='numpy' explicitly for this shape.".format(tuple(shape)))
+                    "hip backend: unpacked shape {0} is not supported (power-of-two axes, nx, ny in 8..2048, nz in "
+                    "8..1024); use backend='numpy' explicitly for this shape.".format(tuple(shape)))
             # a reverse plan that shares our memory also shares our device plan (one device buffer, as the
             # reference's pair of plans shares one host buffer)
-            self.device = _device if _device is not None else _hip.DevicePlan(nx, ny, nz, cdtype)
+            self.device = _device if _device is not None else _hip.DevicePlan(nx, ny, nz, cdtype, unpacked=not packed)
         else:
             if inverse:
                 self.transformer = np.fft.irfftn if packed else np.fft.ifftn
@@ -300,6 +308,14 @@ class Plan(object):
         """Run the transform; returns ``data_out`` (transform.py:303-315)."""
         if self.backend == "hip":
             dev = self.device
+            if not self.packed:                     # complex-to-complex over the full array
+                dev.upload_c(self.data_in)
+                dev.execute_c2c(self.inverse)
+                if self.data_out.flags.c_contiguous:
+                    dev.download_c(self.data_out)
+                else:
+                    self.data_out[:] = dev.download_c()
+                return self.data_out
             if self.inverse:
                 dev.upload_k(np.ascontiguousarray(self.data_in))
                 dev.execute_c2r()

@@ -103,6 +103,16 @@ def realise_fast(nx, ny, nz, spacing, log10k, sigma, seed, dtype=np.float32):
     return out, s1.value, s2.value
 
 
+def c2c(data, inverse):
+    """Unpacked complex-to-complex transform through the emulated kernels (returns a new array)."""
+    out = np.ascontiguousarray(data).copy()
+    nx, ny, nz = out.shape
+    rc = lib().emu_c2c(int(out.dtype == np.complex128), nx, ny, nz, 1 if inverse else -1,
+                       out.ctypes.data_as(ctypes.c_void_p))
+    assert rc == 0, rc
+    return out
+
+
 def r2c(field):
     nx, ny, nz = field.shape
     ct = np.complex64 if field.dtype == np.float32 else np.complex128

@@ -164,3 +164,20 @@ def test_row_r2c_all_sizes(M, dtype):
     # round trip through the emulated c2r
     back, s1, s2 = emu_util.c2r(spec)
     assert np.max(np.abs(back - f)) <= (5e-6 if dtype == np.float32 else 1e-12)
+
+
+@pytest.mark.parametrize("shape", [(8, 8, 8), (16, 8, 32), (8, 64, 16), (32, 16, 128), (16, 16, 1024), (128, 8, 8)])
+def test_unpacked_c2c_against_numpy(shape):
+    """Plan(packed=False) (transform.py:207-213,266-270): forward = np.fft.fftn, inverse = np.fft.ifftn,
+    through the strided x / y passes and the plain row pass (RowC2C) of the device code."""
+    rng = np.random.RandomState(11)
+    for ct, tol in ((np.complex64, 2e-6), (np.complex128, 1e-14)):
+        a = (rng.normal(size=shape) + 1j * rng.normal(size=shape)).astype(ct)
+        fwd = emu_util.c2c(a, inverse=False)
+        ref = np.fft.fftn(a.astype(np.complex128))
+        assert np.max(np.abs(fwd - ref)) <= tol * np.sqrt(a.size) * 4
+        inv = emu_util.c2c(a, inverse=True)
+        ref = np.fft.ifftn(a.astype(np.complex128))
+        assert np.max(np.abs(inv - ref)) <= 4 * tol
+        back = emu_util.c2c(fwd, inverse=True)
+        assert np.max(np.abs(back - a)) <= 20 * tol

@@ -556,3 +556,34 @@ def test_mt19937_replay_matches_numpy(hip, dpower, shape, seed):
     dref, rms = cpu_ref.generate_delta_field(nx, ny, nz, SPACING, k, Pk, seed=seed)
     assert np.max(np.abs(d - dref)) <= TOL_F32 * rms
     plan.close()
+
+
+@pytest.mark.parametrize("shape", [(8, 8, 8), (16, 64, 32), (64, 64, 64), (256, 16, 1024), (32, 128, 256)])
+def test_unpacked_c2c_plan_against_numpy(hip, shape):
+    """transform.Plan(packed=False) on the GPU (transform.py:207-213,266-270; the reference's
+    tests/test_transform.py round trips): forward = np.fft.fftn, inverse = np.fft.ifftn, in place,
+    and a reverse plan that shares the buffer undoes the transform."""
+    from randomfield_amd import transform
+    rng = np.random.RandomState(3)
+    for ct, tol in ((np.complex64, 2e-6), (np.complex128, 1e-14)):
+        a = (rng.normal(size=shape) + 1j * rng.normal(size=shape)).astype(ct)
+        plan = transform.Plan(shape, dtype_in=ct, inverse=False, packed=False, backend="hip")
+        assert plan.device is not None and plan.data_out is plan.data_in
+        plan.data_in[:] = a
+        out = plan.execute()
+        assert out is plan.data_out and out.dtype == ct and out.shape == shape
+        ref = np.fft.fftn(a.astype(np.complex128))
+        assert np.max(np.abs(out - ref)) <= tol * np.sqrt(a.size) * 4
+        back = plan.create_reverse_plan()                  # shares the host buffer and the device plan
+        assert back.device is plan.device and back.data_in is plan.data_out
+        res = back.execute()
+        assert np.max(np.abs(res - a)) <= 20 * tol
+        inv = transform.Plan(shape, dtype_in=ct, inverse=True, packed=False, backend="hip")
+        inv.data_in[:] = a
+        assert np.max(np.abs(inv.execute() - np.fft.ifftn(a.astype(np.complex128)))) <= 4 * tol
+        plan.device.close()
+        inv.device.close()
+    with pytest.raises(RuntimeError):
+        transform.Plan((6, 8, 8), dtype_in=np.complex64, packed=False, backend="hip")       # not a power of two
+    with pytest.raises(RuntimeError):
+        transform.Plan((8, 8, 2048), dtype_in=np.complex64, packed=False, backend="hip")    # nz beyond the row kernels
