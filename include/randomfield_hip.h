@@ -139,6 +139,13 @@ int rf_download_real(rf_plan* plan, void* host, int layout, int x0, int x1);
 /* raw device pointers (real field / k buffer) for zero-copy consumers */
 int rf_device_ptr(rf_plan* plan, void** real_field, void** kspace);
 
+/* ---- lensing potential (generate.py:352-416): psi[x][y][e] = Simpson integral over iz in [i_min, e] of
+ * -2 (cot_z[iz] - cot_z[e]) * field[x][y][iz] with step `spacing` (scipy.integrate.simps(even='avg') semantics),
+ * 0 for e < i_min.  Reads the real field on the device, writes an auxiliary real field (the k buffer's memory:
+ * any k-space data there is lost); cot_z = cotK(D) of generate.py:383-395, nz doubles. */
+int rf_lensing_potential(rf_plan* plan, const double* cot_z, int nz, double spacing, int i_min);
+int rf_download_aux(rf_plan* plan, void* host, int x0, int x1);   /* planes [x0, x1) of the auxiliary field, dense */
+
 /* ---- stream control and timing ------------------------------------------ */
 int rf_sync(rf_plan* plan);
 /* GPU time (hipEvents on the plan's stream) of the last rf_realise / rf_realise_batch /

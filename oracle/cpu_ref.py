@@ -44,7 +44,7 @@ __all__ = [
     "randomize", "symmetrize_packed", "is_hermitian_packed", "c2r", "r2c",
     "generate_kspace", "generate_delta_field", "lognormal", "scale_z",
     "potential_kspace", "philox4x32_10", "philox_normals", "native_noise_index",
-    "native_noise", "default_like_power",
+    "native_noise", "default_like_power", "simps_avg", "cot_k", "lensing_potential",
 ]
 
 
@@ -369,6 +369,72 @@ def potential_kspace(data, spacing):
     pot[0, 0, 0] = 0                                                 # :213
     pot *= data                                                      # :215
     return pot
+
+
+# --------------------------------------------------------------------------
+# lensing potential: generate.py:352-416
+# --------------------------------------------------------------------------
+
+def _basic_simps(y, start, stop, x):
+    """Composite Simpson sum over the interval pairs [start, stop] of the last axis for samples at
+    (possibly non-uniform) x -- the `_basic_simps` helper of scipy.integrate (scipy <= 1.10; the reference
+    calls `scipy.integrate.simps`, removed from current scipy, whose published algorithm is restated here)."""
+    h = np.diff(x)
+    s0, s1, s2 = slice(start, stop, 2), slice(start + 1, stop + 1, 2), slice(start + 2, stop + 2, 2)
+    h0, h1 = h[s0], h[s1]
+    hsum, hprod, h0divh1 = h0 + h1, h0 * h1, h0 / h1
+    tmp = hsum / 6.0 * (y[..., s0] * (2 - 1.0 / h0divh1) + y[..., s1] * hsum * hsum / hprod + y[..., s2] * (2 - h0divh1))
+    return np.sum(tmp, axis=-1)
+
+
+def simps_avg(y, x):
+    """scipy.integrate.simps(y, x, axis=-1, even='avg') as shipped when the reference was written: for an odd
+    number of samples the composite Simpson rule; for an even number the average of (Simpson on the first N-1
+    samples + trapezoid on the last interval) and (trapezoid on the first interval + Simpson on the last N-1)."""
+    y = np.asarray(y)
+    x = np.asarray(x, np.float64)
+    N = y.shape[-1]
+    if N % 2 == 0:
+        val = 0.5 * (x[-1] - x[-2]) * (y[..., -1] + y[..., -2])
+        result = _basic_simps(y, 0, N - 3, x)
+        val = val + 0.5 * (x[1] - x[0]) * (y[..., 1] + y[..., 0])
+        result = result + _basic_simps(y, 1, N - 2, x)
+        return result / 2.0 + val / 2.0
+    return _basic_simps(y, 0, N - 2, x)
+
+
+def cot_k(DC, DA, K=0.0):
+    """cotK(D) along the line of sight -- generate.py:383-395 (K in (Mpc/h)**-2; K = 0: flat)."""
+    DC = np.asarray(DC, np.float64)
+    DA = np.asarray(DA, np.float64)
+    if K < 0:
+        cosK = np.cosh(np.sqrt(-K) * DC)
+    elif K > 0:
+        cosK = np.cos(np.sqrt(K) * DC)
+    else:
+        cosK = np.ones_like(DA, dtype=float)
+    cotK = np.ones_like(cosK)
+    cotK[1:] = cosK[1:] / DA[1:]
+    return cotK
+
+
+def lensing_potential(dPhi, DC, DA, K=0.0, i_min=None):
+    """psi(r) = integral of -2 [cotK(D) - cotK(D_src)] dPhi along z with the reference's slice loop and
+    Simpson rule -- generate.py:397-411.  dPhi: real (nx, ny, nz) array; returns a new array of its dtype."""
+    nDC = len(DC)
+    if i_min is None:
+        i_min = nDC // 32
+    if i_min < 0 or i_min >= nDC:
+        raise ValueError("Invalid i_min {}. Expected 0 - {}.".format(i_min, nDC - 1))
+    cotK = cot_k(DC, DA, K)
+    psi = np.empty_like(dPhi)
+    for i in range(nDC, i_min, -1):
+        psi[:, :, i_min:i] = dPhi[:, :, i_min:i]
+        psi[:, :, i_min:i] *= -2 * (cotK[i_min:i] - cotK[i - 1])
+        psi[:, :, i - 1] = simps_avg(psi[:, :, i_min:i], np.asarray(DC, np.float64)[i_min:i])
+    if i_min > 0:
+        psi[:, :, :i_min] = 0.0
+    return psi
 
 
 # --------------------------------------------------------------------------

@@ -58,6 +58,8 @@ SIGNATURES = {
     "rf_affine_z": (ctypes.c_int, [ctypes.c_void_p, _c_dp, ctypes.c_int, ctypes.c_double]),
     "rf_save_potential": (ctypes.c_int, [ctypes.c_void_p]),
     "rf_load_potential": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_double]),
+    "rf_lensing_potential": (ctypes.c_int, [ctypes.c_void_p, _c_dp, ctypes.c_int, ctypes.c_double, ctypes.c_int]),
+    "rf_download_aux": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
     "rf_upload_k": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "rf_download_k": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "rf_upload_real": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
@@ -251,6 +253,20 @@ class DevicePlan(object):
         check(self._lib.rf_noise_mt19937(self._h, state.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)),
                                          ctypes.byref(acc)), "rf_noise_mt19937")
         return acc.value
+
+    def lensing_potential(self, cot_z, spacing, i_min):
+        """psi of the real field on the device into the auxiliary buffer (generate.py:352-416)."""
+        cot_z = _f64(cot_z)
+        check(self._lib.rf_lensing_potential(self._h, _dp(cot_z), len(cot_z), float(spacing), int(i_min)),
+              "rf_lensing_potential")
+
+    def download_aux(self, x0=0, x1=None, out=None):
+        x1 = self.nx if x1 is None else x1
+        if out is None:
+            out = np.empty((x1 - x0, self.ny, self.nz), self.real_dtype)
+        check(self._lib.rf_download_aux(self._h, out.ctypes.data_as(ctypes.c_void_p), int(x0), int(x1)),
+              "rf_download_aux")
+        return out
 
     def download_noise(self, first=0, count=None):
         total = 2 * self.nx * self.ny * (self.nz // 2 + 1)

@@ -69,3 +69,26 @@ def apply_lognormal_transform(delta, growth, sigma=None):
     delta = np.exp(delta, out=delta)
     delta /= np.sqrt(t)
     return delta
+
+
+def simps_avg(y, h):
+    """Composite Simpson rule along the last axis for uniformly spaced samples (step ``h``) with the
+    even-count handling of ``scipy.integrate.simps(even='avg')`` -- the routine the reference calls in
+    ``calculate_lensing_potential`` (generate.py:405-406), which current scipy no longer ships: for an even
+    number of samples, the average of (Simpson on the first N-1 + trapezoid on the last interval) and
+    (trapezoid on the first interval + Simpson on the last N-1)."""
+    y = np.asarray(y, np.float64)
+    N = y.shape[-1]
+
+    def basic(a):            # odd number of samples
+        if a.shape[-1] < 3:
+            return np.zeros(a.shape[:-1])
+        return (h / 3.0) * (a[..., 0] + a[..., -1] + 4.0 * a[..., 1:-1:2].sum(-1) + 2.0 * a[..., 2:-1:2].sum(-1))
+
+    if N % 2:
+        return basic(y)
+    if N < 2:
+        return np.zeros(y.shape[:-1])
+    first = basic(y[..., :-1]) + 0.5 * h * (y[..., -2] + y[..., -1])
+    last = 0.5 * h * (y[..., 0] + y[..., 1]) + basic(y[..., 1:])
+    return 0.5 * (first + last)

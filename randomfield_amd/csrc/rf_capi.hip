@@ -140,6 +140,7 @@ struct rf_plan {
   double* ztab = nullptr;                 // 2 * nz doubles for lognormal / affine tables
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // start, after x, y, z, reduce; [5] = after the kz = 0 repair launch
   bool repair_timed = false;
+  bool aux_valid = false;              // the k buffer's memory currently holds an auxiliary REAL field (lensing potential)
   bool unpacked = false;               // c2c plan: W is the full [nx][ny][nz] complex array, only rf_*_c / rf_execute_c2c apply
   bool timed = false;
   struct BatchGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };
@@ -678,6 +679,7 @@ int rf_generate(rf_plan* p, uint64_t seed, int mode, const double* noise_host) {
   RF_HIP(launch_gen_kspace(p->f64, p->K, make_gen(p, seed, mode, false), p->stream));
   if (mode == RF_NOISE_EXTERNAL) RF_HIP(hipStreamSynchronize(p->stream));  // host noise buffer may be released by the caller
   p->k_valid = true;
+  p->aux_valid = false;
   return 0;
 }
 
@@ -713,6 +715,7 @@ int rf_execute_r2c(rf_plan* p) {
   p->real_valid = false;      // the field buffer now holds packed k space
   p->stats_valid = false;
   p->k_valid = true;
+  p->aux_valid = false;
   return 0;
 }
 
@@ -876,6 +879,39 @@ int rf_affine_z(rf_plan* p, const double* mul_z, int nz, double add) {
 
 int rf_scale_z(rf_plan* p, const double* factor_z, int nz) { return rf_affine_z(p, factor_z, nz, 0.0); }
 
+// Lensing potential psi of the real field on the device (the Newtonian potential on the light cone) into the
+// auxiliary buffer: generate.py:352-416 with cot_z = cotK(D) (generate.py:383-395) and D = spacing * iz.
+int rf_lensing_potential(rf_plan* p, const double* cot_z, int nz, double spacing, int i_min) {
+  RF_REQUIRE(p && cot_z, "null argument");
+  RF_REQUIRE(!p->unpacked, "this call does not apply to an unpacked c2c plan");
+  RF_REQUIRE(p->nranks == 1, "rf_lensing_potential is single-GPU only");
+  RF_REQUIRE(nz == p->nz, "table length must equal nz");
+  RF_REQUIRE(i_min >= 0 && i_min < nz, "invalid i_min");
+  RF_REQUIRE(spacing > 0, "spacing must be positive");
+  RF_REQUIRE(p->real_valid, "no real-space field on the device");
+  RF_HIP(hipSetDevice(p->device));
+  if (int rc = ensure_k(p)) return rc;            // (nx ny (nz/2+1)) complex >= (nx ny nz) real
+  RF_HIP(hipMemcpyAsync(p->ztab, cot_z, nz * sizeof(double), hipMemcpyHostToDevice, p->stream));
+  RF_HIP(launch_lensing(p->f64, p->cur, p->K, (long long)p->nx * p->ny, nz, p->ztab, spacing, i_min, p->stream));
+  RF_HIP(hipStreamSynchronize(p->stream));
+  p->k_valid = false;
+  p->aux_valid = true;
+  return 0;
+}
+
+// planes [x0, x1) of the auxiliary real field (dense [nx][ny][nz])
+int rf_download_aux(rf_plan* p, void* host, int x0, int x1) {
+  RF_REQUIRE(p && host, "null argument");
+  RF_REQUIRE(!p->unpacked, "this call does not apply to an unpacked c2c plan");
+  RF_REQUIRE(p->K && p->aux_valid, "no auxiliary field on the device");
+  RF_REQUIRE(0 <= x0 && x0 < x1 && x1 <= p->nx, "invalid x range");
+  RF_HIP(hipSetDevice(p->device));
+  const size_t plane = (size_t)p->ny * p->nz * (p->csize / 2);
+  RF_HIP(hipMemcpyAsync(host, (const char*)p->K + (size_t)x0 * plane, (size_t)(x1 - x0) * plane, hipMemcpyDeviceToHost, p->stream));
+  RF_HIP(hipStreamSynchronize(p->stream));
+  return 0;
+}
+
 int rf_save_potential(rf_plan* p) {
   RF_REQUIRE(p, "null plan");
   RF_REQUIRE(!p->unpacked, "this call does not apply to an unpacked c2c plan");
@@ -897,6 +933,7 @@ int rf_load_potential(rf_plan* p, double scale) {
   if (int rc = ensure_k(p)) return rc;
   RF_HIP(launch_scale_copy(p->f64, p->P, p->K, (long long)p->nx * p->ny * (p->nzc + 1), scale, p->stream));
   p->k_valid = true;
+  p->aux_valid = false;
   return 0;
 }
 
@@ -909,6 +946,7 @@ int rf_upload_k(rf_plan* p, const void* host) {
   RF_HIP(hipMemcpyAsync(p->K, host, p->k_bytes, hipMemcpyHostToDevice, p->stream));
   RF_HIP(hipStreamSynchronize(p->stream));
   p->k_valid = true;
+  p->aux_valid = false;
   return 0;
 }
 

@@ -136,6 +136,70 @@ inline unsigned grid_for(long long n, int block) {
   if (g < 1) g = 1;
   return (unsigned)g;
 }
+
+// ---- lensing potential (generate.py:352-416): psi[e] = Simpson integral over j in [i_min, e] of
+// -2 (cot[j] - cot[e]) phi[j] dD along z.  The reference recomputes the integral for every endpoint e (O(nz^2)
+// per column); with a uniform step h the composite rule of scipy.integrate.simps(even='avg') is a closed form in
+// the prefix sums of the samples at even and odd positions, for the two sequences a_j = cot[j] phi[j] and
+// b_j = phi[j]:  psi[e] = -2 (S_a(e) - cot[e] S_b(e)).  One wave per (x, y) row: every lane owns nz/64
+// consecutive samples, the four prefix sums cross the lanes with a wave scan, accumulation in float64.
+__device__ __forceinline__ double lens_simps(double E, double O, double y0, double y1, double yp, double ym, int m, double h) {
+  // E, O: inclusive sums over even / odd positions <= m; y0, y1, yp = y[m-1], ym = y[m]
+  if (m == 0) return 0.0;
+  if ((m & 1) == 0) return (h / 3.0) * (4.0 * O + 2.0 * E - y0 - ym);
+  const double A = (m >= 3 ? (h / 3.0) * (4.0 * (O - ym) + 2.0 * E - y0 - yp) : 0.0) + 0.5 * h * (yp + ym);
+  const double B = 0.5 * h * (y0 + y1) + (m >= 3 ? (h / 3.0) * (4.0 * (E - y0) + 2.0 * O - y1 - ym) : 0.0);
+  return 0.5 * (A + B);
+}
+
+__device__ __forceinline__ double wave_excl_scan(double v, int lane) {
+  double inc = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const double t = __shfl_up(inc, off);
+    if (lane >= off) inc += t;
+  }
+  return inc - v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void lensing_kernel(const T* __restrict__ phi, T* __restrict__ psi, long long nrows, int nz,
+                                                      const double* __restrict__ cot, double h, int i_min) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= nrows) return;                         // the whole wave leaves together
+  const T* in = phi + row * (long long)nz;
+  T* out = psi + row * (long long)nz;
+  const int epl = nz >= 64 ? nz / 64 : 1;           // samples per lane (nz is a power of two)
+  const int j0 = lane * epl;
+  double Ea = 0, Oa = 0, Eb = 0, Ob = 0;
+  for (int e = 0; e < epl; ++e) {
+    const int j = j0 + e;
+    if (j < nz && j >= i_min) {
+      const double v = (double)in[j], a = cot[j] * v;
+      if ((j - i_min) & 1) { Oa += a; Ob += v; } else { Ea += a; Eb += v; }
+    }
+  }
+  Ea = wave_excl_scan(Ea, lane); Oa = wave_excl_scan(Oa, lane);
+  Eb = wave_excl_scan(Eb, lane); Ob = wave_excl_scan(Ob, lane);
+  const double b0 = (double)in[i_min], a0 = cot[i_min] * b0;
+  const double b1 = i_min + 1 < nz ? (double)in[i_min + 1] : 0.0, a1 = i_min + 1 < nz ? cot[i_min + 1] * b1 : 0.0;
+  double bp = 0.0, ap = 0.0;                        // the sample before this lane's first one
+  if (j0 - 1 >= i_min && j0 - 1 < nz) { bp = (double)in[j0 - 1]; ap = cot[j0 - 1] * bp; }
+  for (int e = 0; e < epl; ++e) {
+    const int j = j0 + e;
+    if (j >= nz) break;
+    if (j < i_min) { out[j] = (T)0; continue; }
+    const int m = j - i_min;
+    const double c = cot[j], v = (double)in[j], a = c * v;
+    if (m & 1) { Oa += a; Ob += v; } else { Ea += a; Eb += v; }
+    const double Sa = lens_simps(Ea, Oa, a0, a1, ap, a, m, h);
+    const double Sb = lens_simps(Eb, Ob, b0, b1, bp, v, m, h);
+    out[j] = (T)(-2.0 * (Sa - c * Sb));
+    ap = a; bp = v;
+  }
+}
+
 }  // namespace
 
 hipError_t launch_gen_kspace(int f64, void* K, const GenParams& gp, hipStream_t s) {
@@ -188,6 +252,14 @@ hipError_t launch_affine_z(int f64, void* W, long long nrows, int nz, const doub
     const long long nvec = total / 4;
     hipLaunchKernelGGL((affine_vec_kernel<float, 4>), dim3(grid_for(nvec, 256)), dim3(256), 0, s, (float*)W, nvec, nz, mul_z, add, has_add);
   }
+  return hipGetLastError();
+}
+
+hipError_t launch_lensing(int f64, const void* phi, void* psi, long long nrows, int nz, const double* cot_z, double h, int i_min,
+                          hipStream_t s) {
+  const unsigned grid = (unsigned)((nrows + 3) / 4);
+  if (f64) hipLaunchKernelGGL(lensing_kernel<double>, dim3(grid), dim3(256), 0, s, (const double*)phi, (double*)psi, nrows, nz, cot_z, h, i_min);
+  else hipLaunchKernelGGL(lensing_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)phi, (float*)psi, nrows, nz, cot_z, h, i_min);
   return hipGetLastError();
 }
 

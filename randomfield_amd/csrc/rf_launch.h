@@ -46,6 +46,9 @@ hipError_t launch_lognormal(int f64, void* W, long long nrows, int nz, const dou
                             double sigma, hipStream_t s);
 hipError_t launch_affine_z(int f64, void* W, long long nrows, int nz, const double* mul_z, double add,
                            hipStream_t s);
+// psi[x][y][e] = -2 * Simpson_{j in [i_min, e]} (cot_z[j] - cot_z[e]) phi[x][y][j] h  (generate.py:397-411), dense real arrays
+hipError_t launch_lensing(int f64, const void* phi, void* psi, long long nrows, int nz, const double* cot_z, double h, int i_min,
+                          hipStream_t s);
 // P = K / k^2 (0 at DC), API layout; and K = scale * P
 hipError_t launch_save_potential(int f64, const void* K, void* P, int nx, int ny, int nz, const double* kx2,
                                  const double* ky2, const double* kz2, hipStream_t s);

@@ -79,11 +79,16 @@ class Generator(object):
         no host work, different (statistically equivalent) realisations.
     growth_function, mean_matter_density, redshifts : (nz,) arrays, optional
         The cosmology tables, for use without astropy.
+    transverse_distance : (nz,) array, optional
+        Comoving transverse distance DA along z in Mpc/h (``self.DA`` of the reference,
+        generate.py:117-118), for :meth:`calculate_lensing_potential`.
+    curvature_K : float, optional
+        Curvature constant K in (Mpc/h)**-2 (generate.py:380-381: -Ok0 (H0/c)**2); 0 = flat.
     """
 
     def __init__(self, nx, ny, nz, grid_spacing_Mpc_h, num_plot_sections=4, cosmology=None, power=None,
                  verbose=False, *, backend=None, dtype=np.complex64, rng="reference", growth_function=None,
-                 mean_matter_density=None, redshifts=None):
+                 mean_matter_density=None, redshifts=None, transverse_distance=None, curvature_K=0.0):
         self.backend = transform.resolve_backend(backend)
         if rng not in ("reference", "native"):
             raise ValueError("Invalid rng: {0} (expected 'reference' or 'native').".format(rng))
@@ -117,6 +122,8 @@ class Generator(object):
         self.mean_matter_density = (None if mean_matter_density is None
                                     else np.asarray(mean_matter_density, float).reshape(nz))
         self.DC = np.arange(nz) * self.grid_spacing_Mpc_h
+        self.DA = None if transverse_distance is None else np.asarray(transverse_distance, float).reshape(nz)
+        self.curvature_K = float(curvature_K)
 
         self.delta_field_rms = None
         self.smoothed_power = None
@@ -229,8 +236,9 @@ class Generator(object):
     def _need_table(self, name):
         value = getattr(self, name)
         if value is None:
-            raise RuntimeError("Generator.{0} is not available: pass {0}= (an (nz,) array) to the constructor "
-                               "(astropy-based tables are outside the accelerated path).".format(name))
+            arg = {"DA": "transverse_distance"}.get(name, name)
+            raise RuntimeError("Generator.{0} is not available: pass {1}= (an (nz,) array) to the constructor "
+                               "(astropy-based tables are outside the accelerated path).".format(name, arg))
         return value
 
     def convert_delta_to_density(self, apply_lognormal_transform=True, show_plot=False, save_plot_name=None, *,
@@ -306,8 +314,50 @@ class Generator(object):
         self._field_on_host = False
         return self.download_field() if download else None
 
-    def calculate_lensing_potential(self, *args, **kwargs):
-        raise NotImplementedError("calculate_lensing_potential is outside the accelerated path (see DESIGN.md).")
+    def calculate_lensing_potential(self, i_min=None, show_plot=False, save_plot_name=None):
+        """
+        Calculate the lensing potential psi(r) (generate.py:352-416):
+
+            psi(r, z) = integral from D_min to D_src of -2 [cotK(D) - cotK(D_src)] dPhi(r, z) dD
+
+        with the reference's Simpson rule along z, D_min = ``DC[i_min]`` (default nz // 32).
+        Call :meth:`calculate_newtonian_potential` (``light_cone=True``) just before.  Needs the
+        ``transverse_distance=`` table (and ``curvature_K=`` for a curved cosmology).
+
+        Returns a new array; the plan's buffer (the Newtonian potential) is not modified.  On the
+        hip backend the O(nz**2)-per-column loop of the reference runs as one prefix scan per row.
+        """
+        if show_plot or save_plot_name is not None:
+            raise NotImplementedError("plot_slice is outside the accelerated path (see DESIGN.md).")
+        nDC = self.DC.size
+        if i_min is None:
+            i_min = nDC // 32
+        if i_min < 0 or i_min >= nDC:
+            raise ValueError("Invalid i_min {}. Expected 0 - {}.".format(i_min, nDC - 1))
+        DA = self._need_table("DA")
+        K = self.curvature_K
+        if K < 0:
+            cosK = np.cosh(np.sqrt(-K) * self.DC)
+        elif K > 0:
+            cosK = np.cos(np.sqrt(K) * self.DC)
+        else:
+            cosK = np.ones_like(DA, dtype=float)
+        cotK = np.ones_like(cosK)
+        cotK[1:] = cosK[1:] / DA[1:]
+        if self.backend == "numpy":
+            dPhi = self.plan_c2r.data_out
+            psi = np.empty_like(dPhi)
+            h = float(self.grid_spacing_Mpc_h)
+            for i in range(nDC, i_min, -1):
+                psi[:, :, i_min:i] = dPhi[:, :, i_min:i]
+                psi[:, :, i_min:i] *= -2 * (cotK[i_min:i] - cotK[i - 1])
+                psi[:, :, i - 1] = cosmotools.simps_avg(psi[:, :, i_min:i], h)
+            if i_min > 0:
+                psi[:, :, :i_min] = 0.
+            return psi
+        dev = self.plan_c2r.device
+        dev.lensing_potential(cotK, self.grid_spacing_Mpc_h, i_min)
+        return dev.download_aux()
 
     def plot_slice(self, *args, **kwargs):
         raise NotImplementedError("plot_slice is outside the accelerated path (see DESIGN.md).")

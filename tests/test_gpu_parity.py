@@ -587,3 +587,47 @@ def test_unpacked_c2c_plan_against_numpy(hip, shape):
         transform.Plan((6, 8, 8), dtype_in=np.complex64, packed=False, backend="hip")       # not a power of two
     with pytest.raises(RuntimeError):
         transform.Plan((8, 8, 2048), dtype_in=np.complex64, packed=False, backend="hip")    # nz beyond the row kernels
+
+
+@pytest.mark.parametrize("shape", [(8, 8, 16), (16, 8, 64), (8, 16, 256), (4 * 2, 8, 2048)])
+def test_lensing_potential_kernel_against_oracle(hip, shape):
+    """rf_lensing_potential (generate.py:352-416 as one prefix scan per row) against the oracle's restatement of
+    the reference's slice loop + scipy.integrate.simps(even='avg'), float32 and float64, flat and curved."""
+    nx, ny, nz = shape
+    rng = np.random.RandomState(5)
+    spacing = 2.5
+    DC = np.arange(nz) * spacing
+    DA = DC * (1 + 0.02 * np.arange(nz) / nz)
+    for dtype, ct, tol in ((np.float32, np.complex64, 2e-6), (np.float64, np.complex128, 1e-12)):
+        phi = rng.normal(size=shape).astype(dtype)
+        plan = hip.DevicePlan(nx, ny, nz, ct)
+        plan.upload_real(phi)
+        for K, i_min in ((0.0, nz // 32), (0.0, 0), (-3e-8, 3), (2e-8, nz - 2)):
+            cot = cpu_ref.cot_k(DC, DA, K)
+            plan.lensing_potential(cot, spacing, i_min)
+            psi = plan.download_aux()
+            ref = cpu_ref.lensing_potential(phi, DC, DA, K=K, i_min=i_min)
+            assert psi.dtype == dtype and psi.shape == shape
+            assert np.max(np.abs(psi - ref)) <= tol * np.max(np.abs(ref)) + 1e-300
+            assert np.array_equal(plan.download_real(), phi)               # the input field is untouched
+        plan.close()
+
+
+def test_generator_lensing_potential(hip):
+    """The drop-in sequence generate_delta_field(save_potential=True) -> calculate_newtonian_potential ->
+    calculate_lensing_potential on the GPU against the oracle applied to the downloaded Newtonian potential."""
+    from randomfield_amd import Generator
+    nx, ny, nz, spacing = 32, 16, 128, 2.5
+    z = np.linspace(0, 0.1, nz)
+    DA = np.arange(nz) * spacing * (1 - 0.05 * np.arange(nz) / nz)
+    gen = Generator(nx, ny, nz, spacing, backend="hip", growth_function=np.exp(-z), redshifts=z,
+                    transverse_distance=DA, curvature_K=-1e-8)
+    gen.generate_delta_field(seed=4, save_potential=True)
+    phi = gen.calculate_newtonian_potential(scale=-2.5e-5).copy()
+    psi = gen.calculate_lensing_potential()
+    ref = cpu_ref.lensing_potential(phi, gen.DC, DA, K=-1e-8)
+    assert psi.shape == phi.shape and psi.dtype == np.float32
+    assert np.max(np.abs(psi - ref)) <= 2e-6 * np.max(np.abs(ref))
+    with pytest.raises(ValueError):
+        gen.calculate_lensing_potential(i_min=-1)
+    gen.plan_c2r.device.close()

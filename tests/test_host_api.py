@@ -7,6 +7,8 @@ from itertools import product
 import numpy as np
 import pytest
 
+from oracle import cpu_ref
+
 from conftest import golden
 from randomfield_amd import cosmotools, powertools, transform
 from randomfield_amd import random as rf_random
@@ -297,6 +299,29 @@ def test_generator_potential_and_errors():
     assert np.all(rho > 0) and rho.base is not None
     phi = gen3.calculate_newtonian_potential(scale=-1.0)
     assert phi.shape == (16, 16, 16) and np.isfinite(phi).all()
+
+
+def test_lensing_potential_numpy_backend_matches_oracle():
+    """calculate_lensing_potential (generate.py:352-416) on the numpy backend against the oracle's restatement
+    of the reference loop + scipy's simps(even='avg'), flat and curved, several i_min; and its error paths."""
+    nx, ny, nz, spacing = 8, 8, 64, 2.5
+    z = np.linspace(0, 0.05, nz)
+    DA = np.arange(nz) * spacing * (1 + 0.01 * np.arange(nz) / nz)
+    for K in (0.0, -2e-8, 3e-8):
+        gen = Generator(nx, ny, nz, spacing, backend="numpy", growth_function=np.exp(-z), redshifts=z,
+                        transverse_distance=DA, curvature_K=K)
+        gen.generate_delta_field(seed=11, save_potential=True)
+        phi = gen.calculate_newtonian_potential(scale=-2.5e-5).copy()
+        for i_min in (None, 0, 1, 5, nz - 1):
+            psi = gen.calculate_lensing_potential(i_min=i_min)
+            ref = cpu_ref.lensing_potential(phi, gen.DC, DA, K=K, i_min=i_min)
+            assert psi.shape == phi.shape and psi.dtype == phi.dtype and psi is not gen.plan_c2r.data_out
+            assert np.max(np.abs(psi - ref)) <= 1e-6 * np.max(np.abs(ref)) + 1e-30
+            assert np.array_equal(gen.plan_c2r.data_out, phi)          # the Newtonian potential is untouched
+    with pytest.raises(ValueError):
+        gen.calculate_lensing_potential(i_min=nz)
+    with pytest.raises(RuntimeError):
+        Generator(nx, ny, nz, spacing, backend="numpy").calculate_lensing_potential()     # no DA table
 
 
 def test_gaussian_variance():

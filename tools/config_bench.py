@@ -74,10 +74,31 @@ def run_reference(n, reps=3):
     plan.close()
 
 
+def run_lensing(n, reps=3):
+    """rf_lensing_potential on an n^3 float32 field."""
+    plan = _hip.DevicePlan(n, n, n, np.complex64)
+    plan.upload_real(np.random.RandomState(1).normal(size=(n, n, n)).astype(np.float32))
+    cot = np.ones(n)
+    cot[1:] = 1.0 / (np.arange(1, n) * 2.5)
+    plan.lensing_potential(cot, 2.5, n // 32)
+    times = []
+    for i in range(reps):
+        plan.sync()
+        t0 = time.perf_counter()
+        plan.lensing_potential(cot, 2.5, n // 32)
+        plan.sync()
+        times.append(time.perf_counter() - t0)
+    t = float(np.median(times))
+    print(json.dumps({"case": "%d^3 f32 lensing potential" % n, "ms": round(t * 1e3, 3),
+                      "GBs_read_plus_write": round(2 * 4 * n ** 3 / t / 1e9, 1)}), flush=True)
+    plan.close()
+
+
 if __name__ == "__main__":
     run(512, np.complex64)
     run(1024, np.complex64)
     run(1024, np.complex128)
     run(1024, np.complex128, lognormal=True)
     run_reference(1024)
+    run_lensing(1024)
     run(2048, np.complex64, reps=3)
