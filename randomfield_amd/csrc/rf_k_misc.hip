@@ -162,41 +162,70 @@ __device__ __forceinline__ double wave_excl_scan(double v, int lane) {
   return inc - v;
 }
 
+// A wave walks its row in segments of 64 * VW samples (VW = samples per 16-byte vector): every lane loads ONE vector
+// per segment (a fully coalesced 1-KiB wave access), the four running sums and the previous sample are carried from
+// segment to segment (lane 63's inclusive values).  Rows shorter than a segment use guarded scalar accesses.
 template <typename T>
 __global__ __launch_bounds__(256) void lensing_kernel(const T* __restrict__ phi, T* __restrict__ psi, long long nrows, int nz,
                                                       const double* __restrict__ cot, double h, int i_min) {
+  constexpr int VW = 16 / (int)sizeof(T);
+  struct alignas(16) Vec { T e[VW]; };
   const int lane = threadIdx.x & 63;
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= nrows) return;                         // the whole wave leaves together
   const T* in = phi + row * (long long)nz;
   T* out = psi + row * (long long)nz;
-  const int epl = nz >= 64 ? nz / 64 : 1;           // samples per lane (nz is a power of two)
-  const int j0 = lane * epl;
-  double Ea = 0, Oa = 0, Eb = 0, Ob = 0;
-  for (int e = 0; e < epl; ++e) {
-    const int j = j0 + e;
-    if (j < nz && j >= i_min) {
-      const double v = (double)in[j], a = cot[j] * v;
-      if ((j - i_min) & 1) { Oa += a; Ob += v; } else { Ea += a; Eb += v; }
-    }
-  }
-  Ea = wave_excl_scan(Ea, lane); Oa = wave_excl_scan(Oa, lane);
-  Eb = wave_excl_scan(Eb, lane); Ob = wave_excl_scan(Ob, lane);
+  const bool vec = nz >= 64 * VW;                   // nz is a power of two: then a multiple of the segment length
   const double b0 = (double)in[i_min], a0 = cot[i_min] * b0;
   const double b1 = i_min + 1 < nz ? (double)in[i_min + 1] : 0.0, a1 = i_min + 1 < nz ? cot[i_min + 1] * b1 : 0.0;
-  double bp = 0.0, ap = 0.0;                        // the sample before this lane's first one
-  if (j0 - 1 >= i_min && j0 - 1 < nz) { bp = (double)in[j0 - 1]; ap = cot[j0 - 1] * bp; }
-  for (int e = 0; e < epl; ++e) {
-    const int j = j0 + e;
-    if (j >= nz) break;
-    if (j < i_min) { out[j] = (T)0; continue; }
-    const int m = j - i_min;
-    const double c = cot[j], v = (double)in[j], a = c * v;
-    if (m & 1) { Oa += a; Ob += v; } else { Ea += a; Eb += v; }
-    const double Sa = lens_simps(Ea, Oa, a0, a1, ap, a, m, h);
-    const double Sb = lens_simps(Eb, Ob, b0, b1, bp, v, m, h);
-    out[j] = (T)(-2.0 * (Sa - c * Sb));
-    ap = a; bp = v;
+  double cEa = 0, cOa = 0, cEb = 0, cOb = 0;        // sums over all earlier segments
+#pragma unroll 1
+  for (int seg = 0; seg < nz; seg += 64 * VW) {
+    const int j0 = seg + lane * VW;
+    Vec v;
+    if (vec) v = *reinterpret_cast<const Vec*>(in + j0);
+    else {
+#pragma unroll
+      for (int e = 0; e < VW; ++e) v.e[e] = j0 + e < nz ? in[j0 + e] : (T)0;
+    }
+    double c[VW];
+    double Ea = 0, Oa = 0, Eb = 0, Ob = 0;
+#pragma unroll
+    for (int e = 0; e < VW; ++e) {
+      const int j = j0 + e;
+      c[e] = j < nz ? cot[j] : 0.0;
+      if (j < nz && j >= i_min) {
+        const double x = (double)v.e[e], a = c[e] * x;
+        if ((j - i_min) & 1) { Oa += a; Ob += x; } else { Ea += a; Eb += x; }
+      }
+    }
+    const double tEa = Ea, tOa = Oa, tEb = Eb, tOb = Ob;                 // this lane's share of the segment
+    Ea = cEa + wave_excl_scan(Ea, lane); Oa = cOa + wave_excl_scan(Oa, lane);
+    Eb = cEb + wave_excl_scan(Eb, lane); Ob = cOb + wave_excl_scan(Ob, lane);
+    // inclusive totals at the end of the segment = lane 63's exclusive prefix + its own share
+    cEa = __shfl(Ea + tEa, 63); cOa = __shfl(Oa + tOa, 63); cEb = __shfl(Eb + tEb, 63); cOb = __shfl(Ob + tOb, 63);
+    double bp = 0.0, ap = 0.0;                      // the sample before this lane's first one
+    if (j0 - 1 >= i_min && j0 - 1 < nz) { bp = (double)in[j0 - 1]; ap = cot[j0 - 1] * bp; }
+    Vec o;
+#pragma unroll
+    for (int e = 0; e < VW; ++e) {
+      const int j = j0 + e;
+      o.e[e] = (T)0;
+      if (j < nz && j >= i_min) {
+        const int m = j - i_min;
+        const double x = (double)v.e[e], a = c[e] * x;
+        if (m & 1) { Oa += a; Ob += x; } else { Ea += a; Eb += x; }
+        const double Sa = lens_simps(Ea, Oa, a0, a1, ap, a, m, h);
+        const double Sb = lens_simps(Eb, Ob, b0, b1, bp, x, m, h);
+        o.e[e] = (T)(-2.0 * (Sa - c[e] * Sb));
+        ap = a; bp = x;
+      }
+    }
+    if (vec) *reinterpret_cast<Vec*>(out + j0) = o;
+    else {
+#pragma unroll
+      for (int e = 0; e < VW; ++e) if (j0 + e < nz) out[j0 + e] = o.e[e];
+    }
   }
 }
 
@@ -255,12 +284,16 @@ hipError_t launch_affine_z(int f64, void* W, long long nrows, int nz, const doub
   return hipGetLastError();
 }
 
+template <typename T>
+static hipError_t launch_lensing_t(const T* phi, T* psi, long long nrows, int nz, const double* cot_z, double h, int i_min, hipStream_t s) {
+  hipLaunchKernelGGL(lensing_kernel<T>, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, s, phi, psi, nrows, nz, cot_z, h, i_min);
+  return hipGetLastError();
+}
+
 hipError_t launch_lensing(int f64, const void* phi, void* psi, long long nrows, int nz, const double* cot_z, double h, int i_min,
                           hipStream_t s) {
-  const unsigned grid = (unsigned)((nrows + 3) / 4);
-  if (f64) hipLaunchKernelGGL(lensing_kernel<double>, dim3(grid), dim3(256), 0, s, (const double*)phi, (double*)psi, nrows, nz, cot_z, h, i_min);
-  else hipLaunchKernelGGL(lensing_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)phi, (float*)psi, nrows, nz, cot_z, h, i_min);
-  return hipGetLastError();
+  return f64 ? launch_lensing_t<double>((const double*)phi, (double*)psi, nrows, nz, cot_z, h, i_min, s)
+             : launch_lensing_t<float>((const float*)phi, (float*)psi, nrows, nz, cot_z, h, i_min, s);
 }
 
 hipError_t launch_save_potential(int f64, const void* K, void* P, int nx, int ny, int nz, const double* kx2,
