@@ -125,12 +125,12 @@ struct rf_plan {
   size_t noise_cap = 0;
   bool noise_resident = false;            // the device noise buffer holds a full set of deviates
   // MT19937 replay (rf_noise_mt19937): jump-polynomial bit positions per tree level, scratch
-  uint16_t* mt_pos = nullptr;
+  uint32_t* mt_pos = nullptr;          // set-bit positions of the jump polynomials, widened to 32 bits (scalar loads)
   std::vector<int> mt_npos;
   int mt_stride = 0, mt_bps = 0;          // positions per level (padded), blocks of 624 words per segment
-  uint32_t *mt_states = nullptr, *mt_seq = nullptr;
+  uint32_t* mt_states = nullptr;
   unsigned long long *mt_counts = nullptr, *mt_offsets = nullptr;
-  size_t mt_states_cap = 0, mt_seq_cap = 0, mt_seg_cap = 0;
+  size_t mt_states_cap = 0, mt_seg_cap = 0;
   double* partials = nullptr;
   long long npartials = 0;
   double* stats = nullptr;                // [2 * stats_cap] (sum, sumsq) per realisation
@@ -578,7 +578,7 @@ int rf_plan_destroy(rf_plan* p) {
   if (p->comm_stream) { (void)hipStreamSynchronize(p->comm_stream); (void)hipStreamDestroy(p->comm_stream); }
   for (auto& e : p->pev) if (e) (void)hipEventDestroy(e);
   void* bufs[] = {p->W, p->R, p->W2, p->R2, p->K, p->P, p->tw_x, p->tw_y, p->tw_z, p->kx2, p->ky2, p->kz2, p->xt, p->st, p->sl, p->bin,
-                  p->noise, p->mt_pos, p->mt_states, p->mt_seq, p->mt_counts, p->mt_offsets, p->partials, p->stats, p->seeds_dev, p->ztab, p->ky2f,
+                  p->noise, p->mt_pos, p->mt_states, p->mt_counts, p->mt_offsets, p->partials, p->stats, p->seeds_dev, p->ztab, p->ky2f,
                   p->kz2f, p->frec};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -1036,8 +1036,14 @@ int rf_mt_set_jump(rf_plan* p, int nlevels, const uint16_t* pos, const int* npos
   RF_HIP(hipStreamSynchronize(p->stream));
   if (p->mt_pos) RF_HIP(hipFree(p->mt_pos));
   p->mt_pos = nullptr;
-  RF_HIP(hipMalloc((void**)&p->mt_pos, (size_t)nlevels * stride * sizeof(uint16_t)));
-  RF_HIP(hipMemcpy(p->mt_pos, pos, (size_t)nlevels * stride * sizeof(uint16_t), hipMemcpyHostToDevice));
+  // the kernel reads the positions with scalar loads, which have dword granularity: widen; pad rows to 8 entries
+  const int wstride = (stride + 7) / 8 * 8;
+  std::vector<uint32_t> wide((size_t)nlevels * wstride, 0u);
+  for (int l = 0; l < nlevels; ++l)
+    for (int j = 0; j < npos[l]; ++j) wide[(size_t)l * wstride + j] = pos[(size_t)l * stride + j];
+  RF_HIP(hipMalloc((void**)&p->mt_pos, wide.size() * sizeof(uint32_t)));
+  RF_HIP(hipMemcpy(p->mt_pos, wide.data(), wide.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  stride = wstride;
   p->mt_npos.assign(npos, npos + nlevels);
   p->mt_stride = stride;
   p->mt_bps = blocks_per_segment;
@@ -1067,13 +1073,6 @@ int rf_noise_mt19937(rf_plan* p, const uint32_t* state624, unsigned long long* a
     RF_HIP(hipMalloc((void**)&p->mt_states, nstates * 624 * sizeof(uint32_t)));
     p->mt_states_cap = nstates;
   }
-  const size_t chunk = nstates / 2 < 512 ? (nstates / 2 ? nstates / 2 : 1) : 512;      // sources expanded per launch
-  if (p->mt_seq_cap < chunk) {
-    if (p->mt_seq) RF_HIP(hipFree(p->mt_seq));
-    p->mt_seq = nullptr;
-    RF_HIP(hipMalloc((void**)&p->mt_seq, chunk * (size_t)mt_seq_words() * sizeof(uint32_t)));
-    p->mt_seq_cap = chunk;
-  }
   if (p->mt_seg_cap < (size_t)nseg + 1) {
     if (p->mt_counts) RF_HIP(hipFree(p->mt_counts));
     if (p->mt_offsets) RF_HIP(hipFree(p->mt_offsets));
@@ -1089,12 +1088,9 @@ int rf_noise_mt19937(rf_plan* p, const uint32_t* state624, unsigned long long* a
     const long long nsrc_all = 1LL << k;
     long long ndst_all = (long long)nseg - nsrc_all;
     if (ndst_all > nsrc_all) ndst_all = nsrc_all;
-    for (long long s0 = 0; s0 < ndst_all; s0 += (long long)chunk) {
-      const int cnt = (int)((ndst_all - s0) < (long long)chunk ? (ndst_all - s0) : (long long)chunk);
-      RF_HIP(launch_mt_expand(p->mt_states + (size_t)s0 * 624, p->mt_seq, cnt, s));
-      RF_HIP(launch_mt_combine(p->mt_seq, p->mt_pos + (size_t)k * p->mt_stride, p->mt_npos[k],
-                               p->mt_states + (size_t)(nsrc_all + s0) * 624, cnt, s));
-    }
+    if (ndst_all > 0)
+      RF_HIP(launch_mt_jump(p->mt_states, p->mt_pos + (size_t)k * p->mt_stride, p->mt_npos[k], p->mt_states + (size_t)nsrc_all * 624,
+                            (int)ndst_all, s));
   }
   RF_HIP(launch_mt_polar(false, p->mt_states, nseg, p->mt_bps, total_blocks, p->mt_counts, nullptr, nullptr, ncells, s));
   RF_HIP(launch_mt_scan(p->mt_counts, p->mt_offsets, nseg, s));

@@ -7,9 +7,9 @@
 //
 // Parallelisation (randomfield_amd/mt19937.py has the mathematics):
 //   1. jump tree: the state J words ahead is the XOR of the sequence words x_{i+j} over the set
-//      coefficients j of t^J mod phi(t).  mt_expand_kernel writes 33 blocks of the sequence of each source
-//      state, mt_combine_kernel XORs them; level k of the tree doubles the number of segment start states.
-//   2. mt_polar_kernel<false>: every segment (1024 blocks of 624 outputs) counts its accepted attempts;
+//      coefficients j of t^J mod phi(t).  mt_jump_kernel builds 33 blocks of the sequence of a source state in
+//      LDS and XORs them; level k of the tree doubles the number of segment start states.
+//   2. mt_polar_kernel<false>: every segment (1024 blocks of 624 outputs, one WAVE each) counts its accepted attempts;
 //      an exclusive scan of the counts gives each segment the index of its first cell;
 //   3. mt_polar_kernel<true>: the same generation again, now writing the deviates of the accepted attempts.
 #include <hip/hip_runtime.h>
@@ -49,116 +49,146 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
   return y;
 }
 
-// sequence words x_p .. x_{p + MT_SEQ_WORDS - 1} of source state `src` (one workgroup per source)
-__global__ __launch_bounds__(256) void mt_expand_kernel(const uint32_t* __restrict__ states, uint32_t* __restrict__ seq) {
-  __shared__ uint32_t buf[2][MT_N];
-  const uint32_t* st = states + (size_t)blockIdx.x * MT_N;
-  uint32_t* out = seq + (size_t)blockIdx.x * MT_SEQ_WORDS;
-  for (int i = threadIdx.x; i < MT_N; i += blockDim.x) buf[0][i] = st[i];
+// One jump: destination state d = source state d advanced by the level's distance.  One workgroup per destination:
+// the 33-block sequence window of the source (82 KB) is generated into LDS, then lane i XORs the window words
+// i + pos[j] over the set coefficients j of the jump polynomial (~10^4 conflict-free LDS reads per lane instead
+// of as many L2 reads: the global-memory version of this step took 13 of the replay's 28 ms).
+__global__ __launch_bounds__(640) void mt_jump_kernel(const uint32_t* __restrict__ states_src, const uint32_t* __restrict__ pos,
+                                                      int npos, uint32_t* __restrict__ states_dst) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t win[];     // MT_SEQ_WORDS words
+  const int t = threadIdx.x;
+  const uint32_t* st = states_src + (size_t)blockIdx.x * MT_N;
+  if (t < MT_N) win[t] = st[t];
   __syncthreads();
-  int c = 0;
-  for (int b = 0; b < MT_SEQ_BLOCKS; ++b) {
-    for (int i = threadIdx.x; i < MT_N; i += blockDim.x) out[(size_t)b * MT_N + i] = buf[c][i];
-    if (b + 1 < MT_SEQ_BLOCKS) mt_next_block(buf[c], buf[c ^ 1]);
-    c ^= 1;
+  // x[n + 624] = f(x[n], x[n + 1], x[n + 397]): within a block of 624 new words, words [0, 227) need old words only,
+  // [227, 454) need new words [0, 227), [454, 624) need new words [227, 397)
+  for (int b = 1; b < MT_SEQ_BLOCKS; ++b) {
+    uint32_t* nw = win + b * MT_N;
+    const uint32_t* od = nw - MT_N;
+    if (t < 227) nw[t] = mt_f(od[t], od[t + 1], od[t + MT_M]);
+    __syncthreads();
+    if (t >= 227 && t < 454) nw[t] = mt_f(od[t], od[t + 1], od[t + MT_M]);
+    __syncthreads();
+    if (t >= 454 && t < MT_N) nw[t] = mt_f(od[t], od[t + 1], od[t + MT_M]);
+    __syncthreads();
+  }
+  if (t < MT_N) {
+    uint32_t acc = 0;
+    const uint32_t* w = win + t;
+    int j = 0;                                     // pos[] is uniform: scalar loads, 8 positions per s_load_dwordx8
+    for (; j + 8 <= npos; j += 8)
+      acc ^= w[pos[j]] ^ w[pos[j + 1]] ^ w[pos[j + 2]] ^ w[pos[j + 3]] ^ w[pos[j + 4]] ^ w[pos[j + 5]] ^ w[pos[j + 6]] ^ w[pos[j + 7]];
+    for (; j < npos; ++j) acc ^= w[pos[j]];
+    states_dst[(size_t)blockIdx.x * MT_N + t] = acc;
   }
 }
 
-// dst state word i = XOR_j seq[src][i + pos[j]]   (one workgroup of 640 threads per destination)
-__global__ __launch_bounds__(640) void mt_combine_kernel(const uint32_t* __restrict__ seq, const uint16_t* __restrict__ pos,
-                                                         int npos, uint32_t* __restrict__ states_dst) {
-  const int i = threadIdx.x;
-  if (i >= MT_N) return;
-  const uint32_t* s = seq + (size_t)blockIdx.x * MT_SEQ_WORDS + i;
-  uint32_t acc = 0;
-  for (int j = 0; j < npos; ++j) acc ^= s[pos[j]];
-  states_dst[(size_t)blockIdx.x * MT_N + i] = acc;
-}
-
-// One workgroup per segment.  FILL = false: counts[seg] = accepted attempts of the segment.
+// One WAVE per segment (4 segments per 256-thread workgroup), no workgroup barriers: the 624-word state lives in the
+// wave's own LDS window and is regenerated IN PLACE in 64-lane chunks -- word i needs the old words i, i+1 and either
+// the old word i+397 (i < 227) or the new word i-227, which an earlier chunk has already written (LDS operations of
+// one wave execute in order; `volatile` keeps the compiler from reordering them).
+// FILL = false: counts[seg] = accepted attempts of the segment.
 // FILL = true: writes (f x2, f x1) of every accepted attempt whose cell index < ncells.
 template <bool FILL>
 __global__ __launch_bounds__(256) void mt_polar_kernel(const uint32_t* __restrict__ states, int blocks_per_segment,
-                                                       long long total_blocks, unsigned long long* __restrict__ counts,
+                                                       long long total_blocks, int nseg, unsigned long long* __restrict__ counts,
                                                        const unsigned long long* __restrict__ offsets,
                                                        double* __restrict__ noise, unsigned long long ncells) {
-  __shared__ uint32_t buf[2][MT_N];
-  __shared__ uint32_t wsum[4];
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const long long seg = blockIdx.x;
+  __shared__ uint32_t lds[4][MT_N + 16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long seg = (long long)blockIdx.x * 4 + wave;
+  if (seg >= nseg) return;                                   // whole waves leave; nobody waits at a barrier
+  volatile uint32_t* mt = lds[wave];
   long long nb = total_blocks - seg * blocks_per_segment;
   if (nb > blocks_per_segment) nb = blocks_per_segment;
   const uint32_t* st = states + (size_t)seg * MT_N;
-  for (int i = t; i < MT_N; i += blockDim.x) buf[0][i] = st[i];
-  __syncthreads();
-  int c = 0;
+  for (int i = lane; i < MT_N; i += 64) mt[i] = st[i];
   unsigned long long running = FILL ? offsets[seg] : 0ull;   // cell index of this segment's next accepted attempt
   for (long long b = 0; b < nb; ++b) {
-    mt_next_block(buf[c], buf[c ^ 1]);      // the outputs of this block are the tempered words of buf[c ^ 1]
-    c ^= 1;
-    bool acc = false;
-    double x1 = 0, x2 = 0, r2 = 0;
-    if (t < MT_N / 4) {
-      const uint32_t w0 = mt_temper(buf[c][4 * t]), w1 = mt_temper(buf[c][4 * t + 1]);
-      const uint32_t w2 = mt_temper(buf[c][4 * t + 2]), w3 = mt_temper(buf[c][4 * t + 3]);
-      const double u1 = ((double)(w0 >> 5) * 67108864.0 + (double)(w1 >> 6)) / 9007199254740992.0;
-      const double u2 = ((double)(w2 >> 5) * 67108864.0 + (double)(w3 >> 6)) / 9007199254740992.0;
-      x1 = 2.0 * u1 - 1.0;
-      x2 = 2.0 * u2 - 1.0;
-      r2 = sum_of_squares(x1, x2);                                // no FMA: numpy's C code rounds both products
-      acc = (r2 < 1.0) && (r2 != 0.0);
-    }
-    const unsigned long long ball = __ballot(acc);
-    if (lane == 0) wsum[wave] = (uint32_t)__popcll(ball);
-    __syncthreads();
-    const uint32_t n0 = wsum[0], n1 = wsum[1], n2 = wsum[2];
-    if (FILL && acc) {
-      const uint32_t before = (wave > 0 ? n0 : 0u) + (wave > 1 ? n1 : 0u) + (wave > 2 ? n2 : 0u) +
-                              (uint32_t)__popcll(ball & ((1ull << lane) - 1ull));
-      const unsigned long long cell = running + before;
-      if (cell < ncells) {
-        // r2 - 1 is exact for r2 >= 1/2, and log1p keeps full relative accuracy where log(r2) -> 0
-        const double lg = r2 > 0.5 ? log1p(r2 - 1.0) : log(r2);
-        const double f = sqrt(-2.0 * lg / r2);
-        noise[2 * cell] = f * x2;           // legacy_gauss returns f*x2 first, then the saved f*x1
-        noise[2 * cell + 1] = f * x1;
+    // regenerate: the outputs of this block are the tempered NEW words
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+      const int i = 64 * k + lane;
+      if (i < MT_N) {
+        // word 623 follows the same rule with its neighbour wrapped to the (new) word 0: 623 - 227 = 396
+        const uint32_t third = i < MT_N - MT_M ? mt[i + MT_M] : mt[i - (MT_N - MT_M)];
+        const uint32_t nxt = mt[i + 1 == MT_N ? 0 : i + 1];
+        const uint32_t v = mt_f(mt[i], nxt, third);
+        mt[i] = v;                                           // every lane has read before any lane writes (lock step)
       }
     }
-    running += (unsigned long long)(n0 + n1 + n2);    // waves 0..2 hold the 156 attempts
-    __syncthreads();                                   // wsum is rewritten next iteration
+    // polar method: attempt a uses outputs 4a .. 4a+3; 156 attempts per block, in lane order
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+      const int a = 64 * it + lane;
+      bool acc = false;
+      double x1 = 0, x2 = 0, r2 = 0;
+      if (a < MT_N / 4) {
+        const uint32_t w0 = mt_temper(mt[4 * a]), w1 = mt_temper(mt[4 * a + 1]);
+        const uint32_t w2 = mt_temper(mt[4 * a + 2]), w3 = mt_temper(mt[4 * a + 3]);
+        const double u1 = ((double)(w0 >> 5) * 67108864.0 + (double)(w1 >> 6)) / 9007199254740992.0;
+        const double u2 = ((double)(w2 >> 5) * 67108864.0 + (double)(w3 >> 6)) / 9007199254740992.0;
+        x1 = 2.0 * u1 - 1.0;
+        x2 = 2.0 * u2 - 1.0;
+        r2 = sum_of_squares(x1, x2);                          // no FMA: numpy's C code rounds both products
+        acc = (r2 < 1.0) && (r2 != 0.0);
+      }
+      const unsigned long long ball = __ballot(acc);
+      if (FILL && acc) {
+        const unsigned long long cell = running + (unsigned long long)__popcll(ball & ((1ull << lane) - 1ull));
+        if (cell < ncells) {
+          const double f = sqrt(-2.0 * log(r2) / r2);
+          noise[2 * cell] = f * x2;                           // legacy_gauss returns f*x2 first, then the saved f*x1
+          noise[2 * cell + 1] = f * x1;
+        }
+      }
+      running += (unsigned long long)__popcll(ball);
+    }
   }
-  if (!FILL && t == 0) counts[seg] = running;
+  if (!FILL && lane == 0) counts[seg] = running;
 }
 
-__global__ void mt_scan_kernel(const unsigned long long* __restrict__ counts, unsigned long long* __restrict__ offsets, int n) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    unsigned long long s = 0;
-    for (int i = 0; i < n; ++i) { offsets[i] = s; s += counts[i]; }
-    offsets[n] = s;                                    // total number of accepted attempts
+// exclusive scan of the per-segment counts by ONE wave: lane l owns a contiguous chunk, wave scan across lanes
+__global__ __launch_bounds__(64) void mt_scan_kernel(const unsigned long long* __restrict__ counts, unsigned long long* __restrict__ offsets, int n) {
+  const int lane = threadIdx.x;
+  const int per = (n + 63) / 64, lo = lane * per, hi = lo + per < n ? lo + per : n;
+  unsigned long long sum = 0;
+  for (int i = lo; i < hi; ++i) sum += counts[i];
+  unsigned long long inc = sum;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned long long t = __shfl_up(inc, off);
+    if (lane >= off) inc += t;
   }
+  unsigned long long run = inc - sum;
+  for (int i = lo; i < hi; ++i) { offsets[i] = run; run += counts[i]; }
+  if (lane == 63) offsets[n] = inc;                    // total number of accepted attempts
 }
 
 }  // namespace
 
-hipError_t launch_mt_expand(const uint32_t* states, uint32_t* seq, int nsrc, hipStream_t s) {
-  hipLaunchKernelGGL(mt_expand_kernel, dim3(nsrc), dim3(256), 0, s, states, seq);
-  return hipGetLastError();
-}
-hipError_t launch_mt_combine(const uint32_t* seq, const uint16_t* pos, int npos, uint32_t* states_dst, int ndst, hipStream_t s) {
-  hipLaunchKernelGGL(mt_combine_kernel, dim3(ndst), dim3(640), 0, s, seq, pos, npos, states_dst);
+hipError_t launch_mt_jump(const uint32_t* states_src, const uint32_t* pos, int npos, uint32_t* states_dst, int ndst, hipStream_t s) {
+  constexpr int lds = MT_SEQ_WORDS * (int)sizeof(uint32_t);
+  static bool prepared = false;
+  if (!prepared) {
+    hipError_t e = hipFuncSetAttribute((const void*)mt_jump_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    prepared = true;
+  }
+  hipLaunchKernelGGL(mt_jump_kernel, dim3(ndst), dim3(640), lds, s, states_src, pos, npos, states_dst);
   return hipGetLastError();
 }
 hipError_t launch_mt_polar(bool fill, const uint32_t* states, int nseg, int blocks_per_segment, long long total_blocks,
                            unsigned long long* counts, const unsigned long long* offsets, double* noise,
                            unsigned long long ncells, hipStream_t s) {
-  if (fill) hipLaunchKernelGGL(mt_polar_kernel<true>, dim3(nseg), dim3(256), 0, s, states, blocks_per_segment, total_blocks, counts, offsets, noise, ncells);
-  else hipLaunchKernelGGL(mt_polar_kernel<false>, dim3(nseg), dim3(256), 0, s, states, blocks_per_segment, total_blocks, counts, offsets, noise, ncells);
+  const unsigned grid = (unsigned)((nseg + 3) / 4);
+  if (fill) hipLaunchKernelGGL(mt_polar_kernel<true>, dim3(grid), dim3(256), 0, s, states, blocks_per_segment, total_blocks, nseg, counts, offsets, noise, ncells);
+  else hipLaunchKernelGGL(mt_polar_kernel<false>, dim3(grid), dim3(256), 0, s, states, blocks_per_segment, total_blocks, nseg, counts, offsets, noise, ncells);
   return hipGetLastError();
 }
 hipError_t launch_mt_scan(const unsigned long long* counts, unsigned long long* offsets, int n, hipStream_t s) {
   hipLaunchKernelGGL(mt_scan_kernel, dim3(1), dim3(64), 0, s, counts, offsets, n);
   return hipGetLastError();
 }
-int mt_seq_words() { return MT_SEQ_WORDS; }
 
 }  // namespace rf

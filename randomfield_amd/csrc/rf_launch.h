@@ -55,12 +55,10 @@ hipError_t launch_save_potential(int f64, const void* K, void* P, int nx, int ny
 hipError_t launch_scale_copy(int f64, const void* P, void* K, long long n, double scale, hipStream_t s);
 
 // on-GPU replay of RandomState(seed).normal (rf_k_mt.hip)
-hipError_t launch_mt_expand(const uint32_t* states, uint32_t* seq, int nsrc, hipStream_t s);
-hipError_t launch_mt_combine(const uint32_t* seq, const uint16_t* pos, int npos, uint32_t* states_dst, int ndst, hipStream_t s);
+hipError_t launch_mt_jump(const uint32_t* states_src, const uint32_t* pos, int npos, uint32_t* states_dst, int ndst, hipStream_t s);
 hipError_t launch_mt_polar(bool fill, const uint32_t* states, int nseg, int blocks_per_segment, long long total_blocks,
                            unsigned long long* counts, const unsigned long long* offsets, double* noise,
                            unsigned long long ncells, hipStream_t s);
 hipError_t launch_mt_scan(const unsigned long long* counts, unsigned long long* offsets, int n, hipStream_t s);
-int mt_seq_words();
 
 }  // namespace rf
