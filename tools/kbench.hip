@@ -244,14 +244,14 @@ int main(int argc, char** argv) {
     for (int rep = 0; rep < 3; ++rep) {
       CK(hipDeviceSynchronize());
       auto t0 = std::chrono::high_resolution_clock::now();
-      hipLaunchKernelGGL(kx, dim3((unsigned)xt), dim3(C::NT), xl, s1, xio, tw, xt, 1LL, 0LL);
-      hipLaunchKernelGGL(ky, dim3((unsigned)yt), dim3(C::NT), C::LDS_BYTES, s2, yio, tw, yt, 1LL, 0LL);
+      hipLaunchKernelGGL(kx, dim3((unsigned)xt), dim3(C::NT), xl, s1, xio, tw, xt, 1LL, 0LL, 0);
+      hipLaunchKernelGGL(ky, dim3((unsigned)yt), dim3(C::NT), C::LDS_BYTES, s2, yio, tw, yt, 1LL, 0LL, 0);
       CK(hipDeviceSynchronize());
       auto t1 = std::chrono::high_resolution_clock::now();
-      hipLaunchKernelGGL(kx, dim3((unsigned)xt), dim3(C::NT), xl, s1, xio, tw, xt, 1LL, 0LL);
+      hipLaunchKernelGGL(kx, dim3((unsigned)xt), dim3(C::NT), xl, s1, xio, tw, xt, 1LL, 0LL, 0);
       CK(hipDeviceSynchronize());
       auto t2 = std::chrono::high_resolution_clock::now();
-      hipLaunchKernelGGL(ky, dim3((unsigned)yt), dim3(C::NT), C::LDS_BYTES, s2, yio, tw, yt, 1LL, 0LL);
+      hipLaunchKernelGGL(ky, dim3((unsigned)yt), dim3(C::NT), C::LDS_BYTES, s2, yio, tw, yt, 1LL, 0LL, 0);
       CK(hipDeviceSynchronize());
       auto t3 = std::chrono::high_resolution_clock::now();
       auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
@@ -284,14 +284,14 @@ int main(int argc, char** argv) {
       for (int rep = 0; rep < 2; ++rep) {
         CK(hipDeviceSynchronize());
         auto t0 = std::chrono::high_resolution_clock::now();
-        hipLaunchKernelGGL(kx, dim3((unsigned)xt), dim3(C::NT), xl, sx, xio, tw, xt, 1LL, 0LL);
-        hipLaunchKernelGGL(ky, dim3((unsigned)yt), dim3(CY::NT), CY::LDS_BYTES, sy, yio, tw, yt, 1LL, 0LL);
+        hipLaunchKernelGGL(kx, dim3((unsigned)xt), dim3(C::NT), xl, sx, xio, tw, xt, 1LL, 0LL, 0);
+        hipLaunchKernelGGL(ky, dim3((unsigned)yt), dim3(CY::NT), CY::LDS_BYTES, sy, yio, tw, yt, 1LL, 0LL, 0);
         CK(hipDeviceSynchronize());
         auto t1 = std::chrono::high_resolution_clock::now();
-        hipLaunchKernelGGL(kx, dim3((unsigned)xt), dim3(C::NT), xl, sx, xio, tw, xt, 1LL, 0LL);
+        hipLaunchKernelGGL(kx, dim3((unsigned)xt), dim3(C::NT), xl, sx, xio, tw, xt, 1LL, 0LL, 0);
         CK(hipDeviceSynchronize());
         auto t2 = std::chrono::high_resolution_clock::now();
-        hipLaunchKernelGGL(ky, dim3((unsigned)yt), dim3(CY::NT), CY::LDS_BYTES, sy, yio, tw, yt, 1LL, 0LL);
+        hipLaunchKernelGGL(ky, dim3((unsigned)yt), dim3(CY::NT), CY::LDS_BYTES, sy, yio, tw, yt, 1LL, 0LL, 0);
         CK(hipDeviceSynchronize());
         auto t3 = std::chrono::high_resolution_clock::now();
         auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
