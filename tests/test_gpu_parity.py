@@ -631,3 +631,17 @@ def test_generator_lensing_potential(hip):
     with pytest.raises(ValueError):
         gen.calculate_lensing_potential(i_min=-1)
     gen.plan_c2r.device.close()
+
+
+def test_randomised_call_sequences(hip, monkeypatch):
+    """A few seconds of tools/fuzz_api.py: random shapes, dtypes and call sequences through the C-ABI (realise with
+    native / external / replayed noise, generate + c2r, r2c round trips, lognormal, affine, potential, graph batches,
+    lensing), every result checked against the oracle or numpy."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_api.py")
+    spec = importlib.util.spec_from_file_location("fuzz_api", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    monkeypatch.setattr("sys.argv", ["fuzz_api.py", "6", "42"])
+    mod.main()
