@@ -65,6 +65,28 @@ def main_multi(args, rank, world, local_rank, shape, power, spacing):
     plan = dplan.plan
     plan.set_kgrid(*powertools.ksq_axes(nx, ny, nz, spacing))
     plan.set_power(*powertools.sigma_table(power, (nx, ny, nz), spacing))
+    # Two ways to run the slab decomposition: "exchange" = kz slabs + ONE RCCL all-to-all, pipelined
+    # behind the next realisation's generation; "replicate" = no all-to-all, every rank generates all of k space and keeps
+    # its x slab (P-fold redundant x-pass arithmetic).  xGMI is point to point, so which one is faster depends on how many
+    # links the job spans (2 GPUs share ONE link): measure both on a few realisations and take the faster.
+    mode = os.environ.get("RANDOMFIELD_MULTI_MODE", "auto")
+    calib = {}
+    if world > 1 and mode == "auto":
+        for m in ("exchange", "replicate"):
+            plan.set_replicated_generation(m == "replicate")
+            plan.realise_batch(np.arange(7000, 7002, dtype=np.uint64), want_rms=False)
+            plan.sync()
+            dplan.barrier()
+            t0 = time.perf_counter()
+            plan.realise_batch(np.arange(7100, 7103, dtype=np.uint64), want_rms=False)
+            plan.sync()
+            dplan.barrier()
+            calib[m] = float(dplan.allreduce([(time.perf_counter() - t0) / 3], op="max")[0]) * 1e3
+        mode = min(calib, key=calib.get)
+    elif mode not in ("exchange", "replicate"):
+        mode = "exchange"
+    if world > 1:
+        plan.set_replicated_generation(mode == "replicate")
     plan.realise(seed=999)                             # eager single step: per-phase event times
     plan.sync()
     kern = np.array(plan.kernel_ms())                  # x, y, exchange+z, all-reduce
@@ -82,17 +104,21 @@ def main_multi(args, rank, world, local_rank, shape, power, spacing):
     mean, std = plan.moments()
     cells = float(nx) * ny * nz
     sweep = 8.0 * nx * ny * (nz // 2 + 1)
-    xgmi_bytes = (world - 1) / world * sweep / world     # all-to-all egress per GPU
+    xgmi_bytes = (world - 1) / world * sweep / world if mode == "exchange" else 0.0     # all-to-all egress per GPU
     out = {
         "metric": "Mcells/s for N^3 delta(x) realisation",
         "value": round(cells * args.steps / wall / 1e6, 1), "unit": "Mcells/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(wall / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%dx%dx%d float32 delta(x) realisations, kz-slab/x-slab decomposition over %d GPUs, "
-                               "one RCCL all-to-all per realisation overlapped with the next realisation's generation, "
+        "config": {"workload": "%dx%dx%d float32 delta(x) realisations, x-slab decomposition over %d GPUs (%s), "
                                "native Philox4x32-10 RNG, shipped 500-row P(k)"
-                               % (nx, ny, nz, world), "grid": [nx, ny, nz], "rms_last": round(std, 6)},
+                               % (nx, ny, nz, world,
+                                  "kz-slab generation + ONE RCCL all-to-all per realisation, overlapped with the next "
+                                  "realisation's generation" if mode == "exchange" else
+                                  "replicated generation: every rank generates all of k space and keeps its x slab, no all-to-all"),
+                   "grid": [nx, ny, nz], "rms_last": round(std, 6), "multi_gpu_mode": mode,
+                   "mode_calibration_ms_per_step": {k: round(v, 3) for k, v in calib.items()}},
         "pipeline": {"algorithmic_GBs": round(5 * sweep * args.steps / wall / 1e9, 1),
                      "frac_of_hbm_peak": round(5 * sweep * args.steps / wall / 1e9 / (HBM_PEAK_GBS * world), 4),
                      "kernel_ms_rank0_unpipelined_step": {"x": round(float(kern[0]), 4), "y": round(float(kern[1]), 4),

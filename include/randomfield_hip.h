@@ -49,8 +49,11 @@ int rf_plan_nbytes(rf_plan* plan, size_t* nbytes);          /* transform.py:221,
 /* plan options.  RF_FLAG_EXACT_GENERATION = 1 makes native-noise float32 realisations use the
  * reference's exact float64 rounding chain for |k| and sigma(k) instead of the fast float32 one.
  * RF_FLAG_FORCE_SLAB_PATH = 2 routes a single-rank plan through the multi-GPU slab pipeline (y pass on the
- * slab, exchange = copy of the own block, gathering z pass, pipelined batches): a test hook. */
-enum { RF_FLAG_EXACT_GENERATION = 1, RF_FLAG_FORCE_SLAB_PATH = 2 };
+ * slab, exchange = copy of the own block, gathering z pass, pipelined batches): a test hook.
+ * RF_FLAG_REPLICATED_GENERATION = 4 (multi-rank plans, native generator): no all-to-all -- every rank generates all of
+ * k space on the fly, runs the full x-FFT and keeps only its own x slab; y and z passes are local.  P-fold redundant
+ * x-pass arithmetic instead of the exchange: faster when few GPUs share few xGMI links (2 GPUs: one link). */
+enum { RF_FLAG_EXACT_GENERATION = 1, RF_FLAG_FORCE_SLAB_PATH = 2, RF_FLAG_REPLICATED_GENERATION = 4 };
 int rf_plan_set_flag(rf_plan* plan, int flag, int value);
 /* run on a caller-owned HIP stream (hipStream_t passed as void*); NULL restores the plan's own stream */
 int rf_plan_set_stream(rf_plan* plan, void* hip_stream);

@@ -210,6 +210,10 @@ class DevicePlan(object):
         """Native-noise float32 realisations with the reference's exact float64 chain (slower)."""
         check(self._lib.rf_plan_set_flag(self._h, 1, int(bool(on))), "rf_plan_set_flag")
 
+    def set_replicated_generation(self, on=True):
+        """Multi-rank plans: no all-to-all; every rank generates all of k space and keeps its x slab (native rng)."""
+        check(self._lib.rf_plan_set_flag(self._h, 4, int(bool(on))), "rf_plan_set_flag")
+
     def set_force_slab_path(self, on=True):
         """Route this single-rank plan through the multi-GPU slab pipeline (test hook)."""
         check(self._lib.rf_plan_set_flag(self._h, 2, int(bool(on))), "rf_plan_set_flag")

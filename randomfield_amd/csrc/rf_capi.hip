@@ -99,6 +99,7 @@ struct rf_plan {
   hipStream_t comm_stream = nullptr;      // exchange stream of pipelined slab batches
   hipEvent_t pev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // fwd[2], exch[2], z[2]
   bool force_slab = false;                // single-rank plan routed through the slab pipeline (tests)
+  bool replicate = false;                 // multi-rank plan without an exchange: every rank generates all of k space (see queue_x)
   ncclComm_t comm = nullptr;
   size_t csize = 8;                       // bytes per complex element
   hipStream_t own_stream = nullptr, stream = nullptr;
@@ -245,27 +246,37 @@ int build_fast(rf_plan* p) {
 }
 
 // x pass (generation or API k-space fused into its load) into buffer W on stream sx
+// Replicated-generation mode of a multi-rank plan (RF_FLAG_REPLICATED_GENERATION): the native generator is keyed by
+// the global cell index and the x pass reads nothing, so a rank can generate ALL of k space on the fly, run the
+// full x-FFT and store only its own x slab [rank*nxl, (rank+1)*nxl); the y and z passes are then local and no
+// all-to-all is needed (only the 2-double all-reduce of the moments).  It trades P-fold redundant x-pass arithmetic
+// for the exchange: a win when the exchange is slower than (P-1) x passes -- 2 GPUs share ONE xGMI link.
 int queue_x(rf_plan* p, const GenParams& gp, const void* kspace, void* W, hipStream_t sx, bool timed = false) {
-  const long long nzl = p->nzl;     // kz planes held by this rank (nz/2 on one GPU)
-  const ColGeom gx{(long long)p->ny * nzl, 0, (long long)p->ny * nzl};
   const bool fast = !kspace && gp.noise_mode == NOISE_PHILOX && p->have_fast && !p->exact_gen;
+  const bool rep = p->replicate && p->nranks > 1;
+  RF_REQUIRE(!rep || fast, "replicated generation needs the native generator (fast path)");
+  const long long nzl = rep ? p->nzc : p->nzl;     // kz planes generated by this rank (nz/2 on one GPU)
+  const int kz0 = rep ? 0 : p->kz0;
+  const ColGeom gx{(long long)p->ny * nzl, 0, (long long)p->ny * nzl};
   if (timed) { RF_HIP(hipEventRecord(p->ev[5], sx)); p->repair_timed = fast; }   // overwritten by the launcher if it splits
   if (fast)
     RF_HIP(launch_col_fastgen(p->f64, p->nx, W, gx, (long long)p->ny * nzl, make_fast(p, gp.seed, gp.seed_dev != nullptr, gp.seed_dev),
-                              p->kz0, (int)nzl, p->tw_x, sx, false, timed ? p->ev[5] : nullptr));
+                              kz0, (int)nzl, p->tw_x, sx, false, timed ? p->ev[5] : nullptr,
+                              rep ? p->rank * p->nxl : 0, rep ? (p->rank + 1) * p->nxl : 1 << 30));
   else
-    RF_HIP(launch_col_gen(p->f64, p->nx, W, gx, (long long)p->ny * nzl, gp, kspace, p->kz0, (int)nzl, p->tw_x, sx));
+    RF_HIP(launch_col_gen(p->f64, p->nx, W, gx, (long long)p->ny * nzl, gp, kspace, kz0, (int)nzl, p->tw_x, sx));
   return 0;
 }
 
 // x pass (generation or API k-space fused into its load) + y pass of buffer W on stream s.
 // Records ev[1] (after x) and ev[2] (after y) when `timed`.
 int queue_xy(rf_plan* p, const GenParams& gp, const void* kspace, void* W, hipStream_t s, bool timed) {
-  const long long nzl = p->nzl;
+  const bool rep = p->replicate && p->nranks > 1;
+  const long long nzl = rep ? p->nzc : p->nzl, nxp = rep ? p->nxl : p->nx;      // the local array is [nxp][ny][nzl]
   const ColGeom gy{nzl, (long long)p->ny * nzl, nzl};
   if (int rc = queue_x(p, gp, kspace, W, s, timed)) return rc;
   if (timed) RF_HIP(hipEventRecord(p->ev[1], s));
-  RF_HIP(launch_col_plain(p->f64, p->ny, +1, W, gy, (long long)p->nx * nzl, p->tw_y, s));
+  RF_HIP(launch_col_plain(p->f64, p->ny, +1, W, gy, nxp * nzl, p->tw_y, s));
   if (timed) RF_HIP(hipEventRecord(p->ev[2], s));
   return 0;
 }
@@ -306,6 +317,30 @@ int queue_exchange_rccl(rf_plan* p, const void* W, void* R, hipStream_t s) {
 // z(i) waits for exch(i); exch(i) waits for x,y(i) and -- because it overwrites R[i%2] -- for z(i-2).
 // One all-reduce of all n (sum, sumsq) pairs at the end.
 int slab_batch(rf_plan* p, const uint64_t* seeds, int n) {
+  if (p->replicate && p->nranks > 1) {          // no exchange to overlap: realisations back to back, one all-reduce at the end
+    if (p->stats_cap < n) {
+      RF_HIP(hipStreamSynchronize(p->stream));
+      if (p->stats) RF_HIP(hipFree(p->stats));
+      p->stats = nullptr;
+      RF_HIP(hipMalloc((void**)&p->stats, 2 * (size_t)(n + 64) * sizeof(double)));
+      p->stats_cap = n + 64;
+    }
+    const double scale = 1.0 / ((double)p->nx * (double)p->ny * (double)p->nz);
+    RF_HIP(hipEventRecord(p->ev[0], p->stream));
+    for (int i = 0; i < n; ++i) {
+      if (int rc = queue_xy(p, make_gen(p, seeds[i], RF_NOISE_NATIVE, false), nullptr, p->W, p->stream, false)) return rc;
+      RF_HIP(launch_row_c2r(p->f64, (int)p->nzc, p->W, (long long)p->nxl * p->ny, scale, p->tw_z, p->partials, p->stream));
+      RF_HIP(launch_reduce_partials(p->partials, p->npartials, p->stats + 2 * i, p->partials + 2 * p->npartials, p->stream));
+    }
+    if (p->comm) RF_NCCL(g_rccl.AllReduce(p->stats, p->stats, 2 * (size_t)n, ncclFloat64, ncclSum, p->comm, p->stream));
+    RF_HIP(hipEventRecord(p->ev[4], p->stream));
+    p->cur = p->W;
+    p->stats_slot = n - 1;
+    p->timed = false;
+    p->real_valid = true;
+    p->stats_valid = true;
+    return 0;
+  }
   if (!p->W2) {
     RF_HIP(hipMalloc(&p->W2, p->w_bytes));
     RF_HIP(hipMalloc(&p->R2, p->w_bytes));
@@ -367,6 +402,19 @@ int queue_z(rf_plan* p, void* W, hipStream_t s, double* stats_out, bool timed) {
 int queue_c2r(rf_plan* p, const GenParams& gp, const void* kspace) {
   if (p->timed) RF_HIP(hipEventRecord(p->ev[0], p->stream));
   if (int rc = queue_xy(p, gp, kspace, p->W, p->stream, p->timed)) return rc;
+  if (p->replicate && p->nranks > 1) {          // the local array already is this rank's x slab [nxl][ny][nz/2]
+    const double scale = 1.0 / ((double)p->nx * (double)p->ny * (double)p->nz);
+    RF_HIP(launch_row_c2r(p->f64, (int)p->nzc, p->W, (long long)p->nxl * p->ny, scale, p->tw_z, p->partials, p->stream));
+    RF_HIP(launch_reduce_partials(p->partials, p->npartials, p->stats, p->partials + 2 * p->npartials, p->stream));
+    if (p->timed) RF_HIP(hipEventRecord(p->ev[3], p->stream));
+    if (p->comm) RF_NCCL(g_rccl.AllReduce(p->stats, p->stats, 2, ncclFloat64, ncclSum, p->comm, p->stream));
+    if (p->timed) RF_HIP(hipEventRecord(p->ev[4], p->stream));
+    p->cur = p->W;
+    p->real_valid = true;
+    p->stats_slot = 0;
+    p->stats_valid = true;
+    return 0;
+  }
   if (p->nranks > 1 || p->force_slab) {
     if (int rc = queue_exchange_rccl(p, p->W, p->R, p->stream)) return rc;
     if (int rc = queue_z_slab(p, p->R, p->W, p->stats, p->stream)) return rc;
@@ -598,8 +646,13 @@ int rf_plan_nbytes(rf_plan* p, size_t* nbytes) {
 int rf_plan_set_flag(rf_plan* p, int flag, int value) {
   RF_REQUIRE(p, "null plan");
   RF_REQUIRE(!p->unpacked, "this call does not apply to an unpacked c2c plan");
-  RF_REQUIRE(flag == RF_FLAG_EXACT_GENERATION || flag == RF_FLAG_FORCE_SLAB_PATH, "unknown flag");
+  RF_REQUIRE(flag == RF_FLAG_EXACT_GENERATION || flag == RF_FLAG_FORCE_SLAB_PATH || flag == RF_FLAG_REPLICATED_GENERATION, "unknown flag");
   RF_HIP(hipStreamSynchronize(p->stream));
+  if (flag == RF_FLAG_REPLICATED_GENERATION) {
+    RF_REQUIRE(p->nranks > 1, "RF_FLAG_REPLICATED_GENERATION is for multi-rank plans");
+    p->replicate = value != 0;
+    return 0;
+  }
   if (flag == RF_FLAG_FORCE_SLAB_PATH) {
     RF_REQUIRE(p->nranks == 1, "RF_FLAG_FORCE_SLAB_PATH is for single-rank plans");
     if (value && !p->R) RF_HIP(hipMalloc(&p->R, p->w_bytes));

@@ -140,6 +140,8 @@ struct FastGenColIOT {
   ColGeom g;
   FastGenParams gp;
   int kz0, nzl;
+  int x0 = 0, x1 = 1 << 30;  // replicated-generation mode (multi-GPU without an exchange): only rows [x0, x1) are stored,
+                             // and `base` has been moved back by x0 rows so that row x0 lands on the local array's row 0
   const FastRec* rec;      // set by prologue(): LDS copy of the sigma records (or the global one)
   static constexpr int LDS_EXTRA = FAST_LDS_BINS * (int)sizeof(FastRec);
   // keep the compiler from interleaving all R generation bodies of a butterfly (register blow-up);
@@ -186,6 +188,8 @@ struct FastGenColIOT {
     return fast_fix_kz0(gp, rec, seed, rb + ro, (int)(C / nzl));
   }
   RF_HD void store(long long C, int rb, int ro, const V16<float>& v) const {
+    const int row = rb + ro;
+    if (row < x0 || row >= x1) return;
     *reinterpret_cast<V16<float>*>((base + g.uniform_part(ro)) + g.lane_part(C, rb)) = v;
   }
 };
@@ -200,6 +204,7 @@ struct FastGenColIO64 {
   ColGeom g;
   FastGenParams gp;
   int kz0, nzl;
+  int x0 = 0, x1 = 1 << 30;  // replicated-generation mode: see FastGenColIOT
   const FastRec* rec;
   static constexpr int LDS_EXTRA = FAST_LDS_BINS * (int)sizeof(FastRec);
   RF_HD static void sched_fence(int = 0) {}
@@ -230,6 +235,8 @@ struct FastGenColIO64 {
     return mk<double>((double)c.x, (double)c.y);
   }
   RF_HD void store(long long C, int rb, int ro, const V16<double>& v) const {
+    const int row = rb + ro;
+    if (row < x0 || row >= x1) return;
     *reinterpret_cast<V16<double>*>((base + g.uniform_part(ro)) + g.lane_part(C, rb)) = v;
   }
 };

@@ -42,9 +42,10 @@ hipError_t launch_t(int N, cplx<T>* W, ColGeom g, long long ncols, const GenPara
 // it is needed; every other tile by the kernel WITHOUT it (skip_period = tiles per iy).
 template <class C, class IO0, class IO1, class CT>
 hipError_t launch_fast_one(const FastGenParams& gp, CT* W, ColGeom g, long long ncols, int kz0, int nzl,
-                           const CT* tw, hipStream_t s, bool po, hipEvent_t after_repair) {
-  IO0 io0; io0.base = W; io0.g = g; io0.gp = gp; io0.kz0 = kz0; io0.nzl = nzl; io0.rec = nullptr;
-  IO1 io1; io1.base = W; io1.g = g; io1.gp = gp; io1.kz0 = kz0; io1.nzl = nzl; io1.rec = nullptr;
+                           const CT* tw, hipStream_t s, bool po, hipEvent_t after_repair, int x0, int x1) {
+  CT* base = x0 > 0 ? W - (long long)x0 * g.row_stride : W;      // row x0 of the transform lands on row 0 of W
+  IO0 io0; io0.base = base; io0.g = g; io0.gp = gp; io0.kz0 = kz0; io0.nzl = nzl; io0.rec = nullptr; io0.x0 = x0; io0.x1 = x1;
+  IO1 io1; io1.base = base; io1.g = g; io1.gp = gp; io1.kz0 = kz0; io1.nzl = nzl; io1.rec = nullptr; io1.x0 = x0; io1.x1 = x1;
   const bool split = nzl > C::TC && nzl % C::TC == 0;
   if (po) {
     hipError_t e = launch_one<C, IO0>(io0, ncols, tw, s, true);
@@ -61,17 +62,17 @@ hipError_t launch_fast_one(const FastGenParams& gp, CT* W, ColGeom g, long long 
 }
 
 hipError_t launch_col_fastgen(int f64, int N, void* W, ColGeom g, long long ncols, const FastGenParams& gp, int kz0, int nzl,
-                              const void* tw, hipStream_t s, bool po, hipEvent_t after_repair) {
+                              const void* tw, hipStream_t s, bool po, hipEvent_t after_repair, int x0, int x1) {
   if (f64) {
     switch (N) {
-#define X(NN) case NN: return launch_fast_one<typename GenSel<double, NN>::type, FastGenColIO64<0>, FastGenColIO64<1>, cplx<double>>(gp, (cplx<double>*)W, g, ncols, kz0, nzl, (const cplx<double>*)tw, s, po, after_repair);
+#define X(NN) case NN: return launch_fast_one<typename GenSel<double, NN>::type, FastGenColIO64<0>, FastGenColIO64<1>, cplx<double>>(gp, (cplx<double>*)W, g, ncols, kz0, nzl, (const cplx<double>*)tw, s, po, after_repair, x0, x1);
       RF_COL_SIZES(X)
 #undef X
       default: return hipErrorInvalidValue;
     }
   }
   switch (N) {
-#define X(NN) case NN: return launch_fast_one<typename GenSel<float, NN>::type, FastGenColIOT<0, 0>, FastGenColIOT<0, 1>, cplx<float>>(gp, (cplx<float>*)W, g, ncols, kz0, nzl, (const cplx<float>*)tw, s, po, after_repair);
+#define X(NN) case NN: return launch_fast_one<typename GenSel<float, NN>::type, FastGenColIOT<0, 0>, FastGenColIOT<0, 1>, cplx<float>>(gp, (cplx<float>*)W, g, ncols, kz0, nzl, (const cplx<float>*)tw, s, po, after_repair, x0, x1);
     RF_COL_SIZES(X)
 #undef X
     default: return hipErrorInvalidValue;

@@ -17,8 +17,11 @@ hipError_t launch_col_gen(int f64, int N, void* W, ColGeom g, long long ncols, c
                           bool prepare_only = false);
 // x pass fused with the fast native generation (float32 arithmetic; float64 plans widen the result)
 // (when the kz = 0 tiles run as a separate repairing launch first, `after_repair` is recorded between the two)
+// [x0, x1): rows that are stored (replicated-generation mode: W is then the local x slab, row x0 at its start);
+// the default keeps every row.
 hipError_t launch_col_fastgen(int f64, int N, void* W, ColGeom g, long long ncols, const FastGenParams& gp, int kz0, int nzl,
-                              const void* tw, hipStream_t s, bool prepare_only = false, hipEvent_t after_repair = nullptr);
+                              const void* tw, hipStream_t s, bool prepare_only = false, hipEvent_t after_repair = nullptr,
+                              int x0 = 0, int x1 = 1 << 30);
 int col_tile_cols(int f64, int N);   // tile width (columns) of the strided pass of length N, 0 if unsupported
 // z pass of c2r: rows of M = nz/2 complex -> nz reals, scaled; partials[2*tile] = (sum, sumsq)
 hipError_t launch_row_c2r(int f64, int M, void* W, long long nrows, double scale, const void* tw,

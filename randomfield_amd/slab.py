@@ -110,7 +110,9 @@ class DistributedPlan(object):
     """One rank's share of a multi-GPU plan: DevicePlan(nranks, rank) + RCCL communicator.
 
     Reads RANK / WORLD_SIZE / LOCAL_RANK from the environment (as set by ``torch.distributed.run``).
-    After construction ``barrier()`` and ``allreduce()`` go through RCCL on the plan's stream."""
+    After construction ``barrier()`` and ``allreduce()`` go through RCCL on the plan's stream.
+    ``plan.set_replicated_generation(True)`` switches to the communication-free mode (every rank generates all
+    of k space and keeps its x slab; native generator only) -- see DESIGN.md section 5."""
 
     def __init__(self, nx, ny, nz, dtype=np.complex64, device=None, rank=None, world=None):
         from . import _hip
