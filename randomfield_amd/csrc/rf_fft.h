@@ -132,9 +132,11 @@ template <typename T> struct GenColIO {
 };
 
 // x pass fused with the fast float32 native generation (one Philox call per lane load)
+// SLAB: 1 = only rows [x0, x1) are stored (replicated-generation mode); a separate instantiation so that the
+// guard costs the ordinary kernel nothing.
 // FIX: 1 = this kernel repairs the kz = 0 slot (rolled loop through LDS); 0 = it does not (the tiles that
 // hold kz = 0 are then re-run by a FIX = 1 launch).  An out-of-line call was measured 3x slower (scratch).
-template <int AB = 0, int FIX = 1>
+template <int AB = 0, int FIX = 1, int SLAB = 0>
 struct FastGenColIOT {
   cplx<float>* base;
   ColGeom g;
@@ -188,8 +190,8 @@ struct FastGenColIOT {
     return fast_fix_kz0(gp, rec, seed, rb + ro, (int)(C / nzl));
   }
   RF_HD void store(long long C, int rb, int ro, const V16<float>& v) const {
-    const int row = rb + ro;
-    if (row < x0 || row >= x1) return;
+    // x0, x1 are multiples of the last pass's row stride L (the launcher checks it) and rb < L: the test is uniform
+    if (SLAB && (ro < x0 || ro >= x1)) return;
     *reinterpret_cast<V16<float>*>((base + g.uniform_part(ro)) + g.lane_part(C, rb)) = v;
   }
 };
@@ -198,7 +200,7 @@ using FastGenColIO = FastGenColIOT<0, 1>;
 // The same fast generation for float64 plans (native generator only: parity / reference-noise mode keeps the exact
 // float64 chain of GenColIO).  The deviates and sigma are formed in float32 -- hardware log / sin / cos, LDS
 // records -- and widened; the transform itself is float64.  One complex128 per lane (CPL = 1).
-template <int FIX = 1>
+template <int FIX = 1, int SLAB = 0>
 struct FastGenColIO64 {
   cplx<double>* base;
   ColGeom g;
@@ -235,8 +237,7 @@ struct FastGenColIO64 {
     return mk<double>((double)c.x, (double)c.y);
   }
   RF_HD void store(long long C, int rb, int ro, const V16<double>& v) const {
-    const int row = rb + ro;
-    if (row < x0 || row >= x1) return;
+    if (SLAB && (ro < x0 || ro >= x1)) return;          // uniform: see FastGenColIOT::store
     *reinterpret_cast<V16<double>*>((base + g.uniform_part(ro)) + g.lane_part(C, rb)) = v;
   }
 };

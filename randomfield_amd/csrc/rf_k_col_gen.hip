@@ -43,6 +43,9 @@ hipError_t launch_t(int N, cplx<T>* W, ColGeom g, long long ncols, const GenPara
 template <class C, class IO0, class IO1, class CT>
 hipError_t launch_fast_one(const FastGenParams& gp, CT* W, ColGeom g, long long ncols, int kz0, int nzl,
                            const CT* tw, hipStream_t s, bool po, hipEvent_t after_repair, int x0, int x1) {
+  // the slab-restricted instantiations test the workgroup-uniform row offset m * L of the last pass: the slab
+  // boundaries must be multiples of L = N / (radix of the last pass)
+  if ((x0 > 0 || x1 < C::N) && (C::NPASS < 2 || x0 % (C::N / C::RL) || x1 % (C::N / C::RL))) return hipErrorInvalidValue;
   CT* base = x0 > 0 ? W - (long long)x0 * g.row_stride : W;      // row x0 of the transform lands on row 0 of W
   IO0 io0; io0.base = base; io0.g = g; io0.gp = gp; io0.kz0 = kz0; io0.nzl = nzl; io0.rec = nullptr; io0.x0 = x0; io0.x1 = x1;
   IO1 io1; io1.base = base; io1.g = g; io1.gp = gp; io1.kz0 = kz0; io1.nzl = nzl; io1.rec = nullptr; io1.x0 = x0; io1.x1 = x1;
@@ -63,20 +66,31 @@ hipError_t launch_fast_one(const FastGenParams& gp, CT* W, ColGeom g, long long 
 
 hipError_t launch_col_fastgen(int f64, int N, void* W, ColGeom g, long long ncols, const FastGenParams& gp, int kz0, int nzl,
                               const void* tw, hipStream_t s, bool po, hipEvent_t after_repair, int x0, int x1) {
+  const bool slab = x0 > 0 || x1 < N;          // replicated-generation mode: the SLAB instantiations guard their stores
+#define RF_FAST(T, IO0, IO1)                                                                                              \
+  switch (N) {                                                                                                           \
+    RF_COL_SIZES(X)                                                                                                       \
+    default: return hipErrorInvalidValue;                                                                                \
+  }
   if (f64) {
-    switch (N) {
-#define X(NN) case NN: return launch_fast_one<typename GenSel<double, NN>::type, FastGenColIO64<0>, FastGenColIO64<1>, cplx<double>>(gp, (cplx<double>*)W, g, ncols, kz0, nzl, (const cplx<double>*)tw, s, po, after_repair, x0, x1);
-      RF_COL_SIZES(X)
+    if (slab || po) {
+#define X(NN) case NN: { hipError_t e = launch_fast_one<typename GenSel<double, NN>::type, FastGenColIO64<0, 1>, FastGenColIO64<1, 1>, cplx<double>>(gp, (cplx<double>*)W, g, ncols, kz0, nzl, (const cplx<double>*)tw, s, po, after_repair, x0, x1); if (!po || e != hipSuccess) return e; break; }
+      RF_FAST(double, 0, 0)
 #undef X
-      default: return hipErrorInvalidValue;
     }
-  }
-  switch (N) {
-#define X(NN) case NN: return launch_fast_one<typename GenSel<float, NN>::type, FastGenColIOT<0, 0>, FastGenColIOT<0, 1>, cplx<float>>(gp, (cplx<float>*)W, g, ncols, kz0, nzl, (const cplx<float>*)tw, s, po, after_repair, x0, x1);
-    RF_COL_SIZES(X)
+#define X(NN) case NN: return launch_fast_one<typename GenSel<double, NN>::type, FastGenColIO64<0, 0>, FastGenColIO64<1, 0>, cplx<double>>(gp, (cplx<double>*)W, g, ncols, kz0, nzl, (const cplx<double>*)tw, s, po, after_repair, x0, x1);
+    RF_FAST(double, 0, 0)
 #undef X
-    default: return hipErrorInvalidValue;
   }
+  if (slab || po) {
+#define X(NN) case NN: { hipError_t e = launch_fast_one<typename GenSel<float, NN>::type, FastGenColIOT<0, 0, 1>, FastGenColIOT<0, 1, 1>, cplx<float>>(gp, (cplx<float>*)W, g, ncols, kz0, nzl, (const cplx<float>*)tw, s, po, after_repair, x0, x1); if (!po || e != hipSuccess) return e; break; }
+    RF_FAST(float, 0, 0)
+#undef X
+  }
+#define X(NN) case NN: return launch_fast_one<typename GenSel<float, NN>::type, FastGenColIOT<0, 0, 0>, FastGenColIOT<0, 1, 0>, cplx<float>>(gp, (cplx<float>*)W, g, ncols, kz0, nzl, (const cplx<float>*)tw, s, po, after_repair, x0, x1);
+  RF_FAST(float, 0, 0)
+#undef X
+#undef RF_FAST
 }
 
 hipError_t launch_col_gen(int f64, int N, void* W, ColGeom g, long long ncols, const GenParams& gp,

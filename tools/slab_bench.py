@@ -25,5 +25,5 @@ def run(shape, nranks, rank):
 
 run((2048, 2048, 2048), 8, 0)
 run((2048, 2048, 2048), 8, 3)
-run((2048, 2048, 1024), 4, 1)
-run((2048, 1024, 1024), 2, 1)
+run((1024, 2048, 2048), 4, 1)
+run((1024, 1024, 2048), 2, 1)
