@@ -208,7 +208,7 @@ def main():
     traffic = None
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
-        key = ["FastGenColIOT<0, 0>", "PlainColIO", "row_c2r_kernel"][dom]
+        key = ["FastGenColIOT<0, 0, 0>", "PlainColIO", "row_c2r_kernel"][dom]
         if (nx, ny, nz) == (1024, 1024, 1024) and args.gpus == 1:
             for name, v in tj["kernels"].items():
                 if key in name:
