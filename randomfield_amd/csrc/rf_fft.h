@@ -406,7 +406,7 @@ struct RowCfg {
   static_assert(R1_ * R2_ * R3_ == M_, "radices must multiply to M");
   static constexpr int NPASS = (R2 == 1 ? 1 : (R3 == 1 ? 2 : 3));
   static constexpr int RL = (NPASS == 1 ? R1 : (NPASS == 2 ? R2 : R3));
-  static constexpr int RS = M + ((M - 1) >> 4) + 1 + 1;       // LDS row stride (complex), odd-ish shift between rows
+  static constexpr int RS = M + ((M - 1) >> 3) + 1 + 1;       // LDS row stride (complex): pad16() of the last element + 2
   static constexpr int TILE_BYTES = (NPASS == 1 ? 0 : NRT * RS * (int)sizeof(cplx<T>));
   static constexpr int TW_BYTES = 2 * M * (int)sizeof(cplx<T>);    // twiddle table exp(2 pi i q / 2M), staged behind the tile
   static constexpr int LDS_BYTES = TILE_BYTES + TW_BYTES;
