@@ -213,6 +213,9 @@ FastGenParams make_fast(rf_plan* p, uint64_t seed, bool seed_from_dev, const uin
 
 // (re)build the fast-path records once both the k grid and the power table are known
 int build_fast(rf_plan* p) {
+  // captured batch graphs carry the generation parameters (table pointers, bin scalars) by value: they are stale now
+  RF_HIP(hipStreamSynchronize(p->stream));
+  drop_graphs(p);
   p->have_fast = false;
   if (!p->have_kgrid || !p->have_power) return 0;
   double kmax2 = 0, kmin2 = 1e300;

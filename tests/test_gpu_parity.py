@@ -682,3 +682,28 @@ def test_replicated_generation_mode_matches_single_rank(hip, dpower, shape, dtyp
     n = float(nx) * ny * nz
     assert abs(np.sqrt(s2 / n - (s1 / n) ** 2) - std) <= 1e-9 * std
     one.close()
+
+
+def test_batch_graphs_follow_table_changes(hip, dpower):
+    """Captured batch graphs carry the generation tables by value: replacing P(k) (or the k grid) between two batches
+    of the same length must not replay the old tables (regression: the graphs used to survive rf_set_power)."""
+    k, Pk = dpower
+    shape = (64, 64, 64)
+    plan = make_plan(hip, shape, np.complex64, k, Pk)
+    seeds = np.array([3, 4, 5], dtype=np.uint64)
+    rms1 = plan.realise_batch(seeds)
+    f1 = plan.download_real()
+    xt, st = cpu_ref.sigma_table(k, 4.0 * Pk, 64, 64, 64, SPACING)      # 4 x the power = 2 x the amplitude
+    plan.set_power(xt, st)
+    rms2 = plan.realise_batch(seeds)
+    f2 = plan.download_real()
+    assert np.allclose(rms2, 2.0 * rms1, rtol=1e-5)
+    assert np.max(np.abs(f2 - 2.0 * f1)) <= 1e-5 * rms2[-1]
+    # a different table shape (fewer rows: new record layout) as well
+    sub = slice(None, None, 3)
+    k3, P3 = np.append(k[sub], k[-1]), np.append(Pk[sub], Pk[-1])
+    plan.set_power(*cpu_ref.sigma_table(k3, P3, 64, 64, 64, SPACING))
+    rms3 = plan.realise_batch(seeds)
+    plan.realise(seed=5)
+    assert abs(plan.moments()[1] - rms3[-1]) <= 1e-12 * rms3[-1]
+    plan.close()
