@@ -218,6 +218,7 @@ int build_fast(rf_plan* p) {
   drop_graphs(p);
   p->have_fast = false;
   if (!p->have_kgrid || !p->have_power) return 0;
+  if (!col_fastgen_supported(p->f64, p->nx)) return 0;   // e.g. float64, nx = 2048: the exact kernel is used
   double kmax2 = 0, kmin2 = 1e300;
   auto scan = [&](const std::vector<double>& a) { for (double v : a) if (v > 0 && v < kmin2) kmin2 = v; };
   scan(p->h_kx2); scan(p->h_ky2); scan(p->h_kz2);

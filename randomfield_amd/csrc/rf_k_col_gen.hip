@@ -66,6 +66,7 @@ hipError_t launch_fast_one(const FastGenParams& gp, CT* W, ColGeom g, long long 
 
 hipError_t launch_col_fastgen(int f64, int N, void* W, ColGeom g, long long ncols, const FastGenParams& gp, int kz0, int nzl,
                               const void* tw, hipStream_t s, bool po, hipEvent_t after_repair, int x0, int x1) {
+  if (!col_fastgen_supported(f64, N)) return po ? hipSuccess : hipErrorInvalidValue;    // the caller keeps the exact kernel
   const bool slab = x0 > 0 || x1 < N;          // replicated-generation mode: the SLAB instantiations guard their stores
 #define RF_FAST(T, IO0, IO1)                                                                                              \
   switch (N) {                                                                                                           \
@@ -91,6 +92,17 @@ hipError_t launch_col_fastgen(int f64, int N, void* W, ColGeom g, long long ncol
   RF_FAST(float, 0, 0)
 #undef X
 #undef RF_FAST
+}
+
+// does the fast-generation x pass of this length fit a CU's LDS (tile + twiddles + the generation tables)?
+bool col_fastgen_supported(int f64, int N) {
+  switch (N) {
+#define X(NN) case NN: return f64 ? GenSel<double, NN>::type::LDS_BYTES + FastGenColIO64<1, 0>::LDS_EXTRA <= 160 * 1024 \
+                                  : GenSel<float, NN>::type::LDS_BYTES + FastGenColIOT<0, 1, 0>::LDS_EXTRA <= 160 * 1024;
+    RF_COL_SIZES(X)
+#undef X
+    default: return false;
+  }
 }
 
 hipError_t launch_col_gen(int f64, int N, void* W, ColGeom g, long long ncols, const GenParams& gp,

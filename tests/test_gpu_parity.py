@@ -707,3 +707,18 @@ def test_batch_graphs_follow_table_changes(hip, dpower):
     plan.realise(seed=5)
     assert abs(plan.moments()[1] - rms3[-1]) <= 1e-12 * rms3[-1]
     plan.close()
+
+
+@pytest.mark.parametrize("shape", [(2048, 8, 32), (8, 2048, 32), (16, 8, 2048)])
+def test_float64_plans_with_a_2048_axis(hip, dpower, shape):
+    """float64 plans whose length-2048 tile fills a CU's LDS (no room for the fast generation tables: the exact kernel
+    is used for nx = 2048) -- regression: such plans failed at creation."""
+    nx, ny, nz = shape
+    k, Pk = dpower
+    plan = make_plan(hip, shape, np.complex128, k, Pk)
+    plan.realise(seed=9)
+    d = plan.download_real()
+    noise = cpu_ref.native_noise(9, nx, ny, nz, np.complex128)
+    ref, rms = cpu_ref.generate_delta_field(nx, ny, nz, SPACING, k, Pk, noise=noise, dtype=np.complex128)
+    assert np.max(np.abs(d - ref)) <= 2e-5 * rms
+    plan.close()
