@@ -654,6 +654,8 @@ int rf_plan_set_flag(rf_plan* p, int flag, int value) {
   RF_HIP(hipStreamSynchronize(p->stream));
   if (flag == RF_FLAG_REPLICATED_GENERATION) {
     RF_REQUIRE(p->nranks > 1, "RF_FLAG_REPLICATED_GENERATION is for multi-rank plans");
+    RF_REQUIRE(!value || col_replicate_supported(p->f64, p->nx, p->nranks),
+               "replicated generation is not available for this shape (nx too small for the number of ranks, or float64 with nx = 2048)");
     p->replicate = value != 0;
     return 0;
   }

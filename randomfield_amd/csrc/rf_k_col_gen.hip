@@ -105,6 +105,18 @@ bool col_fastgen_supported(int f64, int N) {
   }
 }
 
+// replicated-generation mode stores rows [rank N/P, (rank+1) N/P) only and tests the row offset m * L of the last pass:
+// available when the x pass has an LDS stage and N/P is a multiple of L = N / (radix of the last pass)
+bool col_replicate_supported(int f64, int N, int nranks) {
+  if (!col_fastgen_supported(f64, N) || nranks < 1 || N % nranks) return false;
+  switch (N) {
+#define X(NN) case NN: { using C = GenSel<float, NN>::type; return C::NPASS >= 2 && (NN / nranks) % (NN / C::RL) == 0; }
+    RF_COL_SIZES(X)
+#undef X
+    default: return false;
+  }
+}
+
 hipError_t launch_col_gen(int f64, int N, void* W, ColGeom g, long long ncols, const GenParams& gp,
                           const void* kspace, int kz0, int nzl, const void* tw, hipStream_t s, bool po) {
   if (f64) return launch_t<double>(N, (cplx<double>*)W, g, ncols, gp, (const cplx<double>*)kspace, kz0, nzl, (const cplx<double>*)tw, s, po);

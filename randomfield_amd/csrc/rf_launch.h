@@ -18,6 +18,7 @@ hipError_t launch_col_gen(int f64, int N, void* W, ColGeom g, long long ncols, c
 // x pass fused with the fast native generation (float32 arithmetic; float64 plans widen the result)
 // (when the kz = 0 tiles run as a separate repairing launch first, `after_repair` is recorded between the two)
 bool col_fastgen_supported(int f64, int N);   // false when tile + twiddles + generation tables exceed a CU's LDS (float64, N = 2048)
+bool col_replicate_supported(int f64, int N, int nranks);   // can the x pass of length N keep 1/nranks of its rows?
 // [x0, x1): rows that are stored (replicated-generation mode: W is then the local x slab, row x0 at its start);
 // the default keeps every row.
 hipError_t launch_col_fastgen(int f64, int N, void* W, ColGeom g, long long ncols, const FastGenParams& gp, int kz0, int nzl,
