@@ -75,7 +75,10 @@ def main_multi(args, rank, world, local_rank, shape, power, spacing):
     calib = {}
     if world > 1 and mode == "auto":
         for m in ("exchange", "replicate"):
-            plan.set_replicated_generation(m == "replicate")
+            try:
+                plan.set_replicated_generation(m == "replicate")
+            except RuntimeError:          # shape without a replicated-generation instantiation: the exchange mode it is
+                continue
             plan.realise_batch(np.arange(7000, 7002, dtype=np.uint64), want_rms=False)
             plan.sync()
             dplan.barrier()
