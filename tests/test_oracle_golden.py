@@ -157,3 +157,23 @@ def test_philox_known_answer():
     for v in (re, im):
         assert abs(v.mean()) < 0.01 and abs(v.std() - 1) < 0.01
     assert abs(np.mean(re * im)) < 0.01
+
+
+def test_simps_restatement_against_scipy():
+    """The oracle's restatement of scipy.integrate.simps(even='avg') (what generate.py:405 called; removed from
+    current scipy): the odd-count branch equals today's scipy.integrate.simpson, the even-count branch equals its
+    published definition -- the average of (Simpson on the first N-1 samples + trapezoid on the last interval) and
+    (trapezoid on the first interval + Simpson on the last N-1) -- built from scipy's own odd-count rule."""
+    from scipy import integrate
+    rng = np.random.RandomState(2)
+    for N in range(1, 14):
+        x = np.cumsum(0.5 + rng.rand(N))                     # non-uniform abscissae too
+        y = rng.normal(size=(3, N))
+        got = cpu_ref.simps_avg(y, x)
+        if N % 2:
+            ref = integrate.simpson(y, x=x) if N > 1 else np.zeros(3)
+        else:
+            a = (integrate.simpson(y[:, :-1], x=x[:-1]) if N > 2 else 0.0) + 0.5 * (x[-1] - x[-2]) * (y[:, -1] + y[:, -2])
+            b = 0.5 * (x[1] - x[0]) * (y[:, 0] + y[:, 1]) + (integrate.simpson(y[:, 1:], x=x[1:]) if N > 2 else 0.0)
+            ref = 0.5 * (a + b)
+        assert np.allclose(got, ref, rtol=1e-13, atol=1e-13), N
