@@ -6,6 +6,7 @@
 // checks index math, twiddles, Hermitian packing and the generation rules
 // against the oracle without a GPU.  It is not a product path: nothing in
 // randomfield_amd/ loads it.
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <vector>
@@ -23,6 +24,7 @@ void run_col_pass(const IO& io_in, long long ncols, const cplx<typename C::T>* t
   std::vector<cx> lds((size_t)(C::LDS_BYTES + IO::LDS_EXTRA) / sizeof(cx));   // exactly the kernel's dynamic LDS
   std::vector<typename F::Regs> regs(C::NT);
   std::vector<IO> ios(C::NT, io_in);             // every "thread" has its own copy of the kernel argument
+  for (auto& io : ios) io.bind_seed();
   const long long ntiles = ncols / C::TC;
   for (long long tile = 0; tile < ntiles; ++tile) {
     const cx* ltw = tw;
@@ -228,16 +230,13 @@ template <typename T, class IO>
 int realise_fast_impl(int nx, int ny, int nz, const GenHost& h, uint64_t seed, double xlo, double xhi, double dkx,
                       cplx<T>* W, double* s1, double* s2) {
   const long long nzc = nz / 2;
-  std::vector<float> ky2(ny), kz2(nzc + 1);
-  for (int i = 0; i < ny; ++i) ky2[i] = (float)h.gp.ky2[i];
-  for (int i = 0; i <= nzc; ++i) kz2[i] = (float)h.gp.kz2[i];
   std::vector<FastRec> rec;
   IO io;
   io.base = W; io.g = ColGeom{(long long)ny * nzc, 0, (long long)ny * nzc}; io.kz0 = 0; io.nzl = (int)nzc; io.rec = nullptr;
   FastGenParams& f = io.gp;
   double x0, dx;
   if (!build_fast_records(h.tab, xlo, xhi, rec, x0, dx)) return -3;
-  f.nx = nx; f.ny = ny; f.nz = nz; f.dkx = (float)dkx; f.ky2 = ky2.data(); f.kz2 = kz2.data();
+  f.nx = nx; f.ny = ny; f.nz = nz; f.dkx = (float)dkx; f.dky = (float)std::sqrt(h.gp.ky2[1]); f.dkz = (float)std::sqrt(h.gp.kz2[1]);
   f.rec = rec.data(); f.nbins = (int)rec.size();
   f.u_scale = (float)(0.5 * std::log10(2.0) / dx); f.u_off = (float)(-x0 / dx);
   f.seed = seed; f.seed_dev = nullptr;

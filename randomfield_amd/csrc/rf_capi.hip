@@ -115,10 +115,9 @@ struct rf_plan {
   double x0 = 0, inv_dx = 0;
   bool have_kgrid = false, have_power = false;
   // fast float32 native generation: float copies of the k^2 tables + per-bin sigma records
-  float *ky2f = nullptr, *kz2f = nullptr;
   FastRec* frec = nullptr;
   int fnbins = 0;
-  float fdkx = 0, fu_scale = 0, fu_off = 0;
+  float fdkx = 0, fdky = 0, fdkz = 0, fu_scale = 0, fu_off = 0;
   bool have_fast = false, exact_gen = false;
   std::vector<double> h_kx2, h_ky2, h_kz2;   // host copies (k range of the grid for the fast records)
   SigmaTableHost h_tab;
@@ -205,7 +204,7 @@ int upload_noise(rf_plan* p, int mode, const double* noise_host) {
 FastGenParams make_fast(rf_plan* p, uint64_t seed, bool seed_from_dev, const uint64_t* seed_ptr) {
   FastGenParams f;
   f.nx = p->nx; f.ny = p->ny; f.nz = p->nz;
-  f.dkx = p->fdkx; f.ky2 = p->ky2f; f.kz2 = p->kz2f;
+  f.dkx = p->fdkx; f.dky = p->fdky; f.dkz = p->fdkz;
   f.rec = p->frec; f.nbins = p->fnbins; f.u_scale = p->fu_scale; f.u_off = p->fu_off;
   f.seed = seed; f.seed_dev = seed_from_dev ? seed_ptr : nullptr;
   return f;
@@ -230,14 +229,21 @@ int build_fast(rf_plan* p) {
   if (!build_fast_records(p->h_tab, 0.5 * std::log10(kmin2) - 0.01, 0.5 * std::log10(kmax2) + 0.01, rec, x0, dx))
     return 0;   // knots too dense for the per-bin records: the exact kernel is used instead
   if ((int)rec.size() > FAST_LDS_BINS) return 0;   // the records must fit the kernel's LDS table
-  // the fast kernel forms kx arithmetically: kx(i) = dkx * signed index; needs a uniform fftfreq-style x axis
-  if (p->nx < 2 || !(p->h_kx2[1] > 0)) return 0;
-  p->fdkx = (float)std::sqrt(p->h_kx2[1]);
-  for (int i = 0; i < p->nx; ++i) {
-    const double j = i < p->nx / 2 ? i : i - p->nx;
-    const double want = j * j * p->h_kx2[1];
-    if (std::fabs(p->h_kx2[i] - want) > 1e-9 * (want + 1e-300)) return 0;   // not a regular grid: exact kernel
-  }
+  // the fast kernel forms |k|^2 arithmetically, k_axis(i) = dk_axis * signed index: needs uniform fftfreq-style axes
+  // (powertools.py:27-37 always makes them so); anything else keeps the exact kernel, which reads the tables
+  auto regular = [](const std::vector<double>& a, int n, bool half, float& dk) {
+    if (n < 2 || (int)a.size() < 2 || !(a[1] > 0)) return false;
+    for (int i = 0; i < (int)a.size(); ++i) {
+      const double j = (half || i < n / 2) ? i : i - n;
+      const double want = j * j * a[1];
+      if (std::fabs(a[i] - want) > 1e-9 * (want + 1e-300)) return false;
+    }
+    dk = (float)std::sqrt(a[1]);
+    return true;
+  };
+  if (!regular(p->h_kx2, p->nx, false, p->fdkx) || !regular(p->h_ky2, p->ny, false, p->fdky) ||
+      !regular(p->h_kz2, p->nz, true, p->fdkz))
+    return 0;
   p->fu_scale = (float)(0.5 * std::log10(2.0) / dx);
   p->fu_off = (float)(-x0 / dx);
   if (p->frec) RF_HIP(hipFree(p->frec));
@@ -521,8 +527,6 @@ int rf_plan_create(rf_plan** out, int nx, int ny, int nz, int dtype, int device,
       (e = hipMalloc((void**)&p->kx2, nx * sizeof(double))) != hipSuccess ||
       (e = hipMalloc((void**)&p->ky2, ny * sizeof(double))) != hipSuccess ||
       (e = hipMalloc((void**)&p->kz2, (p->nzc + 1) * sizeof(double))) != hipSuccess ||
-      (e = hipMalloc((void**)&p->ky2f, ny * sizeof(float))) != hipSuccess ||
-      (e = hipMalloc((void**)&p->kz2f, (p->nzc + 1) * sizeof(float))) != hipSuccess ||
       (e = hipMalloc((void**)&p->ztab, 2 * nz * sizeof(double))) != hipSuccess)
     return cleanup(fail(2, std::string("hipMalloc workspace: ") + hipGetErrorString(e)));
   for (auto& ev : p->ev)
@@ -630,8 +634,7 @@ int rf_plan_destroy(rf_plan* p) {
   if (p->comm_stream) { (void)hipStreamSynchronize(p->comm_stream); (void)hipStreamDestroy(p->comm_stream); }
   for (auto& e : p->pev) if (e) (void)hipEventDestroy(e);
   void* bufs[] = {p->W, p->R, p->W2, p->R2, p->K, p->P, p->tw_x, p->tw_y, p->tw_z, p->kx2, p->ky2, p->kz2, p->xt, p->st, p->sl, p->bin,
-                  p->noise, p->mt_pos, p->mt_states, p->mt_counts, p->mt_offsets, p->partials, p->stats, p->seeds_dev, p->ztab, p->ky2f,
-                  p->kz2f, p->frec};
+                  p->noise, p->mt_pos, p->mt_states, p->mt_counts, p->mt_offsets, p->partials, p->stats, p->seeds_dev, p->ztab, p->frec};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   for (auto& ev : p->ev)
@@ -688,14 +691,6 @@ int rf_set_kgrid(rf_plan* p, const double* kx2, const double* ky2, const double*
   RF_HIP(hipMemcpyAsync(p->kz2, kz2, (p->nzc + 1) * sizeof(double), hipMemcpyHostToDevice, p->stream));
   RF_HIP(hipStreamSynchronize(p->stream));
   p->h_kx2.assign(kx2, kx2 + p->nx); p->h_ky2.assign(ky2, ky2 + p->ny); p->h_kz2.assign(kz2, kz2 + p->nzc + 1);
-  std::vector<float> f;
-  auto up = [&](float* dst, const double* src, int n) {
-    f.resize(n);
-    for (int i = 0; i < n; ++i) f[i] = (float)src[i];
-    return hipMemcpy(dst, f.data(), n * sizeof(float), hipMemcpyHostToDevice);
-  };
-  RF_HIP(up(p->ky2f, ky2, p->ny));
-  RF_HIP(up(p->kz2f, kz2, p->nzc + 1));
   p->have_kgrid = true;
   return build_fast(p);
 }

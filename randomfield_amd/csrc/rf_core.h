@@ -162,6 +162,8 @@ RF_HD uint64_t pin_uniform(uint64_t x) {
 #endif
 }
 
+RF_HD long long pin_uniform_ll(long long x) { return (long long)pin_uniform((uint64_t)x); }
+
 RF_HD uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
 #if defined(__HIP_DEVICE_COMPILE__)
   return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);      // one v_bitop3_b32 instead of two v_xor_b32
@@ -394,9 +396,9 @@ struct FastRec {          // 16 bytes per bin of the uniform acceleration grid i
 
 struct FastGenParams {
   int nx, ny, nz;
-  float dkx;              // kx(i) = dkx * signed index  (2 pi / (nx spacing))
-  const float* ky2;       // float32 copies of the k^2 axis tables
-  const float* kz2;
+  float dkx, dky, dkz;    // k_axis(i) = dk_axis * signed fftfreq index (2 pi / (n spacing)): the kernels form |k|^2
+                          // arithmetically, so the generation loop reads no global memory at all (on gfx950 a load
+                          // would also wait for every store issued before it -- one counter for both)
   const FastRec* rec;     // global copy of the records; the kernels stage them in LDS when nbins <= FAST_LDS_BINS
   int nbins;
   float u_scale, u_off;   // bin coordinate u = log2(k^2) * u_scale + u_off
@@ -432,9 +434,14 @@ RF_HD float fast_sigma(const FastGenParams& g, const FastRec* rec, float t /* |k
 
 // signed fftfreq index of ix without a select: nx is a power of two, so (ix & nx/2) is 0 or nx/2
 RF_HD int fast_signed_index(int ix, int nx) { return ix - 2 * (ix & (nx >> 1)); }
-RF_HD float fast_kx2(const FastGenParams& g, int ix) {
-  const float kx = (float)fast_signed_index(ix, g.nx) * g.dkx;
-  return kx * kx;
+// kx^2 + ky^2 of column (ix, iy), and |k|^2 of its cell kz (0 <= kz <= nz/2: no wrap on the half axis)
+RF_HD float fast_kxy2(const FastGenParams& g, int ix, int iy) {
+  const float kx = (float)fast_signed_index(ix, g.nx) * g.dkx, ky = (float)fast_signed_index(iy, g.ny) * g.dky;
+  return fmaf(kx, kx, ky * ky);
+}
+RF_HD float fast_k2(const FastGenParams& g, float kxy, int kz) {
+  const float k = (float)kz * g.dkz;
+  return fmaf(k, k, kxy);
 }
 
 // Philox counter of the cell pair (kz even, kz + 1) of column (ix, iy): half the native noise index
@@ -445,15 +452,15 @@ RF_HD uint64_t fast_pair_counter(const FastGenParams& g, int ix, int iy, int kz)
 // AB: development-only ablation mask (1: no Philox, 2: no sigma lookup, 4: no Box-Muller); 0 in the product.
 // The two packed cells kz, kz + 1 of one column from ONE Philox call: k^2 = kxy + kz2a / kz2b.
 template <int AB = 0>
-RF_HD void fast_gen_pair_at(const FastGenParams& g, const FastRec* rec, uint64_t seed, uint64_t ctr, float kxy,
-                            float kz2a, float kz2b, cplx<float>& c0, cplx<float>& c1) {
+RF_HD void fast_gen_pair_at(const FastGenParams& g, const FastRec* rec, uint64_t seed, uint64_t ctr, float k2a,
+                            float k2b, cplx<float>& c0, cplx<float>& c1) {
   PhiloxOut o;
   if (AB & 1) { o.w[0] = (uint32_t)ctr; o.w[1] = (uint32_t)ctr * 3u; o.w[2] = (uint32_t)ctr * 5u; o.w[3] = (uint32_t)ctr * 7u; }
   else if (AB & 8) o = philox4x32<7>(ctr, 0, seed);   // timing experiment only
   else o = philox4x32_10(ctr, 0, seed);
   float g0, g1;
-  const float s0 = (AB & 2) ? kxy + kz2a : fast_sigma(g, rec, kxy + kz2a);
-  const float s1 = (AB & 2) ? kxy + kz2b : fast_sigma(g, rec, kxy + kz2b);
+  const float s0 = (AB & 2) ? k2a : fast_sigma(g, rec, k2a);
+  const float s1 = (AB & 2) ? k2b : fast_sigma(g, rec, k2b);
   if (AB & 4) { g0 = s0 * (float)o.w[0]; g1 = s0 * (float)o.w[1]; } else BoxMuller<float>::run_scaled(o.w[0], o.w[1], s0, g0, g1);
   c0 = mk<float>(g0, g1);
   if (AB & 4) { g0 = s1 * (float)o.w[2]; g1 = s1 * (float)o.w[3]; } else BoxMuller<float>::run_scaled(o.w[2], o.w[3], s1, g0, g1);
@@ -462,8 +469,8 @@ RF_HD void fast_gen_pair_at(const FastGenParams& g, const FastRec* rec, uint64_t
 template <int AB = 0>
 RF_HD void fast_gen_pair(const FastGenParams& g, const FastRec* rec, uint64_t seed, int ix, int iy, int kz,
                          cplx<float>& c0, cplx<float>& c1) {
-  fast_gen_pair_at<AB>(g, rec, seed, fast_pair_counter(g, ix, iy, kz), fast_kx2(g, ix) + g.ky2[iy], g.kz2[kz], g.kz2[kz + 1],
-                       c0, c1);
+  const float kxy = fast_kxy2(g, ix, iy);
+  fast_gen_pair_at<AB>(g, rec, seed, fast_pair_counter(g, ix, iy, kz), fast_k2(g, kxy, kz), fast_k2(g, kxy, kz + 1), c0, c1);
 }
 
 // One packed cell with native noise index ci (float64 plans: one complex128 per lane, so the two cells of a Philox
@@ -483,14 +490,14 @@ RF_HD cplx<float> fast_fix_kz0(const FastGenParams& g, const FastRec* rec, uint6
   const int role = sym_role(g.nx, g.ny, ix, iy);
   int sx = ix, sy = iy;
   if (role == RF_DEST) { sx = (g.nx - ix) % g.nx; sy = (g.ny - iy) % g.ny; }
-  const float kxy_s = fast_kx2(g, sx) + g.ky2[sy];
+  const float kxy_s = fast_kxy2(g, sx, sy);
   const uint64_t scol = (uint64_t)sx * (uint64_t)g.ny + (uint64_t)sy;
   float g0, g1;
-  const float s0 = fast_sigma(g, rec, kxy_s + g.kz2[0]);
+  const float s0 = fast_sigma(g, rec, fast_k2(g, kxy_s, 0));
   const PhiloxOut os = philox4x32_10((scol * (uint64_t)nzc) >> 1, 0, seed);
   BoxMuller<float>::run_scaled(os.w[0], os.w[1], s0, g0, g1);
   cplx<float> a = mk<float>(g0, g1);
-  const float sn = fast_sigma(g, rec, kxy_s + g.kz2[nzc]);
+  const float sn = fast_sigma(g, rec, fast_k2(g, kxy_s, nzc));
   const uint64_t cn = (uint64_t)g.nx * (uint64_t)g.ny * (uint64_t)nzc + scol;
   const PhiloxOut on = philox4x32_10(cn >> 1, 0, seed);
   if (cn & 1) BoxMuller<float>::run_scaled(on.w[2], on.w[3], sn, g0, g1);

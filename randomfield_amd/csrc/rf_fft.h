@@ -30,6 +30,28 @@ template <typename T> struct alignas(16) V16 {
   static constexpr int CPL = 16 / (int)sizeof(cplx<T>);
   cplx<T> c[CPL];
 };
+// One 16-byte global access per V16: through a 4 x 32-bit vector type, so that the compiler cannot split it into two
+// 8-byte accesses when the halves sit in non-adjacent registers (it did: half-width stores, twice as many of them).
+template <typename T> RF_HD void v16_store(void* p, const V16<T>& v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef unsigned u4 __attribute__((ext_vector_type(4)));
+  union { V16<T> s; u4 q; } u;
+  u.s = v;
+  *reinterpret_cast<u4*>(p) = u.q;
+#else
+  *reinterpret_cast<V16<T>*>(p) = v;
+#endif
+}
+template <typename T> RF_HD V16<T> v16_load(const void* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef unsigned u4 __attribute__((ext_vector_type(4)));
+  union { V16<T> s; u4 q; } u;
+  u.q = *reinterpret_cast<const u4*>(p);
+  return u.s;
+#else
+  return *reinterpret_cast<const V16<T>*>(p);
+#endif
+}
 
 // ---------------------------------------------------------------------------
 // Column pass configuration
@@ -56,33 +78,61 @@ struct ColCfg {
   static constexpr int IT2 = (NPASS == 3 ? ceil_div(N / R2, BPM) : 1);
   static constexpr int ITL = ceil_div(N / RL, BPI);
   RF_HD static int prow(int r) { return r ^ ((r / R1) & 1); }
+  // most butterflies per column of any global-memory pass (first: N / R1, last: N / RL): bounds the lane offsets
+  static constexpr int LMAX = N / (R1 < RL ? R1 : RL);
 };
 
 // Addressing of a column pass over the packed device array.
 //   flattened column C in [0, ncols); element (row, C) lives at
-//   (C / inner) * outer_stride + (C % inner) + row * row_stride   (complex units)
-// The IO calls name a cell as (C, rb, ro): row = rb + ro with rb the lane's butterfly index and ro = m * L
-// the same for all lanes.  So an address splits into a lane part that does not depend on m (a common
-// subexpression of the R unrolled accesses) and a workgroup-uniform part (scalar ALU).
+//   (C / inner) * outer_stride + (C % inner) + row * row_stride   (complex units; inner is a power of two)
+// The IO calls name a cell as (C0, cl, rb, ro): column C0 + cl with C0 the first column of the workgroup's tile
+// (a tile never straddles `inner`), row rb + ro with rb the lane's butterfly index and ro = m * L the same for
+// all lanes.  So an address splits into a workgroup-uniform 64-bit part (scalar ALU; it becomes the SGPR base of
+// the memory instruction) and a lane part that does not depend on m and fits 32 bits: ONE address VGPR serves all
+// R accesses of a butterfly (64-bit lane addresses cost two VGPRs and a 64-bit add per access).  WIDE (a template
+// flag of the IO) = the lane part may exceed 32 bits of bytes: only float64 passes of length 2048 over 16-MiB-plus
+// row strides need it (needs_wide(), checked by the launchers).
 struct ColGeom {
   long long inner, outer_stride, row_stride;
-  RF_HD long long lane_part(long long C, int rb) const {
-    return (C / inner) * outer_stride + (C % inner) + (long long)rb * row_stride;
+  // (tiles start at multiples of their width, and widths and `inner` are powers of two: either a tile lies inside
+  // one run of `inner` columns, or it covers whole runs and the lane's column offset cl selects the run)
+  RF_HD int inner_shift() const { return 63 - __builtin_clzll((unsigned long long)inner); }
+  RF_HD long long uniform_part(long long C0, int ro) const {
+    return (C0 >> inner_shift()) * outer_stride + (C0 & (inner - 1)) + (long long)ro * row_stride;
   }
-  RF_HD long long uniform_part(int ro) const { return (long long)ro * row_stride; }
+  RF_HD uint32_t lane_part(int cl, int rb) const {
+    return (uint32_t)(cl >> inner_shift()) * (uint32_t)outer_stride + ((uint32_t)cl & (uint32_t)(inner - 1)) + (uint32_t)rb * (uint32_t)row_stride;
+  }
+  RF_HD long long lane_part_wide(int cl, int rb) const {
+    return (long long)(cl >> inner_shift()) * outer_stride + ((long long)cl & (inner - 1)) + (long long)rb * row_stride;
+  }
+  // does the lane part of a pass with L butterflies per column and TC columns per tile need 64 bits?
+  bool needs_wide(int L, int TC, int elem_bytes) const {
+    const unsigned long long runs = inner < TC ? (unsigned long long)(TC / inner) : 0;
+    return ((unsigned long long)(L - 1) * (unsigned long long)row_stride + runs * (unsigned long long)outer_stride + (unsigned long long)TC) *
+               (unsigned long long)elem_bytes >= (1ull << 32);
+  }
+  template <bool WIDE, typename E> RF_HD E* at(E* base, long long C0, int cl, int rb, int ro) const {
+    E* ub = base + uniform_part(C0, ro);
+#ifndef RF_FORCE_WIDE
+#define RF_FORCE_WIDE 0
+#endif
+    if (WIDE || RF_FORCE_WIDE) return ub + lane_part_wide(cl, rb);
+    return reinterpret_cast<E*>(reinterpret_cast<char*>(ub) + (size_t)(lane_part(cl, rb) * (uint32_t)sizeof(E)));
+  }
 };
 
-template <typename T> struct PlainColIO {
+template <typename T, bool WIDE = false> struct PlainColIO {
   cplx<T>* base;
   ColGeom g;
-  RF_HD cplx<T>* at(long long C, int rb, int ro) const { return (base + g.uniform_part(ro)) + g.lane_part(C, rb); }
-  RF_HD V16<T> load(long long C, int rb, int ro) const { return *reinterpret_cast<const V16<T>*>(at(C, rb, ro)); }
-  RF_HD void store(long long C, int rb, int ro, const V16<T>& v) const { *reinterpret_cast<V16<T>*>(at(C, rb, ro)) = v; }
+  RF_HD V16<T> load(long long C0, int cl, int rb, int ro) const { return v16_load<T>(g.at<WIDE>(base, C0, cl, rb, ro)); }
+  RF_HD void store(long long C0, int cl, int rb, int ro, const V16<T>& v) const { v16_store<T>(g.at<WIDE>(base, C0, cl, rb, ro), v); }
   static constexpr int FIX_MODE = 0;
   RF_HD bool needs_fix(long long) const { return false; }
   RF_HD cplx<T> fix_value(long long, int, int) const { return cplx<T>(); }
   static constexpr int LDS_EXTRA = 0;
   RF_HD void prologue(int, int, void*) {}
+  RF_HD void bind_seed() {}
   RF_HD static void sched_fence(int = 0) {}      // loads of one butterfly are meant to be issued back to back
   static constexpr bool ROLLED_LOAD = false;
 };
@@ -91,16 +141,17 @@ template <typename T> struct PlainColIO {
 // k-space cell instead of reading memory.  Columns are the flattened (iy, kz).
 // If `kspace` is non-null the cell is read from an API-layout array
 // [nx][ny][nz/2+1] instead (unfused c2r of uploaded / separately generated data).
-template <typename T> struct GenColIO {
+template <typename T, bool WIDE = false> struct GenColIO {
   cplx<T>* base;           // destination W
   ColGeom g;               // x-pass geometry: inner = ny*nzc, row_stride = ny*nzc
   GenParams gp;
   const cplx<T>* kspace;   // optional source in API layout
   int kz0, nzl;            // this rank's kz slab [kz0, kz0 + nzl) of the nz/2 packed planes
-  RF_HD V16<T> load(long long C, int rb, int ro) const {
+  RF_HD V16<T> load(long long C0, int cl, int rb, int ro) const {
     V16<T> v;
+    const long long C = C0 + cl;
     const int nzc = gp.nz / 2;
-    const uint64_t seed = gp.seed_dev ? *gp.seed_dev : gp.seed;
+    const uint64_t seed = gp.seed;
     const int ix = rb + ro;
 #pragma unroll
     for (int c = 0; c < V16<T>::CPL; ++c) {
@@ -117,14 +168,17 @@ template <typename T> struct GenColIO {
     }
     return v;
   }
-  RF_HD void store(long long C, int rb, int ro, const V16<T>& v) const {
-    *reinterpret_cast<V16<T>*>((base + g.uniform_part(ro)) + g.lane_part(C, rb)) = v;
+  RF_HD void store(long long C0, int cl, int rb, int ro, const V16<T>& v) const {
+    v16_store<T>(g.at<WIDE>(base, C0, cl, rb, ro), v);
   }
   static constexpr int FIX_MODE = 0;
   RF_HD bool needs_fix(long long) const { return false; }
   RF_HD cplx<T> fix_value(long long, int, int) const { return cplx<T>(); }
   static constexpr int LDS_EXTRA = 0;
   RF_HD void prologue(int, int, void*) {}
+  // the kernel calls this once before any load(): a seed kept in device memory (graph replay) is read once, through
+  // the scalar unit, instead of once per cell
+  RF_HD void bind_seed() { if (gp.seed_dev) { gp.seed = pin_uniform(*gp.seed_dev); gp.seed_dev = nullptr; } }
   RF_HD static void sched_fence(int = 0) {}
   // the exact-chain generation body (float64 lookups, libm-grade log10 / sin / cos) is far too big to be
   // replicated R times: the load loop stays rolled and parks its values in the thread's own LDS slots
@@ -144,6 +198,7 @@ struct FastGenColIOT {
   int kz0, nzl;
   int x0 = 0, x1 = 1 << 30;  // replicated-generation mode (multi-GPU without an exchange): only rows [x0, x1) are stored,
                              // and `base` has been moved back by x0 rows so that row x0 lands on the local array's row 0
+  RF_HD int nzl_shift() const { return 31 - __builtin_clz((unsigned)nzl); }
   const FastRec* rec;      // set by prologue(): LDS copy of the sigma records (or the global one)
   static constexpr int LDS_EXTRA = FAST_LDS_BINS * (int)sizeof(FastRec);
   // keep the compiler from interleaving all R generation bodies of a butterfly (register blow-up);
@@ -164,35 +219,39 @@ struct FastGenColIOT {
     for (int i = tid; i < gp.nbins && i < FAST_LDS_BINS; i += nthreads) l[i] = gp.rec[i];
     rec = l;
   }
+  RF_HD void bind_seed() { if (gp.seed_dev) { gp.seed = pin_uniform(*gp.seed_dev); gp.seed_dev = nullptr; } }
   // Cell pair (kz, kz + 1) of column (ix = rb + ro, iy).  What does not depend on m (= ro / L) is a common
   // subexpression of the R unrolled loads, and what does not depend on the lane runs on the scalar ALU: the
   // Philox counter is (lane part) + (uniform part), two vector adds per load instead of a 64-bit multiply chain.
-  RF_HD V16<float> load(long long C, int rb, int ro) const {
+  RF_HD V16<float> load(long long C0, int cl, int rb, int ro) const {
     V16<float> v;
-    const uint64_t seed = gp.seed_dev ? *gp.seed_dev : gp.seed;
-    const int iy = (int)(C / nzl), kz = kz0 + (int)(C % nzl);                          // lane, m-invariant
+    const long long C = C0 + cl;
+    const uint64_t seed = gp.seed;                                                      // bind_seed() ran first
+    // nzl = (nz/2) / ranks is a power of two (the launcher checks it): shift and mask instead of a 64-bit division
+    const int iy = (int)((unsigned)C >> nzl_shift()), kz = kz0 + (int)((unsigned)C & (unsigned)(nzl - 1));   // lane, m-invariant
     const uint64_t half_plane = ((uint64_t)gp.ny * (uint64_t)(gp.nz / 2)) >> 1;        // counters per unit of ix
     const uint64_t ctr_l = (uint64_t)rb * half_plane + (((uint64_t)iy * (uint64_t)(gp.nz / 2) + (uint64_t)kz) >> 1);
     const uint64_t ctr_u = pin_uniform((uint64_t)ro * half_plane);
     // signed fftfreq index: rb < L <= nx/2, so the wrap depends on ro alone
     const int ro_s = ro >= (gp.nx >> 1) ? ro - gp.nx : ro;
-    const float kx = (float)(rb + ro_s) * gp.dkx;
-    fast_gen_pair_at<AB>(gp, rec, seed, ctr_l + ctr_u, kx * kx + gp.ky2[iy], gp.kz2[kz], gp.kz2[kz + 1], v.c[0], v.c[1]);
+    const float kx = (float)(rb + ro_s) * gp.dkx, ky = (float)fast_signed_index(iy, gp.ny) * gp.dky;
+    const float kxy = fmaf(kx, kx, ky * ky);                                           // == fast_kxy2(gp, rb + ro, iy)
+    fast_gen_pair_at<AB>(gp, rec, seed, ctr_l + ctr_u, fast_k2(gp, kxy, kz), fast_k2(gp, kxy, kz + 1), v.c[0], v.c[1]);
     return v;
   }
   // the lane that owns slot kz = 0 replaces its provisional first cell of every row by the packed,
   // symmetrised (kz=0, kz=nz/2) pair (cold path: one lane in four of one tile in nz/16)
   static constexpr bool ROLLED_LOAD = false;
   static constexpr int FIX_MODE = FIX;
-  RF_HD bool needs_fix(long long C) const { return FIX != 0 && kz0 + (int)(C % nzl) == 0; }
+  RF_HD bool needs_fix(long long C) const { return FIX != 0 && kz0 + (int)((unsigned)C & (unsigned)(nzl - 1)) == 0; }
   RF_HD cplx<float> fix_value(long long C, int rb, int ro) const {
-    const uint64_t seed = gp.seed_dev ? *gp.seed_dev : gp.seed;
-    return fast_fix_kz0(gp, rec, seed, rb + ro, (int)(C / nzl));
+    const uint64_t seed = gp.seed;                                                      // bind_seed() ran first
+    return fast_fix_kz0(gp, rec, seed, rb + ro, (int)((unsigned)C >> nzl_shift()));
   }
-  RF_HD void store(long long C, int rb, int ro, const V16<float>& v) const {
+  RF_HD void store(long long C0, int cl, int rb, int ro, const V16<float>& v) const {
     // x0, x1 are multiples of the last pass's row stride L (the launcher checks it) and rb < L: the test is uniform
     if (SLAB && (ro < x0 || ro >= x1)) return;
-    *reinterpret_cast<V16<float>*>((base + g.uniform_part(ro)) + g.lane_part(C, rb)) = v;
+    v16_store<float>(g.at<false>(base, C0, cl, rb, ro), v);
   }
 };
 using FastGenColIO = FastGenColIOT<0, 1>;
@@ -207,6 +266,7 @@ struct FastGenColIO64 {
   FastGenParams gp;
   int kz0, nzl;
   int x0 = 0, x1 = 1 << 30;  // replicated-generation mode: see FastGenColIOT
+  RF_HD int nzl_shift() const { return 31 - __builtin_clz((unsigned)nzl); }
   const FastRec* rec;
   static constexpr int LDS_EXTRA = FAST_LDS_BINS * (int)sizeof(FastRec);
   RF_HD static void sched_fence(int = 0) {}
@@ -215,30 +275,32 @@ struct FastGenColIO64 {
     for (int i = tid; i < gp.nbins && i < FAST_LDS_BINS; i += nthreads) l[i] = gp.rec[i];
     rec = l;
   }
-  RF_HD V16<double> load(long long C, int rb, int ro) const {
-    const uint64_t seed = gp.seed_dev ? *gp.seed_dev : gp.seed;
-    const int iy = (int)(C / nzl), kz = kz0 + (int)(C % nzl);                          // lane, m-invariant
+  RF_HD void bind_seed() { if (gp.seed_dev) { gp.seed = pin_uniform(*gp.seed_dev); gp.seed_dev = nullptr; } }
+  RF_HD V16<double> load(long long C0, int cl, int rb, int ro) const {
+    const long long C = C0 + cl;
+    const uint64_t seed = gp.seed;                                                      // bind_seed() ran first
+    const int iy = (int)((unsigned)C >> nzl_shift()), kz = kz0 + (int)((unsigned)C & (unsigned)(nzl - 1));   // lane, m-invariant
     const uint64_t plane = (uint64_t)gp.ny * (uint64_t)(gp.nz / 2);                    // noise cells per unit of ix
     const uint64_t ci_l = (uint64_t)rb * plane + (uint64_t)iy * (uint64_t)(gp.nz / 2) + (uint64_t)kz;
     const uint64_t ci_u = pin_uniform((uint64_t)ro * plane);
     const int ro_s = ro >= (gp.nx >> 1) ? ro - gp.nx : ro;
-    const float kx = (float)(rb + ro_s) * gp.dkx;
-    const cplx<float> c = fast_gen_one(gp, rec, seed, ci_l + ci_u, kx * kx + gp.ky2[iy] + gp.kz2[kz]);
+    const float kx = (float)(rb + ro_s) * gp.dkx, ky = (float)fast_signed_index(iy, gp.ny) * gp.dky;
+    const cplx<float> c = fast_gen_one(gp, rec, seed, ci_l + ci_u, fast_k2(gp, fmaf(kx, kx, ky * ky), kz));
     V16<double> v;
     v.c[0] = mk<double>((double)c.x, (double)c.y);
     return v;
   }
   static constexpr bool ROLLED_LOAD = false;
   static constexpr int FIX_MODE = FIX;
-  RF_HD bool needs_fix(long long C) const { return FIX != 0 && kz0 + (int)(C % nzl) == 0; }
+  RF_HD bool needs_fix(long long C) const { return FIX != 0 && kz0 + (int)((unsigned)C & (unsigned)(nzl - 1)) == 0; }
   RF_HD cplx<double> fix_value(long long C, int rb, int ro) const {
-    const uint64_t seed = gp.seed_dev ? *gp.seed_dev : gp.seed;
-    const cplx<float> c = fast_fix_kz0(gp, rec, seed, rb + ro, (int)(C / nzl));
+    const uint64_t seed = gp.seed;                                                      // bind_seed() ran first
+    const cplx<float> c = fast_fix_kz0(gp, rec, seed, rb + ro, (int)((unsigned)C >> nzl_shift()));
     return mk<double>((double)c.x, (double)c.y);
   }
-  RF_HD void store(long long C, int rb, int ro, const V16<double>& v) const {
+  RF_HD void store(long long C0, int cl, int rb, int ro, const V16<double>& v) const {
     if (SLAB && (ro < x0 || ro >= x1)) return;          // uniform: see FastGenColIOT::store
-    *reinterpret_cast<V16<double>*>((base + g.uniform_part(ro)) + g.lane_part(C, rb)) = v;
+    v16_store<double>(g.at<false>(base, C0, cl, rb, ro), v);
   }
 };
 
@@ -277,7 +339,9 @@ struct ColFFT {
   RF_HD static void pass_first(int tid, long long tile, const IO& io, cx* lds) {
     constexpr int R = C::R1, L = N / R;
     const int lp = tid % LPR, jl = tid / LPR;
-    const long long Ccol = tile * C::TC + (long long)lp * CPL;
+    const long long C0 = tile * C::TC;                       // workgroup-uniform
+    const int cl = lp * CPL;
+    const long long Ccol = C0 + cl;
 #pragma unroll
     for (int it = 0; it < C::IT1; ++it) {
       const int j = it * BPI + jl;
@@ -285,7 +349,7 @@ struct ColFFT {
         cx v[CPL][R];
         if (IO::ROLLED_LOAD && C::NPASS > 1) {
 #pragma unroll 1
-          for (int m = 0; m < R; ++m) *lds_at(lds, j * R + m, lp) = io.load(Ccol, j, m * L);
+          for (int m = 0; m < R; ++m) *lds_at(lds, j * R + m, lp) = io.load(C0, cl, j, m * L);
 #pragma unroll
           for (int m = 0; m < R; ++m) {
             V x = *lds_at(lds, j * R + m, lp);
@@ -295,7 +359,7 @@ struct ColFFT {
         } else {
 #pragma unroll
           for (int m = 0; m < R; ++m) {
-            V x = io.load(Ccol, j, m * L);
+            V x = io.load(C0, cl, j, m * L);
 #pragma unroll
             for (int c = 0; c < CPL; ++c) v[c][m] = x.c[c];
             IO::sched_fence(m);
@@ -321,7 +385,7 @@ struct ColFFT {
           V x;
 #pragma unroll
           for (int c = 0; c < CPL; ++c) x.c[c] = v[c][m];
-          if (C::NPASS == 1) io.store(Ccol, j * R, m, x);
+          if (C::NPASS == 1) io.store(C0, cl, j * R, m, x);
           else *lds_at(lds, j * R + m, lp) = x;
         }
       }
@@ -361,36 +425,44 @@ struct ColFFT {
     }
   }
 
-  // last pass (NPASS >= 2): LDS -> RL butterfly -> global
-  RF_HD static void pass_last(int tid, long long tile, const IO& io, const cx* tw, cx* lds) {
+  // last pass (NPASS >= 2): LDS -> RL butterfly -> global.  The butterfly of iteration `it` leaves one 16-byte
+  // vector per output row m (row j + m L of this lane's CPL columns) in out[m].
+  RF_HD static void last_butterfly(int j, int lp, const cx* tw, cx* lds, V* out) {
     constexpr int R = C::RL, L = N / R;  // Ns == L, out_base(j) == j, twiddle index == m*j
+    cx v[CPL][R];
+#pragma unroll
+    for (int m = 0; m < R; ++m) {
+      V x = *lds_at(lds, j + m * L, lp);
+      if (m > 0) {
+        const cx w = tw_dir<DIR>(tw[m * j]);
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) x.c[c] = cmul(x.c[c], w);
+      }
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) v[c][m] = x.c[c];
+    }
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) DFT<R, DIR>::run(v[c]);
+#pragma unroll
+    for (int m = 0; m < R; ++m) {
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) out[m].c[c] = v[c][m];
+    }
+  }
+  RF_HD static void pass_last(int tid, long long tile, const IO& io, const cx* tw, cx* lds) {
+    constexpr int R = C::RL, L = N / R;
     const int lp = tid % LPR, jl = tid / LPR;
-    const long long Ccol = tile * C::TC + (long long)lp * CPL;
+    const long long C0 = tile * C::TC;                       // workgroup-uniform
+    const int cl = lp * CPL;
+    const long long Ccol = C0 + cl;
 #pragma unroll
     for (int it = 0; it < C::ITL; ++it) {
       const int j = it * BPI + jl;
       if (j < L) {
-        cx v[CPL][R];
+        V out[R];
+        last_butterfly(j, lp, tw, lds, out);
 #pragma unroll
-        for (int m = 0; m < R; ++m) {
-          V x = *lds_at(lds, j + m * L, lp);
-          if (m > 0) {
-            const cx w = tw_dir<DIR>(tw[m * j]);
-#pragma unroll
-            for (int c = 0; c < CPL; ++c) x.c[c] = cmul(x.c[c], w);
-          }
-#pragma unroll
-          for (int c = 0; c < CPL; ++c) v[c][m] = x.c[c];
-        }
-#pragma unroll
-        for (int c = 0; c < CPL; ++c) DFT<R, DIR>::run(v[c]);
-#pragma unroll
-        for (int m = 0; m < R; ++m) {
-          V x;
-#pragma unroll
-          for (int c = 0; c < CPL; ++c) x.c[c] = v[c][m];
-          io.store(Ccol, j, m * L, x);
-        }
+        for (int m = 0; m < R; ++m) io.store(C0, cl, j, m * L, out[m]);
       }
     }
   }
@@ -419,14 +491,41 @@ struct RowCfg {
 
 // c2r row IO over the device array viewed as complex [nrows][M] on input and
 // real [nrows][2M] on output (same memory).  Accumulates sum / sum of squares.
+// streaming (non-temporal) access to one complex element: the z pass touches every byte exactly once, so there is
+// nothing to keep in the caches (a read+write sweep with the hint ran 6 % faster than without, tools/xbench.hip)
+#ifndef RF_Z_NT
+#define RF_Z_NT 1
+#endif
+template <typename T> RF_HD cplx<T> stream_load(const cplx<T>* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (RF_Z_NT) {
+    typedef T vt __attribute__((ext_vector_type(2)));
+    const vt v = __builtin_nontemporal_load(reinterpret_cast<const vt*>(p));
+    return mk<T>(v.x, v.y);
+  }
+#endif
+  return *p;
+}
+template <typename T> RF_HD void stream_store(cplx<T>* p, cplx<T> z) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (RF_Z_NT) {
+    typedef T vt __attribute__((ext_vector_type(2)));
+    vt v; v.x = z.x; v.y = z.y;
+    __builtin_nontemporal_store(v, reinterpret_cast<vt*>(p));
+    return;
+  }
+#endif
+  *p = z;
+}
+
 template <typename T> struct PlainRowIO {
   cplx<T>* base;
   T scale;                       // 1 / (nx ny nz)
   int M_of;                      // complex elements per row (nz / 2)
-  RF_HD cplx<T> load(long long row, int k) const { return base[row * (long long)M_of + k]; }
+  RF_HD cplx<T> load(long long row, int k) const { return stream_load(base + row * (long long)M_of + k); }
   RF_HD void store(long long row, int n, cplx<T> z, double& s1, double& s2) const {
     z.x *= scale; z.y *= scale;
-    base[row * (long long)M_of + n] = z;
+    stream_store(base + row * (long long)M_of + n, z);
     s1 += (double)z.x + (double)z.y;
     s2 += (double)z.x * (double)z.x + (double)z.y * (double)z.y;
   }

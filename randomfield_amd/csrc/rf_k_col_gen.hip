@@ -2,34 +2,44 @@
 #include "rf_kernels.h"
 #include "rf_launch.h"
 
+
 namespace rf {
 namespace {
 // runs tiles  b * tile_mul + tile_add,  b in [0, ntiles)
 template <class C, class IO>
-hipError_t launch_one(const IO& io, long long ncols, const cplx<typename C::T>* tw, hipStream_t s, bool prepare_only,
+hipError_t launch_one(const IO& io_in, long long ncols, const cplx<typename C::T>* tw, hipStream_t s, bool prepare_only,
                       long long ntiles_sub = -1, long long tile_mul = 1, long long tile_add = 0, int skip_period = 0) {
-  if (ncols % C::TC) return hipErrorInvalidValue;
+  if (ncols % C::TC || io_in.g.inner <= 0 || (io_in.g.inner & (io_in.g.inner - 1))) return hipErrorInvalidValue;
+  const IO& io = io_in;
   const long long ntiles = ntiles_sub >= 0 ? ntiles_sub : ncols / C::TC;
   auto k = col_kernel<C, +1, IO>;
   constexpr int lds_bytes = C::LDS_BYTES + IO::LDS_EXTRA;
-  static bool prepared = false;
-  if (!prepared) {
-    if (lds_bytes > 65536) {
-      hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-      if (e != hipSuccess) return e;
-    }
-    prepared = true;
-  }
+  static LdsAttrLatch latch;
+  if (hipError_t e = latch.ensure((const void*)k, lds_bytes); e != hipSuccess) return e;
   if (prepare_only) return hipSuccess;
   hipLaunchKernelGGL(k, dim3((unsigned)ntiles), dim3(C::NT), lds_bytes, s, io, tw, ntiles, tile_mul, tile_add, skip_period);
   return hipGetLastError();
 }
+
 template <typename T>
 hipError_t launch_t(int N, cplx<T>* W, ColGeom g, long long ncols, const GenParams& gp, const cplx<T>* kspace,
                     int kz0, int nzl, const cplx<T>* tw, hipStream_t s, bool po) {
   GenColIO<T> io; io.base = W; io.g = g; io.gp = gp; io.kspace = kspace; io.kz0 = kz0; io.nzl = nzl;
   switch (N) {
-#define X(NN) case NN: return launch_one<typename GenSel<T, NN>::type, GenColIO<T>>(io, ncols, tw, s, po);
+#define X(NN)                                                                                                    \
+  case NN: {                                                                                                     \
+    using C = typename GenSel<T, NN>::type;                                                                      \
+    if constexpr (NN == 2048 && sizeof(T) == 8) {               /* 64-bit lane offsets: float64, length 2048 */ \
+      if (po || g.needs_wide(C::LMAX, C::TC, (int)sizeof(cplx<T>))) {                                            \
+        GenColIO<T, true> iow; iow.base = W; iow.g = g; iow.gp = gp; iow.kspace = kspace; iow.kz0 = kz0; iow.nzl = nzl; \
+        hipError_t e = launch_one<C, GenColIO<T, true>>(iow, ncols, tw, s, po);                                  \
+        if (!po || e != hipSuccess) return e;                                                                    \
+      }                                                                                                          \
+    } else if (g.needs_wide(C::LMAX, C::TC, (int)sizeof(cplx<T>))) {                                             \
+      return hipErrorInvalidValue;                                                                               \
+    }                                                                                                            \
+    return launch_one<C, GenColIO<T>>(io, ncols, tw, s, po);                                                     \
+  }
     RF_COL_SIZES(X)
 #undef X
     default: return hipErrorInvalidValue;
@@ -45,17 +55,18 @@ hipError_t launch_fast_one(const FastGenParams& gp, CT* W, ColGeom g, long long 
                            const CT* tw, hipStream_t s, bool po, hipEvent_t after_repair, int x0, int x1) {
   // the slab-restricted instantiations test the workgroup-uniform row offset m * L of the last pass: the slab
   // boundaries must be multiples of L = N / (radix of the last pass)
+  if (nzl <= 0 || (nzl & (nzl - 1)) || ncols >= (1LL << 31) || g.needs_wide(C::LMAX, C::TC, (int)sizeof(CT))) return hipErrorInvalidValue;   // the IO splits a column index by shift and mask
   if ((x0 > 0 || x1 < C::N) && (C::NPASS < 2 || x0 % (C::N / C::RL) || x1 % (C::N / C::RL))) return hipErrorInvalidValue;
   CT* base = x0 > 0 ? W - (long long)x0 * g.row_stride : W;      // row x0 of the transform lands on row 0 of W
   IO0 io0; io0.base = base; io0.g = g; io0.gp = gp; io0.kz0 = kz0; io0.nzl = nzl; io0.rec = nullptr; io0.x0 = x0; io0.x1 = x1;
   IO1 io1; io1.base = base; io1.g = g; io1.gp = gp; io1.kz0 = kz0; io1.nzl = nzl; io1.rec = nullptr; io1.x0 = x0; io1.x1 = x1;
   const bool split = nzl > C::TC && nzl % C::TC == 0;
+  const long long tiles_per_iy = nzl / C::TC, ntiles = ncols / C::TC;
   if (po) {
     hipError_t e = launch_one<C, IO0>(io0, ncols, tw, s, true);
     return e != hipSuccess ? e : launch_one<C, IO1>(io1, ncols, tw, s, true);
   }
   if (!split) return launch_one<C, IO1>(io1, ncols, tw, s, false);
-  const long long tiles_per_iy = nzl / C::TC, ntiles = ncols / C::TC;
   if (kz0 != 0) return launch_one<C, IO0>(io0, ncols, tw, s, false);   // only the slab that owns kz = 0 needs the repair
   // first the (few) tiles that hold slot kz = 0, with the repair; then every other tile without it
   hipError_t e = launch_one<C, IO1>(io1, ncols, tw, s, false, ncols / nzl, tiles_per_iy, 0);

@@ -5,19 +5,14 @@
 namespace rf {
 namespace {
 template <class C, int DIR, class IO>
-hipError_t launch_one(const IO& io, long long ncols, const cplx<typename C::T>* tw, hipStream_t s, bool prepare_only) {
-  if (ncols % C::TC) return hipErrorInvalidValue;
+hipError_t launch_one(const IO& io_in, long long ncols, const cplx<typename C::T>* tw, hipStream_t s, bool prepare_only) {
+  if (ncols % C::TC || io_in.g.inner <= 0 || (io_in.g.inner & (io_in.g.inner - 1))) return hipErrorInvalidValue;
+  const IO& io = io_in;
   const long long ntiles = ncols / C::TC;
   auto k = col_kernel<C, DIR, IO>;
   constexpr int lds_bytes = C::LDS_BYTES + IO::LDS_EXTRA;
-  static bool prepared = false;
-  if (!prepared) {
-    if (lds_bytes > 65536) {
-      hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-      if (e != hipSuccess) return e;
-    }
-    prepared = true;
-  }
+  static LdsAttrLatch latch;
+  if (hipError_t e = latch.ensure((const void*)k, lds_bytes); e != hipSuccess) return e;
   if (prepare_only) return hipSuccess;
   hipLaunchKernelGGL(k, dim3((unsigned)ntiles), dim3(C::NT), lds_bytes, s, io, tw, ntiles, 1LL, 0LL, 0);
   return hipGetLastError();
@@ -26,7 +21,20 @@ template <typename T, int DIR>
 hipError_t launch_t(int N, cplx<T>* base, ColGeom g, long long ncols, const cplx<T>* tw, hipStream_t s, bool po) {
   PlainColIO<T> io; io.base = base; io.g = g;
   switch (N) {
-#define X(NN) case NN: return launch_one<typename ColSel<T, NN>::type, DIR, PlainColIO<T>>(io, ncols, tw, s, po);
+#define X(NN)                                                                                                    \
+  case NN: {                                                                                                     \
+    using C = typename ColSel<T, NN>::type;                                                                      \
+    if constexpr (NN == 2048 && sizeof(T) == 8) {               /* 64-bit lane offsets: float64, length 2048 */ \
+      if (po || g.needs_wide(C::LMAX, C::TC, (int)sizeof(cplx<T>))) {                                            \
+        PlainColIO<T, true> iow; iow.base = base; iow.g = g;                                                     \
+        hipError_t e = launch_one<C, DIR, PlainColIO<T, true>>(iow, ncols, tw, s, po);                           \
+        if (!po || e != hipSuccess) return e;                                                                    \
+      }                                                                                                          \
+    } else if (g.needs_wide(C::LMAX, C::TC, (int)sizeof(cplx<T>))) {                                             \
+      return hipErrorInvalidValue;                                                                               \
+    }                                                                                                            \
+    return launch_one<C, DIR, PlainColIO<T>>(io, ncols, tw, s, po);                                              \
+  }
     RF_COL_SIZES(X)
 #undef X
     default: return hipErrorInvalidValue;

@@ -169,12 +169,8 @@ __global__ __launch_bounds__(64) void mt_scan_kernel(const unsigned long long* _
 
 hipError_t launch_mt_jump(const uint32_t* states_src, const uint32_t* pos, int npos, uint32_t* states_dst, int ndst, hipStream_t s) {
   constexpr int lds = MT_SEQ_WORDS * (int)sizeof(uint32_t);
-  static bool prepared = false;
-  if (!prepared) {
-    hipError_t e = hipFuncSetAttribute((const void*)mt_jump_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return e;
-    prepared = true;
-  }
+  static LdsAttrLatch latch;
+  if (hipError_t e = latch.ensure((const void*)mt_jump_kernel, lds); e != hipSuccess) return e;
   hipLaunchKernelGGL(mt_jump_kernel, dim3(ndst), dim3(640), lds, s, states_src, pos, npos, states_dst);
   return hipGetLastError();
 }

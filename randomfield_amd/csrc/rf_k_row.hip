@@ -13,14 +13,8 @@ hipError_t launch_one(const IO& io, long long nrows, const cplx<typename C::T>* 
   const long long ntiles = (nrows + C::NRT - 1) / C::NRT;
   auto k = row_c2r_kernel<C, IO>;
   constexpr int lds = row_lds_bytes<C>();
-  static bool prepared = false;
-  if (!prepared) {
-    if (lds > 65536) {
-      hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      if (e != hipSuccess) return e;
-    }
-    prepared = true;
-  }
+  static LdsAttrLatch latch;
+  if (hipError_t e = latch.ensure((const void*)k, lds); e != hipSuccess) return e;
   if (prepare_only) return hipSuccess;
   hipLaunchKernelGGL(k, dim3((unsigned)ntiles), dim3(C::NT), lds, s, io, tw, nrows, partials);
   return hipGetLastError();
@@ -51,14 +45,8 @@ hipError_t launch_fwd_one(const PlainRowFwdIO<typename C::T>& io, long long nrow
   const long long ntiles = (nrows + C::NRT - 1) / C::NRT;
   auto k = row_r2c_kernel<C, PlainRowFwdIO<typename C::T>>;
   constexpr int lds = C::LDS_BYTES > 64 ? C::LDS_BYTES : 64;
-  static bool prepared = false;
-  if (!prepared) {
-    if (lds > 65536) {
-      hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      if (e != hipSuccess) return e;
-    }
-    prepared = true;
-  }
+  static LdsAttrLatch latch;
+  if (hipError_t e = latch.ensure((const void*)k, lds); e != hipSuccess) return e;
   if (po) return hipSuccess;
   hipLaunchKernelGGL(k, dim3((unsigned)ntiles), dim3(C::NT), lds, s, io, tw, nrows);
   return hipGetLastError();

@@ -9,14 +9,8 @@ hipError_t launch_one(const ScaledRowIO<typename C::T>& io, long long nrows, con
   const long long ntiles = (nrows + C::NRT - 1) / C::NRT;
   auto k = row_c2c_kernel<C, DIR, ScaledRowIO<typename C::T>>;
   constexpr int lds = C::LDS_BYTES > 64 ? C::LDS_BYTES : 64;
-  static bool prepared = false;
-  if (!prepared) {
-    if (lds > 65536) {
-      hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      if (e != hipSuccess) return e;
-    }
-    prepared = true;
-  }
+  static LdsAttrLatch latch;
+  if (hipError_t e = latch.ensure((const void*)k, lds); e != hipSuccess) return e;
   if (po) return hipSuccess;
   hipLaunchKernelGGL(k, dim3((unsigned)ntiles), dim3(C::NT), lds, s, io, tw, nrows);
   return hipGetLastError();

@@ -38,6 +38,7 @@ __global__ __launch_bounds__(C::NT, (col_min_waves<C, IO>())) void col_kernel(IO
     tile = (long long)(t + t / (unsigned)(skip_period - 1) + 1u);
   }
   const cx* ltw = tw;
+  io.bind_seed();
   if (F::HAS_PROLOGUE) {
     F::prologue(tid, io, tw, lds);          // twiddles (+ the IO's tables) -> LDS
     if (C::NPASS >= 2) ltw = F::lds_tw(lds);

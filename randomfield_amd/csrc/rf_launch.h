@@ -2,9 +2,39 @@
 // one family of kernels so that the files compile in parallel.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include "rf_configs.h"
 
 namespace rf {
+
+// Kernels with more than 64 KB of dynamic LDS need hipFuncSetAttribute(MaxDynamicSharedMemorySize) once PER DEVICE:
+// every launcher keeps one of these per kernel instantiation (bit d = device d is prepared; thread safe).
+struct LdsAttrLatch {
+  std::atomic<unsigned long long> done{0};
+  hipError_t ensure(const void* kernel, int lds_bytes) {
+    if (lds_bytes <= 65536) return hipSuccess;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
+    return e;
+  }
+};
+
+// compute units of the current device (cached per device): persistent kernels launch a multiple of it
+inline int device_cu_count() {
+  static std::atomic<int> cache[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  int v = cache[dev & 63].load(std::memory_order_relaxed);
+  if (v > 0) return v;
+  if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+  cache[dev & 63].store(v, std::memory_order_relaxed);
+  return v;
+}
 
 // strided FFT pass in place (y pass of c2r; x/y passes of r2c). dir = +1 inverse, -1 forward.
 // prepare_only = true sets the kernel's function attributes (dynamic LDS > 64 KB) without launching
