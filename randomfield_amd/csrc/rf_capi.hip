@@ -137,6 +137,12 @@ struct rf_plan {
   int stats_cap = 0;
   uint64_t* seeds_dev = nullptr;
   int seeds_cap = 0;
+  // the caller's seed array may be a temporary: it is copied into one of two plan-owned pinned staging slots before
+  // the asynchronous upload (a slot is reused only after the upload that last read it has completed)
+  uint64_t* seeds_pin[2] = {nullptr, nullptr};
+  hipEvent_t seeds_ev[2] = {nullptr, nullptr};
+  int seeds_pin_cap = 0, seeds_turn = 0;
+  double* coll_scratch = nullptr;         // 2 doubles on the device for host-side all-reduces (never aliases `stats`)
   double* ztab = nullptr;                 // 2 * nz doubles for lognormal / affine tables
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // start, after x, y, z, reduce; [5] = after the kz = 0 repair launch
   bool repair_timed = false;
@@ -524,6 +530,7 @@ int rf_plan_create(rf_plan** out, int nx, int ny, int nz, int dtype, int device,
   p->stats_cap = 64;
   if ((e = hipMalloc((void**)&p->partials, (2 * p->npartials + 512) * sizeof(double))) != hipSuccess ||
       (e = hipMalloc((void**)&p->stats, 2 * p->stats_cap * sizeof(double))) != hipSuccess ||
+      (e = hipMalloc((void**)&p->coll_scratch, 2 * sizeof(double))) != hipSuccess ||
       (e = hipMalloc((void**)&p->kx2, nx * sizeof(double))) != hipSuccess ||
       (e = hipMalloc((void**)&p->ky2, ny * sizeof(double))) != hipSuccess ||
       (e = hipMalloc((void**)&p->kz2, (p->nzc + 1) * sizeof(double))) != hipSuccess ||
@@ -634,9 +641,13 @@ int rf_plan_destroy(rf_plan* p) {
   if (p->comm_stream) { (void)hipStreamSynchronize(p->comm_stream); (void)hipStreamDestroy(p->comm_stream); }
   for (auto& e : p->pev) if (e) (void)hipEventDestroy(e);
   void* bufs[] = {p->W, p->R, p->W2, p->R2, p->K, p->P, p->tw_x, p->tw_y, p->tw_z, p->kx2, p->ky2, p->kz2, p->xt, p->st, p->sl, p->bin,
-                  p->noise, p->mt_pos, p->mt_states, p->mt_counts, p->mt_offsets, p->partials, p->stats, p->seeds_dev, p->ztab, p->frec};
+                  p->noise, p->mt_pos, p->mt_states, p->mt_counts, p->mt_offsets, p->partials, p->stats, p->seeds_dev, p->ztab, p->frec, p->coll_scratch};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
+  for (int i = 0; i < 2; ++i) {
+    if (p->seeds_pin[i]) (void)hipHostFree(p->seeds_pin[i]);
+    if (p->seeds_ev[i]) (void)hipEventDestroy(p->seeds_ev[i]);
+  }
   for (auto& ev : p->ev)
     if (ev) (void)hipEventDestroy(ev);
   if (p->own_stream) (void)hipStreamDestroy(p->own_stream);
@@ -864,7 +875,22 @@ int rf_realise_batch(rf_plan* p, const uint64_t* seeds, int n, double* rms_out) 
     return 0;
   }
   if (int rc = batch_prepare(p, n)) return rc;
-  RF_HIP(hipMemcpyAsync(p->seeds_dev, seeds, n * sizeof(uint64_t), hipMemcpyHostToDevice, p->stream));
+  if (p->seeds_pin_cap < n) {
+    RF_HIP(hipStreamSynchronize(p->stream));
+    for (int i = 0; i < 2; ++i) {
+      if (p->seeds_pin[i]) RF_HIP(hipHostFree(p->seeds_pin[i]));
+      p->seeds_pin[i] = nullptr;
+      RF_HIP(hipHostMalloc((void**)&p->seeds_pin[i], (size_t)(n + 64) * sizeof(uint64_t), hipHostMallocDefault));
+      if (!p->seeds_ev[i]) RF_HIP(hipEventCreateWithFlags(&p->seeds_ev[i], hipEventDisableTiming));
+    }
+    p->seeds_pin_cap = n + 64;
+  }
+  const int slot = p->seeds_turn;
+  p->seeds_turn ^= 1;
+  RF_HIP(hipEventSynchronize(p->seeds_ev[slot]));        // returns at once for an event that was never recorded
+  std::memcpy(p->seeds_pin[slot], seeds, n * sizeof(uint64_t));
+  RF_HIP(hipMemcpyAsync(p->seeds_dev, p->seeds_pin[slot], n * sizeof(uint64_t), hipMemcpyHostToDevice, p->stream));
+  RF_HIP(hipEventRecord(p->seeds_ev[slot], p->stream));
   RF_HIP(hipEventRecord(p->ev[0], p->stream));
   RF_HIP(hipGraphLaunch(p->graphs[n].exec, p->stream));
   RF_HIP(hipEventRecord(p->ev[4], p->stream));
@@ -1194,8 +1220,8 @@ int rf_comm_init(rf_plan* p, const void* id128) {
   memcpy(&id, id128, sizeof(id));
   RF_NCCL(g_rccl.CommInitRank(&p->comm, p->nranks, id, p->rank));
   // one tiny collective now: a broken communicator should fail here, not inside a timed region
-  RF_HIP(hipMemsetAsync(p->stats, 0, 2 * sizeof(double), p->stream));
-  RF_NCCL(g_rccl.AllReduce(p->stats, p->stats, 2, ncclFloat64, ncclSum, p->comm, p->stream));
+  RF_HIP(hipMemsetAsync(p->coll_scratch, 0, 2 * sizeof(double), p->stream));
+  RF_NCCL(g_rccl.AllReduce(p->coll_scratch, p->coll_scratch, 2, ncclFloat64, ncclSum, p->comm, p->stream));
   RF_HIP(hipStreamSynchronize(p->stream));
   return 0;
 }
@@ -1206,9 +1232,8 @@ int rf_comm_allreduce_f64(rf_plan* p, double* inout, int n, int op) {
   RF_REQUIRE(n >= 1 && n <= 2, "n must be 1 or 2");
   RF_REQUIRE(op == 0 || op == 1, "op must be 0 (sum) or 1 (max)");
   RF_HIP(hipSetDevice(p->device));
-  if (p->nranks == 1 || !p->comm) { RF_HIP(hipStreamSynchronize(p->stream)); return 0; }
-  // scratch: the two doubles behind the moments pair (stats has at least 128 slots)
-  double* d = p->stats + 2 * (p->stats_cap - 1);
+  if (!p->comm) { RF_HIP(hipStreamSynchronize(p->stream)); return 0; }     // a one-rank communicator still runs the collective
+  double* d = p->coll_scratch;            // its own two doubles: `stats` holds the moments of up to stats_cap realisations
   RF_HIP(hipMemcpyAsync(d, inout, n * sizeof(double), hipMemcpyHostToDevice, p->stream));
   RF_NCCL(g_rccl.AllReduce(d, d, n, ncclFloat64, op == 0 ? ncclSum : ncclMax, p->comm, p->stream));
   RF_HIP(hipMemcpyAsync(inout, d, n * sizeof(double), hipMemcpyDeviceToHost, p->stream));
@@ -1241,6 +1266,10 @@ int rf_slab_exchange_local(rf_plan** plans, int n) {
   for (int g = 0; g < n; ++g)        // sender g, receiver h: block h of W_g -> block g of R_h
     for (int h = 0; h < n; ++h)
       RF_HIP(hipMemcpy((char*)plans[h]->R + g * blk, (char*)plans[g]->W + h * blk, blk, hipMemcpyDeviceToDevice));
+  // a device-to-device hipMemcpy may return before the copy has run (it is only ordered on the null stream), and the
+  // plans' streams do not synchronise with the null stream: without this the gathering z pass of a large grid read
+  // blocks that had not arrived yet (caught by the full-size config-4 test; small grids happened to win the race)
+  RF_HIP(hipDeviceSynchronize());
   return 0;
 }
 

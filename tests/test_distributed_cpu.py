@@ -1,4 +1,4 @@
-"""world_size-2 gloo test (CPU): the multi-GPU path's rendezvous, unique-id hand-off and, above all,
+"""world_size-2 and world_size-4 gloo tests (CPU): the multi-GPU path's rendezvous, unique-id hand-off and, above all,
 the slab / all-to-all block layout.  Each rank computes its kz slab with the oracle, runs the x and y
 inverse transforms locally, exchanges the blocks defined in randomfield_amd/slab.py with a real
 all_to_all over gloo, gathers its rows and runs the z c2r -- and must end up with exactly its x slab of
@@ -75,12 +75,11 @@ def _worker(rank, world, port, shape, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2])
-def test_slab_exchange_two_processes(tmp_path, world):
+@pytest.mark.parametrize("world,shape", [(2, (8, 8, 16)), (4, (16, 8, 32))])
+def test_slab_exchange_processes(tmp_path, world, shape):
     pytest.importorskip("torch")
     import torch.multiprocessing as mp
     from oracle import cpu_ref
-    shape = (8, 8, 16)
     mp.spawn(_worker, args=(world, _free_port(), shape, str(tmp_path)), nprocs=world, join=True)
     nx, ny, nz = shape
     pw = np.load(os.path.join(ROOT, "tests", "golden", "default_power.npz"))
