@@ -20,7 +20,13 @@ def per_kernel(path, counter):
 def main():
     fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
     write = per_kernel(sys.argv[2], "WRITE_SIZE")
-    out = {"note": sys.argv[4] if len(sys.argv) > 4 else "", "unit": "bytes per launch",
+    note = sys.argv[4] if len(sys.argv) > 4 else ""
+    try:
+        import subprocess
+        commit = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], text=True).strip()
+    except Exception:
+        commit = "unknown"
+    out = {"note": note, "source": "profiles/traffic_latest.json (%s) @ commit %s" % (note, commit), "unit": "bytes per launch",
            "correction": "read = 2 * FETCH_SIZE * 1024 (gfx950 wide-read under-count), write = WRITE_SIZE * 1024",
            "kernels": {}}
     for k in sorted(set(fetch) | set(write)):
