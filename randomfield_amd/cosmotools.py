@@ -1,48 +1,18 @@
 """
 Cosmology side-car -- the part of ``randomfield/cosmotools.py`` that touches the
-N^3 grid (:func:`apply_lognormal_transform`, cosmotools.py:206-221) plus thin
-wrappers for the O(nz) background tables.
+N^3 grid: :func:`apply_lognormal_transform` (cosmotools.py:206-221).
 
-The reference computes redshifts, growth function and mean matter densities
-with astropy (cosmotools.py:14-203).  Those are host-side O(nz) tables that the
-hot path only *consumes*; astropy is optional here: when it is missing,
-:class:`randomfield_amd.generate.Generator` accepts the tables as arrays.
+The reference derives redshifts, growth function, mean matter densities and the
+transverse distance from an astropy cosmology (cosmotools.py:14-203).  Those are
+host-side O(nz) tables that the hot path only *consumes*; building them is out of
+scope here (cosmology is not on the accelerated path), so
+:class:`randomfield_amd.generate.Generator` takes them as (nz,) arrays.
 """
 from __future__ import annotations
 
 import numpy as np
 
-__all__ = ["apply_lognormal_transform", "lognormal_tables", "create_cosmology", "have_astropy"]
-
-
-def have_astropy():
-    try:
-        import astropy.cosmology  # noqa: F401
-        return True
-    except Exception:
-        return False
-
-
-def create_cosmology(*args, **kwargs):
-    """Create a background cosmology (cosmotools.py:14-45); needs astropy."""
-    try:
-        import astropy.cosmology
-    except ImportError:
-        raise ImportError("astropy is required for create_cosmology(); pass growth_function= / "
-                          "mean_matter_density= arrays to Generator instead.")
-    if len(args) > 0 and len(kwargs) > 0:
-        raise TypeError("Cannot specify both a name and parameters.")
-    if len(args) > 1:
-        raise TypeError("Invalid arguments: expected a name or parameters.")
-    if len(args) == 1:
-        if not isinstance(args[0], str):
-            raise TypeError("Invalid arguments: expected a name or parameters.")
-        if args[0] not in ("WMAP5", "WMAP7", "WMAP9", "Planck13"):
-            raise ValueError("Unknown cosmology: {0}.".format(args[0]))
-        return getattr(astropy.cosmology, args[0])
-    if kwargs:
-        return astropy.cosmology.FlatLambdaCDM(**kwargs)
-    return astropy.cosmology.Planck13
+__all__ = ["apply_lognormal_transform", "lognormal_tables", "simps_avg"]
 
 
 def lognormal_tables(growth, sigma, nz):
@@ -55,19 +25,18 @@ def lognormal_tables(growth, sigma, nz):
 
 def apply_lognormal_transform(delta, growth, sigma=None):
     """
-    Transform delta values drawn from a normal distribution with mean zero and
-    standard deviation sigma to have a log-normal distribution with mean one
-    and standard deviation growth * sigma (cosmotools.py:206-221).  Transforms
-    are applied in place, overwriting the input delta field.  If sigma is not
-    specified, np.std(delta) will be used.  Host (numpy) version.
+    Map a zero-mean normal field of standard deviation ``sigma`` (default: ``np.std(delta)``) onto a
+    log-normal field with mean one and standard deviation ``growth * sigma``, in place
+    (cosmotools.py:206-221); ``growth`` is a scalar or broadcasts against ``delta`` (per-z tables).
+    Host (numpy) version: with spread = 1 + (sigma * growth)**2,
+    delta -> exp(delta / sigma * sqrt(log spread)) / sqrt(spread), evaluated in that order.
     """
-    if sigma is None:
-        sigma = np.std(delta)
-    t = 1 + (sigma * growth) ** 2
-    delta /= sigma
-    delta *= np.sqrt(np.log(t))
-    delta = np.exp(delta, out=delta)
-    delta /= np.sqrt(t)
+    sigma = np.std(delta) if sigma is None else sigma
+    spread = np.square(sigma * growth) + 1
+    np.divide(delta, sigma, out=delta)
+    np.multiply(delta, np.sqrt(np.log(spread)), out=delta)
+    np.exp(delta, out=delta)
+    np.divide(delta, np.sqrt(spread), out=delta)
     return delta
 
 

@@ -55,9 +55,12 @@ class Generator(object):
         Uniform grid spacing in Mpc/h.
     num_plot_sections : int
         Kept for compatibility: nz must be divisible by it (generate.py:86-90).
-    cosmology : astropy.cosmology.FLRW, optional
-        Background cosmology (needs astropy).  Only used for the O(nz) tables
-        (redshifts, growth function, mean matter density).
+    cosmology : object, optional
+        Kept for the caller's reference; the package never evaluates it.  The O(nz)
+        tables the reference derives from it (generate.py:104-129) are separate
+        arguments below, and passing ``cosmology`` without ``growth_function`` and
+        ``mean_matter_density`` raises ``ValueError``.  Only its ``Om0`` attribute is
+        read, by :meth:`calculate_newtonian_potential` when ``scale`` is not given.
     power : numpy.ndarray, optional
         Structured array with fields 'k', 'Pk' (powertools.validate_power).
         Defaults to the shipped Planck13 table.
@@ -78,7 +81,7 @@ class Generator(object):
         'native' uses the GPU's counter-based Philox4x32-10 + Box-Muller generator:
         no host work, different (statistically equivalent) realisations.
     growth_function, mean_matter_density, redshifts : (nz,) arrays, optional
-        The cosmology tables, for use without astropy.
+        The cosmology tables along z (the reference builds them with astropy, generate.py:104-129).
     transverse_distance : (nz,) array, optional
         Comoving transverse distance DA along z in Mpc/h (``self.DA`` of the reference,
         generate.py:117-118), for :meth:`calculate_lensing_potential`.
@@ -106,9 +109,15 @@ class Generator(object):
             raise ValueError("Z-axis does not evenly divided into {0} plot sections.".format(num_plot_sections))
         self.num_plot_sections = num_plot_sections
 
+        # The reference derives its O(nz) background tables (redshifts, growth function, mean matter density, DA;
+        # generate.py:104-129) from an astropy cosmology.  That derivation is outside this package:
+        # the tables are constructor arguments.  A `cosmology` object is kept for the caller's reference only, and
+        # asking for one WITHOUT the tables it would have produced is refused here rather than failing later.
         self.cosmology = cosmology
-        if cosmology is None and cosmotools.have_astropy():
-            self.cosmology = cosmotools.create_cosmology()
+        if cosmology is not None and (growth_function is None or mean_matter_density is None):
+            raise ValueError("cosmology= is not evaluated by this package: pass the tables it implies as arrays "
+                             "(growth_function=, mean_matter_density=, and redshifts= / transverse_distance= if "
+                             "needed).")
         if power is None:
             if cosmology is not None:
                 raise ValueError("A tabulated power= is required with a custom cosmology "
@@ -116,7 +125,6 @@ class Generator(object):
             power = powertools.load_default_power()
         self.power = powertools.validate_power(power)
 
-        # O(nz) background tables (generate.py:104-129): arrays win, else astropy if present
         self.redshifts = None if redshifts is None else np.asarray(redshifts, float).reshape(nz)
         self.growth_function = None if growth_function is None else np.asarray(growth_function, float).reshape(nz)
         self.mean_matter_density = (None if mean_matter_density is None
@@ -282,19 +290,18 @@ class Generator(object):
         transform of ``scale * delta(k)/k**2`` with scale = -3/2 H0**2 Omega_m
         (in s**-2, H0 = 100 km/s/Mpc), optionally times G(z)/(1+z) along z.
 
-        ``scale`` may be given explicitly; otherwise it is derived from the
-        cosmology (needs astropy).
+        ``scale`` may be given explicitly; otherwise it is -3/2 H0**2 ``cosmology.Om0``.
         """
         if show_plot or save_plot_name is not None:
             raise NotImplementedError("plot_slice is outside the accelerated path (see DESIGN.md).")
         if self.potential is None:
             raise RuntimeError("No saved potential field.")
         if scale is None:
-            if self.cosmology is None:
-                raise RuntimeError("calculate_newtonian_potential needs scale= or an astropy cosmology.")
-            import astropy.units as u
-            H0 = 100 * (u.km / u.s) / u.Mpc
-            scale = (-1.5 * H0 ** 2 * self.cosmology.Om0).to(u.s ** -2).value
+            om0 = getattr(self.cosmology, "Om0", None)
+            if om0 is None:
+                raise RuntimeError("calculate_newtonian_potential needs scale= (or a cosmology= object with Om0).")
+            H0 = 100.0 / 3.0856775814913673e19          # 100 km/s/Mpc in 1/s
+            scale = -1.5 * H0 ** 2 * float(om0)
         factor = None
         if light_cone:
             factor = self._need_table("growth_function") / (1 + self._need_table("redshifts"))

@@ -20,13 +20,16 @@ __all__ = ["get_k_bounds", "create_ksq_grids", "ksq_axes", "fill_with_log10k", "
            "sigma_table", "tabulate_sigmas", "load_default_power", "make_power"]
 
 
+def grid_k_range(shape, spacing):
+    """(k_min, k_max) of an (nx, ny, nz) grid: the fundamental mode of the longest axis and the corner of the
+    Nyquist cube (powertools.py:19-23)."""
+    fundamental = 2 * np.pi / spacing
+    return fundamental / max(shape), fundamental * np.sqrt(3) / 2
+
+
 def get_k_bounds(data, spacing, packed=True):
     """Bounds of wavenumber values for the specified grid (powertools.py:16-24)."""
-    nx, ny, nz = transform.expanded_shape(data, packed=packed)
-    k0 = (2 * np.pi) / spacing
-    k_min = k0 / max(nx, ny, nz)
-    k_max = k0 * np.sqrt(3) / 2
-    return k_min, k_max
+    return grid_k_range(transform.expanded_shape(data, packed=packed), spacing)
 
 
 def ksq_axes(nx, ny, nz, spacing, packed=True):
@@ -53,38 +56,43 @@ def fill_with_log10k(data, spacing, packed=True):
     """
     Fill an array with values of log10(k) (powertools.py:40-61).
 
-    Note that the value at [0, 0, 0] will be log10(0) = -inf.  The rounding
-    chain of the reference is kept: the float64 sum kx2+ky2 is rounded to the
-    array dtype, kz2 is added in float64 and rounded again, then log10 and the
-    halving are done in the array dtype.
+    Note that the value at [0, 0, 0] will be log10(0) = -inf.  Built from the
+    three axis tables: the (nx, ny) plane of kx**2 + ky**2 is formed in float64
+    and rounded to the array's real type once, kz**2 is then added to it in
+    float64 and the sum rounded again -- the same two roundings per cell as the
+    reference's in-place ufunc chain, which is what makes the result
+    bit-identical to it -- then log10 and the halving in the array's real type.
     """
-    kx2_grid, ky2_grid, kz2_grid = create_ksq_grids(data, spacing, packed)
-    data.imag = 0
-    np.add(kx2_grid, ky2_grid, out=data.real, casting="same_kind")
-    np.add(data.real, kz2_grid, out=data.real, casting="same_kind")
+    kx2, ky2, kz2 = ksq_axes(*transform.expanded_shape(data, packed=packed), spacing, packed=packed)
+    re = data.real
+    plane = np.add.outer(kx2, ky2).astype(re.dtype)
+    np.add(plane[:, :, None], kz2[None, None, :], out=re, casting="same_kind")
     with np.errstate(divide="ignore"):
-        np.log10(data.real, out=data.real)
-    data.real *= 0.5
+        np.log10(re, out=re)
+    np.multiply(re, re.dtype.type(0.5), out=re)
+    data.imag = 0
     return data
 
 
+# validate_power: (test on the table -> True when it FAILS, message), checked in this order (powertools.py:64-82)
+_POWER_RULES = (
+    (lambda p: not np.all(np.isfinite(p["k"])), "Power spectrum has some invalid values of k."),
+    (lambda p: not np.all(np.isfinite(p["Pk"])), "Power spectrum has some invalid values of P(k)."),
+    (lambda p: not np.array_equal(p["k"], np.unique(p["k"])), "Power spectrum k values are not strictly increasing."),
+    (lambda p: p["k"][0] <= 0, "Power spectrum min(k) is <= 0."),
+    (lambda p: np.any(p["Pk"] < 0), "Power values P(k) are not all non-negative."),
+)
+
+
 def validate_power(power):
-    """Validates a power spectrum (powertools.py:64-82)."""
+    """Validates a power spectrum (powertools.py:64-82); returns it."""
     if not isinstance(power, np.ndarray):
         raise ValueError("Invalid type for power: {0}.".format(type(power)))
-    names = power.dtype.names or ()
-    if "k" not in names or "Pk" not in names:
+    if not {"k", "Pk"} <= set(power.dtype.names or ()):
         raise ValueError('Missing required fields "k", "Pk" in power.')
-    if not np.all(np.isfinite(power["k"])):
-        raise ValueError("Power spectrum has some invalid values of k.")
-    if not np.all(np.isfinite(power["Pk"])):
-        raise ValueError("Power spectrum has some invalid values of P(k).")
-    if not np.array_equal(power["k"], np.unique(power["k"])):
-        raise ValueError("Power spectrum k values are not strictly increasing.")
-    if power["k"][0] <= 0:
-        raise ValueError("Power spectrum min(k) is <= 0.")
-    if np.any(power["Pk"] < 0):
-        raise ValueError("Power values P(k) are not all non-negative.")
+    for fails, message in _POWER_RULES:
+        if fails(power):
+            raise ValueError(message)
     return power
 
 
@@ -92,19 +100,19 @@ def filter_power(power, sigma, out=None):
     """
     Apply a Gaussian filtering to a power spectrum (powertools.py:85-122):
     P(k) -> P(k) * exp(-(k*sigma)**2), i.e. delta(r) is convolved with a 3D
-    Gaussian of width sigma.
+    Gaussian of width sigma.  ``out=None`` returns a filtered copy, ``out=power``
+    filters in place, any other ``out`` receives the filtered table.
     """
     if sigma < 0:
         raise ValueError("Invalid smoothing sigma: {0}.".format(sigma))
     if out is None:
-        out = np.copy(power)
+        out = power.copy()
     elif out is not power:
-        validate_power(power)
-        if out.shape != power.shape:
+        if validate_power(power).shape != out.shape:
             raise ValueError("Output power has wrong shape: {0}.".format(out.shape))
-        out[:] = power
+        out[...] = power
     if sigma > 0:
-        out["Pk"] *= np.exp(-(power["k"] * sigma) ** 2)
+        np.multiply(out["Pk"], np.exp(-np.square(power["k"] * sigma)), out=out["Pk"])
     return out
 
 
@@ -115,21 +123,17 @@ def sigma_table(power, shape, spacing):
     range check that the table covers the grid's [k_min, k_max].
     These are what the HIP kernels consume (``rf_set_power``).
     """
-    validate_power(power)
-    nx, ny, nz = shape
-    N3 = nx * ny * nz
-    Vbox = N3 * spacing ** 3
-    power_k_min, power_k_max = np.min(power["k"]), np.max(power["k"])
-    if power_k_min <= 0:
-        raise ValueError("Power uses min(k) <= 0: {0}.".format(power_k_min))
-    k0 = (2 * np.pi) / spacing
-    data_k_min, data_k_max = k0 / max(nx, ny, nz), k0 * np.sqrt(3) / 2
-    if power_k_min > data_k_min or power_k_max < data_k_max:
+    k, Pk = validate_power(power)["k"], power["Pk"]
+    cells = shape[0] * shape[1] * shape[2]
+    volume = cells * spacing ** 3
+    table_lo, table_hi = np.min(k), np.max(k)
+    if table_lo <= 0:
+        raise ValueError("Power uses min(k) <= 0: {0}.".format(table_lo))
+    grid_lo, grid_hi = grid_k_range(shape, spacing)
+    if table_lo > grid_lo or table_hi < grid_hi:
         raise ValueError("Power k range [{0}:{1}] does not cover data k range [{2}:{3}]."
-                         .format(power_k_min, power_k_max, data_k_min, data_k_max))
-    log10_k = np.log10(power["k"])
-    sigma = N3 * np.sqrt(power["Pk"] / (2 * Vbox))
-    return log10_k, sigma
+                         .format(table_lo, table_hi, grid_lo, grid_hi))
+    return np.log10(k), cells * np.sqrt(Pk / (2 * volume))
 
 
 def tabulate_sigmas(data, power, spacing, packed=True):
@@ -155,13 +159,15 @@ def make_power(k, Pk):
     return power
 
 
-def load_default_power(scaled_by_h=True):
+def load_default_power(scaled_by_h=True, h=None):
     """
     Loads the default power spectrum P(k, z=0) (powertools.py:167-197): 500 rows,
     1e-4 <= k <= 22 h/Mpc, Planck13 via CLASS; units h/Mpc and (Mpc/h)**3.
 
     The table is stored as ``data/default_power.npz`` (binary copy of the
-    reference's data file).  ``scaled_by_h=False`` needs the cosmology's h.
+    reference's data file).  ``scaled_by_h=False`` converts to 1/Mpc and Mpc**3 and
+    needs the Hubble parameter ``h`` (the reference takes it from its astropy
+    cosmology, which is outside this package's scope: Planck13 has h = 0.6777).
     """
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "default_power.npz")
     try:
@@ -170,8 +176,8 @@ def load_default_power(scaled_by_h=True):
         raise RuntimeError("Unable to load default_power.npz")
     power = make_power(table["k"], table["Pk"])
     if scaled_by_h is False:
-        from . import cosmotools
-        h = cosmotools.create_cosmology().h
+        if h is None:
+            raise ValueError("load_default_power(scaled_by_h=False) needs h= (e.g. 0.6777 for Planck13).")
         power["k"] *= h
         power["Pk"] /= h ** 3
     return power

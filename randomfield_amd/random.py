@@ -24,13 +24,12 @@ def reference_normals(seed, size):
 def randomize(data, seed=None):
     """
     Randomize data by multiplying existing sigma values by normal deviates
-    (random.py:12-29): imag := real, then every real component of the flat
-    interleaved view is scaled by its own N(0,1) deviate (float64 product rounded
-    to the array dtype).  The global numpy RNG state is left alone.
+    (random.py:12-29).  On entry the real parts hold sigma; on exit every complex
+    cell is sigma * (g_re + i g_im) with consecutive deviates of the stream going
+    to (re, im) of consecutive cells in C order; each product is formed in float64
+    and rounded once to the array's type.  The global numpy RNG state is left alone.
     """
-    data.imag = data.real
-    real_type = transform.scalar_type(data.dtype)
-    real_size = 2 * data.size
-    sigmas = data.view(real_type).reshape(real_size)
-    sigmas *= reference_normals(seed, real_size)
+    pairs = data.view(transform.scalar_type(data.dtype)).reshape(-1, 2)     # one (re, im) row per cell, same memory
+    pairs[:, 1] = pairs[:, 0]
+    np.multiply(pairs, reference_normals(seed, pairs.size).reshape(pairs.shape), out=pairs, casting="same_kind")
     return data

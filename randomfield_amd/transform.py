@@ -59,18 +59,15 @@ def allocate(shape, dtype, use_pyfftw=True):
 
 
 def expanded_shape(data, packed=False):
-    """Determine the expanded shape of a 3D array (transform.py:46-60)."""
-    nx, ny, nz = data.shape
-    if nx % 2 or ny % 2:
+    """Logical (nx, ny, nz) of a 3D array; a packed array stores nz/2 + 1 planes (transform.py:46-60)."""
+    nx, ny, nz_stored = data.shape
+    if (nx | ny) & 1:
         raise ValueError("First two dimensions of array must be even.")
-    if packed:
-        if nz % 2 == 0:
-            raise ValueError("Last dimension of packed array must be odd.")
-        nz = 2 * (nz - 1)
-    else:
-        if nz % 2:
-            raise ValueError("Last dimension of unpacked array must be even.")
-    return nx, ny, nz
+    stored_is_odd = bool(nz_stored & 1)
+    if stored_is_odd != bool(packed):
+        raise ValueError("Last dimension of packed array must be odd." if packed
+                         else "Last dimension of unpacked array must be even.")
+    return nx, ny, (2 * (nz_stored - 1) if packed else nz_stored)
 
 
 def _sctype(rep):
@@ -165,6 +162,59 @@ def symmetrize(data, packed=False):
     data.real[0, 0, 0] = 0
 
 
+class _Layout(object):
+    """Shapes and scalar types of a plan's two sides."""
+    __slots__ = ("shape", "shape_in", "shape_out", "dtype_in", "dtype_out")
+
+    def __init__(self, shape, shape_in, shape_out, dtype_in, dtype_out):
+        self.shape, self.shape_in, self.shape_out = shape, shape_in, shape_out
+        self.dtype_in, self.dtype_out = dtype_in, dtype_out
+
+
+# (packed, inverse) -> (required family of dtype_in, message when it is not met, dtype_out from dtype_in)
+_KINDS = {
+    (True, True): (np.complexfloating, "Invalid dtype_in for inverse packed transform (should be complex): {0}.",
+                   lambda t: scalar_type(t)),
+    (True, False): (np.floating, "Invalid dtype_in for forward packed transform (should be floating): {0}.",
+                    lambda t: complex_type(t)),
+    (False, True): (np.complexfloating, "Expected complex dtype_in for transform: {0}.", lambda t: t),
+    (False, False): (np.complexfloating, "Expected complex dtype_in for transform: {0}.", lambda t: t),
+}
+
+
+def _resolve_layout(shape, dtype_in, data_in, overwrite, inverse, packed):
+    """Validate the constructor arguments of :class:`Plan` and work out both sides' shapes and types
+    (the argument rules, exception types and messages of transform.py:170-225)."""
+    try:
+        nx, ny, nz = shape
+    except (TypeError, ValueError):
+        raise ValueError("Expected 3D shape.")
+    if (nx | ny | nz) & 1:
+        raise ValueError("All shape dimensions must be even.")
+    shape = (nx, ny, nz)
+    if data_in is not None:
+        if not isinstance(data_in, np.ndarray):
+            raise ValueError("Invalid type for data_in: {0}.".format(type(data_in)))
+        dtype_in = data_in.dtype
+    dtype_in = _sctype(dtype_in)
+    if dtype_in is None:
+        raise ValueError("Invalid dtype_in: {0}.".format(dtype_in))
+    family, complaint, out_of = _KINDS[(bool(packed), bool(inverse))]
+    if not issubclass(dtype_in, family):
+        raise ValueError(complaint.format(dtype_in))
+    half, padded = (nx, ny, nz // 2 + 1), (nx, ny, nz + 2)       # complex side / in-place real side of a packed plan
+    real_side = padded if overwrite else shape
+    if not packed:
+        shape_in = shape_out = shape
+    elif inverse:
+        shape_in, shape_out = half, real_side
+    else:
+        shape_in, shape_out = real_side, half
+    if data_in is not None and data_in.shape != shape_in:
+        raise ValueError("data_in has wrong shape {0}, expected {1}.".format(data_in.shape, shape_in))
+    return _Layout(shape, shape_in, shape_out, dtype_in, out_of(dtype_in))
+
+
 class Plan(object):
     """
     A plan for performing fast Fourier transforms on a single buffer
@@ -187,68 +237,30 @@ class Plan(object):
 
     def __init__(self, shape, dtype_in=None, data_in=None, overwrite=True, inverse=True, packed=True,
                  use_pyfftw=True, backend=None, _device=None):
-        try:
-            nx, ny, nz = shape
-        except (TypeError, ValueError):
-            raise ValueError("Expected 3D shape.")
-        if nx % 2 or ny % 2 or nz % 2:
-            raise ValueError("All shape dimensions must be even.")
-
-        if data_in is not None:
-            if not isinstance(data_in, np.ndarray):
-                raise ValueError("Invalid type for data_in: {0}.".format(type(data_in)))
-            dtype_in = data_in.dtype
-        dtype_in = _sctype(dtype_in)
-        if dtype_in is None:
-            raise ValueError("Invalid dtype_in: {0}.".format(dtype_in))
-
-        if packed:
-            if inverse:
-                shape_in = (nx, ny, nz // 2 + 1)
-                if not issubclass(dtype_in, np.complexfloating):
-                    raise ValueError("Invalid dtype_in for inverse packed transform "
-                                     "(should be complex): {0}.".format(dtype_in))
-                dtype_out = scalar_type(dtype_in)
-                shape_out = (nx, ny, nz + 2) if overwrite else tuple(shape)
-            else:
-                shape_in = (nx, ny, nz + 2) if overwrite else tuple(shape)
-                if not issubclass(dtype_in, np.floating):
-                    raise ValueError("Invalid dtype_in for forward packed transform "
-                                     "(should be floating): {0}.".format(dtype_in))
-                dtype_out = complex_type(dtype_in)
-                shape_out = (nx, ny, nz // 2 + 1)
-        else:
-            if not issubclass(dtype_in, np.complexfloating):
-                raise ValueError("Expected complex dtype_in for transform: {0}.".format(dtype_in))
-            shape_in = shape_out = tuple(shape)
-            dtype_out = dtype_in
-
-        if data_in is not None:
-            if data_in.shape != shape_in:
-                raise ValueError("data_in has wrong shape {0}, expected {1}.".format(data_in.shape, shape_in))
-            self.data_in = data_in
-            self.nbytes_allocated = 0
-        else:
-            self.data_in = allocate(shape_in, dtype_in, use_pyfftw=use_pyfftw)
-            self.nbytes_allocated = self.data_in.nbytes
-        if overwrite:
-            if packed:
-                self.data_out = self.data_in.view(dtype_out).reshape(shape_out)
-                # hide the FFTW-style padding without copying (transform.py:231-238)
-                if inverse:
-                    self.data_out_padded = self.data_out
-                    self.data_out = self.data_out[:, :, :nz]
-                else:
-                    self.data_in_padded = self.data_in
-                    self.data_in = self.data_in[:, :, :nz]
-            else:
-                self.data_out = self.data_in
-        else:
-            self.data_out = allocate(shape_out, dtype_out, use_pyfftw=use_pyfftw)
+        lay = _resolve_layout(shape, dtype_in, data_in, overwrite, inverse, packed)
+        nz = lay.shape[2]
+        self.nbytes_allocated = 0
+        if data_in is None:
+            data_in = allocate(lay.shape_in, lay.dtype_in, use_pyfftw=use_pyfftw)
+            self.nbytes_allocated += data_in.nbytes
+        # One buffer, several views (transform.py:227-242): an overwriting packed plan reinterprets its input
+        # buffer as the output type; whichever side is real carries FFTW's two padding columns, exposed as
+        # `*_padded` and hidden from `data_in` / `data_out` by a slice (no copy).
+        self.data_in = data_in
+        if not overwrite:
+            self.data_out = allocate(lay.shape_out, lay.dtype_out, use_pyfftw=use_pyfftw)
             self.nbytes_allocated += self.data_out.nbytes
+        elif not packed:
+            self.data_out = data_in
+        else:
+            alias = data_in.view(lay.dtype_out).reshape(lay.shape_out)
+            if inverse:
+                self.data_out_padded, self.data_out = alias, alias[:, :, :nz]
+            else:
+                self.data_in_padded, self.data_in, self.data_out = data_in, data_in[:, :, :nz], alias
 
         self.use_pyfftw = False          # pyFFTW is never used (kept as an attribute for compatibility)
-        self.shape = tuple(shape)
+        self.shape = lay.shape
         self.inverse = inverse
         self.packed = packed
         self.overwrite = overwrite
@@ -258,7 +270,8 @@ class Plan(object):
         if self.backend == "hip":
             from . import _hip
             _hip.require_gpu()           # raises: library missing / no GPU
-            cdtype = dtype_in if (inverse or not packed) else dtype_out
+            nx, ny = lay.shape[0], lay.shape[1]
+            cdtype = lay.dtype_in if (inverse or not packed) else lay.dtype_out
             if np.dtype(cdtype) not in (np.dtype(np.complex64), np.dtype(np.complex128)):
                 raise RuntimeError("hip backend supports complex64 / complex128 only: {0}.".format(cdtype))
             if packed:
@@ -288,21 +301,17 @@ class Plan(object):
         as our data_out.  Otherwise a new un-initialized data_in buffer is
         allocated for the new plan.
         """
-        inverse = not self.inverse
-        if reuse_output:
-            if self.packed and self.inverse and overwrite:
-                if not self.overwrite:
-                    raise RuntimeError("Cannot re-use output for reverse plan.")
-                data_in = self.data_out_padded
-            else:
-                data_in = self.data_out
-            dtype_in = None
-        else:
-            data_in = None
-            dtype_in = self.data_out.dtype
-        return Plan(shape=self.shape, dtype_in=dtype_in, data_in=data_in, overwrite=overwrite, inverse=inverse,
-                    packed=self.packed, use_pyfftw=self.use_pyfftw, backend=self.backend,
+        spec = dict(shape=self.shape, overwrite=overwrite, inverse=not self.inverse, packed=self.packed,
+                    use_pyfftw=self.use_pyfftw, backend=self.backend,
                     _device=self.device if self.backend == "hip" else None)
+        if not reuse_output:
+            return Plan(dtype_in=self.data_out.dtype, **spec)
+        # an overwriting reverse of a packed c2r plan needs the padded real buffer, which exists only if this plan
+        # overwrites too
+        wants_padded = self.packed and self.inverse and overwrite
+        if wants_padded and not self.overwrite:
+            raise RuntimeError("Cannot re-use output for reverse plan.")
+        return Plan(data_in=self.data_out_padded if wants_padded else self.data_out, **spec)
 
     def execute(self):
         """Run the transform; returns ``data_out`` (transform.py:303-315)."""

@@ -819,3 +819,24 @@ def test_collectives_leave_the_moments_alone(hip, dpower):
     rms2 = plan.realise_batch(seeds)
     assert np.array_equal(rms, rms2)
     plan.close()
+
+
+@pytest.mark.parametrize("K", [0.0, 2e-6, -3e-6])
+def test_lensing_kernel_closed_form(hip, K):
+    """rf_lensing_potential against analytic line-of-sight integrals (tests/lensing_closed_form.py): constant, linear
+    and quadratic potentials, flat and curved, odd and even sample counts; float64 plan to 1e-11, float32 to 2e-6.
+    Independent of the oracle's Simpson restatement (generate.py:397-411)."""
+    import lensing_closed_form as lcf
+    nx, ny, nz, h = 8, 8, 64, 2.5
+    for dtype, ct, tol in ((np.float64, np.complex128, 1e-11), (np.float32, np.complex64, 2e-6)):
+        plan = hip.DevicePlan(nx, ny, nz, ct)
+        for coeffs in ([1.5], [0.2, -0.01], [1.0, 0.03, -2e-4]):
+            for i_min in (1, 2, 9):
+                DC, DA = lcf.tables(nz, h, K)
+                phi = np.polynomial.Polynomial(coeffs)(DC)
+                plan.upload_real(np.broadcast_to(phi, (nx, ny, nz)).astype(dtype))
+                plan.lensing_potential(cpu_ref.cot_k(DC, DA, K), h, i_min)
+                psi = plan.download_aux()
+                want = lcf.expected(coeffs, nz, h, i_min)
+                assert np.max(np.abs(psi - want[None, None, :])) <= tol * np.max(np.abs(want))
+        plan.close()

@@ -177,3 +177,22 @@ def test_simps_restatement_against_scipy():
             b = 0.5 * (x[1] - x[0]) * (y[:, 0] + y[:, 1]) + (integrate.simpson(y[:, 1:], x=x[1:]) if N > 2 else 0.0)
             ref = 0.5 * (a + b)
         assert np.allclose(got, ref, rtol=1e-13, atol=1e-13), N
+
+
+@pytest.mark.parametrize("K", [0.0, 2e-6, -3e-6])
+@pytest.mark.parametrize("coeffs", [[1.5], [0.2, -0.01], [1.0, 0.03, -2e-4]])
+def test_lensing_oracle_closed_form(K, coeffs):
+    """The oracle's slice loop + Simpson restatement against analytic integrals (tests/lensing_closed_form.py):
+    constant, linear and quadratic potentials, flat and curved models, odd and even sample counts -- a pin of
+    generate.py:397-411 that does not rest on this repo's reading of scipy.integrate.simps."""
+    import lensing_closed_form as lcf
+    nz, h = 48, 2.5
+    for i_min in (1, 2, 7):
+        DC, DA = lcf.tables(nz, h, K)
+        phi = np.polynomial.Polynomial(coeffs)(DC)
+        field = np.broadcast_to(phi, (2, 3, nz)).copy()
+        psi = cpu_ref.lensing_potential(field, DC, DA, K=K, i_min=i_min)
+        want = lcf.expected(coeffs, nz, h, i_min)
+        scale = np.max(np.abs(want))
+        assert np.max(np.abs(psi - want[None, None, :])) <= 1e-11 * scale
+        assert np.all(psi[:, :, :i_min] == 0)
