@@ -263,6 +263,31 @@ int emu_realise_fast(int f64, int nx, int ny, int nz, const double* kx2, const d
   return realise_fast_impl<float, FastGenColIO>(nx, ny, nz, h, seed, xlo, xhi, dkx, (cplx<float>*)W, s1, s2);
 }
 
+// Row T alone: the fast float32 sigma(|k|^2) lookup (per-bin records, rf_core.h fast_sigma) next to the exact float64
+// interpolation of the same table, for n values of |k|^2 -- bounds the table-lookup error separately from the
+// transcendental error of the deviates.  [xlo, xhi] = padded log10 k range of the grid, as the library passes it.
+int emu_fast_sigma(const double* log10k, const double* sigma, int nt, double xlo, double xhi, const float* k2, int n,
+                   float* out_fast, double* out_exact) {
+  SigmaTableHost tab;
+  build_sigma_table(log10k, sigma, nt, tab);
+  std::vector<FastRec> rec;
+  double x0, dx;
+  if (!build_fast_records(tab, xlo, xhi, rec, x0, dx)) return -3;
+  FastGenParams f;
+  memset(&f, 0, sizeof f);
+  f.rec = rec.data(); f.nbins = (int)rec.size();
+  f.u_scale = (float)(0.5 * std::log10(2.0) / dx); f.u_off = (float)(-x0 / dx);
+  GenParams g;
+  memset(&g, 0, sizeof g);
+  g.xt = tab.xt.data(); g.st = tab.st.data(); g.sl = tab.sl.data(); g.bin = tab.bin.data();
+  g.nt = nt; g.nbins = (int)tab.bin.size(); g.x0 = tab.x0; g.inv_dx = tab.inv_dx;
+  for (int i = 0; i < n; ++i) {
+    out_fast[i] = fast_sigma(f, rec.data(), k2[i]);
+    out_exact[i] = sigma_lookup(g, 0.5 * std::log10((double)k2[i]));
+  }
+  return f.nbins;
+}
+
 // k-space after symmetrise in the API layout [nx][ny][nz/2+1] (rows K,T,R,S)
 int emu_generate_kspace(int f64, int nx, int ny, int nz, const double* kx2, const double* ky2, const double* kz2,
                         const double* log10k, const double* sigma, int nt, int noise_mode, uint64_t seed,

@@ -122,3 +122,20 @@ def r2c(field):
                        out.ctypes.data_as(ctypes.c_void_p))
     assert rc == 0, rc
     return out
+
+
+def fast_sigma(log10k, sigma, xlo, xhi, k2):
+    """fast float32 sigma lookup and the exact float64 interpolation for an array of |k|^2 values; also the number
+    of per-bin records the fast table needed"""
+    log10k = np.ascontiguousarray(log10k, np.float64)
+    sigma = np.ascontiguousarray(sigma, np.float64)
+    k2 = np.ascontiguousarray(k2, np.float32)
+    fast = np.empty(k2.size, np.float32)
+    exact = np.empty(k2.size, np.float64)
+    f = lib().emu_fast_sigma
+    f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_void_p,
+                  ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    nb = f(log10k.ctypes.data, sigma.ctypes.data, len(log10k), xlo, xhi, k2.ctypes.data, k2.size, fast.ctypes.data,
+           exact.ctypes.data)
+    assert nb > 0, nb
+    return fast, exact, nb

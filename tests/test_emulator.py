@@ -181,3 +181,29 @@ def test_unpacked_c2c_against_numpy(shape):
         assert np.max(np.abs(inv - ref)) <= 4 * tol
         back = emu_util.c2c(fwd, inverse=True)
         assert np.max(np.abs(back - a)) <= 20 * tol
+
+
+def test_fast_sigma_lookup_error_bound(default_power):
+    """Row T of the fast native generation (powertools.py:125-164 semantics): the float32 per-bin records against the
+    exact float64 piecewise-linear interpolation over the whole |k|^2 range of a 1024^3 and a 64^3 grid, including
+    values next to bin edges and table knots.  This is the table part of the native path's error budget; the
+    hardware transcendentals are bounded by the GPU tests.  Bound: 1e-6 relative; measured 6.0e-7 (the bin
+    coordinate u = a log2|k|^2 + b is a float32 of magnitude <= 512, i.e. resolved to 3e-5 of a bin, times the
+    <= 2 % change of sigma across a bin)."""
+    from oracle import cpu_ref
+    k, Pk = default_power["k"], default_power["Pk"]
+    for n in (1024, 64):
+        xt, st = cpu_ref.sigma_table(k, Pk, n, n, n, 2.5)
+        k0 = 2 * np.pi / 2.5
+        xlo, xhi = np.log10(k0 / n) - 0.01, np.log10(k0 * np.sqrt(3) / 2) + 0.01
+        rng = np.random.RandomState(n)
+        # all |k|^2 of the form dk^2 * (integer), a log-uniform sample, and points hugging the table knots
+        ints = np.unique(np.concatenate([np.arange(1, 4096), rng.randint(1, 3 * (n // 2) ** 2, 200000)]))
+        k2 = [(k0 / n) ** 2 * ints, 10 ** rng.uniform(2 * (xlo + 0.011), 2 * (xhi - 0.011), 200000)]
+        knots = xt[(xt > xlo + 0.02) & (xt < xhi - 0.02)]
+        k2.append(np.concatenate([10 ** (2 * knots) * (1 + e) for e in (-3e-7, -1e-7, 0.0, 1e-7, 3e-7)]))
+        k2 = np.concatenate(k2).astype(np.float32)
+        fast, exact, nb = emu_util.fast_sigma(xt, st, xlo, xhi, k2)
+        assert nb <= 512                                        # the records fit the kernel's LDS table
+        rel = np.abs(fast - exact) / np.maximum(np.abs(exact), 1e-300)
+        assert np.max(rel) <= 1e-6, "fast sigma lookup off by %.3g relative" % np.max(rel)
