@@ -198,7 +198,8 @@ def test_fast_sigma_lookup_error_bound(default_power):
         xlo, xhi = np.log10(k0 / n) - 0.01, np.log10(k0 * np.sqrt(3) / 2) + 0.01
         rng = np.random.RandomState(n)
         # all |k|^2 of the form dk^2 * (integer), a log-uniform sample, and points hugging the table knots
-        ints = np.unique(np.concatenate([np.arange(1, 4096), rng.randint(1, 3 * (n // 2) ** 2, 200000)]))
+        top = 3 * (n // 2) ** 2                                  # |k|^2 / dk^2 never exceeds this on the grid
+        ints = np.unique(np.concatenate([np.arange(1, min(4096, top + 1)), rng.randint(1, top + 1, 200000)]))
         k2 = [(k0 / n) ** 2 * ints, 10 ** rng.uniform(2 * (xlo + 0.011), 2 * (xhi - 0.011), 200000)]
         knots = xt[(xt > xlo + 0.02) & (xt < xhi - 0.02)]
         k2.append(np.concatenate([10 ** (2 * knots) * (1 + e) for e in (-3e-7, -1e-7, 0.0, 1e-7, 3e-7)]))
