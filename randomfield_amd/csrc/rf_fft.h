@@ -118,7 +118,7 @@ struct ColGeom {
 #define RF_FORCE_WIDE 0
 #endif
     if (WIDE || RF_FORCE_WIDE) return ub + lane_part_wide(cl, rb);
-    return reinterpret_cast<E*>(reinterpret_cast<char*>(ub) + (size_t)(lane_part(cl, rb) * (uint32_t)sizeof(E)));
+    return reinterpret_cast<E*>((size_t)ub + (size_t)(lane_part(cl, rb) * (uint32_t)sizeof(E)));
   }
 };
 
