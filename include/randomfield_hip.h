@@ -107,6 +107,11 @@ int rf_execute_c2c(rf_plan* plan, int direction);
  * (generate.py:191-199,218-219).  Generation is fused into the first FFT pass; the
  * k-space array is never materialised.  rms/mean are available from rf_moments(). */
 int rf_realise(rf_plan* plan, uint64_t seed, int mode, const double* noise_host);
+/* The reference's DEFAULT call, generate_delta_field(save_potential=True) (generate.py:191-219): as rf_realise, and
+ * delta(k) / k^2 (0 at DC; generate.py:200-217) is left in the plan's potential buffer for rf_load_potential.  Native
+ * noise on a float32 single-GPU plan: the potential is a second store stream of the generation pass (delta(k) is never
+ * materialised); otherwise the call runs rf_generate -> rf_save_potential -> rf_execute_c2r. */
+int rf_realise_potential(rf_plan* plan, uint64_t seed, int mode, const double* noise_host);
 /* n realisations back to back (native noise); the field of the last seed stays resident; rms_out[i]
  * (may be NULL) = np.std of field i.  Single-GPU plans replay one captured hipGraph.  Multi-GPU plans
  * pipeline instead: realisation i+1's generation / x / y passes run on the compute stream while

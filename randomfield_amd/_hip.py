@@ -50,6 +50,7 @@ SIGNATURES = {
     "rf_download_c": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "rf_execute_c2c": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "rf_realise": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, _c_dp]),
+    "rf_realise_potential": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, _c_dp]),
     "rf_realise_batch": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64), ctypes.c_int, _c_dp]),
     "rf_realise_batch_prepare": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "rf_moments": (ctypes.c_int, [ctypes.c_void_p, _c_dp, _c_dp]),
@@ -296,6 +297,12 @@ class DevicePlan(object):
     def realise(self, seed=0, noise=None):
         mode, ptr, keep = self._noise_arg(noise)
         check(self._lib.rf_realise(self._h, ctypes.c_uint64(int(seed) & (2 ** 64 - 1)), mode, ptr), "rf_realise")
+
+    def realise_potential(self, seed=0, noise=None):
+        """generate_delta_field(save_potential=True): the field, and delta(k)/k**2 in the potential buffer."""
+        mode, ptr, keep = self._noise_arg(noise)
+        check(self._lib.rf_realise_potential(self._h, ctypes.c_uint64(int(seed) & (2 ** 64 - 1)), mode, ptr),
+              "rf_realise_potential")
 
     def realise_batch(self, seeds, want_rms=True):
         seeds = np.ascontiguousarray(seeds, dtype=np.uint64)

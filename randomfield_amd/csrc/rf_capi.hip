@@ -142,6 +142,7 @@ struct rf_plan {
   uint64_t* seeds_pin[2] = {nullptr, nullptr};
   hipEvent_t seeds_ev[2] = {nullptr, nullptr};
   int seeds_pin_cap = 0, seeds_turn = 0;
+  void* pot_target = nullptr;             // non-null while rf_realise_potential queues its x pass: where delta(k)/k^2 goes
   double* coll_scratch = nullptr;         // 2 doubles on the device for host-side all-reduces (never aliases `stats`)
   double* ztab = nullptr;                 // 2 * nz doubles for lognormal / affine tables
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // start, after x, y, z, reduce; [5] = after the kz = 0 repair launch
@@ -278,7 +279,7 @@ int queue_x(rf_plan* p, const GenParams& gp, const void* kspace, void* W, hipStr
   if (fast)
     RF_HIP(launch_col_fastgen(p->f64, p->nx, W, gx, (long long)p->ny * nzl, make_fast(p, gp.seed, gp.seed_dev != nullptr, gp.seed_dev),
                               kz0, (int)nzl, p->tw_x, sx, false, timed ? p->ev[5] : nullptr,
-                              rep ? p->rank * p->nxl : 0, rep ? (p->rank + 1) * p->nxl : 1 << 30));
+                              rep ? p->rank * p->nxl : 0, rep ? (p->rank + 1) * p->nxl : 1 << 30, p->pot_target));
   else
     RF_HIP(launch_col_gen(p->f64, p->nx, W, gx, (long long)p->ny * nzl, gp, kspace, kz0, (int)nzl, p->tw_x, sx));
   return 0;
@@ -796,6 +797,30 @@ int rf_realise(rf_plan* p, uint64_t seed, int mode, const double* noise_host) {
   if (rc) return rc;
   if (mode == RF_NOISE_EXTERNAL) RF_HIP(hipStreamSynchronize(p->stream));
   return 0;
+}
+
+// generate_delta_field(save_potential=True) (generate.py:191-219): the field as rf_realise, plus delta(k) / k^2 in the
+// plan's potential buffer.  With the native generator on a float32 single-GPU plan the potential is a second store
+// stream of the generation pass; every other case runs the unfused sequence generate -> save_potential -> c2r.
+int rf_realise_potential(rf_plan* p, uint64_t seed, int mode, const double* noise_host) {
+  RF_REQUIRE(p, "null plan");
+  RF_REQUIRE(!p->unpacked, "this call does not apply to an unpacked c2c plan");
+  RF_REQUIRE(p->nranks == 1, "k-space buffer operations are single-GPU only");
+  RF_REQUIRE(p->have_kgrid && p->have_power, "rf_set_kgrid and rf_set_power must be called first");
+  RF_REQUIRE(mode == RF_NOISE_NATIVE || mode == RF_NOISE_EXTERNAL || mode == RF_NOISE_RESIDENT, "invalid noise mode");
+  RF_HIP(hipSetDevice(p->device));
+  const bool fused = mode == RF_NOISE_NATIVE && p->have_fast && !p->exact_gen && !p->f64 && !p->force_slab;
+  if (!fused) {
+    if (int rc = rf_generate(p, seed, mode, noise_host)) return rc;
+    if (int rc = rf_save_potential(p)) return rc;
+    return rf_execute_c2r(p);
+  }
+  if (!p->P) RF_HIP(hipMalloc(&p->P, p->k_bytes));
+  p->timed = true;
+  p->pot_target = p->P;
+  const int rc = queue_c2r(p, make_gen(p, seed, mode, false), nullptr);
+  p->pot_target = nullptr;
+  return rc;
 }
 
 // issue the n realisations of a batch on the plan's stream (under stream capture)

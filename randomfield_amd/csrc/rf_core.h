@@ -485,7 +485,17 @@ RF_HD cplx<float> fast_gen_one(const FastGenParams& g, const FastRec* rec, uint6
 
 // slot kz = 0 of column (ix, iy): (plane kz=0) + i (plane kz=nz/2), each Hermitian-symmetrised
 // by the rules of gen_cell() (transform.py:141-158)
-RF_HD cplx<float> fast_fix_kz0(const FastGenParams& g, const FastRec* rec, uint64_t seed, int ix, int iy) {
+RF_HD float fast_rcp(float t) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_rcpf(t);   // v_rcp_f32 (1 ulp)
+#else
+  return 1.0f / t;
+#endif
+}
+
+// p0, pn: delta(k) / k^2 of the symmetrised cells kz = 0 and kz = nz/2 (0 at DC) for the save_potential store
+RF_HD cplx<float> fast_fix_kz0(const FastGenParams& g, const FastRec* rec, uint64_t seed, int ix, int iy,
+                               cplx<float>& p0, cplx<float>& pn) {
   const int nzc = g.nz / 2;
   const int role = sym_role(g.nx, g.ny, ix, iy);
   int sx = ix, sy = iy;
@@ -506,6 +516,10 @@ RF_HD cplx<float> fast_fix_kz0(const FastGenParams& g, const FastRec* rec, uint6
   if (role == RF_DEST) { a.y = -a.y; n.y = -n.y; }
   if (role == RF_SELF) { a.y = 0.0f; n.y = 0.0f; }
   if (ix == 0 && iy == 0) a = mk<float>(0.0f, 0.0f);     // DC mode (its sigma lookup is meaningless)
+  // the potential of a destination cell is the conjugate of its source's: same |k|^2 on both sides of the mirror
+  const float r0 = (ix == 0 && iy == 0) ? 0.0f : fast_rcp(fast_k2(g, kxy_s, 0)), rn = fast_rcp(fast_k2(g, kxy_s, nzc));
+  p0 = mk<float>(a.x * r0, a.y * r0);
+  pn = mk<float>(n.x * rn, n.y * rn);
   return mk<float>(a.x - n.y, a.y + n.x);
 }
 

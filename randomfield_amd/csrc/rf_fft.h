@@ -190,11 +190,15 @@ template <typename T, bool WIDE = false> struct GenColIO {
 // guard costs the ordinary kernel nothing.
 // FIX: 1 = this kernel repairs the kz = 0 slot (rolled loop through LDS); 0 = it does not (the tiles that
 // hold kz = 0 are then re-run by a FIX = 1 launch).  An out-of-line call was measured 3x slower (scratch).
-template <int AB = 0, int FIX = 1, int SLAB = 0>
+// POT: 1 = the pass also stores delta(k) / k^2 (0 at DC) of every generated cell into `pot`, an API-layout array
+// [nx][ny][nz/2+1] -- the save_potential=True branch of generate_delta_field (generate.py:200-217) without ever
+// materialising delta(k) itself.  (Rows of nz/2+1 cells are only 8-byte aligned: two 8-byte stores per lane.)
+template <int AB = 0, int FIX = 1, int SLAB = 0, int POT = 0>
 struct FastGenColIOT {
   cplx<float>* base;
   ColGeom g;
   FastGenParams gp;
+  cplx<float>* pot = nullptr;
   int kz0, nzl;
   int x0 = 0, x1 = 1 << 30;  // replicated-generation mode (multi-GPU without an exchange): only rows [x0, x1) are stored,
                              // and `base` has been moved back by x0 rows so that row x0 lands on the local array's row 0
@@ -236,7 +240,16 @@ struct FastGenColIOT {
     const int ro_s = ro >= (gp.nx >> 1) ? ro - gp.nx : ro;
     const float kx = (float)(rb + ro_s) * gp.dkx, ky = (float)fast_signed_index(iy, gp.ny) * gp.dky;
     const float kxy = fmaf(kx, kx, ky * ky);                                           // == fast_kxy2(gp, rb + ro, iy)
-    fast_gen_pair_at<AB>(gp, rec, seed, ctr_l + ctr_u, fast_k2(gp, kxy, kz), fast_k2(gp, kxy, kz + 1), v.c[0], v.c[1]);
+    const float k2a = fast_k2(gp, kxy, kz), k2b = fast_k2(gp, kxy, kz + 1);
+    fast_gen_pair_at<AB>(gp, rec, seed, ctr_l + ctr_u, k2a, k2b, v.c[0], v.c[1]);
+    if (POT) {
+      // row (ix, iy) of the API layout; the slot kz = 0 (Hermitian planes) is written by fix_value() instead
+      const int nzp = gp.nz / 2 + 1;
+      cplx<float>* row = (pot + (long long)ro * gp.ny * nzp) + (uint32_t)((rb * gp.ny + iy) * nzp);
+      const float ra = fast_rcp(k2a), rb2 = fast_rcp(k2b);
+      if (!(FIX != 0 && kz == 0)) row[kz] = mk<float>(v.c[0].x * ra, v.c[0].y * ra);
+      row[kz + 1] = mk<float>(v.c[1].x * rb2, v.c[1].y * rb2);
+    }
     return v;
   }
   // the lane that owns slot kz = 0 replaces its provisional first cell of every row by the packed,
@@ -246,7 +259,16 @@ struct FastGenColIOT {
   RF_HD bool needs_fix(long long C) const { return FIX != 0 && kz0 + (int)((unsigned)C & (unsigned)(nzl - 1)) == 0; }
   RF_HD cplx<float> fix_value(long long C, int rb, int ro) const {
     const uint64_t seed = gp.seed;                                                      // bind_seed() ran first
-    return fast_fix_kz0(gp, rec, seed, rb + ro, (int)((unsigned)C >> nzl_shift()));
+    const int iy = (int)((unsigned)C >> nzl_shift());
+    cplx<float> p0, pn;
+    const cplx<float> packed = fast_fix_kz0(gp, rec, seed, rb + ro, iy, p0, pn);
+    if (POT) {
+      const int nzp = gp.nz / 2 + 1;
+      cplx<float>* row = pot + ((long long)(rb + ro) * gp.ny + iy) * nzp;
+      row[0] = p0;
+      row[nzp - 1] = pn;
+    }
+    return packed;
   }
   RF_HD void store(long long C0, int cl, int rb, int ro, const V16<float>& v) const {
     // x0, x1 are multiples of the last pass's row stride L (the launcher checks it) and rb < L: the test is uniform
@@ -254,7 +276,7 @@ struct FastGenColIOT {
     v16_store<float>(g.at<false>(base, C0, cl, rb, ro), v);
   }
 };
-using FastGenColIO = FastGenColIOT<0, 1>;
+using FastGenColIO = FastGenColIOT<0, 1>;   // (emulator)
 
 // The same fast generation for float64 plans (native generator only: parity / reference-noise mode keeps the exact
 // float64 chain of GenColIO).  The deviates and sigma are formed in float32 -- hardware log / sin / cos, LDS
@@ -264,6 +286,7 @@ struct FastGenColIO64 {
   cplx<double>* base;
   ColGeom g;
   FastGenParams gp;
+  cplx<double>* pot = nullptr;   // (unused: the fused potential store exists for float32 plans only)
   int kz0, nzl;
   int x0 = 0, x1 = 1 << 30;  // replicated-generation mode: see FastGenColIOT
   RF_HD int nzl_shift() const { return 31 - __builtin_clz((unsigned)nzl); }
@@ -295,7 +318,8 @@ struct FastGenColIO64 {
   RF_HD bool needs_fix(long long C) const { return FIX != 0 && kz0 + (int)((unsigned)C & (unsigned)(nzl - 1)) == 0; }
   RF_HD cplx<double> fix_value(long long C, int rb, int ro) const {
     const uint64_t seed = gp.seed;                                                      // bind_seed() ran first
-    const cplx<float> c = fast_fix_kz0(gp, rec, seed, rb + ro, (int)((unsigned)C >> nzl_shift()));
+    cplx<float> p0, pn;
+    const cplx<float> c = fast_fix_kz0(gp, rec, seed, rb + ro, (int)((unsigned)C >> nzl_shift()), p0, pn);
     return mk<double>((double)c.x, (double)c.y);
   }
   RF_HD void store(long long C0, int cl, int rb, int ro, const V16<double>& v) const {

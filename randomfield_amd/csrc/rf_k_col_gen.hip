@@ -52,14 +52,15 @@ hipError_t launch_t(int N, cplx<T>* W, ColGeom g, long long ncols, const GenPara
 // it is needed; every other tile by the kernel WITHOUT it (skip_period = tiles per iy).
 template <class C, class IO0, class IO1, class CT>
 hipError_t launch_fast_one(const FastGenParams& gp, CT* W, ColGeom g, long long ncols, int kz0, int nzl,
-                           const CT* tw, hipStream_t s, bool po, hipEvent_t after_repair, int x0, int x1) {
+                           const CT* tw, hipStream_t s, bool po, hipEvent_t after_repair, int x0, int x1, CT* pot = nullptr) {
   // the slab-restricted instantiations test the workgroup-uniform row offset m * L of the last pass: the slab
   // boundaries must be multiples of L = N / (radix of the last pass)
   if (nzl <= 0 || (nzl & (nzl - 1)) || ncols >= (1LL << 31) || g.needs_wide(C::LMAX, C::TC, (int)sizeof(CT))) return hipErrorInvalidValue;   // the IO splits a column index by shift and mask
   if ((x0 > 0 || x1 < C::N) && (C::NPASS < 2 || x0 % (C::N / C::RL) || x1 % (C::N / C::RL))) return hipErrorInvalidValue;
   CT* base = x0 > 0 ? W - (long long)x0 * g.row_stride : W;      // row x0 of the transform lands on row 0 of W
   IO0 io0; io0.base = base; io0.g = g; io0.gp = gp; io0.kz0 = kz0; io0.nzl = nzl; io0.rec = nullptr; io0.x0 = x0; io0.x1 = x1;
-  IO1 io1; io1.base = base; io1.g = g; io1.gp = gp; io1.kz0 = kz0; io1.nzl = nzl; io1.rec = nullptr; io1.x0 = x0; io1.x1 = x1;
+  io0.pot = pot;
+  IO1 io1; io1.base = base; io1.g = g; io1.gp = gp; io1.kz0 = kz0; io1.nzl = nzl; io1.rec = nullptr; io1.x0 = x0; io1.x1 = x1; io1.pot = pot;
   const bool split = nzl > C::TC && nzl % C::TC == 0;
   const long long tiles_per_iy = nzl / C::TC, ntiles = ncols / C::TC;
   if (po) {
@@ -76,9 +77,20 @@ hipError_t launch_fast_one(const FastGenParams& gp, CT* W, ColGeom g, long long 
 }
 
 hipError_t launch_col_fastgen(int f64, int N, void* W, ColGeom g, long long ncols, const FastGenParams& gp, int kz0, int nzl,
-                              const void* tw, hipStream_t s, bool po, hipEvent_t after_repair, int x0, int x1) {
+                              const void* tw, hipStream_t s, bool po, hipEvent_t after_repair, int x0, int x1, void* pot) {
   if (!col_fastgen_supported(f64, N)) return po ? hipSuccess : hipErrorInvalidValue;    // the caller keeps the exact kernel
   const bool slab = x0 > 0 || x1 < N;          // replicated-generation mode: the SLAB instantiations guard their stores
+  if ((pot || po) && !f64) {                   // generation + potential store (save_potential=True), float32, whole grid
+    if (slab && pot) return hipErrorInvalidValue;
+    switch (N) {
+#define X(NN) case NN: { hipError_t e = launch_fast_one<typename GenSel<float, NN>::type, FastGenColIOT<0, 0, 0, 1>, FastGenColIOT<0, 1, 0, 1>, cplx<float>>(gp, (cplx<float>*)W, g, ncols, kz0, nzl, (const cplx<float>*)tw, s, po, after_repair, x0, x1, (cplx<float>*)pot); if (!po || e != hipSuccess) return e; break; }
+      RF_COL_SIZES(X)
+#undef X
+      default: return hipErrorInvalidValue;
+    }
+  } else if (pot) {
+    return hipErrorInvalidValue;
+  }
 #define RF_FAST(T, IO0, IO1)                                                                                              \
   switch (N) {                                                                                                           \
     RF_COL_SIZES(X)                                                                                                       \

@@ -218,9 +218,9 @@ class Generator(object):
                 noise = None
                 dseed = self._native_seed(seed)
             if save_potential:
-                dev.generate(dseed, noise)          # rows K,T,R,S -> k-space on the device
-                dev.save_potential()                # generate.py:200-217
-                dev.execute_c2r()
+                # generate.py:200-217.  Native noise: delta(k)/k**2 is a second store stream of the generation pass;
+                # otherwise the library runs rows K,T,R,S -> k-space, the division, and the c2r transform.
+                dev.realise_potential(dseed, noise)
                 self.potential = _DevicePotential(self)
             else:
                 dev.realise(dseed, noise)           # fused: k-space never materialised

@@ -834,9 +834,45 @@ def test_lensing_kernel_closed_form(hip, K):
             for i_min in (1, 2, 9):
                 DC, DA = lcf.tables(nz, h, K)
                 phi = np.polynomial.Polynomial(coeffs)(DC)
-                plan.upload_real(np.broadcast_to(phi, (nx, ny, nz)).astype(dtype))
+                plan.upload_real(np.ascontiguousarray(np.broadcast_to(phi, (nx, ny, nz)), dtype=dtype))
                 plan.lensing_potential(cpu_ref.cot_k(DC, DA, K), h, i_min)
                 psi = plan.download_aux()
                 want = lcf.expected(coeffs, nz, h, i_min)
                 assert np.max(np.abs(psi - want[None, None, :])) <= tol * np.max(np.abs(want))
         plan.close()
+
+
+@pytest.mark.parametrize("shape", [(64, 32, 128), (1024, 8, 32), (512, 16, 64), (16, 16, 16)])
+def test_fused_potential_store_native(hip, dpower, shape):
+    """rf_realise_potential = the reference's default generate_delta_field(save_potential=True) (generate.py:191-219) with
+    the native generator: delta(k)/k**2 written by the generation pass itself.  The field must be the one rf_realise
+    gives (to float32 rounding), and the potential the oracle's delta(k)/k**2 of the same noise (float32 generation: 1e-5 of the
+    largest magnitude; the unfused route generate -> save_potential agrees with it to the same bound)."""
+    k, Pk = dpower
+    nx, ny, nz = shape
+    plan = make_plan(hip, shape, np.complex64, k, Pk)
+    plan.realise(seed=77)
+    d0 = plan.download_real()
+    std = plan.moments()[1]
+    plan.realise_potential(seed=77)
+    # same cells, same draws; another kernel instantiation may contract multiply-adds differently
+    assert np.max(np.abs(plan.download_real() - d0)) <= 1e-6 * std
+    plan.realise_potential(seed=77)
+    d1 = plan.download_real()
+    plan.realise_potential(seed=77)
+    assert np.array_equal(plan.download_real(), d1)               # run-to-run deterministic
+    plan.load_potential(1.0)
+    pot = plan.download_k()
+    noise = cpu_ref.native_noise(77, nx, ny, nz, np.complex64)
+    kref = cpu_ref.generate_kspace(nx, ny, nz, SPACING, k, Pk, noise=noise, dtype=np.complex128)
+    ref = cpu_ref.potential_kspace(kref, SPACING)
+    scale = np.max(np.abs(ref))
+    assert pot.shape == ref.shape and pot[0, 0, 0] == 0
+    assert np.max(np.abs(pot - ref)) <= 1e-5 * scale
+    # the Newtonian potential from it: inverse transform of scale * potential
+    plan.load_potential(-2.0)
+    plan.execute_c2r()
+    phi = plan.download_real()
+    want = np.fft.irfftn(-2.0 * ref, s=(nx, ny, nz), axes=(0, 1, 2))
+    assert np.max(np.abs(phi - want)) <= 1e-5 * want.std()
+    plan.close()
