@@ -576,6 +576,35 @@ int main(int argc, char** argv) {
       report("z pass alone", t.run([&]() { hipLaunchKernelGGL(kz, dim3((unsigned)ntz), dim3(CR::NT), CR::LDS_BYTES, 0, zio, tw, nrows, partials); }), 2 * sweep);
     }
   }
+
+  if (argc >= 2 && strchr(argv[1], 'L')) {
+    // length-2048 x pass (one 152 KiB tile per CU): fresh workgroup per tile vs persistent workgroups
+    const int NXL = 2048;
+    cplx<float>* WL;
+    CK(hipMalloc((void**)&WL, (size_t)NXL * NY * nzc * 8));
+    auto tw2h = make_twiddles<float>(2048);
+    cplx<float>* tw2;
+    CK(hipMalloc((void**)&tw2, tw2h.size() * 8));
+    CK(hipMemcpy(tw2, tw2h.data(), tw2h.size() * 8, hipMemcpyHostToDevice));
+    using C = ColCfg<float, 2048, 8, 16, 16, 8, 1024>;
+    using IO = FastGenColIOT<0, 0, 0>;
+    FastGenParams fpl = fp; fpl.nx = NXL;
+    IO io; io.rec = nullptr; io.base = WL; io.g = ColGeom{(long long)NY * nzc, 0, (long long)NY * nzc}; io.gp = fpl; io.kz0 = 0; io.nzl = (int)nzc;
+    const long long ncols = (long long)NY * nzc;
+    const double sw = (double)NXL * NY * nzc * 8;
+    report("x pass N=2048: one workgroup per tile", bench_x<C, IO>(t, io, tw2, ncols, 0, 0), sw);
+    for (int grid : {256, 512, 1024, 4096}) {
+      char nm[128];
+      snprintf(nm, sizeof nm, "x pass N=2048: persistent grid=%d", grid);
+      report(nm, bench_x<C, IO>(t, io, tw2, ncols, 0, grid), sw);
+    }
+    using CP = ColCfg<float, 2048, 8, 16, 16, 8, 1024>;
+    PlainColIO<float> yio; yio.base = WL; yio.g = ColGeom{nzc, (long long)NY * nzc, nzc};   // y-geometry with 2048 rows: treat as [1024 planes][2048 iy]
+    yio.g = ColGeom{nzc, (long long)2048 * nzc, nzc};
+    const long long ycols = (long long)1024 * nzc;
+    report("y pass N=2048: one workgroup per tile", bench_x<CP, PlainColIO<float>>(t, yio, tw2, ycols, 0, 0), 2 * sw);
+    report("y pass N=2048: persistent grid=256", bench_x<CP, PlainColIO<float>>(t, yio, tw2, ycols, 0, 256), 2 * sw);
+  }
   if (do_y) {
     using C = ColCfg<float, 1024, 16, 8, 8, 8, 512>;
     using IO = PlainColIO<float>;
