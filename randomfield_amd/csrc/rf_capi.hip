@@ -564,8 +564,8 @@ int rf_plan_create_c2c(rf_plan** out, int nx, int ny, int nz, int dtype, int dev
   RF_REQUIRE(out != nullptr, "plan pointer is null");
   *out = nullptr;
   RF_REQUIRE(dtype == RF_F32 || dtype == RF_F64, "dtype must be RF_F32 or RF_F64");
-  if (!col_size_supported(nx) || !col_size_supported(ny) || !row_size_supported(nz))
-    return fail(1, "unsupported shape for a c2c plan: nx, ny must be powers of two in [8, 2048], nz in [8, 1024]");
+  if (!col_size_supported(nx) || !col_size_supported(ny) || !rowc_size_supported(nz))
+    return fail(1, "unsupported shape for a c2c plan: nx, ny, nz must be powers of two in [8, 2048]");
   const int tcx = col_tile_cols(dtype, nx), tcy = col_tile_cols(dtype, ny);
   if (((long long)ny * nz) % tcx || ((long long)nx * nz) % tcy) return fail(1, "unsupported shape for a c2c plan: too few columns for a tile");
   RF_HIP(hipSetDevice(device));

@@ -43,8 +43,11 @@ RF_ROW(128,  8,  16, 1,  32,  8,  4,  4,  16,  256)
 RF_ROW(256,  8,  8,  4,  16,  8,  8,  4,  8,   256)
 RF_ROW(512,  8,  8,  8,  8,   8,  8,  8,  4,   256)
 RF_ROW(1024, 8,  16, 8,  4,   8,  8,  16, 2,   256)
+// rows of 2048 complex: only the unpacked c2c transform has them (a packed plan's rows hold nz/2 <= 1024)
+RF_ROW(2048, 8,  16, 16, 2,   8,  16, 16, 1,   256)
 #undef RF_ROW
 #define RF_ROW_SIZES(X) X(8) X(16) X(32) X(64) X(128) X(256) X(512) X(1024)
+#define RF_ROWC_SIZES(X) RF_ROW_SIZES(X) X(2048)
 
 inline bool col_size_supported(int n) {
   switch (n) {
@@ -64,5 +67,6 @@ inline bool row_size_supported(int m) {
     default: return false;
   }
 }
+inline bool rowc_size_supported(int m) { return m == 2048 || row_size_supported(m); }   // unpacked c2c rows
 
 }  // namespace rf

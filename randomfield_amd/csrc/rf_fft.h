@@ -160,7 +160,18 @@ template <typename T, bool WIDE = false> struct GenColIO {
       if (kspace) {
         const cplx<T>* p = kspace + ((long long)ix * gp.ny + iy) * (nzc + 1);
         cplx<T> a = p[kz];
-        if (kz == 0) { cplx<T> n = p[nzc]; a = mk<T>(a.x - n.y, a.y + n.x); }
+        if (kz == 0) {
+          // The planes kz = 0 and kz = nz/2 travel as ONE complex plane (a + i n), which needs both to be 2-D
+          // Hermitian.  np.fft.irfftn (transform.py:314) accepts anything there and, by discarding the imaginary part
+          // after the x and y transforms, in effect uses the Hermitian part of each plane: so that is what is packed.
+          // (Hermitian input, e.g. after symmetrize(), is reproduced bit for bit: (a + conj a*)/2 with a == conj a*.)
+          const int mx = (gp.nx - ix) % gp.nx, my = (gp.ny - iy) % gp.ny;
+          const cplx<T>* pm = kspace + ((long long)mx * gp.ny + my) * (nzc + 1);
+          const cplx<T> am = pm[0], n0 = p[nzc], nm = pm[nzc];
+          const cplx<T> ah = mk<T>((T)0.5 * (a.x + am.x), (T)0.5 * (a.y - am.y));
+          const cplx<T> nh = mk<T>((T)0.5 * (n0.x + nm.x), (T)0.5 * (n0.y - nm.y));
+          a = mk<T>(ah.x - nh.y, ah.y + nh.x);
+        }
         v.c[c] = a;
       } else {
         v.c[c] = gen_packed<T>(gp, seed, ix, iy, kz);

@@ -20,7 +20,7 @@ hipError_t launch_t(int M, cplx<T>* W, long long nrows, double scale, const cplx
   ScaledRowIO<T> io; io.base = W; io.M_of = M; io.scale = (T)scale;
   switch (M) {
 #define X(MM) case MM: return launch_one<typename RowSel<T, MM>::type, DIR>(io, nrows, tw, s, po);
-    RF_ROW_SIZES(X)
+    RF_ROWC_SIZES(X)
 #undef X
     default: return hipErrorInvalidValue;
   }

@@ -231,8 +231,10 @@ class Plan(object):
     copies are the price of the numpy-array API; device-resident use goes through
     :class:`randomfield_amd.generate.Generator` or :attr:`device`).  Packed inverse
     (c2r) and forward (r2c) plans and unpacked complex-to-complex plans (both directions)
-    run on the GPU; a c2r transform assumes Hermitian input in the kz = 0 and kz = nz/2
-    planes, as FFTW's multi-dimensional c2r does.
+    run on the GPU.  A c2r transform treats the kz = 0 and kz = nz/2 planes exactly as
+    ``np.fft.irfftn`` does: only their 2-D Hermitian parts contribute (the device packs the
+    two planes into one complex plane and projects them on upload; Hermitian input, e.g.
+    after :func:`symmetrize`, passes through unchanged).
     """
 
     def __init__(self, shape, dtype_in=None, data_in=None, overwrite=True, inverse=True, packed=True,
@@ -280,10 +282,10 @@ class Plan(object):
                         "hip backend: shape {0} is not supported (power-of-two axes, nx, ny in 8..2048, nz in "
                         "16..2048); use backend='numpy' explicitly for this shape.".format(tuple(shape)))
             elif not (_is_pow2(nx) and _is_pow2(ny) and _is_pow2(nz) and 8 <= nx <= 2048 and 8 <= ny <= 2048
-                      and 8 <= nz <= 1024):
+                      and 8 <= nz <= 2048):
                 raise RuntimeError(
-                    "hip backend: unpacked shape {0} is not supported (power-of-two axes, nx, ny in 8..2048, nz in "
-                    "8..1024); use backend='numpy' explicitly for this shape.".format(tuple(shape)))
+                    "hip backend: unpacked shape {0} is not supported (power-of-two axes in 8..2048); use "
+                    "backend='numpy' explicitly for this shape.".format(tuple(shape)))
             # a reverse plan that shares our memory also shares our device plan (one device buffer, as the
             # reference's pair of plans shares one host buffer)
             self.device = _device if _device is not None else _hip.DevicePlan(nx, ny, nz, cdtype, unpacked=not packed)

@@ -205,6 +205,30 @@ __global__ __launch_bounds__(C::NT, (col_min_waves<C, IO>())) void col_kernel_pe
 
 }  // namespace rf
 
+
+// ---- intermediate-layout experiment: pairs of x rows interleaved at 64 B granularity, so that the 16 rows a wave
+// stores with one instruction are 8 whole 128-byte lines:  (ix, iy, kz) -> ((ix/2)*ny + iy)*2*nzc + (kz/8)*16 + (ix%2)*8 + kz%8
+struct IlvXGenIO : FastGenColIOT<0, 0, 0> {
+  int nzc_, ny_;
+  __device__ __forceinline__ void store(long long C0, int cl, int rb, int ro, const V16<float>& v) const {
+    const long long iy = C0 / nzc_, kz0 = C0 % nzc_;
+    cplx<float>* ub = base + ((long long)(ro >> 1) * ny_ + iy) * (2LL * nzc_) + (kz0 >> 3) * 16;
+    const uint32_t lane = (uint32_t)(rb >> 1) * (uint32_t)(2 * ny_ * nzc_) + (uint32_t)(rb & 1) * 8u + (uint32_t)cl;
+    v16_store<float>(reinterpret_cast<char*>(ub) + (size_t)(lane * 8u), v);
+  }
+};
+// y pass reading that layout (tile = (ix, 8 kz)) and writing the standard layout into another buffer
+struct IlvYIO : PlainColIO<float> {
+  const cplx<float>* src;
+  int nzc_, ny_;
+  __device__ __forceinline__ V16<float> load(long long C0, int cl, int rb, int ro) const {
+    const long long ix = C0 / nzc_, kz0 = C0 % nzc_;
+    const cplx<float>* ub = src + ((ix >> 1) * ny_ + ro) * (2LL * nzc_) + (kz0 >> 3) * 16 + (ix & 1) * 8;
+    const uint32_t lane = (uint32_t)rb * (uint32_t)(2 * nzc_) + (uint32_t)cl;
+    return v16_load<float>(reinterpret_cast<const char*>(ub) + (size_t)(lane * 8u));
+  }
+};
+
 // ---- x pass variants -----------------------------------------------------------------------------------
 template <class C, class IO>
 float bench_x(Timer& t, const IO& io, const cplx<float>* tw, long long ncols, int extra_lds, int persistent_grid) {
@@ -604,6 +628,28 @@ int main(int argc, char** argv) {
     const long long ycols = (long long)1024 * nzc;
     report("y pass N=2048: one workgroup per tile", bench_x<CP, PlainColIO<float>>(t, yio, tw2, ycols, 0, 0), 2 * sw);
     report("y pass N=2048: persistent grid=256", bench_x<CP, PlainColIO<float>>(t, yio, tw2, ycols, 0, 256), 2 * sw);
+  }
+
+  if (argc >= 2 && strchr(argv[1], 'i')) {
+    using C = ColCfg<float, 1024, 8, 16, 8, 8, 512>;
+    using IO = FastGenColIOT<0, 0, 0>;
+    IO io; io.rec = nullptr; io.base = W; io.g = ColGeom{(long long)NY * nzc, 0, (long long)NY * nzc}; io.gp = fp; io.kz0 = 0; io.nzl = (int)nzc;
+    const long long ncols = (long long)NY * nzc;
+    cplx<float>* W2;
+    CK(hipMalloc((void**)&W2, ncplx * 8));
+    CK(hipMemset(W2, 0, ncplx * 8));
+    IlvXGenIO xi; static_cast<IO&>(xi) = io; xi.nzc_ = (int)nzc; xi.ny_ = NY;
+    for (int rep = 0; rep < 2; ++rep) {
+      report("x pass, standard layout (half-line stores)", bench_x<C, IO>(t, io, tw, ncols, 0, 0), sweep);
+      report("x pass, x-pair interleaved layout (whole-line stores)", bench_x<C, IlvXGenIO>(t, xi, tw, ncols, 0, 0), sweep);
+    }
+    using CY = ColCfg<float, 1024, 16, 8, 8, 8, 512>;
+    PlainColIO<float> yio; yio.base = W; yio.g = ColGeom{nzc, (long long)NY * nzc, nzc};
+    IlvYIO yi; static_cast<PlainColIO<float>&>(yi) = yio; yi.base = W2; yi.src = W; yi.nzc_ = (int)nzc; yi.ny_ = NY;
+    for (int rep = 0; rep < 2; ++rep) {
+      report("y pass in place, standard layout", bench_x<CY, PlainColIO<float>>(t, yio, tw, (long long)NX * nzc, 0, 0), 2 * sweep);
+      report("y pass reading the interleaved layout, writing the standard one (out of place)", bench_x<CY, IlvYIO>(t, yi, tw, (long long)NX * nzc, 0, 0), 2 * sweep);
+    }
   }
   if (do_y) {
     using C = ColCfg<float, 1024, 16, 8, 8, 8, 512>;
