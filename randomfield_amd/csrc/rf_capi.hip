@@ -142,6 +142,7 @@ struct rf_plan {
   uint64_t* seeds_pin[2] = {nullptr, nullptr};
   hipEvent_t seeds_ev[2] = {nullptr, nullptr};
   int seeds_pin_cap = 0, seeds_turn = 0;
+  bool resident_fast = false;             // the current call draws from the device-resident deviates (RF_NOISE_RESIDENT)
   void* pot_target = nullptr;             // non-null while rf_realise_potential queues its x pass: where delta(k)/k^2 goes
   double* coll_scratch = nullptr;         // 2 doubles on the device for host-side all-reduces (never aliases `stats`)
   double* ztab = nullptr;                 // 2 * nz doubles for lognormal / affine tables
@@ -214,6 +215,7 @@ FastGenParams make_fast(rf_plan* p, uint64_t seed, bool seed_from_dev, const uin
   f.dkx = p->fdkx; f.dky = p->fdky; f.dkz = p->fdkz;
   f.rec = p->frec; f.nbins = p->fnbins; f.u_scale = p->fu_scale; f.u_off = p->fu_off;
   f.seed = seed; f.seed_dev = seed_from_dev ? seed_ptr : nullptr;
+  f.noise = nullptr;
   return f;
 }
 
@@ -269,15 +271,21 @@ int build_fast(rf_plan* p) {
 // all-to-all is needed (only the 2-double all-reduce of the moments).  It trades P-fold redundant x-pass arithmetic
 // for the exchange: a win when the exchange is slower than (P-1) x passes -- 2 GPUs share ONE xGMI link.
 int queue_x(rf_plan* p, const GenParams& gp, const void* kspace, void* W, hipStream_t sx, bool timed = false) {
-  const bool fast = !kspace && gp.noise_mode == NOISE_PHILOX && p->have_fast && !p->exact_gen;
+  // resident deviates (the numpy stream replayed by rf_noise_mt19937) take the fast float32 sigma path too; host-supplied
+  // deviates (RF_NOISE_EXTERNAL, the parity mode) keep the exact reference dtype chain
+  const bool fast_noise = !kspace && gp.noise_mode == NOISE_EXTERNAL && p->resident_fast && p->have_fast && !p->exact_gen &&
+                          !p->f64 && p->nranks == 1 && !p->pot_target;
+  const bool fast = (!kspace && gp.noise_mode == NOISE_PHILOX && p->have_fast && !p->exact_gen) || fast_noise;
   const bool rep = p->replicate && p->nranks > 1;
   RF_REQUIRE(!rep || fast, "replicated generation needs the native generator (fast path)");
   const long long nzl = rep ? p->nzc : p->nzl;     // kz planes generated by this rank (nz/2 on one GPU)
   const int kz0 = rep ? 0 : p->kz0;
   const ColGeom gx{(long long)p->ny * nzl, 0, (long long)p->ny * nzl};
   if (timed) { RF_HIP(hipEventRecord(p->ev[5], sx)); p->repair_timed = fast; }   // overwritten by the launcher if it splits
+  FastGenParams fgp = make_fast(p, gp.seed, gp.seed_dev != nullptr, gp.seed_dev);
+  if (fast_noise) fgp.noise = gp.noise;
   if (fast)
-    RF_HIP(launch_col_fastgen(p->f64, p->nx, W, gx, (long long)p->ny * nzl, make_fast(p, gp.seed, gp.seed_dev != nullptr, gp.seed_dev),
+    RF_HIP(launch_col_fastgen(p->f64, p->nx, W, gx, (long long)p->ny * nzl, fgp,
                               kz0, (int)nzl, p->tw_x, sx, false, timed ? p->ev[5] : nullptr,
                               rep ? p->rank * p->nxl : 0, rep ? (p->rank + 1) * p->nxl : 1 << 30, p->pot_target));
   else
@@ -793,7 +801,9 @@ int rf_realise(rf_plan* p, uint64_t seed, int mode, const double* noise_host) {
   RF_HIP(hipSetDevice(p->device));
   if (int rc = upload_noise(p, mode, noise_host)) return rc;
   p->timed = true;
+  p->resident_fast = (mode == RF_NOISE_RESIDENT);
   int rc = queue_c2r(p, make_gen(p, seed, mode, false), nullptr);
+  p->resident_fast = false;
   if (rc) return rc;
   if (mode == RF_NOISE_EXTERNAL) RF_HIP(hipStreamSynchronize(p->stream));
   return 0;

@@ -404,6 +404,8 @@ struct FastGenParams {
   float u_scale, u_off;   // bin coordinate u = log2(k^2) * u_scale + u_off
   uint64_t seed;
   const uint64_t* seed_dev;
+  const double* noise;    // SRC = 1 kernels: resident float64 deviates in the reference's order (random.py:24-28),
+                          // 2 per cell of the API layout [nx][ny][nz/2+1]
 };
 enum { FAST_LDS_BINS = 512 };
 
@@ -520,6 +522,27 @@ RF_HD cplx<float> fast_fix_kz0(const FastGenParams& g, const FastRec* rec, uint6
   const float r0 = (ix == 0 && iy == 0) ? 0.0f : fast_rcp(fast_k2(g, kxy_s, 0)), rn = fast_rcp(fast_k2(g, kxy_s, nzc));
   p0 = mk<float>(a.x * r0, a.y * r0);
   pn = mk<float>(n.x * rn, n.y * rn);
+  return mk<float>(a.x - n.y, a.y + n.x);
+}
+
+// The same slot from resident deviates (the reference's stream, e.g. replayed MT19937): cell = sigma * (g_re + i g_im)
+// with the float64 product rounded once (random.py:28), symmetrised as above.
+RF_HD cplx<float> fast_noise_cell(const FastGenParams& g, const FastRec* rec, int ix, int iy, int kz, float k2) {
+  const double* d = g.noise + 2 * (((long long)ix * g.ny + iy) * (g.nz / 2 + 1) + kz);
+  const double s = (double)fast_sigma(g, rec, k2);
+  return mk<float>((float)(s * d[0]), (float)(s * d[1]));
+}
+RF_HD cplx<float> fast_fix_kz0_noise(const FastGenParams& g, const FastRec* rec, int ix, int iy) {
+  const int nzc = g.nz / 2;
+  const int role = sym_role(g.nx, g.ny, ix, iy);
+  int sx = ix, sy = iy;
+  if (role == RF_DEST) { sx = (g.nx - ix) % g.nx; sy = (g.ny - iy) % g.ny; }
+  const float kxy_s = fast_kxy2(g, sx, sy);
+  cplx<float> a = fast_noise_cell(g, rec, sx, sy, 0, fast_k2(g, kxy_s, 0));
+  cplx<float> n = fast_noise_cell(g, rec, sx, sy, nzc, fast_k2(g, kxy_s, nzc));
+  if (role == RF_DEST) { a.y = -a.y; n.y = -n.y; }
+  if (role == RF_SELF) { a.y = 0.0f; n.y = 0.0f; }
+  if (ix == 0 && iy == 0) a = mk<float>(0.0f, 0.0f);
   return mk<float>(a.x - n.y, a.y + n.x);
 }
 

@@ -204,7 +204,11 @@ template <typename T, bool WIDE = false> struct GenColIO {
 // POT: 1 = the pass also stores delta(k) / k^2 (0 at DC) of every generated cell into `pot`, an API-layout array
 // [nx][ny][nz/2+1] -- the save_potential=True branch of generate_delta_field (generate.py:200-217) without ever
 // materialising delta(k) itself.  (Rows of nz/2+1 cells are only 8-byte aligned: two 8-byte stores per lane.)
-template <int AB = 0, int FIX = 1, int SLAB = 0, int POT = 0>
+// SRC: 0 = native Philox + Box-Muller draws; 1 = deviates resident in device memory (the reference's numpy stream,
+// rng='reference'): same float32 |k| and sigma arithmetic, the draw replaced by two 16-byte loads per lane.  The field
+// then differs from the exact-chain kernel's by the float32 sigma rounding only (<= 1e-6 relative, far inside the
+// 1e-5 * rms parity tolerance) and the pass is HBM-bound (12.9 GB) instead of latency-bound on table lookups.
+template <int AB = 0, int FIX = 1, int SLAB = 0, int POT = 0, int SRC = 0>
 struct FastGenColIOT {
   cplx<float>* base;
   ColGeom g;
@@ -252,7 +256,17 @@ struct FastGenColIOT {
     const float kx = (float)(rb + ro_s) * gp.dkx, ky = (float)fast_signed_index(iy, gp.ny) * gp.dky;
     const float kxy = fmaf(kx, kx, ky * ky);                                           // == fast_kxy2(gp, rb + ro, iy)
     const float k2a = fast_k2(gp, kxy, kz), k2b = fast_k2(gp, kxy, kz + 1);
-    fast_gen_pair_at<AB>(gp, rec, seed, ctr_l + ctr_u, k2a, k2b, v.c[0], v.c[1]);
+    if (SRC == 0) {
+      fast_gen_pair_at<AB>(gp, rec, seed, ctr_l + ctr_u, k2a, k2b, v.c[0], v.c[1]);
+    } else {
+      // cells (ix, iy, kz) and (ix, iy, kz + 1) are adjacent in the reference's order: 4 doubles, 32 contiguous bytes
+      const int nzp = gp.nz / 2 + 1;
+      const double* d = (gp.noise + 2LL * ro * gp.ny * nzp) + 2u * (uint32_t)((rb * gp.ny + iy) * nzp + kz);
+      const V16<double> ga = v16_load<double>(d), gb = v16_load<double>(d + 2);     // one complex128 = one deviate pair
+      const double sa = (double)fast_sigma(gp, rec, k2a), sb = (double)fast_sigma(gp, rec, k2b);
+      v.c[0] = mk<float>((float)(sa * ga.c[0].x), (float)(sa * ga.c[0].y));
+      v.c[1] = mk<float>((float)(sb * gb.c[0].x), (float)(sb * gb.c[0].y));
+    }
     if (POT) {
       // row (ix, iy) of the API layout; the slot kz = 0 (Hermitian planes) is written by fix_value() instead
       const int nzp = gp.nz / 2 + 1;
@@ -272,6 +286,7 @@ struct FastGenColIOT {
     const uint64_t seed = gp.seed;                                                      // bind_seed() ran first
     const int iy = (int)((unsigned)C >> nzl_shift());
     cplx<float> p0, pn;
+    if (SRC != 0) return fast_fix_kz0_noise(gp, rec, rb + ro, iy);
     const cplx<float> packed = fast_fix_kz0(gp, rec, seed, rb + ro, iy, p0, pn);
     if (POT) {
       const int nzp = gp.nz / 2 + 1;

@@ -80,6 +80,17 @@ hipError_t launch_col_fastgen(int f64, int N, void* W, ColGeom g, long long ncol
                               const void* tw, hipStream_t s, bool po, hipEvent_t after_repair, int x0, int x1, void* pot) {
   if (!col_fastgen_supported(f64, N)) return po ? hipSuccess : hipErrorInvalidValue;    // the caller keeps the exact kernel
   const bool slab = x0 > 0 || x1 < N;          // replicated-generation mode: the SLAB instantiations guard their stores
+  if ((gp.noise || po) && !f64) {              // resident deviates (rng='reference') through the fast float32 sigma path
+    if (gp.noise && (slab || pot)) return hipErrorInvalidValue;
+    switch (N) {
+#define X(NN) case NN: { hipError_t e = launch_fast_one<typename GenSel<float, NN>::type, FastGenColIOT<0, 0, 0, 0, 1>, FastGenColIOT<0, 1, 0, 0, 1>, cplx<float>>(gp, (cplx<float>*)W, g, ncols, kz0, nzl, (const cplx<float>*)tw, s, po, after_repair, x0, x1); if (!po || e != hipSuccess) return e; break; }
+      RF_COL_SIZES(X)
+#undef X
+      default: return hipErrorInvalidValue;
+    }
+  } else if (gp.noise) {
+    return hipErrorInvalidValue;
+  }
   if ((pot || po) && !f64) {                   // generation + potential store (save_potential=True), float32, whole grid
     if (slab && pot) return hipErrorInvalidValue;
     switch (N) {

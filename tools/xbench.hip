@@ -399,7 +399,7 @@ int main(int argc, char** argv) {
   CK(hipMalloc((void**)&dk2, 1024 * 4)); CK(hipMemcpy(dk2, k2.data(), 1024 * 4, hipMemcpyHostToDevice));
   CK(hipMalloc((void**)&drec, rec.size() * sizeof(FastRec))); CK(hipMemcpy(drec, rec.data(), rec.size() * sizeof(FastRec), hipMemcpyHostToDevice));
   fp.nx = NX; fp.ny = NY; fp.nz = NZ; fp.dky = fp.dkx; fp.dkz = fp.dkx; fp.rec = drec; fp.nbins = (int)rec.size();
-  fp.seed = 123; fp.seed_dev = nullptr;
+  fp.seed = 123; fp.seed_dev = nullptr; fp.noise = nullptr;
 
   if (argc >= 2 && strchr(argv[1], 's')) {
     // does the power-of-two row stride of the x pass (4 MiB) camp on memory channels?  pad it.
