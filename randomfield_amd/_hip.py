@@ -239,7 +239,8 @@ class DevicePlan(object):
     # -- the reference's noise stream generated on the GPU --------------------
     def reference_noise(self, seed):
         """Fill the device noise buffer with ``RandomState(seed).normal(size=2*M)`` (MT19937 + polar
-        method replayed on the GPU; integer seeds < 2**32).  Afterwards pass ``noise='resident'``."""
+        method replayed on the GPU) for any seed numpy's legacy seeding accepts: an integer < 2**32, an
+        array of integers (``init_by_array``) or None.  Afterwards pass ``noise='resident'``."""
         from . import mt19937
         if not getattr(self, "_mt_ready", False):
             polys = mt19937.jump_polynomials(20)
@@ -253,7 +254,7 @@ class DevicePlan(object):
                                            npos.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), stride,
                                            mt19937.SEGMENT_BLOCKS), "rf_mt_set_jump")
             self._mt_ready = True
-        state = np.ascontiguousarray(mt19937.init_genrand(int(seed)), np.uint32)
+        state = np.ascontiguousarray(mt19937.seed_state(seed), np.uint32)
         acc = ctypes.c_ulonglong(0)
         check(self._lib.rf_noise_mt19937(self._h, state.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)),
                                          ctypes.byref(acc)), "rf_noise_mt19937")

@@ -206,13 +206,10 @@ class Generator(object):
             log10_k, sigma = powertools.sigma_table(self.smoothed_power, (nx, ny, nz), self.grid_spacing_Mpc_h)
             dev.set_power(log10_k, sigma)
             if self.rng == "reference":
-                if seed is None:
-                    seed = int.from_bytes(os.urandom(4), "little")      # RandomState(None) seeds itself from the OS
-                if isinstance(seed, (int, np.integer)) and 0 <= int(seed) < 2 ** 32:
-                    dev.reference_noise(int(seed))                      # MT19937 + polar method replayed on the GPU
-                    noise = "resident"
-                else:                                                   # array seeds etc.: draw on the host, upload
-                    noise = rf_random.reference_normals(seed, 2 * nx * ny * (nz // 2 + 1))
+                # RandomState(seed).normal (random.py:24): MT19937 + polar method replayed on the GPU from the seed's
+                # 624-word start state -- integer seeds, array seeds (init_by_array) and None alike; no host deviates
+                dev.reference_noise(seed)
+                noise = "resident"
                 dseed = 0
             else:
                 noise = None

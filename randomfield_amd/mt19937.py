@@ -43,6 +43,56 @@ def init_genrand(seed):
     return mt
 
 
+def init_by_array(key):
+    """Initial state of ``RandomState(key)`` for a 1-D array seed (mt19937ar.c ``init_by_array``, the routine
+    numpy's legacy seeding calls for anything that is not a scalar integer)."""
+    key = [int(v) & 0xFFFFFFFF for v in np.asarray(key).ravel()]
+    if not key:
+        raise ValueError("Seed must be non-empty")
+    mt = [int(v) for v in init_genrand(19650218)]
+    i, j = 1, 0
+    for _ in range(max(N, len(key))):
+        mt[i] = ((mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1664525)) + key[j] + j) & 0xFFFFFFFF
+        i, j = i + 1, j + 1
+        if i >= N:
+            mt[0], i = mt[N - 1], 1
+        if j >= len(key):
+            j = 0
+    for _ in range(N - 1):
+        mt[i] = ((mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1566083941)) - i) & 0xFFFFFFFF
+        i += 1
+        if i >= N:
+            mt[0], i = mt[N - 1], 1
+    mt[0] = 0x80000000
+    return np.array(mt, np.uint32)
+
+
+def seed_state(seed):
+    """The 624-word state ``RandomState(seed)`` starts from (random.py:24), for every kind of seed numpy's legacy
+    seeding accepts: an integer in [0, 2**32) (ValueError outside, as numpy), or an array-like of integers; None
+    draws a 32-bit seed from the OS (numpy reads its entropy there too, so such a run is not reproducible either)."""
+    if seed is None:
+        return init_genrand(int.from_bytes(os.urandom(4), "little"))
+    # numpy squeezes ndarray seeds first (a one-element ARRAY seeds like its scalar; a one-element list does not)
+    arr = seed.squeeze() if hasattr(seed, "squeeze") else np.asarray(seed)
+    arr = np.asarray(arr)
+    if arr.ndim == 0 and not hasattr(seed, "squeeze") and not np.isscalar(seed):
+        arr = arr.reshape(1)
+    if arr.ndim == 0:
+        if not np.issubdtype(arr.dtype, np.integer):
+            raise TypeError("Cannot cast scalar seed to an integer")
+        if not 0 <= int(arr) < 2 ** 32:
+            raise ValueError("Seed must be between 0 and 2**32 - 1")
+        return init_genrand(int(arr))
+    if arr.ndim != 1 or not np.issubdtype(arr.dtype, np.integer):
+        raise ValueError("Seed array must be 1-d (integers)")
+    if arr.size == 0:
+        raise ValueError("Seed must be non-empty")
+    if (arr.astype(object) < 0).any() or (arr.astype(object) >= 2 ** 32).any():
+        raise ValueError("Seed values must be between 0 and 2**32 - 1")
+    return init_by_array(arr)
+
+
 def next_block(mt):
     """Regenerate the state: words x_{p+624 .. p+1247} from x_{p .. p+623} (vectorised in the three
     dependency-free chunks of the recurrence).  Returns a new array."""

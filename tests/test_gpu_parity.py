@@ -916,3 +916,23 @@ def test_config5_float64_lognormal_full_size(hip, dpower):
         assert np.max(np.abs(got - want) / want) <= 1e-12
         assert abs(got.mean() - 1.0) < 0.02
     plan.close()
+
+
+def test_reference_rng_array_and_none_seeds(hip, dpower):
+    """random.py:24 hands the seed to np.random.RandomState: array seeds (init_by_array) and None are replayed on the
+    GPU like integer seeds -- no host deviates are drawn or uploaded."""
+    from randomfield_amd import Generator
+    k, Pk = dpower
+    n = 32
+    gen = Generator(n, n, n, SPACING)
+    for seed in ([1, 2, 3], np.arange(700) * 7 + 1, np.array([77])):
+        d = gen.generate_delta_field(seed=seed, save_potential=False).copy()
+        noise = np.random.RandomState(seed).normal(size=2 * n * n * (n // 2 + 1))
+        ref, rms = cpu_ref.generate_delta_field(n, n, n, SPACING, k, Pk, noise=noise)
+        assert np.max(np.abs(d - ref)) <= TOL_F32 * rms
+    a = gen.generate_delta_field(seed=None, save_potential=False).copy()
+    b = gen.generate_delta_field(seed=None, save_potential=False)
+    assert np.isfinite(a).all() and not np.array_equal(a, b)
+    with pytest.raises(ValueError):
+        gen.generate_delta_field(seed=2 ** 32)
+    gen.plan_c2r.device.close()

@@ -17,6 +17,29 @@ def test_seeding_matches_numpy(seed):
     assert np.array_equal(mt.init_genrand(seed), np.random.RandomState(seed).get_state()[1])
 
 
+@pytest.mark.parametrize("key", [[0, 0], [1, 2, 3], [2 ** 32 - 1] * 7, list(range(700)), np.arange(5, dtype=np.int64) * 123456789])
+def test_array_seeding_matches_numpy(key):
+    """init_by_array: the state numpy's legacy RandomState(array) starts from (random.py:24 accepts any such seed)."""
+    want = np.random.RandomState(key).get_state()[1]
+    assert np.array_equal(mt.init_by_array(key), want)
+    assert np.array_equal(mt.seed_state(np.asarray(key)), want)
+    assert np.array_equal(mt.seed_state([5]), np.random.RandomState([5]).get_state()[1])     # a list: init_by_array
+    assert np.array_equal(mt.seed_state(np.array([5])), np.random.RandomState(np.array([5])).get_state()[1])   # squeezed to 5
+
+
+def test_seed_state_rules():
+    assert np.array_equal(mt.seed_state(7), mt.init_genrand(7))
+    assert mt.seed_state(None).shape == (624,)
+    with pytest.raises(ValueError):
+        mt.seed_state(2 ** 32)
+    with pytest.raises(ValueError):
+        mt.seed_state(-1)
+    with pytest.raises(ValueError):
+        mt.seed_state([[1, 2], [3, 4]])
+    with pytest.raises(ValueError):
+        mt.seed_state([1, 2 ** 32])
+
+
 def test_sequence_and_tempering_match_numpy_raw_words():
     n = 5 * mt.N
     raw = np.frombuffer(np.random.RandomState(42).bytes(4 * n), dtype="<u4")
