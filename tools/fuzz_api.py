@@ -41,7 +41,7 @@ def main():
         M = nx * ny * (nz // 2 + 1)
         field = None
         for _ in range(rng.randint(2, 7)):
-            op = rng.choice(["ext", "native", "gen", "r2c", "lognormal", "affine", "potential", "batch", "mt", "lens"])
+            op = rng.choice(["ext", "native", "gen", "r2c", "lognormal", "affine", "potential", "rpot", "batch", "mt", "lens"])
             counts[op] = counts.get(op, 0) + 1
             if op == "ext":
                 seed = int(rng.randint(1, 10 ** 6))
@@ -96,6 +96,19 @@ def main():
                 ref = (field * mul.astype(rt) + rt(add)).astype(rt)
                 assert np.allclose(got, ref, rtol=3e-6 if ct == np.complex64 else 1e-13, atol=1e-6 if ct == np.complex64 else 1e-13)
                 field = got
+            elif op == "rpot":
+                # the reference API's default call: field + delta(k)/k^2 in one go (fused for native noise on float32 plans)
+                seed = int(rng.randint(1, 2 ** 31))
+                p.realise_potential(seed=seed)
+                field = p.download_real()
+                noise = cpu_ref.native_noise(seed, nx, ny, nz, ct)
+                ref, rms = cpu_ref.generate_delta_field(nx, ny, nz, SPACING, k, Pk, noise=noise, dtype=ct, double_fft=True)
+                assert np.max(np.abs(field - ref)) <= 2e-5 * rms, ("rpot field", shape, ct)
+                p.load_potential(1.0)
+                got = p.download_k()
+                kref = cpu_ref.generate_kspace(nx, ny, nz, SPACING, k, Pk, noise=noise, dtype=np.complex128)
+                pref = cpu_ref.potential_kspace(kref, SPACING)
+                assert np.max(np.abs(got - pref)) <= 2e-5 * max(np.max(np.abs(pref)), 1e-30), ("rpot potential", shape, ct)
             elif op == "potential":
                 seed = int(rng.randint(1, 10 ** 6))
                 noise = cpu_ref.reference_noise(seed, M)
