@@ -80,11 +80,12 @@ int rf_generate(rf_plan* plan, uint64_t seed, int mode, const double* noise_host
  * (random.py:24-28) = MT19937 + legacy polar method, filled into the plan's device noise buffer in the
  * reference's order; afterwards rf_generate / rf_realise with mode RF_NOISE_RESIDENT use it (same-seed
  * parity without drawing 2*M deviates on the host and uploading them).
- * rf_mt_set_jump: positions of the set coefficients of t^(L*2^k) mod phi(t), k < nlevels, L =
- * 624*blocks_per_segment words (computed by randomfield_amd/mt19937.py); pos is nlevels x stride uint16.
+ * rf_mt_set_jump: the jump polynomials of a radix-R tree over the segments (L = 624*blocks_per_segment words each):
+ * row t*(R-1) + (m-1) holds the positions of the set coefficients of t^(m * R^t * L) mod phi(t), m = 1 .. R-1, for
+ * as many stages t as the largest grid needs (computed by randomfield_amd/mt19937.py); pos is npolys x stride uint16.
  * rf_noise_mt19937: state624 = the generator's initial state (init_genrand(seed)); *accepted (may be NULL)
  * receives the number of accepted polar attempts that were generated. */
-int rf_mt_set_jump(rf_plan* plan, int nlevels, const uint16_t* pos, const int* npos, int stride, int blocks_per_segment);
+int rf_mt_set_jump(rf_plan* plan, int npolys, const uint16_t* pos, const int* npos, int stride, int blocks_per_segment, int radix);
 int rf_noise_mt19937(rf_plan* plan, const uint32_t* state624, unsigned long long* accepted);
 /* copy deviates [first, first+count) of the device noise buffer to the host (tests) */
 int rf_download_noise(rf_plan* plan, double* host, unsigned long long first, unsigned long long count);

@@ -39,7 +39,7 @@ SIGNATURES = {
     "rf_set_power": (ctypes.c_int, [ctypes.c_void_p, _c_dp, _c_dp, ctypes.c_int]),
     "rf_generate": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, _c_dp]),
     "rf_mt_set_jump": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_uint16),
-                                      ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_int]),
+                                      ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "rf_noise_mt19937": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32),
                                         ctypes.POINTER(ctypes.c_ulonglong)]),
     "rf_download_noise": (ctypes.c_int, [ctypes.c_void_p, _c_dp, ctypes.c_ulonglong, ctypes.c_ulonglong]),
@@ -243,7 +243,7 @@ class DevicePlan(object):
         array of integers (``init_by_array``) or None.  Afterwards pass ``noise='resident'``."""
         from . import mt19937
         if not getattr(self, "_mt_ready", False):
-            polys = mt19937.jump_polynomials(20)
+            polys = mt19937.tree_polynomials(4)
             pos = [mt19937.set_bit_positions(p) for p in polys]
             stride = max(len(q) for q in pos)
             table = np.zeros((len(pos), stride), np.uint16)
@@ -252,7 +252,7 @@ class DevicePlan(object):
             npos = np.array([len(q) for q in pos], np.int32)
             check(self._lib.rf_mt_set_jump(self._h, len(pos), table.ctypes.data_as(ctypes.POINTER(ctypes.c_uint16)),
                                            npos.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), stride,
-                                           mt19937.SEGMENT_BLOCKS), "rf_mt_set_jump")
+                                           mt19937.SEGMENT_BLOCKS, mt19937.TREE_RADIX), "rf_mt_set_jump")
             self._mt_ready = True
         state = np.ascontiguousarray(mt19937.seed_state(seed), np.uint32)
         acc = ctypes.c_ulonglong(0)

@@ -127,7 +127,8 @@ struct rf_plan {
   // MT19937 replay (rf_noise_mt19937): jump-polynomial bit positions per tree level, scratch
   uint32_t* mt_pos = nullptr;          // set-bit positions of the jump polynomials, widened to 32 bits (scalar loads)
   std::vector<int> mt_npos;
-  int mt_stride = 0, mt_bps = 0;          // positions per level (padded), blocks of 624 words per segment
+  int mt_stride = 0, mt_bps = 0, mt_radix = 2;   // positions per polynomial (padded), blocks of 624 words per segment, tree radix
+  int* mt_npos_dev = nullptr;
   uint32_t* mt_states = nullptr;
   unsigned long long *mt_counts = nullptr, *mt_offsets = nullptr;
   size_t mt_states_cap = 0, mt_seg_cap = 0;
@@ -650,7 +651,7 @@ int rf_plan_destroy(rf_plan* p) {
   if (p->comm_stream) { (void)hipStreamSynchronize(p->comm_stream); (void)hipStreamDestroy(p->comm_stream); }
   for (auto& e : p->pev) if (e) (void)hipEventDestroy(e);
   void* bufs[] = {p->W, p->R, p->W2, p->R2, p->K, p->P, p->tw_x, p->tw_y, p->tw_z, p->kx2, p->ky2, p->kz2, p->xt, p->st, p->sl, p->bin,
-                  p->noise, p->mt_pos, p->mt_states, p->mt_counts, p->mt_offsets, p->partials, p->stats, p->seeds_dev, p->ztab, p->frec, p->coll_scratch};
+                  p->noise, p->mt_pos, p->mt_npos_dev, p->mt_states, p->mt_counts, p->mt_offsets, p->partials, p->stats, p->seeds_dev, p->ztab, p->frec, p->coll_scratch};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   for (int i = 0; i < 2; ++i) {
@@ -1143,25 +1144,29 @@ int rf_kernel_ms(rf_plan* p, float* ms5) {
   return 0;
 }
 
-int rf_mt_set_jump(rf_plan* p, int nlevels, const uint16_t* pos, const int* npos, int stride, int blocks_per_segment) {
+int rf_mt_set_jump(rf_plan* p, int npolys, const uint16_t* pos, const int* npos, int stride, int blocks_per_segment, int radix) {
   RF_REQUIRE(p && pos && npos, "null argument");
   RF_REQUIRE(!p->unpacked, "this call does not apply to an unpacked c2c plan");
-  RF_REQUIRE(nlevels >= 1 && stride >= 1 && blocks_per_segment >= 1, "invalid jump table");
+  RF_REQUIRE(npolys >= 1 && stride >= 1 && blocks_per_segment >= 1 && radix >= 2 && npolys % (radix - 1) == 0, "invalid jump table");
   RF_HIP(hipSetDevice(p->device));
   RF_HIP(hipStreamSynchronize(p->stream));
   if (p->mt_pos) RF_HIP(hipFree(p->mt_pos));
+  if (p->mt_npos_dev) RF_HIP(hipFree(p->mt_npos_dev));
   p->mt_pos = nullptr;
+  p->mt_npos_dev = nullptr;
   // the kernel reads the positions with scalar loads, which have dword granularity: widen; pad rows to 8 entries
   const int wstride = (stride + 7) / 8 * 8;
-  std::vector<uint32_t> wide((size_t)nlevels * wstride, 0u);
-  for (int l = 0; l < nlevels; ++l)
+  std::vector<uint32_t> wide((size_t)npolys * wstride, 0u);
+  for (int l = 0; l < npolys; ++l)
     for (int j = 0; j < npos[l]; ++j) wide[(size_t)l * wstride + j] = pos[(size_t)l * stride + j];
   RF_HIP(hipMalloc((void**)&p->mt_pos, wide.size() * sizeof(uint32_t)));
   RF_HIP(hipMemcpy(p->mt_pos, wide.data(), wide.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-  stride = wstride;
-  p->mt_npos.assign(npos, npos + nlevels);
-  p->mt_stride = stride;
+  RF_HIP(hipMalloc((void**)&p->mt_npos_dev, (size_t)npolys * sizeof(int)));
+  RF_HIP(hipMemcpy(p->mt_npos_dev, npos, (size_t)npolys * sizeof(int), hipMemcpyHostToDevice));
+  p->mt_npos.assign(npos, npos + npolys);
+  p->mt_stride = wstride;
   p->mt_bps = blocks_per_segment;
+  p->mt_radix = radix;
   return 0;
 }
 
@@ -1178,10 +1183,13 @@ int rf_noise_mt19937(rf_plan* p, const uint32_t* state624, unsigned long long* a
   const unsigned long long attempts = (unsigned long long)std::ceil((double)ncells / pa + 10.0 * std::sqrt((double)ncells * (1 - pa)) / pa + 1024.0);
   const long long total_blocks = (long long)((4 * attempts + 623) / 624);
   const int nseg = (int)((total_blocks + p->mt_bps - 1) / p->mt_bps);
-  int levels = 0;
-  while ((1 << levels) < nseg) ++levels;
-  RF_REQUIRE(levels <= (int)p->mt_npos.size(), "grid too large for the uploaded jump table");
-  const size_t nstates = (size_t)1 << levels;
+  // stages of the radix-R jump tree: stage t needs the R - 1 polynomials t^(m R^t L), rows t (R - 1) .. of the table
+  const int R = p->mt_radix;
+  int stages = 0;
+  long long reach = 1;
+  while (reach < nseg) { reach *= R; ++stages; }
+  RF_REQUIRE(stages * (R - 1) <= (int)p->mt_npos.size(), "grid too large for the uploaded jump table");
+  const size_t nstates = (size_t)nseg;
   if (p->mt_states_cap < nstates) {
     if (p->mt_states) RF_HIP(hipFree(p->mt_states));
     p->mt_states = nullptr;
@@ -1198,14 +1206,12 @@ int rf_noise_mt19937(rf_plan* p, const uint32_t* state624, unsigned long long* a
   }
   hipStream_t s = p->stream;
   RF_HIP(hipMemcpyAsync(p->mt_states, state624, 624 * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-  // jump tree: level k turns the states of segments [0, 2^k) into those of [2^k, 2^(k+1)) (distance 2^k segments)
-  for (int k = 0; k < levels; ++k) {
-    const long long nsrc_all = 1LL << k;
-    long long ndst_all = (long long)nseg - nsrc_all;
-    if (ndst_all > nsrc_all) ndst_all = nsrc_all;
-    if (ndst_all > 0)
-      RF_HIP(launch_mt_jump(p->mt_states, p->mt_pos + (size_t)k * p->mt_stride, p->mt_npos[k], p->mt_states + (size_t)nsrc_all * 624,
-                            (int)ndst_all, s));
+  // jump tree: stage t turns the start states of segments [0, R^t) into those of [R^t, R^(t+1))
+  long long dist = 1;
+  for (int t = 0; t < stages; ++t, dist *= R) {
+    const int nsrc = (int)(dist < nseg ? dist : nseg);
+    RF_HIP(launch_mt_jump(p->mt_states, p->mt_pos + (size_t)t * (R - 1) * p->mt_stride, p->mt_npos_dev + t * (R - 1), p->mt_stride, nsrc,
+                          dist, R - 1, nseg, s));
   }
   RF_HIP(launch_mt_polar(false, p->mt_states, nseg, p->mt_bps, total_blocks, p->mt_counts, nullptr, nullptr, ncells, s));
   RF_HIP(launch_mt_scan(p->mt_counts, p->mt_offsets, nseg, s));

@@ -8,7 +8,7 @@
 // Parallelisation (randomfield_amd/mt19937.py has the mathematics):
 //   1. jump tree: the state J words ahead is the XOR of the sequence words x_{i+j} over the set
 //      coefficients j of t^J mod phi(t).  mt_jump_kernel builds 33 blocks of the sequence of a source state in
-//      LDS and XORs them; level k of the tree doubles the number of segment start states.
+//      LDS and XORs them; stage t of the radix-16 tree multiplies the number of segment start states by 16.
 //   2. mt_polar_kernel<false>: every segment (1024 blocks of 624 outputs, one WAVE each) counts its accepted attempts;
 //      an exclusive scan of the counts gives each segment the index of its first cell;
 //   3. mt_polar_kernel<true>: the same generation again, now writing the deviates of the accepted attempts.
@@ -22,6 +22,7 @@ namespace {
 constexpr int MT_N = 624, MT_M = 397;
 constexpr int MT_SEQ_BLOCKS = 33;                  // 33 * 624 = 20592 >= 19937 + 624 sequence words per source
 constexpr int MT_SEQ_WORDS = MT_SEQ_BLOCKS * MT_N;
+constexpr int MT_POS_MAX = 12288;                  // staged positions per polynomial (a degree-19936 polynomial has ~10^4 set bits)
 
 __device__ __forceinline__ uint32_t mt_f(uint32_t a, uint32_t b, uint32_t c) {
   const uint32_t y = (a & 0x80000000u) | (b & 0x7FFFFFFFu);
@@ -49,15 +50,22 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
   return y;
 }
 
-// One jump: destination state d = source state d advanced by the level's distance.  One workgroup per destination:
-// the 33-block sequence window of the source (82 KB) is generated into LDS, then lane i XORs the window words
-// i + pos[j] over the set coefficients j of the jump polynomial (~10^4 conflict-free LDS reads per lane instead
-// of as many L2 reads: the global-memory version of this step took 13 of the replay's 28 ms).
-__global__ __launch_bounds__(640) void mt_jump_kernel(const uint32_t* __restrict__ states_src, const uint32_t* __restrict__ pos,
-                                                      int npos, uint32_t* __restrict__ states_dst) {
+// Jumps of one tree stage.  Stage t of the radix-R tree turns the start states of segments [0, R^t) into those of
+// [R^t, R^(t+1)): destination i + m R^t = source i advanced by m R^t segments, m = 1 .. R-1, with the jump polynomial
+// t^(m R^t L) mod phi (row m-1 of the stage's position table).  One workgroup per (source, group of multipliers): the
+// 33-block sequence window of the source (82 KB) is generated into LDS ONCE, then for every multiplier of the group
+// lane i XORs the window words i + pos[j] over the set coefficients j of that polynomial (~10^4 conflict-free LDS
+// reads per lane; as global-memory reads this step took 13 of the replay's 28 ms in round 1).  Building the window
+// is about half of a single jump, and a binary tree spends nine of its thirteen levels waiting for one or a few
+// workgroups: radix 16 needs four launches and shares each window between up to 15 jumps (5.6 -> 2 ms at 1024^3).
+__global__ __launch_bounds__(640) void mt_jump_kernel(const uint32_t* __restrict__ states, const uint32_t* __restrict__ pos,
+                                                      const int* __restrict__ npos, int pos_stride, int nsrc, long long dist,
+                                                      int nmult, int mult_per_wg, int nseg) {
   extern __shared__ __attribute__((aligned(16))) uint32_t win[];     // MT_SEQ_WORDS words
   const int t = threadIdx.x;
-  const uint32_t* st = states_src + (size_t)blockIdx.x * MT_N;
+  const int src = blockIdx.x % nsrc, m0 = 1 + (blockIdx.x / nsrc) * mult_per_wg;
+  if ((long long)src + (long long)m0 * dist >= nseg) return;         // uniform: no destination of this workgroup exists
+  const uint32_t* st = states + (size_t)src * MT_N;
   if (t < MT_N) win[t] = st[t];
   __syncthreads();
   // x[n + 624] = f(x[n], x[n + 1], x[n + 397]): within a block of 624 new words, words [0, 227) need old words only,
@@ -72,14 +80,31 @@ __global__ __launch_bounds__(640) void mt_jump_kernel(const uint32_t* __restrict
     if (t >= 454 && t < MT_N) nw[t] = mt_f(od[t], od[t + 1], od[t + MT_M]);
     __syncthreads();
   }
-  if (t < MT_N) {
-    uint32_t acc = 0;
-    const uint32_t* w = win + t;
-    int j = 0;                                     // pos[] is uniform: scalar loads, 8 positions per s_load_dwordx8
-    for (; j + 8 <= npos; j += 8)
-      acc ^= w[pos[j]] ^ w[pos[j + 1]] ^ w[pos[j + 2]] ^ w[pos[j + 3]] ^ w[pos[j + 4]] ^ w[pos[j + 5]] ^ w[pos[j + 6]] ^ w[pos[j + 7]];
-    for (; j < npos; ++j) acc ^= w[pos[j]];
-    states_dst[(size_t)blockIdx.x * MT_N + t] = acc;
+  // the ~10^4 positions of a polynomial are staged in LDS behind the window (16-bit, 8 per 16-byte broadcast read):
+  // fetched with scalar loads inside the XOR loop, every 8 LDS reads waited for one scalar-cache round trip and a
+  // jump took 0.25 ms; from LDS the loop runs at the LDS rate (~0.09 ms)
+  uint16_t* lpos = reinterpret_cast<uint16_t*>(win + MT_SEQ_WORDS);
+  const uint32_t* w = win + (t < MT_N ? t : 0);
+  for (int m = m0; m < m0 + mult_per_wg && m <= nmult; ++m) {
+    const long long dst = (long long)src + (long long)m * dist;
+    if (dst >= nseg) break;                                           // uniform
+    const uint32_t* pm = pos + (size_t)(m - 1) * pos_stride;
+    const int np = npos[m - 1], np8 = (np + 7) & ~7;                  // rows are zero-padded to multiples of 8 entries
+    __syncthreads();                                                  // the previous multiplier's loop is done with lpos
+    for (int i = t; i < np8; i += 640) lpos[i] = (uint16_t)pm[i];
+    __syncthreads();
+    if (t < MT_N) {
+      uint32_t acc = 0;
+      typedef unsigned short us8 __attribute__((ext_vector_type(8)));
+      const us8* lp = reinterpret_cast<const us8*>(lpos);
+      const int full = np >> 3;
+      for (int j = 0; j < full; ++j) {
+        const us8 q = lp[j];                                          // same address in every lane: broadcast
+        acc ^= w[q.s0] ^ w[q.s1] ^ w[q.s2] ^ w[q.s3] ^ w[q.s4] ^ w[q.s5] ^ w[q.s6] ^ w[q.s7];
+      }
+      for (int j = full << 3; j < np; ++j) acc ^= w[lpos[j]];
+      const_cast<uint32_t*>(states)[(size_t)dst * MT_N + t] = acc;
+    }
   }
 }
 
@@ -167,11 +192,19 @@ __global__ __launch_bounds__(64) void mt_scan_kernel(const unsigned long long* _
 
 }  // namespace
 
-hipError_t launch_mt_jump(const uint32_t* states_src, const uint32_t* pos, int npos, uint32_t* states_dst, int ndst, hipStream_t s) {
-  constexpr int lds = MT_SEQ_WORDS * (int)sizeof(uint32_t);
+hipError_t launch_mt_jump(uint32_t* states, const uint32_t* pos, const int* npos, int pos_stride, int nsrc, long long dist,
+                          int nmult, int nseg, hipStream_t s) {
+  if (pos_stride > MT_POS_MAX) return hipErrorInvalidValue;
+  constexpr int lds = MT_SEQ_WORDS * (int)sizeof(uint32_t) + MT_POS_MAX * (int)sizeof(uint16_t);
   static LdsAttrLatch latch;
   if (hipError_t e = latch.ensure((const void*)mt_jump_kernel, lds); e != hipSuccess) return e;
-  hipLaunchKernelGGL(mt_jump_kernel, dim3(ndst), dim3(640), lds, s, states_src, pos, npos, states_dst);
+  // one 82 KB window (+ 24 KB of positions) per CU: share a source's window between as many multipliers as it takes to fit one round
+  const int cus = device_cu_count();
+  int per = (int)(((long long)nsrc * nmult + cus - 1) / cus);
+  per = per < 1 ? 1 : (per > nmult ? nmult : per);
+  const int groups = (nmult + per - 1) / per;
+  hipLaunchKernelGGL(mt_jump_kernel, dim3((unsigned)(nsrc * groups)), dim3(640), lds, s, states, pos, npos, pos_stride, nsrc, dist, nmult,
+                     per, nseg);
   return hipGetLastError();
 }
 hipError_t launch_mt_polar(bool fill, const uint32_t* states, int nseg, int blocks_per_segment, long long total_blocks,

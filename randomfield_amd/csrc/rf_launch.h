@@ -91,7 +91,10 @@ hipError_t launch_save_potential(int f64, const void* K, void* P, int nx, int ny
 hipError_t launch_scale_copy(int f64, const void* P, void* K, long long n, double scale, hipStream_t s);
 
 // on-GPU replay of RandomState(seed).normal (rf_k_mt.hip)
-hipError_t launch_mt_jump(const uint32_t* states_src, const uint32_t* pos, int npos, uint32_t* states_dst, int ndst, hipStream_t s);
+// one stage of the jump tree: states[i + m * dist] = states[i] advanced by m * dist segments, i < nsrc, m = 1 .. nmult
+// (pos: nmult rows of pos_stride positions, npos: their lengths, both in device memory)
+hipError_t launch_mt_jump(uint32_t* states, const uint32_t* pos, const int* npos, int pos_stride, int nsrc, long long dist, int nmult,
+                          int nseg, hipStream_t s);
 hipError_t launch_mt_polar(bool fill, const uint32_t* states, int nseg, int blocks_per_segment, long long total_blocks,
                            unsigned long long* counts, const unsigned long long* offsets, double* noise,
                            unsigned long long ncells, hipStream_t s);

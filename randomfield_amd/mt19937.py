@@ -265,6 +265,35 @@ def jump_polynomials(nlevels=20, cache=True):
     return arr
 
 
+TREE_RADIX = 16
+_TREE_CACHE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data",
+                           "mt19937_tree_R%d_L%d.npz" % (TREE_RADIX, SEGMENT_WORDS))
+
+
+def tree_polynomials(nstages=4, cache=True):
+    """The jump polynomials of the radix-16 tree over segments: row t*15 + (m-1) = t^(m * 16^t * SEGMENT_WORDS) mod phi,
+    m = 1 .. 15, as (nstages*15, 624) uint32 coefficient words.  4 stages reach 65 536 segments (1.0e10 polar attempts:
+    a 2048^3 grid needs 35 000).  Cached next to the package data (built in ~5 s otherwise)."""
+    rows = nstages * (TREE_RADIX - 1)
+    if cache and os.path.exists(_TREE_CACHE):
+        arr = np.load(_TREE_CACHE)["polys"]
+        if arr.shape[0] >= rows:
+            return arr[:rows]
+    phi = characteristic_polynomial()
+    out = []
+    for t in range(nstages):
+        for m in range(1, TREE_RADIX):
+            g = power_of_t(m * TREE_RADIX ** t * SEGMENT_WORDS, phi)
+            out.append(np.frombuffer(g.to_bytes(N * 4, "little"), dtype="<u4").astype(np.uint32))
+    arr = np.stack(out)
+    if cache:
+        try:
+            np.savez_compressed(_TREE_CACHE, polys=arr)
+        except OSError:
+            pass
+    return arr
+
+
 def set_bit_positions(poly_words):
     """Positions j of the set coefficient bits of one jump polynomial (ascending uint16 array)."""
     bits = np.unpackbits(np.asarray(poly_words, "<u4").view(np.uint8), bitorder="little")

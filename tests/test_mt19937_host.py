@@ -87,3 +87,18 @@ def test_attempts_margin():
         need = mt.attempts_needed(ncells)
         p = np.pi / 4
         assert (need * p - ncells) / np.sqrt(need * p * (1 - p)) > 9.0     # > 9 sigma of head-room
+
+
+def test_tree_polynomials_are_the_right_powers(phi):
+    """rows of the radix-16 tree table: t^(m 16^t L); where m 16^t is a power of two they equal the binary-tree rows"""
+    tree = mt.tree_polynomials(3)
+    binary = mt.jump_polynomials(10)
+    assert tree.shape == (45, mt.N)
+    for (t, m, k) in ((0, 1, 0), (0, 2, 1), (0, 4, 2), (0, 8, 3), (1, 1, 4), (1, 2, 5), (2, 1, 8), (2, 2, 9)):
+        assert np.array_equal(tree[t * 15 + m - 1], binary[k])
+    g = mt.power_of_t(3 * 16 * mt.SEGMENT_WORDS, phi)
+    assert np.array_equal(tree[15 + 2], np.frombuffer(g.to_bytes(mt.N * 4, "little"), dtype="<u4"))
+    # a jump by 5 segments lands on the sequence 5 L words ahead
+    st = mt.init_genrand(4)
+    seq = mt.sequence(st, 5 * mt.SEGMENT_WORDS + mt.N)
+    assert _same_state(mt.jump_state(st, tree[4]), seq[5 * mt.SEGMENT_WORDS:5 * mt.SEGMENT_WORDS + mt.N])
