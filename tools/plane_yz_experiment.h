@@ -1,7 +1,8 @@
 // plane_yz_experiment.h -- EXPERIMENT (round 2), not part of the product: y and z passes fused plane by plane through
 // L2 / Infinity-Cache resident scratch planes, with per-XCD ticket queues and dataflow flags.  Correct by construction
 // of the dependency order and it runs, but on MI355X it is not faster than the two separate passes yet: 3.23 ms against
-// 1.58 + 1.49 ms at 1024^3 (tools/xbench.hip `f`; ticket + flag overhead alone 0.54 ms; each role alone 2.0 ms).  The
+// 1.58 + 1.49 ms at 1024^3 (tools/xbench.hip `f`; ticket + flag overhead alone 0.54 ms; each role alone 2.0 ms); the
+// non-persistent v2 at the end of this file (`g`) takes 5.05 ms.  The
 // per-item critical path (load -> three LDS passes -> store, ~12 us) times twice as many items over the same 512
 // resident workgroups is what bounds it, not HBM.  See DESIGN.md section 3.5.
 #pragma once
@@ -252,5 +253,134 @@ __global__ __launch_bounds__(CY::NT, 4) void plane_yz_kernel(cplx<typename CY::T
   }
 }
 
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// v2: the same plane pipeline WITHOUT persistent workgroups and tickets.  One workgroup per item; blockIdx b belongs to
+// group b % 8 (blocks b and b + 8 share an XCD: observed dispatch rule, VERIFIED at run time through XCC_ID -- a
+// mismatch sets the sticky error) and q = b / 8 is its position in the group's item order Y(s0) Y(s1) Z(s0) Y(s2)
+// Z(s1) ...; group g owns the planes g, g + 8, g + 16, ...  An item waits (bounded) for items with smaller q of its
+// own group only: Z(s) for the NYI Y items of s, Y(s + NS) for the NZI Z items of s.  Workgroups are dispatched in
+// blockIdx order, so the producers of a waiting item hold their slots already.  Fresh workgroups per item keep what
+// made the separate passes fast (a finished workgroup's stores drain while the next one starts; no vmcnt ordering
+// between items), at the price of staging the twiddle tables (16 KB from L2) per item.
+struct PlaneCtl2 {
+  static constexpr int GROUPS = 8, MAXSEQ = 512;
+  unsigned error;
+  unsigned pad0[31];
+  unsigned group_xcc[GROUPS];    // XCC_ID + 1 of the first workgroup of each group (0 = not yet registered)
+  unsigned pad1[24];
+  unsigned done_y[GROUPS][MAXSEQ];
+  unsigned done_z[GROUPS][MAXSEQ];
+};
+
+template <class CY, class CZ, int ZR, int NS>
+__global__ __launch_bounds__(CY::NT, 4) void plane_yz_kernel_v2(cplx<typename CY::T>* __restrict__ W, int nx,
+                                                                cplx<typename CY::T>* __restrict__ scratch,
+                                                                const cplx<typename CY::T>* __restrict__ tw_y,
+                                                                const cplx<typename CY::T>* __restrict__ tw_z,
+                                                                typename CY::T scale, double* __restrict__ partials,
+                                                                PlaneCtl2* __restrict__ ctl, int debug_skip) {
+  using T = typename CY::T;
+  using cx = cplx<T>;
+  using FY = ColFFT<CY, +1, PlaneYIO<T>>;
+  using FZ = RowC2R<CZ, PlaneZIO<T>>;
+  static_assert(CY::NT == CZ::NT && CY::NPASS == 3 && ZR % CZ::NRT == 0, "plane kernel: configuration");
+  constexpr int NY = CY::N, M = CZ::M;
+  constexpr int NYI = M / CY::TC, NZI = NY / ZR;
+  constexpr int TILE = CY::TILE_BYTES > CZ::TILE_BYTES ? CY::TILE_BYTES : CZ::TILE_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char rf_smem[];
+  cx* lds = reinterpret_cast<cx*>(rf_smem);
+  cx* ltw_y = reinterpret_cast<cx*>(rf_smem + TILE);
+  cx* ltw_z = reinterpret_cast<cx*>(rf_smem + TILE + CY::TW_BYTES);
+  unsigned* mail = reinterpret_cast<unsigned*>(rf_smem);
+  const int tid = threadIdx.x;
+  const unsigned g = blockIdx.x & 7u, q = blockIdx.x >> 3;
+  const unsigned r = q / (unsigned)(NYI + NZI), i = q % (unsigned)(NYI + NZI);
+  const bool is_y = i < (unsigned)NYI;
+  const int seq = is_y ? (int)r : (int)r - 1;
+  const int item = (int)(is_y ? i : i - (unsigned)NYI);
+  if (seq < 0) return;                                              // Z items of sequence -1
+  const long long plane = (long long)g + 8LL * seq;
+  if (plane >= nx) return;                                          // idle tail
+  // stage only the table this item needs
+  if (is_y) { for (int k = tid; k < NY; k += CY::NT) ltw_y[k] = tw_y[k]; }
+  else      { for (int k = tid; k < 2 * M; k += CY::NT) ltw_z[k] = tw_z[k]; }
+  if (tid == 0) {
+    bool ok = true;
+    const unsigned xcc = xcc_id() + 1u;
+    const unsigned prev = atomicCAS(&ctl->group_xcc[g], 0u, xcc);
+    if (prev != 0u && prev != xcc) ok = false;                      // this group spans two XCDs: its scratch is not coherent
+    if (ok) {
+      if (is_y) { if (seq >= NS) ok = ctl_wait_ge(&ctl->done_z[g][seq - NS], (unsigned)NZI, &ctl->error); }
+      else ok = ctl_wait_ge(&ctl->done_y[g][seq], (unsigned)NYI, &ctl->error);
+    }
+    if (!ok) __hip_atomic_store(&ctl->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    mail[0] = ok ? 1u : 0u;
+  }
+  __syncthreads();
+  const unsigned go = (unsigned)__builtin_amdgcn_readfirstlane((int)mail[0]);
+  __syncthreads();
+  if (!go) return;
+  const long long plane_elems = (long long)NY * M;
+  cx* Wp = W + plane * plane_elems;
+  cx* Sp = scratch + ((long long)g * NS + (seq % NS)) * plane_elems;
+  const int tl = tid;
+  if ((is_y && (debug_skip & 1)) || (!is_y && (debug_skip & 2))) {
+    if (tid == 0) atomicAdd(is_y ? &ctl->done_y[g][seq] : &ctl->done_z[g][seq], 1u);
+    return;
+  }
+  if (is_y) {
+    PlaneYIO<T> io;
+    io.src = Wp; io.dst = Sp; io.g = ColGeom{(long long)M, 0, (long long)M};
+    FY::pass_first(tl, item, io, lds);
+    typename FY::Regs rr;
+    __syncthreads();
+    FY::pass_mid_read(tl, ltw_y, lds, rr);
+    __syncthreads();
+    FY::pass_mid_write(tl, lds, rr);
+    __syncthreads();
+    FY::pass_last(tl, item, io, ltw_y, lds);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                              // vmcnt(0): this thread's scratch stores are in the L2
+    __syncthreads();
+    if (tid == 0) atomicAdd(&ctl->done_y[g][seq], 1u);
+  } else {
+    PlaneZIO<T> io;
+    io.src = Sp; io.dst = Wp; io.scale = scale; io.M_of = M;
+    typename FZ::Regs rr;
+    double s1 = 0, s2 = 0;
+#pragma unroll 1
+    for (int sub = 0; sub < ZR / CZ::NRT; ++sub) {
+      const long long tile = (long long)item * (ZR / CZ::NRT) + sub;
+      FZ::pass_first(tl, tile, NY, io, ltw_z, lds, rr);
+      __syncthreads();
+      if (sub == ZR / CZ::NRT - 1 && tid == 0) atomicAdd(&ctl->done_z[g][seq], 1u);   // all scratch reads have returned
+      FZ::pass_mid_read(tl, ltw_z, lds, rr);
+      __syncthreads();
+      FZ::pass_mid_write(tl, lds, rr);
+      __syncthreads();
+      FZ::pass_last(tl, tile, NY, io, ltw_z, lds, rr);
+      s1 += rr.s1; s2 += rr.s2;
+      __syncthreads();
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      s1 += __shfl_down(s1, off);
+      s2 += __shfl_down(s2, off);
+    }
+    double* red = reinterpret_cast<double*>(rf_smem);
+    const int wave = tid >> 6, lane = tid & 63;
+    if (lane == 0) { red[2 * wave] = s1; red[2 * wave + 1] = s2; }
+    __syncthreads();
+    if (tid == 0) {
+      double a = 0, b = 0;
+#pragma unroll
+      for (int w = 0; w < CY::NT / 64; ++w) { a += red[2 * w]; b += red[2 * w + 1]; }
+      const long long slot_p = plane * NZI + item;
+      partials[2 * slot_p] = a;
+      partials[2 * slot_p + 1] = b;
+    }
+  }
+}
 
 }  // namespace rf

@@ -651,6 +651,42 @@ int main(int argc, char** argv) {
       report("y pass reading the interleaved layout, writing the standard one (out of place)", bench_x<CY, IlvYIO>(t, yi, tw, (long long)NX * nzc, 0, 0), 2 * sweep);
     }
   }
+
+  if (argc >= 2 && strchr(argv[1], 'g')) {
+    // fused y + z, v2: one workgroup per item, blockIdx-ordered roles
+    using CY = ColCfg<float, 1024, RF_FUSED_R1, RF_FUSED_R2, 8, 8, 512>;
+    using CZ = RowCfg<float, 512, 8, 8, 8, 8, 512>;
+    constexpr int ZR = 16, NS = 3;
+    auto k = plane_yz_kernel_v2<CY, CZ, ZR, NS>;
+    constexpr int TILE = CY::TILE_BYTES > CZ::TILE_BYTES ? CY::TILE_BYTES : CZ::TILE_BYTES;
+    constexpr int lds = TILE + CY::TW_BYTES + CZ::TW_BYTES;
+    CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    cplx<float>* S;
+    const size_t plane = (size_t)NY * nzc * 8;
+    CK(hipMalloc((void**)&S, plane * NS * 8));
+    PlaneCtl2* ctl;
+    CK(hipMalloc((void**)&ctl, sizeof(PlaneCtl2)));
+    double* partials;
+    CK(hipMalloc((void**)&partials, 2 * sizeof(double) * (size_t)NX * NY));
+    const int nxp = getenv("RF_NXP") ? atoi(getenv("RF_NXP")) : NX;
+    const int nseq = (nxp + 7) / 8;
+    const unsigned grid = 8u * (unsigned)(nseq + 1) * 128u;        // rounds 0 .. nseq: round r holds Y(r) and Z(r - 1)
+    const int dbg_only = getenv("RF_DBG") ? atoi(getenv("RF_DBG")) : -1;
+    for (int dbg : {0, 1, 2, 3}) {
+      if (dbg_only >= 0 && dbg != dbg_only) continue;
+      char nm[160];
+      snprintf(nm, sizeof nm, "fused y+z v2 (one workgroup per item), %d planes, skip=%d (1: no Y work, 2: no Z work)", nxp, dbg);
+      report(nm, t.run([&]() {
+        CK(hipMemsetAsync(ctl, 0, sizeof(PlaneCtl2), 0));
+        hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, 0, W, nxp, S, tw, tw, 1.0f, partials, ctl, dbg);
+      }), 2 * sweep * nxp / NX);
+      PlaneCtl2 h;
+      CK(hipMemcpy(&h, ctl, sizeof h, hipMemcpyDeviceToHost));
+      printf("   error %u, group xcc ids %u %u %u %u %u %u %u %u, done_y[0][0..2] %u %u %u, done_z %u %u %u\n", h.error, h.group_xcc[0], h.group_xcc[1],
+             h.group_xcc[2], h.group_xcc[3], h.group_xcc[4], h.group_xcc[5], h.group_xcc[6], h.group_xcc[7], h.done_y[0][0], h.done_y[0][1],
+             h.done_y[0][2], h.done_z[0][0], h.done_z[0][1], h.done_z[0][2]);
+    }
+  }
   if (do_y) {
     using C = ColCfg<float, 1024, 16, 8, 8, 8, 512>;
     using IO = PlainColIO<float>;
