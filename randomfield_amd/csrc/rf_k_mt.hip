@@ -98,6 +98,7 @@ __global__ __launch_bounds__(640) void mt_jump_kernel(const uint32_t* __restrict
       typedef unsigned short us8 __attribute__((ext_vector_type(8)));
       const us8* lp = reinterpret_cast<const us8*>(lpos);
       const int full = np >> 3;
+#pragma unroll 4
       for (int j = 0; j < full; ++j) {
         const us8 q = lp[j];                                          // same address in every lane: broadcast
         acc ^= w[q.s0] ^ w[q.s1] ^ w[q.s2] ^ w[q.s3] ^ w[q.s4] ^ w[q.s5] ^ w[q.s6] ^ w[q.s7];
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(256) void mt_polar_kernel(const uint32_t* __restric
                                                        long long total_blocks, int nseg, unsigned long long* __restrict__ counts,
                                                        const unsigned long long* __restrict__ offsets,
                                                        double* __restrict__ noise, unsigned long long ncells) {
-  __shared__ uint32_t lds[4][MT_N + 16];
+  __shared__ __attribute__((aligned(16))) uint32_t lds[4][MT_N + 16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long long seg = (long long)blockIdx.x * 4 + wave;
   if (seg >= nseg) return;                                   // whole waves leave; nobody waits at a barrier
@@ -149,8 +150,14 @@ __global__ __launch_bounds__(256) void mt_polar_kernel(const uint32_t* __restric
       bool acc = false;
       double x1 = 0, x2 = 0, r2 = 0;
       if (a < MT_N / 4) {
-        const uint32_t w0 = mt_temper(mt[4 * a]), w1 = mt_temper(mt[4 * a + 1]);
-        const uint32_t w2 = mt_temper(mt[4 * a + 2]), w3 = mt_temper(mt[4 * a + 3]);
+        // the attempt's four words with ONE 16-byte LDS read (four 4-byte reads at a lane stride of 16 bytes are
+        // 4-way bank conflicts); the compiler barrier keeps it behind the volatile in-place regeneration above,
+        // and the LDS operations of one wave execute in program order
+        asm volatile("" ::: "memory");
+        typedef unsigned u4 __attribute__((ext_vector_type(4)));
+        const u4 raw = *reinterpret_cast<const u4*>(const_cast<const uint32_t*>(lds[wave]) + 4 * a);
+        const uint32_t w0 = mt_temper(raw.x), w1 = mt_temper(raw.y);
+        const uint32_t w2 = mt_temper(raw.z), w3 = mt_temper(raw.w);
         const double u1 = ((double)(w0 >> 5) * 67108864.0 + (double)(w1 >> 6)) / 9007199254740992.0;
         const double u2 = ((double)(w2 >> 5) * 67108864.0 + (double)(w3 >> 6)) / 9007199254740992.0;
         x1 = 2.0 * u1 - 1.0;
