@@ -12,6 +12,7 @@
 #include <vector>
 #include "../rf_configs.h"
 #include "../rf_host.h"
+#include "../rf_generic.h"
 
 using namespace rf;
 
@@ -248,9 +249,84 @@ int realise_fast_impl(int nx, int ny, int nz, const GenHost& h, uint64_t seed, d
   return dispatch_row_c2r<T>((int)nzc, W, (long long)nx * ny, 1.0 / ((double)nx * ny * nz), s1, s2);
 }
 
+
+// ---- non-power-of-two path (rf_generic.h): the same block functions the kernels run, one "thread" per block ----
+struct NoSync { void operator()() const {} };
+
+template <typename T>
+int generic_c2r_impl(int nx, int ny, int nz, const cplx<T>* K, T* W, double* s1, double* s2) {
+  GenericAxis ax, ay, az;
+  if (!generic_factor(nx, ax) || !generic_factor(ny, ay) || !generic_factor(nz / 2, az) || (nz & 1)) return -1;
+  const long long nzh = nz / 2 + 1;
+  auto rx = make_twiddles<T>(nx), ry = make_twiddles<T>(ny), rz = make_twiddles<T>(nz);
+  std::vector<cplx<T>> G((size_t)nx * ny * nzh);
+  const int TC = 3, TR = 2;                                   // deliberately not dividing the line counts
+  std::vector<cplx<T>> lds(2 * (size_t)std::max(std::max(nx, ny), nz) * 4);
+  const long long lx = (long long)ny * nzh, ly = (long long)nx * nzh, lz = (long long)nx * ny;
+  for (long long b = 0; b * TC < lx; ++b)
+    generic_axis_block<T>(K, G.data(), ax, lx, lx, 0, lx, TC, rx.data(), +1, (T)1, lds.data(), b, 0, 1, NoSync());
+  for (long long b = 0; b * TC < ly; ++b)
+    generic_axis_block<T>(G.data(), G.data(), ay, nzh, nzh, ny * nzh, ly, TC, ry.data(), +1, (T)1, lds.data(), b, 0, 1, NoSync());
+  double a1 = 0, a2 = 0;
+  const T scale = (T)(1.0 / ((double)nx * ny * nz));
+  for (long long b = 0; b * TR < lz; ++b)
+    generic_row_c2r_block<T>(G.data(), W, az, lz, TR, rz.data(), scale, lds.data(), b, 0, 1, NoSync(), a1, a2);
+  if (s1) *s1 = a1;
+  if (s2) *s2 = a2;
+  return 0;
+}
+
+template <typename T>
+int generic_r2c_impl(int nx, int ny, int nz, const T* W, cplx<T>* K) {
+  GenericAxis ax, ay, az;
+  if (!generic_factor(nx, ax) || !generic_factor(ny, ay) || !generic_factor(nz / 2, az) || (nz & 1)) return -1;
+  const long long nzh = nz / 2 + 1;
+  auto rx = make_twiddles<T>(nx), ry = make_twiddles<T>(ny), rz = make_twiddles<T>(nz);
+  const int TC = 3, TR = 2;
+  std::vector<cplx<T>> lds(2 * (size_t)std::max(std::max(nx, ny), nz) * 4);
+  const long long lx = (long long)ny * nzh, ly = (long long)nx * nzh, lz = (long long)nx * ny;
+  for (long long b = 0; b * TR < lz; ++b) generic_row_r2c_block<T>(W, K, az, lz, TR, rz.data(), lds.data(), b, 0, 1, NoSync());
+  for (long long b = 0; b * TC < ly; ++b)
+    generic_axis_block<T>(K, K, ay, nzh, nzh, ny * nzh, ly, TC, ry.data(), -1, (T)1, lds.data(), b, 0, 1, NoSync());
+  for (long long b = 0; b * TC < lx; ++b)
+    generic_axis_block<T>(K, K, ax, lx, lx, 0, lx, TC, rx.data(), -1, (T)1, lds.data(), b, 0, 1, NoSync());
+  return 0;
+}
+
+template <typename T>
+int generic_c2c_impl(int nx, int ny, int nz, int dir, cplx<T>* D) {
+  GenericAxis ax, ay, az;
+  if (!generic_factor(nx, ax) || !generic_factor(ny, ay) || !generic_factor(nz, az)) return -1;
+  auto rx = make_twiddles<T>(nx), ry = make_twiddles<T>(ny), rz = make_twiddles<T>(nz);
+  const int TC = 3;
+  std::vector<cplx<T>> lds(2 * (size_t)std::max(std::max(nx, ny), nz) * 4);
+  const long long lx = (long long)ny * nz, ly = (long long)nx * nz, lz = (long long)nx * ny;
+  const T scale = dir > 0 ? (T)(1.0 / ((double)nx * ny * nz)) : (T)1;
+  for (long long b = 0; b * TC < lx; ++b)
+    generic_axis_block<T>(D, D, ax, lx, lx, 0, lx, TC, rx.data(), dir, (T)1, lds.data(), b, 0, 1, NoSync());
+  for (long long b = 0; b * TC < ly; ++b)
+    generic_axis_block<T>(D, D, ay, nz, nz, (long long)ny * nz, ly, TC, ry.data(), dir, (T)1, lds.data(), b, 0, 1, NoSync());
+  for (long long b = 0; b * TC < lz; ++b)
+    generic_axis_block<T>(D, D, az, 1, 1, nz, lz, TC, rz.data(), dir, scale, lds.data(), b, 0, 1, NoSync());
+  return 0;
+}
+
 }  // namespace
 
 extern "C" {
+
+// the generic (any even shape) transforms: API-layout half spectrum <-> dense real field; c2c in place
+int emu_generic_c2r(int f64, int nx, int ny, int nz, const void* K, void* W, double* s1, double* s2) {
+  return f64 ? generic_c2r_impl<double>(nx, ny, nz, (const cplx<double>*)K, (double*)W, s1, s2)
+             : generic_c2r_impl<float>(nx, ny, nz, (const cplx<float>*)K, (float*)W, s1, s2);
+}
+int emu_generic_r2c(int f64, int nx, int ny, int nz, const void* W, void* K) {
+  return f64 ? generic_r2c_impl<double>(nx, ny, nz, (const double*)W, (cplx<double>*)K)
+             : generic_r2c_impl<float>(nx, ny, nz, (const float*)W, (cplx<float>*)K);
+}
+int emu_generic_c2c(int f64, int nx, int ny, int nz, int dir, void* D) {
+  return f64 ? generic_c2c_impl<double>(nx, ny, nz, dir, (cplx<double>*)D) : generic_c2c_impl<float>(nx, ny, nz, dir, (cplx<float>*)D);
+}
 
 // fused realisation with the fast native generation (float32 arithmetic; f64 != 0: float64 plan, values widened);
 // [xlo, xhi] = log10 k range of the grid (padded)

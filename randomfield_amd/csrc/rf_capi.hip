@@ -151,6 +151,11 @@ struct rf_plan {
   bool repair_timed = false;
   bool aux_valid = false;              // the k buffer's memory currently holds an auxiliary REAL field (lensing potential)
   bool unpacked = false;               // c2c plan: W is the full [nx][ny][nz] complex array, only rf_*_c / rf_execute_c2c apply
+  // non-power-of-two grid (rf_generic.h): the transforms run on API-layout arrays, K -> G -> W; no fused generation,
+  // no graphs, one rank.  gax / gay factor nx / ny, gaz factors nz/2 (packed plans) or nz (c2c plans)
+  bool generic = false;
+  void* G = nullptr;                   // lazy scratch [nx][ny][nz/2+1] complex
+  GenericAxis gax, gay, gaz;
   bool timed = false;
   struct BatchGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };
   std::map<int, BatchGraph> graphs;       // captured batch graphs, keyed by the number of realisations
@@ -172,6 +177,17 @@ void drop_graphs(rf_plan* p) {
 int ensure_k(rf_plan* p) {
   if (!p->K) RF_HIP(hipMalloc(&p->K, p->k_bytes));
   return 0;
+}
+
+int ensure_g(rf_plan* p) {
+  if (!p->G) RF_HIP(hipMalloc(&p->G, p->k_bytes));
+  return 0;
+}
+
+// any even shape with axes up to GENERIC_MAX_N (transform.py:172-177 asks for even axes, nothing more)
+bool generic_shape(int nx, int ny, int nz, GenericAxis& ax, GenericAxis& ay, GenericAxis& az_half) {
+  if (nx < 2 || ny < 2 || nz < 2 || (nx & 1) || (ny & 1) || (nz & 1)) return false;
+  return generic_factor(nx, ax) && generic_factor(ny, ay) && generic_factor(nz / 2, az_half) && nz <= GENERIC_MAX_N;
 }
 
 GenParams make_gen(rf_plan* p, uint64_t seed, int mode, bool seed_from_dev) {
@@ -226,7 +242,7 @@ int build_fast(rf_plan* p) {
   RF_HIP(hipStreamSynchronize(p->stream));
   drop_graphs(p);
   p->have_fast = false;
-  if (!p->have_kgrid || !p->have_power) return 0;
+  if (!p->have_kgrid || !p->have_power || p->generic) return 0;
   if (!col_fastgen_supported(p->f64, p->nx)) return 0;   // e.g. float64, nx = 2048: the exact kernel is used
   double kmax2 = 0, kmin2 = 1e300;
   auto scan = [&](const std::vector<double>& a) { for (double v : a) if (v > 0 && v < kmin2) kmin2 = v; };
@@ -424,8 +440,40 @@ int queue_z(rf_plan* p, void* W, hipStream_t s, double* stats_out, bool timed) {
   return 0;
 }
 
+// non-power-of-two grid: API-layout half spectrum K -> x pass into G -> y pass in G -> contiguous c2r pass into W,
+// (sum, sumsq) into stats_out
+int generic_c2r(rf_plan* p, const void* K, double* stats_out) {
+  if (int rc = ensure_g(p)) return rc;
+  const long long nzh = p->nzc + 1, lx = (long long)p->ny * nzh, ly = (long long)p->nx * nzh, lz = (long long)p->nx * p->ny;
+  hipStream_t s = p->stream;
+  RF_HIP(launch_generic_axis(p->f64, K, p->G, p->gax, lx, lx, 0, lx, p->tw_x, +1, 1.0, s));
+  RF_HIP(launch_generic_axis(p->f64, p->G, p->G, p->gay, nzh, nzh, (long long)p->ny * nzh, ly, p->tw_y, +1, 1.0, s));
+  const double scale = 1.0 / ((double)p->nx * (double)p->ny * (double)p->nz);
+  RF_HIP(launch_generic_row_c2r(p->f64, p->G, p->W, p->gaz, lz, p->tw_z, scale, p->partials, s));
+  RF_HIP(launch_reduce_partials(p->partials, p->npartials, stats_out, p->partials + 2 * p->npartials, s));
+  return 0;
+}
+
 // one realisation / transform on the plan's stream into the primary buffer
 int queue_c2r(rf_plan* p, const GenParams& gp, const void* kspace) {
+  if (p->generic) {
+    RF_HIP(hipEventRecord(p->ev[0], p->stream));
+    if (!kspace) {                                  // rows K,T,R,S into the API-layout buffer first
+      if (int rc = ensure_k(p)) return rc;
+      RF_HIP(launch_gen_kspace(p->f64, p->K, gp, p->stream));
+      p->k_valid = true;
+      p->aux_valid = false;
+      kspace = p->K;
+    }
+    if (int rc = generic_c2r(p, kspace, p->stats)) return rc;
+    RF_HIP(hipEventRecord(p->ev[4], p->stream));
+    p->timed = false;                               // no per-kernel events on this path
+    p->cur = p->W;
+    p->stats_slot = 0;
+    p->real_valid = true;
+    p->stats_valid = true;
+    return 0;
+  }
   if (p->timed) RF_HIP(hipEventRecord(p->ev[0], p->stream));
   if (int rc = queue_xy(p, gp, kspace, p->W, p->stream, p->timed)) return rc;
   if (p->replicate && p->nranks > 1) {          // the local array already is this rank's x slab [nxl][ny][nz/2]
@@ -499,8 +547,11 @@ int rf_device_count(int* count) {
   return 0;
 }
 
+// 1: tiled power-of-two kernels; 2: the generic path for other even shapes (rf_generic.h); 0: not supported
 int rf_shape_supported(int nx, int ny, int nz) {
-  return shape_check(nx, ny, nz, 0, nullptr) == 0 && shape_check(nx, ny, nz, 1, nullptr) == 0;
+  if (shape_check(nx, ny, nz, 0, nullptr) == 0 && shape_check(nx, ny, nz, 1, nullptr) == 0) return 1;
+  GenericAxis a, b, c;
+  return generic_shape(nx, ny, nz, a, b, c) ? 2 : 0;
 }
 
 int rf_plan_create(rf_plan** out, int nx, int ny, int nz, int dtype, int device, int nranks, int rank) {
@@ -509,9 +560,16 @@ int rf_plan_create(rf_plan** out, int nx, int ny, int nz, int dtype, int device,
   RF_REQUIRE(dtype == RF_F32 || dtype == RF_F64, "dtype must be RF_F32 or RF_F64");
   std::string why;
   RF_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "invalid nranks/rank");
-  if (shape_check(nx, ny, nz, dtype, &why, nranks)) return fail(1, "unsupported shape: " + why);
+  GenericAxis gax, gay, gaz;
+  bool generic = false;
+  if (shape_check(nx, ny, nz, dtype, &why, nranks)) {
+    generic = nranks == 1 && generic_shape(nx, ny, nz, gax, gay, gaz);
+    if (!generic) return fail(1, "unsupported shape: " + why + (nranks == 1 ? " (and not an even shape with axes <= 2048 either)" : ""));
+  }
   RF_HIP(hipSetDevice(device));
   rf_plan* p = new rf_plan();
+  p->generic = generic;
+  if (generic) { p->gax = gax; p->gay = gay; p->gaz = gaz; }
   p->nx = nx; p->ny = ny; p->nz = nz; p->nzc = nz / 2; p->f64 = dtype; p->device = device;
   p->nranks = nranks; p->rank = rank;
   p->csize = dtype ? 16 : 8;
@@ -536,7 +594,8 @@ int rf_plan_create(rf_plan** out, int nx, int ny, int nz, int dtype, int device,
     if (!rc) rc = upload_twiddles<float>(&p->tw_z, nz);
   }
   if (rc) return cleanup(rc);
-  p->npartials = nranks > 1 ? row_c2r_tiles(dtype, p->nzc, (long long)p->nxl * ny) : row_c2r_tiles(dtype, p->nzc, (long long)nx * ny);
+  p->npartials = generic ? generic_row_blocks(dtype, (int)p->nzc, (long long)nx * ny)
+               : nranks > 1 ? row_c2r_tiles(dtype, p->nzc, (long long)p->nxl * ny) : row_c2r_tiles(dtype, p->nzc, (long long)nx * ny);
   p->stats_cap = 64;
   if ((e = hipMalloc((void**)&p->partials, (2 * p->npartials + 512) * sizeof(double))) != hipSuccess ||
       (e = hipMalloc((void**)&p->stats, 2 * p->stats_cap * sizeof(double))) != hipSuccess ||
@@ -548,7 +607,7 @@ int rf_plan_create(rf_plan** out, int nx, int ny, int nz, int dtype, int device,
     return cleanup(fail(2, std::string("hipMalloc workspace: ") + hipGetErrorString(e)));
   for (auto& ev : p->ev)
     if ((e = hipEventCreate(&ev)) != hipSuccess) return cleanup(fail(2, std::string("hipEventCreate: ") + hipGetErrorString(e)));
-  {  // function attributes (dynamic LDS above 64 KB) are set here, never inside a graph capture
+  if (!generic) {  // function attributes (dynamic LDS above 64 KB) are set here, never inside a graph capture
     GenParams gp0; memset(&gp0, 0, sizeof(gp0)); gp0.nx = nx; gp0.ny = ny; gp0.nz = nz;
     const long long nzc = p->nzc, nzl = p->nzl;
     const ColGeom gx{(long long)ny * nzl, 0, (long long)ny * nzl}, gy{nzl, (long long)ny * nzl, nzl};
@@ -573,12 +632,19 @@ int rf_plan_create_c2c(rf_plan** out, int nx, int ny, int nz, int dtype, int dev
   RF_REQUIRE(out != nullptr, "plan pointer is null");
   *out = nullptr;
   RF_REQUIRE(dtype == RF_F32 || dtype == RF_F64, "dtype must be RF_F32 or RF_F64");
-  if (!col_size_supported(nx) || !col_size_supported(ny) || !rowc_size_supported(nz))
-    return fail(1, "unsupported shape for a c2c plan: nx, ny, nz must be powers of two in [8, 2048]");
-  const int tcx = col_tile_cols(dtype, nx), tcy = col_tile_cols(dtype, ny);
-  if (((long long)ny * nz) % tcx || ((long long)nx * nz) % tcy) return fail(1, "unsupported shape for a c2c plan: too few columns for a tile");
+  bool generic = !col_size_supported(nx) || !col_size_supported(ny) || !rowc_size_supported(nz);
+  if (!generic) {
+    const int tcx = col_tile_cols(dtype, nx), tcy = col_tile_cols(dtype, ny);
+    generic = ((long long)ny * nz) % tcx || ((long long)nx * nz) % tcy;      // too few columns for a tile
+  }
+  GenericAxis gax, gay, gaz;
+  if (generic && !(nx >= 2 && ny >= 2 && nz >= 2 && !(nx & 1) && !(ny & 1) && !(nz & 1) && generic_factor(nx, gax) &&
+                   generic_factor(ny, gay) && generic_factor(nz, gaz)))
+    return fail(1, "unsupported shape for a c2c plan: nx, ny, nz must be even and at most 2048");
   RF_HIP(hipSetDevice(device));
   rf_plan* p = new rf_plan();
+  p->generic = generic;
+  if (generic) { p->gax = gax; p->gay = gay; p->gaz = gaz; }
   p->nx = nx; p->ny = ny; p->nz = nz; p->nzc = nz / 2; p->f64 = dtype; p->device = device;
   p->nranks = 1; p->rank = 0; p->csize = dtype ? 16 : 8; p->nxl = nx; p->nzl = p->nzc; p->kz0 = 0;
   p->unpacked = true;
@@ -597,7 +663,7 @@ int rf_plan_create_c2c(rf_plan** out, int nx, int ny, int nz, int dtype, int dev
   for (auto& ev : p->ev)
     if ((e = hipEventCreate(&ev)) != hipSuccess) return cleanup(fail(2, std::string("hipEventCreate: ") + hipGetErrorString(e)));
   const ColGeom gx{(long long)ny * nz, 0, (long long)ny * nz}, gy{nz, (long long)ny * nz, nz};
-  for (int dir = -1; dir <= 1; dir += 2)
+  for (int dir = -1; dir <= 1 && !generic; dir += 2)
     if ((e = launch_row_c2c(dtype, nz, dir, p->W, (long long)nx * ny, 1.0, p->tw_z, p->stream, true)) != hipSuccess ||
         (e = launch_col_plain(dtype, ny, dir, p->W, gy, (long long)nx * nz, p->tw_y, p->stream, true)) != hipSuccess ||
         (e = launch_col_plain(dtype, nx, dir, p->W, gx, (long long)ny * nz, p->tw_x, p->stream, true)) != hipSuccess)
@@ -634,9 +700,16 @@ int rf_execute_c2c(rf_plan* p, int direction) {
   const ColGeom gx{(long long)p->ny * nz, 0, (long long)p->ny * nz}, gy{nz, (long long)p->ny * nz, nz};
   const double scale = direction > 0 ? 1.0 / ((double)p->nx * (double)p->ny * (double)p->nz) : 1.0;
   RF_HIP(hipEventRecord(p->ev[0], p->stream));
-  RF_HIP(launch_col_plain(p->f64, p->nx, direction, p->W, gx, (long long)p->ny * nz, p->tw_x, p->stream));
-  RF_HIP(launch_col_plain(p->f64, p->ny, direction, p->W, gy, (long long)p->nx * nz, p->tw_y, p->stream));
-  RF_HIP(launch_row_c2c(p->f64, (int)nz, direction, p->W, (long long)p->nx * p->ny, scale, p->tw_z, p->stream));
+  if (p->generic) {
+    const long long lx = (long long)p->ny * nz, ly = (long long)p->nx * nz, lz = (long long)p->nx * p->ny;
+    RF_HIP(launch_generic_axis(p->f64, p->W, p->W, p->gax, lx, lx, 0, lx, p->tw_x, direction, 1.0, p->stream));
+    RF_HIP(launch_generic_axis(p->f64, p->W, p->W, p->gay, nz, nz, (long long)p->ny * nz, ly, p->tw_y, direction, 1.0, p->stream));
+    RF_HIP(launch_generic_axis(p->f64, p->W, p->W, p->gaz, 1, 1, nz, lz, p->tw_z, direction, scale, p->stream));
+  } else {
+    RF_HIP(launch_col_plain(p->f64, p->nx, direction, p->W, gx, (long long)p->ny * nz, p->tw_x, p->stream));
+    RF_HIP(launch_col_plain(p->f64, p->ny, direction, p->W, gy, (long long)p->nx * nz, p->tw_y, p->stream));
+    RF_HIP(launch_row_c2c(p->f64, (int)nz, direction, p->W, (long long)p->nx * p->ny, scale, p->tw_z, p->stream));
+  }
   RF_HIP(hipEventRecord(p->ev[4], p->stream));
   p->timed = false;
   return 0;
@@ -650,7 +723,7 @@ int rf_plan_destroy(rf_plan* p) {
   if (p->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(p->comm);
   if (p->comm_stream) { (void)hipStreamSynchronize(p->comm_stream); (void)hipStreamDestroy(p->comm_stream); }
   for (auto& e : p->pev) if (e) (void)hipEventDestroy(e);
-  void* bufs[] = {p->W, p->R, p->W2, p->R2, p->K, p->P, p->tw_x, p->tw_y, p->tw_z, p->kx2, p->ky2, p->kz2, p->xt, p->st, p->sl, p->bin,
+  void* bufs[] = {p->W, p->R, p->W2, p->R2, p->K, p->P, p->G, p->tw_x, p->tw_y, p->tw_z, p->kx2, p->ky2, p->kz2, p->xt, p->st, p->sl, p->bin,
                   p->noise, p->mt_pos, p->mt_npos_dev, p->mt_states, p->mt_counts, p->mt_offsets, p->partials, p->stats, p->seeds_dev, p->ztab, p->frec, p->coll_scratch};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -667,7 +740,7 @@ int rf_plan_destroy(rf_plan* p) {
 
 int rf_plan_nbytes(rf_plan* p, size_t* nbytes) {
   RF_REQUIRE(p && nbytes, "null argument");
-  *nbytes = p->w_bytes * (1 + (p->R ? 1 : 0) + (p->W2 ? 2 : 0)) + (p->K ? p->k_bytes : 0) + (p->P ? p->k_bytes : 0);
+  *nbytes = p->w_bytes * (1 + (p->R ? 1 : 0) + (p->W2 ? 2 : 0)) + (p->K ? p->k_bytes : 0) + (p->P ? p->k_bytes : 0) + (p->G ? p->k_bytes : 0);
   return 0;
 }
 
@@ -685,6 +758,7 @@ int rf_plan_set_flag(rf_plan* p, int flag, int value) {
   }
   if (flag == RF_FLAG_FORCE_SLAB_PATH) {
     RF_REQUIRE(p->nranks == 1, "RF_FLAG_FORCE_SLAB_PATH is for single-rank plans");
+    RF_REQUIRE(!p->generic, "RF_FLAG_FORCE_SLAB_PATH needs power-of-two axes");
     if (value && !p->R) RF_HIP(hipMalloc(&p->R, p->w_bytes));
     p->force_slab = value != 0;
     drop_graphs(p);
@@ -781,6 +855,17 @@ int rf_execute_r2c(rf_plan* p) {
   const long long nzc = p->nzc;
   const ColGeom gx{(long long)p->ny * nzc, 0, (long long)p->ny * nzc}, gy{nzc, (long long)p->ny * nzc, nzc};
   RF_HIP(hipEventRecord(p->ev[0], p->stream));
+  if (p->generic) {            // rows -> half spectrum in K, then the y and x forward passes in place
+    const long long nzh = nzc + 1, lx = (long long)p->ny * nzh, ly = (long long)p->nx * nzh;
+    RF_HIP(launch_generic_row_r2c(p->f64, p->W, p->K, p->gaz, (long long)p->nx * p->ny, p->tw_z, p->stream));
+    RF_HIP(launch_generic_axis(p->f64, p->K, p->K, p->gay, nzh, nzh, (long long)p->ny * nzh, ly, p->tw_y, -1, 1.0, p->stream));
+    RF_HIP(launch_generic_axis(p->f64, p->K, p->K, p->gax, lx, lx, 0, lx, p->tw_x, -1, 1.0, p->stream));
+    RF_HIP(hipEventRecord(p->ev[4], p->stream));
+    p->timed = false;
+    p->k_valid = true;          // the real field in W is untouched on this path
+    p->aux_valid = false;
+    return 0;
+  }
   RF_HIP(launch_row_r2c(p->f64, (int)nzc, p->W, (long long)p->nx * p->ny, p->tw_z, p->stream));     // z, in place
   RF_HIP(launch_col_plain(p->f64, p->ny, -1, p->W, gy, (long long)p->nx * nzc, p->tw_y, p->stream));   // y forward
   RF_HIP(launch_col_plain(p->f64, p->nx, -1, p->W, gx, (long long)p->ny * nzc, p->tw_x, p->stream));   // x forward
@@ -820,7 +905,7 @@ int rf_realise_potential(rf_plan* p, uint64_t seed, int mode, const double* nois
   RF_REQUIRE(p->have_kgrid && p->have_power, "rf_set_kgrid and rf_set_power must be called first");
   RF_REQUIRE(mode == RF_NOISE_NATIVE || mode == RF_NOISE_EXTERNAL || mode == RF_NOISE_RESIDENT, "invalid noise mode");
   RF_HIP(hipSetDevice(p->device));
-  const bool fused = mode == RF_NOISE_NATIVE && p->have_fast && !p->exact_gen && !p->f64 && !p->force_slab;
+  const bool fused = mode == RF_NOISE_NATIVE && p->have_fast && !p->exact_gen && !p->f64 && !p->force_slab && !p->generic;
   if (!fused) {
     if (int rc = rf_generate(p, seed, mode, noise_host)) return rc;
     if (int rc = rf_save_potential(p)) return rc;
@@ -886,7 +971,7 @@ static int batch_prepare(rf_plan* p, int n) {
 int rf_realise_batch_prepare(rf_plan* p, int n) {
   RF_REQUIRE(p, "null plan");
   RF_REQUIRE(!p->unpacked, "this call does not apply to an unpacked c2c plan");
-  if (p->nranks > 1 || p->force_slab) return 0;     // slab batches are not graph-captured
+  if (p->nranks > 1 || p->force_slab || p->generic) return 0;     // slab / generic batches are not graph-captured
   return batch_prepare(p, n);
 }
 
@@ -898,6 +983,37 @@ int rf_realise_batch(rf_plan* p, const uint64_t* seeds, int n, double* rms_out) 
     RF_REQUIRE(p->have_kgrid && p->have_power, "rf_set_kgrid and rf_set_power must be called first");
     RF_HIP(hipSetDevice(p->device));
     if (int rc = slab_batch(p, seeds, n)) return rc;
+    if (rms_out) {
+      std::vector<double> st(2 * (size_t)n);
+      RF_HIP(hipMemcpyAsync(st.data(), p->stats, st.size() * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+      RF_HIP(hipStreamSynchronize(p->stream));
+      const double cnt = (double)p->nx * p->ny * p->nz;
+      for (int i = 0; i < n; ++i) {
+        const double m = st[2 * i] / cnt, v = st[2 * i + 1] / cnt - m * m;
+        rms_out[i] = v > 0 ? std::sqrt(v) : 0.0;
+      }
+    }
+    return 0;
+  }
+  if (p->generic) {             // no fused generation, no graph: realisations one after the other
+    RF_REQUIRE(p->have_kgrid && p->have_power, "rf_set_kgrid and rf_set_power must be called first");
+    RF_HIP(hipSetDevice(p->device));
+    if (p->stats_cap < n) {
+      RF_HIP(hipStreamSynchronize(p->stream));
+      if (p->stats) RF_HIP(hipFree(p->stats));
+      p->stats = nullptr;
+      RF_HIP(hipMalloc((void**)&p->stats, 2 * (size_t)(n + 64) * sizeof(double)));
+      p->stats_cap = n + 64;
+    }
+    if (int rc = ensure_k(p)) return rc;
+    RF_HIP(hipEventRecord(p->ev[0], p->stream));
+    for (int i = 0; i < n; ++i) {
+      RF_HIP(launch_gen_kspace(p->f64, p->K, make_gen(p, seeds[i], RF_NOISE_NATIVE, false), p->stream));
+      if (int rc = generic_c2r(p, p->K, p->stats + 2 * i)) return rc;
+    }
+    RF_HIP(hipEventRecord(p->ev[4], p->stream));
+    p->cur = p->W; p->timed = false; p->real_valid = true; p->stats_valid = true; p->k_valid = true; p->aux_valid = false;
+    p->stats_slot = n - 1;
     if (rms_out) {
       std::vector<double> st(2 * (size_t)n);
       RF_HIP(hipMemcpyAsync(st.data(), p->stats, st.size() * sizeof(double), hipMemcpyDeviceToHost, p->stream));

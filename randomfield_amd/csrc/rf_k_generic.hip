@@ -1,0 +1,110 @@
+// kernels of the non-power-of-two path (rf_generic.h): one workgroup per group of lines, lines staged in LDS
+#include "rf_generic.h"
+#include "rf_launch.h"
+
+namespace rf {
+namespace {
+
+struct BlockSync { __device__ void operator()() const { __syncthreads(); } };
+
+template <typename T>
+__global__ __launch_bounds__(256) void generic_axis_kernel(const cplx<T>* src, cplx<T>* dst, GenericAxis ax, long long stride,
+                                                          long long inner, long long outer, long long nlines, int TC,
+                                                          const cplx<T>* __restrict__ root, int sign, T scale) {
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  generic_axis_block<T>(src, dst, ax, stride, inner, outer, nlines, TC, root, sign, scale, reinterpret_cast<cplx<T>*>(lds_raw),
+                        (long long)blockIdx.x, (int)threadIdx.x, (int)blockDim.x, BlockSync());
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void generic_row_c2r_kernel(const cplx<T>* __restrict__ G, T* __restrict__ W, GenericAxis ax,
+                                                             long long nrows, int TR, const cplx<T>* __restrict__ root, T scale,
+                                                             double* __restrict__ partials) {
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  __shared__ double red[2 * 4];
+  double s1 = 0.0, s2 = 0.0;
+  generic_row_c2r_block<T>(G, W, ax, nrows, TR, root, scale, reinterpret_cast<cplx<T>*>(lds_raw), (long long)blockIdx.x,
+                           (int)threadIdx.x, (int)blockDim.x, BlockSync(), s1, s2);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_down(s1, off); s2 += __shfl_down(s2, off); }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) { red[2 * wave] = s1; red[2 * wave + 1] = s2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {          // fixed order: deterministic
+    double a = 0.0, b = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { a += red[2 * w]; b += red[2 * w + 1]; }
+    partials[2 * (long long)blockIdx.x] = a;
+    partials[2 * (long long)blockIdx.x + 1] = b;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void generic_row_r2c_kernel(const T* __restrict__ W, cplx<T>* __restrict__ G, GenericAxis ax,
+                                                             long long nrows, int TR, const cplx<T>* __restrict__ root) {
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  generic_row_r2c_block<T>(W, G, ax, nrows, TR, root, reinterpret_cast<cplx<T>*>(lds_raw), (long long)blockIdx.x,
+                           (int)threadIdx.x, (int)blockDim.x, BlockSync());
+}
+
+template <typename T>
+hipError_t axis_t(const void* src, void* dst, const GenericAxis& ax, long long stride, long long inner, long long outer,
+                  long long nlines, const void* root, int sign, double scale, hipStream_t s) {
+  // lines that are neighbours in memory (inner > 1) are transformed 16 at a time: 128-byte (float32) segments
+  const int tc = generic_lines_per_block(ax.n, (int)sizeof(cplx<T>), inner > 1 ? 16 : 4);
+  const long long nblk = (nlines + tc - 1) / tc;
+  if (nblk <= 0) return hipSuccess;
+  if (nblk > 0x7fffffffLL) return hipErrorInvalidValue;
+  const size_t lds = 2 * (size_t)ax.n * tc * sizeof(cplx<T>);
+  hipLaunchKernelGGL(generic_axis_kernel<T>, dim3((unsigned)nblk), dim3(256), lds, s, (const cplx<T>*)src, (cplx<T>*)dst, ax, stride,
+                     inner, outer, nlines, tc, (const cplx<T>*)root, sign, (T)scale);
+  return hipGetLastError();
+}
+
+template <typename T> int rows_per_block(int M) { return generic_lines_per_block(M, (int)sizeof(cplx<T>), 8, 49152); }   // + the reduction's static LDS
+
+}  // namespace
+
+hipError_t launch_generic_axis(int f64, const void* src, void* dst, const GenericAxis& ax, long long stride, long long inner,
+                               long long outer, long long nlines, const void* root, int sign, double scale, hipStream_t s) {
+  return f64 ? axis_t<double>(src, dst, ax, stride, inner, outer, nlines, root, sign, scale, s)
+             : axis_t<float>(src, dst, ax, stride, inner, outer, nlines, root, sign, scale, s);
+}
+
+long long generic_row_blocks(int f64, int M, long long nrows) {
+  const int tr = f64 ? rows_per_block<double>(M) : rows_per_block<float>(M);
+  return (nrows + tr - 1) / tr;
+}
+
+hipError_t launch_generic_row_c2r(int f64, const void* G, void* W, const GenericAxis& ax, long long nrows, const void* root,
+                                  double scale, double* partials, hipStream_t s) {
+  const long long nblk = generic_row_blocks(f64, ax.n, nrows);
+  if (nblk <= 0 || nblk > 0x7fffffffLL) return hipErrorInvalidValue;
+  if (f64) {
+    const int tr = rows_per_block<double>(ax.n);
+    hipLaunchKernelGGL(generic_row_c2r_kernel<double>, dim3((unsigned)nblk), dim3(256), 2 * (size_t)ax.n * tr * sizeof(cplx<double>), s,
+                       (const cplx<double>*)G, (double*)W, ax, nrows, tr, (const cplx<double>*)root, scale, partials);
+  } else {
+    const int tr = rows_per_block<float>(ax.n);
+    hipLaunchKernelGGL(generic_row_c2r_kernel<float>, dim3((unsigned)nblk), dim3(256), 2 * (size_t)ax.n * tr * sizeof(cplx<float>), s,
+                       (const cplx<float>*)G, (float*)W, ax, nrows, tr, (const cplx<float>*)root, (float)scale, partials);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_generic_row_r2c(int f64, const void* W, void* G, const GenericAxis& ax, long long nrows, const void* root,
+                                  hipStream_t s) {
+  const long long nblk = generic_row_blocks(f64, ax.n, nrows);
+  if (nblk <= 0 || nblk > 0x7fffffffLL) return hipErrorInvalidValue;
+  if (f64) {
+    const int tr = rows_per_block<double>(ax.n);
+    hipLaunchKernelGGL(generic_row_r2c_kernel<double>, dim3((unsigned)nblk), dim3(256), 2 * (size_t)ax.n * tr * sizeof(cplx<double>), s,
+                       (const double*)W, (cplx<double>*)G, ax, nrows, tr, (const cplx<double>*)root);
+  } else {
+    const int tr = rows_per_block<float>(ax.n);
+    hipLaunchKernelGGL(generic_row_r2c_kernel<float>, dim3((unsigned)nblk), dim3(256), 2 * (size_t)ax.n * tr * sizeof(cplx<float>), s,
+                       (const float*)W, (cplx<float>*)G, ax, nrows, tr, (const cplx<float>*)root);
+  }
+  return hipGetLastError();
+}
+
+}  // namespace rf

@@ -46,7 +46,7 @@ template <typename T, int VEC>
 __global__ __launch_bounds__(256) void lognormal_vec_kernel(T* __restrict__ W, long long nvec, int nz,
                                                             const double* __restrict__ a_z,
                                                             const double* __restrict__ b_z, T sigma) {
-  struct alignas(16) Vec { T v[VEC]; };
+  struct alignas(VEC * sizeof(T)) Vec { T v[VEC]; };
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
     Vec x = reinterpret_cast<const Vec*>(W)[i];
     const int iz0 = (int)((i * VEC) % nz);
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void lognormal_vec_kernel(T* __restrict__ W, l
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void affine_vec_kernel(T* __restrict__ W, long long nvec, int nz,
                                                          const double* __restrict__ mul_z, double add, int has_add) {
-  struct alignas(16) Vec { T v[VEC]; };
+  struct alignas(VEC * sizeof(T)) Vec { T v[VEC]; };
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
     Vec x = reinterpret_cast<const Vec*>(W)[i];
     const int iz0 = (int)((i * VEC) % nz);
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void lensing_kernel(const T* __restrict__ phi,
   if (row >= nrows) return;                         // the whole wave leaves together
   const T* in = phi + row * (long long)nz;
   T* out = psi + row * (long long)nz;
-  const bool vec = nz >= 64 * VW;                   // nz is a power of two: then a multiple of the segment length
+  const bool vec = nz % (64 * VW) == 0;             // whole segments, 16-byte aligned rows; anything else: guarded scalar accesses
   const double b0 = (double)in[i_min], a0 = cot[i_min] * b0;
   const double b1 = i_min + 1 < nz ? (double)in[i_min + 1] : 0.0, a1 = i_min + 1 < nz ? cot[i_min + 1] * b1 : 0.0;
   double cEa = 0, cOa = 0, cEb = 0, cOb = 0;        // sums over all earlier segments
@@ -264,9 +264,12 @@ hipError_t launch_lognormal(int f64, void* W, long long nrows, int nz, const dou
   if (f64) {
     const long long nvec = total / 2;
     hipLaunchKernelGGL((lognormal_vec_kernel<double, 2>), dim3(grid_for(nvec, 256)), dim3(256), 0, s, (double*)W, nvec, nz, a_z, b_z, sigma);
-  } else {
+  } else if (nz % 4 == 0) {
     const long long nvec = total / 4;
     hipLaunchKernelGGL((lognormal_vec_kernel<float, 4>), dim3(grid_for(nvec, 256)), dim3(256), 0, s, (float*)W, nvec, nz, a_z, b_z, (float)sigma);
+  } else {                       // nz = 2 (mod 4) (non-power-of-two grids): a vector must not straddle two rows
+    const long long nvec = total / 2;
+    hipLaunchKernelGGL((lognormal_vec_kernel<float, 2>), dim3(grid_for(nvec, 256)), dim3(256), 0, s, (float*)W, nvec, nz, a_z, b_z, (float)sigma);
   }
   return hipGetLastError();
 }
@@ -277,9 +280,12 @@ hipError_t launch_affine_z(int f64, void* W, long long nrows, int nz, const doub
   if (f64) {
     const long long nvec = total / 2;
     hipLaunchKernelGGL((affine_vec_kernel<double, 2>), dim3(grid_for(nvec, 256)), dim3(256), 0, s, (double*)W, nvec, nz, mul_z, add, has_add);
-  } else {
+  } else if (nz % 4 == 0) {
     const long long nvec = total / 4;
     hipLaunchKernelGGL((affine_vec_kernel<float, 4>), dim3(grid_for(nvec, 256)), dim3(256), 0, s, (float*)W, nvec, nz, mul_z, add, has_add);
+  } else {
+    const long long nvec = total / 2;
+    hipLaunchKernelGGL((affine_vec_kernel<float, 2>), dim3(grid_for(nvec, 256)), dim3(256), 0, s, (float*)W, nvec, nz, mul_z, add, has_add);
   }
   return hipGetLastError();
 }

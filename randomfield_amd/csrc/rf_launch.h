@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <atomic>
 #include "rf_configs.h"
+#include "rf_generic.h"
 
 namespace rf {
 
@@ -99,5 +100,17 @@ hipError_t launch_mt_polar(bool fill, const uint32_t* states, int nseg, int bloc
                            unsigned long long* counts, const unsigned long long* offsets, double* noise,
                            unsigned long long ncells, hipStream_t s);
 hipError_t launch_mt_scan(const unsigned long long* counts, unsigned long long* offsets, int n, hipStream_t s);
+
+// non-power-of-two grids (rf_generic.h, rf_k_generic.hip); root = exp(2 pi i t / n) tables as made by make_twiddles
+// complex pass along one axis: line l starts at (l / inner) * outer + l % inner, elements `stride` apart; src == dst allowed
+hipError_t launch_generic_axis(int f64, const void* src, void* dst, const GenericAxis& ax, long long stride, long long inner,
+                               long long outer, long long nlines, const void* root, int sign, double scale, hipStream_t s);
+// rows of nz/2+1 half-spectrum bins (G) <-> dense rows of nz reals (W); ax factors nz/2, root_nz has nz entries;
+// the c2r pass leaves (sum, sumsq) of block b in partials[2b], partials[2b+1]
+long long generic_row_blocks(int f64, int M, long long nrows);
+hipError_t launch_generic_row_c2r(int f64, const void* G, void* W, const GenericAxis& ax, long long nrows, const void* root_nz,
+                                  double scale, double* partials, hipStream_t s);
+hipError_t launch_generic_row_r2c(int f64, const void* W, void* G, const GenericAxis& ax, long long nrows, const void* root_nz,
+                                  hipStream_t s);
 
 }  // namespace rf

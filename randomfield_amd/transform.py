@@ -17,8 +17,10 @@ Backends.  The reference switches between pyFFTW and ``numpy.fft`` on the
   GPU is visible or the shape is not supported, the constructor raises
   ``RuntimeError`` -- it never silently computes on the CPU.
 * ``backend='numpy'`` (explicit opt-in; or ``RANDOMFIELD_BACKEND=numpy``): the
-  reference's own ``numpy.fft`` fallback, kept for shapes the HIP kernels do not
-  cover (non power-of-two axes such as (4, 6, 8)) and for hosts without a GPU.
+  reference's own ``numpy.fft`` fallback, kept for hosts without a GPU and for shapes
+  the HIP kernels do not cover (an axis longer than 2048).  Power-of-two axes run on
+  the tiled kernels; any other even shape -- the reference's own test shapes (4, 6, 8)
+  and (40, 60, 80) among them -- on the generic mixed-radix kernels.
 
 ``use_pyfftw`` is accepted for signature compatibility and recorded, but pyFFTW
 is never used.
@@ -31,10 +33,6 @@ import numpy as np
 
 __all__ = ["allocate", "expanded_shape", "scalar_type", "complex_type", "is_hermitian", "symmetrize", "Plan",
            "resolve_backend"]
-
-
-def _is_pow2(n):
-    return n > 0 and (n & (n - 1)) == 0
 
 
 def resolve_backend(backend=None):
@@ -276,16 +274,12 @@ class Plan(object):
             cdtype = lay.dtype_in if (inverse or not packed) else lay.dtype_out
             if np.dtype(cdtype) not in (np.dtype(np.complex64), np.dtype(np.complex128)):
                 raise RuntimeError("hip backend supports complex64 / complex128 only: {0}.".format(cdtype))
-            if packed:
-                if not _hip.shape_supported(nx, ny, nz):
-                    raise RuntimeError(
-                        "hip backend: shape {0} is not supported (power-of-two axes, nx, ny in 8..2048, nz in "
-                        "16..2048); use backend='numpy' explicitly for this shape.".format(tuple(shape)))
-            elif not (_is_pow2(nx) and _is_pow2(ny) and _is_pow2(nz) and 8 <= nx <= 2048 and 8 <= ny <= 2048
-                      and 8 <= nz <= 2048):
+            # power-of-two axes (8..2048; nz from 16) run on the tiled kernels, any other even shape with axes up to
+            # 2048 on the generic mixed-radix kernels (csrc/rf_generic.h); the library decides and refuses the rest
+            if max(nx, ny, nz) > 2048 or (packed and not _hip.shape_supported(nx, ny, nz)):
                 raise RuntimeError(
-                    "hip backend: unpacked shape {0} is not supported (power-of-two axes in 8..2048); use "
-                    "backend='numpy' explicitly for this shape.".format(tuple(shape)))
+                    "hip backend: shape {0} is not supported (even axes up to 2048); use backend='numpy' explicitly "
+                    "for this shape.".format(tuple(shape)))
             # a reverse plan that shares our memory also shares our device plan (one device buffer, as the
             # reference's pair of plans shares one host buffer)
             self.device = _device if _device is not None else _hip.DevicePlan(nx, ny, nz, cdtype, unpacked=not packed)

@@ -139,3 +139,37 @@ def fast_sigma(log10k, sigma, xlo, xhi, k2):
            exact.ctypes.data)
     assert nb > 0, nb
     return fast, exact, nb
+
+
+# ---- the generic (non-power-of-two) kernels of csrc/rf_generic.h ----------------------------------
+def generic_c2r(kspace):
+    nx, ny, nzh = kspace.shape
+    nz = 2 * (nzh - 1)
+    rt = np.float32 if kspace.dtype == np.complex64 else np.float64
+    out = np.empty((nx, ny, nz), rt)
+    s1, s2 = ctypes.c_double(), ctypes.c_double()
+    ks = np.ascontiguousarray(kspace)
+    rc = lib().emu_generic_c2r(int(kspace.dtype == np.complex128), nx, ny, nz, ks.ctypes.data_as(ctypes.c_void_p),
+                               out.ctypes.data_as(ctypes.c_void_p), ctypes.byref(s1), ctypes.byref(s2))
+    assert rc == 0, rc
+    return out, s1.value, s2.value
+
+
+def generic_r2c(field):
+    nx, ny, nz = field.shape
+    ct = np.complex64 if field.dtype == np.float32 else np.complex128
+    out = np.empty((nx, ny, nz // 2 + 1), ct)
+    f = np.ascontiguousarray(field)
+    rc = lib().emu_generic_r2c(int(ct == np.complex128), nx, ny, nz, f.ctypes.data_as(ctypes.c_void_p),
+                               out.ctypes.data_as(ctypes.c_void_p))
+    assert rc == 0, rc
+    return out
+
+
+def generic_c2c(data, inverse):
+    out = np.ascontiguousarray(data).copy()
+    nx, ny, nz = out.shape
+    rc = lib().emu_generic_c2c(int(out.dtype == np.complex128), nx, ny, nz, 1 if inverse else -1,
+                               out.ctypes.data_as(ctypes.c_void_p))
+    assert rc == 0, rc
+    return out

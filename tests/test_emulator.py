@@ -208,3 +208,41 @@ def test_fast_sigma_lookup_error_bound(default_power):
         assert nb <= 512                                        # the records fit the kernel's LDS table
         rel = np.abs(fast - exact) / np.maximum(np.abs(exact), 1e-300)
         assert np.max(rel) <= 1e-6, "fast sigma lookup off by %.3g relative" % np.max(rel)
+
+
+GENERIC_SHAPES = [(4, 6, 8), (6, 4, 12), (40, 60, 80), (10, 14, 22), (2, 2, 2), (12, 18, 6), (26, 34, 46), (24, 8, 16)]
+
+
+@pytest.mark.parametrize("shape", GENERIC_SHAPES)
+def test_generic_mixed_radix_transforms_against_numpy(shape):
+    """The non-power-of-two path (csrc/rf_generic.h): the block functions the generic kernels run, executed by one
+    "thread" per block.  c2r = np.fft.irfftn incl. its treatment of non-Hermitian DC / Nyquist bins (the reference's
+    backend, transform.py:314), r2c = np.fft.rfftn, c2c = fftn / ifftn; line and row counts that do not divide the
+    block sizes are part of the case."""
+    rng = np.random.RandomState(5)
+    nx, ny, nz = shape
+    for ct, rt, tol in ((np.complex64, np.float32, 3e-6), (np.complex128, np.float64, 3e-14)):
+        ks = (rng.normal(size=(nx, ny, nz // 2 + 1)) + 1j * rng.normal(size=(nx, ny, nz // 2 + 1))).astype(ct)
+        out, s1, s2 = emu_util.generic_c2r(ks)
+        ref = np.fft.irfftn(ks.astype(np.complex128), s=shape, axes=(0, 1, 2))
+        assert np.max(np.abs(out - ref)) <= tol * ref.std()
+        assert abs(s1 - ref.sum()) <= 10 * tol * ref.std() * ref.size and abs(s2 - (ref ** 2).sum()) <= 10 * tol * (ref ** 2).sum()
+        f = rng.normal(size=shape).astype(rt)
+        spec = emu_util.generic_r2c(f)
+        ref = np.fft.rfftn(f.astype(np.float64))
+        assert np.max(np.abs(spec - ref)) <= tol * np.abs(ref).std() * 4
+        a = (rng.normal(size=shape) + 1j * rng.normal(size=shape)).astype(ct)
+        for inverse, fn in ((False, np.fft.fftn), (True, np.fft.ifftn)):
+            ref = fn(a.astype(np.complex128))
+            assert np.max(np.abs(emu_util.generic_c2c(a, inverse) - ref)) <= tol * np.abs(ref).std() * 4
+
+
+@pytest.mark.parametrize("name", ["stages_4x6x8_c64.npz", "stages_6x4x12_c64.npz", "stages_4x6x8_c128.npz"])
+def test_generic_c2r_reproduces_reference_fields(name):
+    """The reference's own k-space -> delta(x) pairs at its test shapes (tests/test_transform.py:11)."""
+    g = golden(name)
+    out, s1, s2 = emu_util.generic_c2r(g["kspace"])
+    tol = 1e-6 if g["kspace"].dtype == np.complex64 else 1e-14
+    assert np.max(np.abs(out - g["delta"])) <= tol * float(g["rms"])
+    n = out.size
+    assert abs(np.sqrt(s2 / n - (s1 / n) ** 2) - float(g["rms"])) <= 10 * tol * float(g["rms"])

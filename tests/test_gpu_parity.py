@@ -43,7 +43,9 @@ def make_plan(hip, shape, dtype, k, Pk, spacing=SPACING):
 
 
 STAGES = ["stages_16x16x16_c64.npz", "stages_32x32x32_c64.npz", "stages_16x32x64_c64.npz",
-          "stages_16x16x16_c128.npz", "stages_32x32x32_c128.npz"]
+          "stages_16x16x16_c128.npz", "stages_32x32x32_c128.npz",
+          # the reference's own test shapes (tests/test_transform.py:11): non-power-of-two axes, generic kernels
+          "stages_4x6x8_c64.npz", "stages_6x4x12_c64.npz", "stages_4x6x8_c128.npz"]
 
 
 @pytest.mark.parametrize("name", STAGES)
@@ -350,7 +352,9 @@ def test_plan_api_hip_backend(hip):
 
 def test_errors_are_loud(hip, dpower):
     with pytest.raises(RuntimeError):
-        hip.DevicePlan(4, 6, 8)                                      # unsupported shape: no silent CPU path
+        hip.DevicePlan(4, 6, 7)                                      # unsupported shape (odd axis): no silent CPU path
+    with pytest.raises(RuntimeError):
+        hip.DevicePlan(4096, 16, 16)                                 # axis longer than any kernel covers
     plan = hip.DevicePlan(16, 16, 16)
     with pytest.raises(RuntimeError):
         plan.realise(seed=1)                                         # tables not set
@@ -363,7 +367,7 @@ def test_errors_are_loud(hip, dpower):
     plan.close()
     from randomfield_amd.transform import Plan
     with pytest.raises(RuntimeError):
-        Plan(shape=(4, 6, 8), dtype_in=np.complex64)                 # hip backend refuses, does not fall back
+        Plan(shape=(4096, 16, 16), dtype_in=np.complex64)            # hip backend refuses, does not fall back
 
 
 def _virtual_rank_field(hip, shape, dtype, k, Pk, nranks, seed=None, noise=None, exact=False):
@@ -936,3 +940,116 @@ def test_reference_rng_array_and_none_seeds(hip, dpower):
     with pytest.raises(ValueError):
         gen.generate_delta_field(seed=2 ** 32)
     gen.plan_c2r.device.close()
+
+
+# ---- non-power-of-two grids: the generic mixed-radix kernels (csrc/rf_generic.h) ---------------------------------
+# (the generation rows need nz % 4 == 0 -- transform.py:53-56 wants an odd packed last axis; plans take any even nz)
+GENERIC_SHAPES = [(40, 60, 80), (10, 14, 24), (12, 18, 8), (26, 34, 44), (24, 8, 16), (2, 2, 4), (6, 1000, 20)]
+
+
+@pytest.mark.parametrize("shape", GENERIC_SHAPES)
+def test_generic_shapes_against_oracle(hip, dpower, shape):
+    """Any even shape runs on the GPU (transform.py:172-177 asks for nothing more; (40, 60, 80) is the shape of the
+    reference's tests/test_random.py:12-22): same-noise field, rms, k-space, forward transform and potential
+    against the oracle / numpy, float32 and float64."""
+    nx, ny, nz = shape
+    k, Pk = dpower
+    spacing = 2.5 if max(shape) <= 100 else 0.5                  # keep the grid's k range inside the table
+    noise = cpu_ref.reference_noise(11, nx * ny * (nz // 2 + 1))
+    for dtype, tol in ((np.complex64, TOL_F32), (np.complex128, TOL_F64)):
+        ref, rms = cpu_ref.generate_delta_field(nx, ny, nz, spacing, k, Pk, noise=noise, dtype=dtype, double_fft=True)
+        plan = make_plan(hip, shape, dtype, k, Pk, spacing=spacing)
+        plan.realise(noise=noise)
+        d = plan.download_real()
+        assert d.shape == shape and np.max(np.abs(d - ref)) <= tol * rms
+        mean, std = plan.moments()
+        assert abs(std - rms) <= tol * rms
+        ks = plan.download_k()                                   # the generic path materialises k space
+        kref = cpu_ref.generate_kspace(nx, ny, nz, spacing, k, Pk, noise=noise, dtype=dtype)
+        assert np.max(np.abs(ks - kref)) <= (5e-7 if dtype == np.complex64 else 1e-14) * np.max(np.abs(kref))
+        assert cpu_ref.is_hermitian_packed(ks, rtol=0, atol=0)
+        # forward transform of the field: back to the same k space (np.fft.rfftn normalisation)
+        plan.execute_r2c()
+        back = plan.download_k()
+        assert np.max(np.abs(back - kref)) <= 20 * tol * np.max(np.abs(kref))
+        # native generator: deterministic, right amplitude (statistics need cells: skip the tiny grids)
+        plan.realise(seed=3)
+        a = plan.download_real()
+        plan.realise(seed=3)
+        assert np.array_equal(a, plan.download_real())
+        if nx * ny * nz >= 4000:
+            assert abs(plan.moments()[1] / rms - 1) < 0.5
+        rms_b = plan.realise_batch([3, 4, 5])
+        assert abs(rms_b[0] - float(np.std(a.astype(np.float64)))) <= 10 * tol * rms and len(set(rms_b)) == 3
+        plan.close()
+
+
+def test_generic_shape_generator_api(hip, dpower):
+    """The drop-in Generator at the reference's (40, 60, 80): default call (save_potential=True, the reference's
+    stream replayed on the GPU), Newtonian potential, density and lensing against this repo's numpy backend, which
+    is pinned to the reference on the CPU."""
+    from randomfield_amd import Generator
+    nx, ny, nz = 40, 60, 80
+    z = np.linspace(0, 0.1, nz)
+    kw = dict(growth_function=np.exp(-z), mean_matter_density=1 + z, redshifts=z,
+              transverse_distance=np.arange(nz) * 2.5)
+    dev = Generator(nx, ny, nz, 2.5, **kw)
+    cpu = Generator(nx, ny, nz, 2.5, backend="numpy", **kw)
+    a = dev.generate_delta_field(seed=21).copy()
+    b = cpu.generate_delta_field(seed=21).copy()
+    rms = float(cpu.delta_field_rms)
+    assert a.shape == (nx, ny, nz) and np.max(np.abs(a - b)) <= TOL_F32 * rms
+    assert abs(float(dev.delta_field_rms) - rms) <= TOL_F32 * rms
+    assert np.max(np.abs(dev.potential.download() - cpu.potential)) <= 1e-6 * np.max(np.abs(cpu.potential))
+    pa = dev.calculate_newtonian_potential(scale=-1.5).copy()
+    pb = cpu.calculate_newtonian_potential(scale=-1.5).copy()
+    assert np.max(np.abs(pa - pb)) <= TOL_F32 * pb.std()
+    la, lb = dev.calculate_lensing_potential(), cpu.calculate_lensing_potential()
+    assert np.max(np.abs(la - lb)) <= 2e-5 * np.abs(lb).max()
+    dev.generate_delta_field(seed=21, save_potential=False)
+    cpu.generate_delta_field(seed=21, save_potential=False)
+    ra, rb = dev.convert_delta_to_density(), cpu.convert_delta_to_density()
+    assert np.max(np.abs(ra - rb) / rb) <= 1e-4
+
+
+def test_generic_shape_plans(hip):
+    """transform.Plan on the hip backend at the reference's test shape (4, 6, 8) and at (40, 60, 80): packed c2r / r2c
+    round trip and unpacked c2c, the cases of tests/test_transform.py:150-300."""
+    from randomfield_amd.transform import Plan, symmetrize
+    from randomfield_amd import cosmotools
+    rng = np.random.RandomState(8)
+    # nz = 2 (mod 4): the z-table kernels must not let a vector straddle two rows (rows L of a (10, 14, 22) plan)
+    dp = hip.DevicePlan(10, 14, 22)
+    f = rng.normal(size=(10, 14, 22)).astype(np.float32)
+    z = np.linspace(0, 0.1, 22)
+    dp.upload_real(f, padded=False)
+    dp.lognormal(*cosmotools.lognormal_tables(np.exp(-z), 1.5, 22), 1.5)
+    ref = cpu_ref.lognormal(f.copy(), np.exp(-z), sigma=np.float32(1.5))
+    assert np.max(np.abs(dp.download_real() - ref) / ref) <= 1e-5
+    dp.upload_real(f, padded=False)
+    dp.affine_z(np.exp(-z), 1.0)
+    dp.scale_z(1 + z)
+    ref = (f.astype(np.float64) * np.exp(-z) + 1) * (1 + z)
+    assert np.max(np.abs(dp.download_real() - ref)) <= 1e-5 * np.abs(ref).max()
+    dp.close()
+    for shape in ((4, 6, 8), (40, 60, 80), (10, 14, 22), (12, 18, 6)):
+        nx, ny, nz = shape
+        for ct, tol in ((np.complex64, 2e-6), (np.complex128, 1e-14)):
+            plan = Plan(shape=shape, dtype_in=ct)
+            assert plan.backend == "hip"
+            rt = plan.data_out.dtype
+            plan.data_in.view(rt).reshape(nx, ny, nz + 2)[:] = rng.normal(size=(nx, ny, nz + 2))
+            ks = plan.data_in.copy()
+            out = plan.execute().copy()
+            ref = np.fft.irfftn(ks.astype(np.complex128), s=shape, axes=(0, 1, 2))
+            assert np.max(np.abs(out - ref)) <= 10 * tol * ref.std()
+            rev = plan.create_reverse_plan()
+            back = rev.execute()
+            kref = np.fft.rfftn(ref)
+            assert np.max(np.abs(back - kref)) <= 20 * tol * np.abs(kref).std()
+            for inverse, fn in ((True, np.fft.ifftn), (False, np.fft.fftn)):
+                c = Plan(shape=shape, dtype_in=ct, packed=False, inverse=inverse)
+                c.data_in[:] = rng.normal(size=shape) + 1j * rng.normal(size=shape)
+                src = c.data_in.copy()
+                ref = fn(src.astype(np.complex128))
+                assert np.max(np.abs(c.execute() - ref)) <= 10 * tol * np.abs(ref).std()
