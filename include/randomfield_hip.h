@@ -180,6 +180,10 @@ int rf_comm_allreduce_f64(rf_plan* plan, double* inout, int n, int op);
  * rf_slab_exchange_local performs the all-to-all between n "virtual ranks" that live on ONE device
  * (plain device copies, no RCCL): it checks layouts and kernels where only one GPU is available. */
 int rf_slab_forward(rf_plan* plan, uint64_t seed, int mode, const double* noise_host);
+/* the same forward half fed like rf_realise_potential (generate.py:200-217: the rank's planes of delta(k)/k^2 are
+ * kept in its potential buffer) or like rf_execute_c2r (from the rank's k buffer, e.g. after rf_load_potential) */
+enum { RF_SLAB_GENERATE = 0, RF_SLAB_GENERATE_SAVE_POTENTIAL = 1, RF_SLAB_FROM_KSPACE = 2 };
+int rf_slab_forward_ex(rf_plan* plan, uint64_t seed, int mode, const double* noise_host, int source);
 int rf_slab_exchange_local(rf_plan** plans, int n);
 int rf_slab_backward(rf_plan* plan);
 int rf_slab_stats(rf_plan* plan, double* sum, double* sumsq);

@@ -73,6 +73,7 @@ SIGNATURES = {
     "rf_comm_init": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "rf_comm_allreduce_f64": (ctypes.c_int, [ctypes.c_void_p, _c_dp, ctypes.c_int, ctypes.c_int]),
     "rf_slab_forward": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, _c_dp]),
+    "rf_slab_forward_ex": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, _c_dp, ctypes.c_int]),
     "rf_slab_exchange_local": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int]),
     "rf_slab_backward": (ctypes.c_int, [ctypes.c_void_p]),
     "rf_slab_stats": (ctypes.c_int, [ctypes.c_void_p, _c_dp, _c_dp]),
@@ -267,7 +268,7 @@ class DevicePlan(object):
               "rf_lensing_potential")
 
     def download_aux(self, x0=0, x1=None, out=None):
-        x1 = self.nx if x1 is None else x1
+        x1 = self.nx_local if x1 is None else x1
         if out is None:
             out = np.empty((x1 - x0, self.ny, self.nz), self.real_dtype)
         check(self._lib.rf_download_aux(self._h, out.ctypes.data_as(ctypes.c_void_p), int(x0), int(x1)),
@@ -275,7 +276,8 @@ class DevicePlan(object):
         return out
 
     def download_noise(self, first=0, count=None):
-        total = 2 * self.nx * self.ny * (self.nz // 2 + 1)
+        """Resident deviates, 2 per cell of the (k_shape) side array, flattened."""
+        total = 2 * int(np.prod(self.k_shape))
         count = total - first if count is None else count
         out = np.empty(count, np.float64)
         check(self._lib.rf_download_noise(self._h, _dp(out), int(first), int(count)), "rf_download_noise")
@@ -345,17 +347,23 @@ class DevicePlan(object):
         check(self._lib.rf_load_potential(self._h, float(scale)), "rf_load_potential")
 
     # -- host <-> device --------------------------------------------------
+    @property
+    def k_shape(self):
+        """Shape of this rank's k-space side arrays (k buffer, potential): (nx, ny, nz/2 + 1) on one GPU; a kz-slab rank
+        holds its nz/(2 ranks) planes followed by the Nyquist plane (meaningful on rank 0, which packs it into kz = 0)."""
+        return (self.nx, self.ny, self.nz // 2 // self.nranks + 1)
+
     def upload_k(self, data):
-        if data.shape != (self.nx, self.ny, self.nz // 2 + 1) or data.dtype != self.complex_dtype:
+        if data.shape != self.k_shape or data.dtype != self.complex_dtype:
             raise ValueError("upload_k: wrong shape or dtype")
         data = np.ascontiguousarray(data)
         check(self._lib.rf_upload_k(self._h, data.ctypes.data_as(ctypes.c_void_p)), "rf_upload_k")
 
     def download_k(self, out=None):
         if out is None:
-            out = np.empty((self.nx, self.ny, self.nz // 2 + 1), self.complex_dtype)
-        if not out.flags.c_contiguous or out.dtype != self.complex_dtype or out.shape != (self.nx, self.ny, self.nz // 2 + 1):
-            raise ValueError("download_k: out must be a C-contiguous (nx, ny, nz/2+1) array of the plan's dtype")
+            out = np.empty(self.k_shape, self.complex_dtype)
+        if not out.flags.c_contiguous or out.dtype != self.complex_dtype or out.shape != self.k_shape:
+            raise ValueError("download_k: out must be a C-contiguous %r array of the plan's dtype" % (self.k_shape,))
         check(self._lib.rf_download_k(self._h, out.ctypes.data_as(ctypes.c_void_p)), "rf_download_k")
         return out
 
@@ -405,9 +413,13 @@ class DevicePlan(object):
     def barrier(self):
         self.allreduce([0.0])
 
-    def slab_forward(self, seed=0, noise=None):
+    def slab_forward(self, seed=0, noise=None, source="generate"):
+        """Forward half of the slab pipeline on this rank's kz planes.  ``source``: 'generate' (rows K..S fused into the
+        x pass), 'potential' (the same and delta(k)/k**2 kept in the potential buffer) or 'kspace' (from the k buffer)."""
         mode, ptr, keep = self._noise_arg(noise)
-        check(self._lib.rf_slab_forward(self._h, ctypes.c_uint64(int(seed) & (2 ** 64 - 1)), mode, ptr), "rf_slab_forward")
+        src = {"generate": 0, "potential": 1, "kspace": 2}[source]
+        check(self._lib.rf_slab_forward_ex(self._h, ctypes.c_uint64(int(seed) & (2 ** 64 - 1)), mode, ptr, src),
+              "rf_slab_forward_ex")
 
     @staticmethod
     def slab_exchange_local(plans):

@@ -207,6 +207,7 @@ void fill_gen(GenHost& h, int nx, int ny, int nz, const double* kx2, const doubl
   g.xt = h.tab.xt.data(); g.st = h.tab.st.data(); g.sl = h.tab.sl.data(); g.bin = h.tab.bin.data();
   g.nt = nt; g.nbins = (int)h.tab.bin.size(); g.x0 = h.tab.x0; g.inv_dx = h.tab.inv_dx;
   g.noise_mode = noise_mode; g.seed = seed; g.seed_dev = nullptr; g.noise = noise;
+  g.zpitch = nz / 2 + 1; g.zoff = 0;
 }
 
 template <typename T>
@@ -215,7 +216,7 @@ int c2r_impl(int nx, int ny, int nz, const GenHost* gen, const cplx<T>* kspace, 
   // x pass (generation or API-layout k-space fused into the load)
   GenColIO<T> gio;
   gio.base = W; gio.g = ColGeom{(long long)ny * nzc, 0, (long long)ny * nzc};
-  if (gen) gio.gp = gen->gp; else { memset(&gio.gp, 0, sizeof(gio.gp)); gio.gp.nx = nx; gio.gp.ny = ny; gio.gp.nz = nz; }
+  if (gen) gio.gp = gen->gp; else { memset(&gio.gp, 0, sizeof(gio.gp)); gio.gp.nx = nx; gio.gp.ny = ny; gio.gp.nz = nz; gio.gp.zpitch = nz / 2 + 1; }
   gio.kspace = kspace; gio.kz0 = 0; gio.nzl = (int)nzc;
   int rc = dispatch_col<T, +1, GenColIO<T>, GenSel>(nx, gio, (long long)ny * nzc);
   if (rc) return rc;
@@ -240,7 +241,7 @@ int realise_fast_impl(int nx, int ny, int nz, const GenHost& h, uint64_t seed, d
   f.nx = nx; f.ny = ny; f.nz = nz; f.dkx = (float)dkx; f.dky = (float)std::sqrt(h.gp.ky2[1]); f.dkz = (float)std::sqrt(h.gp.kz2[1]);
   f.rec = rec.data(); f.nbins = (int)rec.size();
   f.u_scale = (float)(0.5 * std::log10(2.0) / dx); f.u_off = (float)(-x0 / dx);
-  f.seed = seed; f.seed_dev = nullptr; f.noise = nullptr;
+  f.seed = seed; f.seed_dev = nullptr; f.noise = nullptr; f.zpitch = nz / 2 + 1; f.zoff = 0;
   int rc = dispatch_col<T, +1, IO, GenSel>(nx, io, (long long)ny * nzc);
   if (rc) return rc;
   PlainColIO<T> pio; pio.base = W; pio.g = ColGeom{nzc, (long long)ny * nzc, nzc};

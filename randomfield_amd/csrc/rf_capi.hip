@@ -198,11 +198,12 @@ GenParams make_gen(rf_plan* p, uint64_t seed, int mode, bool seed_from_dev) {
   g.nt = p->nt; g.nbins = p->nbins; g.x0 = p->x0; g.inv_dx = p->inv_dx;
   g.noise_mode = (mode == RF_NOISE_RESIDENT) ? (int)RF_NOISE_EXTERNAL : mode; g.seed = seed; g.seed_dev = nullptr; (void)seed_from_dev;   // graph batches point seed_dev at seeds_dev[i]
   g.noise = p->noise;
+  g.zpitch = p->nzl + 1; g.zoff = p->kz0;      // side arrays (noise, K, P) hold this rank's planes + the Nyquist plane
   return g;
 }
 
 int ensure_noise(rf_plan* p) {
-  const size_t n = 2 * (size_t)p->nx * p->ny * (p->nzc + 1);
+  const size_t n = 2 * (size_t)p->nx * p->ny * (p->nzl + 1);       // this rank's planes + the Nyquist plane
   if (p->noise_cap < n) {
     if (p->noise) RF_HIP(hipFree(p->noise));
     p->noise = nullptr; p->noise_cap = 0; p->noise_resident = false;
@@ -220,8 +221,15 @@ int upload_noise(rf_plan* p, int mode, const double* noise_host) {
   if (mode != RF_NOISE_EXTERNAL) return 0;
   RF_REQUIRE(noise_host != nullptr, "external noise mode needs a host noise array");
   if (int rc = ensure_noise(p)) return rc;
-  const size_t n = 2 * (size_t)p->nx * p->ny * (p->nzc + 1);
-  RF_HIP(hipMemcpyAsync(p->noise, noise_host, n * sizeof(double), hipMemcpyHostToDevice, p->stream));
+  // the host array is the reference's full set, 2 doubles per cell of [nx][ny][nz/2+1]; a kz-slab rank keeps its own
+  // planes and the Nyquist plane (one rank: everything, one contiguous copy)
+  const size_t cell = 2 * sizeof(double), hp = (size_t)(p->nzc + 1) * cell, dp = (size_t)(p->nzl + 1) * cell, rows = (size_t)p->nx * p->ny;
+  if (p->nranks == 1) {
+    RF_HIP(hipMemcpyAsync(p->noise, noise_host, rows * hp, hipMemcpyHostToDevice, p->stream));
+  } else {
+    RF_HIP(hipMemcpy2DAsync(p->noise, dp, (const char*)noise_host + (size_t)p->kz0 * cell, hp, (size_t)p->nzl * cell, rows, hipMemcpyHostToDevice, p->stream));
+    RF_HIP(hipMemcpy2DAsync((char*)p->noise + (size_t)p->nzl * cell, dp, (const char*)noise_host + (size_t)p->nzc * cell, hp, cell, rows, hipMemcpyHostToDevice, p->stream));
+  }
   p->noise_resident = true;
   return 0;
 }
@@ -233,6 +241,7 @@ FastGenParams make_fast(rf_plan* p, uint64_t seed, bool seed_from_dev, const uin
   f.rec = p->frec; f.nbins = p->fnbins; f.u_scale = p->fu_scale; f.u_off = p->fu_off;
   f.seed = seed; f.seed_dev = seed_from_dev ? seed_ptr : nullptr;
   f.noise = nullptr;
+  f.zpitch = p->nzl + 1; f.zoff = p->kz0;
   return f;
 }
 
@@ -291,7 +300,7 @@ int queue_x(rf_plan* p, const GenParams& gp, const void* kspace, void* W, hipStr
   // resident deviates (the numpy stream replayed by rf_noise_mt19937) take the fast float32 sigma path too; host-supplied
   // deviates (RF_NOISE_EXTERNAL, the parity mode) keep the exact reference dtype chain
   const bool fast_noise = !kspace && gp.noise_mode == NOISE_EXTERNAL && p->resident_fast && p->have_fast && !p->exact_gen &&
-                          !p->f64 && p->nranks == 1 && !p->pot_target;
+                          !p->f64 && !p->pot_target && !(p->replicate && p->nranks > 1);
   const bool fast = (!kspace && gp.noise_mode == NOISE_PHILOX && p->have_fast && !p->exact_gen) || fast_noise;
   const bool rep = p->replicate && p->nranks > 1;
   RF_REQUIRE(!rep || fast, "replicated generation needs the native generator (fast path)");
@@ -575,7 +584,7 @@ int rf_plan_create(rf_plan** out, int nx, int ny, int nz, int dtype, int device,
   p->csize = dtype ? 16 : 8;
   p->nxl = nx / nranks; p->nzl = p->nzc / nranks; p->kz0 = rank * p->nzl;
   p->w_bytes = (size_t)nx * ny * p->nzl * p->csize;       // == nxl * ny * nzc: the local share of the field
-  p->k_bytes = (size_t)nx * ny * (p->nzc + 1) * p->csize;
+  p->k_bytes = (size_t)nx * ny * (p->nzl + 1) * p->csize;    // side arrays: this rank's planes + the Nyquist plane
   auto cleanup = [&](int rc) { rf_plan_destroy(p); return rc; };
   hipError_t e;
   if ((e = hipStreamCreateWithFlags(&p->own_stream, hipStreamNonBlocking)) != hipSuccess)
@@ -819,11 +828,10 @@ int rf_set_power(rf_plan* p, const double* log10k, const double* sigma, int n) {
 int rf_generate(rf_plan* p, uint64_t seed, int mode, const double* noise_host) {
   RF_REQUIRE(p, "null plan");
   RF_REQUIRE(!p->unpacked, "this call does not apply to an unpacked c2c plan");
-  RF_REQUIRE(p->nranks == 1, "k-space buffer operations are single-GPU only");
   RF_REQUIRE(p->have_kgrid && p->have_power, "rf_set_kgrid and rf_set_power must be called first");
   RF_REQUIRE(mode == RF_NOISE_NATIVE || mode == RF_NOISE_EXTERNAL || mode == RF_NOISE_RESIDENT, "invalid noise mode");
   RF_HIP(hipSetDevice(p->device));
-  if (int rc = ensure_k(p)) return rc;
+  if (int rc = ensure_k(p)) return rc;        // a kz-slab rank holds (and generates) its own planes + the Nyquist plane
   if (int rc = upload_noise(p, mode, noise_host)) return rc;
   RF_HIP(launch_gen_kspace(p->f64, p->K, make_gen(p, seed, mode, false), p->stream));
   if (mode == RF_NOISE_EXTERNAL) RF_HIP(hipStreamSynchronize(p->stream));  // host noise buffer may be released by the caller
@@ -835,14 +843,11 @@ int rf_generate(rf_plan* p, uint64_t seed, int mode, const double* noise_host) {
 int rf_execute_c2r(rf_plan* p) {
   RF_REQUIRE(p, "null plan");
   RF_REQUIRE(!p->unpacked, "this call does not apply to an unpacked c2c plan");
-  RF_REQUIRE(p->nranks == 1, "k-space buffer operations are single-GPU only");
   RF_REQUIRE(p->K && p->k_valid, "no k-space data: call rf_generate or rf_upload_k first");
+  RF_REQUIRE(!(p->replicate && p->nranks > 1), "replicated-generation plans have no distributed k-space buffer");
   RF_HIP(hipSetDevice(p->device));
-  GenParams gp;
-  memset(&gp, 0, sizeof(gp));
-  gp.nx = p->nx; gp.ny = p->ny; gp.nz = p->nz;
   p->timed = true;
-  return queue_c2r(p, gp, p->K);
+  return queue_c2r(p, make_gen(p, 0, RF_NOISE_NATIVE, false), p->K);
 }
 
 int rf_execute_r2c(rf_plan* p) {
@@ -898,25 +903,32 @@ int rf_realise(rf_plan* p, uint64_t seed, int mode, const double* noise_host) {
 // generate_delta_field(save_potential=True) (generate.py:191-219): the field as rf_realise, plus delta(k) / k^2 in the
 // plan's potential buffer.  With the native generator on a float32 single-GPU plan the potential is a second store
 // stream of the generation pass; every other case runs the unfused sequence generate -> save_potential -> c2r.
-int rf_realise_potential(rf_plan* p, uint64_t seed, int mode, const double* noise_host) {
-  RF_REQUIRE(p, "null plan");
-  RF_REQUIRE(!p->unpacked, "this call does not apply to an unpacked c2c plan");
-  RF_REQUIRE(p->nranks == 1, "k-space buffer operations are single-GPU only");
+// whole = false stops after the y pass (the slab pipeline's forward half, rf_slab_forward_ex)
+static int potential_forward(rf_plan* p, uint64_t seed, int mode, const double* noise_host, bool whole) {
   RF_REQUIRE(p->have_kgrid && p->have_power, "rf_set_kgrid and rf_set_power must be called first");
   RF_REQUIRE(mode == RF_NOISE_NATIVE || mode == RF_NOISE_EXTERNAL || mode == RF_NOISE_RESIDENT, "invalid noise mode");
+  RF_REQUIRE(!(p->replicate && p->nranks > 1), "replicated-generation plans keep no k-space potential: clear RF_FLAG_REPLICATED_GENERATION");
   RF_HIP(hipSetDevice(p->device));
-  const bool fused = mode == RF_NOISE_NATIVE && p->have_fast && !p->exact_gen && !p->f64 && !p->force_slab && !p->generic;
+  const bool fused = mode == RF_NOISE_NATIVE && p->have_fast && !p->exact_gen && !p->f64 && !p->generic;
   if (!fused) {
     if (int rc = rf_generate(p, seed, mode, noise_host)) return rc;
     if (int rc = rf_save_potential(p)) return rc;
-    return rf_execute_c2r(p);
+    if (whole) return rf_execute_c2r(p);
+    return queue_xy(p, make_gen(p, 0, RF_NOISE_NATIVE, false), p->K, p->W, p->stream, false);
   }
   if (!p->P) RF_HIP(hipMalloc(&p->P, p->k_bytes));
-  p->timed = true;
+  p->timed = whole;
   p->pot_target = p->P;
-  const int rc = queue_c2r(p, make_gen(p, seed, mode, false), nullptr);
+  const GenParams gp = make_gen(p, seed, mode, false);
+  const int rc = whole ? queue_c2r(p, gp, nullptr) : queue_xy(p, gp, nullptr, p->W, p->stream, false);
   p->pot_target = nullptr;
   return rc;
+}
+
+int rf_realise_potential(rf_plan* p, uint64_t seed, int mode, const double* noise_host) {
+  RF_REQUIRE(p, "null plan");
+  RF_REQUIRE(!p->unpacked, "this call does not apply to an unpacked c2c plan");
+  return potential_forward(p, seed, mode, noise_host, true);
 }
 
 // issue the n realisations of a batch on the plan's stream (under stream capture)
@@ -1116,7 +1128,6 @@ int rf_scale_z(rf_plan* p, const double* factor_z, int nz) { return rf_affine_z(
 int rf_lensing_potential(rf_plan* p, const double* cot_z, int nz, double spacing, int i_min) {
   RF_REQUIRE(p && cot_z, "null argument");
   RF_REQUIRE(!p->unpacked, "this call does not apply to an unpacked c2c plan");
-  RF_REQUIRE(p->nranks == 1, "rf_lensing_potential is single-GPU only");
   RF_REQUIRE(nz == p->nz, "table length must equal nz");
   RF_REQUIRE(i_min >= 0 && i_min < nz, "invalid i_min");
   RF_REQUIRE(spacing > 0, "spacing must be positive");
@@ -1124,7 +1135,7 @@ int rf_lensing_potential(rf_plan* p, const double* cot_z, int nz, double spacing
   RF_HIP(hipSetDevice(p->device));
   if (int rc = ensure_k(p)) return rc;            // (nx ny (nz/2+1)) complex >= (nx ny nz) real
   RF_HIP(hipMemcpyAsync(p->ztab, cot_z, nz * sizeof(double), hipMemcpyHostToDevice, p->stream));
-  RF_HIP(launch_lensing(p->f64, p->cur, p->K, (long long)p->nx * p->ny, nz, p->ztab, spacing, i_min, p->stream));
+  RF_HIP(launch_lensing(p->f64, p->cur, p->K, (long long)p->nxl * p->ny, nz, p->ztab, spacing, i_min, p->stream));   // rows are local: x slab
   RF_HIP(hipStreamSynchronize(p->stream));
   p->k_valid = false;
   p->aux_valid = true;
@@ -1136,7 +1147,7 @@ int rf_download_aux(rf_plan* p, void* host, int x0, int x1) {
   RF_REQUIRE(p && host, "null argument");
   RF_REQUIRE(!p->unpacked, "this call does not apply to an unpacked c2c plan");
   RF_REQUIRE(p->K && p->aux_valid, "no auxiliary field on the device");
-  RF_REQUIRE(0 <= x0 && x0 < x1 && x1 <= p->nx, "invalid x range");
+  RF_REQUIRE(0 <= x0 && x0 < x1 && x1 <= p->nxl, "invalid x range (multi-GPU plans hold nx/ranks local planes)");
   RF_HIP(hipSetDevice(p->device));
   const size_t plane = (size_t)p->ny * p->nz * (p->csize / 2);
   RF_HIP(hipMemcpyAsync(host, (const char*)p->K + (size_t)x0 * plane, (size_t)(x1 - x0) * plane, hipMemcpyDeviceToHost, p->stream));
@@ -1147,23 +1158,21 @@ int rf_download_aux(rf_plan* p, void* host, int x0, int x1) {
 int rf_save_potential(rf_plan* p) {
   RF_REQUIRE(p, "null plan");
   RF_REQUIRE(!p->unpacked, "this call does not apply to an unpacked c2c plan");
-  RF_REQUIRE(p->nranks == 1, "k-space buffer operations are single-GPU only");
   RF_REQUIRE(p->K && p->k_valid, "no k-space data");
   RF_REQUIRE(p->have_kgrid, "rf_set_kgrid must be called first");
   RF_HIP(hipSetDevice(p->device));
   if (!p->P) RF_HIP(hipMalloc(&p->P, p->k_bytes));
-  RF_HIP(launch_save_potential(p->f64, p->K, p->P, p->nx, p->ny, p->nz, p->kx2, p->ky2, p->kz2, p->stream));
+  RF_HIP(launch_save_potential(p->f64, p->K, p->P, p->nx, p->ny, p->nz, p->kx2, p->ky2, p->kz2, p->nzl + 1, p->kz0, p->stream));
   return 0;
 }
 
 int rf_load_potential(rf_plan* p, double scale) {
   RF_REQUIRE(p, "null plan");
   RF_REQUIRE(!p->unpacked, "this call does not apply to an unpacked c2c plan");
-  RF_REQUIRE(p->nranks == 1, "k-space buffer operations are single-GPU only");
   RF_REQUIRE(p->P, "no saved potential");
   RF_HIP(hipSetDevice(p->device));
   if (int rc = ensure_k(p)) return rc;
-  RF_HIP(launch_scale_copy(p->f64, p->P, p->K, (long long)p->nx * p->ny * (p->nzc + 1), scale, p->stream));
+  RF_HIP(launch_scale_copy(p->f64, p->P, p->K, (long long)p->nx * p->ny * (p->nzl + 1), scale, p->stream));
   p->k_valid = true;
   p->aux_valid = false;
   return 0;
@@ -1172,7 +1181,6 @@ int rf_load_potential(rf_plan* p, double scale) {
 int rf_upload_k(rf_plan* p, const void* host) {
   RF_REQUIRE(p && host, "null argument");
   RF_REQUIRE(!p->unpacked, "this call does not apply to an unpacked c2c plan");
-  RF_REQUIRE(p->nranks == 1, "k-space buffer operations are single-GPU only");
   RF_HIP(hipSetDevice(p->device));
   if (int rc = ensure_k(p)) return rc;
   RF_HIP(hipMemcpyAsync(p->K, host, p->k_bytes, hipMemcpyHostToDevice, p->stream));
@@ -1289,7 +1297,6 @@ int rf_mt_set_jump(rf_plan* p, int npolys, const uint16_t* pos, const int* npos,
 int rf_noise_mt19937(rf_plan* p, const uint32_t* state624, unsigned long long* accepted) {
   RF_REQUIRE(p && state624, "null argument");
   RF_REQUIRE(!p->unpacked, "this call does not apply to an unpacked c2c plan");
-  RF_REQUIRE(p->nranks == 1, "rf_noise_mt19937 is single-GPU only");
   RF_REQUIRE(p->mt_pos && !p->mt_npos.empty(), "rf_mt_set_jump must be called first");
   RF_HIP(hipSetDevice(p->device));
   if (int rc = ensure_noise(p)) return rc;
@@ -1329,14 +1336,16 @@ int rf_noise_mt19937(rf_plan* p, const uint32_t* state624, unsigned long long* a
     RF_HIP(launch_mt_jump(p->mt_states, p->mt_pos + (size_t)t * (R - 1) * p->mt_stride, p->mt_npos_dev + t * (R - 1), p->mt_stride, nsrc,
                           dist, R - 1, nseg, s));
   }
-  RF_HIP(launch_mt_polar(false, p->mt_states, nseg, p->mt_bps, total_blocks, p->mt_counts, nullptr, nullptr, ncells, s));
+  RF_HIP(launch_mt_polar(false, p->mt_states, nseg, p->mt_bps, total_blocks, p->mt_counts, nullptr, nullptr, ncells, (int)p->nzc + 1, (int)p->nzl + 1, p->kz0, s));
   RF_HIP(launch_mt_scan(p->mt_counts, p->mt_offsets, nseg, s));
   unsigned long long total = 0;
   RF_HIP(hipMemcpyAsync(&total, p->mt_offsets + nseg, sizeof(total), hipMemcpyDeviceToHost, s));
   RF_HIP(hipStreamSynchronize(s));
   if (accepted) *accepted = total;
   RF_REQUIRE(total >= ncells, "MT19937 replay: not enough accepted polar attempts (increase the margin)");
-  RF_HIP(launch_mt_polar(true, p->mt_states, nseg, p->mt_bps, total_blocks, p->mt_counts, p->mt_offsets, p->noise, ncells, s));
+  // a kz-slab rank replays the WHOLE stream (the destination of a deviate depends on every earlier acceptance) and keeps
+  // the deviates of its own planes: the replay is replicated work, not distributed
+  RF_HIP(launch_mt_polar(true, p->mt_states, nseg, p->mt_bps, total_blocks, p->mt_counts, p->mt_offsets, p->noise, ncells, (int)p->nzc + 1, (int)p->nzl + 1, p->kz0, s));
   p->noise_resident = true;
   return 0;
 }
@@ -1345,7 +1354,7 @@ int rf_download_noise(rf_plan* p, double* host, unsigned long long first, unsign
   RF_REQUIRE(p && host, "null argument");
   RF_REQUIRE(!p->unpacked, "this call does not apply to an unpacked c2c plan");
   RF_REQUIRE(p->noise_resident, "no deviates resident on the device");
-  RF_REQUIRE(first + count <= 2ull * p->nx * p->ny * (p->nzc + 1), "range outside the noise buffer");
+  RF_REQUIRE(first + count <= 2ull * p->nx * p->ny * (p->nzl + 1), "range outside the noise buffer");
   RF_HIP(hipSetDevice(p->device));
   RF_HIP(hipMemcpyAsync(host, p->noise + first, count * sizeof(double), hipMemcpyDeviceToHost, p->stream));
   RF_HIP(hipStreamSynchronize(p->stream));
@@ -1406,7 +1415,28 @@ int rf_slab_forward(rf_plan* p, uint64_t seed, int mode, const double* noise_hos
   RF_REQUIRE(p->have_kgrid && p->have_power, "rf_set_kgrid and rf_set_power must be called first");
   RF_HIP(hipSetDevice(p->device));
   if (int rc = upload_noise(p, mode, noise_host)) return rc;
-  if (int rc = queue_xy(p, make_gen(p, seed, mode, false), nullptr, p->W, p->stream, false)) return rc;
+  p->resident_fast = (mode == RF_NOISE_RESIDENT);
+  const int rc = queue_xy(p, make_gen(p, seed, mode, false), nullptr, p->W, p->stream, false);
+  p->resident_fast = false;
+  if (rc) return rc;
+  RF_HIP(hipStreamSynchronize(p->stream));
+  return 0;
+}
+
+// the forward half with the other two sources of rf_realise_potential / rf_execute_c2r
+int rf_slab_forward_ex(rf_plan* p, uint64_t seed, int mode, const double* noise_host, int source) {
+  RF_REQUIRE(p, "null plan");
+  RF_REQUIRE(!p->unpacked, "this call does not apply to an unpacked c2c plan");
+  RF_REQUIRE(p->nranks > 1, "rf_slab_* are for multi-rank plans");
+  RF_REQUIRE(source == RF_SLAB_GENERATE || source == RF_SLAB_GENERATE_SAVE_POTENTIAL || source == RF_SLAB_FROM_KSPACE, "invalid source");
+  if (source == RF_SLAB_GENERATE) return rf_slab_forward(p, seed, mode, noise_host);
+  RF_HIP(hipSetDevice(p->device));
+  if (source == RF_SLAB_GENERATE_SAVE_POTENTIAL) {
+    if (int rc = potential_forward(p, seed, mode, noise_host, false)) return rc;
+  } else {
+    RF_REQUIRE(p->K && p->k_valid, "no k-space data: call rf_generate, rf_load_potential or rf_upload_k first");
+    if (int rc = queue_xy(p, make_gen(p, 0, RF_NOISE_NATIVE, false), p->K, p->W, p->stream, false)) return rc;
+  }
   RF_HIP(hipStreamSynchronize(p->stream));
   return 0;
 }

@@ -256,7 +256,14 @@ struct GenParams {
   uint64_t seed;
   const uint64_t* seed_dev;   // if non-null the seed is read from device memory (graph replay)
   const double* noise;        // external mode: 2*nx*ny*(nz/2+1) float64 deviates, reference order
+  // The API-layout side arrays (noise, k space, potential) of a kz-slab rank hold its planes only: rows of `zpitch`
+  // slots, slot j < zpitch - 1 = plane zoff + j, the last slot = the Nyquist plane kz = nz/2 (which rank 0 packs into
+  // its slot kz = 0).  One rank: zpitch = nz/2 + 1, zoff = 0 -- the reference's layout itself.
+  int zpitch, zoff;
 };
+
+// slot of plane kz in a row of a side array (GenParams / FastGenParams)
+template <class G> RF_HD int side_slot(const G& g, int kz) { return kz == g.nz / 2 ? g.zpitch - 1 : kz - g.zoff; }
 
 // no-FMA arithmetic: these must round exactly like numpy's separate ufunc calls / numpy's C code built
 // without FMA.  (hipcc contracts a*b+c by default and its __dmul_rn/__dadd_rn are plain operators, so the
@@ -322,7 +329,7 @@ RF_HD uint64_t native_noise_index(const GenParams& g, int ix, int iy, int iz) {
 template <typename T>
 RF_HD void noise_of_cell(const GenParams& g, uint64_t seed, int ix, int iy, int iz, double& gre, double& gim) {
   if (g.noise_mode == NOISE_EXTERNAL) {
-    const uint64_t c = ((uint64_t)ix * (uint64_t)g.ny + (uint64_t)iy) * (uint64_t)(g.nz / 2 + 1) + (uint64_t)iz;
+    const uint64_t c = ((uint64_t)ix * (uint64_t)g.ny + (uint64_t)iy) * (uint64_t)g.zpitch + (uint64_t)side_slot(g, iz);
     gre = g.noise[2 * c];
     gim = g.noise[2 * c + 1];
   } else {
@@ -406,6 +413,7 @@ struct FastGenParams {
   const uint64_t* seed_dev;
   const double* noise;    // SRC = 1 kernels: resident float64 deviates in the reference's order (random.py:24-28),
                           // 2 per cell of the API layout [nx][ny][nz/2+1]
+  int zpitch, zoff;       // row pitch and first plane of the side arrays (noise, potential): see GenParams
 };
 enum { FAST_LDS_BINS = 512 };
 
@@ -528,7 +536,7 @@ RF_HD cplx<float> fast_fix_kz0(const FastGenParams& g, const FastRec* rec, uint6
 // The same slot from resident deviates (the reference's stream, e.g. replayed MT19937): cell = sigma * (g_re + i g_im)
 // with the float64 product rounded once (random.py:28), symmetrised as above.
 RF_HD cplx<float> fast_noise_cell(const FastGenParams& g, const FastRec* rec, int ix, int iy, int kz, float k2) {
-  const double* d = g.noise + 2 * (((long long)ix * g.ny + iy) * (g.nz / 2 + 1) + kz);
+  const double* d = g.noise + 2 * (((long long)ix * g.ny + iy) * g.zpitch + side_slot(g, kz));
   const double s = (double)fast_sigma(g, rec, k2);
   return mk<float>((float)(s * d[0]), (float)(s * d[1]));
 }

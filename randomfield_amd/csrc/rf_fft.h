@@ -158,16 +158,16 @@ template <typename T, bool WIDE = false> struct GenColIO {
       const long long Cc = C + c;
       const int iy = (int)(Cc / nzl), kz = kz0 + (int)(Cc % nzl);
       if (kspace) {
-        const cplx<T>* p = kspace + ((long long)ix * gp.ny + iy) * (nzc + 1);
-        cplx<T> a = p[kz];
+        const cplx<T>* p = kspace + ((long long)ix * gp.ny + iy) * gp.zpitch;      // rows of this rank's planes + Nyquist
+        cplx<T> a = p[kz - gp.zoff];
         if (kz == 0) {
           // The planes kz = 0 and kz = nz/2 travel as ONE complex plane (a + i n), which needs both to be 2-D
           // Hermitian.  np.fft.irfftn (transform.py:314) accepts anything there and, by discarding the imaginary part
           // after the x and y transforms, in effect uses the Hermitian part of each plane: so that is what is packed.
           // (Hermitian input, e.g. after symmetrize(), is reproduced bit for bit: (a + conj a*)/2 with a == conj a*.)
           const int mx = (gp.nx - ix) % gp.nx, my = (gp.ny - iy) % gp.ny;
-          const cplx<T>* pm = kspace + ((long long)mx * gp.ny + my) * (nzc + 1);
-          const cplx<T> am = pm[0], n0 = p[nzc], nm = pm[nzc];
+          const cplx<T>* pm = kspace + ((long long)mx * gp.ny + my) * gp.zpitch;
+          const cplx<T> am = pm[0], n0 = p[gp.zpitch - 1], nm = pm[gp.zpitch - 1];
           const cplx<T> ah = mk<T>((T)0.5 * (a.x + am.x), (T)0.5 * (a.y - am.y));
           const cplx<T> nh = mk<T>((T)0.5 * (n0.x + nm.x), (T)0.5 * (n0.y - nm.y));
           a = mk<T>(ah.x - nh.y, ah.y + nh.x);
@@ -260,8 +260,8 @@ struct FastGenColIOT {
       fast_gen_pair_at<AB>(gp, rec, seed, ctr_l + ctr_u, k2a, k2b, v.c[0], v.c[1]);
     } else {
       // cells (ix, iy, kz) and (ix, iy, kz + 1) are adjacent in the reference's order: 4 doubles, 32 contiguous bytes
-      const int nzp = gp.nz / 2 + 1;
-      const double* d = (gp.noise + 2LL * ro * gp.ny * nzp) + 2u * (uint32_t)((rb * gp.ny + iy) * nzp + kz);
+      const int nzp = gp.zpitch;
+      const double* d = (gp.noise + 2LL * ro * gp.ny * nzp) + 2u * (uint32_t)((rb * gp.ny + iy) * nzp + (kz - gp.zoff));
       const V16<double> ga = v16_load<double>(d), gb = v16_load<double>(d + 2);     // one complex128 = one deviate pair
       const double sa = (double)fast_sigma(gp, rec, k2a), sb = (double)fast_sigma(gp, rec, k2b);
       v.c[0] = mk<float>((float)(sa * ga.c[0].x), (float)(sa * ga.c[0].y));
@@ -269,11 +269,11 @@ struct FastGenColIOT {
     }
     if (POT) {
       // row (ix, iy) of the API layout; the slot kz = 0 (Hermitian planes) is written by fix_value() instead
-      const int nzp = gp.nz / 2 + 1;
+      const int nzp = gp.zpitch, sl = kz - gp.zoff;
       cplx<float>* row = (pot + (long long)ro * gp.ny * nzp) + (uint32_t)((rb * gp.ny + iy) * nzp);
       const float ra = fast_rcp(k2a), rb2 = fast_rcp(k2b);
-      if (!(FIX != 0 && kz == 0)) row[kz] = mk<float>(v.c[0].x * ra, v.c[0].y * ra);
-      row[kz + 1] = mk<float>(v.c[1].x * rb2, v.c[1].y * rb2);
+      if (!(FIX != 0 && kz == 0)) row[sl] = mk<float>(v.c[0].x * ra, v.c[0].y * ra);
+      row[sl + 1] = mk<float>(v.c[1].x * rb2, v.c[1].y * rb2);
     }
     return v;
   }
@@ -289,7 +289,7 @@ struct FastGenColIOT {
     if (SRC != 0) return fast_fix_kz0_noise(gp, rec, rb + ro, iy);
     const cplx<float> packed = fast_fix_kz0(gp, rec, seed, rb + ro, iy, p0, pn);
     if (POT) {
-      const int nzp = gp.nz / 2 + 1;
+      const int nzp = gp.zpitch;                 // only the rank with kz0 = 0 gets here: slot 0 = plane 0
       cplx<float>* row = pot + ((long long)(rb + ro) * gp.ny + iy) * nzp;
       row[0] = p0;
       row[nzp - 1] = pn;

@@ -9,11 +9,11 @@ namespace {
 
 template <typename T>
 __global__ __launch_bounds__(256) void gen_kspace_kernel(cplx<T>* __restrict__ K, GenParams gp) {
-  const int nzh = gp.nz / 2 + 1;
+  const int nzh = gp.zpitch;            // this rank's planes + the Nyquist plane (nz/2 + 1 on one rank)
   const long long total = (long long)gp.nx * gp.ny * nzh;
   const uint64_t seed = gp.seed_dev ? *gp.seed_dev : gp.seed;
   for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += (long long)gridDim.x * blockDim.x) {
-    const int iz = (int)(c % nzh);
+    const int sl = (int)(c % nzh), iz = sl == nzh - 1 ? gp.nz / 2 : gp.zoff + sl;
     const long long col = c / nzh;
     const int iy = (int)(col % gp.ny), ix = (int)(col / gp.ny);
     K[c] = gen_cell<T>(gp, seed, ix, iy, iz);
@@ -83,11 +83,12 @@ __global__ __launch_bounds__(256) void affine_vec_kernel(T* __restrict__ W, long
 template <typename T>
 __global__ __launch_bounds__(256) void save_potential_kernel(const cplx<T>* __restrict__ K, cplx<T>* __restrict__ P,
                                                              int nx, int ny, int nz, const double* __restrict__ kx2,
-                                                             const double* __restrict__ ky2, const double* __restrict__ kz2) {
-  const int nzh = nz / 2 + 1;
+                                                             const double* __restrict__ ky2, const double* __restrict__ kz2,
+                                                             int zpitch, int zoff) {
+  const int nzh = zpitch;
   const long long total = (long long)nx * ny * nzh;
   for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += (long long)gridDim.x * blockDim.x) {
-    const int iz = (int)(c % nzh);
+    const int sl = (int)(c % nzh), iz = sl == nzh - 1 ? nz / 2 : zoff + sl;
     const long long col = c / nzh;
     const int iy = (int)(col % ny), ix = (int)(col / ny);
     T t = (T)(kx2[ix] + ky2[iy]);
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(256) void save_potential_kernel(const cplx<T>* __re
     cplx<T> d = K[c];
     // complex (inv + 0i) * d: the 0*x terms of numpy's complex product vanish exactly
     cplx<T> r = mk<T>(inv * d.x, inv * d.y);
-    if (c == 0) r = mk<T>((T)0, (T)0);
+    if (ix == 0 && iy == 0 && iz == 0) r = mk<T>((T)0, (T)0);
     P[c] = r;
   }
 }
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(256) void lensing_kernel(const T* __restrict__ phi,
 }  // namespace
 
 hipError_t launch_gen_kspace(int f64, void* K, const GenParams& gp, hipStream_t s) {
-  const long long total = (long long)gp.nx * gp.ny * (gp.nz / 2 + 1);
+  const long long total = (long long)gp.nx * gp.ny * gp.zpitch;
   if (f64) hipLaunchKernelGGL(gen_kspace_kernel<double>, dim3(grid_for(total, 256)), dim3(256), 0, s, (cplx<double>*)K, gp);
   else hipLaunchKernelGGL(gen_kspace_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, s, (cplx<float>*)K, gp);
   return hipGetLastError();
@@ -303,10 +304,10 @@ hipError_t launch_lensing(int f64, const void* phi, void* psi, long long nrows, 
 }
 
 hipError_t launch_save_potential(int f64, const void* K, void* P, int nx, int ny, int nz, const double* kx2,
-                                 const double* ky2, const double* kz2, hipStream_t s) {
-  const long long total = (long long)nx * ny * (nz / 2 + 1);
-  if (f64) hipLaunchKernelGGL(save_potential_kernel<double>, dim3(grid_for(total, 256)), dim3(256), 0, s, (const cplx<double>*)K, (cplx<double>*)P, nx, ny, nz, kx2, ky2, kz2);
-  else hipLaunchKernelGGL(save_potential_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, s, (const cplx<float>*)K, (cplx<float>*)P, nx, ny, nz, kx2, ky2, kz2);
+                                 const double* ky2, const double* kz2, int zpitch, int zoff, hipStream_t s) {
+  const long long total = (long long)nx * ny * zpitch;
+  if (f64) hipLaunchKernelGGL(save_potential_kernel<double>, dim3(grid_for(total, 256)), dim3(256), 0, s, (const cplx<double>*)K, (cplx<double>*)P, nx, ny, nz, kx2, ky2, kz2, zpitch, zoff);
+  else hipLaunchKernelGGL(save_potential_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, s, (const cplx<float>*)K, (cplx<float>*)P, nx, ny, nz, kx2, ky2, kz2, zpitch, zoff);
   return hipGetLastError();
 }
 

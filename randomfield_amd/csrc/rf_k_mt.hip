@@ -119,7 +119,11 @@ template <bool FILL>
 __global__ __launch_bounds__(256) void mt_polar_kernel(const uint32_t* __restrict__ states, int blocks_per_segment,
                                                        long long total_blocks, int nseg, unsigned long long* __restrict__ counts,
                                                        const unsigned long long* __restrict__ offsets,
-                                                       double* __restrict__ noise, unsigned long long ncells) {
+                                                       double* __restrict__ noise, unsigned long long ncells,
+                                                       int nzh, int zpitch, int zoff) {
+  // nzh = nz/2 + 1 cells per (ix, iy) row of the stream.  zpitch == nzh: the buffer is the whole stream in its own
+  // order.  zpitch < nzh (a kz-slab rank): rows of zpitch slots -- planes [zoff, zoff + zpitch - 1) and, last, the
+  // Nyquist plane nzh - 1; deviates of other planes are dropped (every rank replays the whole stream).
   __shared__ __attribute__((aligned(16))) uint32_t lds[4][MT_N + 16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long long seg = (long long)blockIdx.x * 4 + wave;
@@ -168,10 +172,19 @@ __global__ __launch_bounds__(256) void mt_polar_kernel(const uint32_t* __restric
       const unsigned long long ball = __ballot(acc);
       if (FILL && acc) {
         const unsigned long long cell = running + (unsigned long long)__popcll(ball & ((1ull << lane) - 1ull));
-        if (cell < ncells) {
+        bool keep = cell < ncells;
+        unsigned long long dst = cell;
+        if (keep && zpitch != nzh) {
+          const unsigned long long col = cell / (unsigned)nzh;
+          const int kz = (int)(cell - col * (unsigned)nzh);
+          const int sl = kz == nzh - 1 ? zpitch - 1 : kz - zoff;
+          keep = sl >= 0 && sl < zpitch && (kz == nzh - 1 || sl < zpitch - 1);
+          dst = col * (unsigned)zpitch + (unsigned)sl;
+        }
+        if (keep) {
           const double f = sqrt(-2.0 * log(r2) / r2);
-          noise[2 * cell] = f * x2;                           // legacy_gauss returns f*x2 first, then the saved f*x1
-          noise[2 * cell + 1] = f * x1;
+          noise[2 * dst] = f * x2;                            // legacy_gauss returns f*x2 first, then the saved f*x1
+          noise[2 * dst + 1] = f * x1;
         }
       }
       running += (unsigned long long)__popcll(ball);
@@ -216,10 +229,10 @@ hipError_t launch_mt_jump(uint32_t* states, const uint32_t* pos, const int* npos
 }
 hipError_t launch_mt_polar(bool fill, const uint32_t* states, int nseg, int blocks_per_segment, long long total_blocks,
                            unsigned long long* counts, const unsigned long long* offsets, double* noise,
-                           unsigned long long ncells, hipStream_t s) {
+                           unsigned long long ncells, int nzh, int zpitch, int zoff, hipStream_t s) {
   const unsigned grid = (unsigned)((nseg + 3) / 4);
-  if (fill) hipLaunchKernelGGL(mt_polar_kernel<true>, dim3(grid), dim3(256), 0, s, states, blocks_per_segment, total_blocks, nseg, counts, offsets, noise, ncells);
-  else hipLaunchKernelGGL(mt_polar_kernel<false>, dim3(grid), dim3(256), 0, s, states, blocks_per_segment, total_blocks, nseg, counts, offsets, noise, ncells);
+  if (fill) hipLaunchKernelGGL(mt_polar_kernel<true>, dim3(grid), dim3(256), 0, s, states, blocks_per_segment, total_blocks, nseg, counts, offsets, noise, ncells, nzh, zpitch, zoff);
+  else hipLaunchKernelGGL(mt_polar_kernel<false>, dim3(grid), dim3(256), 0, s, states, blocks_per_segment, total_blocks, nseg, counts, offsets, noise, ncells, nzh, zpitch, zoff);
   return hipGetLastError();
 }
 hipError_t launch_mt_scan(const unsigned long long* counts, unsigned long long* offsets, int n, hipStream_t s) {

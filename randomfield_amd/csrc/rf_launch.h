@@ -87,8 +87,9 @@ hipError_t launch_affine_z(int f64, void* W, long long nrows, int nz, const doub
 hipError_t launch_lensing(int f64, const void* phi, void* psi, long long nrows, int nz, const double* cot_z, double h, int i_min,
                           hipStream_t s);
 // P = K / k^2 (0 at DC), API layout; and K = scale * P
+// (side arrays of a kz-slab rank: rows of zpitch slots, first plane zoff -- GenParams)
 hipError_t launch_save_potential(int f64, const void* K, void* P, int nx, int ny, int nz, const double* kx2,
-                                 const double* ky2, const double* kz2, hipStream_t s);
+                                 const double* ky2, const double* kz2, int zpitch, int zoff, hipStream_t s);
 hipError_t launch_scale_copy(int f64, const void* P, void* K, long long n, double scale, hipStream_t s);
 
 // on-GPU replay of RandomState(seed).normal (rf_k_mt.hip)
@@ -98,7 +99,8 @@ hipError_t launch_mt_jump(uint32_t* states, const uint32_t* pos, const int* npos
                           int nseg, hipStream_t s);
 hipError_t launch_mt_polar(bool fill, const uint32_t* states, int nseg, int blocks_per_segment, long long total_blocks,
                            unsigned long long* counts, const unsigned long long* offsets, double* noise,
-                           unsigned long long ncells, hipStream_t s);
+                           unsigned long long ncells, int nzh, int zpitch, int zoff, hipStream_t s);
+// (nzh = nz/2 + 1 cells per row of the stream; zpitch / zoff: the noise buffer's rows, see GenParams)
 hipError_t launch_mt_scan(const unsigned long long* counts, unsigned long long* offsets, int n, hipStream_t s);
 
 // non-power-of-two grids (rf_generic.h, rf_k_generic.hip); root = exp(2 pi i t / n) tables as made by make_twiddles

@@ -599,8 +599,10 @@ def test_unpacked_c2c_plan_against_numpy(hip, shape):
         assert np.max(np.abs(inv.execute() - np.fft.ifftn(a.astype(np.complex128)))) <= 4 * tol
         plan.device.close()
         inv.device.close()
-    with pytest.raises(RuntimeError):
-        transform.Plan((6, 8, 8), dtype_in=np.complex64, packed=False, backend="hip")       # not a power of two
+    small = transform.Plan((6, 8, 8), dtype_in=np.complex64, packed=False, backend="hip")   # not a power of two: generic kernels
+    small.data_in[:] = rng.normal(size=(6, 8, 8))
+    src = small.data_in.copy()
+    assert np.max(np.abs(small.execute() - np.fft.ifftn(src.astype(np.complex128)))) <= 1e-6
     with pytest.raises(RuntimeError):
         transform.Plan((8, 8, 4096), dtype_in=np.complex64, packed=False, backend="hip")    # nz beyond the row kernels
 
@@ -1053,3 +1055,114 @@ def test_generic_shape_plans(hip):
                 src = c.data_in.copy()
                 ref = fn(src.astype(np.complex128))
                 assert np.max(np.abs(c.execute() - ref)) <= 10 * tol * np.abs(ref).std()
+
+
+# ---- the reference's default call and its own random stream on kz-slab ranks (virtual ranks on one device) --------
+def _slab_plans(hip, shape, dtype, k, Pk, nranks, exact=False):
+    from randomfield_amd import powertools
+    nx, ny, nz = shape
+    plans = []
+    for r in range(nranks):
+        p = hip.DevicePlan(nx, ny, nz, dtype, nranks=nranks, rank=r)
+        p.set_kgrid(*powertools.ksq_axes(nx, ny, nz, SPACING))
+        p.set_power(*cpu_ref.sigma_table(k, Pk, nx, ny, nz, SPACING))
+        p.set_exact_generation(exact)
+        plans.append(p)
+    return plans
+
+
+def _slab_run(hip, plans, **forward):
+    for p in plans:
+        p.slab_forward(**forward)
+    hip.DevicePlan.slab_exchange_local(plans)
+    for p in plans:
+        p.slab_backward()
+    return np.concatenate([p.download_real() for p in plans], axis=0)
+
+
+def _slab_side_array(plans, getter, nzc):
+    """Assemble the (nx, ny, nz/2+1) array from the ranks' side arrays (own planes, then the Nyquist plane)."""
+    parts = [getter(p) for p in plans]
+    nzl = parts[0].shape[2] - 1
+    assert nzl * len(plans) == nzc
+    return np.concatenate([a[:, :, :nzl] for a in parts] + [parts[0][:, :, nzl:]], axis=2)
+
+
+@pytest.mark.parametrize("nranks", [2, 4])
+@pytest.mark.parametrize("shape,dtype,exact", [((64, 32, 128), np.complex64, False), ((32, 64, 64), np.complex64, True),
+                                                ((32, 16, 64), np.complex128, False)])
+def test_slab_ranks_default_call_and_newtonian_potential(hip, dpower, shape, dtype, exact, nranks):
+    """generate_delta_field(save_potential=True) + calculate_newtonian_potential (generate.py:200-217, 282-350) on kz-slab
+    ranks: field, saved potential (every rank keeps its planes of delta(k)/k**2; fused second store stream of the
+    generation pass for the native float32 generator, generate -> divide -> transform otherwise) and the transform of the
+    scaled potential equal the single-rank results."""
+    k, Pk = dpower
+    nx, ny, nz = shape
+    tol = 2e-6 if dtype == np.complex64 else 1e-13
+    one = make_plan(hip, shape, dtype, k, Pk)
+    one.set_exact_generation(exact)
+    one.realise_potential(seed=9)
+    ref = one.download_real()
+    std = one.moments()[1]
+    one.load_potential(1.0)
+    pref = one.download_k()
+    one.load_potential(-1.5)
+    one.execute_c2r()
+    phiref = one.download_real()
+    plans = _slab_plans(hip, shape, dtype, k, Pk, nranks, exact)
+    field = _slab_run(hip, plans, seed=9, source="potential")
+    assert np.max(np.abs(field - ref)) <= tol * std
+    def pot(p):
+        p.load_potential(1.0)
+        return p.download_k()
+    assert plans[1].k_shape == (nx, ny, nz // 2 // nranks + 1)
+    got = _slab_side_array(plans, pot, nz // 2)
+    assert np.max(np.abs(got - pref)) <= tol * np.max(np.abs(pref))
+    for p in plans:
+        p.load_potential(-1.5)
+    phi = _slab_run(hip, plans, source="kspace")
+    assert np.max(np.abs(phi - phiref)) <= tol * phiref.std()
+    # lensing scan along z: rows are local to the x slabs
+    cot = 1.0 / (1.0 + np.arange(nz))
+    one.lensing_potential(cot, SPACING, 2)
+    lref = one.download_aux()
+    for p in plans:
+        p.lensing_potential(cot, SPACING, 2)
+    lens = np.concatenate([p.download_aux() for p in plans], axis=0)
+    assert np.max(np.abs(lens - lref)) <= 10 * tol * np.abs(lref).max()
+    for p in plans + [one]:
+        p.close()
+
+
+@pytest.mark.parametrize("nranks", [2, 4])
+def test_slab_ranks_reference_stream(hip, dpower, nranks):
+    """rng='reference' on kz-slab ranks: every rank replays RandomState(seed).normal on the GPU and keeps the deviates of
+    its own planes; host-supplied deviates are cut the same way.  Field = the single-rank field = the reference's."""
+    k, Pk = dpower
+    shape = (32, 32, 64)
+    nx, ny, nz = shape
+    seed = 321
+    noise = cpu_ref.reference_noise(seed, nx * ny * (nz // 2 + 1))
+    ref, rms = cpu_ref.generate_delta_field(nx, ny, nz, SPACING, k, Pk, noise=noise, double_fft=True)
+    plans = _slab_plans(hip, shape, np.complex64, k, Pk, nranks)
+    for p in plans:
+        p.reference_noise(seed)
+    got = _slab_side_array(plans, lambda p: p.download_noise().reshape(p.k_shape + (2,)), nz // 2)
+    assert np.max(np.abs(got.reshape(-1) - noise) / np.maximum(np.abs(noise), 1e-300)) <= 1e-14   # numpy's stream, value for value
+    field = _slab_run(hip, plans, noise="resident")
+    assert np.max(np.abs(field - ref)) <= TOL_F32 * rms
+    field = _slab_run(hip, plans, noise=noise)                          # host deviates, exact reference chain
+    assert np.max(np.abs(field - ref)) <= TOL_F32 * rms
+    field = _slab_run(hip, plans, noise="resident", source="potential")  # the default call with the reference's stream
+    assert np.max(np.abs(field - ref)) <= TOL_F32 * rms
+    def pot(p):
+        p.load_potential(1.0)
+        return p.download_k()
+    kref = cpu_ref.generate_kspace(nx, ny, nz, SPACING, k, Pk, noise=noise)
+    from randomfield_amd import powertools
+    kx2, ky2, kz2 = powertools.ksq_axes(nx, ny, nz, SPACING)
+    k2 = (kx2[:, None, None] + ky2[None, :, None] + kz2[None, None, :]).astype(np.float32)
+    k2[0, 0, 0] = np.inf
+    assert np.max(np.abs(_slab_side_array(plans, pot, nz // 2) - kref / k2)) <= 2e-6 * np.max(np.abs(kref / k2))
+    for p in plans:
+        p.close()
