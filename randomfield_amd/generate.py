@@ -87,20 +87,35 @@ class Generator(object):
         generate.py:117-118), for :meth:`calculate_lensing_potential`.
     curvature_K : float, optional
         Curvature constant K in (Mpc/h)**-2 (generate.py:380-381: -Ok0 (H0/c)**2); 0 = flat.
+    distributed : bool, optional
+        One process per GPU (RANK / WORLD_SIZE / LOCAL_RANK from the environment, as ``torch.distributed.run`` sets
+        them): k space is split by kz planes, the field by x planes, and every method works on this rank's
+        ``nx / WORLD_SIZE`` planes of the field (``data_out`` has that many; see :mod:`randomfield_amd.slab`).  All ranks
+        must make the same calls with the same arguments; ``seed=None`` is agreed between the ranks.
     """
 
     def __init__(self, nx, ny, nz, grid_spacing_Mpc_h, num_plot_sections=4, cosmology=None, power=None,
                  verbose=False, *, backend=None, dtype=np.complex64, rng="reference", growth_function=None,
-                 mean_matter_density=None, redshifts=None, transverse_distance=None, curvature_K=0.0):
+                 mean_matter_density=None, redshifts=None, transverse_distance=None, curvature_K=0.0, distributed=False):
         self.backend = transform.resolve_backend(backend)
+        self.distributed = bool(distributed)
+        if self.distributed and self.backend != "hip":
+            raise ValueError("distributed=True needs backend='hip'.")
         if rng not in ("reference", "native"):
             raise ValueError("Invalid rng: {0} (expected 'reference' or 'native').".format(rng))
         if rng == "native" and self.backend != "hip":
             raise ValueError("rng='native' is the GPU generator; it needs backend='hip'.")
         self.rng = rng
-        self.plan_c2r = transform.Plan(shape=(nx, ny, nz), dtype_in=dtype, packed=True, overwrite=True,
-                                       inverse=True, use_pyfftw=True, backend=self.backend)
-        self.plan_r2c = self.plan_c2r.create_reverse_plan(reuse_output=True, overwrite=True)
+        if self.distributed:
+            from . import slab
+            if (nx | ny | nz) & 1:
+                raise ValueError("All shape dimensions must be even.")
+            self.plan_c2r = slab.SlabHostPlan(slab.DistributedPlan(nx, ny, nz, dtype), dtype)
+            self.plan_r2c = None         # the forward transform is single-GPU (and the reference never executes this plan)
+        else:
+            self.plan_c2r = transform.Plan(shape=(nx, ny, nz), dtype_in=dtype, packed=True, overwrite=True,
+                                           inverse=True, use_pyfftw=True, backend=self.backend)
+            self.plan_r2c = self.plan_c2r.create_reverse_plan(reuse_output=True, overwrite=True)
         self.grid_spacing_Mpc_h = grid_spacing_Mpc_h
         self.k_min, self.k_max = powertools.get_k_bounds(self.plan_c2r.data_in, grid_spacing_Mpc_h, packed=True)
         self.potential = None
@@ -142,7 +157,7 @@ class Generator(object):
 
         self.verbose = verbose
         if self.verbose:
-            Mb = (self.plan_c2r.nbytes_allocated + self.plan_r2c.nbytes_allocated) / 2.0 ** 20
+            Mb = (self.plan_c2r.nbytes_allocated + (self.plan_r2c.nbytes_allocated if self.plan_r2c else 0)) / 2.0 ** 20
             print("Allocated {0:.1f} Mb for {1} x {2} x {3} grid.".format(Mb, nx, ny, nz))
             print("{0} Mpc/h spacing covered by k = {1:.5f} - {2:.5f} h/Mpc."
                   .format(self.grid_spacing_Mpc_h, self.k_min, self.k_max))
@@ -157,6 +172,8 @@ class Generator(object):
     def _native_seed(self, seed):
         if seed is None:
             seed = int.from_bytes(os.urandom(8), "little")
+            if self.distributed:
+                seed = self.plan_c2r.agree_on(seed >> 12)          # 52 bits survive the float64 all-reduce
         return int(seed) & (2 ** 64 - 1)
 
     def generate_delta_field(self, smoothing_length_Mpc_h=0., seed=None, save_potential=True, show_plot=False,
@@ -208,6 +225,8 @@ class Generator(object):
             if self.rng == "reference":
                 # RandomState(seed).normal (random.py:24): MT19937 + polar method replayed on the GPU from the seed's
                 # 624-word start state -- integer seeds, array seeds (init_by_array) and None alike; no host deviates
+                if seed is None and self.distributed:
+                    seed = self.plan_c2r.agree_on(int.from_bytes(os.urandom(4), "little"))
                 dev.reference_noise(seed)
                 noise = "resident"
                 dseed = 0

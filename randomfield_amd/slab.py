@@ -20,7 +20,7 @@ import os
 import numpy as np
 
 __all__ = ["slab_layout", "exchange_blocks", "gather_rows", "exchange_unique_id", "init_process_group",
-           "DistributedPlan"]
+           "DistributedPlan", "SlabHostPlan"]
 
 
 def slab_layout(nx, ny, nz, nranks, rank):
@@ -137,3 +137,28 @@ class DistributedPlan(object):
 
     def allreduce(self, values, op="sum"):
         return self.plan.allreduce(values, op)
+
+
+class SlabHostPlan(object):
+    """What :class:`randomfield_amd.generate.Generator` needs from ``transform.Plan``, for one rank of a multi-GPU job:
+    the global ``shape``, this rank's host window of the real-space field (``data_out_padded`` (nx/ranks, ny, nz+2) and
+    its ``data_out`` view, aliasing as transform.py:227-235) and the device plan.  There is no host-side k-space array:
+    k space lives on the devices, split by kz planes."""
+
+    def __init__(self, dist, dtype=np.complex64):
+        self.dist = dist
+        self.device = dist.plan
+        nx, ny, nz = dist.plan.nx, dist.plan.ny, dist.plan.nz
+        self.shape = (nx, ny, nz)
+        self.inverse, self.packed, self.overwrite, self.backend = True, True, True, "hip"
+        rt = dist.plan.real_dtype
+        self.data_out_padded = np.empty((dist.plan.nx_local, ny, nz + 2), rt)
+        self.data_out = self.data_out_padded[:, :, :nz]
+        # shape-only stand-in for the (nx, ny, nz/2+1) complex array the reference allocates on the host (zero strides:
+        # one element of memory); the shape rules that look at it (transform.py:46-60) still apply
+        self.data_in = np.lib.stride_tricks.as_strided(np.zeros(1, dtype), shape=(nx, ny, nz // 2 + 1), strides=(0, 0, 0))
+        self.nbytes_allocated = self.data_out_padded.nbytes
+
+    def agree_on(self, value):
+        """The same integer on every rank (max over ranks; exact below 2**53)."""
+        return int(self.dist.allreduce([float(value)], op="max")[0])

@@ -1166,3 +1166,30 @@ def test_slab_ranks_reference_stream(hip, dpower, nranks):
     assert np.max(np.abs(_slab_side_array(plans, pot, nz // 2) - kref / k2)) <= 2e-6 * np.max(np.abs(kref / k2))
     for p in plans:
         p.close()
+
+
+def test_distributed_generator_single_rank(hip, monkeypatch):
+    """Generator(distributed=True) with WORLD_SIZE = 1: the per-rank plumbing (SlabHostPlan window, agreed seeds, local
+    potential / lensing downloads) gives the ordinary Generator's results.  With more ranks the same calls run the slab
+    pipeline that the virtual-rank tests above check step by step."""
+    from randomfield_amd import Generator
+    for key, val in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0")):
+        monkeypatch.setenv(key, val)
+    nz = 64
+    z = np.linspace(0, 0.1, nz)
+    kw = dict(growth_function=np.exp(-z), mean_matter_density=1 + z, redshifts=z, transverse_distance=np.arange(nz) * 2.5)
+    for rng_kind in ("reference", "native"):
+        one = Generator(32, 32, nz, 2.5, rng=rng_kind, **kw)
+        dist = Generator(32, 32, nz, 2.5, rng=rng_kind, distributed=True, **kw)
+        assert dist.plan_c2r.data_out.shape == (32, 32, nz) and dist.plan_r2c is None
+        a = one.generate_delta_field(seed=5).copy()
+        b = dist.generate_delta_field(seed=5).copy()
+        assert np.array_equal(a, b) and one.delta_field_rms == dist.delta_field_rms
+        assert np.array_equal(one.potential.download(), dist.potential.download())
+        pa, pb = one.calculate_newtonian_potential(scale=-1.5).copy(), dist.calculate_newtonian_potential(scale=-1.5).copy()
+        assert np.array_equal(pa, pb)
+        assert np.array_equal(one.calculate_lensing_potential(), dist.calculate_lensing_potential())
+        one.generate_delta_field(seed=5, save_potential=False)
+        dist.generate_delta_field(seed=5, save_potential=False)
+        assert np.array_equal(one.convert_delta_to_density(), dist.convert_delta_to_density())
+        assert dist.generate_delta_field(seed=None, save_potential=False).shape == (32, 32, nz)   # agreed seed path
