@@ -89,6 +89,12 @@ int rf_generate(rf_plan* plan, uint64_t seed, int mode, const double* noise_host
  * receives the number of accepted polar attempts that were generated. */
 int rf_mt_set_jump(rf_plan* plan, int npolys, const uint16_t* pos, const int* npos, int stride, int blocks_per_segment, int radix);
 int rf_noise_mt19937(rf_plan* plan, const uint32_t* state624, unsigned long long* accepted);
+/* single = 1 (a request, honoured by float32 plans that have the fast generation pass; others keep float64): keep the
+ * deviates as float32 pairs instead -- half the memory traffic of the replay and of
+ * the generation pass that reads them; accept / reject stays in float64, f = sqrt(-2 log r2 / r2) is formed in float32
+ * (1e-7 relative).  rf_realise / rf_realise_potential with RF_NOISE_RESIDENT use whichever copy is resident; rf_generate,
+ * rf_download_noise and float64 plans need the float64 ones (single = 0, = rf_noise_mt19937). */
+int rf_noise_mt19937_ex(rf_plan* plan, const uint32_t* state624, unsigned long long* accepted, int single);
 /* copy deviates [first, first+count) of the device noise buffer to the host (tests) */
 int rf_download_noise(rf_plan* plan, double* host, unsigned long long first, unsigned long long count);
 

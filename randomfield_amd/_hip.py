@@ -42,6 +42,8 @@ SIGNATURES = {
                                       ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "rf_noise_mt19937": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32),
                                         ctypes.POINTER(ctypes.c_ulonglong)]),
+    "rf_noise_mt19937_ex": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32),
+                                           ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]),
     "rf_download_noise": (ctypes.c_int, [ctypes.c_void_p, _c_dp, ctypes.c_ulonglong, ctypes.c_ulonglong]),
     "rf_execute_c2r": (ctypes.c_int, [ctypes.c_void_p]),
     "rf_execute_r2c": (ctypes.c_int, [ctypes.c_void_p]),
@@ -238,10 +240,12 @@ class DevicePlan(object):
 
     # -- generation / transforms -----------------------------------------
     # -- the reference's noise stream generated on the GPU --------------------
-    def reference_noise(self, seed):
+    def reference_noise(self, seed, single=False):
         """Fill the device noise buffer with ``RandomState(seed).normal(size=2*M)`` (MT19937 + polar
         method replayed on the GPU) for any seed numpy's legacy seeding accepts: an integer < 2**32, an
-        array of integers (``init_by_array``) or None.  Afterwards pass ``noise='resident'``."""
+        array of integers (``init_by_array``) or None.  Afterwards pass ``noise='resident'``.
+        ``single=True`` (complex64 plans) keeps float32 copies of the deviates instead of the float64 values: the fused
+        ``realise`` / ``realise_potential`` read half as many bytes; ``generate`` and ``download_noise`` need float64."""
         from . import mt19937
         if not getattr(self, "_mt_ready", False):
             polys = mt19937.tree_polynomials(4)
@@ -257,8 +261,8 @@ class DevicePlan(object):
             self._mt_ready = True
         state = np.ascontiguousarray(mt19937.seed_state(seed), np.uint32)
         acc = ctypes.c_ulonglong(0)
-        check(self._lib.rf_noise_mt19937(self._h, state.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)),
-                                         ctypes.byref(acc)), "rf_noise_mt19937")
+        check(self._lib.rf_noise_mt19937_ex(self._h, state.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)),
+                                            ctypes.byref(acc), 1 if single else 0), "rf_noise_mt19937_ex")
         return acc.value
 
     def lensing_potential(self, cot_z, spacing, i_min):

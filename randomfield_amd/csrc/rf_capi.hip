@@ -124,6 +124,9 @@ struct rf_plan {
   double* noise = nullptr;
   size_t noise_cap = 0;
   bool noise_resident = false;            // the device noise buffer holds a full set of deviates
+  float* noise32 = nullptr;               // the same deviates as float32 pairs (rf_noise_mt19937_ex(single = 1)); only one
+  size_t noise32_cap = 0;                 // of the two buffers is valid at a time
+  bool noise32_resident = false;
   // MT19937 replay (rf_noise_mt19937): jump-polynomial bit positions per tree level, scratch
   uint32_t* mt_pos = nullptr;          // set-bit positions of the jump polynomials, widened to 32 bits (scalar loads)
   std::vector<int> mt_npos;
@@ -215,7 +218,7 @@ int ensure_noise(rf_plan* p) {
 
 int upload_noise(rf_plan* p, int mode, const double* noise_host) {
   if (mode == RF_NOISE_RESIDENT) {
-    RF_REQUIRE(p->noise_resident, "no deviates resident on the device: call rf_noise_mt19937 (or an external-noise run) first");
+    RF_REQUIRE(p->noise_resident || p->noise32_resident, "no deviates resident on the device: call rf_noise_mt19937 (or an external-noise run) first");
     return 0;
   }
   if (mode != RF_NOISE_EXTERNAL) return 0;
@@ -231,6 +234,7 @@ int upload_noise(rf_plan* p, int mode, const double* noise_host) {
     RF_HIP(hipMemcpy2DAsync((char*)p->noise + (size_t)p->nzl * cell, dp, (const char*)noise_host + (size_t)p->nzc * cell, hp, cell, rows, hipMemcpyHostToDevice, p->stream));
   }
   p->noise_resident = true;
+  p->noise32_resident = false;
   return 0;
 }
 
@@ -240,7 +244,7 @@ FastGenParams make_fast(rf_plan* p, uint64_t seed, bool seed_from_dev, const uin
   f.dkx = p->fdkx; f.dky = p->fdky; f.dkz = p->fdkz;
   f.rec = p->frec; f.nbins = p->fnbins; f.u_scale = p->fu_scale; f.u_off = p->fu_off;
   f.seed = seed; f.seed_dev = seed_from_dev ? seed_ptr : nullptr;
-  f.noise = nullptr;
+  f.noise = nullptr; f.noise32 = nullptr;
   f.zpitch = p->nzl + 1; f.zoff = p->kz0;
   return f;
 }
@@ -299,8 +303,11 @@ int build_fast(rf_plan* p) {
 int queue_x(rf_plan* p, const GenParams& gp, const void* kspace, void* W, hipStream_t sx, bool timed = false) {
   // resident deviates (the numpy stream replayed by rf_noise_mt19937) take the fast float32 sigma path too; host-supplied
   // deviates (RF_NOISE_EXTERNAL, the parity mode) keep the exact reference dtype chain
+  // (float32 copies of the deviates exist for this path only, and it can store the potential too; float64 ones cannot)
   const bool fast_noise = !kspace && gp.noise_mode == NOISE_EXTERNAL && p->resident_fast && p->have_fast && !p->exact_gen &&
-                          !p->f64 && !p->pot_target && !(p->replicate && p->nranks > 1);
+                          !p->f64 && !(p->replicate && p->nranks > 1) && (p->noise32_resident || !p->pot_target);
+  RF_REQUIRE(kspace || gp.noise_mode != NOISE_EXTERNAL || fast_noise || p->noise_resident,
+             "only float32 copies of the deviates are resident: this path (exact chain / float64 plan) needs rf_noise_mt19937's float64 ones");
   const bool fast = (!kspace && gp.noise_mode == NOISE_PHILOX && p->have_fast && !p->exact_gen) || fast_noise;
   const bool rep = p->replicate && p->nranks > 1;
   RF_REQUIRE(!rep || fast, "replicated generation needs the native generator (fast path)");
@@ -309,7 +316,8 @@ int queue_x(rf_plan* p, const GenParams& gp, const void* kspace, void* W, hipStr
   const ColGeom gx{(long long)p->ny * nzl, 0, (long long)p->ny * nzl};
   if (timed) { RF_HIP(hipEventRecord(p->ev[5], sx)); p->repair_timed = fast; }   // overwritten by the launcher if it splits
   FastGenParams fgp = make_fast(p, gp.seed, gp.seed_dev != nullptr, gp.seed_dev);
-  if (fast_noise) fgp.noise = gp.noise;
+  if (fast_noise && p->noise32_resident) fgp.noise32 = reinterpret_cast<const cplx<float>*>(p->noise32);
+  else if (fast_noise) fgp.noise = gp.noise;
   if (fast)
     RF_HIP(launch_col_fastgen(p->f64, p->nx, W, gx, (long long)p->ny * nzl, fgp,
                               kz0, (int)nzl, p->tw_x, sx, false, timed ? p->ev[5] : nullptr,
@@ -468,6 +476,7 @@ int queue_c2r(rf_plan* p, const GenParams& gp, const void* kspace) {
   if (p->generic) {
     RF_HIP(hipEventRecord(p->ev[0], p->stream));
     if (!kspace) {                                  // rows K,T,R,S into the API-layout buffer first
+      RF_REQUIRE(gp.noise_mode != NOISE_EXTERNAL || p->noise_resident, "no float64 deviates resident on the device");
       if (int rc = ensure_k(p)) return rc;
       RF_HIP(launch_gen_kspace(p->f64, p->K, gp, p->stream));
       p->k_valid = true;
@@ -733,7 +742,7 @@ int rf_plan_destroy(rf_plan* p) {
   if (p->comm_stream) { (void)hipStreamSynchronize(p->comm_stream); (void)hipStreamDestroy(p->comm_stream); }
   for (auto& e : p->pev) if (e) (void)hipEventDestroy(e);
   void* bufs[] = {p->W, p->R, p->W2, p->R2, p->K, p->P, p->G, p->tw_x, p->tw_y, p->tw_z, p->kx2, p->ky2, p->kz2, p->xt, p->st, p->sl, p->bin,
-                  p->noise, p->mt_pos, p->mt_npos_dev, p->mt_states, p->mt_counts, p->mt_offsets, p->partials, p->stats, p->seeds_dev, p->ztab, p->frec, p->coll_scratch};
+                  p->noise, p->noise32, p->mt_pos, p->mt_npos_dev, p->mt_states, p->mt_counts, p->mt_offsets, p->partials, p->stats, p->seeds_dev, p->ztab, p->frec, p->coll_scratch};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   for (int i = 0; i < 2; ++i) {
@@ -833,6 +842,7 @@ int rf_generate(rf_plan* p, uint64_t seed, int mode, const double* noise_host) {
   RF_HIP(hipSetDevice(p->device));
   if (int rc = ensure_k(p)) return rc;        // a kz-slab rank holds (and generates) its own planes + the Nyquist plane
   if (int rc = upload_noise(p, mode, noise_host)) return rc;
+  RF_REQUIRE(mode != RF_NOISE_RESIDENT || p->noise_resident, "rf_generate needs float64 deviates: only float32 copies are resident");
   RF_HIP(launch_gen_kspace(p->f64, p->K, make_gen(p, seed, mode, false), p->stream));
   if (mode == RF_NOISE_EXTERNAL) RF_HIP(hipStreamSynchronize(p->stream));  // host noise buffer may be released by the caller
   p->k_valid = true;
@@ -909,7 +919,8 @@ static int potential_forward(rf_plan* p, uint64_t seed, int mode, const double* 
   RF_REQUIRE(mode == RF_NOISE_NATIVE || mode == RF_NOISE_EXTERNAL || mode == RF_NOISE_RESIDENT, "invalid noise mode");
   RF_REQUIRE(!(p->replicate && p->nranks > 1), "replicated-generation plans keep no k-space potential: clear RF_FLAG_REPLICATED_GENERATION");
   RF_HIP(hipSetDevice(p->device));
-  const bool fused = mode == RF_NOISE_NATIVE && p->have_fast && !p->exact_gen && !p->f64 && !p->generic;
+  const bool fused = (mode == RF_NOISE_NATIVE || (mode == RF_NOISE_RESIDENT && p->noise32_resident)) && p->have_fast &&
+                     !p->exact_gen && !p->f64 && !p->generic;
   if (!fused) {
     if (int rc = rf_generate(p, seed, mode, noise_host)) return rc;
     if (int rc = rf_save_potential(p)) return rc;
@@ -919,9 +930,11 @@ static int potential_forward(rf_plan* p, uint64_t seed, int mode, const double* 
   if (!p->P) RF_HIP(hipMalloc(&p->P, p->k_bytes));
   p->timed = whole;
   p->pot_target = p->P;
+  p->resident_fast = (mode == RF_NOISE_RESIDENT);
   const GenParams gp = make_gen(p, seed, mode, false);
   const int rc = whole ? queue_c2r(p, gp, nullptr) : queue_xy(p, gp, nullptr, p->W, p->stream, false);
   p->pot_target = nullptr;
+  p->resident_fast = false;
   return rc;
 }
 
@@ -1295,11 +1308,28 @@ int rf_mt_set_jump(rf_plan* p, int npolys, const uint16_t* pos, const int* npos,
 }
 
 int rf_noise_mt19937(rf_plan* p, const uint32_t* state624, unsigned long long* accepted) {
+  return rf_noise_mt19937_ex(p, state624, accepted, 0);
+}
+
+int rf_noise_mt19937_ex(rf_plan* p, const uint32_t* state624, unsigned long long* accepted, int single) {
   RF_REQUIRE(p && state624, "null argument");
+  // `single` is a request: plans without the fast float32 generation pass (float64, generic shapes, exact-generation
+  // flag, tables too dense for the per-bin records) read float64 deviates and get them
+  if (single && (p->f64 || p->generic || !p->have_fast || p->exact_gen)) single = 0;
   RF_REQUIRE(!p->unpacked, "this call does not apply to an unpacked c2c plan");
   RF_REQUIRE(p->mt_pos && !p->mt_npos.empty(), "rf_mt_set_jump must be called first");
   RF_HIP(hipSetDevice(p->device));
-  if (int rc = ensure_noise(p)) return rc;
+  if (single) {
+    const size_t n = 2 * (size_t)p->nx * p->ny * (p->nzl + 1);
+    if (p->noise32_cap < n) {
+      if (p->noise32) RF_HIP(hipFree(p->noise32));
+      p->noise32 = nullptr; p->noise32_cap = 0; p->noise32_resident = false;
+      RF_HIP(hipMalloc((void**)&p->noise32, n * sizeof(float)));
+      p->noise32_cap = n;
+    }
+  } else if (int rc = ensure_noise(p)) {
+    return rc;
+  }
   const unsigned long long ncells = (unsigned long long)p->nx * p->ny * (p->nzc + 1);
   // polar attempts to generate: acceptance pi/4, margin of 10 sigma + 1024 (mt19937.attempts_needed)
   const double pa = 0.78539816339744830962;
@@ -1345,15 +1375,17 @@ int rf_noise_mt19937(rf_plan* p, const uint32_t* state624, unsigned long long* a
   RF_REQUIRE(total >= ncells, "MT19937 replay: not enough accepted polar attempts (increase the margin)");
   // a kz-slab rank replays the WHOLE stream (the destination of a deviate depends on every earlier acceptance) and keeps
   // the deviates of its own planes: the replay is replicated work, not distributed
-  RF_HIP(launch_mt_polar(true, p->mt_states, nseg, p->mt_bps, total_blocks, p->mt_counts, p->mt_offsets, p->noise, ncells, (int)p->nzc + 1, (int)p->nzl + 1, p->kz0, s));
-  p->noise_resident = true;
+  RF_HIP(launch_mt_polar(true, p->mt_states, nseg, p->mt_bps, total_blocks, p->mt_counts, p->mt_offsets,
+                         single ? reinterpret_cast<double*>(p->noise32) : p->noise, ncells, (int)p->nzc + 1, (int)p->nzl + 1, p->kz0, s, single != 0));
+  p->noise_resident = !single;
+  p->noise32_resident = single != 0;
   return 0;
 }
 
 int rf_download_noise(rf_plan* p, double* host, unsigned long long first, unsigned long long count) {
   RF_REQUIRE(p && host, "null argument");
   RF_REQUIRE(!p->unpacked, "this call does not apply to an unpacked c2c plan");
-  RF_REQUIRE(p->noise_resident, "no deviates resident on the device");
+  RF_REQUIRE(p->noise_resident, "no float64 deviates resident on the device");
   RF_REQUIRE(first + count <= 2ull * p->nx * p->ny * (p->nzl + 1), "range outside the noise buffer");
   RF_HIP(hipSetDevice(p->device));
   RF_HIP(hipMemcpyAsync(host, p->noise + first, count * sizeof(double), hipMemcpyDeviceToHost, p->stream));

@@ -414,6 +414,7 @@ struct FastGenParams {
   const double* noise;    // SRC = 1 kernels: resident float64 deviates in the reference's order (random.py:24-28),
                           // 2 per cell of the API layout [nx][ny][nz/2+1]
   int zpitch, zoff;       // row pitch and first plane of the side arrays (noise, potential): see GenParams
+  const cplx<float>* noise32;   // SRC = 2 kernels: the same deviates as float32 pairs (g_re, g_im), one per cell
 };
 enum { FAST_LDS_BINS = 512 };
 
@@ -534,23 +535,36 @@ RF_HD cplx<float> fast_fix_kz0(const FastGenParams& g, const FastRec* rec, uint6
 }
 
 // The same slot from resident deviates (the reference's stream, e.g. replayed MT19937): cell = sigma * (g_re + i g_im)
-// with the float64 product rounded once (random.py:28), symmetrised as above.
+// with the float64 product rounded once (random.py:28), symmetrised as above.  SRC = 1: float64 deviates; SRC = 2: the
+// float32 copies (float32 plans: the product is then formed in float32, 6e-8 relative from the once-rounded one).
+template <int SRC>
 RF_HD cplx<float> fast_noise_cell(const FastGenParams& g, const FastRec* rec, int ix, int iy, int kz, float k2) {
-  const double* d = g.noise + 2 * (((long long)ix * g.ny + iy) * g.zpitch + side_slot(g, kz));
+  const long long c = ((long long)ix * g.ny + iy) * g.zpitch + side_slot(g, kz);
+  if (SRC == 2) {
+    const float s = fast_sigma(g, rec, k2);
+    const cplx<float> d = g.noise32[c];
+    return mk<float>(s * d.x, s * d.y);
+  }
+  const double* d = g.noise + 2 * c;
   const double s = (double)fast_sigma(g, rec, k2);
   return mk<float>((float)(s * d[0]), (float)(s * d[1]));
 }
-RF_HD cplx<float> fast_fix_kz0_noise(const FastGenParams& g, const FastRec* rec, int ix, int iy) {
+// p0, pn: delta(k) / k^2 of the two symmetrised cells, as fast_fix_kz0()
+template <int SRC>
+RF_HD cplx<float> fast_fix_kz0_noise(const FastGenParams& g, const FastRec* rec, int ix, int iy, cplx<float>& p0, cplx<float>& pn) {
   const int nzc = g.nz / 2;
   const int role = sym_role(g.nx, g.ny, ix, iy);
   int sx = ix, sy = iy;
   if (role == RF_DEST) { sx = (g.nx - ix) % g.nx; sy = (g.ny - iy) % g.ny; }
   const float kxy_s = fast_kxy2(g, sx, sy);
-  cplx<float> a = fast_noise_cell(g, rec, sx, sy, 0, fast_k2(g, kxy_s, 0));
-  cplx<float> n = fast_noise_cell(g, rec, sx, sy, nzc, fast_k2(g, kxy_s, nzc));
+  cplx<float> a = fast_noise_cell<SRC>(g, rec, sx, sy, 0, fast_k2(g, kxy_s, 0));
+  cplx<float> n = fast_noise_cell<SRC>(g, rec, sx, sy, nzc, fast_k2(g, kxy_s, nzc));
   if (role == RF_DEST) { a.y = -a.y; n.y = -n.y; }
   if (role == RF_SELF) { a.y = 0.0f; n.y = 0.0f; }
   if (ix == 0 && iy == 0) a = mk<float>(0.0f, 0.0f);
+  const float r0 = (ix == 0 && iy == 0) ? 0.0f : fast_rcp(fast_k2(g, kxy_s, 0)), rn = fast_rcp(fast_k2(g, kxy_s, nzc));
+  p0 = mk<float>(a.x * r0, a.y * r0);
+  pn = mk<float>(n.x * rn, n.y * rn);
   return mk<float>(a.x - n.y, a.y + n.x);
 }
 

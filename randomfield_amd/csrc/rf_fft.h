@@ -204,7 +204,8 @@ template <typename T, bool WIDE = false> struct GenColIO {
 // POT: 1 = the pass also stores delta(k) / k^2 (0 at DC) of every generated cell into `pot`, an API-layout array
 // [nx][ny][nz/2+1] -- the save_potential=True branch of generate_delta_field (generate.py:200-217) without ever
 // materialising delta(k) itself.  (Rows of nz/2+1 cells are only 8-byte aligned: two 8-byte stores per lane.)
-// SRC: 0 = native Philox + Box-Muller draws; 1 = deviates resident in device memory (the reference's numpy stream,
+// SRC: 0 = native Philox + Box-Muller draws; 1 = deviates resident in device memory as float64 (2 = as float32 pairs;
+// the reference's numpy stream,
 // rng='reference'): same float32 |k| and sigma arithmetic, the draw replaced by two 16-byte loads per lane.  The field
 // then differs from the exact-chain kernel's by the float32 sigma rounding only (<= 1e-6 relative, far inside the
 // 1e-5 * rms parity tolerance) and the pass is HBM-bound (12.9 GB) instead of latency-bound on table lookups.
@@ -258,7 +259,7 @@ struct FastGenColIOT {
     const float k2a = fast_k2(gp, kxy, kz), k2b = fast_k2(gp, kxy, kz + 1);
     if (SRC == 0) {
       fast_gen_pair_at<AB>(gp, rec, seed, ctr_l + ctr_u, k2a, k2b, v.c[0], v.c[1]);
-    } else {
+    } else if (SRC == 1) {
       // cells (ix, iy, kz) and (ix, iy, kz + 1) are adjacent in the reference's order: 4 doubles, 32 contiguous bytes
       const int nzp = gp.zpitch;
       const double* d = (gp.noise + 2LL * ro * gp.ny * nzp) + 2u * (uint32_t)((rb * gp.ny + iy) * nzp + (kz - gp.zoff));
@@ -266,6 +267,14 @@ struct FastGenColIOT {
       const double sa = (double)fast_sigma(gp, rec, k2a), sb = (double)fast_sigma(gp, rec, k2b);
       v.c[0] = mk<float>((float)(sa * ga.c[0].x), (float)(sa * ga.c[0].y));
       v.c[1] = mk<float>((float)(sb * gb.c[0].x), (float)(sb * gb.c[0].y));
+    } else {
+      // float32 copies of the same deviates: 16 contiguous bytes (rows of zpitch = odd cells: 8-byte aligned only)
+      const int nzp = gp.zpitch;
+      const cplx<float>* d = (gp.noise32 + (long long)ro * gp.ny * nzp) + (uint32_t)((rb * gp.ny + iy) * nzp + (kz - gp.zoff));
+      const cplx<float> ga = d[0], gb = d[1];
+      const float sa = fast_sigma(gp, rec, k2a), sb = fast_sigma(gp, rec, k2b);
+      v.c[0] = mk<float>(sa * ga.x, sa * ga.y);
+      v.c[1] = mk<float>(sb * gb.x, sb * gb.y);
     }
     if (POT) {
       // row (ix, iy) of the API layout; the slot kz = 0 (Hermitian planes) is written by fix_value() instead
@@ -286,8 +295,8 @@ struct FastGenColIOT {
     const uint64_t seed = gp.seed;                                                      // bind_seed() ran first
     const int iy = (int)((unsigned)C >> nzl_shift());
     cplx<float> p0, pn;
-    if (SRC != 0) return fast_fix_kz0_noise(gp, rec, rb + ro, iy);
-    const cplx<float> packed = fast_fix_kz0(gp, rec, seed, rb + ro, iy, p0, pn);
+    const cplx<float> packed = SRC != 0 ? fast_fix_kz0_noise<SRC == 0 ? 1 : SRC>(gp, rec, rb + ro, iy, p0, pn)
+                                        : fast_fix_kz0(gp, rec, seed, rb + ro, iy, p0, pn);
     if (POT) {
       const int nzp = gp.zpitch;                 // only the rank with kz0 = 0 gets here: slot 0 = plane 0
       cplx<float>* row = pot + ((long long)(rb + ro) * gp.ny + iy) * nzp;

@@ -80,7 +80,7 @@ hipError_t launch_col_fastgen(int f64, int N, void* W, ColGeom g, long long ncol
                               const void* tw, hipStream_t s, bool po, hipEvent_t after_repair, int x0, int x1, void* pot) {
   if (!col_fastgen_supported(f64, N)) return po ? hipSuccess : hipErrorInvalidValue;    // the caller keeps the exact kernel
   const bool slab = x0 > 0 || x1 < N;          // replicated-generation mode: the SLAB instantiations guard their stores
-  if ((gp.noise || po) && !f64) {              // resident deviates (rng='reference') through the fast float32 sigma path
+  if ((gp.noise || po) && !f64) {              // resident float64 deviates (rng='reference') through the fast float32 sigma path
     if (gp.noise && (slab || pot)) return hipErrorInvalidValue;
     switch (N) {
 #define X(NN) case NN: { hipError_t e = launch_fast_one<typename GenSel<float, NN>::type, FastGenColIOT<0, 0, 0, 0, 1>, FastGenColIOT<0, 1, 0, 0, 1>, cplx<float>>(gp, (cplx<float>*)W, g, ncols, kz0, nzl, (const cplx<float>*)tw, s, po, after_repair, x0, x1); if (!po || e != hipSuccess) return e; break; }
@@ -89,6 +89,25 @@ hipError_t launch_col_fastgen(int f64, int N, void* W, ColGeom g, long long ncol
       default: return hipErrorInvalidValue;
     }
   } else if (gp.noise) {
+    return hipErrorInvalidValue;
+  }
+  if ((gp.noise32 || po) && !f64) {            // resident float32 deviates, without / with the potential store
+    if (gp.noise32 && slab) return hipErrorInvalidValue;
+    if (!pot || po)
+      switch (N) {
+#define X(NN) case NN: { hipError_t e = launch_fast_one<typename GenSel<float, NN>::type, FastGenColIOT<0, 0, 0, 0, 2>, FastGenColIOT<0, 1, 0, 0, 2>, cplx<float>>(gp, (cplx<float>*)W, g, ncols, kz0, nzl, (const cplx<float>*)tw, s, po, after_repair, x0, x1); if (!po || e != hipSuccess) return e; break; }
+        RF_COL_SIZES(X)
+#undef X
+        default: return hipErrorInvalidValue;
+      }
+    if (pot || po)
+      switch (N) {
+#define X(NN) case NN: { hipError_t e = launch_fast_one<typename GenSel<float, NN>::type, FastGenColIOT<0, 0, 0, 1, 2>, FastGenColIOT<0, 1, 0, 1, 2>, cplx<float>>(gp, (cplx<float>*)W, g, ncols, kz0, nzl, (const cplx<float>*)tw, s, po, after_repair, x0, x1, (cplx<float>*)pot); if (!po || e != hipSuccess) return e; break; }
+        RF_COL_SIZES(X)
+#undef X
+        default: return hipErrorInvalidValue;
+      }
+  } else if (gp.noise32) {
     return hipErrorInvalidValue;
   }
   if ((pot || po) && !f64) {                   // generation + potential store (save_potential=True), float32, whole grid

@@ -115,7 +115,11 @@ __global__ __launch_bounds__(640) void mt_jump_kernel(const uint32_t* __restrict
 // one wave execute in order; `volatile` keeps the compiler from reordering them).
 // FILL = false: counts[seg] = accepted attempts of the segment.
 // FILL = true: writes (f x2, f x1) of every accepted attempt whose cell index < ncells.
-template <bool FILL>
+// F32 (with FILL): the pair is written as two float32 -- for float32 plans, whose cells sigma * g are float32 anyway.
+// The accept / reject arithmetic stays in float64 (it decides WHICH cell a deviate belongs to); only
+// f = sqrt(-2 log(r2) / r2) is evaluated in float32 (hardware log2 / rcp / sqrt, 1 ulp each), with the rounding of r2 to
+// float32 compensated to first order so that the relative error stays at the 1e-7 level where log(r2) -> 0.
+template <bool FILL, bool F32>
 __global__ __launch_bounds__(256) void mt_polar_kernel(const uint32_t* __restrict__ states, int blocks_per_segment,
                                                        long long total_blocks, int nseg, unsigned long long* __restrict__ counts,
                                                        const unsigned long long* __restrict__ offsets,
@@ -128,7 +132,11 @@ __global__ __launch_bounds__(256) void mt_polar_kernel(const uint32_t* __restric
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long long seg = (long long)blockIdx.x * 4 + wave;
   if (seg >= nseg) return;                                   // whole waves leave; nobody waits at a barrier
-  volatile uint32_t* mt = lds[wave];
+  // an explicitly LDS-qualified pointer: a plain `volatile uint32_t*` is a GENERIC pointer to the compiler, and every
+  // access through it became a flat_load / flat_store (slow path into LDS, and ordered behind this wave's outstanding
+  // global stores of deviates through the shared vmcnt counter) instead of ds_read / ds_write
+  typedef __attribute__((address_space(3))) uint32_t lds_u32;
+  volatile lds_u32* mt = (volatile lds_u32*)(&lds[wave][0]);
   long long nb = total_blocks - seg * blocks_per_segment;
   if (nb > blocks_per_segment) nb = blocks_per_segment;
   const uint32_t* st = states + (size_t)seg * MT_N;
@@ -181,7 +189,14 @@ __global__ __launch_bounds__(256) void mt_polar_kernel(const uint32_t* __restric
           keep = sl >= 0 && sl < zpitch && (kz == nzh - 1 || sl < zpitch - 1);
           dst = col * (unsigned)zpitch + (unsigned)sl;
         }
-        if (keep) {
+        if (keep && F32) {
+          // log(r2) = log(r2f) + (r2 - r2f) / r2f: the hardware log2 (1 ulp of its result, also where it -> 0) of the
+          // rounded argument, plus the first-order term of the rounding (exact difference in float64)
+          const float r2f = (float)r2, inv = __builtin_amdgcn_rcpf(r2f);
+          const float lg = fmaf(__builtin_amdgcn_logf(r2f), 0.69314718056f, (float)(r2 - (double)r2f) * inv);
+          const float f = __builtin_amdgcn_sqrtf(-2.0f * lg * inv);
+          reinterpret_cast<float2*>(noise)[dst] = make_float2(f * (float)x2, f * (float)x1);
+        } else if (keep) {
           const double f = sqrt(-2.0 * log(r2) / r2);
           noise[2 * dst] = f * x2;                            // legacy_gauss returns f*x2 first, then the saved f*x1
           noise[2 * dst + 1] = f * x1;
@@ -229,10 +244,11 @@ hipError_t launch_mt_jump(uint32_t* states, const uint32_t* pos, const int* npos
 }
 hipError_t launch_mt_polar(bool fill, const uint32_t* states, int nseg, int blocks_per_segment, long long total_blocks,
                            unsigned long long* counts, const unsigned long long* offsets, double* noise,
-                           unsigned long long ncells, int nzh, int zpitch, int zoff, hipStream_t s) {
+                           unsigned long long ncells, int nzh, int zpitch, int zoff, hipStream_t s, bool single) {
   const unsigned grid = (unsigned)((nseg + 3) / 4);
-  if (fill) hipLaunchKernelGGL(mt_polar_kernel<true>, dim3(grid), dim3(256), 0, s, states, blocks_per_segment, total_blocks, nseg, counts, offsets, noise, ncells, nzh, zpitch, zoff);
-  else hipLaunchKernelGGL(mt_polar_kernel<false>, dim3(grid), dim3(256), 0, s, states, blocks_per_segment, total_blocks, nseg, counts, offsets, noise, ncells, nzh, zpitch, zoff);
+  if (fill && single) hipLaunchKernelGGL((mt_polar_kernel<true, true>), dim3(grid), dim3(256), 0, s, states, blocks_per_segment, total_blocks, nseg, counts, offsets, noise, ncells, nzh, zpitch, zoff);
+  else if (fill) hipLaunchKernelGGL((mt_polar_kernel<true, false>), dim3(grid), dim3(256), 0, s, states, blocks_per_segment, total_blocks, nseg, counts, offsets, noise, ncells, nzh, zpitch, zoff);
+  else hipLaunchKernelGGL((mt_polar_kernel<false, false>), dim3(grid), dim3(256), 0, s, states, blocks_per_segment, total_blocks, nseg, counts, offsets, noise, ncells, nzh, zpitch, zoff);
   return hipGetLastError();
 }
 hipError_t launch_mt_scan(const unsigned long long* counts, unsigned long long* offsets, int n, hipStream_t s) {

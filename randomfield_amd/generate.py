@@ -227,7 +227,8 @@ class Generator(object):
                 # 624-word start state -- integer seeds, array seeds (init_by_array) and None alike; no host deviates
                 if seed is None and self.distributed:
                     seed = self.plan_c2r.agree_on(int.from_bytes(os.urandom(4), "little"))
-                dev.reference_noise(seed)
+                # (a complex64 plan keeps float32 copies of the deviates: its cells sigma * g are float32 anyway)
+                dev.reference_noise(seed, single=self.plan_c2r.data_out.dtype == np.float32)
                 noise = "resident"
                 dseed = 0
             else:

@@ -1193,3 +1193,55 @@ def test_distributed_generator_single_rank(hip, monkeypatch):
         dist.generate_delta_field(seed=5, save_potential=False)
         assert np.array_equal(one.convert_delta_to_density(), dist.convert_delta_to_density())
         assert dist.generate_delta_field(seed=None, save_potential=False).shape == (32, 32, nz)   # agreed seed path
+
+
+def test_reference_stream_float32_copies(hip, dpower):
+    """rf_noise_mt19937_ex(single = 1): the replayed numpy stream kept as float32 pairs (what Generator(complex64,
+    rng='reference') uses).  Accept / reject is still float64, so every deviate lands in the same cell; the field, the
+    fused potential store and the kz-slab ranks agree with the float64 deviates to 3e-6 * rms (float32 rounding of g,
+    log1p near r2 = 1), inside the parity tolerance against the oracle."""
+    k, Pk = dpower
+    shape = (64, 32, 128)
+    nx, ny, nz = shape
+    seed = 77
+    noise = cpu_ref.reference_noise(seed, nx * ny * (nz // 2 + 1))
+    ref, rms = cpu_ref.generate_delta_field(nx, ny, nz, SPACING, k, Pk, noise=noise, double_fft=True)
+    plan = make_plan(hip, shape, np.complex64, k, Pk)
+    plan.reference_noise(seed, single=False)
+    plan.realise(noise="resident")
+    d64 = plan.download_real()
+    plan.reference_noise(seed, single=True)
+    with pytest.raises(RuntimeError):
+        plan.download_noise(0, 4)                                        # only float32 copies are resident now
+    with pytest.raises(RuntimeError):
+        plan.generate(noise="resident")                                  # the unfused generator reads float64 deviates
+    plan.realise(noise="resident")
+    d32 = plan.download_real()
+    assert np.max(np.abs(d32 - d64)) <= 3e-6 * rms and np.max(np.abs(d32 - ref)) <= TOL_F32 * rms
+    assert abs(plan.moments()[1] - rms) <= TOL_F32 * rms
+    plan.realise_potential(noise="resident")                             # fused: second store stream of the generation pass
+    assert np.max(np.abs(plan.download_real() - ref)) <= TOL_F32 * rms
+    plan.load_potential(1.0)
+    pot = plan.download_k()
+    kref = cpu_ref.generate_kspace(nx, ny, nz, SPACING, k, Pk, noise=noise)
+    from randomfield_amd import powertools
+    kx2, ky2, kz2 = powertools.ksq_axes(nx, ny, nz, SPACING)
+    k2 = (kx2[:, None, None] + ky2[None, :, None] + kz2[None, None, :]).astype(np.float32)
+    k2[0, 0, 0] = np.inf
+    assert np.max(np.abs(pot - kref / k2)) <= 2e-6 * np.max(np.abs(kref / k2))
+    # the exact-generation flag turns the request into float64 deviates (that chain reads nothing else)
+    plan.set_exact_generation(True)
+    plan.reference_noise(seed, single=True)
+    assert np.allclose(plan.download_noise(0, 8), noise[:8], rtol=1e-14, atol=0)
+    plan.close()
+    plans = _slab_plans(hip, shape, np.complex64, k, Pk, 4)
+    for p in plans:
+        p.reference_noise(seed, single=True)
+    field = _slab_run(hip, plans, noise="resident", source="potential")
+    assert np.max(np.abs(field - ref)) <= TOL_F32 * rms
+    def slab_pot(p):
+        p.load_potential(1.0)
+        return p.download_k()
+    assert np.max(np.abs(_slab_side_array(plans, slab_pot, nz // 2) - kref / k2)) <= 2e-6 * np.max(np.abs(kref / k2))
+    for p in plans:
+        p.close()
