@@ -135,6 +135,8 @@ struct rf_plan {
   uint32_t* mt_states = nullptr;
   unsigned long long *mt_counts = nullptr, *mt_offsets = nullptr;
   size_t mt_states_cap = 0, mt_seg_cap = 0;
+  void* mt_scratch = nullptr;          // one-pass replay: every segment's accepted pairs, densely from slot seg * (attempts per segment)
+  size_t mt_scratch_bytes = 0;
   double* partials = nullptr;
   long long npartials = 0;
   double* stats = nullptr;                // [2 * stats_cap] (sum, sumsq) per realisation
@@ -742,7 +744,7 @@ int rf_plan_destroy(rf_plan* p) {
   if (p->comm_stream) { (void)hipStreamSynchronize(p->comm_stream); (void)hipStreamDestroy(p->comm_stream); }
   for (auto& e : p->pev) if (e) (void)hipEventDestroy(e);
   void* bufs[] = {p->W, p->R, p->W2, p->R2, p->K, p->P, p->G, p->tw_x, p->tw_y, p->tw_z, p->kx2, p->ky2, p->kz2, p->xt, p->st, p->sl, p->bin,
-                  p->noise, p->noise32, p->mt_pos, p->mt_npos_dev, p->mt_states, p->mt_counts, p->mt_offsets, p->partials, p->stats, p->seeds_dev, p->ztab, p->frec, p->coll_scratch};
+                  p->noise, p->noise32, p->mt_scratch, p->mt_pos, p->mt_npos_dev, p->mt_states, p->mt_counts, p->mt_offsets, p->partials, p->stats, p->seeds_dev, p->ztab, p->frec, p->coll_scratch};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   for (int i = 0; i < 2; ++i) {
@@ -1366,17 +1368,29 @@ int rf_noise_mt19937_ex(rf_plan* p, const uint32_t* state624, unsigned long long
     RF_HIP(launch_mt_jump(p->mt_states, p->mt_pos + (size_t)t * (R - 1) * p->mt_stride, p->mt_npos_dev + t * (R - 1), p->mt_stride, nsrc,
                           dist, R - 1, nseg, s));
   }
-  RF_HIP(launch_mt_polar(false, p->mt_states, nseg, p->mt_bps, total_blocks, p->mt_counts, nullptr, nullptr, ncells, (int)p->nzc + 1, (int)p->nzl + 1, p->kz0, s));
+  // ONE generation pass: every segment writes its accepted pairs densely into its own run of the scratch array
+  // (capacity = its attempts) and counts them; a scan of the counts gives each run its first cell, and a copy kernel
+  // moves the runs into place.  (Round 1 generated every block twice -- a count pass, then a fill pass that knew the
+  // offsets: 2.5 + 3.3 ms against 3.3 + 1.x ms for fill + move.)  A kz-slab rank replays the WHOLE stream (where a
+  // deviate goes depends on every earlier acceptance) and keeps the deviates of its own planes while moving.
+  const unsigned long long cap = (unsigned long long)p->mt_bps * (624 / 4);
+  const size_t pair = single ? 2 * sizeof(float) : 2 * sizeof(double), need = (size_t)nseg * cap * pair;
+  if (p->mt_scratch_bytes < need) {
+    if (p->mt_scratch) RF_HIP(hipFree(p->mt_scratch));
+    p->mt_scratch = nullptr; p->mt_scratch_bytes = 0;
+    RF_HIP(hipMalloc(&p->mt_scratch, need));
+    p->mt_scratch_bytes = need;
+  }
+  RF_HIP(launch_mt_polar(true, p->mt_states, nseg, p->mt_bps, total_blocks, p->mt_counts, nullptr, (double*)p->mt_scratch, ncells,
+                         (int)p->nzc + 1, (int)p->nzl + 1, p->kz0, s, single != 0, cap));
   RF_HIP(launch_mt_scan(p->mt_counts, p->mt_offsets, nseg, s));
+  RF_HIP(launch_mt_compact(single != 0, p->mt_scratch, p->mt_counts, p->mt_offsets, nseg, cap, single ? (void*)p->noise32 : (void*)p->noise,
+                           ncells, (int)p->nzc + 1, (int)p->nzl + 1, p->kz0, s));
   unsigned long long total = 0;
   RF_HIP(hipMemcpyAsync(&total, p->mt_offsets + nseg, sizeof(total), hipMemcpyDeviceToHost, s));
   RF_HIP(hipStreamSynchronize(s));
   if (accepted) *accepted = total;
   RF_REQUIRE(total >= ncells, "MT19937 replay: not enough accepted polar attempts (increase the margin)");
-  // a kz-slab rank replays the WHOLE stream (the destination of a deviate depends on every earlier acceptance) and keeps
-  // the deviates of its own planes: the replay is replicated work, not distributed
-  RF_HIP(launch_mt_polar(true, p->mt_states, nseg, p->mt_bps, total_blocks, p->mt_counts, p->mt_offsets,
-                         single ? reinterpret_cast<double*>(p->noise32) : p->noise, ncells, (int)p->nzc + 1, (int)p->nzl + 1, p->kz0, s, single != 0));
   p->noise_resident = !single;
   p->noise32_resident = single != 0;
   return 0;

@@ -9,9 +9,10 @@
 //   1. jump tree: the state J words ahead is the XOR of the sequence words x_{i+j} over the set
 //      coefficients j of t^J mod phi(t).  mt_jump_kernel builds 33 blocks of the sequence of a source state in
 //      LDS and XORs them; stage t of the radix-16 tree multiplies the number of segment start states by 16.
-//   2. mt_polar_kernel<false>: every segment (1024 blocks of 624 outputs, one WAVE each) counts its accepted attempts;
-//      an exclusive scan of the counts gives each segment the index of its first cell;
-//   3. mt_polar_kernel<true>: the same generation again, now writing the deviates of the accepted attempts.
+//   2. mt_polar_kernel<true, .> with slack_cap: every segment (1024 blocks of 624 outputs, one WAVE each) generates its
+//      outputs ONCE, writes the deviates of its accepted attempts densely into its own run of a scratch array and counts them;
+//   3. an exclusive scan of the counts gives each run the index of its first cell, and mt_compact_kernel moves the runs
+//      into place (round 1: a count pass and a fill pass, i.e. every block generated twice; those modes are still here).
 #include <hip/hip_runtime.h>
 #include "rf_launch.h"
 #include "rf_core.h"
@@ -42,6 +43,8 @@ __device__ __forceinline__ void mt_next_block(const uint32_t* cur, uint32_t* nxt
   __syncthreads();
 }
 
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
+
 __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
   y ^= y >> 11;
   y ^= (y << 7) & 0x9D2C5680u;
@@ -58,7 +61,14 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
 // reads per lane; as global-memory reads this step took 13 of the replay's 28 ms in round 1).  Building the window
 // is about half of a single jump, and a binary tree spends nine of its thirteen levels waiting for one or a few
 // workgroups: radix 16 needs four launches and shares each window between up to 15 jumps (5.6 -> 2 ms at 1024^3).
-__global__ __launch_bounds__(640) void mt_jump_kernel(const uint32_t* __restrict__ states, const uint32_t* __restrict__ pos,
+// Thread layout of the XOR loop: MT_JUMP_GROUPS groups of 320 threads.  A thread owns TWO output words, u and u + 320 (the
+// two LDS reads of a position share one address computation and merge into one ds_read2st64_b32), and a group takes every
+// MT_JUMP_GROUPS-th chunk of 8 positions; the groups' partial XORs are combined through LDS at the end.  Why: ds_read_b32
+// reaches its 128 B/clk only with ~4 waves per SIMD (MI355X_MICROARCH.md, LDS), and the 106 KB window + position table
+// allow one workgroup per CU -- with 10 waves (one word per thread) a jump took 0.19 ms of a CU against a floor of
+// 0.08 ms for its 25 MB of LDS reads, and halving the VALU work per word without more waves changed nothing.
+constexpr int MT_JUMP_LANES = 320, MT_JUMP_GROUPS = 3, MT_JUMP_THREADS = MT_JUMP_LANES * MT_JUMP_GROUPS;
+__global__ __launch_bounds__(MT_JUMP_THREADS) void mt_jump_kernel(const uint32_t* __restrict__ states, const uint32_t* __restrict__ pos,
                                                       const int* __restrict__ npos, int pos_stride, int nsrc, long long dist,
                                                       int nmult, int mult_per_wg, int nseg) {
   extern __shared__ __attribute__((aligned(16))) uint32_t win[];     // MT_SEQ_WORDS words
@@ -81,30 +91,47 @@ __global__ __launch_bounds__(640) void mt_jump_kernel(const uint32_t* __restrict
     __syncthreads();
   }
   // the ~10^4 positions of a polynomial are staged in LDS behind the window (16-bit, 8 per 16-byte broadcast read):
-  // fetched with scalar loads inside the XOR loop, every 8 LDS reads waited for one scalar-cache round trip and a
-  // jump took 0.25 ms; from LDS the loop runs at the LDS rate (~0.09 ms)
+  // fetched with scalar loads inside the XOR loop, every 8 LDS reads waited for one scalar-cache round trip
   uint16_t* lpos = reinterpret_cast<uint16_t*>(win + MT_SEQ_WORDS);
-  const uint32_t* w = win + (t < MT_N ? t : 0);
+  uint32_t* part = win + MT_SEQ_WORDS + MT_POS_MAX / 2;               // (GROUPS - 1) x 640 words behind the position table
+  const int grp = t / MT_JUMP_LANES, u = t - grp * MT_JUMP_LANES;
+  const bool two = u + MT_JUMP_LANES < MT_N;                          // lanes 304..319 own one word only
+  constexpr int hi = MT_JUMP_LANES;         // a compile-time offset, so that the pair merges into one ds_read2st64_b32; lanes
+                                            // 304..319 read up to 15 words past the window (the position table: still
+                                            // inside the allocation) and discard what they get
+  const uint32_t* w = win + u;
   for (int m = m0; m < m0 + mult_per_wg && m <= nmult; ++m) {
     const long long dst = (long long)src + (long long)m * dist;
     if (dst >= nseg) break;                                           // uniform
     const uint32_t* pm = pos + (size_t)(m - 1) * pos_stride;
     const int np = npos[m - 1], np8 = (np + 7) & ~7;                  // rows are zero-padded to multiples of 8 entries
-    __syncthreads();                                                  // the previous multiplier's loop is done with lpos
-    for (int i = t; i < np8; i += 640) lpos[i] = (uint16_t)pm[i];
+    __syncthreads();                                                  // the previous multiplier is done with lpos and part
+    for (int i = t; i < np8; i += MT_JUMP_THREADS) lpos[i] = (uint16_t)pm[i];
     __syncthreads();
-    if (t < MT_N) {
-      uint32_t acc = 0;
-      typedef unsigned short us8 __attribute__((ext_vector_type(8)));
-      const us8* lp = reinterpret_cast<const us8*>(lpos);
-      const int full = np >> 3;
+    uint32_t a0 = 0, a1 = 0;
+    typedef unsigned short us8 __attribute__((ext_vector_type(8)));
+    const us8* lp = reinterpret_cast<const us8*>(lpos);
+    const int full = np >> 3;
 #pragma unroll 4
-      for (int j = 0; j < full; ++j) {
-        const us8 q = lp[j];                                          // same address in every lane: broadcast
-        acc ^= w[q.s0] ^ w[q.s1] ^ w[q.s2] ^ w[q.s3] ^ w[q.s4] ^ w[q.s5] ^ w[q.s6] ^ w[q.s7];
-      }
-      for (int j = full << 3; j < np; ++j) acc ^= w[lpos[j]];
-      const_cast<uint32_t*>(states)[(size_t)dst * MT_N + t] = acc;
+    for (int j = grp; j < full; j += MT_JUMP_GROUPS) {
+      const us8 q = lp[j];                                            // same address in every lane: broadcast
+      const uint32_t *p0 = w + q.s0, *p1 = w + q.s1, *p2 = w + q.s2, *p3 = w + q.s3, *p4 = w + q.s4, *p5 = w + q.s5, *p6 = w + q.s6,
+                     *p7 = w + q.s7;
+      // three-input XORs (v_bitop3_b32): 8 instead of 16 VALU instructions per chunk -- with ~4 waves per SIMD the loop
+      // is as close to the VALU's rate as to the LDS's
+      a0 = xor3(xor3(xor3(xor3(a0, p0[0], p1[0]), p2[0], p3[0]), p4[0], p5[0]), p6[0], p7[0]);
+      a1 = xor3(xor3(xor3(xor3(a1, p0[hi], p1[hi]), p2[hi], p3[hi]), p4[hi], p5[hi]), p6[hi], p7[hi]);
+    }
+    if (grp == 0)
+      for (int j = full << 3; j < np; ++j) { a0 ^= w[lpos[j]]; a1 ^= w[lpos[j] + hi]; }
+    if (grp > 0) { part[(grp - 1) * 2 * MT_JUMP_LANES + u] = a0; part[(grp - 1) * 2 * MT_JUMP_LANES + MT_JUMP_LANES + u] = a1; }
+    __syncthreads();
+    if (grp == 0) {
+#pragma unroll
+      for (int g = 0; g < MT_JUMP_GROUPS - 1; ++g) { a0 ^= part[g * 2 * MT_JUMP_LANES + u]; a1 ^= part[g * 2 * MT_JUMP_LANES + MT_JUMP_LANES + u]; }
+      uint32_t* out = const_cast<uint32_t*>(states) + (size_t)dst * MT_N;
+      out[u] = a0;
+      if (two) out[u + MT_JUMP_LANES] = a1;
     }
   }
 }
@@ -124,7 +151,10 @@ __global__ __launch_bounds__(256) void mt_polar_kernel(const uint32_t* __restric
                                                        long long total_blocks, int nseg, unsigned long long* __restrict__ counts,
                                                        const unsigned long long* __restrict__ offsets,
                                                        double* __restrict__ noise, unsigned long long ncells,
-                                                       int nzh, int zpitch, int zoff) {
+                                                       int nzh, int zpitch, int zoff, unsigned long long slack_cap) {
+  // slack_cap != 0 (FILL only): ONE pass instead of count + fill -- the segment writes its accepted pairs densely from
+  // slot seg * slack_cap of a scratch array (slack_cap = attempts per segment, so it always fits) and leaves their
+  // number in counts[seg]; mt_compact_kernel then moves every segment's run to its place in the stream.
   // nzh = nz/2 + 1 cells per (ix, iy) row of the stream.  zpitch == nzh: the buffer is the whole stream in its own
   // order.  zpitch < nzh (a kz-slab rank): rows of zpitch slots -- planes [zoff, zoff + zpitch - 1) and, last, the
   // Nyquist plane nzh - 1; deviates of other planes are dropped (every rank replays the whole stream).
@@ -141,7 +171,7 @@ __global__ __launch_bounds__(256) void mt_polar_kernel(const uint32_t* __restric
   if (nb > blocks_per_segment) nb = blocks_per_segment;
   const uint32_t* st = states + (size_t)seg * MT_N;
   for (int i = lane; i < MT_N; i += 64) mt[i] = st[i];
-  unsigned long long running = FILL ? offsets[seg] : 0ull;   // cell index of this segment's next accepted attempt
+  unsigned long long running = !FILL ? 0ull : slack_cap ? (unsigned long long)seg * slack_cap : offsets[seg];   // cell index of this segment's next accepted attempt
   for (long long b = 0; b < nb; ++b) {
     // regenerate: the outputs of this block are the tempered NEW words
 #pragma unroll
@@ -180,9 +210,9 @@ __global__ __launch_bounds__(256) void mt_polar_kernel(const uint32_t* __restric
       const unsigned long long ball = __ballot(acc);
       if (FILL && acc) {
         const unsigned long long cell = running + (unsigned long long)__popcll(ball & ((1ull << lane) - 1ull));
-        bool keep = cell < ncells;
+        bool keep = slack_cap != 0 || cell < ncells;
         unsigned long long dst = cell;
-        if (keep && zpitch != nzh) {
+        if (keep && !slack_cap && zpitch != nzh) {
           const unsigned long long col = cell / (unsigned)nzh;
           const int kz = (int)(cell - col * (unsigned)nzh);
           const int sl = kz == nzh - 1 ? zpitch - 1 : kz - zoff;
@@ -206,6 +236,7 @@ __global__ __launch_bounds__(256) void mt_polar_kernel(const uint32_t* __restric
     }
   }
   if (!FILL && lane == 0) counts[seg] = running;
+  if (FILL && slack_cap && lane == 0) counts[seg] = running - (unsigned long long)seg * slack_cap;
 }
 
 // exclusive scan of the per-segment counts by ONE wave: lane l owns a contiguous chunk, wave scan across lanes
@@ -225,12 +256,50 @@ __global__ __launch_bounds__(64) void mt_scan_kernel(const unsigned long long* _
   if (lane == 63) offsets[n] = inc;                    // total number of accepted attempts
 }
 
+// pairs [0, counts[seg]) of segment seg's scratch run -> cells offsets[seg] + i of the stream (cells >= ncells are
+// dropped; a kz-slab rank keeps its own planes, as in mt_polar_kernel).  PAIR = float2 or double2.
+constexpr int MT_COMPACT_CHUNK = 16384;
+template <typename PAIR>
+__global__ __launch_bounds__(256) void mt_compact_kernel(const PAIR* __restrict__ scratch, const unsigned long long* __restrict__ counts,
+                                                         const unsigned long long* __restrict__ offsets, unsigned long long cap,
+                                                         PAIR* __restrict__ noise, unsigned long long ncells, int nzh, int zpitch,
+                                                         int zoff) {
+  const unsigned long long seg = blockIdx.x, n = counts[seg], first = offsets[seg];
+  const unsigned long long lo = (unsigned long long)blockIdx.y * MT_COMPACT_CHUNK;
+  if (lo >= n) return;
+  const unsigned long long hi = lo + MT_COMPACT_CHUNK < n ? lo + MT_COMPACT_CHUNK : n;
+  const PAIR* src = scratch + seg * cap;
+  for (unsigned long long i = lo + threadIdx.x; i < hi; i += 256) {
+    const unsigned long long cell = first + i;
+    if (cell >= ncells) break;
+    unsigned long long dst = cell;
+    if (zpitch != nzh) {
+      const unsigned long long col = cell / (unsigned)nzh;
+      const int kz = (int)(cell - col * (unsigned)nzh);
+      const int sl = kz == nzh - 1 ? zpitch - 1 : kz - zoff;
+      if (!(sl >= 0 && sl < zpitch && (kz == nzh - 1 || sl < zpitch - 1))) continue;
+      dst = col * (unsigned)zpitch + (unsigned)sl;
+    }
+    noise[dst] = src[i];
+  }
+}
+
 }  // namespace
+
+hipError_t launch_mt_compact(bool single, const void* scratch, const unsigned long long* counts, const unsigned long long* offsets,
+                             int nseg, unsigned long long cap, void* noise, unsigned long long ncells, int nzh, int zpitch, int zoff,
+                             hipStream_t s) {
+  const dim3 grid((unsigned)nseg, (unsigned)((cap + MT_COMPACT_CHUNK - 1) / MT_COMPACT_CHUNK));
+  if (single) hipLaunchKernelGGL(mt_compact_kernel<float2>, grid, dim3(256), 0, s, (const float2*)scratch, counts, offsets, cap, (float2*)noise, ncells, nzh, zpitch, zoff);
+  else hipLaunchKernelGGL(mt_compact_kernel<double2>, grid, dim3(256), 0, s, (const double2*)scratch, counts, offsets, cap, (double2*)noise, ncells, nzh, zpitch, zoff);
+  return hipGetLastError();
+}
 
 hipError_t launch_mt_jump(uint32_t* states, const uint32_t* pos, const int* npos, int pos_stride, int nsrc, long long dist,
                           int nmult, int nseg, hipStream_t s) {
   if (pos_stride > MT_POS_MAX) return hipErrorInvalidValue;
-  constexpr int lds = MT_SEQ_WORDS * (int)sizeof(uint32_t) + MT_POS_MAX * (int)sizeof(uint16_t);
+  constexpr int lds = MT_SEQ_WORDS * (int)sizeof(uint32_t) + MT_POS_MAX * (int)sizeof(uint16_t) +
+                      (MT_JUMP_GROUPS - 1) * 2 * MT_JUMP_LANES * (int)sizeof(uint32_t);   // window, positions, partial XORs
   static LdsAttrLatch latch;
   if (hipError_t e = latch.ensure((const void*)mt_jump_kernel, lds); e != hipSuccess) return e;
   // one 82 KB window (+ 24 KB of positions) per CU: share a source's window between as many multipliers as it takes to fit one round
@@ -238,17 +307,18 @@ hipError_t launch_mt_jump(uint32_t* states, const uint32_t* pos, const int* npos
   int per = (int)(((long long)nsrc * nmult + cus - 1) / cus);
   per = per < 1 ? 1 : (per > nmult ? nmult : per);
   const int groups = (nmult + per - 1) / per;
-  hipLaunchKernelGGL(mt_jump_kernel, dim3((unsigned)(nsrc * groups)), dim3(640), lds, s, states, pos, npos, pos_stride, nsrc, dist, nmult,
+  hipLaunchKernelGGL(mt_jump_kernel, dim3((unsigned)(nsrc * groups)), dim3(MT_JUMP_THREADS), lds, s, states, pos, npos, pos_stride, nsrc, dist, nmult,
                      per, nseg);
   return hipGetLastError();
 }
 hipError_t launch_mt_polar(bool fill, const uint32_t* states, int nseg, int blocks_per_segment, long long total_blocks,
                            unsigned long long* counts, const unsigned long long* offsets, double* noise,
-                           unsigned long long ncells, int nzh, int zpitch, int zoff, hipStream_t s, bool single) {
+                           unsigned long long ncells, int nzh, int zpitch, int zoff, hipStream_t s, bool single,
+                           unsigned long long slack_cap) {
   const unsigned grid = (unsigned)((nseg + 3) / 4);
-  if (fill && single) hipLaunchKernelGGL((mt_polar_kernel<true, true>), dim3(grid), dim3(256), 0, s, states, blocks_per_segment, total_blocks, nseg, counts, offsets, noise, ncells, nzh, zpitch, zoff);
-  else if (fill) hipLaunchKernelGGL((mt_polar_kernel<true, false>), dim3(grid), dim3(256), 0, s, states, blocks_per_segment, total_blocks, nseg, counts, offsets, noise, ncells, nzh, zpitch, zoff);
-  else hipLaunchKernelGGL((mt_polar_kernel<false, false>), dim3(grid), dim3(256), 0, s, states, blocks_per_segment, total_blocks, nseg, counts, offsets, noise, ncells, nzh, zpitch, zoff);
+  if (fill && single) hipLaunchKernelGGL((mt_polar_kernel<true, true>), dim3(grid), dim3(256), 0, s, states, blocks_per_segment, total_blocks, nseg, counts, offsets, noise, ncells, nzh, zpitch, zoff, slack_cap);
+  else if (fill) hipLaunchKernelGGL((mt_polar_kernel<true, false>), dim3(grid), dim3(256), 0, s, states, blocks_per_segment, total_blocks, nseg, counts, offsets, noise, ncells, nzh, zpitch, zoff, slack_cap);
+  else hipLaunchKernelGGL((mt_polar_kernel<false, false>), dim3(grid), dim3(256), 0, s, states, blocks_per_segment, total_blocks, nseg, counts, offsets, noise, ncells, nzh, zpitch, zoff, 0ull);
   return hipGetLastError();
 }
 hipError_t launch_mt_scan(const unsigned long long* counts, unsigned long long* offsets, int n, hipStream_t s) {

@@ -99,7 +99,14 @@ hipError_t launch_mt_jump(uint32_t* states, const uint32_t* pos, const int* npos
                           int nseg, hipStream_t s);
 hipError_t launch_mt_polar(bool fill, const uint32_t* states, int nseg, int blocks_per_segment, long long total_blocks,
                            unsigned long long* counts, const unsigned long long* offsets, double* noise,
-                           unsigned long long ncells, int nzh, int zpitch, int zoff, hipStream_t s, bool single = false);
+                           unsigned long long ncells, int nzh, int zpitch, int zoff, hipStream_t s, bool single = false,
+                           unsigned long long slack_cap = 0);
+// slack_cap != 0 (with fill): one-pass variant -- `noise` is a scratch array of nseg * slack_cap pairs, segment seg writes its
+// accepted pairs densely from slot seg * slack_cap and their number to counts[seg]; launch_mt_compact then moves the runs
+// to their cells (offsets = exclusive scan of counts)
+hipError_t launch_mt_compact(bool single, const void* scratch, const unsigned long long* counts, const unsigned long long* offsets,
+                             int nseg, unsigned long long cap, void* noise, unsigned long long ncells, int nzh, int zpitch, int zoff,
+                             hipStream_t s);
 // (single: `noise` is an array of float32 pairs instead of float64 pairs)
 // (nzh = nz/2 + 1 cells per row of the stream; zpitch / zoff: the noise buffer's rows, see GenParams)
 hipError_t launch_mt_scan(const unsigned long long* counts, unsigned long long* offsets, int n, hipStream_t s);
