@@ -19,8 +19,8 @@ import os
 
 import numpy as np
 
-__all__ = ["slab_layout", "exchange_blocks", "gather_rows", "exchange_unique_id", "init_process_group",
-           "DistributedPlan", "SlabHostPlan"]
+__all__ = ["slab_layout", "exchange_blocks", "gather_rows", "side_array_planes", "split_side_array",
+           "assemble_side_array", "exchange_unique_id", "init_process_group", "DistributedPlan", "SlabHostPlan"]
 
 
 def slab_layout(nx, ny, nz, nranks, rank):
@@ -45,6 +45,27 @@ def gather_rows(recv_blocks):
     """Assemble the z-pass input [nxl][ny][nz/2] of a rank from its P received blocks
     (block g holds the kz planes of rank g's slab)."""
     return np.concatenate(recv_blocks, axis=2)
+
+
+def side_array_planes(nz, nranks, rank):
+    """kz planes held, in order, by the k-space side arrays (k buffer, saved potential, resident deviates) of a rank:
+    its own nz/(2 ranks) planes and then the Nyquist plane nz/2, which rank 0 packs into slot kz = 0 of the
+    device-internal layout (the other ranks carry the slot but never read it).  One rank: 0 .. nz/2, the reference's
+    own (nx, ny, nz/2 + 1) layout."""
+    nzl = nz // 2 // nranks
+    return list(range(rank * nzl, (rank + 1) * nzl)) + [nz // 2]
+
+
+def split_side_array(full, nranks, rank):
+    """A rank's share of an (nx, ny, nz/2 + 1) k-space array."""
+    nz = 2 * (full.shape[2] - 1)
+    return np.ascontiguousarray(full[:, :, side_array_planes(nz, nranks, rank)])
+
+
+def assemble_side_array(parts):
+    """The (nx, ny, nz/2 + 1) array from every rank's share (the Nyquist plane is taken from rank 0)."""
+    nzl = parts[0].shape[2] - 1
+    return np.concatenate([a[:, :, :nzl] for a in parts] + [parts[0][:, :, nzl:]], axis=2)
 
 
 def _rendezvous_path():

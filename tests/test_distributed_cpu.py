@@ -47,30 +47,43 @@ def _worker(rank, world, port, shape, out_dir):
     packed = full_k[:, :, :nzc].copy()
     packed[:, :, 0] = full_k[:, :, 0] + 1j * full_k[:, :, nzc]          # device-internal packing of DC/Nyquist planes
     mine = packed[:, :, lay["kz0"]:lay["kz0"] + lay["nzl"]]             # this rank's kz slab
-    mine = np.fft.ifft(np.fft.ifft(mine, axis=0), axis=1) * (nx * ny)   # x and y passes (unnormalised)
-    # THE exchange: grouped point-to-point sends/receives, block h -> rank h (what the library does with
-    # ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd; the own block is a local copy)
-    send = [torch.from_numpy(np.ascontiguousarray(b).view(np.float64)) for b in slab.exchange_blocks(mine, world)]
-    recv = [torch.empty_like(send[0]) for _ in range(world)]
-    recv[rank].copy_(send[rank])
-    ops = []
-    for h in range(world):
-        if h != rank:
-            ops.append(dist.P2POp(dist.isend, send[h], h))
-            ops.append(dist.P2POp(dist.irecv, recv[h], h))
-    for req in dist.batch_isend_irecv(ops):
-        req.wait()
-    rows = slab.gather_rows([t.numpy().view(np.complex128) for t in recv])   # [nxl][ny][nz/2]
-    assert rows.shape == (lay["nxl"], ny, nzc)
-    half = np.empty((lay["nxl"], ny, nzc + 1), np.complex128)            # unpack slot 0 -> DC and Nyquist elements
-    half[:, :, :nzc] = rows
-    half[:, :, 0] = rows[:, :, 0].real
-    half[:, :, nzc] = rows[:, :, 0].imag
-    delta = np.fft.irfft(half, n=nz, axis=2) / (nx * ny)
+
+    def pipeline(mine):
+        mine = np.fft.ifft(np.fft.ifft(mine, axis=0), axis=1) * (nx * ny)   # x and y passes (unnormalised)
+        # THE exchange: grouped point-to-point sends/receives, block h -> rank h (what the library does with
+        # ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd; the own block is a local copy)
+        send = [torch.from_numpy(np.ascontiguousarray(b).view(np.float64)) for b in slab.exchange_blocks(mine, world)]
+        recv = [torch.empty_like(send[0]) for _ in range(world)]
+        recv[rank].copy_(send[rank])
+        ops = []
+        for h in range(world):
+            if h != rank:
+                ops.append(dist.P2POp(dist.isend, send[h], h))
+                ops.append(dist.P2POp(dist.irecv, recv[h], h))
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        rows = slab.gather_rows([t.numpy().view(np.complex128) for t in recv])   # [nxl][ny][nz/2]
+        assert rows.shape == (lay["nxl"], ny, nzc)
+        half = np.empty((lay["nxl"], ny, nzc + 1), np.complex128)            # unpack slot 0 -> DC and Nyquist elements
+        half[:, :, :nzc] = rows
+        half[:, :, 0] = rows[:, :, 0].real
+        half[:, :, nzc] = rows[:, :, 0].imag
+        return np.fft.irfft(half, n=nz, axis=2) / (nx * ny)
+
+    delta = pipeline(mine)
+    # the reference's default call + Newtonian potential on slab ranks (generate.py:200-217, 333-343): every rank keeps its
+    # planes of delta(k)/k**2 -- own planes, then the Nyquist plane (slab.side_array_planes) -- and later transforms
+    # scale * potential from that share alone
+    share = slab.split_side_array(cpu_ref.potential_kspace(full_k, 2.5), world, rank)
+    assert share.shape == (nx, ny, lay["nzl"] + 1)
+    again = share[:, :, :lay["nzl"]].copy()
+    if rank == 0:
+        again[:, :, 0] = share[:, :, 0] + 1j * share[:, :, lay["nzl"]]     # rank 0 packs the Nyquist plane into slot kz = 0
+    phi = pipeline(-1.5 * again)
     # global rms through a 2-double all-reduce
     st = torch.tensor([delta.sum(), (delta ** 2).sum()], dtype=torch.float64)
     dist.all_reduce(st)
-    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), delta=delta, stats=st.numpy(), x0=lay["x0"])
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), delta=delta, stats=st.numpy(), x0=lay["x0"], phi=phi, share=share)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -85,10 +98,16 @@ def test_slab_exchange_processes(tmp_path, world, shape):
     pw = np.load(os.path.join(ROOT, "tests", "golden", "default_power.npz"))
     noise = cpu_ref.reference_noise(11, nx * ny * (nz // 2 + 1))
     ref, rms = cpu_ref.generate_delta_field(nx, ny, nz, 2.5, pw["k"], pw["Pk"], noise=noise, dtype=np.complex128)
+    from randomfield_amd import slab
+    pot = cpu_ref.potential_kspace(cpu_ref.generate_kspace(nx, ny, nz, 2.5, pw["k"], pw["Pk"], noise=noise, dtype=np.complex128), 2.5)
+    phi_ref = np.fft.irfftn(-1.5 * pot, s=shape, axes=(0, 1, 2))
+    shares = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))["share"] for r in range(world)]
+    assert np.array_equal(slab.assemble_side_array(shares), pot)
     for r in range(world):
         g = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
         x0 = int(g["x0"])
         assert np.allclose(g["delta"], ref[x0:x0 + nx // world], rtol=0, atol=1e-12 * rms)
+        assert np.allclose(g["phi"], phi_ref[x0:x0 + nx // world], rtol=0, atol=1e-12 * phi_ref.std())
         n = ref.size
         assert abs(np.sqrt(g["stats"][1] / n - (g["stats"][0] / n) ** 2) - rms) < 1e-12 * rms
 

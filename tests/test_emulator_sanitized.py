@@ -1,6 +1,6 @@
 """The kernel phase functions under AddressSanitizer + UBSan on the CPU (GPU sanitizers are not available
 on this pool): every supported axis length of the strided passes, the c2r and r2c row passes and both
-generation flavours run in a separate process against an instrumented build of the emulator, whose LDS /
+generation flavours, and the generic mixed-radix blocks, run in a separate process against an instrumented build of the emulator, whose LDS /
 global "memory" are exactly-sized heap arrays -- any out-of-bounds index aborts the run."""
 import os
 import subprocess
@@ -41,6 +41,14 @@ for shape in ((8, 8, 16), (16, 32, 64), (64, 16, 32)):
         emu_util.realise(nx, ny, nz, 2.5, xt, st, noise=noise, dtype=dt)
         emu_util.realise(nx, ny, nz, 2.5, xt, st, seed=3, dtype=dt)
     emu_util.realise_fast(nx, ny, nz, 2.5, xt, st, seed=3)
+for shape in ((4, 6, 8), (40, 60, 80), (10, 14, 22), (2, 2, 2), (26, 34, 46)):        # the generic mixed-radix blocks
+    for ct, rt in ((np.complex64, np.float32), (np.complex128, np.float64)):
+        nx, ny, nz = shape
+        ks = (rng.normal(size=(nx, ny, nz // 2 + 1)) + 1j * rng.normal(size=(nx, ny, nz // 2 + 1))).astype(ct)
+        out, s1, s2 = emu_util.generic_c2r(ks)
+        assert np.max(np.abs(out - np.fft.irfftn(ks.astype(np.complex128), s=shape, axes=(0, 1, 2)))) < 1e-3
+        emu_util.generic_r2c(out)
+        emu_util.generic_c2c(ks, True)
 print("SANITIZED-OK")
 '''
 

@@ -1082,10 +1082,10 @@ def _slab_run(hip, plans, **forward):
 
 def _slab_side_array(plans, getter, nzc):
     """Assemble the (nx, ny, nz/2+1) array from the ranks' side arrays (own planes, then the Nyquist plane)."""
+    from randomfield_amd import slab
     parts = [getter(p) for p in plans]
-    nzl = parts[0].shape[2] - 1
-    assert nzl * len(plans) == nzc
-    return np.concatenate([a[:, :, :nzl] for a in parts] + [parts[0][:, :, nzl:]], axis=2)
+    assert (parts[0].shape[2] - 1) * len(plans) == nzc
+    return slab.assemble_side_array(parts)
 
 
 @pytest.mark.parametrize("nranks", [2, 4])

@@ -30,7 +30,10 @@ def main():
     k, Pk = POWER["k"], POWER["Pk"]
     while time.time() - t0 < budget:
         it += 1
-        shape = tuple(int(2 ** rng.randint(3, 8)) for _ in range(2)) + (int(2 ** rng.randint(4, 9)),)
+        if rng.rand() < 0.35:      # any even shape (nz a multiple of 4 for the generation rows): the generic mixed-radix kernels
+            shape = (2 * int(rng.randint(1, 40)), 2 * int(rng.randint(1, 40)), 4 * int(rng.randint(1, 24)))
+        else:
+            shape = tuple(int(2 ** rng.randint(3, 8)) for _ in range(2)) + (int(2 ** rng.randint(4, 9)),)
         nx, ny, nz = shape
         if nx * ny * nz > 2 ** 22:
             continue
@@ -41,7 +44,7 @@ def main():
         M = nx * ny * (nz // 2 + 1)
         field = None
         for _ in range(rng.randint(2, 7)):
-            op = rng.choice(["ext", "native", "gen", "r2c", "lognormal", "affine", "potential", "rpot", "batch", "mt", "lens"])
+            op = rng.choice(["ext", "native", "gen", "r2c", "lognormal", "affine", "potential", "rpot", "batch", "mt", "mt32", "lens"])
             counts[op] = counts.get(op, 0) + 1
             if op == "ext":
                 seed = int(rng.randint(1, 10 ** 6))
@@ -139,6 +142,19 @@ def main():
                 assert np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1e-300)) <= 1e-15, ("mt", shape, seed)
                 p.realise(noise="resident")
                 field = p.download_real()
+            elif op == "mt32":
+                # the same stream kept as float32 pairs (a request: plans without the fast generation pass keep float64),
+                # then the reference's default call from the resident deviates
+                seed = int(rng.randint(0, 2 ** 31))
+                p.reference_noise(seed, single=True)
+                noise = cpu_ref.reference_noise(seed, M)
+                ref, rms = cpu_ref.generate_delta_field(nx, ny, nz, SPACING, k, Pk, noise=noise, dtype=ct, double_fft=True)
+                p.realise_potential(noise="resident")
+                field = p.download_real()
+                assert np.max(np.abs(field - ref)) <= tol * rms, ("mt32 field", shape, ct)
+                p.load_potential(1.0)
+                pref = cpu_ref.potential_kspace(cpu_ref.generate_kspace(nx, ny, nz, SPACING, k, Pk, noise=noise, dtype=np.complex128), SPACING)
+                assert np.max(np.abs(p.download_k() - pref)) <= 2e-5 * max(np.max(np.abs(pref)), 1e-30), ("mt32 potential", shape, ct)
             elif op == "lens" and field is not None:
                 DA = np.arange(nz) * SPACING * (1 + 0.02 * np.arange(nz) / nz)
                 i_min = int(rng.randint(0, nz))
