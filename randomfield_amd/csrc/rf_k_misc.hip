@@ -40,15 +40,33 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const double* __re
   }
 }
 
+// streaming (non-temporal) vector accesses of the elementwise maps: every element is read once and written once
+template <typename T, int VEC> struct MapVec {
+  typedef T vt __attribute__((ext_vector_type(VEC)));
+  T v[VEC];
+  __device__ static MapVec load(const T* base, long long i) {
+    const vt x = __builtin_nontemporal_load(reinterpret_cast<const vt*>(base) + i);
+    MapVec r;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) r.v[e] = x[e];
+    return r;
+  }
+  __device__ void store(T* base, long long i) const {
+    vt x;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) x[e] = v[e];
+    __builtin_nontemporal_store(x, reinterpret_cast<vt*>(base) + i);
+  }
+};
+
 // cosmotools.py:216-220: delta /= sigma; delta *= sqrt(log t); delta = exp(delta); delta /= sqrt(t)
 // each step rounded to the array dtype; the two table factors are float64 (growth is a float64 (nz,) array)
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void lognormal_vec_kernel(T* __restrict__ W, long long nvec, int nz,
                                                             const double* __restrict__ a_z,
                                                             const double* __restrict__ b_z, T sigma) {
-  struct alignas(VEC * sizeof(T)) Vec { T v[VEC]; };
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
-    Vec x = reinterpret_cast<const Vec*>(W)[i];
+    MapVec<T, VEC> x = MapVec<T, VEC>::load(W, i);
     const int iz0 = (int)((i * VEC) % nz);
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
@@ -58,16 +76,15 @@ __global__ __launch_bounds__(256) void lognormal_vec_kernel(T* __restrict__ W, l
       d = (T)((double)d / b_z[iz0 + e]);
       x.v[e] = d;
     }
-    reinterpret_cast<Vec*>(W)[i] = x;
+    x.store(W, i);
   }
 }
 
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void affine_vec_kernel(T* __restrict__ W, long long nvec, int nz,
                                                          const double* __restrict__ mul_z, double add, int has_add) {
-  struct alignas(VEC * sizeof(T)) Vec { T v[VEC]; };
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
-    Vec x = reinterpret_cast<const Vec*>(W)[i];
+    MapVec<T, VEC> x = MapVec<T, VEC>::load(W, i);
     const int iz0 = (int)((i * VEC) % nz);
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
@@ -75,7 +92,7 @@ __global__ __launch_bounds__(256) void affine_vec_kernel(T* __restrict__ W, long
       if (has_add) d = d + (T)add;                   // delta += 1 in the array dtype
       x.v[e] = d;
     }
-    reinterpret_cast<Vec*>(W)[i] = x;
+    x.store(W, i);
   }
 }
 
