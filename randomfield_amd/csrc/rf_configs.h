@@ -29,12 +29,20 @@ RF_COL(512,  8,  8,  8, 16, 512)
 #endif
 template <> struct ColSel<float, 1024>  { using type = ColCfg<float,  1024, RF_COL32_1024>; };
 template <> struct ColSel<double, 1024> { using type = ColCfg<double, 1024, RF_COL64_1024>; };
-RF_COL(2048, 8,  16, 16, 8, 1024)
+#ifndef RF_COL32_2048
+#define RF_COL32_2048 8, 16, 16, 8, 1024
+#endif
+#ifndef RF_GEN32_2048
+#define RF_GEN32_2048 RF_COL32_2048
+#endif
+template <> struct ColSel<float, 2048>  { using type = ColCfg<float,  2048, RF_COL32_2048>; };
+template <> struct ColSel<double, 2048> { using type = ColCfg<double, 2048, 8, 16, 16, 4, 1024>; };
 #undef RF_COL
 // fused-generation x pass: same tiles, radices chosen for register pressure (generation happens
 // in pass 1, so a small first radix keeps the live set low)
 template <typename T, int N> struct GenSel { using type = typename ColSel<T, N>::type; };
 template <> struct GenSel<float, 1024> { using type = ColCfg<float, 1024, 8, 16, 8, 8, 512>; };
+template <> struct GenSel<float, 2048> { using type = ColCfg<float, 2048, RF_GEN32_2048>; };
 #ifndef RF_GEN64_1024
 #define RF_GEN64_1024 8, 8, 16, 8, 1024
 #endif

@@ -32,12 +32,20 @@ template <typename T> struct alignas(16) V16 {
 };
 // One 16-byte global access per V16: through a 4 x 32-bit vector type, so that the compiler cannot split it into two
 // 8-byte accesses when the halves sit in non-adjacent registers (it did: half-width stores, twice as many of them).
+// The pointer is cast to the GLOBAL address space: the arrays reach the kernels inside by-value structs, the compiler
+// could not prove where they point and emitted flat_load / flat_store (64-bit VGPR addresses, counted on the LDS
+// counter as well) -- with the cast they are global_load / global_store with an SGPR base and a 32-bit lane offset.
 template <typename T> RF_HD void v16_store(void* p, const V16<T>& v) {
 #if defined(__HIP_DEVICE_COMPILE__)
   typedef unsigned u4 __attribute__((ext_vector_type(4)));
+#ifdef RF_FLAT_ACCESS          /* development: the old generic-pointer accesses, for A/B timing */
+  typedef u4 gu4;
+#else
+  typedef __attribute__((address_space(1))) u4 gu4;
+#endif
   union { V16<T> s; u4 q; } u;
   u.s = v;
-  *reinterpret_cast<u4*>(p) = u.q;
+  *(gu4*)p = u.q;
 #else
   *reinterpret_cast<V16<T>*>(p) = v;
 #endif
@@ -45,8 +53,13 @@ template <typename T> RF_HD void v16_store(void* p, const V16<T>& v) {
 template <typename T> RF_HD V16<T> v16_load(const void* p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   typedef unsigned u4 __attribute__((ext_vector_type(4)));
+#ifdef RF_FLAT_ACCESS
+  typedef u4 gu4;
+#else
+  typedef __attribute__((address_space(1))) u4 gu4;
+#endif
   union { V16<T> s; u4 q; } u;
-  u.q = *reinterpret_cast<const u4*>(p);
+  u.q = *(const gu4*)p;
   return u.s;
 #else
   return *reinterpret_cast<const V16<T>*>(p);

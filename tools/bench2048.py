@@ -11,6 +11,9 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from randomfield_amd import _hip, powertools   # noqa: E402
 
+if len(sys.argv) > 1:
+    _hip.LIB_PATH = os.path.abspath(sys.argv[1])      # a variant build of the library (kernel experiments)
+quick = len(sys.argv) > 2
 n = 2048
 power = powertools.load_default_power()
 plan = _hip.DevicePlan(n, n, n, np.complex64)
@@ -32,6 +35,8 @@ sweep = 8.0 * n * n * (n // 2 + 1)
 print(json.dumps({"case": "2048^3 f32 single GPU", "ms": round(t * 1e3, 3), "frac_hbm_peak": round(5 * sweep / t / 8e12, 4),
                   "kernel_ms[x,y,z,reduce,x_fix]": [round(float(v), 3) for v in kern / 4]}), flush=True)
 plan.close()
+if quick:
+    sys.exit(0)
 # per-rank slab compute, rank 0 and rank 3 of 8 (virtual ranks: forward = generation + x + y on the kz slab, backward = z)
 for r in (0, 3):
     p = _hip.DevicePlan(n, n, n, np.complex64, nranks=8, rank=r)
