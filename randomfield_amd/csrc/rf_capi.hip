@@ -921,8 +921,10 @@ static int potential_forward(rf_plan* p, uint64_t seed, int mode, const double* 
   RF_REQUIRE(mode == RF_NOISE_NATIVE || mode == RF_NOISE_EXTERNAL || mode == RF_NOISE_RESIDENT, "invalid noise mode");
   RF_REQUIRE(!(p->replicate && p->nranks > 1), "replicated-generation plans keep no k-space potential: clear RF_FLAG_REPLICATED_GENERATION");
   RF_HIP(hipSetDevice(p->device));
-  const bool fused = (mode == RF_NOISE_NATIVE || (mode == RF_NOISE_RESIDENT && p->noise32_resident)) && p->have_fast &&
-                     !p->exact_gen && !p->f64 && !p->generic;
+  // fused: delta(k) / k^2 is a second store stream of the generation pass -- native generator (float32 and float64 plans)
+  // or resident float32 deviates (float32 plans)
+  const bool fused = ((mode == RF_NOISE_NATIVE) || (mode == RF_NOISE_RESIDENT && p->noise32_resident && !p->f64)) && p->have_fast &&
+                     !p->exact_gen && !p->generic;
   if (!fused) {
     if (int rc = rf_generate(p, seed, mode, noise_host)) return rc;
     if (int rc = rf_save_potential(p)) return rc;

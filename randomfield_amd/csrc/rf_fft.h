@@ -329,12 +329,12 @@ using FastGenColIO = FastGenColIOT<0, 1>;   // (emulator)
 // The same fast generation for float64 plans (native generator only: parity / reference-noise mode keeps the exact
 // float64 chain of GenColIO).  The deviates and sigma are formed in float32 -- hardware log / sin / cos, LDS
 // records -- and widened; the transform itself is float64.  One complex128 per lane (CPL = 1).
-template <int FIX = 1, int SLAB = 0>
+template <int FIX = 1, int SLAB = 0, int POT = 0>
 struct FastGenColIO64 {
   cplx<double>* base;
   ColGeom g;
   FastGenParams gp;
-  cplx<double>* pot = nullptr;   // (unused: the fused potential store exists for float32 plans only)
+  cplx<double>* pot = nullptr;   // POT = 1: where delta(k) / k^2 goes (API-layout rows of gp.zpitch cells, 16-byte aligned)
   int kz0, nzl;
   int x0 = 0, x1 = 1 << 30;  // replicated-generation mode: see FastGenColIOT
   RF_HD int nzl_shift() const { return 31 - __builtin_clz((unsigned)nzl); }
@@ -356,9 +356,16 @@ struct FastGenColIO64 {
     const uint64_t ci_u = pin_uniform((uint64_t)ro * plane);
     const int ro_s = ro >= (gp.nx >> 1) ? ro - gp.nx : ro;
     const float kx = (float)(rb + ro_s) * gp.dkx, ky = (float)fast_signed_index(iy, gp.ny) * gp.dky;
-    const cplx<float> c = fast_gen_one(gp, rec, seed, ci_l + ci_u, fast_k2(gp, fmaf(kx, kx, ky * ky), kz));
+    const float k2 = fast_k2(gp, fmaf(kx, kx, ky * ky), kz);
+    const cplx<float> c = fast_gen_one(gp, rec, seed, ci_l + ci_u, k2);
     V16<double> v;
     v.c[0] = mk<double>((double)c.x, (double)c.y);
+    if (POT && !(FIX != 0 && kz == 0)) {          // (slot kz = 0: the two Hermitian planes, written by fix_value())
+      const float r = fast_rcp(k2);
+      V16<double> q;
+      q.c[0] = mk<double>((double)(c.x * r), (double)(c.y * r));
+      v16_store<double>((pot + (long long)ro * gp.ny * gp.zpitch) + (uint32_t)((rb * gp.ny + iy) * gp.zpitch + (kz - gp.zoff)), q);
+    }
     return v;
   }
   static constexpr bool ROLLED_LOAD = false;
@@ -367,7 +374,13 @@ struct FastGenColIO64 {
   RF_HD cplx<double> fix_value(long long C, int rb, int ro) const {
     const uint64_t seed = gp.seed;                                                      // bind_seed() ran first
     cplx<float> p0, pn;
-    const cplx<float> c = fast_fix_kz0(gp, rec, seed, rb + ro, (int)((unsigned)C >> nzl_shift()), p0, pn);
+    const int iy = (int)((unsigned)C >> nzl_shift());
+    const cplx<float> c = fast_fix_kz0(gp, rec, seed, rb + ro, iy, p0, pn);
+    if (POT) {
+      cplx<double>* row = pot + ((long long)(rb + ro) * gp.ny + iy) * gp.zpitch;      // only the rank with kz0 = 0 gets here
+      row[0] = mk<double>((double)p0.x, (double)p0.y);
+      row[gp.zpitch - 1] = mk<double>((double)pn.x, (double)pn.y);
+    }
     return mk<double>((double)c.x, (double)c.y);
   }
   RF_HD void store(long long C0, int cl, int rb, int ro, const V16<double>& v) const {

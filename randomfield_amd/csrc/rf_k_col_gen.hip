@@ -118,8 +118,14 @@ hipError_t launch_col_fastgen(int f64, int N, void* W, ColGeom g, long long ncol
 #undef X
       default: return hipErrorInvalidValue;
     }
-  } else if (pot) {
-    return hipErrorInvalidValue;
+  } else if (pot || po) {                      // float64 plans: the same second store stream, values widened
+    if (slab && pot) return hipErrorInvalidValue;
+    switch (N) {
+#define X(NN) case NN: { if (!col_fastgen_supported(1, NN)) { if (po) break; return hipErrorInvalidValue; } hipError_t e = launch_fast_one<typename GenSel<double, NN>::type, FastGenColIO64<0, 0, 1>, FastGenColIO64<1, 0, 1>, cplx<double>>(gp, (cplx<double>*)W, g, ncols, kz0, nzl, (const cplx<double>*)tw, s, po, after_repair, x0, x1, (cplx<double>*)pot); if (!po || e != hipSuccess) return e; break; }
+      RF_COL_SIZES(X)
+#undef X
+      default: return hipErrorInvalidValue;
+    }
   }
 #define RF_FAST(T, IO0, IO1)                                                                                              \
   switch (N) {                                                                                                           \
