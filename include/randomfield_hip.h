@@ -118,9 +118,11 @@ int rf_execute_c2c(rf_plan* plan, int direction);
  * k-space array is never materialised.  rms/mean are available from rf_moments(). */
 int rf_realise(rf_plan* plan, uint64_t seed, int mode, const double* noise_host);
 /* The reference's DEFAULT call, generate_delta_field(save_potential=True) (generate.py:191-219): as rf_realise, and
- * delta(k) / k^2 (0 at DC; generate.py:200-217) is left in the plan's potential buffer for rf_load_potential.  Native
- * noise on a float32 single-GPU plan: the potential is a second store stream of the generation pass (delta(k) is never
- * materialised); otherwise the call runs rf_generate -> rf_save_potential -> rf_execute_c2r. */
+ * delta(k) / k^2 (0 at DC; generate.py:200-217) is left in the plan's potential buffer for rf_load_potential (on a kz-slab
+ * rank: its own planes, then the Nyquist plane).  With the native generator (float32 and float64 plans) or resident float32
+ * deviates (rf_noise_mt19937_ex(single), float32 plans) the potential is a second store stream of the generation pass and
+ * delta(k) is never materialised; otherwise (host deviates, exact-generation flag, generic shapes) the call runs
+ * rf_generate -> rf_save_potential -> rf_execute_c2r. */
 int rf_realise_potential(rf_plan* plan, uint64_t seed, int mode, const double* noise_host);
 /* n realisations back to back (native noise); the field of the last seed stays resident; rms_out[i]
  * (may be NULL) = np.std of field i.  Single-GPU plans replay one captured hipGraph.  Multi-GPU plans

@@ -913,7 +913,7 @@ int rf_realise(rf_plan* p, uint64_t seed, int mode, const double* noise_host) {
 }
 
 // generate_delta_field(save_potential=True) (generate.py:191-219): the field as rf_realise, plus delta(k) / k^2 in the
-// plan's potential buffer.  With the native generator on a float32 single-GPU plan the potential is a second store
+// plan's potential buffer.  With the native generator (or resident float32 deviates) the potential is a second store
 // stream of the generation pass; every other case runs the unfused sequence generate -> save_potential -> c2r.
 // whole = false stops after the y pass (the slab pipeline's forward half, rf_slab_forward_ex)
 static int potential_forward(rf_plan* p, uint64_t seed, int mode, const double* noise_host, bool whole) {
