@@ -106,7 +106,8 @@ struct rf_plan {
   void* W = nullptr;                      // [nx][ny][nz] real == [nx][ny][nz/2] complex (packed Nyquist)
   void* K = nullptr;                      // lazy: API-layout k-space [nx][ny][nz/2+1]
   void* P = nullptr;                      // lazy: saved potential, API layout
-  size_t w_bytes = 0, k_bytes = 0;
+  size_t w_bytes = 0, k_bytes = 0, p_bytes = 0;      // field buffer, k-space side array, potential array (padded rows)
+  int ppitch = 0;                         // cells per row of the potential array: nzl + 1, rounded up to even on float32 plans
   void *tw_x = nullptr, *tw_y = nullptr, *tw_z = nullptr;
   double *kx2 = nullptr, *ky2 = nullptr, *kz2 = nullptr;
   double *xt = nullptr, *st = nullptr, *sl = nullptr;
@@ -247,7 +248,7 @@ FastGenParams make_fast(rf_plan* p, uint64_t seed, bool seed_from_dev, const uin
   f.rec = p->frec; f.nbins = p->fnbins; f.u_scale = p->fu_scale; f.u_off = p->fu_off;
   f.seed = seed; f.seed_dev = seed_from_dev ? seed_ptr : nullptr;
   f.noise = nullptr; f.noise32 = nullptr;
-  f.zpitch = p->nzl + 1; f.zoff = p->kz0;
+  f.zpitch = p->nzl + 1; f.zoff = p->kz0; f.ppitch = p->ppitch;
   return f;
 }
 
@@ -596,6 +597,8 @@ int rf_plan_create(rf_plan** out, int nx, int ny, int nz, int dtype, int device,
   p->nxl = nx / nranks; p->nzl = p->nzc / nranks; p->kz0 = rank * p->nzl;
   p->w_bytes = (size_t)nx * ny * p->nzl * p->csize;       // == nxl * ny * nzc: the local share of the field
   p->k_bytes = (size_t)nx * ny * (p->nzl + 1) * p->csize;    // side arrays: this rank's planes + the Nyquist plane
+  p->ppitch = dtype ? (int)p->nzl + 1 : (int)p->nzl + 2;     // (nzl is even) float32: 16-byte aligned cell pairs for the fused store
+  p->p_bytes = (size_t)nx * ny * p->ppitch * p->csize;
   auto cleanup = [&](int rc) { rf_plan_destroy(p); return rc; };
   hipError_t e;
   if ((e = hipStreamCreateWithFlags(&p->own_stream, hipStreamNonBlocking)) != hipSuccess)
@@ -760,7 +763,7 @@ int rf_plan_destroy(rf_plan* p) {
 
 int rf_plan_nbytes(rf_plan* p, size_t* nbytes) {
   RF_REQUIRE(p && nbytes, "null argument");
-  *nbytes = p->w_bytes * (1 + (p->R ? 1 : 0) + (p->W2 ? 2 : 0)) + (p->K ? p->k_bytes : 0) + (p->P ? p->k_bytes : 0) + (p->G ? p->k_bytes : 0);
+  *nbytes = p->w_bytes * (1 + (p->R ? 1 : 0) + (p->W2 ? 2 : 0)) + (p->K ? p->k_bytes : 0) + (p->P ? p->p_bytes : 0) + (p->G ? p->k_bytes : 0);
   return 0;
 }
 
@@ -931,7 +934,7 @@ static int potential_forward(rf_plan* p, uint64_t seed, int mode, const double* 
     if (whole) return rf_execute_c2r(p);
     return queue_xy(p, make_gen(p, 0, RF_NOISE_NATIVE, false), p->K, p->W, p->stream, false);
   }
-  if (!p->P) RF_HIP(hipMalloc(&p->P, p->k_bytes));
+  if (!p->P) RF_HIP(hipMalloc(&p->P, p->p_bytes));
   p->timed = whole;
   p->pot_target = p->P;
   p->resident_fast = (mode == RF_NOISE_RESIDENT);
@@ -1178,8 +1181,8 @@ int rf_save_potential(rf_plan* p) {
   RF_REQUIRE(p->K && p->k_valid, "no k-space data");
   RF_REQUIRE(p->have_kgrid, "rf_set_kgrid must be called first");
   RF_HIP(hipSetDevice(p->device));
-  if (!p->P) RF_HIP(hipMalloc(&p->P, p->k_bytes));
-  RF_HIP(launch_save_potential(p->f64, p->K, p->P, p->nx, p->ny, p->nz, p->kx2, p->ky2, p->kz2, p->nzl + 1, p->kz0, p->stream));
+  if (!p->P) RF_HIP(hipMalloc(&p->P, p->p_bytes));
+  RF_HIP(launch_save_potential(p->f64, p->K, p->P, p->nx, p->ny, p->nz, p->kx2, p->ky2, p->kz2, p->nzl + 1, p->kz0, p->ppitch, p->stream));
   return 0;
 }
 
@@ -1189,7 +1192,7 @@ int rf_load_potential(rf_plan* p, double scale) {
   RF_REQUIRE(p->P, "no saved potential");
   RF_HIP(hipSetDevice(p->device));
   if (int rc = ensure_k(p)) return rc;
-  RF_HIP(launch_scale_copy(p->f64, p->P, p->K, (long long)p->nx * p->ny * (p->nzl + 1), scale, p->stream));
+  RF_HIP(launch_scale_copy(p->f64, p->P, p->K, (long long)p->nx * p->ny * (p->nzl + 1), (int)p->nzl + 1, p->ppitch, scale, p->stream));
   p->k_valid = true;
   p->aux_valid = false;
   return 0;

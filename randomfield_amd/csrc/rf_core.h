@@ -414,6 +414,8 @@ struct FastGenParams {
   const double* noise;    // SRC = 1 kernels: resident float64 deviates in the reference's order (random.py:24-28),
                           // 2 per cell of the API layout [nx][ny][nz/2+1]
   int zpitch, zoff;       // row pitch and first plane of the side arrays (noise, potential): see GenParams
+  int ppitch;             // row pitch (cells) of the POTENTIAL array: zpitch rounded up to even for float32 plans, so that the
+                          // generation pass stores a cell pair (kz even, kz + 1) with one aligned 16-byte store
   const cplx<float>* noise32;   // SRC = 2 kernels: the same deviates as float32 pairs (g_re, g_im), one per cell
 };
 enum { FAST_LDS_BINS = 512 };

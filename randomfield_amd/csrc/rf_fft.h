@@ -291,11 +291,15 @@ struct FastGenColIOT {
     }
     if (POT) {
       // row (ix, iy) of the API layout; the slot kz = 0 (Hermitian planes) is written by fix_value() instead
-      const int nzp = gp.zpitch, sl = kz - gp.zoff;
+      // rows of gp.ppitch (even) cells: the pair (kz even, kz + 1) is one aligned 16-byte store
+      const int nzp = gp.ppitch, sl = kz - gp.zoff;
       cplx<float>* row = (pot + (long long)ro * gp.ny * nzp) + (uint32_t)((rb * gp.ny + iy) * nzp);
       const float ra = fast_rcp(k2a), rb2 = fast_rcp(k2b);
-      if (!(FIX != 0 && kz == 0)) row[sl] = mk<float>(v.c[0].x * ra, v.c[0].y * ra);
-      row[sl + 1] = mk<float>(v.c[1].x * rb2, v.c[1].y * rb2);
+      V16<float> q;
+      q.c[0] = mk<float>(v.c[0].x * ra, v.c[0].y * ra);
+      q.c[1] = mk<float>(v.c[1].x * rb2, v.c[1].y * rb2);
+      if (FIX != 0 && kz == 0) row[sl + 1] = q.c[1];          // slot kz = 0 itself: written by fix_value()
+      else v16_store<float>(row + sl, q);
     }
     return v;
   }
@@ -311,10 +315,9 @@ struct FastGenColIOT {
     const cplx<float> packed = SRC != 0 ? fast_fix_kz0_noise<SRC == 0 ? 1 : SRC>(gp, rec, rb + ro, iy, p0, pn)
                                         : fast_fix_kz0(gp, rec, seed, rb + ro, iy, p0, pn);
     if (POT) {
-      const int nzp = gp.zpitch;                 // only the rank with kz0 = 0 gets here: slot 0 = plane 0
-      cplx<float>* row = pot + ((long long)(rb + ro) * gp.ny + iy) * nzp;
+      cplx<float>* row = pot + ((long long)(rb + ro) * gp.ny + iy) * gp.ppitch;   // only the rank with kz0 = 0 gets here: slot 0 = plane 0
       row[0] = p0;
-      row[nzp - 1] = pn;
+      row[gp.zpitch - 1] = pn;
     }
     return packed;
   }
@@ -364,7 +367,7 @@ struct FastGenColIO64 {
       const float r = fast_rcp(k2);
       V16<double> q;
       q.c[0] = mk<double>((double)(c.x * r), (double)(c.y * r));
-      v16_store<double>((pot + (long long)ro * gp.ny * gp.zpitch) + (uint32_t)((rb * gp.ny + iy) * gp.zpitch + (kz - gp.zoff)), q);
+      v16_store<double>((pot + (long long)ro * gp.ny * gp.ppitch) + (uint32_t)((rb * gp.ny + iy) * gp.ppitch + (kz - gp.zoff)), q);
     }
     return v;
   }
@@ -377,7 +380,7 @@ struct FastGenColIO64 {
     const int iy = (int)((unsigned)C >> nzl_shift());
     const cplx<float> c = fast_fix_kz0(gp, rec, seed, rb + ro, iy, p0, pn);
     if (POT) {
-      cplx<double>* row = pot + ((long long)(rb + ro) * gp.ny + iy) * gp.zpitch;      // only the rank with kz0 = 0 gets here
+      cplx<double>* row = pot + ((long long)(rb + ro) * gp.ny + iy) * gp.ppitch;      // only the rank with kz0 = 0 gets here
       row[0] = mk<double>((double)p0.x, (double)p0.y);
       row[gp.zpitch - 1] = mk<double>((double)pn.x, (double)pn.y);
     }

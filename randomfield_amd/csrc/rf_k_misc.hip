@@ -101,7 +101,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void save_potential_kernel(const cplx<T>* __restrict__ K, cplx<T>* __restrict__ P,
                                                              int nx, int ny, int nz, const double* __restrict__ kx2,
                                                              const double* __restrict__ ky2, const double* __restrict__ kz2,
-                                                             int zpitch, int zoff) {
+                                                             int zpitch, int zoff, int ppitch) {
   const int nzh = zpitch;
   const long long total = (long long)nx * ny * nzh;
   for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += (long long)gridDim.x * blockDim.x) {
@@ -115,15 +115,17 @@ __global__ __launch_bounds__(256) void save_potential_kernel(const cplx<T>* __re
     // complex (inv + 0i) * d: the 0*x terms of numpy's complex product vanish exactly
     cplx<T> r = mk<T>(inv * d.x, inv * d.y);
     if (ix == 0 && iy == 0 && iz == 0) r = mk<T>((T)0, (T)0);
-    P[c] = r;
+    P[col * ppitch + sl] = r;                 // the potential array's rows may be padded (FastGenParams::ppitch)
   }
 }
 
+// K (rows of zpitch cells) = scale * P (rows of ppitch >= zpitch cells)
 template <typename T>
 __global__ __launch_bounds__(256) void scale_copy_kernel(const cplx<T>* __restrict__ P, cplx<T>* __restrict__ K,
-                                                         long long n, T scale) {
+                                                         long long n, int zpitch, int ppitch, T scale) {
   for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < n; c += (long long)gridDim.x * blockDim.x) {
-    cplx<T> p = P[c];
+    const long long col = c / zpitch;
+    cplx<T> p = P[col * ppitch + (c - col * zpitch)];
     K[c] = mk<T>(p.x * scale, p.y * scale);
   }
 }
@@ -321,16 +323,16 @@ hipError_t launch_lensing(int f64, const void* phi, void* psi, long long nrows, 
 }
 
 hipError_t launch_save_potential(int f64, const void* K, void* P, int nx, int ny, int nz, const double* kx2,
-                                 const double* ky2, const double* kz2, int zpitch, int zoff, hipStream_t s) {
+                                 const double* ky2, const double* kz2, int zpitch, int zoff, int ppitch, hipStream_t s) {
   const long long total = (long long)nx * ny * zpitch;
-  if (f64) hipLaunchKernelGGL(save_potential_kernel<double>, dim3(grid_for(total, 256)), dim3(256), 0, s, (const cplx<double>*)K, (cplx<double>*)P, nx, ny, nz, kx2, ky2, kz2, zpitch, zoff);
-  else hipLaunchKernelGGL(save_potential_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, s, (const cplx<float>*)K, (cplx<float>*)P, nx, ny, nz, kx2, ky2, kz2, zpitch, zoff);
+  if (f64) hipLaunchKernelGGL(save_potential_kernel<double>, dim3(grid_for(total, 256)), dim3(256), 0, s, (const cplx<double>*)K, (cplx<double>*)P, nx, ny, nz, kx2, ky2, kz2, zpitch, zoff, ppitch);
+  else hipLaunchKernelGGL(save_potential_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, s, (const cplx<float>*)K, (cplx<float>*)P, nx, ny, nz, kx2, ky2, kz2, zpitch, zoff, ppitch);
   return hipGetLastError();
 }
 
-hipError_t launch_scale_copy(int f64, const void* P, void* K, long long n, double scale, hipStream_t s) {
-  if (f64) hipLaunchKernelGGL(scale_copy_kernel<double>, dim3(grid_for(n, 256)), dim3(256), 0, s, (const cplx<double>*)P, (cplx<double>*)K, n, scale);
-  else hipLaunchKernelGGL(scale_copy_kernel<float>, dim3(grid_for(n, 256)), dim3(256), 0, s, (const cplx<float>*)P, (cplx<float>*)K, n, (float)scale);
+hipError_t launch_scale_copy(int f64, const void* P, void* K, long long n, int zpitch, int ppitch, double scale, hipStream_t s) {
+  if (f64) hipLaunchKernelGGL(scale_copy_kernel<double>, dim3(grid_for(n, 256)), dim3(256), 0, s, (const cplx<double>*)P, (cplx<double>*)K, n, zpitch, ppitch, scale);
+  else hipLaunchKernelGGL(scale_copy_kernel<float>, dim3(grid_for(n, 256)), dim3(256), 0, s, (const cplx<float>*)P, (cplx<float>*)K, n, zpitch, ppitch, (float)scale);
   return hipGetLastError();
 }
 }  // namespace rf

@@ -89,8 +89,9 @@ hipError_t launch_lensing(int f64, const void* phi, void* psi, long long nrows, 
 // P = K / k^2 (0 at DC), API layout; and K = scale * P
 // (side arrays of a kz-slab rank: rows of zpitch slots, first plane zoff -- GenParams)
 hipError_t launch_save_potential(int f64, const void* K, void* P, int nx, int ny, int nz, const double* kx2,
-                                 const double* ky2, const double* kz2, int zpitch, int zoff, hipStream_t s);
-hipError_t launch_scale_copy(int f64, const void* P, void* K, long long n, double scale, hipStream_t s);
+                                 const double* ky2, const double* kz2, int zpitch, int zoff, int ppitch, hipStream_t s);
+// (n = cells of K; P's rows hold ppitch >= zpitch cells)
+hipError_t launch_scale_copy(int f64, const void* P, void* K, long long n, int zpitch, int ppitch, double scale, hipStream_t s);
 
 // on-GPU replay of RandomState(seed).normal (rf_k_mt.hip)
 // one stage of the jump tree: states[i + m * dist] = states[i] advanced by m * dist segments, i < nsrc, m = 1 .. nmult
