@@ -38,11 +38,7 @@ template <typename T> struct alignas(16) V16 {
 template <typename T> RF_HD void v16_store(void* p, const V16<T>& v) {
 #if defined(__HIP_DEVICE_COMPILE__)
   typedef unsigned u4 __attribute__((ext_vector_type(4)));
-#ifdef RF_FLAT_ACCESS          /* development: the old generic-pointer accesses, for A/B timing */
-  typedef u4 gu4;
-#else
   typedef __attribute__((address_space(1))) u4 gu4;
-#endif
   union { V16<T> s; u4 q; } u;
   u.s = v;
   *(gu4*)p = u.q;
@@ -53,11 +49,7 @@ template <typename T> RF_HD void v16_store(void* p, const V16<T>& v) {
 template <typename T> RF_HD V16<T> v16_load(const void* p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   typedef unsigned u4 __attribute__((ext_vector_type(4)));
-#ifdef RF_FLAT_ACCESS
-  typedef u4 gu4;
-#else
   typedef __attribute__((address_space(1))) u4 gu4;
-#endif
   union { V16<T> s; u4 q; } u;
   u.q = *(const gu4*)p;
   return u.s;
