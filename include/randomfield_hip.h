@@ -92,7 +92,8 @@ int rf_noise_mt19937(rf_plan* plan, const uint32_t* state624, unsigned long long
 /* single = 1 (a request, honoured by float32 plans that have the fast generation pass; others keep float64): keep the
  * deviates as float32 pairs instead -- half the memory traffic of the replay and of
  * the generation pass that reads them; accept / reject stays in float64, f = sqrt(-2 log r2 / r2) is formed in float32
- * (1e-7 relative).  rf_realise / rf_realise_potential with RF_NOISE_RESIDENT use whichever copy is resident; rf_generate,
+ * (1e-7 relative); the pairs stay in the replay's per-segment runs (8 bytes per polar attempt of the whole stream) and the
+ * generation pass locates them.  rf_realise / rf_realise_potential with RF_NOISE_RESIDENT use whichever copy is resident; rf_generate,
  * rf_download_noise and float64 plans need the float64 ones (single = 0, = rf_noise_mt19937). */
 int rf_noise_mt19937_ex(rf_plan* plan, const uint32_t* state624, unsigned long long* accepted, int single);
 /* copy deviates [first, first+count) of the device noise buffer to the host (tests) */

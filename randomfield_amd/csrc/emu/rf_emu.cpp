@@ -241,7 +241,7 @@ int realise_fast_impl(int nx, int ny, int nz, const GenHost& h, uint64_t seed, d
   f.nx = nx; f.ny = ny; f.nz = nz; f.dkx = (float)dkx; f.dky = (float)std::sqrt(h.gp.ky2[1]); f.dkz = (float)std::sqrt(h.gp.kz2[1]);
   f.rec = rec.data(); f.nbins = (int)rec.size();
   f.u_scale = (float)(0.5 * std::log10(2.0) / dx); f.u_off = (float)(-x0 / dx);
-  f.seed = seed; f.seed_dev = nullptr; f.noise = nullptr; f.noise32 = nullptr; f.zpitch = nz / 2 + 1; f.zoff = 0; f.ppitch = nz / 2 + 2;
+  f.seed = seed; f.seed_dev = nullptr; f.noise = nullptr; f.noise32 = nullptr; f.seg_off = nullptr; f.seg_cap = 0; f.seg_inv = 0; f.nseg = 0; f.zpitch = nz / 2 + 1; f.zoff = 0; f.ppitch = nz / 2 + 2;
   int rc = dispatch_col<T, +1, IO, GenSel>(nx, io, (long long)ny * nzc);
   if (rc) return rc;
   PlainColIO<T> pio; pio.base = W; pio.g = ColGeom{nzc, (long long)ny * nzc, nzc};

@@ -125,16 +125,20 @@ struct rf_plan {
   double* noise = nullptr;
   size_t noise_cap = 0;
   bool noise_resident = false;            // the device noise buffer holds a full set of deviates
-  float* noise32 = nullptr;               // the same deviates as float32 pairs (rf_noise_mt19937_ex(single = 1)); only one
-  size_t noise32_cap = 0;                 // of the two buffers is valid at a time
+  // float32 deviates (rf_noise_mt19937_ex(single = 1)) stay where the one-pass replay writes them: mt_scratch, every
+  // segment's accepted pairs from slot seg * seg_cap, located through mt_offsets (FastGenParams::seg_*).  Only one of
+  // the two forms (float64 in cell order / float32 in segment order) is valid at a time.
   bool noise32_resident = false;
+  unsigned long long seg_cap = 0;
+  double seg_inv = 0;
+  int nseg = 0;
   // MT19937 replay (rf_noise_mt19937): jump-polynomial bit positions per tree level, scratch
   uint32_t* mt_pos = nullptr;          // set-bit positions of the jump polynomials, widened to 32 bits (scalar loads)
   std::vector<int> mt_npos;
   int mt_stride = 0, mt_bps = 0, mt_radix = 2;   // positions per polynomial (padded), blocks of 624 words per segment, tree radix
   int* mt_npos_dev = nullptr;
   uint32_t* mt_states = nullptr;
-  unsigned long long *mt_counts = nullptr, *mt_offsets = nullptr;
+  unsigned long long *mt_counts = nullptr, *mt_offsets = nullptr, *mt_pairs = nullptr;
   size_t mt_states_cap = 0, mt_seg_cap = 0;
   void* mt_scratch = nullptr;          // one-pass replay: every segment's accepted pairs, densely from slot seg * (attempts per segment)
   size_t mt_scratch_bytes = 0;
@@ -319,7 +323,10 @@ int queue_x(rf_plan* p, const GenParams& gp, const void* kspace, void* W, hipStr
   const ColGeom gx{(long long)p->ny * nzl, 0, (long long)p->ny * nzl};
   if (timed) { RF_HIP(hipEventRecord(p->ev[5], sx)); p->repair_timed = fast; }   // overwritten by the launcher if it splits
   FastGenParams fgp = make_fast(p, gp.seed, gp.seed_dev != nullptr, gp.seed_dev);
-  if (fast_noise && p->noise32_resident) fgp.noise32 = reinterpret_cast<const cplx<float>*>(p->noise32);
+  if (fast_noise && p->noise32_resident) {
+    fgp.noise32 = reinterpret_cast<const cplx<float>*>(p->mt_scratch);      // (a later float64 replay reuses the scratch: it clears noise32_resident)
+    fgp.seg_off = p->mt_pairs; fgp.seg_cap = p->seg_cap; fgp.seg_inv = p->seg_inv; fgp.nseg = p->nseg;
+  }
   else if (fast_noise) fgp.noise = gp.noise;
   if (fast)
     RF_HIP(launch_col_fastgen(p->f64, p->nx, W, gx, (long long)p->ny * nzl, fgp,
@@ -747,7 +754,7 @@ int rf_plan_destroy(rf_plan* p) {
   if (p->comm_stream) { (void)hipStreamSynchronize(p->comm_stream); (void)hipStreamDestroy(p->comm_stream); }
   for (auto& e : p->pev) if (e) (void)hipEventDestroy(e);
   void* bufs[] = {p->W, p->R, p->W2, p->R2, p->K, p->P, p->G, p->tw_x, p->tw_y, p->tw_z, p->kx2, p->ky2, p->kz2, p->xt, p->st, p->sl, p->bin,
-                  p->noise, p->noise32, p->mt_scratch, p->mt_pos, p->mt_npos_dev, p->mt_states, p->mt_counts, p->mt_offsets, p->partials, p->stats, p->seeds_dev, p->ztab, p->frec, p->coll_scratch};
+                  p->noise, p->mt_scratch, p->mt_pos, p->mt_npos_dev, p->mt_states, p->mt_counts, p->mt_offsets, p->mt_pairs, p->partials, p->stats, p->seeds_dev, p->ztab, p->frec, p->coll_scratch};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   for (int i = 0; i < 2; ++i) {
@@ -1326,17 +1333,8 @@ int rf_noise_mt19937_ex(rf_plan* p, const uint32_t* state624, unsigned long long
   RF_REQUIRE(!p->unpacked, "this call does not apply to an unpacked c2c plan");
   RF_REQUIRE(p->mt_pos && !p->mt_npos.empty(), "rf_mt_set_jump must be called first");
   RF_HIP(hipSetDevice(p->device));
-  if (single) {
-    const size_t n = 2 * (size_t)p->nx * p->ny * (p->nzl + 1);
-    if (p->noise32_cap < n) {
-      if (p->noise32) RF_HIP(hipFree(p->noise32));
-      p->noise32 = nullptr; p->noise32_cap = 0; p->noise32_resident = false;
-      RF_HIP(hipMalloc((void**)&p->noise32, n * sizeof(float)));
-      p->noise32_cap = n;
-    }
-  } else if (int rc = ensure_noise(p)) {
-    return rc;
-  }
+  if (!single)
+    if (int rc = ensure_noise(p)) return rc;
   const unsigned long long ncells = (unsigned long long)p->nx * p->ny * (p->nzc + 1);
   // polar attempts to generate: acceptance pi/4, margin of 10 sigma + 1024 (mt19937.attempts_needed)
   const double pa = 0.78539816339744830962;
@@ -1362,6 +1360,9 @@ int rf_noise_mt19937_ex(rf_plan* p, const uint32_t* state624, unsigned long long
     p->mt_counts = p->mt_offsets = nullptr;
     RF_HIP(hipMalloc((void**)&p->mt_counts, ((size_t)nseg + 1) * sizeof(unsigned long long)));
     RF_HIP(hipMalloc((void**)&p->mt_offsets, ((size_t)nseg + 1) * sizeof(unsigned long long)));
+    if (p->mt_pairs) RF_HIP(hipFree(p->mt_pairs));
+    p->mt_pairs = nullptr;
+    RF_HIP(hipMalloc((void**)&p->mt_pairs, 2 * ((size_t)nseg + 1) * sizeof(unsigned long long)));
     p->mt_seg_cap = (size_t)nseg + 1;
   }
   hipStream_t s = p->stream;
@@ -1388,12 +1389,19 @@ int rf_noise_mt19937_ex(rf_plan* p, const uint32_t* state624, unsigned long long
   }
   RF_HIP(launch_mt_polar(true, p->mt_states, nseg, p->mt_bps, total_blocks, p->mt_counts, nullptr, (double*)p->mt_scratch, ncells,
                          (int)p->nzc + 1, (int)p->nzl + 1, p->kz0, s, single != 0, cap));
-  RF_HIP(launch_mt_scan(p->mt_counts, p->mt_offsets, nseg, s));
-  RF_HIP(launch_mt_compact(single != 0, p->mt_scratch, p->mt_counts, p->mt_offsets, nseg, cap, single ? (void*)p->noise32 : (void*)p->noise,
-                           ncells, (int)p->nzc + 1, (int)p->nzl + 1, p->kz0, s));
-  unsigned long long total = 0;
+  RF_HIP(launch_mt_scan(p->mt_counts, p->mt_offsets, nseg, s, p->mt_pairs));
+  // float64 deviates are moved into cell order (and cut to this rank's planes); float32 ones stay in the segments' runs:
+  // the generation pass finds cell c through the scan (slack_cell), which saves the 1.7 ms copy per 1024^3
+  if (!single)
+    RF_HIP(launch_mt_compact(false, p->mt_scratch, p->mt_counts, p->mt_offsets, nseg, cap, p->noise, ncells, (int)p->nzc + 1,
+                             (int)p->nzl + 1, p->kz0, s));
+  unsigned long long total = 0, full = 0;
   RF_HIP(hipMemcpyAsync(&total, p->mt_offsets + nseg, sizeof(total), hipMemcpyDeviceToHost, s));
+  RF_HIP(hipMemcpyAsync(&full, p->mt_offsets + (nseg > 1 ? nseg - 1 : 1), sizeof(full), hipMemcpyDeviceToHost, s));
   RF_HIP(hipStreamSynchronize(s));
+  p->nseg = nseg;
+  p->seg_cap = cap;
+  p->seg_inv = full > 0 ? (double)(nseg > 1 ? nseg - 1 : 1) / (double)full : 0.0;     // the last segment may be a short one
   if (accepted) *accepted = total;
   RF_REQUIRE(total >= ncells, "MT19937 replay: not enough accepted polar attempts (increase the margin)");
   p->noise_resident = !single;

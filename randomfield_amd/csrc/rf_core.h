@@ -416,7 +416,14 @@ struct FastGenParams {
   int zpitch, zoff;       // row pitch and first plane of the side arrays (noise, potential): see GenParams
   int ppitch;             // row pitch (cells) of the POTENTIAL array: zpitch rounded up to even for float32 plans, so that the
                           // generation pass stores a cell pair (kz even, kz + 1) with one aligned 16-byte store
-  const cplx<float>* noise32;   // SRC = 2 kernels: the same deviates as float32 pairs (g_re, g_im), one per cell
+  // SRC = 2 kernels: the same deviates as float32 pairs (g_re, g_im), read where the one-pass replay left them -- every
+  // MT19937 segment's accepted pairs densely from slot seg * seg_cap of `noise32`, cell c of the stream in the segment
+  // with seg_off[seg] <= c < seg_off[seg + 1] (exclusive scan of the per-segment counts).  No copy into cell order.
+  const cplx<float>* noise32;
+  const unsigned long long* seg_off;   // [2 nseg]: (first cell of segment s, first cell of segment s + 1) pairs -- one 16-byte load
+  unsigned long long seg_cap;          // attempts (= slots) per segment
+  double seg_inv;                      // 1 / (accepted pairs of a full segment): first guess of a cell's segment
+  int nseg;
 };
 enum { FAST_LDS_BINS = 512 };
 
@@ -539,14 +546,40 @@ RF_HD cplx<float> fast_fix_kz0(const FastGenParams& g, const FastRec* rec, uint6
 // The same slot from resident deviates (the reference's stream, e.g. replayed MT19937): cell = sigma * (g_re + i g_im)
 // with the float64 product rounded once (random.py:28), symmetrised as above.  SRC = 1: float64 deviates; SRC = 2: the
 // float32 copies (float32 plans: the product is then formed in float32, 6e-8 relative from the once-rounded one).
+struct U64Pair { unsigned long long lo, hi; };
+RF_HD U64Pair v16_load_any(const unsigned long long* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef unsigned long long u2 __attribute__((ext_vector_type(2)));
+  const u2 v = *reinterpret_cast<const __attribute__((address_space(1))) u2*>((const __attribute__((address_space(1))) unsigned long long*)p);
+  return U64Pair{v.x, v.y};
+#else
+  return U64Pair{p[0], p[1]};
+#endif
+}
+// Where the pair of stream cell c lives (SRC = 2): the segment is guessed from the mean acceptance count (the counts are
+// binomial: the guess is off by at most one segment) and corrected against the scan; o1 = first cell of the next segment.
+RF_HD const cplx<float>* slack_cell(const FastGenParams& g, unsigned long long c, int& seg, unsigned long long& o1) {
+  int s = (int)(((double)(unsigned)(c >> 32) * 4294967296.0 + (double)(unsigned)c) * g.seg_inv);
+  s = s < 0 ? 0 : (s > g.nseg - 1 ? g.nseg - 1 : s);
+  U64Pair pr = v16_load_any(g.seg_off + 2 * s);
+  unsigned long long o0 = pr.lo, on = pr.hi;
+  while (c < o0) { pr = v16_load_any(g.seg_off + 2 * --s); o0 = pr.lo; on = pr.hi; }
+  while (c >= on) { pr = v16_load_any(g.seg_off + 2 * ++s); o0 = pr.lo; on = pr.hi; }
+  seg = s;
+  o1 = on;
+  return g.noise32 + (unsigned long long)s * g.seg_cap + (c - o0);
+}
+
 template <int SRC>
 RF_HD cplx<float> fast_noise_cell(const FastGenParams& g, const FastRec* rec, int ix, int iy, int kz, float k2) {
-  const long long c = ((long long)ix * g.ny + iy) * g.zpitch + side_slot(g, kz);
   if (SRC == 2) {
+    int seg;
+    unsigned long long o1;
     const float s = fast_sigma(g, rec, k2);
-    const cplx<float> d = g.noise32[c];
+    const cplx<float> d = *slack_cell(g, ((unsigned long long)ix * g.ny + iy) * (unsigned)(g.nz / 2 + 1) + (unsigned)kz, seg, o1);
     return mk<float>(s * d.x, s * d.y);
   }
+  const long long c = ((long long)ix * g.ny + iy) * g.zpitch + side_slot(g, kz);
   const double* d = g.noise + 2 * c;
   const double s = (double)fast_sigma(g, rec, k2);
   return mk<float>((float)(s * d[0]), (float)(s * d[1]));

@@ -273,10 +273,13 @@ struct FastGenColIOT {
       v.c[0] = mk<float>((float)(sa * ga.c[0].x), (float)(sa * ga.c[0].y));
       v.c[1] = mk<float>((float)(sb * gb.c[0].x), (float)(sb * gb.c[0].y));
     } else {
-      // float32 copies of the same deviates: 16 contiguous bytes (rows of zpitch = odd cells: 8-byte aligned only)
-      const int nzp = gp.zpitch;
-      const cplx<float>* d = (gp.noise32 + (long long)ro * gp.ny * nzp) + (uint32_t)((rb * gp.ny + iy) * nzp + (kz - gp.zoff));
-      const cplx<float> ga = d[0], gb = d[1];
+      // float32 pairs where the one-pass replay left them (rf_core.h slack_cell): cells c and c + 1 of the stream are
+      // neighbours unless a segment ends between them
+      const unsigned long long c = ((unsigned long long)(rb + ro) * gp.ny + iy) * (unsigned)(gp.nz / 2 + 1) + (unsigned)kz;
+      int seg;
+      unsigned long long o1;
+      const cplx<float>* d = slack_cell(gp, c, seg, o1);
+      const cplx<float> ga = d[0], gb = c + 1 < o1 ? d[1] : gp.noise32[(unsigned long long)(seg + 1) * gp.seg_cap];
       const float sa = fast_sigma(gp, rec, k2a), sb = fast_sigma(gp, rec, k2b);
       v.c[0] = mk<float>(sa * ga.x, sa * ga.y);
       v.c[1] = mk<float>(sb * gb.x, sb * gb.y);

@@ -240,7 +240,8 @@ __global__ __launch_bounds__(256) void mt_polar_kernel(const uint32_t* __restric
 }
 
 // exclusive scan of the per-segment counts by ONE wave: lane l owns a contiguous chunk, wave scan across lanes
-__global__ __launch_bounds__(64) void mt_scan_kernel(const unsigned long long* __restrict__ counts, unsigned long long* __restrict__ offsets, int n) {
+__global__ __launch_bounds__(64) void mt_scan_kernel(const unsigned long long* __restrict__ counts, unsigned long long* __restrict__ offsets, int n,
+                                                    unsigned long long* __restrict__ pairs) {
   const int lane = threadIdx.x;
   const int per = (n + 63) / 64, lo = lane * per, hi = lo + per < n ? lo + per : n;
   unsigned long long sum = 0;
@@ -252,7 +253,11 @@ __global__ __launch_bounds__(64) void mt_scan_kernel(const unsigned long long* _
     if (lane >= off) inc += t;
   }
   unsigned long long run = inc - sum;
-  for (int i = lo; i < hi; ++i) { offsets[i] = run; run += counts[i]; }
+  for (int i = lo; i < hi; ++i) {
+    offsets[i] = run;
+    if (pairs) { pairs[2 * i] = run; pairs[2 * i + 1] = run + counts[i]; }     // (first cell, first cell of the next segment)
+    run += counts[i];
+  }
   if (lane == 63) offsets[n] = inc;                    // total number of accepted attempts
 }
 
@@ -321,8 +326,8 @@ hipError_t launch_mt_polar(bool fill, const uint32_t* states, int nseg, int bloc
   else hipLaunchKernelGGL((mt_polar_kernel<false, false>), dim3(grid), dim3(256), 0, s, states, blocks_per_segment, total_blocks, nseg, counts, offsets, noise, ncells, nzh, zpitch, zoff, 0ull);
   return hipGetLastError();
 }
-hipError_t launch_mt_scan(const unsigned long long* counts, unsigned long long* offsets, int n, hipStream_t s) {
-  hipLaunchKernelGGL(mt_scan_kernel, dim3(1), dim3(64), 0, s, counts, offsets, n);
+hipError_t launch_mt_scan(const unsigned long long* counts, unsigned long long* offsets, int n, hipStream_t s, unsigned long long* pairs) {
+  hipLaunchKernelGGL(mt_scan_kernel, dim3(1), dim3(64), 0, s, counts, offsets, n, pairs);
   return hipGetLastError();
 }
 

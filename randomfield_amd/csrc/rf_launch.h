@@ -110,7 +110,9 @@ hipError_t launch_mt_compact(bool single, const void* scratch, const unsigned lo
                              hipStream_t s);
 // (single: `noise` is an array of float32 pairs instead of float64 pairs)
 // (nzh = nz/2 + 1 cells per row of the stream; zpitch / zoff: the noise buffer's rows, see GenParams)
-hipError_t launch_mt_scan(const unsigned long long* counts, unsigned long long* offsets, int n, hipStream_t s);
+// (pairs, optional: [2 n] = (offsets[i], offsets[i + 1]) -- what the generation pass loads with one 16-byte access)
+hipError_t launch_mt_scan(const unsigned long long* counts, unsigned long long* offsets, int n, hipStream_t s,
+                          unsigned long long* pairs = nullptr);
 
 // non-power-of-two grids (rf_generic.h, rf_k_generic.hip); root = exp(2 pi i t / n) tables as made by make_twiddles
 // complex pass along one axis: line l starts at (l / inner) * outer + l % inner, elements `stride` apart; src == dst allowed
