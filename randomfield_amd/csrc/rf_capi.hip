@@ -604,7 +604,11 @@ int rf_plan_create(rf_plan** out, int nx, int ny, int nz, int dtype, int device,
   p->nxl = nx / nranks; p->nzl = p->nzc / nranks; p->kz0 = rank * p->nzl;
   p->w_bytes = (size_t)nx * ny * p->nzl * p->csize;       // == nxl * ny * nzc: the local share of the field
   p->k_bytes = (size_t)nx * ny * (p->nzl + 1) * p->csize;    // side arrays: this rank's planes + the Nyquist plane
-  p->ppitch = dtype ? (int)p->nzl + 1 : (int)p->nzl + 2;     // (nzl is even) float32: 16-byte aligned cell pairs for the fused store
+  // float32: an even pitch (nzl is even), so that the fused store writes 16-byte aligned cell pairs; on large grids 64 cells
+  // beyond the row instead of 2 -- the time of the two strided store streams of rf_realise_potential depends on where the
+  // allocator puts the two arrays (tools/frag_probe.py, 1024^3: 5.6 / 6.8 / 6.9 ms in three allocation histories with pitch
+  // nz/2 + 2; 5.5 / 6.1 / 6.0 ms with nz/2 + 64), which a row stride further from the field's 4 MiB softens
+  p->ppitch = dtype ? (int)p->nzl + 1 : (int)p->nzl + (p->nzl >= 256 ? 64 : 2);
   p->p_bytes = (size_t)nx * ny * p->ppitch * p->csize;
   auto cleanup = [&](int rc) { rf_plan_destroy(p); return rc; };
   hipError_t e;
