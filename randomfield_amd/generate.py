@@ -150,6 +150,7 @@ class Generator(object):
 
         self.delta_field_rms = None
         self.smoothed_power = None
+        self._device_table = None
         self._field_on_host = False
         if self.backend == "hip":
             dev = self.plan_c2r.device
@@ -221,7 +222,10 @@ class Generator(object):
         else:
             dev = self.plan_c2r.device
             log10_k, sigma = powertools.sigma_table(self.smoothed_power, (nx, ny, nz), self.grid_spacing_Mpc_h)
-            dev.set_power(log10_k, sigma)
+            table = (log10_k.tobytes(), sigma.tobytes())
+            if table != self._device_table:      # same power and smoothing as last time: the device tables are current
+                dev.set_power(log10_k, sigma)     # (re-uploading them costs a stream sync and a table rebuild per call)
+                self._device_table = table
             if self.rng == "reference":
                 # RandomState(seed).normal (random.py:24): MT19937 + polar method replayed on the GPU from the seed's
                 # 624-word start state -- integer seeds, array seeds (init_by_array) and None alike; no host deviates

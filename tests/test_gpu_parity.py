@@ -284,9 +284,14 @@ def test_generator_api_hip_backend(hip):
     assert abs(gen.delta_field_rms - rms) <= TOL_F32 * rms and isinstance(gen.delta_field_rms, np.float32)
     assert data.base is not None                                      # a view of the plan's buffer
     first = data.copy()
-    again = gen.generate_delta_field(seed=123, save_potential=False)  # fused path (float32 sigma arithmetic), same answer
+    again = gen.generate_delta_field(seed=123, save_potential=False).copy()  # fused path (float32 sigma arithmetic), same answer
     assert np.max(np.abs(again - first)) <= 3e-6 * rms and gen.potential is None
     assert np.max(np.abs(again[::8, ::8, ::8] - g["sub"])) <= TOL_F32 * rms
+    # the device's power tables follow the smoothing length from call to call (they are only re-sent when they change)
+    smooth = gen.generate_delta_field(seed=123, smoothing_length_Mpc_h=5.0, save_potential=False).copy()
+    assert float(gen.delta_field_rms) < 0.8 * rms and not np.allclose(smooth, first)
+    back = gen.generate_delta_field(seed=123, save_potential=False)
+    assert np.array_equal(back, again)
     nat = Generator(64, 64, 64, 2.5, rng="native")
     a = nat.generate_delta_field(seed=5, save_potential=False).copy()
     b = nat.generate_delta_field(seed=5, save_potential=False)
