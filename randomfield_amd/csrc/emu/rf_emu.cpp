@@ -316,6 +316,22 @@ int generic_c2c_impl(int nx, int ny, int nz, int dir, cplx<T>* D) {
 
 extern "C" {
 
+// slack_cell (rf_core.h): where the generation pass finds the float32 deviate pair of stream cell c when the pairs were left
+// in the replay's per-segment runs.  pairs = (first cell, first cell of the next segment) per segment; out[i] = slot index.
+int emu_slack_lookup(const unsigned long long* pairs, int nseg, unsigned long long cap, double inv, const unsigned long long* cells,
+                     int n, unsigned long long* out, int* seg_out) {
+  FastGenParams g;
+  memset(&g, 0, sizeof g);
+  std::vector<cplx<float>> dummy(1);
+  g.noise32 = dummy.data(); g.seg_off = pairs; g.seg_cap = cap; g.seg_inv = inv; g.nseg = nseg;
+  for (int i = 0; i < n; ++i) {
+    unsigned long long o1;
+    const cplx<float>* p = slack_cell(g, cells[i], seg_out[i], o1);
+    out[i] = (unsigned long long)(p - g.noise32);
+  }
+  return 0;
+}
+
 // the generic (any even shape) transforms: API-layout half spectrum <-> dense real field; c2c in place
 int emu_generic_c2r(int f64, int nx, int ny, int nz, const void* K, void* W, double* s1, double* s2) {
   return f64 ? generic_c2r_impl<double>(nx, ny, nz, (const cplx<double>*)K, (double*)W, s1, s2)

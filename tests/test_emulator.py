@@ -246,3 +246,32 @@ def test_generic_c2r_reproduces_reference_fields(name):
     assert np.max(np.abs(out - g["delta"])) <= tol * float(g["rms"])
     n = out.size
     assert abs(np.sqrt(s2 / n - (s1 / n) ** 2) - float(g["rms"])) <= 10 * tol * float(g["rms"])
+
+
+def test_slack_cell_lookup_of_resident_float32_deviates():
+    """rng='reference' on complex64 plans: the generation pass locates the pair of stream cell c in the replay's per-segment
+    runs (rf_core.h slack_cell: guess the segment from the mean count, correct against the scan).  Against
+    numpy.searchsorted, with a good guess, a deliberately bad one, a short last segment and a single segment."""
+    import ctypes
+    lib = emu_util.lib()
+    rng = np.random.RandomState(4)
+    u64p = ctypes.POINTER(ctypes.c_ulonglong)
+    for nseg, mean, last in ((4300, 125463, 30000), (7, 1000, 1000), (1, 500, 500), (2, 3, 1)):
+        counts = rng.binomial(int(mean / 0.7854) + 1, 0.7854, size=nseg).astype(np.uint64)
+        counts[-1] = last
+        off = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64)
+        pairs = np.ascontiguousarray(np.stack([off[:-1], off[1:]], axis=1).reshape(-1))
+        cap = int(mean / 0.7854) + 8
+        total = int(off[-1])
+        cells = np.unique(np.concatenate([rng.randint(0, total, size=2000), off[:-1], off[1:] - 1])).astype(np.uint64)
+        cells = np.ascontiguousarray(cells[cells < total])
+        want_seg = np.searchsorted(off, cells, side="right") - 1
+        want = want_seg.astype(np.uint64) * np.uint64(cap) + (cells - off[want_seg])
+        full = float(off[nseg - 1]) / (nseg - 1) if nseg > 1 else float(total)
+        for inv in (1.0 / full, 0.7 / full, 1.6 / full):          # the library's guess, and two bad ones
+            out = np.zeros(len(cells), np.uint64)
+            seg = np.zeros(len(cells), np.int32)
+            lib.emu_slack_lookup(pairs.ctypes.data_as(u64p), nseg, ctypes.c_ulonglong(cap), ctypes.c_double(inv),
+                                 cells.ctypes.data_as(u64p), len(cells), out.ctypes.data_as(u64p),
+                                 seg.ctypes.data_as(ctypes.POINTER(ctypes.c_int)))
+            assert np.array_equal(seg, want_seg) and np.array_equal(out, want)
