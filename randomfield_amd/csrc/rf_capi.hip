@@ -1391,8 +1391,7 @@ int rf_noise_mt19937_ex(rf_plan* p, const uint32_t* state624, unsigned long long
     RF_HIP(hipMalloc(&p->mt_scratch, need));
     p->mt_scratch_bytes = need;
   }
-  RF_HIP(launch_mt_polar(true, p->mt_states, nseg, p->mt_bps, total_blocks, p->mt_counts, nullptr, (double*)p->mt_scratch, ncells,
-                         (int)p->nzc + 1, (int)p->nzl + 1, p->kz0, s, single != 0, cap));
+  RF_HIP(launch_mt_polar(single != 0, p->mt_states, nseg, p->mt_bps, total_blocks, p->mt_counts, p->mt_scratch, cap, s));
   RF_HIP(launch_mt_scan(p->mt_counts, p->mt_offsets, nseg, s, p->mt_pairs));
   // float64 deviates are moved into cell order (and cut to this rank's planes); float32 ones stay in the segments' runs:
   // the generation pass finds cell c through the scan (slack_cell), which saves the 1.7 ms copy per 1024^3

@@ -9,10 +9,10 @@
 //   1. jump tree: the state J words ahead is the XOR of the sequence words x_{i+j} over the set
 //      coefficients j of t^J mod phi(t).  mt_jump_kernel builds 33 blocks of the sequence of a source state in
 //      LDS and XORs them; stage t of the radix-16 tree multiplies the number of segment start states by 16.
-//   2. mt_polar_kernel<true, .> with slack_cap: every segment (1024 blocks of 624 outputs, one WAVE each) generates its
-//      outputs ONCE, writes the deviates of its accepted attempts densely into its own run of a scratch array and counts them;
-//   3. an exclusive scan of the counts gives each run the index of its first cell, and mt_compact_kernel moves the runs
-//      into place (round 1: a count pass and a fill pass, i.e. every block generated twice; those modes are still here).
+//   2. mt_polar_kernel: every segment (1024 blocks of 624 outputs, one WAVE each) generates its outputs ONCE, writes the
+//      deviates of its accepted attempts densely into its own run of a scratch array and counts them;
+//   3. an exclusive scan of the counts gives each run the index of its first cell; float64 runs are moved into cell order
+//      by mt_compact_kernel, float32 runs are read in place by the generation pass (rf_core.h slack_cell).
 #include <hip/hip_runtime.h>
 #include "rf_launch.h"
 #include "rf_core.h"
@@ -140,24 +140,18 @@ __global__ __launch_bounds__(MT_JUMP_THREADS) void mt_jump_kernel(const uint32_t
 // wave's own LDS window and is regenerated IN PLACE in 64-lane chunks -- word i needs the old words i, i+1 and either
 // the old word i+397 (i < 227) or the new word i-227, which an earlier chunk has already written (LDS operations of
 // one wave execute in order; `volatile` keeps the compiler from reordering them).
-// FILL = false: counts[seg] = accepted attempts of the segment.
-// FILL = true: writes (f x2, f x1) of every accepted attempt whose cell index < ncells.
-// F32 (with FILL): the pair is written as two float32 -- for float32 plans, whose cells sigma * g are float32 anyway.
+// The segment generates its outputs ONCE: it writes (f x2, f x1) of its accepted attempts densely from slot seg * cap of the
+// scratch array `runs` (cap = attempts per segment, so a run always fits) and leaves their number in counts[seg]; the scan
+// of the counts tells later stages which cells a run holds (mt_compact_kernel moves float64 runs into cell order, the
+// generation pass reads float32 runs in place).  Round 1 generated every block twice: a count pass, then a fill pass.
+// F32: the pair is written as two float32 -- for float32 plans, whose cells sigma * g are float32 anyway.
 // The accept / reject arithmetic stays in float64 (it decides WHICH cell a deviate belongs to); only
 // f = sqrt(-2 log(r2) / r2) is evaluated in float32 (hardware log2 / rcp / sqrt, 1 ulp each), with the rounding of r2 to
 // float32 compensated to first order so that the relative error stays at the 1e-7 level where log(r2) -> 0.
-template <bool FILL, bool F32>
+template <bool F32>
 __global__ __launch_bounds__(256) void mt_polar_kernel(const uint32_t* __restrict__ states, int blocks_per_segment,
                                                        long long total_blocks, int nseg, unsigned long long* __restrict__ counts,
-                                                       const unsigned long long* __restrict__ offsets,
-                                                       double* __restrict__ noise, unsigned long long ncells,
-                                                       int nzh, int zpitch, int zoff, unsigned long long slack_cap) {
-  // slack_cap != 0 (FILL only): ONE pass instead of count + fill -- the segment writes its accepted pairs densely from
-  // slot seg * slack_cap of a scratch array (slack_cap = attempts per segment, so it always fits) and leaves their
-  // number in counts[seg]; mt_compact_kernel then moves every segment's run to its place in the stream.
-  // nzh = nz/2 + 1 cells per (ix, iy) row of the stream.  zpitch == nzh: the buffer is the whole stream in its own
-  // order.  zpitch < nzh (a kz-slab rank): rows of zpitch slots -- planes [zoff, zoff + zpitch - 1) and, last, the
-  // Nyquist plane nzh - 1; deviates of other planes are dropped (every rank replays the whole stream).
+                                                       double* __restrict__ runs, unsigned long long cap) {
   __shared__ __attribute__((aligned(16))) uint32_t lds[4][MT_N + 16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long long seg = (long long)blockIdx.x * 4 + wave;
@@ -171,7 +165,7 @@ __global__ __launch_bounds__(256) void mt_polar_kernel(const uint32_t* __restric
   if (nb > blocks_per_segment) nb = blocks_per_segment;
   const uint32_t* st = states + (size_t)seg * MT_N;
   for (int i = lane; i < MT_N; i += 64) mt[i] = st[i];
-  unsigned long long running = !FILL ? 0ull : slack_cap ? (unsigned long long)seg * slack_cap : offsets[seg];   // cell index of this segment's next accepted attempt
+  unsigned long long running = (unsigned long long)seg * cap;      // slot of this segment's next accepted attempt
   for (long long b = 0; b < nb; ++b) {
     // regenerate: the outputs of this block are the tempered NEW words
 #pragma unroll
@@ -208,35 +202,25 @@ __global__ __launch_bounds__(256) void mt_polar_kernel(const uint32_t* __restric
         acc = (r2 < 1.0) && (r2 != 0.0);
       }
       const unsigned long long ball = __ballot(acc);
-      if (FILL && acc) {
-        const unsigned long long cell = running + (unsigned long long)__popcll(ball & ((1ull << lane) - 1ull));
-        bool keep = slack_cap != 0 || cell < ncells;
-        unsigned long long dst = cell;
-        if (keep && !slack_cap && zpitch != nzh) {
-          const unsigned long long col = cell / (unsigned)nzh;
-          const int kz = (int)(cell - col * (unsigned)nzh);
-          const int sl = kz == nzh - 1 ? zpitch - 1 : kz - zoff;
-          keep = sl >= 0 && sl < zpitch && (kz == nzh - 1 || sl < zpitch - 1);
-          dst = col * (unsigned)zpitch + (unsigned)sl;
-        }
-        if (keep && F32) {
+      if (acc) {
+        const unsigned long long dst = running + (unsigned long long)__popcll(ball & ((1ull << lane) - 1ull));
+        if (F32) {
           // log(r2) = log(r2f) + (r2 - r2f) / r2f: the hardware log2 (1 ulp of its result, also where it -> 0) of the
           // rounded argument, plus the first-order term of the rounding (exact difference in float64)
           const float r2f = (float)r2, inv = __builtin_amdgcn_rcpf(r2f);
           const float lg = fmaf(__builtin_amdgcn_logf(r2f), 0.69314718056f, (float)(r2 - (double)r2f) * inv);
           const float f = __builtin_amdgcn_sqrtf(-2.0f * lg * inv);
-          reinterpret_cast<float2*>(noise)[dst] = make_float2(f * (float)x2, f * (float)x1);
-        } else if (keep) {
+          reinterpret_cast<float2*>(runs)[dst] = make_float2(f * (float)x2, f * (float)x1);
+        } else {
           const double f = sqrt(-2.0 * log(r2) / r2);
-          noise[2 * dst] = f * x2;                            // legacy_gauss returns f*x2 first, then the saved f*x1
-          noise[2 * dst + 1] = f * x1;
+          runs[2 * dst] = f * x2;                             // legacy_gauss returns f*x2 first, then the saved f*x1
+          runs[2 * dst + 1] = f * x1;
         }
       }
       running += (unsigned long long)__popcll(ball);
     }
   }
-  if (!FILL && lane == 0) counts[seg] = running;
-  if (FILL && slack_cap && lane == 0) counts[seg] = running - (unsigned long long)seg * slack_cap;
+  if (lane == 0) counts[seg] = running - (unsigned long long)seg * cap;
 }
 
 // exclusive scan of the per-segment counts by ONE wave: lane l owns a contiguous chunk, wave scan across lanes
@@ -316,14 +300,11 @@ hipError_t launch_mt_jump(uint32_t* states, const uint32_t* pos, const int* npos
                      per, nseg);
   return hipGetLastError();
 }
-hipError_t launch_mt_polar(bool fill, const uint32_t* states, int nseg, int blocks_per_segment, long long total_blocks,
-                           unsigned long long* counts, const unsigned long long* offsets, double* noise,
-                           unsigned long long ncells, int nzh, int zpitch, int zoff, hipStream_t s, bool single,
-                           unsigned long long slack_cap) {
+hipError_t launch_mt_polar(bool single, const uint32_t* states, int nseg, int blocks_per_segment, long long total_blocks,
+                           unsigned long long* counts, void* runs, unsigned long long cap, hipStream_t s) {
   const unsigned grid = (unsigned)((nseg + 3) / 4);
-  if (fill && single) hipLaunchKernelGGL((mt_polar_kernel<true, true>), dim3(grid), dim3(256), 0, s, states, blocks_per_segment, total_blocks, nseg, counts, offsets, noise, ncells, nzh, zpitch, zoff, slack_cap);
-  else if (fill) hipLaunchKernelGGL((mt_polar_kernel<true, false>), dim3(grid), dim3(256), 0, s, states, blocks_per_segment, total_blocks, nseg, counts, offsets, noise, ncells, nzh, zpitch, zoff, slack_cap);
-  else hipLaunchKernelGGL((mt_polar_kernel<false, false>), dim3(grid), dim3(256), 0, s, states, blocks_per_segment, total_blocks, nseg, counts, offsets, noise, ncells, nzh, zpitch, zoff, 0ull);
+  if (single) hipLaunchKernelGGL(mt_polar_kernel<true>, dim3(grid), dim3(256), 0, s, states, blocks_per_segment, total_blocks, nseg, counts, (double*)runs, cap);
+  else hipLaunchKernelGGL(mt_polar_kernel<false>, dim3(grid), dim3(256), 0, s, states, blocks_per_segment, total_blocks, nseg, counts, (double*)runs, cap);
   return hipGetLastError();
 }
 hipError_t launch_mt_scan(const unsigned long long* counts, unsigned long long* offsets, int n, hipStream_t s, unsigned long long* pairs) {

@@ -98,13 +98,12 @@ hipError_t launch_scale_copy(int f64, const void* P, void* K, long long n, int z
 // (pos: nmult rows of pos_stride positions, npos: their lengths, both in device memory)
 hipError_t launch_mt_jump(uint32_t* states, const uint32_t* pos, const int* npos, int pos_stride, int nsrc, long long dist, int nmult,
                           int nseg, hipStream_t s);
-hipError_t launch_mt_polar(bool fill, const uint32_t* states, int nseg, int blocks_per_segment, long long total_blocks,
-                           unsigned long long* counts, const unsigned long long* offsets, double* noise,
-                           unsigned long long ncells, int nzh, int zpitch, int zoff, hipStream_t s, bool single = false,
-                           unsigned long long slack_cap = 0);
-// slack_cap != 0 (with fill): one-pass variant -- `noise` is a scratch array of nseg * slack_cap pairs, segment seg writes its
-// accepted pairs densely from slot seg * slack_cap and their number to counts[seg]; launch_mt_compact then moves the runs
-// to their cells (offsets = exclusive scan of counts)
+// every segment (one wave each) generates its blocks once and writes the deviate pairs of its accepted polar attempts
+// densely from slot seg * cap of `runs` (float64 pairs, or float32 pairs with `single`); counts[seg] = their number
+hipError_t launch_mt_polar(bool single, const uint32_t* states, int nseg, int blocks_per_segment, long long total_blocks,
+                           unsigned long long* counts, void* runs, unsigned long long cap, hipStream_t s);
+// moves the runs into cell order (offsets = exclusive scan of counts); a kz-slab rank keeps its own planes (nzh = nz/2 + 1
+// cells per row of the stream; zpitch / zoff: the destination's rows, see GenParams)
 hipError_t launch_mt_compact(bool single, const void* scratch, const unsigned long long* counts, const unsigned long long* offsets,
                              int nseg, unsigned long long cap, void* noise, unsigned long long ncells, int nzh, int zpitch, int zoff,
                              hipStream_t s);
