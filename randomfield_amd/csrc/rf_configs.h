@@ -61,7 +61,11 @@ RF_ROW(32,   8,  4,  1,  64,  8,  4,  1,  32,  256)
 RF_ROW(64,   8,  8,  1,  64,  8,  8,  1,  32,  256)
 RF_ROW(128,  8,  16, 1,  32,  8,  4,  4,  16,  256)
 RF_ROW(256,  8,  8,  4,  16,  8,  8,  4,  8,   256)
-RF_ROW(512,  8,  8,  8,  8,   8,  8,  8,  4,   256)
+#ifndef RF_ROW64_512
+#define RF_ROW64_512 8, 8, 8, 4, 256
+#endif
+template <> struct RowSel<float, 512>  { using type = RowCfg<float,  512, 8, 8, 8, 8, 256>; };
+template <> struct RowSel<double, 512> { using type = RowCfg<double, 512, RF_ROW64_512>; };
 RF_ROW(1024, 8,  16, 8,  4,   8,  8,  16, 2,   256)
 // rows of 2048 complex: only the unpacked c2c transform has them (a packed plan's rows hold nz/2 <= 1024)
 RF_ROW(2048, 8,  16, 16, 2,   8,  16, 16, 1,   256)
