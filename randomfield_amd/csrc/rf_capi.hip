@@ -774,7 +774,8 @@ int rf_plan_destroy(rf_plan* p) {
 
 int rf_plan_nbytes(rf_plan* p, size_t* nbytes) {
   RF_REQUIRE(p && nbytes, "null argument");
-  *nbytes = p->w_bytes * (1 + (p->R ? 1 : 0) + (p->W2 ? 2 : 0)) + (p->K ? p->k_bytes : 0) + (p->P ? p->p_bytes : 0) + (p->G ? p->k_bytes : 0);
+  *nbytes = p->w_bytes * (1 + (p->R ? 1 : 0) + (p->W2 ? 2 : 0)) + (p->K ? p->k_bytes : 0) + (p->P ? p->p_bytes : 0) + (p->G ? p->k_bytes : 0) +
+            p->noise_cap * sizeof(double) + p->mt_scratch_bytes;      // + resident deviates and the replay's scratch runs
   return 0;
 }
 
