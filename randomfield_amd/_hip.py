@@ -248,7 +248,14 @@ class DevicePlan(object):
         ``realise`` / ``realise_potential`` read half as many bytes; ``generate`` and ``download_noise`` need float64."""
         from . import mt19937
         if not getattr(self, "_mt_ready", False):
-            polys = mt19937.tree_polynomials(4)
+            # segment length for this grid's stream (a whole multiple of the GPU's wave slots on large grids), the stages
+            # of the radix-16 jump tree it needs, and their polynomials' set-bit positions
+            bps = mt19937.segment_blocks_for(self.nx * self.ny * (self.nz // 2 + 1))
+            blocks = -(-4 * mt19937.attempts_needed(self.nx * self.ny * (self.nz // 2 + 1)) // 624)
+            nseg, stages = -(-blocks // bps), 1
+            while mt19937.TREE_RADIX ** stages < nseg:
+                stages += 1
+            polys = mt19937.tree_polynomials(stages, segment_blocks=bps)
             pos = [mt19937.set_bit_positions(p) for p in polys]
             stride = max(len(q) for q in pos)
             table = np.zeros((len(pos), stride), np.uint16)
@@ -257,7 +264,7 @@ class DevicePlan(object):
             npos = np.array([len(q) for q in pos], np.int32)
             check(self._lib.rf_mt_set_jump(self._h, len(pos), table.ctypes.data_as(ctypes.POINTER(ctypes.c_uint16)),
                                            npos.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), stride,
-                                           mt19937.SEGMENT_BLOCKS, mt19937.TREE_RADIX), "rf_mt_set_jump")
+                                           bps, mt19937.TREE_RADIX), "rf_mt_set_jump")
             self._mt_ready = True
         state = np.ascontiguousarray(mt19937.seed_state(seed), np.uint32)
         acc = ctypes.c_ulonglong(0)

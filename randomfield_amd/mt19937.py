@@ -266,29 +266,55 @@ def jump_polynomials(nlevels=20, cache=True):
 
 
 TREE_RADIX = 16
-_TREE_CACHE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data",
-                           "mt19937_tree_R%d_L%d.npz" % (TREE_RADIX, SEGMENT_WORDS))
+WAVE_SLOTS = 4096                     # segments are sized for this many concurrent waves (MI355X: 256 CUs x 16 waves)
+_TREE_MEMO = {}
 
 
-def tree_polynomials(nstages=4, cache=True):
-    """The jump polynomials of the radix-16 tree over segments: row t*15 + (m-1) = t^(m * 16^t * SEGMENT_WORDS) mod phi,
-    m = 1 .. 15, as (nstages*15, 624) uint32 coefficient words.  4 stages reach 65 536 segments (1.0e10 polar attempts:
-    a 2048^3 grid needs 35 000).  Cached next to the package data (built in ~5 s otherwise)."""
+def _tree_cache(segment_blocks):
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "data",
+                        "mt19937_tree_R%d_L%d.npz" % (TREE_RADIX, segment_blocks * N))
+
+
+def segment_blocks_for(ncells, slots=WAVE_SLOTS):
+    """Blocks of 624 words per segment for a stream of ``ncells`` accepted pairs.  One wave replays one segment and all
+    waves are resident at once, so the replay takes as long as the most loaded SIMD: 4300 segments over 4096 wave slots
+    put five waves on some SIMDs and four on the others (1024^3 with 1024-block segments; +20 %).  Large streams
+    therefore get a whole multiple of ``slots`` segments, the multiple chosen so that a segment stays close to
+    SEGMENT_BLOCKS; small ones keep SEGMENT_BLOCKS."""
+    blocks = -(-4 * attempts_needed(ncells) // N)
+    rounds = int(round(blocks / float(slots * SEGMENT_BLOCKS)))
+    if rounds < 1:
+        return SEGMENT_BLOCKS
+    return -(-blocks // (slots * rounds))
+
+
+def tree_polynomials(nstages=4, cache=True, segment_blocks=SEGMENT_BLOCKS):
+    """The jump polynomials of the radix-16 tree over segments of ``segment_blocks`` blocks: row t*15 + (m-1) =
+    t^(m * 16^t * L) mod phi, L = 624 * segment_blocks, m = 1 .. 15, as (nstages*15, 624) uint32 coefficient words.
+    4 stages reach 65 536 segments (1.0e10 polar attempts: a 2048^3 grid needs 35 000).  Cached next to the package
+    data (shipped for the segment lengths of 1024^3 and 2048^3 grids) and per process; built in ~0.2 s per
+    polynomial otherwise."""
     rows = nstages * (TREE_RADIX - 1)
-    if cache and os.path.exists(_TREE_CACHE):
-        arr = np.load(_TREE_CACHE)["polys"]
+    memo = _TREE_MEMO.get(segment_blocks)
+    if memo is not None and memo.shape[0] >= rows:
+        return memo[:rows]
+    path = _tree_cache(segment_blocks)
+    if cache and os.path.exists(path):
+        arr = np.load(path)["polys"]
         if arr.shape[0] >= rows:
+            _TREE_MEMO[segment_blocks] = arr
             return arr[:rows]
     phi = characteristic_polynomial()
     out = []
     for t in range(nstages):
         for m in range(1, TREE_RADIX):
-            g = power_of_t(m * TREE_RADIX ** t * SEGMENT_WORDS, phi)
+            g = power_of_t(m * TREE_RADIX ** t * segment_blocks * N, phi)
             out.append(np.frombuffer(g.to_bytes(N * 4, "little"), dtype="<u4").astype(np.uint32))
     arr = np.stack(out)
+    _TREE_MEMO[segment_blocks] = arr
     if cache:
         try:
-            np.savez_compressed(_TREE_CACHE, polys=arr)
+            np.savez_compressed(path, polys=arr)
         except OSError:
             pass
     return arr
