@@ -45,10 +45,14 @@ __device__ __forceinline__ void mt_next_block(const uint32_t* cur, uint32_t* nxt
 
 __device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
 
+// y ^ (t & mask) in one instruction (v_bitop3_b32, truth table 0x78 = a ^ (b & c)): the two masked steps of the tempering
+// cost a shift and this instead of shift + and + xor -- tempering is 40 % of the replay pass's VALU work
+__device__ __forceinline__ uint32_t xor_masked(uint32_t y, uint32_t t, uint32_t mask) { return __builtin_amdgcn_bitop3_b32(y, t, mask, 0x78); }
+
 __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
   y ^= y >> 11;
-  y ^= (y << 7) & 0x9D2C5680u;
-  y ^= (y << 15) & 0xEFC60000u;
+  y = xor_masked(y, y << 7, 0x9D2C5680u);
+  y = xor_masked(y, y << 15, 0xEFC60000u);
   y ^= y >> 18;
   return y;
 }
@@ -194,10 +198,11 @@ __global__ __launch_bounds__(256) void mt_polar_kernel(const uint32_t* __restric
         const u4 raw = *reinterpret_cast<const u4*>(const_cast<const uint32_t*>(lds[wave]) + 4 * a);
         const uint32_t w0 = mt_temper(raw.x), w1 = mt_temper(raw.y);
         const uint32_t w2 = mt_temper(raw.z), w3 = mt_temper(raw.w);
-        const double u1 = ((double)(w0 >> 5) * 67108864.0 + (double)(w1 >> 6)) / 9007199254740992.0;
-        const double u2 = ((double)(w2 >> 5) * 67108864.0 + (double)(w3 >> 6)) / 9007199254740992.0;
-        x1 = 2.0 * u1 - 1.0;
-        x2 = 2.0 * u2 - 1.0;
+        // numpy: u = (a 2^26 + b) / 2^53 with a = w >> 5, b = w' >> 6, then x = 2 u - 1.  Every step of that is exact in
+        // float64 (53-bit integers, powers of two, |x| < 1 with 52 fractional bits), so x = a 2^-26 + (b 2^-52 - 1) in
+        // two fused multiply-adds is the same number
+        x1 = fma((double)(w0 >> 5), 0x1p-26, fma((double)(w1 >> 6), 0x1p-52, -1.0));
+        x2 = fma((double)(w2 >> 5), 0x1p-26, fma((double)(w3 >> 6), 0x1p-52, -1.0));
         r2 = sum_of_squares(x1, x2);                          // no FMA: numpy's C code rounds both products
         acc = (r2 < 1.0) && (r2 != 0.0);
       }
