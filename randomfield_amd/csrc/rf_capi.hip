@@ -1367,7 +1367,7 @@ int rf_noise_mt19937_ex(rf_plan* p, const uint32_t* state624, unsigned long long
     RF_HIP(hipMalloc((void**)&p->mt_offsets, ((size_t)nseg + 1) * sizeof(unsigned long long)));
     if (p->mt_pairs) RF_HIP(hipFree(p->mt_pairs));
     p->mt_pairs = nullptr;
-    RF_HIP(hipMalloc((void**)&p->mt_pairs, 2 * ((size_t)nseg + 1) * sizeof(unsigned long long)));
+    RF_HIP(hipMalloc((void**)&p->mt_pairs, 2 * ((size_t)nseg + 3) * sizeof(unsigned long long)));     // + sentinel pairs
     p->mt_seg_cap = (size_t)nseg + 1;
   }
   hipStream_t s = p->stream;

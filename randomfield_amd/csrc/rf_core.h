@@ -560,13 +560,27 @@ RF_HD U64Pair v16_load_any(const unsigned long long* p) {
 // binomial: the guess is off by at most one segment) and corrected against the scan; o1 = first cell of the next segment.
 RF_HD const cplx<float>* slack_cell(const FastGenParams& g, unsigned long long c, int& seg, unsigned long long& o1) {
   int s = (int)(((double)(unsigned)(c >> 32) * 4294967296.0 + (double)(unsigned)c) * g.seg_inv);
-  s = s < 0 ? 0 : (s > g.nseg - 1 ? g.nseg - 1 : s);
-  U64Pair pr = v16_load_any(g.seg_off + 2 * s);
-  unsigned long long o0 = pr.lo, on = pr.hi;
-  while (c < o0) { pr = v16_load_any(g.seg_off + 2 * --s); o0 = pr.lo; on = pr.hi; }
-  while (c >= on) { pr = v16_load_any(g.seg_off + 2 * ++s); o0 = pr.lo; on = pr.hi; }
+  const int top = g.nseg - 2 > 1 ? g.nseg - 2 : 1;
+  s = s < 1 ? 1 : (s > top ? top : s);
+  // the four boundaries around the guess with two independent 16-byte loads (no load inside a loop in the common case:
+  // the table loads of all the rows of a butterfly go out together): b0 <= b1 <= b2 <= b3 = first cells of s-1 .. s+2
+  // (the table has a sentinel pair behind the last segment)
+  const U64Pair lo = v16_load_any(g.seg_off + 2 * (s - 1)), hi = v16_load_any(g.seg_off + 2 * (s + 1));
+  const unsigned long long b0 = lo.lo, b1 = lo.hi, b2 = hi.lo, b3 = hi.hi;
+  unsigned long long o0;
+  if (c >= b0 && c < b3) {
+    const bool below = c < b1, above = c >= b2;
+    s = s - (below ? 1 : 0) + (above ? 1 : 0);
+    o0 = below ? b0 : (above ? b2 : b1);
+    o1 = below ? b1 : (above ? b3 : b2);
+  } else {            // a guess more than one segment off: never seen (binomial counts), but walk there if it happens
+    U64Pair pr = v16_load_any(g.seg_off + 2 * s);
+    while (c < pr.lo) pr = v16_load_any(g.seg_off + 2 * --s);
+    while (c >= pr.hi) pr = v16_load_any(g.seg_off + 2 * ++s);
+    o0 = pr.lo;
+    o1 = pr.hi;
+  }
   seg = s;
-  o1 = on;
   return g.noise32 + (unsigned long long)s * g.seg_cap + (c - o0);
 }
 

@@ -247,7 +247,10 @@ __global__ __launch_bounds__(64) void mt_scan_kernel(const unsigned long long* _
     if (pairs) { pairs[2 * i] = run; pairs[2 * i + 1] = run + counts[i]; }     // (first cell, first cell of the next segment)
     run += counts[i];
   }
-  if (lane == 63) offsets[n] = inc;                    // total number of accepted attempts
+  if (lane == 63) {
+    offsets[n] = inc;                                  // total number of accepted attempts
+    if (pairs) pairs[2 * n] = pairs[2 * n + 1] = pairs[2 * n + 2] = pairs[2 * n + 3] = inc;   // two sentinel pairs (slack_cell)
+  }
 }
 
 // pairs [0, counts[seg]) of segment seg's scratch run -> cells offsets[seg] + i of the stream (cells >= ncells are

@@ -260,7 +260,8 @@ def test_slack_cell_lookup_of_resident_float32_deviates():
         counts = rng.binomial(int(mean / 0.7854) + 1, 0.7854, size=nseg).astype(np.uint64)
         counts[-1] = last
         off = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64)
-        pairs = np.ascontiguousarray(np.stack([off[:-1], off[1:]], axis=1).reshape(-1))
+        pairs = np.stack([off[:-1], off[1:]], axis=1).reshape(-1)
+        pairs = np.ascontiguousarray(np.concatenate([pairs, [off[-1]] * 4]).astype(np.uint64))     # + two sentinel pairs
         cap = int(mean / 0.7854) + 8
         total = int(off[-1])
         cells = np.unique(np.concatenate([rng.randint(0, total, size=2000), off[:-1], off[1:] - 1])).astype(np.uint64)
