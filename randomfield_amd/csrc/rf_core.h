@@ -556,6 +556,18 @@ RF_HD U64Pair v16_load_any(const unsigned long long* p) {
   return U64Pair{p[0], p[1]};
 #endif
 }
+// one float32 deviate pair through a GLOBAL-address-space pointer: its address comes out of selects, the compiler cannot
+// infer where it points and would emit flat_load -- counted on lgkmcnt too, so that the LDS reads of the sigma lookup
+// would wait for the deviates' trip to HBM
+RF_HD cplx<float> load_pair_global(const cplx<float>* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  const f2 v = *(const __attribute__((address_space(1))) f2*)p;
+  return mk<float>(v.x, v.y);
+#else
+  return *p;
+#endif
+}
 // Where the pair of stream cell c lives (SRC = 2): the segment is guessed from the mean acceptance count (the counts are
 // binomial: the guess is off by at most one segment) and corrected against the scan; o1 = first cell of the next segment.
 RF_HD const cplx<float>* slack_cell(const FastGenParams& g, unsigned long long c, int& seg, unsigned long long& o1) {
@@ -590,7 +602,7 @@ RF_HD cplx<float> fast_noise_cell(const FastGenParams& g, const FastRec* rec, in
     int seg;
     unsigned long long o1;
     const float s = fast_sigma(g, rec, k2);
-    const cplx<float> d = *slack_cell(g, ((unsigned long long)ix * g.ny + iy) * (unsigned)(g.nz / 2 + 1) + (unsigned)kz, seg, o1);
+    const cplx<float> d = load_pair_global(slack_cell(g, ((unsigned long long)ix * g.ny + iy) * (unsigned)(g.nz / 2 + 1) + (unsigned)kz, seg, o1));
     return mk<float>(s * d.x, s * d.y);
   }
   const long long c = ((long long)ix * g.ny + iy) * g.zpitch + side_slot(g, kz);

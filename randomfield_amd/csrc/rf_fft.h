@@ -275,11 +275,14 @@ struct FastGenColIOT {
     } else {
       // float32 pairs where the one-pass replay left them (rf_core.h slack_cell): cells c and c + 1 of the stream are
       // neighbours unless a segment ends between them
-      const unsigned long long c = ((unsigned long long)(rb + ro) * gp.ny + iy) * (unsigned)(gp.nz / 2 + 1) + (unsigned)kz;
+      // stream cell c = (scalar part of the row offset m L) + (lane part, the same for all R rows of a butterfly): a 64-bit
+      // multiply chain per lane and row made this pass 0.6 ms slower than the addresses themselves cost
+      const unsigned nzh = (unsigned)(gp.nz / 2 + 1);
+      const unsigned long long c = pin_uniform_ll((unsigned long long)ro * gp.ny * nzh) + (unsigned)((rb * gp.ny + iy) * nzh + kz);
       int seg;
       unsigned long long o1;
       const cplx<float>* d = slack_cell(gp, c, seg, o1);
-      const cplx<float> ga = d[0], gb = c + 1 < o1 ? d[1] : gp.noise32[(unsigned long long)(seg + 1) * gp.seg_cap];
+      const cplx<float> ga = load_pair_global(d), gb = load_pair_global(c + 1 < o1 ? d + 1 : gp.noise32 + (unsigned long long)(seg + 1) * gp.seg_cap);
       const float sa = fast_sigma(gp, rec, k2a), sb = fast_sigma(gp, rec, k2b);
       v.c[0] = mk<float>(sa * ga.x, sa * ga.y);
       v.c[1] = mk<float>(sb * gb.x, sb * gb.y);

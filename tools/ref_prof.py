@@ -11,6 +11,8 @@ from randomfield_amd import _hip, powertools   # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 single = len(sys.argv) > 2 and sys.argv[2] == "single"
 pot = len(sys.argv) > 3 and sys.argv[3] == "pot"
+if len(sys.argv) > 4:
+    _hip.LIB_PATH = os.path.abspath(sys.argv[4])      # a variant build of the library (kernel experiments)
 power = powertools.load_default_power()
 plan = _hip.DevicePlan(n, n, n, np.complex64)
 plan.set_kgrid(*powertools.ksq_axes(n, n, n, 2.5))
