@@ -1310,15 +1310,27 @@ int rf_mt_set_jump(rf_plan* p, int npolys, const uint16_t* pos, const int* npos,
   if (p->mt_npos_dev) RF_HIP(hipFree(p->mt_npos_dev));
   p->mt_pos = nullptr;
   p->mt_npos_dev = nullptr;
-  // the kernel reads the positions with scalar loads, which have dword granularity: widen; pad rows to 8 entries
-  const int wstride = (stride + 7) / 8 * 8;
+  // device rows: the even positions, padded to a multiple of 8 entries, then the odd ones (the jump kernel reads aligned
+  // 8-byte word pairs: rf_k_mt.hip); two counts per polynomial
+  const int wstride = ((stride + 7) / 8 + 1) * 8;
   std::vector<uint32_t> wide((size_t)npolys * wstride, 0u);
-  for (int l = 0; l < npolys; ++l)
-    for (int j = 0; j < npos[l]; ++j) wide[(size_t)l * wstride + j] = pos[(size_t)l * stride + j];
+  std::vector<int> counts(2 * (size_t)npolys);
+  for (int l = 0; l < npolys; ++l) {
+    int ne = 0, no = 0;
+    for (int j = 0; j < npos[l]; ++j) ne += (pos[(size_t)l * stride + j] & 1) == 0;
+    const int eoff = (ne + 7) & ~7;
+    RF_REQUIRE(eoff + ((npos[l] - ne + 7) & ~7) <= wstride, "jump table row too long");
+    ne = 0;
+    for (int j = 0; j < npos[l]; ++j) {
+      const uint32_t q = pos[(size_t)l * stride + j];
+      if (q & 1) wide[(size_t)l * wstride + eoff + no++] = q; else wide[(size_t)l * wstride + ne++] = q;
+    }
+    counts[2 * l] = ne; counts[2 * l + 1] = no;
+  }
   RF_HIP(hipMalloc((void**)&p->mt_pos, wide.size() * sizeof(uint32_t)));
   RF_HIP(hipMemcpy(p->mt_pos, wide.data(), wide.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-  RF_HIP(hipMalloc((void**)&p->mt_npos_dev, (size_t)npolys * sizeof(int)));
-  RF_HIP(hipMemcpy(p->mt_npos_dev, npos, (size_t)npolys * sizeof(int), hipMemcpyHostToDevice));
+  RF_HIP(hipMalloc((void**)&p->mt_npos_dev, counts.size() * sizeof(int)));
+  RF_HIP(hipMemcpy(p->mt_npos_dev, counts.data(), counts.size() * sizeof(int), hipMemcpyHostToDevice));
   p->mt_npos.assign(npos, npos + npolys);
   p->mt_stride = wstride;
   p->mt_bps = blocks_per_segment;
@@ -1376,7 +1388,7 @@ int rf_noise_mt19937_ex(rf_plan* p, const uint32_t* state624, unsigned long long
   long long dist = 1;
   for (int t = 0; t < stages; ++t, dist *= R) {
     const int nsrc = (int)(dist < nseg ? dist : nseg);
-    RF_HIP(launch_mt_jump(p->mt_states, p->mt_pos + (size_t)t * (R - 1) * p->mt_stride, p->mt_npos_dev + t * (R - 1), p->mt_stride, nsrc,
+    RF_HIP(launch_mt_jump(p->mt_states, p->mt_pos + (size_t)t * (R - 1) * p->mt_stride, p->mt_npos_dev + 2 * t * (R - 1), p->mt_stride, nsrc,
                           dist, R - 1, nseg, s));
   }
   // ONE generation pass: every segment writes its accepted pairs densely into its own run of the scratch array

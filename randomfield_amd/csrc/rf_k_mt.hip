@@ -65,13 +65,16 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
 // reads per lane; as global-memory reads this step took 13 of the replay's 28 ms in round 1).  Building the window
 // is about half of a single jump, and a binary tree spends nine of its thirteen levels waiting for one or a few
 // workgroups: radix 16 needs four launches and shares each window between up to 15 jumps (5.6 -> 2 ms at 1024^3).
-// Thread layout of the XOR loop: MT_JUMP_GROUPS groups of 320 threads.  A thread owns TWO output words, u and u + 320 (the
-// two LDS reads of a position share one address computation and merge into one ds_read2st64_b32), and a group takes every
-// MT_JUMP_GROUPS-th chunk of 8 positions; the groups' partial XORs are combined through LDS at the end.  Why: ds_read_b32
-// reaches its 128 B/clk only with ~4 waves per SIMD (MI355X_MICROARCH.md, LDS), and the 106 KB window + position table
-// allow one workgroup per CU -- with 10 waves (one word per thread) a jump took 0.19 ms of a CU against a floor of
-// 0.08 ms for its 25 MB of LDS reads, and halving the VALU work per word without more waves changed nothing.
-constexpr int MT_JUMP_LANES = 320, MT_JUMP_GROUPS = 3, MT_JUMP_THREADS = MT_JUMP_LANES * MT_JUMP_GROUPS;
+// Thread layout of the XOR loop: MT_JUMP_GROUPS groups of 320 threads, 312 of them active.  Lane u owns the output words
+// 2u and 2u + 1 and reads them as ONE aligned 8-byte LDS access per position: ds_read_b64 moves 256 B/clk, twice what
+// ds_read_b32 / ds_read2_b32 do (MI355X_MICROARCH.md, LDS), and the XOR loop is bound by exactly that.  Alignment needs
+// position + 2u even, so the positions of a polynomial come in two lists: the even ones feed the pair (2u, 2u + 1), the
+// odd ones the pair (2u - 1, 2u) through a base shifted by one word -- two accumulator pairs per lane, recombined
+// with the neighbour lane's at the end (lane 312 exists for its odd pair (623, 624) only).  A group takes every MT_JUMP_GROUPS-th chunk of 8 positions of each list
+// (ds_read_b32 -- and b64 -- need ~4 waves per SIMD for their rate, and the 106 KB window + tables allow one workgroup
+// per CU); the groups' partial XORs are combined through LDS.  History of one jump on a CU: 0.19 ms with one word per
+// lane and 10 waves, 0.14 ms with two words per ds_read2st64_b32 and 15 waves (floor 0.08 ms at 128 B/clk).
+constexpr int MT_JUMP_LANES = 320, MT_JUMP_USED = MT_N / 2, MT_JUMP_GROUPS = 3, MT_JUMP_THREADS = MT_JUMP_LANES * MT_JUMP_GROUPS;
 __global__ __launch_bounds__(MT_JUMP_THREADS) void mt_jump_kernel(const uint32_t* __restrict__ states, const uint32_t* __restrict__ pos,
                                                       const int* __restrict__ npos, int pos_stride, int nsrc, long long dist,
                                                       int nmult, int mult_per_wg, int nseg) {
@@ -94,48 +97,59 @@ __global__ __launch_bounds__(MT_JUMP_THREADS) void mt_jump_kernel(const uint32_t
     if (t >= 454 && t < MT_N) nw[t] = mt_f(od[t], od[t + 1], od[t + MT_M]);
     __syncthreads();
   }
-  // the ~10^4 positions of a polynomial are staged in LDS behind the window (16-bit, 8 per 16-byte broadcast read):
-  // fetched with scalar loads inside the XOR loop, every 8 LDS reads waited for one scalar-cache round trip
+  // the ~10^4 positions of a polynomial are staged in LDS behind the window (16-bit, 8 per 16-byte broadcast read; row
+  // layout in global memory: the even positions, padded to a multiple of 8, then the odd ones -- npos holds both counts)
   uint16_t* lpos = reinterpret_cast<uint16_t*>(win + MT_SEQ_WORDS);
-  uint32_t* part = win + MT_SEQ_WORDS + MT_POS_MAX / 2;               // (GROUPS - 1) x 640 words behind the position table
+  uint32_t* part = win + MT_SEQ_WORDS + MT_POS_MAX / 2;               // GROUPS x 4 x 320 words behind the position table
   const int grp = t / MT_JUMP_LANES, u = t - grp * MT_JUMP_LANES;
-  const bool two = u + MT_JUMP_LANES < MT_N;                          // lanes 304..319 own one word only
-  constexpr int hi = MT_JUMP_LANES;         // a compile-time offset, so that the pair merges into one ds_read2st64_b32; lanes
-                                            // 304..319 read up to 15 words past the window (the position table: still
-                                            // inside the allocation) and discard what they get
-  const uint32_t* w = win + u;
+  const bool active = u <= MT_JUMP_USED;                              // lane 312: only its odd-list pair (623, 624) is used
+  const uint32_t* w = win + 2 * (active ? u : 1);
+  typedef unsigned u2 __attribute__((ext_vector_type(2)));
+  typedef unsigned short us8 __attribute__((ext_vector_type(8)));
   for (int m = m0; m < m0 + mult_per_wg && m <= nmult; ++m) {
     const long long dst = (long long)src + (long long)m * dist;
     if (dst >= nseg) break;                                           // uniform
     const uint32_t* pm = pos + (size_t)(m - 1) * pos_stride;
-    const int np = npos[m - 1], np8 = (np + 7) & ~7;                  // rows are zero-padded to multiples of 8 entries
+    const int ne = npos[2 * (m - 1)], no = npos[2 * (m - 1) + 1], eoff = (ne + 7) & ~7, total = eoff + ((no + 7) & ~7);
     __syncthreads();                                                  // the previous multiplier is done with lpos and part
-    for (int i = t; i < np8; i += MT_JUMP_THREADS) lpos[i] = (uint16_t)pm[i];
+    for (int i = t; i < total; i += MT_JUMP_THREADS) lpos[i] = (uint16_t)pm[i];
     __syncthreads();
-    uint32_t a0 = 0, a1 = 0;
-    typedef unsigned short us8 __attribute__((ext_vector_type(8)));
-    const us8* lp = reinterpret_cast<const us8*>(lpos);
-    const int full = np >> 3;
-#pragma unroll 4
-    for (int j = grp; j < full; j += MT_JUMP_GROUPS) {
-      const us8 q = lp[j];                                            // same address in every lane: broadcast
-      const uint32_t *p0 = w + q.s0, *p1 = w + q.s1, *p2 = w + q.s2, *p3 = w + q.s3, *p4 = w + q.s4, *p5 = w + q.s5, *p6 = w + q.s6,
-                     *p7 = w + q.s7;
-      // three-input XORs (v_bitop3_b32): 8 instead of 16 VALU instructions per chunk -- with ~4 waves per SIMD the loop
-      // is as close to the VALU's rate as to the LDS's
-      a0 = xor3(xor3(xor3(xor3(a0, p0[0], p1[0]), p2[0], p3[0]), p4[0], p5[0]), p6[0], p7[0]);
-      a1 = xor3(xor3(xor3(xor3(a1, p0[hi], p1[hi]), p2[hi], p3[hi]), p4[hi], p5[hi]), p6[hi], p7[hi]);
-    }
-    if (grp == 0)
-      for (int j = full << 3; j < np; ++j) { a0 ^= w[lpos[j]]; a1 ^= w[lpos[j] + hi]; }
-    if (grp > 0) { part[(grp - 1) * 2 * MT_JUMP_LANES + u] = a0; part[(grp - 1) * 2 * MT_JUMP_LANES + MT_JUMP_LANES + u] = a1; }
-    __syncthreads();
-    if (grp == 0) {
+    u2 A = {0u, 0u}, B = {0u, 0u};
 #pragma unroll
-      for (int g = 0; g < MT_JUMP_GROUPS - 1; ++g) { a0 ^= part[g * 2 * MT_JUMP_LANES + u]; a1 ^= part[g * 2 * MT_JUMP_LANES + MT_JUMP_LANES + u]; }
-      uint32_t* out = const_cast<uint32_t*>(states) + (size_t)dst * MT_N;
-      out[u] = a0;
-      if (two) out[u + MT_JUMP_LANES] = a1;
+    for (int par = 0; par < 2; ++par) {
+      const uint32_t* wb = w - par;                                   // odd positions: the pair one word down, aligned again (position >= 1)
+      const uint16_t* list = lpos + (par ? eoff : 0);
+      const int n = par ? no : ne, full = n >> 3;
+      const us8* lp = reinterpret_cast<const us8*>(list);
+      u2 acc = {0u, 0u};
+#pragma unroll 4
+      for (int j = grp; j < full; j += MT_JUMP_GROUPS) {
+        const us8 q = lp[j];                                          // same address in every lane: broadcast
+#define RF_MT_PAIR(k) (*reinterpret_cast<const u2*>(__builtin_assume_aligned(wb + q.s##k, 8)))
+        const u2 v0 = RF_MT_PAIR(0), v1 = RF_MT_PAIR(1), v2 = RF_MT_PAIR(2), v3 = RF_MT_PAIR(3), v4 = RF_MT_PAIR(4), v5 = RF_MT_PAIR(5),
+                 v6 = RF_MT_PAIR(6), v7 = RF_MT_PAIR(7);
+#undef RF_MT_PAIR
+        acc.x = xor3(xor3(xor3(xor3(acc.x, v0.x, v1.x), v2.x, v3.x), v4.x, v5.x), v6.x, v7.x);
+        acc.y = xor3(xor3(xor3(xor3(acc.y, v0.y, v1.y), v2.y, v3.y), v4.y, v5.y), v6.y, v7.y);
+      }
+      if (grp == 0)
+        for (int j = full << 3; j < n; ++j) { acc.x ^= wb[list[j]]; acc.y ^= wb[list[j] + 1]; }
+      if (par) B = acc; else A = acc;
+    }
+    uint32_t* mine = part + grp * 4 * MT_JUMP_LANES + u;
+    mine[0] = A.x; mine[MT_JUMP_LANES] = A.y; mine[2 * MT_JUMP_LANES] = B.x; mine[3 * MT_JUMP_LANES] = B.y;
+    __syncthreads();
+    if (grp == 0 && u < MT_JUMP_USED) {
+      // word 2u = A.x ^ B.y, word 2u + 1 = A.y ^ (B.x of lane u + 1), each summed over the groups
+      uint32_t lo = 0, hi = 0;
+#pragma unroll
+      for (int g = 0; g < MT_JUMP_GROUPS; ++g) {
+        const uint32_t* pg = part + g * 4 * MT_JUMP_LANES;
+        lo ^= pg[u] ^ pg[3 * MT_JUMP_LANES + u];
+        hi ^= pg[MT_JUMP_LANES + u] ^ pg[2 * MT_JUMP_LANES + u + 1];
+      }
+      u2* out = reinterpret_cast<u2*>(const_cast<uint32_t*>(states) + (size_t)dst * MT_N) + u;
+      *out = u2{lo, hi};
     }
   }
 }
@@ -296,7 +310,7 @@ hipError_t launch_mt_jump(uint32_t* states, const uint32_t* pos, const int* npos
                           int nmult, int nseg, hipStream_t s) {
   if (pos_stride > MT_POS_MAX) return hipErrorInvalidValue;
   constexpr int lds = MT_SEQ_WORDS * (int)sizeof(uint32_t) + MT_POS_MAX * (int)sizeof(uint16_t) +
-                      (MT_JUMP_GROUPS - 1) * 2 * MT_JUMP_LANES * (int)sizeof(uint32_t);   // window, positions, partial XORs
+                      MT_JUMP_GROUPS * 4 * MT_JUMP_LANES * (int)sizeof(uint32_t);   // window, positions, partial XORs
   static LdsAttrLatch latch;
   if (hipError_t e = latch.ensure((const void*)mt_jump_kernel, lds); e != hipSuccess) return e;
   // one 82 KB window (+ 24 KB of positions) per CU: share a source's window between as many multipliers as it takes to fit one round
