@@ -64,7 +64,10 @@ RF_ROW(256,  8,  8,  4,  16,  8,  8,  4,  8,   256)
 #ifndef RF_ROW64_512
 #define RF_ROW64_512 8, 8, 8, 4, 256
 #endif
-template <> struct RowSel<float, 512>  { using type = RowCfg<float,  512, 8, 8, 8, 8, 256>; };
+#ifndef RF_ROW32_512
+#define RF_ROW32_512 8, 8, 8, 8, 256
+#endif
+template <> struct RowSel<float, 512>  { using type = RowCfg<float,  512, RF_ROW32_512>; };
 template <> struct RowSel<double, 512> { using type = RowCfg<double, 512, RF_ROW64_512>; };
 RF_ROW(1024, 8,  16, 8,  4,   8,  8,  16, 2,   256)
 // rows of 2048 complex: only the unpacked c2c transform has them (a packed plan's rows hold nz/2 <= 1024)
