@@ -54,8 +54,15 @@ int rf_plan_nbytes(rf_plan* plan, size_t* nbytes);          /* transform.py:221,
  * slab, exchange = copy of the own block, gathering z pass, pipelined batches): a test hook.
  * RF_FLAG_REPLICATED_GENERATION = 4 (multi-rank plans, native generator): no all-to-all -- every rank generates all of
  * k space on the fly, runs the full x-FFT and keeps only its own x slab; y and z passes are local.  P-fold redundant
- * x-pass arithmetic instead of the exchange: faster when few GPUs share few xGMI links (2 GPUs: one link). */
-enum { RF_FLAG_EXACT_GENERATION = 1, RF_FLAG_FORCE_SLAB_PATH = 2, RF_FLAG_REPLICATED_GENERATION = 4 };
+ * x-pass arithmetic instead of the exchange: faster when few GPUs share few xGMI links (2 GPUs: one link).
+ * RF_FLAG_TRANSPOSED_INTERMEDIATE = 8 (default OFF; an experiment kept for measurement): the x pass stores its tiles contiguously into a scratch array of the
+ * field's size and the y pass transposes back while it transforms; 0 = both passes in place on the one field buffer
+ * (the layout of the reference's single in-place buffer, transform.py:227-238; half the device memory, slower).
+ * RF_FLAG_YZ_SLAB_PLANES = 16 (single-GPU plans; the value is a count, not a boolean): the y and z passes run slab by slab of
+ * `value` x planes, so that the z pass finds what the y pass has just written in the 256 MiB Infinity Cache; -1 (default) picks
+ * slabs of about that size, 0 = whole-grid passes. */
+enum { RF_FLAG_EXACT_GENERATION = 1, RF_FLAG_FORCE_SLAB_PATH = 2, RF_FLAG_REPLICATED_GENERATION = 4, RF_FLAG_TRANSPOSED_INTERMEDIATE = 8,
+       RF_FLAG_YZ_SLAB_PLANES = 16 };
 int rf_plan_set_flag(rf_plan* plan, int flag, int value);
 /* run on a caller-owned HIP stream (hipStream_t passed as void*); NULL restores the plan's own stream */
 int rf_plan_set_stream(rf_plan* plan, void* hip_stream);
@@ -71,7 +78,7 @@ int rf_set_power(rf_plan* plan, const double* log10k, const double* sigma, int n
 /* ---- rows K,T,R,S: fill_with_log10k + tabulate_sigmas + randomize + symmetrize
  * (powertools.py:40-61,125-164; random.py:12-29; transform.py:114-158).
  * Leaves the symmetrised k-space array in the plan's API-layout k buffer.
- * mode RF_NOISE_NATIVE: counter-based Philox4x32-10 + Box-Muller keyed by (seed, cell).
+ * mode RF_NOISE_NATIVE: counter-based Philox4x32-7 + Box-Muller keyed by (seed, cell).
  * mode RF_NOISE_EXTERNAL: noise_host = 2*nx*ny*(nz/2+1) float64 deviates in the order of
  * RandomState(seed).normal(size=2*M) (random.py:24-28) -- the same-seed parity mode.
  * mode RF_NOISE_RESIDENT: the deviates already in the plan's device buffer (rf_noise_mt19937 or a

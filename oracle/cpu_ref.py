@@ -43,7 +43,7 @@ __all__ = [
     "sigma_table", "interp_sigma", "tabulate_sigmas", "legacy_normals",
     "randomize", "symmetrize_packed", "is_hermitian_packed", "c2r", "r2c",
     "generate_kspace", "generate_delta_field", "lognormal", "scale_z",
-    "potential_kspace", "philox4x32_10", "philox_normals", "native_noise_index",
+    "potential_kspace", "philox4x32", "philox4x32_10", "NATIVE_PHILOX_ROUNDS", "philox_normals", "native_noise_index",
     "native_noise", "default_like_power", "simps_avg", "cot_k", "lensing_potential",
 ]
 
@@ -472,8 +472,19 @@ _PHILOX_W0 = 0x9E3779B9
 _PHILOX_W1 = 0xBB67AE85
 
 
+# rounds of the native stream: Philox4x32-7, the smallest round count Salmon et al. (SC'11, table 2) found
+# Crush-resistant (it passes BigCrush); Random123's default of 10 adds a safety margin the field generator
+# does not need and the VALU-bound generation pass pays for (rf_core.h RF_PHILOX_ROUNDS)
+NATIVE_PHILOX_ROUNDS = 7
+
+
 def philox4x32_10(counter_lo, counter_hi, key0, key1):
-    """Philox4x32-10 (Salmon et al. 2011) on arrays of 64-bit counters.
+    """Philox4x32-10 (the Random123 default), kept for the known-answer vectors."""
+    return philox4x32(counter_lo, counter_hi, key0, key1, rounds=10)
+
+
+def philox4x32(counter_lo, counter_hi, key0, key1, rounds=NATIVE_PHILOX_ROUNDS):
+    """Philox4x32-R (Salmon et al. 2011) on arrays of 64-bit counters.
 
     counter words = (lo32(counter_lo), hi32(counter_lo), lo32(counter_hi),
     hi32(counter_hi)); returns four uint32 arrays."""
@@ -484,7 +495,7 @@ def philox4x32_10(counter_lo, counter_hi, key0, key1):
     c0, c1 = c & m32, c >> s32
     c2, c3 = ch & m32, ch >> s32
     k0, k1 = int(key0) & 0xFFFFFFFF, int(key1) & 0xFFFFFFFF
-    for _ in range(10):
+    for _ in range(rounds):
         p0 = _PHILOX_M0 * c0
         p1 = _PHILOX_M1 * c2
         n0 = (p1 >> s32) ^ c1 ^ np.uint64(k0)
@@ -514,7 +525,7 @@ def philox_normals(seed, cell_index, bits=32):
     """
     ci = np.asarray(cell_index, np.uint64)
     seed = int(seed) & 0xFFFFFFFFFFFFFFFF
-    w = philox4x32_10(ci >> np.uint64(1), np.uint64(0), seed & 0xFFFFFFFF, seed >> 32)
+    w = philox4x32(ci >> np.uint64(1), np.uint64(0), seed & 0xFFFFFFFF, seed >> 32)
     odd = (ci & np.uint64(1)).astype(bool)
     wa = np.where(odd, w[2], w[0])
     wb = np.where(odd, w[3], w[1])

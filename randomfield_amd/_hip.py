@@ -222,6 +222,14 @@ class DevicePlan(object):
         """Route this single-rank plan through the multi-GPU slab pipeline (test hook)."""
         check(self._lib.rf_plan_set_flag(self._h, 2, int(bool(on))), "rf_plan_set_flag")
 
+    def set_transposed_intermediate(self, on=True):
+        """x pass -> contiguous tiles in a scratch array, y pass transposes back (default on; off = one in-place buffer)."""
+        check(self._lib.rf_plan_set_flag(self._h, 8, int(bool(on))), "rf_plan_set_flag")
+
+    def set_yz_slab_planes(self, planes=-1):
+        """x planes per slab of the y / z passes (single-GPU plans): -1 automatic (about the Infinity Cache's size), 0 = whole grid."""
+        check(self._lib.rf_plan_set_flag(self._h, 16, int(planes)), "rf_plan_set_flag")
+
     def set_stream(self, hip_stream):
         check(self._lib.rf_plan_set_stream(self._h, ctypes.c_void_p(hip_stream or 0)), "rf_plan_set_stream")
 

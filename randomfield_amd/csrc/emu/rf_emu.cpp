@@ -27,7 +27,8 @@ void run_col_pass(const IO& io_in, long long ncols, const cplx<typename C::T>* t
   std::vector<IO> ios(C::NT, io_in);             // every "thread" has its own copy of the kernel argument
   for (auto& io : ios) io.bind_seed();
   const long long ntiles = ncols / C::TC;
-  for (long long tile = 0; tile < ntiles; ++tile) {
+  for (long long t0 = 0; t0 < ntiles; ++t0) {
+    const long long tile = io_in.remap_tile(t0);
     const cx* ltw = tw;
     if (F::HAS_PROLOGUE) {
       for (int t = 0; t < C::NT; ++t) F::prologue(t, ios[t], tw, lds.data());
@@ -56,6 +57,45 @@ int dispatch_col(int N, const IO& io, long long ncols) {
 #undef X
     default: return -1;
   }
+}
+
+// The product's x -> y hand-off through the transposed intermediate X [kz tile][ny][nx][TC] (rf_capi.hip queue_xy):
+// g_xposed mirrors RF_FLAG_TRANSPOSED_INTERMEDIATE; the rule for when it applies is the product's xpose_ok().
+int g_xposed = 1;
+template <typename T> int tile_cols(int N, bool gen) {
+  switch (N) {
+#define X(NN) case NN: return gen ? GenSel<T, NN>::type::TC : ColSel<T, NN>::type::TC;
+    RF_COL_SIZES(X)
+#undef X
+    default: return 0;
+  }
+}
+template <typename T> bool xpose_ok(int nx, int ny, long long nzl) {
+  const int tcx = tile_cols<T>(nx, true), tcy = tile_cols<T>(ny, false);
+  return g_xposed && tcx > 0 && tcx == tcy && nzl >= tcx && nzl % tcx == 0;
+}
+int g_rowblock = 64;
+template <typename T> int row_block(int N) {          // the product's col_gen_row_block()
+  if (g_rowblock <= 0 || g_rowblock >= N || (g_rowblock & (g_rowblock - 1))) return N;
+  switch (N) {
+#define X(NN) case NN: { using C = typename GenSel<T, NN>::type; return (C::NPASS >= 2 && (NN / C::RL) % g_rowblock == 0) ? g_rowblock : N; }
+    RF_COL_SIZES(X)
+#undef X
+    default: return N;
+  }
+}
+// y pass X -> W
+template <typename T>
+int xposed_y_pass(int nx, int ny, long long nzl, const cplx<T>* X, cplx<T>* W) {
+  const long long tc = tile_cols<T>(ny, false);
+  XposeColIO<T> io;
+  io.src = X; io.gs = xpose_load_geom(nx, ny, nzl, tc, row_block<T>(nx));
+  io.base = W; io.g = ColGeom{nzl, (long long)ny * nzl, nzl};
+  set_xpose_order(io, nx, nzl / tc);
+  return dispatch_col<T, +1>(ny, io, (long long)nx * nzl);
+}
+template <typename T> ColGeom xposed_x_geom(int nx, int ny, long long nzl) {
+  return xpose_store_geom(nx, ny, nzl, tile_cols<T>(nx, true), row_block<T>(nx));
 }
 
 template <class C>
@@ -218,7 +258,17 @@ int c2r_impl(int nx, int ny, int nz, const GenHost* gen, const cplx<T>* kspace, 
   gio.base = W; gio.g = ColGeom{(long long)ny * nzc, 0, (long long)ny * nzc};
   if (gen) gio.gp = gen->gp; else { memset(&gio.gp, 0, sizeof(gio.gp)); gio.gp.nx = nx; gio.gp.ny = ny; gio.gp.nz = nz; gio.gp.zpitch = nz / 2 + 1; }
   gio.kspace = kspace; gio.kz0 = 0; gio.nzl = (int)nzc;
-  int rc = dispatch_col<T, +1, GenColIO<T>, GenSel>(nx, gio, (long long)ny * nzc);
+  int rc;
+  if (xpose_ok<T>(nx, ny, nzc)) {                  // x pass -> transposed intermediate, y pass X -> W
+    std::vector<cplx<T>> X((size_t)nx * ny * nzc);
+    gio.base = X.data(); gio.g = xposed_x_geom<T>(nx, ny, nzc);
+    rc = dispatch_col<T, +1, GenColIO<T>, GenSel>(nx, gio, (long long)ny * nzc);
+    if (rc) return rc;
+    rc = xposed_y_pass<T>(nx, ny, nzc, X.data(), W);
+    if (rc) return rc;
+    return dispatch_row_c2r<T>((int)nzc, W, (long long)nx * ny, 1.0 / ((double)nx * ny * nz), s1, s2);
+  }
+  rc = dispatch_col<T, +1, GenColIO<T>, GenSel>(nx, gio, (long long)ny * nzc);
   if (rc) return rc;
   // y pass, in place
   PlainColIO<T> pio; pio.base = W; pio.g = ColGeom{nzc, (long long)ny * nzc, nzc};
@@ -242,7 +292,17 @@ int realise_fast_impl(int nx, int ny, int nz, const GenHost& h, uint64_t seed, d
   f.rec = rec.data(); f.nbins = (int)rec.size();
   f.u_scale = (float)(0.5 * std::log10(2.0) / dx); f.u_off = (float)(-x0 / dx);
   f.seed = seed; f.seed_dev = nullptr; f.noise = nullptr; f.noise32 = nullptr; f.seg_off = nullptr; f.seg_cap = 0; f.seg_inv = 0; f.nseg = 0; f.zpitch = nz / 2 + 1; f.zoff = 0; f.ppitch = nz / 2 + 2;
-  int rc = dispatch_col<T, +1, IO, GenSel>(nx, io, (long long)ny * nzc);
+  int rc;
+  if (xpose_ok<T>(nx, ny, nzc)) {
+    std::vector<cplx<T>> X((size_t)nx * ny * nzc);
+    io.base = X.data(); io.g = xposed_x_geom<T>(nx, ny, nzc);
+    rc = dispatch_col<T, +1, IO, GenSel>(nx, io, (long long)ny * nzc);
+    if (rc) return rc;
+    rc = xposed_y_pass<T>(nx, ny, nzc, X.data(), W);
+    if (rc) return rc;
+    return dispatch_row_c2r<T>((int)nzc, W, (long long)nx * ny, 1.0 / ((double)nx * ny * nz), s1, s2);
+  }
+  rc = dispatch_col<T, +1, IO, GenSel>(nx, io, (long long)ny * nzc);
   if (rc) return rc;
   PlainColIO<T> pio; pio.base = W; pio.g = ColGeom{nzc, (long long)ny * nzc, nzc};
   rc = dispatch_col<T, +1>(ny, pio, (long long)nx * nzc);
@@ -397,6 +457,11 @@ int emu_generate_kspace(int f64, int nx, int ny, int nz, const double* kx2, cons
       }
   return 0;
 }
+
+// 1 (default): c2r transforms hand x -> y through the transposed intermediate where the product would; 0: in place
+int emu_set_xposed(int on) { const int old = g_xposed; g_xposed = on; return old; }
+int emu_set_rowblock(int rb) { const int old = g_rowblock; g_rowblock = rb; return old; }
+int emu_xpose_applies(int f64, int nx, int ny, int nz) { return f64 ? xpose_ok<double>(nx, ny, nz / 2) : xpose_ok<float>(nx, ny, nz / 2); }
 
 // full fused realisation: generation + x, y, z passes -> W (real [nx][ny][nz]) and (sum, sumsq)
 int emu_realise(int f64, int nx, int ny, int nz, const double* kx2, const double* ky2, const double* kz2,

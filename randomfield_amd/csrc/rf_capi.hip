@@ -105,6 +105,15 @@ struct rf_plan {
   hipStream_t own_stream = nullptr, stream = nullptr;
   void* W = nullptr;                      // [nx][ny][nz] real == [nx][ny][nz/2] complex (packed Nyquist)
   void* K = nullptr;                      // lazy: API-layout k-space [nx][ny][nz/2+1]
+  // lazy: the x pass's TRANSPOSED intermediate [kz tile][ny][nx][tile width]: the x pass stores whole
+  // contiguous tiles there and the y pass goes X -> W out of place.  xposed = the plan may use it (RF_FLAG_TRANSPOSED_INTERMEDIATE).
+  void* X = nullptr;
+  bool xposed = false;
+  // y and z passes slab by slab of x planes: -1 = automatic (slabs of about the Infinity Cache's size),
+  // 0 = whole-grid passes, > 0 = this many x planes per slab (RF_FLAG_YZ_SLAB_PLANES)
+  int yz_slab = -1;
+  std::vector<hipEvent_t> slab_ev;        // timed runs: after y(i), after z(i)
+  int slab_timed = 0;                     // slabs of the last timed run (0: whole-grid passes, ev[2] / ev[3] apply)
   void* P = nullptr;                      // lazy: saved potential, API layout
   size_t w_bytes = 0, k_bytes = 0, p_bytes = 0;      // field buffer, k-space side array, potential array (padded rows)
   int ppitch = 0;                         // cells per row of the potential array: nzl + 1, rounded up to even on float32 plans
@@ -191,6 +200,21 @@ int ensure_k(rf_plan* p) {
 
 int ensure_g(rf_plan* p) {
   if (!p->G) RF_HIP(hipMalloc(&p->G, p->k_bytes));
+  return 0;
+}
+
+// may the x pass write the transposed intermediate?  Needs equal tile widths in the x and y passes and whole tiles per kz run.
+bool xpose_ok(const rf_plan* p) {
+  if (!p->xposed || p->generic || p->unpacked || (p->replicate && p->nranks > 1)) return false;
+  const int tcx = col_gen_tile_cols(p->f64, p->nx), tcy = col_tile_cols(p->f64, p->ny);
+  return tcx > 0 && tcx == tcy && p->nzl >= tcx && p->nzl % tcx == 0;
+}
+#ifndef RF_XP_ROWBLOCK
+#define RF_XP_ROWBLOCK 64
+#endif
+int xpose_row_block(const rf_plan* p) { return col_gen_row_block(p->f64, p->nx, RF_XP_ROWBLOCK); }
+int ensure_x(rf_plan* p) {
+  if (!p->X && xpose_ok(p)) RF_HIP(hipMalloc(&p->X, p->w_bytes));
   return 0;
 }
 
@@ -320,7 +344,11 @@ int queue_x(rf_plan* p, const GenParams& gp, const void* kspace, void* W, hipStr
   RF_REQUIRE(!rep || fast, "replicated generation needs the native generator (fast path)");
   const long long nzl = rep ? p->nzc : p->nzl;     // kz planes generated by this rank (nz/2 on one GPU)
   const int kz0 = rep ? 0 : p->kz0;
-  const ColGeom gx{(long long)p->ny * nzl, 0, (long long)p->ny * nzl};
+  // W == p->X: the transposed intermediate [kz tile][ny][nx][TC] -- a tile (all nx rows of TC adjacent kz of one iy) is one
+  // contiguous block of nx * TC cells there
+  const ColGeom gx = (W == p->X && W != nullptr)
+                         ? xpose_store_geom(p->nx, p->ny, nzl, col_gen_tile_cols(p->f64, p->nx), xpose_row_block(p))
+                         : ColGeom{(long long)p->ny * nzl, 0, (long long)p->ny * nzl};
   if (timed) { RF_HIP(hipEventRecord(p->ev[5], sx)); p->repair_timed = fast; }   // overwritten by the launcher if it splits
   FastGenParams fgp = make_fast(p, gp.seed, gp.seed_dev != nullptr, gp.seed_dev);
   if (fast_noise && p->noise32_resident) {
@@ -343,6 +371,18 @@ int queue_xy(rf_plan* p, const GenParams& gp, const void* kspace, void* W, hipSt
   const bool rep = p->replicate && p->nranks > 1;
   const long long nzl = rep ? p->nzc : p->nzl, nxp = rep ? p->nxl : p->nx;      // the local array is [nxp][ny][nzl]
   const ColGeom gy{nzl, (long long)p->ny * nzl, nzl};
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(s, &cap);
+  if (cap == hipStreamCaptureStatusNone)           // (no allocation inside a graph capture: batch_prepare() has done it)
+    if (int rc = ensure_x(p)) return rc;
+  if (p->X && xpose_ok(p)) {          // x pass -> transposed intermediate X (whole contiguous tiles), y pass X -> W out of place
+    const ColGeom gys = xpose_load_geom(p->nx, p->ny, nzl, col_tile_cols(p->f64, p->ny), xpose_row_block(p));
+    if (int rc = queue_x(p, gp, kspace, p->X, s, timed)) return rc;
+    if (timed) RF_HIP(hipEventRecord(p->ev[1], s));
+    RF_HIP(launch_col_xpose(p->f64, p->ny, p->X, gys, W, gy, nxp * nzl, p->tw_y, s));
+    if (timed) RF_HIP(hipEventRecord(p->ev[2], s));
+    return 0;
+  }
   if (int rc = queue_x(p, gp, kspace, W, s, timed)) return rc;
   if (timed) RF_HIP(hipEventRecord(p->ev[1], s));
   RF_HIP(launch_col_plain(p->f64, p->ny, +1, W, gy, nxp * nzl, p->tw_y, s));
@@ -457,14 +497,76 @@ int slab_batch(rf_plan* p, const uint64_t* seeds, int n) {
   return 0;
 }
 
-// z pass and the moments of buffer W on stream s; stats go to stats_out[0..1]
-int queue_z(rf_plan* p, void* W, hipStream_t s, double* stats_out, bool timed) {
+// x planes per slab of the y / z passes of a single-rank plan (0: whole-grid passes).  The y pass of a slab leaves it in the
+// 256 MiB Infinity Cache for the z pass that follows at once; slabs much smaller than the cache make the launches too small
+// (1024^3 float32, MI355X: 4.85 ms whole grid, 4.56 ms with 64-plane = 256 MiB slabs, 4.79 ms with 32, 5.6 ms with 16).
+int yz_slab_planes(const rf_plan* p) {
+  if (p->nranks > 1 || p->force_slab || p->generic || p->unpacked || p->yz_slab == 0) return 0;
+  const long long plane = (long long)p->ny * p->nzl * (long long)p->csize;
+  long long B = p->yz_slab;
+  if (B < 0) {
+    static const long long target = [] { const char* e = getenv("RF_YZ_SLAB_MB"); return (e && atoll(e) > 0 ? atoll(e) : 256LL) << 20; }();
+    B = 1;
+    while (2 * B * plane <= target) B *= 2;
+  }
+  if (B >= p->nx || p->nx % B) return 0;
+  // whole z-pass workgroups per slab, at the offsets the whole-grid launch would give them
+  if (row_c2r_tiles(p->f64, (int)p->nzc, B * p->ny) * (p->nx / B) != p->npartials) return 0;
+  return (int)B;
+}
+
+// y and z passes of buffer W (x pass done) of a single-rank plan + the moments into stats_out[0..1]: slab by slab when
+// yz_slab_planes() says so.  X (non-null): the x pass left its output in the transposed intermediate.
+int queue_yz(rf_plan* p, void* W, hipStream_t s, double* stats_out, bool timed) {
+  const long long nzl = p->nzl;
+  const ColGeom gy{nzl, (long long)p->ny * nzl, nzl};
   const double scale = 1.0 / ((double)p->nx * (double)p->ny * (double)p->nz);
-  RF_HIP(launch_row_c2r(p->f64, (int)p->nzc, W, (long long)p->nx * p->ny, scale, p->tw_z, p->partials, s));
-  if (timed) RF_HIP(hipEventRecord(p->ev[3], s));
+  const bool xp = p->X && xpose_ok(p);
+  const long long rb = xpose_row_block(p), tcy = col_tile_cols(p->f64, p->ny);
+  const ColGeom gys = xp ? xpose_load_geom(p->nx, p->ny, nzl, tcy, rb) : gy;
+  long long B = yz_slab_planes(p);
+  if (xp && B > 0 && (B % rb || rb >= p->nx)) B = 0;        // a slab of the transposed intermediate is whole blocks of rb x planes
+  if (timed) p->slab_timed = 0;
+  if (B <= 0) {
+    if (xp) RF_HIP(launch_col_xpose(p->f64, p->ny, p->X, gys, W, gy, (long long)p->nx * nzl, p->tw_y, s));
+    else RF_HIP(launch_col_plain(p->f64, p->ny, +1, W, gy, (long long)p->nx * nzl, p->tw_y, s));
+    if (timed) RF_HIP(hipEventRecord(p->ev[2], s));
+    RF_HIP(launch_row_c2r(p->f64, (int)p->nzc, W, (long long)p->nx * p->ny, scale, p->tw_z, p->partials, s));
+    if (timed) RF_HIP(hipEventRecord(p->ev[3], s));
+  } else {
+    const int nslab = (int)(p->nx / B);
+    const long long plane = (long long)p->ny * nzl * (long long)p->csize, tiles_per_slab = p->npartials / nslab;
+    if (timed) {
+      while ((int)p->slab_ev.size() < 2 * nslab) { hipEvent_t e; RF_HIP(hipEventCreate(&e)); p->slab_ev.push_back(e); }
+      p->slab_timed = nslab;
+    }
+    for (int i = 0; i < nslab; ++i) {
+      char* Ws = (char*)W + (long long)i * B * plane;
+      if (xp) RF_HIP(launch_col_xpose(p->f64, p->ny, (const char*)p->X + (long long)i * (B / rb) * p->ny * rb * tcy * (long long)p->csize, gys, Ws, gy,
+                                      B * nzl, p->tw_y, s));
+      else RF_HIP(launch_col_plain(p->f64, p->ny, +1, Ws, gy, B * nzl, p->tw_y, s));
+      if (timed) RF_HIP(hipEventRecord(p->slab_ev[2 * i], s));
+      RF_HIP(launch_row_c2r(p->f64, (int)p->nzc, Ws, B * p->ny, scale, p->tw_z, p->partials + 2 * i * tiles_per_slab, s));
+      if (timed) RF_HIP(hipEventRecord(p->slab_ev[2 * i + 1], s));
+    }
+    if (timed) { RF_HIP(hipEventRecord(p->ev[2], s)); RF_HIP(hipEventRecord(p->ev[3], s)); }   // (rf_kernel_ms sums the slab events instead)
+  }
   RF_HIP(launch_reduce_partials(p->partials, p->npartials, stats_out, p->partials + 2 * p->npartials, s));
   if (timed) RF_HIP(hipEventRecord(p->ev[4], s));
   return 0;
+}
+
+// the whole single-rank pipeline: x pass (generation or API k-space fused into its load; into the transposed intermediate
+// when the plan uses it), then queue_yz
+int queue_xyz(rf_plan* p, const GenParams& gp, const void* kspace, void* W, hipStream_t s, double* stats_out, bool timed) {
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(s, &cap);
+  if (cap == hipStreamCaptureStatusNone)           // (no allocation inside a graph capture: batch_prepare() has done it)
+    if (int rc = ensure_x(p)) return rc;
+  const bool xp = p->X && xpose_ok(p);
+  if (int rc = queue_x(p, gp, kspace, xp ? p->X : W, s, timed)) return rc;
+  if (timed) RF_HIP(hipEventRecord(p->ev[1], s));
+  return queue_yz(p, W, s, stats_out, timed);
 }
 
 // non-power-of-two grid: API-layout half spectrum K -> x pass into G -> y pass in G -> contiguous c2r pass into W,
@@ -503,6 +605,14 @@ int queue_c2r(rf_plan* p, const GenParams& gp, const void* kspace) {
     return 0;
   }
   if (p->timed) RF_HIP(hipEventRecord(p->ev[0], p->stream));
+  if (p->nranks == 1 && !p->force_slab) {       // one GPU: x pass, then the y / z passes (slab by slab on large grids)
+    if (int rc = queue_xyz(p, gp, kspace, p->W, p->stream, p->stats, p->timed)) return rc;
+    p->cur = p->W;
+    p->stats_slot = 0;
+    p->real_valid = true;
+    p->stats_valid = true;
+    return 0;
+  }
   if (int rc = queue_xy(p, gp, kspace, p->W, p->stream, p->timed)) return rc;
   if (p->replicate && p->nranks > 1) {          // the local array already is this rank's x slab [nxl][ny][nz/2]
     const double scale = 1.0 / ((double)p->nx * (double)p->ny * (double)p->nz);
@@ -528,12 +638,7 @@ int queue_c2r(rf_plan* p, const GenParams& gp, const void* kspace) {
     p->stats_valid = true;
     return 0;
   }
-  if (int rc = queue_z(p, p->W, p->stream, p->stats, p->timed)) return rc;
-  p->cur = p->W;
-  p->stats_slot = 0;
-  p->real_valid = true;
-  p->stats_valid = true;
-  return 0;
+  return fail(1, "queue_c2r: unreachable");
 }
 
 template <typename T> int upload_twiddles(void** dst, int n) {
@@ -649,6 +754,7 @@ int rf_plan_create(rf_plan** out, int nx, int ny, int nz, int dtype, int device,
     if ((e = launch_col_gen(dtype, nx, p->W, gx, (long long)ny * nzl, gp0, nullptr, 0, (int)nzl, p->tw_x, p->stream, true)) != hipSuccess ||
         (e = launch_col_fastgen(dtype, nx, p->W, gx, (long long)ny * nzl, fp0, 0, (int)nzl, p->tw_x, p->stream, true)) != hipSuccess ||
         (e = launch_col_plain(dtype, ny, +1, p->W, gy, (long long)nx * nzl, p->tw_y, p->stream, true)) != hipSuccess ||
+        (e = launch_col_xpose(dtype, ny, p->W, gy, p->W, gy, (long long)nx * nzl, p->tw_y, p->stream, true)) != hipSuccess ||
         (e = launch_row_c2r(dtype, (int)nzc, p->W, (long long)p->nxl * ny, 1.0, p->tw_z, p->partials, p->stream, true)) != hipSuccess ||
         (e = launch_row_r2c(dtype, (int)nzc, p->W, (long long)p->nxl * ny, p->tw_z, p->stream, true)) != hipSuccess ||
         (e = launch_col_plain(dtype, ny, -1, p->W, gy, (long long)nx * nzl, p->tw_y, p->stream, true)) != hipSuccess ||
@@ -758,7 +864,7 @@ int rf_plan_destroy(rf_plan* p) {
   if (p->comm_stream) { (void)hipStreamSynchronize(p->comm_stream); (void)hipStreamDestroy(p->comm_stream); }
   for (auto& e : p->pev) if (e) (void)hipEventDestroy(e);
   void* bufs[] = {p->W, p->R, p->W2, p->R2, p->K, p->P, p->G, p->tw_x, p->tw_y, p->tw_z, p->kx2, p->ky2, p->kz2, p->xt, p->st, p->sl, p->bin,
-                  p->noise, p->mt_scratch, p->mt_pos, p->mt_npos_dev, p->mt_states, p->mt_counts, p->mt_offsets, p->mt_pairs, p->partials, p->stats, p->seeds_dev, p->ztab, p->frec, p->coll_scratch};
+                  p->X, p->noise, p->mt_scratch, p->mt_pos, p->mt_npos_dev, p->mt_states, p->mt_counts, p->mt_offsets, p->mt_pairs, p->partials, p->stats, p->seeds_dev, p->ztab, p->frec, p->coll_scratch};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   for (int i = 0; i < 2; ++i) {
@@ -767,6 +873,7 @@ int rf_plan_destroy(rf_plan* p) {
   }
   for (auto& ev : p->ev)
     if (ev) (void)hipEventDestroy(ev);
+  for (auto& ev : p->slab_ev) (void)hipEventDestroy(ev);
   if (p->own_stream) (void)hipStreamDestroy(p->own_stream);
   delete p;
   return 0;
@@ -774,7 +881,7 @@ int rf_plan_destroy(rf_plan* p) {
 
 int rf_plan_nbytes(rf_plan* p, size_t* nbytes) {
   RF_REQUIRE(p && nbytes, "null argument");
-  *nbytes = p->w_bytes * (1 + (p->R ? 1 : 0) + (p->W2 ? 2 : 0)) + (p->K ? p->k_bytes : 0) + (p->P ? p->p_bytes : 0) + (p->G ? p->k_bytes : 0) +
+  *nbytes = p->w_bytes * (1 + (p->R ? 1 : 0) + (p->W2 ? 2 : 0) + (p->X ? 1 : 0)) + (p->K ? p->k_bytes : 0) + (p->P ? p->p_bytes : 0) + (p->G ? p->k_bytes : 0) +
             p->noise_cap * sizeof(double) + p->mt_scratch_bytes;      // + resident deviates and the replay's scratch runs
   return 0;
 }
@@ -782,8 +889,20 @@ int rf_plan_nbytes(rf_plan* p, size_t* nbytes) {
 int rf_plan_set_flag(rf_plan* p, int flag, int value) {
   RF_REQUIRE(p, "null plan");
   RF_REQUIRE(!p->unpacked, "this call does not apply to an unpacked c2c plan");
-  RF_REQUIRE(flag == RF_FLAG_EXACT_GENERATION || flag == RF_FLAG_FORCE_SLAB_PATH || flag == RF_FLAG_REPLICATED_GENERATION, "unknown flag");
+  RF_REQUIRE(flag == RF_FLAG_EXACT_GENERATION || flag == RF_FLAG_FORCE_SLAB_PATH || flag == RF_FLAG_REPLICATED_GENERATION ||
+             flag == RF_FLAG_TRANSPOSED_INTERMEDIATE || flag == RF_FLAG_YZ_SLAB_PLANES, "unknown flag");
   RF_HIP(hipStreamSynchronize(p->stream));
+  if (flag == RF_FLAG_YZ_SLAB_PLANES) {          // -1 automatic, 0 whole-grid passes, > 0 x planes per slab
+    p->yz_slab = value;
+    drop_graphs(p);
+    return 0;
+  }
+  if (flag == RF_FLAG_TRANSPOSED_INTERMEDIATE) {
+    p->xposed = value != 0;
+    drop_graphs(p);
+    if (!p->xposed && p->X) { RF_HIP(hipFree(p->X)); p->X = nullptr; }
+    return 0;
+  }
   if (flag == RF_FLAG_REPLICATED_GENERATION) {
     RF_REQUIRE(p->nranks > 1, "RF_FLAG_REPLICATED_GENERATION is for multi-rank plans");
     RF_REQUIRE(!value || col_replicate_supported(p->f64, p->nx, p->nranks),
@@ -968,8 +1087,7 @@ static int batch_issue(rf_plan* p, int n) {
   for (int i = 0; i < n; ++i) {
     GenParams gp = make_gen(p, 0, RF_NOISE_NATIVE, true);
     gp.seed_dev = p->seeds_dev + i;
-    if (int rc = queue_xy(p, gp, nullptr, p->W, p->stream, false)) return rc;
-    if (int rc = queue_z(p, p->W, p->stream, p->stats + 2 * i, false)) return rc;
+    if (int rc = queue_xyz(p, gp, nullptr, p->W, p->stream, p->stats + 2 * i, false)) return rc;
   }
   return 0;
 }
@@ -997,6 +1115,7 @@ static int batch_prepare(rf_plan* p, int n) {
     p->stats_cap = cap;
   }
   if (p->graphs.count(n)) return 0;
+  if (int rc = ensure_x(p)) return rc;
   const bool timed_save = p->timed;
   p->timed = false;
   RF_HIP(hipStreamSynchronize(p->stream));
@@ -1290,6 +1409,18 @@ int rf_kernel_ms(rf_plan* p, float* ms5) {
   RF_REQUIRE(p->timed, "per-kernel times are recorded by rf_realise / rf_execute_c2r only");
   RF_HIP(hipEventSynchronize(p->ev[4]));
   for (int i = 0; i < 4; ++i) RF_HIP(hipEventElapsedTime(&ms5[i], p->ev[i], p->ev[i + 1]));
+  if (p->slab_timed > 0) {                 // y / z passes ran slab by slab: [1], [2] = the sums over their launches
+    float ys = 0, zs = 0, t = 0;
+    for (int i = 0; i < p->slab_timed; ++i) {
+      RF_HIP(hipEventElapsedTime(&t, i == 0 ? p->ev[1] : p->slab_ev[2 * i - 1], p->slab_ev[2 * i]));
+      ys += t;
+      RF_HIP(hipEventElapsedTime(&t, p->slab_ev[2 * i], p->slab_ev[2 * i + 1]));
+      zs += t;
+    }
+    ms5[1] = ys;
+    ms5[2] = zs;
+    RF_HIP(hipEventElapsedTime(&ms5[3], p->slab_ev[2 * p->slab_timed - 1], p->ev[4]));
+  }
   // the x pass of the fast generation is two launches: the few tiles that hold slot kz = 0 (with the Hermitian
   // repair), then all the others; report them separately so that [0] is the main kernel alone
   ms5[4] = 0.0f;

@@ -99,24 +99,48 @@ struct ColCfg {
 // row strides need it (needs_wide(), checked by the launchers).
 struct ColGeom {
   long long inner, outer_stride, row_stride;
+  // Optional further levels (the blocked, transposed intermediate of the c2r transform).  With
+  // hi = C / inner, lo = C % inner the element (row, C) lives at
+  //     (hi >> hi_shift) * hi_stride + (hi & (2^hi_shift - 1)) * outer_stride
+  //   + (lo >> sub_shift) * sub_stride + (lo & (2^sub_shift - 1))
+  //   + (row >> row_shift) * row_hi_stride + (row & (2^row_shift - 1)) * row_stride.
+  // The defaults (sub_shift = 0, sub_stride = 1, hi_shift = 62, row_shift = 30) are the plain form above.  A tile is at most
+  // 2^sub_shift columns wide when sub_shift > 0, and the uniform row offsets ro of a pass are multiples of 2^row_shift
+  // whenever row_shift < 30 (so the row splits of rb and ro add without a carry): the launchers check both.
+  int sub_shift = 0;
+  long long sub_stride = 1;
+  int hi_shift = 62;
+  long long hi_stride = 0;
+  int row_shift = 30;
+  long long row_hi_stride = 0;
   // (tiles start at multiples of their width, and widths and `inner` are powers of two: either a tile lies inside
   // one run of `inner` columns, or it covers whole runs and the lane's column offset cl selects the run)
   RF_HD int inner_shift() const { return 63 - __builtin_clzll((unsigned long long)inner); }
   RF_HD long long uniform_part(long long C0, int ro) const {
-    return (C0 >> inner_shift()) * outer_stride + (C0 & (inner - 1)) + (long long)ro * row_stride;
+    const long long lo = C0 & (inner - 1), hi = C0 >> inner_shift();
+    return (hi >> hi_shift) * hi_stride + (hi & ((1LL << hi_shift) - 1)) * outer_stride + (lo >> sub_shift) * sub_stride +
+           (lo & ((1LL << sub_shift) - 1)) + (long long)(ro >> row_shift) * row_hi_stride + (long long)(ro & ((1 << row_shift) - 1)) * row_stride;
   }
   RF_HD uint32_t lane_part(int cl, int rb) const {
-    return (uint32_t)(cl >> inner_shift()) * (uint32_t)outer_stride + ((uint32_t)cl & (uint32_t)(inner - 1)) + (uint32_t)rb * (uint32_t)row_stride;
+    const uint32_t lo = (uint32_t)cl & (uint32_t)(inner - 1);
+    return (uint32_t)(cl >> inner_shift()) * (uint32_t)outer_stride + (lo >> sub_shift) * (uint32_t)sub_stride + (lo & ((1u << sub_shift) - 1u)) +
+           (uint32_t)(rb >> row_shift) * (uint32_t)row_hi_stride + ((uint32_t)rb & ((1u << row_shift) - 1u)) * (uint32_t)row_stride;
   }
   RF_HD long long lane_part_wide(int cl, int rb) const {
-    return (long long)(cl >> inner_shift()) * outer_stride + ((long long)cl & (inner - 1)) + (long long)rb * row_stride;
+    const long long lo = (long long)cl & (inner - 1);
+    return (long long)(cl >> inner_shift()) * outer_stride + (lo >> sub_shift) * sub_stride + (lo & ((1LL << sub_shift) - 1)) +
+           (long long)(rb >> row_shift) * row_hi_stride + (long long)(rb & ((1 << row_shift) - 1)) * row_stride;
   }
   // does the lane part of a pass with L butterflies per column and TC columns per tile need 64 bits?
   bool needs_wide(int L, int TC, int elem_bytes) const {
     const unsigned long long runs = inner < TC ? (unsigned long long)(TC / inner) : 0;
-    return ((unsigned long long)(L - 1) * (unsigned long long)row_stride + runs * (unsigned long long)outer_stride + (unsigned long long)TC) *
-               (unsigned long long)elem_bytes >= (1ull << 32);
+    const unsigned long long subs = sub_shift > 0 ? (unsigned long long)((TC - 1) >> sub_shift) : 0;
+    const unsigned long long rlo = (unsigned long long)(L - 1) < (1ull << row_shift) ? (unsigned long long)(L - 1) : (1ull << row_shift) - 1;
+    return (((unsigned long long)(L - 1) >> row_shift) * (unsigned long long)row_hi_stride + rlo * (unsigned long long)row_stride +
+            runs * (unsigned long long)outer_stride + subs * (unsigned long long)sub_stride + (unsigned long long)TC) * (unsigned long long)elem_bytes >= (1ull << 32);
   }
+  // are the uniform row offsets of a pass (multiples of L, or every row when the pass is the only one) compatible with the row split?
+  bool rows_ok(int L, int npass) const { return row_shift >= 30 || (npass >= 2 && L % (1 << row_shift) == 0); }
   template <bool WIDE, typename E> RF_HD E* at(E* base, long long C0, int cl, int rb, int ro) const {
     E* ub = base + uniform_part(C0, ro);
 #ifndef RF_FORCE_WIDE
@@ -140,7 +164,68 @@ template <typename T, bool WIDE = false> struct PlainColIO {
   RF_HD void bind_seed() {}
   RF_HD static void sched_fence(int = 0) {}      // loads of one butterfly are meant to be issued back to back
   static constexpr bool ROLLED_LOAD = false;
+  RF_HD long long remap_tile(long long t) const { return t; }
 };
+
+// y pass of the c2r transform reading the TRANSPOSED intermediate the x pass left in a scratch array (geometry gs) and writing
+// the device layout W (geometry g): out of place, so that the x pass can store whole contiguous tiles.
+template <typename T> struct XposeColIO {
+  const cplx<T>* src;
+  ColGeom gs;
+  cplx<T>* base;
+  ColGeom g;
+  // Order of the tiles.  A tile is (hi = ix, kz tile kt) with logical index hi * tiles_per_run + kt (columns C = hi * nzl + kz, as
+  // in the in-place pass).  In dispatch order, though, kt must not be the fastest index: the tiles of one ix read the same offset
+  // of tiles_per_run different slabs of X (tens of MB apart: measured 2.9 ms against 1.65 ms for the pass).  So consecutive
+  // tiles walk ix inside a GROUP of 2^grp_shift neighbouring kz tiles -- the group keeps the two 64-byte halves of W's 128-byte
+  // lines (kt even / odd) next to each other in time and in one XCD's L2, and the halves of X's lines (ix even / odd) two
+  // tiles apart.  t = ((kg * nhi + hi) << grp_shift) + kl  ->  hi * tiles_per_run + (kg << grp_shift) + kl.
+  int grp_shift = 0, nhi_shift = 0, tpr_shift = 0;
+  RF_HD long long remap_tile(long long t) const {
+    const long long kl = t & ((1LL << grp_shift) - 1), r = t >> grp_shift;
+    const long long hi = r & ((1LL << nhi_shift) - 1), kg = r >> nhi_shift;
+    return (hi << tpr_shift) + (kg << grp_shift) + kl;
+  }
+  RF_HD V16<T> load(long long C0, int cl, int rb, int ro) const { return v16_load<T>(gs.at<false>(src, C0, cl, rb, ro)); }
+  RF_HD void store(long long C0, int cl, int rb, int ro, const V16<T>& v) const { v16_store<T>(g.at<false>(base, C0, cl, rb, ro), v); }
+  static constexpr int FIX_MODE = 0;
+  RF_HD bool needs_fix(long long) const { return false; }
+  RF_HD cplx<T> fix_value(long long, int, int) const { return cplx<T>(); }
+  static constexpr int LDS_EXTRA = 0;
+  RF_HD void prologue(int, int, void*) {}
+  RF_HD void bind_seed() {}
+  RF_HD static void sched_fence(int = 0) {}
+  static constexpr bool ROLLED_LOAD = false;
+};
+
+// The transposed intermediate X of the c2r transform: [kz tile kt][x block xb][iy][rb rows of x][tc columns of kz], i.e. the x
+// pass's tile (all nx rows of tc adjacent kz of one iy) is nx / rb contiguous chunks of rb * tc cells (whole 128-byte lines),
+// and the y pass's tile (all ny rows of the same tc kz of one ix) reads tc-cell segments rb * tc cells apart inside ONE block
+// of ny * rb * tc cells -- with rb = 64 and 8-byte cells the same 4-KiB stride and 4-MiB span as the in-place pass.
+// (rb = nx: no blocking; the y pass then strides over the whole nx * ny * tc slab: 64-KiB stride, measured 1.7x slower.)
+inline int ilog2ll(long long v) { return 63 - __builtin_clzll((unsigned long long)v); }
+inline ColGeom xpose_store_geom(long long nx, long long ny, long long nzl, long long tc, long long rb) {   // x pass: C = iy * nzl + kz, row = ix
+  ColGeom g{nzl, rb * tc, tc};
+  g.sub_shift = ilog2ll(tc); g.sub_stride = ny * nx * tc;
+  if (rb < nx) { g.row_shift = ilog2ll(rb); g.row_hi_stride = ny * rb * tc; }
+  return g;
+}
+inline ColGeom xpose_load_geom(long long nx, long long ny, long long nzl, long long tc, long long rb) {    // y pass: C = ix * nzl + kz, row = iy
+  ColGeom g{nzl, tc, rb * tc};
+  g.sub_shift = ilog2ll(tc); g.sub_stride = ny * nx * tc;
+  if (rb < nx) { g.hi_shift = ilog2ll(rb); g.hi_stride = ny * rb * tc; }
+  return g;
+}
+
+// dispatch order of XposeColIO's tiles: nhi values of the slow index (powers of two), tiles_per_run kz tiles each
+template <class IO> inline void set_xpose_order(IO& io, long long nhi, long long tiles_per_run) {
+  io.nhi_shift = 63 - __builtin_clzll((unsigned long long)nhi);
+  io.tpr_shift = 63 - __builtin_clzll((unsigned long long)tiles_per_run);
+#ifndef RF_XP_GROUP
+#define RF_XP_GROUP 1
+#endif
+  io.grp_shift = io.tpr_shift < RF_XP_GROUP ? io.tpr_shift : RF_XP_GROUP;
+}
 
 // x pass fused with generation (rows K,T,R,S): load() synthesises the packed
 // k-space cell instead of reading memory.  Columns are the flattened (iy, kz).
@@ -199,6 +284,7 @@ template <typename T, bool WIDE = false> struct GenColIO {
   // the exact-chain generation body (float64 lookups, libm-grade log10 / sin / cos) is far too big to be
   // replicated R times: the load loop stays rolled and parks its values in the thread's own LDS slots
   static constexpr bool ROLLED_LOAD = true;
+  RF_HD long long remap_tile(long long t) const { return t; }
 };
 
 // x pass fused with the fast float32 native generation (one Philox call per lane load)
@@ -304,6 +390,7 @@ struct FastGenColIOT {
   // the lane that owns slot kz = 0 replaces its provisional first cell of every row by the packed,
   // symmetrised (kz=0, kz=nz/2) pair (cold path: one lane in four of one tile in nz/16)
   static constexpr bool ROLLED_LOAD = false;
+  RF_HD long long remap_tile(long long t) const { return t; }
   static constexpr int FIX_MODE = FIX;
   RF_HD bool needs_fix(long long C) const { return FIX != 0 && kz0 + (int)((unsigned)C & (unsigned)(nzl - 1)) == 0; }
   RF_HD cplx<float> fix_value(long long C, int rb, int ro) const {
@@ -370,6 +457,7 @@ struct FastGenColIO64 {
     return v;
   }
   static constexpr bool ROLLED_LOAD = false;
+  RF_HD long long remap_tile(long long t) const { return t; }
   static constexpr int FIX_MODE = FIX;
   RF_HD bool needs_fix(long long C) const { return FIX != 0 && kz0 + (int)((unsigned)C & (unsigned)(nzl - 1)) == 0; }
   RF_HD cplx<double> fix_value(long long C, int rb, int ro) const {

@@ -10,6 +10,7 @@ template <class C, class IO>
 hipError_t launch_one(const IO& io_in, long long ncols, const cplx<typename C::T>* tw, hipStream_t s, bool prepare_only,
                       long long ntiles_sub = -1, long long tile_mul = 1, long long tile_add = 0, int skip_period = 0) {
   if (ncols % C::TC || io_in.g.inner <= 0 || (io_in.g.inner & (io_in.g.inner - 1))) return hipErrorInvalidValue;
+  if (!prepare_only && (!io_in.g.rows_ok(C::N / C::RL, C::NPASS) || (io_in.g.sub_shift > 0 && (1 << io_in.g.sub_shift) < C::TC))) return hipErrorInvalidValue;
   const IO& io = io_in;
   const long long ntiles = ntiles_sub >= 0 ? ntiles_sub : ncols / C::TC;
   auto k = col_kernel<C, +1, IO>;
@@ -147,10 +148,35 @@ hipError_t launch_col_fastgen(int f64, int N, void* W, ColGeom g, long long ncol
     RF_FAST(float, 0, 0)
 #undef X
   }
-#define X(NN) case NN: return launch_fast_one<typename GenSel<float, NN>::type, FastGenColIOT<0, 0, 0>, FastGenColIOT<0, 1, 0>, cplx<float>>(gp, (cplx<float>*)W, g, ncols, kz0, nzl, (const cplx<float>*)tw, s, po, after_repair, x0, x1);
+#ifndef RF_GEN_AB
+#define RF_GEN_AB 0                    // ablation mask of the benchmarked kernel (rf_core.h fast_gen_pair_at); 0 in the product
+#endif
+#define X(NN) case NN: return launch_fast_one<typename GenSel<float, NN>::type, FastGenColIOT<RF_GEN_AB, 0, 0>, FastGenColIOT<RF_GEN_AB, 1, 0>, cplx<float>>(gp, (cplx<float>*)W, g, ncols, kz0, nzl, (const cplx<float>*)tw, s, po, after_repair, x0, x1);
   RF_FAST(float, 0, 0)
 #undef X
 #undef RF_FAST
+}
+
+int col_gen_tile_cols(int f64, int N) {
+  switch (N) {
+#define X(NN) case NN: return f64 ? GenSel<double, NN>::type::TC : GenSel<float, NN>::type::TC;
+    RF_COL_SIZES(X)
+#undef X
+    default: return 0;
+  }
+}
+
+// rows of x per block of the transposed intermediate (rf_fft.h xpose_store_geom): `want` if the last pass's uniform row
+// offsets (multiples of N / RL) are whole blocks, else N (no blocking)
+int col_gen_row_block(int f64, int N, int want) {
+  if (want <= 0 || want >= N || (want & (want - 1))) return N;
+  switch (N) {
+#define X(NN) case NN: { using C = GenSel<float, NN>::type; using D = GenSel<double, NN>::type;                              \
+    const int np = f64 ? D::NPASS : C::NPASS, L = f64 ? NN / D::RL : NN / C::RL; return (np >= 2 && L % want == 0) ? want : N; }
+    RF_COL_SIZES(X)
+#undef X
+    default: return N;
+  }
 }
 
 // does the fast-generation x pass of this length fit a CU's LDS (tile + twiddles + the generation tables)?

@@ -40,7 +40,36 @@ hipError_t launch_t(int N, cplx<T>* base, ColGeom g, long long ncols, const cplx
     default: return hipErrorInvalidValue;
   }
 }
+// inverse pass out of place: src (geometry gs) -> dst (geometry gd)
+template <typename T>
+hipError_t launch_xp(int N, const cplx<T>* src, ColGeom gs, cplx<T>* dst, ColGeom gd, long long ncols, const cplx<T>* tw, hipStream_t s, bool po) {
+  XposeColIO<T> io; io.src = src; io.gs = gs; io.base = dst; io.g = gd;
+  if (gd.inner <= 0 || ncols % gd.inner) return hipErrorInvalidValue;
+  const long long nhi = ncols / gd.inner;                 // values of the slow index (ix); gd.inner = kz planes per run
+  if (nhi & (nhi - 1)) return hipErrorInvalidValue;
+  switch (N) {
+#define X(NN)                                                                                                    \
+  case NN: {                                                                                                     \
+    using C = typename ColSel<T, NN>::type;                                                                      \
+    if (!po && (gs.needs_wide(C::LMAX, C::TC, (int)sizeof(cplx<T>)) || gd.needs_wide(C::LMAX, C::TC, (int)sizeof(cplx<T>)) || \
+                gs.inner <= 0 || (gs.inner & (gs.inner - 1)) || (gs.sub_shift > 0 && (1 << gs.sub_shift) < C::TC)))  \
+      return hipErrorInvalidValue;                                                                               \
+    if (gd.inner % C::TC) return po ? hipSuccess : hipErrorInvalidValue;                                        \
+    set_xpose_order(io, nhi, gd.inner / C::TC);                                                                  \
+    return launch_one<C, +1, XposeColIO<T>>(io, ncols, tw, s, po);                                               \
+  }
+    RF_COL_SIZES(X)
+#undef X
+    default: return hipErrorInvalidValue;
+  }
+}
 }  // namespace
+
+hipError_t launch_col_xpose(int f64, int N, const void* src, ColGeom gs, void* dst, ColGeom gd, long long ncols, const void* tw,
+                            hipStream_t s, bool po) {
+  if (f64) return launch_xp<double>(N, (const cplx<double>*)src, gs, (cplx<double>*)dst, gd, ncols, (const cplx<double>*)tw, s, po);
+  return launch_xp<float>(N, (const cplx<float>*)src, gs, (cplx<float>*)dst, gd, ncols, (const cplx<float>*)tw, s, po);
+}
 
 int col_tile_cols(int f64, int N) {
   switch (N) {

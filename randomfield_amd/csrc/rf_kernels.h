@@ -37,6 +37,7 @@ __global__ __launch_bounds__(C::NT, (col_min_waves<C, IO>())) void col_kernel(IO
     const unsigned t = (unsigned)tile;
     tile = (long long)(t + t / (unsigned)(skip_period - 1) + 1u);
   }
+  tile = io.remap_tile(tile);                                                     // (identity except for XposeColIO)
   const cx* ltw = tw;
   io.bind_seed();
   if (F::HAS_PROLOGUE) {
@@ -67,7 +68,12 @@ __global__ __launch_bounds__(C::NT) void row_c2r_kernel(IO io, const cplx<typena
   extern __shared__ __attribute__((aligned(16))) char rf_smem[];
   cx* lds = reinterpret_cast<cx*>(rf_smem);
   const int tid = threadIdx.x;
-  const long long tile = blockIdx.x;
+  // last rows first: the pass before this one wrote the array front to back, so its end is what the 256 MiB Infinity
+  // Cache still holds (measured: DESIGN.md section 3.8)
+#ifndef RF_Z_REVERSE
+#define RF_Z_REVERSE 1
+#endif
+  const long long tile = RF_Z_REVERSE ? (long long)gridDim.x - 1 - blockIdx.x : (long long)blockIdx.x;
   typename F::Regs r;
   F::prologue(tid, tw, lds);                 // twiddles -> LDS
   const cx* ltw = F::lds_tw(lds);
@@ -99,8 +105,8 @@ __global__ __launch_bounds__(C::NT) void row_c2r_kernel(IO io, const cplx<typena
     double a = 0, b = 0;
 #pragma unroll
     for (int w = 0; w < C::NT / 64; ++w) { a += red[2 * w]; b += red[2 * w + 1]; }
-    partials[2 * (long long)blockIdx.x] = a;
-    partials[2 * (long long)blockIdx.x + 1] = b;
+    partials[2 * tile] = a;
+    partials[2 * tile + 1] = b;
   }
 }
 

@@ -41,6 +41,12 @@ inline int device_cu_count() {
 // prepare_only = true sets the kernel's function attributes (dynamic LDS > 64 KB) without launching
 hipError_t launch_col_plain(int f64, int N, int dir, void* base, ColGeom g, long long ncols, const void* tw,
                             hipStream_t s, bool prepare_only = false);
+// inverse strided pass out of place: reads src through geometry gs, writes dst through gd (the y pass of the c2r transform
+// when the x pass left a transposed intermediate: DESIGN.md section 3.8)
+hipError_t launch_col_xpose(int f64, int N, const void* src, ColGeom gs, void* dst, ColGeom gd, long long ncols, const void* tw,
+                            hipStream_t s, bool prepare_only = false);
+int col_gen_tile_cols(int f64, int N);   // tile width of the generation-fused x pass of length N
+int col_gen_row_block(int f64, int N, int want);   // x rows per block of the transposed intermediate: `want`, or N when the pass cannot block
 // x pass of c2r fused with generation (kspace == nullptr) or reading an API-layout k array
 // [kz0, kz0+nzl) is the slab of packed kz planes this rank owns (0, nz/2 on one GPU)
 hipError_t launch_col_gen(int f64, int N, void* W, ColGeom g, long long ncols, const GenParams& gp,

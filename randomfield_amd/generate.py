@@ -78,7 +78,7 @@ class Generator(object):
         random.py:24) -- replayed on the GPU (MT19937 with jump-ahead + polar method)
         for integer seeds -- so the same seed gives the reference's field (to float32
         FFT rounding).
-        'native' uses the GPU's counter-based Philox4x32-10 + Box-Muller generator:
+        'native' uses the GPU's counter-based Philox4x32-7 + Box-Muller generator:
         no host work, different (statistically equivalent) realisations.
     growth_function, mean_matter_density, redshifts : (nz,) arrays, optional
         The cosmology tables along z (the reference builds them with astropy, generate.py:104-129).

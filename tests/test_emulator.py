@@ -276,3 +276,38 @@ def test_slack_cell_lookup_of_resident_float32_deviates():
                                  cells.ctypes.data_as(u64p), len(cells), out.ctypes.data_as(u64p),
                                  seg.ctypes.data_as(ctypes.POINTER(ctypes.c_int)))
             assert np.array_equal(seg, want_seg) and np.array_equal(out, want)
+
+
+@pytest.mark.parametrize("shape,dtype", [((64, 64, 64), np.complex64), ((128, 64, 64), np.complex64), ((64, 128, 128), np.complex64),
+                                         ((256, 256, 32), np.complex64), ((32, 32, 32), np.complex128), ((16, 32, 64), np.complex128),
+                                         ((512, 16, 64), np.complex64), ((512, 512, 32), np.complex64), ((1024, 1024, 16), np.complex64)])
+def test_transposed_intermediate_is_bit_identical(shape, dtype, default_power):
+    """The x -> y hand-off through the transposed scratch array [kz tile][ny][nx][TC] (contiguous x-pass tiles, out-of-place y
+    pass; rf_capi.hip queue_xy, RF_FLAG_TRANSPOSED_INTERMEDIATE) only moves data: fields are bit-identical to the in-place passes."""
+    nx, ny, nz = shape
+    L = emu_util.lib()
+    applies = L.emu_xpose_applies(int(dtype == np.complex128), nx, ny, nz)
+    k, Pk = default_power["k"], default_power["Pk"]
+    xt, st = cpu_ref.sigma_table(k, Pk, nx, ny, nz, 2.5)
+    rng = np.random.RandomState(nx + ny + nz)
+    ks = (rng.normal(size=(nx, ny, nz // 2 + 1)) + 1j * rng.normal(size=(nx, ny, nz // 2 + 1))).astype(dtype)
+    cpu_ref.symmetrize_packed(ks)
+    res = {}
+    for on, rb in ((1, 64), (0, 64), (2, 16), (3, 0)):          # 64 = the product's block of x rows; 0 = unblocked
+        old, oldrb = L.emu_set_xposed(int(on > 0)), L.emu_set_rowblock(rb)
+        try:
+            res[on] = (emu_util.c2r(ks),) if nx >= 512 and ny >= 512 else (
+                emu_util.c2r(ks), emu_util.realise_fast(nx, ny, nz, 2.5, xt, st, seed=7,
+                                                        dtype=np.float32 if dtype == np.complex64 else np.float64))
+        finally:
+            L.emu_set_xposed(old)
+            L.emu_set_rowblock(oldrb)
+    if (nx, ny) != (512, 16):
+        assert applies == 1            # (x and y tiles of different widths: the product keeps the in-place passes)
+    else:
+        assert applies == 0
+    for v in (1, 2, 3):
+        for a, b in zip(res[v], res[0]):
+            assert np.array_equal(a[0], b[0]) and a[1] == b[1] and a[2] == b[2]
+    ref = np.fft.irfftn(ks.astype(np.complex128), s=(nx, ny, nz), axes=(0, 1, 2))
+    assert np.max(np.abs(res[1][0][0] - ref)) <= (4e-6 if dtype == np.complex64 else 1e-13) * ref.std()

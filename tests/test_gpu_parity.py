@@ -162,7 +162,7 @@ def test_1024_cube_known_answer_generator_reference_rng(hip):
 
 
 def test_native_rng_matches_oracle_restatement(hip, dpower):
-    """Native Philox4x32-10 + Box-Muller mode, value by value against the oracle's
+    """Native Philox4x32-7 + Box-Muller mode, value by value against the oracle's
     restatement of the same counter-based stream.  The default (fast) generation
     forms sigma and the deviates with float32 hardware log / sin / cos on float32
     AND float64 plans: 2e-5 * rms.  The exact-chain flavour on a float64 plan

@@ -146,8 +146,16 @@ def test_variance_fixture_matches_analytic():
 
 
 def test_philox_known_answer():
-    """Philox4x32-10 known-answer vectors from the Random123 distribution
-    (kat_vectors): counter/key all zero and all ones."""
+    """Philox4x32 known-answer vectors from the Random123 distribution (kat_vectors): 10 rounds (the library default) and
+    7 rounds (the native stream, cpu_ref.NATIVE_PHILOX_ROUNDS), counter / key all zero, all ones, and the digits of pi."""
+    assert cpu_ref.NATIVE_PHILOX_ROUNDS == 7
+    pi_lo, pi_hi = np.array([0x85A308D3243F6A88], np.uint64), np.array([0x0370734413198A2E], np.uint64)
+    z, f = np.array([0], np.uint64), np.array([0xFFFFFFFFFFFFFFFF], np.uint64)
+    for rounds, args, want in ((7, (z, z, 0, 0), [0x5F6FB709, 0x0D893F64, 0x4F121F81, 0x4F730A48]),
+                               (7, (f, f, 0xFFFFFFFF, 0xFFFFFFFF), [0x5207DDC2, 0x45165E59, 0x4D8EE751, 0x8C52F662]),
+                               (7, (pi_lo, pi_hi, 0xA4093822, 0x299F31D0), [0x4DFCCABA, 0x190A87F0, 0xC47362BA, 0xB6B5242A]),
+                               (10, (pi_lo, pi_hi, 0xA4093822, 0x299F31D0), [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1])):
+        assert [int(v[0]) for v in cpu_ref.philox4x32(*args, rounds=rounds)] == want
     w = cpu_ref.philox4x32_10(np.array([0], np.uint64), np.array([0], np.uint64), 0, 0)
     assert [int(v[0]) for v in w] == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
     ff = np.array([0xFFFFFFFFFFFFFFFF], np.uint64)

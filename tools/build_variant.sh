@@ -1,0 +1,23 @@
+#!/bin/bash
+# usage: tools/build_variant.sh NAME "EXTRA_FLAGS" [files to recompile with the flags ...]   (default: rf_k_col_gen)
+# builds tools/bin/lib_NAME.so = the product library with some translation units recompiled under extra -D flags
+# (the RF_* config macros of rf_configs.h / rf_fft.h); the other objects are reused from randomfield_amd/csrc/*.o
+set -e
+name=$1; extra=$2; shift 2 || true
+files=${@:-rf_k_col_gen}
+root=$(cd "$(dirname "$0")/.." && pwd)
+src=$root/randomfield_amd/csrc
+out=/tmp/rf_variant_$name
+mkdir -p $out $root/tools/bin
+objs=""
+for f in rf_k_col_plain rf_k_col_gen rf_k_row rf_k_row_c2c rf_k_misc rf_k_mt rf_k_generic rf_capi; do
+  if [[ " $files " == *" $f "* ]]; then
+    hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-unused-variable $extra -I$src -c $src/$f.hip -o $out/$f.o &
+    objs="$objs $out/$f.o"
+  else
+    objs="$objs $src/$f.o"
+  fi
+done
+wait
+hipcc -shared -fPIC --offload-arch=gfx950 -o $root/tools/bin/lib_$name.so $objs -ldl
+echo built tools/bin/lib_$name.so
