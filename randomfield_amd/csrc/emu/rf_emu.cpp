@@ -59,9 +59,11 @@ int dispatch_col(int N, const IO& io, long long ncols) {
   }
 }
 
-// The product's x -> y hand-off through the transposed intermediate X [kz tile][ny][nx][TC] (rf_capi.hip queue_xy):
-// g_xposed mirrors RF_FLAG_TRANSPOSED_INTERMEDIATE; the rule for when it applies is the product's xpose_ok().
+// The product's hand-off of the x pass's output through the blocked intermediate X [x block][kz tile][ny][rb][tc] (rf_capi.hip
+// queue_xyz / queue_yz): y pass in place on X, z pass gathering X -> W.  g_xposed mirrors RF_FLAG_TRANSPOSED_INTERMEDIATE; the
+// rule for when it applies is the product's xpose_ok().
 int g_xposed = 1;
+int g_rowblock = 64;
 template <typename T> int tile_cols(int N, bool gen) {
   switch (N) {
 #define X(NN) case NN: return gen ? GenSel<T, NN>::type::TC : ColSel<T, NN>::type::TC;
@@ -70,11 +72,6 @@ template <typename T> int tile_cols(int N, bool gen) {
     default: return 0;
   }
 }
-template <typename T> bool xpose_ok(int nx, int ny, long long nzl) {
-  const int tcx = tile_cols<T>(nx, true), tcy = tile_cols<T>(ny, false);
-  return g_xposed && tcx > 0 && tcx == tcy && nzl >= tcx && nzl % tcx == 0;
-}
-int g_rowblock = 64;
 template <typename T> int row_block(int N) {          // the product's col_gen_row_block()
   if (g_rowblock <= 0 || g_rowblock >= N || (g_rowblock & (g_rowblock - 1))) return N;
   switch (N) {
@@ -84,23 +81,25 @@ template <typename T> int row_block(int N) {          // the product's col_gen_r
     default: return N;
   }
 }
-// y pass X -> W
-template <typename T>
-int xposed_y_pass(int nx, int ny, long long nzl, const cplx<T>* X, cplx<T>* W) {
-  const long long tc = tile_cols<T>(ny, false);
-  XposeColIO<T> io;
-  io.src = X; io.gs = xpose_load_geom(nx, ny, nzl, tc, row_block<T>(nx));
-  io.base = W; io.g = ColGeom{nzl, (long long)ny * nzl, nzl};
-  set_xpose_order(io, nx, nzl / tc);
-  return dispatch_col<T, +1>(ny, io, (long long)nx * nzl);
+template <typename T> bool xgather_ok(int M, int tc, int rb) {     // the product's row_c2r_xgather_ok()
+  switch (M) {
+#define X(MM) case MM: { using C = typename RowSel<T, MM>::type; return tc > 0 && rb > 0 && rb % C::NRT == 0 && M % tc == 0; }
+    RF_ROW_SIZES(X)
+#undef X
+    default: return false;
+  }
+}
+template <typename T> bool xpose_ok(int nx, int ny, long long nzl) {
+  const int tcx = tile_cols<T>(nx, true), tcy = tile_cols<T>(ny, false);
+  return g_xposed && tcx > 0 && tcx == tcy && nzl >= tcx && nzl % tcx == 0 && xgather_ok<T>((int)nzl, tcx, row_block<T>(nx));
 }
 template <typename T> ColGeom xposed_x_geom(int nx, int ny, long long nzl) {
-  return xpose_store_geom(nx, ny, nzl, tile_cols<T>(nx, true), row_block<T>(nx));
+  return xblock_x_geom(nx, ny, nzl, tile_cols<T>(nx, true), row_block<T>(nx));
 }
 
-template <class C>
-void run_row_c2r(const PlainRowIO<typename C::T>& io, long long nrows, const cplx<typename C::T>* tw, double* s1, double* s2) {
-  using F = RowC2R<C, PlainRowIO<typename C::T>>;
+template <class C, class IO>
+void run_row_c2r(const IO& io, long long nrows, const cplx<typename C::T>* tw, double* s1, double* s2) {
+  using F = RowC2R<C, IO>;
   using cx = cplx<typename C::T>;
   std::vector<cx> lds((size_t)C::LDS_BYTES / sizeof(cx));
   std::vector<typename F::Regs> regs(C::NT);
@@ -126,7 +125,29 @@ int dispatch_row_c2r(int M, cplx<T>* base, long long nrows, double scale, double
   auto tw = make_twiddles<T>(2 * M);
   PlainRowIO<T> io; io.base = base; io.scale = (T)scale; io.M_of = M;
   switch (M) {
-#define X(MM) case MM: run_row_c2r<typename RowSel<T, MM>::type>(io, nrows, tw.data(), s1, s2); return 0;
+#define X(MM) case MM: run_row_c2r<typename RowSel<T, MM>::type, PlainRowIO<T>>(io, nrows, tw.data(), s1, s2); return 0;
+    RF_ROW_SIZES(X)
+#undef X
+    default: return -1;
+  }
+}
+
+// y pass in place on X, then the gathering z pass X -> W (+ moments)
+template <typename T>
+int xposed_yz(int nx, int ny, int nz, cplx<T>* X, cplx<T>* W, double* s1, double* s2) {
+  const long long nzc = nz / 2, tc = tile_cols<T>(ny, false), rb = row_block<T>(nx);
+  XposeColIO<T> io;
+  io.src = X; io.gs = xblock_y_geom(nx, ny, nzc, tc, rb);
+  io.base = X; io.g = io.gs;
+  set_xpose_order(io, nx, nzc / tc);
+  if (int rc = dispatch_col<T, +1>(ny, io, (long long)nx * nzc)) return rc;
+  auto tw = make_twiddles<T>(2 * (int)nzc);
+  XGatherRowIO<T> zio;
+  zio.src = X; zio.dst = W; zio.scale = (T)(1.0 / ((double)nx * ny * nz)); zio.M_of = (int)nzc;
+  zio.seg_shift = ilog2ll(tc); zio.rb_shift = ilog2ll(rb); zio.ny_shift = ilog2ll(ny);
+  zio.kt_stride = (long long)ny * rb * tc; zio.xb_stride = (nzc / tc) * zio.kt_stride;
+  switch ((int)nzc) {
+#define X(MM) case MM: run_row_c2r<typename RowSel<T, MM>::type, XGatherRowIO<T>>(zio, (long long)nx * ny, tw.data(), s1, s2); return 0;
     RF_ROW_SIZES(X)
 #undef X
     default: return -1;
@@ -264,9 +285,7 @@ int c2r_impl(int nx, int ny, int nz, const GenHost* gen, const cplx<T>* kspace, 
     gio.base = X.data(); gio.g = xposed_x_geom<T>(nx, ny, nzc);
     rc = dispatch_col<T, +1, GenColIO<T>, GenSel>(nx, gio, (long long)ny * nzc);
     if (rc) return rc;
-    rc = xposed_y_pass<T>(nx, ny, nzc, X.data(), W);
-    if (rc) return rc;
-    return dispatch_row_c2r<T>((int)nzc, W, (long long)nx * ny, 1.0 / ((double)nx * ny * nz), s1, s2);
+    return xposed_yz<T>(nx, ny, nz, X.data(), W, s1, s2);
   }
   rc = dispatch_col<T, +1, GenColIO<T>, GenSel>(nx, gio, (long long)ny * nzc);
   if (rc) return rc;
@@ -298,9 +317,7 @@ int realise_fast_impl(int nx, int ny, int nz, const GenHost& h, uint64_t seed, d
     io.base = X.data(); io.g = xposed_x_geom<T>(nx, ny, nzc);
     rc = dispatch_col<T, +1, IO, GenSel>(nx, io, (long long)ny * nzc);
     if (rc) return rc;
-    rc = xposed_y_pass<T>(nx, ny, nzc, X.data(), W);
-    if (rc) return rc;
-    return dispatch_row_c2r<T>((int)nzc, W, (long long)nx * ny, 1.0 / ((double)nx * ny * nz), s1, s2);
+    return xposed_yz<T>(nx, ny, nz, X.data(), W, s1, s2);
   }
   rc = dispatch_col<T, +1, IO, GenSel>(nx, io, (long long)ny * nzc);
   if (rc) return rc;
@@ -456,6 +473,26 @@ int emu_generate_kspace(int f64, int nx, int ny, int nz, const double* kx2, cons
         else     ((cplx<float>*)out)[c] = gen_cell<float>(h.gp, seed, ix, iy, iz);
       }
   return 0;
+}
+
+// the gathering z pass alone: X = blocked intermediate [nx / rb][M / tc][ny][rb][tc] -> W dense real rows [nx][ny][2 M]
+int emu_row_c2r_xgather(int f64, int M, int nx, int ny, int tc, int rb, const void* X, void* W, double scale, double* s1, double* s2) {
+  auto run = [&](auto tag) -> int {
+    using T = decltype(tag);
+    if (!xgather_ok<T>(M, tc, rb) || nx % rb) return -2;
+    auto tw = make_twiddles<T>(2 * M);
+    XGatherRowIO<T> zio;
+    zio.src = (const cplx<T>*)X; zio.dst = (cplx<T>*)W; zio.scale = (T)scale; zio.M_of = M;
+    zio.seg_shift = ilog2ll(tc); zio.rb_shift = ilog2ll(rb); zio.ny_shift = ilog2ll(ny);
+    zio.kt_stride = (long long)ny * rb * tc; zio.xb_stride = (long long)(M / tc) * zio.kt_stride;
+    switch (M) {
+#define X(MM) case MM: run_row_c2r<typename RowSel<T, MM>::type, XGatherRowIO<T>>(zio, (long long)nx * ny, tw.data(), s1, s2); return 0;
+      RF_ROW_SIZES(X)
+#undef X
+      default: return -1;
+    }
+  };
+  return f64 ? run(double()) : run(float());
 }
 
 // 1 (default): c2r transforms hand x -> y through the transposed intermediate where the product would; 0: in place

@@ -203,16 +203,18 @@ int ensure_g(rf_plan* p) {
   return 0;
 }
 
-// may the x pass write the transposed intermediate?  Needs equal tile widths in the x and y passes and whole tiles per kz run.
-bool xpose_ok(const rf_plan* p) {
-  if (!p->xposed || p->generic || p->unpacked || (p->replicate && p->nranks > 1)) return false;
-  const int tcx = col_gen_tile_cols(p->f64, p->nx), tcy = col_tile_cols(p->f64, p->ny);
-  return tcx > 0 && tcx == tcy && p->nzl >= tcx && p->nzl % tcx == 0;
-}
+// May the plan hand the x pass's output to the y and z passes through the blocked intermediate X (rf_fft.h xblock_*_geom)?
+// Single-rank tiled plans whose x and y passes use tiles of the same width, whose kz runs are whole tiles and whose z pass
+// can gather (whole workgroups per x block and iy, whole segments per thread group).
 #ifndef RF_XP_ROWBLOCK
 #define RF_XP_ROWBLOCK 64
 #endif
 int xpose_row_block(const rf_plan* p) { return col_gen_row_block(p->f64, p->nx, RF_XP_ROWBLOCK); }
+bool xpose_ok(const rf_plan* p) {
+  if (!p->xposed || p->generic || p->unpacked || p->nranks > 1 || p->force_slab) return false;
+  const int tcx = col_gen_tile_cols(p->f64, p->nx), tcy = col_tile_cols(p->f64, p->ny);
+  return tcx > 0 && tcx == tcy && p->nzl >= tcx && p->nzl % tcx == 0 && row_c2r_xgather_ok(p->f64, (int)p->nzc, tcx, xpose_row_block(p));
+}
 int ensure_x(rf_plan* p) {
   if (!p->X && xpose_ok(p)) RF_HIP(hipMalloc(&p->X, p->w_bytes));
   return 0;
@@ -344,10 +346,10 @@ int queue_x(rf_plan* p, const GenParams& gp, const void* kspace, void* W, hipStr
   RF_REQUIRE(!rep || fast, "replicated generation needs the native generator (fast path)");
   const long long nzl = rep ? p->nzc : p->nzl;     // kz planes generated by this rank (nz/2 on one GPU)
   const int kz0 = rep ? 0 : p->kz0;
-  // W == p->X: the transposed intermediate [kz tile][ny][nx][TC] -- a tile (all nx rows of TC adjacent kz of one iy) is one
-  // contiguous block of nx * TC cells there
+  // W == p->X: the blocked intermediate [x block][kz tile][ny][rb][TC] -- a tile (all nx rows of TC adjacent kz of one iy) is
+  // nx / rb contiguous chunks of rb * TC cells there
   const ColGeom gx = (W == p->X && W != nullptr)
-                         ? xpose_store_geom(p->nx, p->ny, nzl, col_gen_tile_cols(p->f64, p->nx), xpose_row_block(p))
+                         ? xblock_x_geom(p->nx, p->ny, nzl, col_gen_tile_cols(p->f64, p->nx), xpose_row_block(p))
                          : ColGeom{(long long)p->ny * nzl, 0, (long long)p->ny * nzl};
   if (timed) { RF_HIP(hipEventRecord(p->ev[5], sx)); p->repair_timed = fast; }   // overwritten by the launcher if it splits
   FastGenParams fgp = make_fast(p, gp.seed, gp.seed_dev != nullptr, gp.seed_dev);
@@ -371,18 +373,6 @@ int queue_xy(rf_plan* p, const GenParams& gp, const void* kspace, void* W, hipSt
   const bool rep = p->replicate && p->nranks > 1;
   const long long nzl = rep ? p->nzc : p->nzl, nxp = rep ? p->nxl : p->nx;      // the local array is [nxp][ny][nzl]
   const ColGeom gy{nzl, (long long)p->ny * nzl, nzl};
-  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-  (void)hipStreamIsCapturing(s, &cap);
-  if (cap == hipStreamCaptureStatusNone)           // (no allocation inside a graph capture: batch_prepare() has done it)
-    if (int rc = ensure_x(p)) return rc;
-  if (p->X && xpose_ok(p)) {          // x pass -> transposed intermediate X (whole contiguous tiles), y pass X -> W out of place
-    const ColGeom gys = xpose_load_geom(p->nx, p->ny, nzl, col_tile_cols(p->f64, p->ny), xpose_row_block(p));
-    if (int rc = queue_x(p, gp, kspace, p->X, s, timed)) return rc;
-    if (timed) RF_HIP(hipEventRecord(p->ev[1], s));
-    RF_HIP(launch_col_xpose(p->f64, p->ny, p->X, gys, W, gy, nxp * nzl, p->tw_y, s));
-    if (timed) RF_HIP(hipEventRecord(p->ev[2], s));
-    return 0;
-  }
   if (int rc = queue_x(p, gp, kspace, W, s, timed)) return rc;
   if (timed) RF_HIP(hipEventRecord(p->ev[1], s));
   RF_HIP(launch_col_plain(p->f64, p->ny, +1, W, gy, nxp * nzl, p->tw_y, s));
@@ -515,42 +505,36 @@ int yz_slab_planes(const rf_plan* p) {
   return (int)B;
 }
 
-// y and z passes of buffer W (x pass done) of a single-rank plan + the moments into stats_out[0..1]: slab by slab when
-// yz_slab_planes() says so.  X (non-null): the x pass left its output in the transposed intermediate.
+// y and z passes of a single-rank plan + the moments into stats_out[0..1], slab by slab when yz_slab_planes() says so.  The x
+// pass has left its output either in W (plain layout: both passes in place) or in the blocked intermediate X (y pass in place
+// on X, z pass gathering X -> W).
 int queue_yz(rf_plan* p, void* W, hipStream_t s, double* stats_out, bool timed) {
   const long long nzl = p->nzl;
-  const ColGeom gy{nzl, (long long)p->ny * nzl, nzl};
   const double scale = 1.0 / ((double)p->nx * (double)p->ny * (double)p->nz);
   const bool xp = p->X && xpose_ok(p);
-  const long long rb = xpose_row_block(p), tcy = col_tile_cols(p->f64, p->ny);
-  const ColGeom gys = xp ? xpose_load_geom(p->nx, p->ny, nzl, tcy, rb) : gy;
+  const long long rb = xpose_row_block(p), tc = col_tile_cols(p->f64, p->ny);
+  const ColGeom gy = xp ? xblock_y_geom(p->nx, p->ny, nzl, tc, rb) : ColGeom{nzl, (long long)p->ny * nzl, nzl};
   long long B = yz_slab_planes(p);
-  if (xp && B > 0 && (B % rb || rb >= p->nx)) B = 0;        // a slab of the transposed intermediate is whole blocks of rb x planes
-  if (timed) p->slab_timed = 0;
-  if (B <= 0) {
-    if (xp) RF_HIP(launch_col_xpose(p->f64, p->ny, p->X, gys, W, gy, (long long)p->nx * nzl, p->tw_y, s));
-    else RF_HIP(launch_col_plain(p->f64, p->ny, +1, W, gy, (long long)p->nx * nzl, p->tw_y, s));
-    if (timed) RF_HIP(hipEventRecord(p->ev[2], s));
-    RF_HIP(launch_row_c2r(p->f64, (int)p->nzc, W, (long long)p->nx * p->ny, scale, p->tw_z, p->partials, s));
-    if (timed) RF_HIP(hipEventRecord(p->ev[3], s));
-  } else {
-    const int nslab = (int)(p->nx / B);
-    const long long plane = (long long)p->ny * nzl * (long long)p->csize, tiles_per_slab = p->npartials / nslab;
-    if (timed) {
-      while ((int)p->slab_ev.size() < 2 * nslab) { hipEvent_t e; RF_HIP(hipEventCreate(&e)); p->slab_ev.push_back(e); }
-      p->slab_timed = nslab;
-    }
-    for (int i = 0; i < nslab; ++i) {
-      char* Ws = (char*)W + (long long)i * B * plane;
-      if (xp) RF_HIP(launch_col_xpose(p->f64, p->ny, (const char*)p->X + (long long)i * (B / rb) * p->ny * rb * tcy * (long long)p->csize, gys, Ws, gy,
-                                      B * nzl, p->tw_y, s));
-      else RF_HIP(launch_col_plain(p->f64, p->ny, +1, Ws, gy, B * nzl, p->tw_y, s));
-      if (timed) RF_HIP(hipEventRecord(p->slab_ev[2 * i], s));
-      RF_HIP(launch_row_c2r(p->f64, (int)p->nzc, Ws, B * p->ny, scale, p->tw_z, p->partials + 2 * i * tiles_per_slab, s));
-      if (timed) RF_HIP(hipEventRecord(p->slab_ev[2 * i + 1], s));
-    }
-    if (timed) { RF_HIP(hipEventRecord(p->ev[2], s)); RF_HIP(hipEventRecord(p->ev[3], s)); }   // (rf_kernel_ms sums the slab events instead)
+  if (xp && B > 0 && B % rb) B = 0;                          // a slab of X is whole x blocks
+  if (B <= 0) B = p->nx;
+  const int nslab = (int)(p->nx / B);
+  const long long plane = (long long)p->ny * nzl * (long long)p->csize, tiles_per_slab = p->npartials / nslab;
+  if (timed) {
+    while ((int)p->slab_ev.size() < 2 * nslab) { hipEvent_t e; RF_HIP(hipEventCreate(&e)); p->slab_ev.push_back(e); }
+    p->slab_timed = nslab;
   }
+  for (int i = 0; i < nslab; ++i) {
+    char* Ws = (char*)W + (long long)i * B * plane;
+    char* Xs = xp ? (char*)p->X + (long long)i * B * plane : nullptr;        // (x blocks are contiguous and as large as their planes)
+    if (xp) RF_HIP(launch_col_xpose(p->f64, p->ny, Xs, gy, Xs, gy, B * nzl, p->tw_y, s));
+    else RF_HIP(launch_col_plain(p->f64, p->ny, +1, Ws, gy, B * nzl, p->tw_y, s));
+    if (timed) RF_HIP(hipEventRecord(p->slab_ev[2 * i], s));
+    double* part = p->partials + 2 * i * tiles_per_slab;
+    if (xp) RF_HIP(launch_row_c2r_xgather(p->f64, (int)p->nzc, Xs, Ws, B * p->ny, scale, (int)tc, (int)rb, p->ny, p->tw_z, part, s));
+    else RF_HIP(launch_row_c2r(p->f64, (int)p->nzc, Ws, B * p->ny, scale, p->tw_z, part, s));
+    if (timed) RF_HIP(hipEventRecord(p->slab_ev[2 * i + 1], s));
+  }
+  if (timed) { RF_HIP(hipEventRecord(p->ev[2], s)); RF_HIP(hipEventRecord(p->ev[3], s)); }   // (rf_kernel_ms sums the slab events)
   RF_HIP(launch_reduce_partials(p->partials, p->npartials, stats_out, p->partials + 2 * p->npartials, s));
   if (timed) RF_HIP(hipEventRecord(p->ev[4], s));
   return 0;
@@ -756,6 +740,7 @@ int rf_plan_create(rf_plan** out, int nx, int ny, int nz, int dtype, int device,
         (e = launch_col_plain(dtype, ny, +1, p->W, gy, (long long)nx * nzl, p->tw_y, p->stream, true)) != hipSuccess ||
         (e = launch_col_xpose(dtype, ny, p->W, gy, p->W, gy, (long long)nx * nzl, p->tw_y, p->stream, true)) != hipSuccess ||
         (e = launch_row_c2r(dtype, (int)nzc, p->W, (long long)p->nxl * ny, 1.0, p->tw_z, p->partials, p->stream, true)) != hipSuccess ||
+        (e = launch_row_c2r_xgather(dtype, (int)nzc, p->W, p->W, (long long)p->nxl * ny, 1.0, 8, 8, ny, p->tw_z, p->partials, p->stream, true)) != hipSuccess ||
         (e = launch_row_r2c(dtype, (int)nzc, p->W, (long long)p->nxl * ny, p->tw_z, p->stream, true)) != hipSuccess ||
         (e = launch_col_plain(dtype, ny, -1, p->W, gy, (long long)nx * nzl, p->tw_y, p->stream, true)) != hipSuccess ||
         (e = launch_col_plain(dtype, nx, -1, p->W, gx, (long long)ny * nzl, p->tw_x, p->stream, true)) != hipSuccess ||

@@ -167,19 +167,17 @@ template <typename T, bool WIDE = false> struct PlainColIO {
   RF_HD long long remap_tile(long long t) const { return t; }
 };
 
-// y pass of the c2r transform reading the TRANSPOSED intermediate the x pass left in a scratch array (geometry gs) and writing
-// the device layout W (geometry g): out of place, so that the x pass can store whole contiguous tiles.
+// Strided pass with separate load and store geometries and its own tile order: the y pass of the c2r transform on the blocked
+// intermediate X (in place: src == base, gs == g = xblock_y_geom), DESIGN.md section 3.8.
 template <typename T> struct XposeColIO {
   const cplx<T>* src;
   ColGeom gs;
   cplx<T>* base;
   ColGeom g;
   // Order of the tiles.  A tile is (hi = ix, kz tile kt) with logical index hi * tiles_per_run + kt (columns C = hi * nzl + kz, as
-  // in the in-place pass).  In dispatch order, though, kt must not be the fastest index: the tiles of one ix read the same offset
-  // of tiles_per_run different slabs of X (tens of MB apart: measured 2.9 ms against 1.65 ms for the pass).  So consecutive
-  // tiles walk ix inside a GROUP of 2^grp_shift neighbouring kz tiles -- the group keeps the two 64-byte halves of W's 128-byte
-  // lines (kt even / odd) next to each other in time and in one XCD's L2, and the halves of X's lines (ix even / odd) two
-  // tiles apart.  t = ((kg * nhi + hi) << grp_shift) + kl  ->  hi * tiles_per_run + (kg << grp_shift) + kl.
+  // in the plain layout).  In X the tiles of neighbouring ix are neighbouring tc-cell segments (two of them share a 128-byte
+  // line when tc cells are 64 bytes) and the kz tiles of one ix are whole blocks apart, so in dispatch order ix is the fast
+  // index: t = ((kg * nhi + hi) << grp_shift) + kl  ->  hi * tiles_per_run + (kg << grp_shift) + kl  (grp_shift = 0 in the product).
   int grp_shift = 0, nhi_shift = 0, tpr_shift = 0;
   RF_HD long long remap_tile(long long t) const {
     const long long kl = t & ((1LL << grp_shift) - 1), r = t >> grp_shift;
@@ -198,22 +196,26 @@ template <typename T> struct XposeColIO {
   static constexpr bool ROLLED_LOAD = false;
 };
 
-// The transposed intermediate X of the c2r transform: [kz tile kt][x block xb][iy][rb rows of x][tc columns of kz], i.e. the x
-// pass's tile (all nx rows of tc adjacent kz of one iy) is nx / rb contiguous chunks of rb * tc cells (whole 128-byte lines),
-// and the y pass's tile (all ny rows of the same tc kz of one ix) reads tc-cell segments rb * tc cells apart inside ONE block
-// of ny * rb * tc cells -- with rb = 64 and 8-byte cells the same 4-KiB stride and 4-MiB span as the in-place pass.
-// (rb = nx: no blocking; the y pass then strides over the whole nx * ny * tc slab: 64-KiB stride, measured 1.7x slower.)
+// The blocked intermediate X of the c2r transform: [x block xb][kz tile kt][iy][rb rows of x][tc columns],
+//   cell (ix, iy, kz)  at  ((xb * nkt + kt) * ny + iy) * rb * tc + (ix % rb) * tc + kz % tc,   xb = ix / rb, kt = kz / tc.
+// * the x pass's tile (all nx rows of tc adjacent kz of one iy) is nx / rb contiguous chunks of rb * tc cells: whole 128-byte
+//   lines (its stores into the plain layout are 64-byte half lines 4 MiB apart);
+// * the y pass runs IN PLACE on X: its tile (all ny rows of tc kz of one ix) is tc-cell segments rb * tc cells apart inside one
+//   block of ny * rb * tc cells -- with rb = 64 and 8-byte cells the 4-KiB stride and 4-MiB span of the plain layout;
+// * the z pass gathers: its NRT rows are consecutive ix of one (xb, iy), so for every kz tile they are ONE contiguous chunk of
+//   NRT * tc cells, and it writes the dense rows of W (XGatherRowIO);
+// * an x block is contiguous: the y / z slabs of RF_FLAG_YZ_SLAB_PLANES are whole blocks.
 inline int ilog2ll(long long v) { return 63 - __builtin_clzll((unsigned long long)v); }
-inline ColGeom xpose_store_geom(long long nx, long long ny, long long nzl, long long tc, long long rb) {   // x pass: C = iy * nzl + kz, row = ix
+inline ColGeom xblock_x_geom(long long nx, long long ny, long long nzl, long long tc, long long rb) {   // x pass: C = iy * nzl + kz, row = ix
   ColGeom g{nzl, rb * tc, tc};
-  g.sub_shift = ilog2ll(tc); g.sub_stride = ny * nx * tc;
-  if (rb < nx) { g.row_shift = ilog2ll(rb); g.row_hi_stride = ny * rb * tc; }
+  g.sub_shift = ilog2ll(tc); g.sub_stride = ny * rb * tc;
+  if (rb < nx) { g.row_shift = ilog2ll(rb); g.row_hi_stride = (nzl / tc) * ny * rb * tc; }
   return g;
 }
-inline ColGeom xpose_load_geom(long long nx, long long ny, long long nzl, long long tc, long long rb) {    // y pass: C = ix * nzl + kz, row = iy
+inline ColGeom xblock_y_geom(long long nx, long long ny, long long nzl, long long tc, long long rb) {   // y pass: C = ix * nzl + kz, row = iy
   ColGeom g{nzl, tc, rb * tc};
-  g.sub_shift = ilog2ll(tc); g.sub_stride = ny * nx * tc;
-  if (rb < nx) { g.hi_shift = ilog2ll(rb); g.hi_stride = ny * rb * tc; }
+  g.sub_shift = ilog2ll(tc); g.sub_stride = ny * rb * tc;
+  if (rb < nx) { g.hi_shift = ilog2ll(rb); g.hi_stride = (nzl / tc) * ny * rb * tc; }
   return g;
 }
 
@@ -222,7 +224,7 @@ template <class IO> inline void set_xpose_order(IO& io, long long nhi, long long
   io.nhi_shift = 63 - __builtin_clzll((unsigned long long)nhi);
   io.tpr_shift = 63 - __builtin_clzll((unsigned long long)tiles_per_run);
 #ifndef RF_XP_GROUP
-#define RF_XP_GROUP 1
+#define RF_XP_GROUP 0
 #endif
   io.grp_shift = io.tpr_shift < RF_XP_GROUP ? io.tpr_shift : RF_XP_GROUP;
 }
@@ -696,6 +698,11 @@ template <typename T> struct PlainRowIO {
   cplx<T>* base;
   T scale;                       // 1 / (nx ny nz)
   int M_of;                      // complex elements per row (nz / 2)
+  // (tile, row of the tile, lane's element, uniform element offset): the split lets a gathering IO keep its address arithmetic
+  // on the scalar unit; here it is just row = tile * NRT + rl, element = kb + ko
+  template <int NRT> RF_HD cplx<T> load2(long long tile, int rl, int kb, int ko) const { return load(tile * NRT + rl, kb + ko); }
+  template <int NRT> RF_HD void store2(long long tile, int rl, int nb, int no, cplx<T> z, double& s1, double& s2) const { store(tile * NRT + rl, nb + no, z, s1, s2); }
+  RF_HD int gather_seg_shift() const { return -1; }
   RF_HD cplx<T> load(long long row, int k) const { return stream_load(base + row * (long long)M_of + k); }
   RF_HD void store(long long row, int n, cplx<T> z, double& s1, double& s2) const {
     z.x *= scale; z.y *= scale;
@@ -716,6 +723,11 @@ template <typename T> struct GatherRowIO {
   int M_of;                      // nz / 2
   int nzl;                       // kz planes per source rank
   long long seg_stride;          // complex elements between two source blocks = nxl * ny * nzl
+  // (tile, row of the tile, lane's element, uniform element offset): the split lets a gathering IO keep its address arithmetic
+  // on the scalar unit; here it is just row = tile * NRT + rl, element = kb + ko
+  template <int NRT> RF_HD cplx<T> load2(long long tile, int rl, int kb, int ko) const { return load(tile * NRT + rl, kb + ko); }
+  template <int NRT> RF_HD void store2(long long tile, int rl, int nb, int no, cplx<T> z, double& s1, double& s2) const { store(tile * NRT + rl, nb + no, z, s1, s2); }
+  RF_HD int gather_seg_shift() const { return -1; }
   RF_HD cplx<T> load(long long row, int k) const {
     const int g = k / nzl, kk = k - g * nzl;
     return src[(long long)g * seg_stride + row * (long long)nzl + kk];
@@ -723,6 +735,56 @@ template <typename T> struct GatherRowIO {
   RF_HD void store(long long row, int n, cplx<T> z, double& s1, double& s2) const {
     z.x *= scale; z.y *= scale;
     dst[row * (long long)M_of + n] = z;
+    s1 += (double)z.x + (double)z.y;
+    s2 += (double)z.x * (double)z.x + (double)z.y * (double)z.y;
+  }
+};
+
+// z pass reading the blocked intermediate X [xb][kt][iy][rb][tc] (xblock_*_geom) and writing the dense rows of W.  The NRT rows
+// of a workgroup are consecutive ix of one (xb, iy): local row index (of the slab the launch covers) = (xb * ny + iy) * rb + r,
+// so tile T covers rows T * NRT .. + NRT of ONE (xb, iy) (rb is a multiple of NRT) and every kz tile of theirs is one contiguous
+// chunk of NRT * tc cells.  SEG_SHIFT = log2(tc): pass 1 deals its threads so that a wave reads whole chunks (RowC2R::pass_first).
+template <typename T> struct XGatherRowIO {
+  const cplx<T>* src;            // X, at the first x block of the slab
+  cplx<T>* dst;                  // W, at the first x plane of the slab
+  T scale;
+  int M_of;                      // nz / 2
+  int seg_shift;                 // log2(tc)
+  int rb_shift, ny_shift;        // log2 of the rows of x per block and of ny (both powers of two on this path)
+  long long kt_stride;           // cells between two kz tiles of a block = ny * rb * tc
+  long long xb_stride;           // cells between two x blocks = (M / tc) * kt_stride
+  RF_HD int gather_seg_shift() const { return seg_shift; }
+  // A tile's NRT rows share (xb, iy) and are consecutive r (NRT divides rb): everything but the row-in-tile, the lane's element
+  // and the kz tile of the uniform offset is workgroup-uniform (scalar unit); the lane part fits 32 bits (one x block).
+  template <int NRT> RF_HD cplx<T> load2(long long tile, int rl, int kb, int ko) const {
+    const long long t0 = tile * NRT, q = t0 >> rb_shift, r0 = t0 & ((1LL << rb_shift) - 1);
+    const long long xb = q >> ny_shift, iy = q & ((1LL << ny_shift) - 1);
+    const int mask = (1 << seg_shift) - 1;
+    const cplx<T>* ub = src + xb * xb_stride + ((((iy << rb_shift) + r0)) << seg_shift) + (long long)(ko >> seg_shift) * kt_stride;
+    const int kl = kb + (ko & mask);                  // (ko is a multiple of the segment length in the product: kl == kb)
+    const uint32_t lane = ((uint32_t)rl << seg_shift) + (uint32_t)(kl >> seg_shift) * (uint32_t)kt_stride + (uint32_t)(kl & mask);
+    return stream_load(reinterpret_cast<const cplx<T>*>((size_t)ub + (size_t)(lane * (uint32_t)sizeof(cplx<T>))));
+  }
+  template <int NRT> RF_HD void store2(long long tile, int rl, int nb, int no, cplx<T> z, double& s1, double& s2) const {
+    const long long t0 = tile * NRT, q = t0 >> rb_shift, r0 = t0 & ((1LL << rb_shift) - 1);
+    const long long xb = q >> ny_shift, iy = q & ((1LL << ny_shift) - 1);
+    cplx<T>* ub = dst + (((((xb << rb_shift) + r0) << ny_shift) + iy)) * (long long)M_of + no;
+    const uint32_t lane = (uint32_t)rl * ((uint32_t)M_of << ny_shift) + (uint32_t)nb;
+    z.x *= scale; z.y *= scale;
+    stream_store(reinterpret_cast<cplx<T>*>((size_t)ub + (size_t)(lane * (uint32_t)sizeof(cplx<T>))), z);
+    s1 += (double)z.x + (double)z.y;
+    s2 += (double)z.x * (double)z.x + (double)z.y * (double)z.y;
+  }
+  RF_HD cplx<T> load(long long row, int k) const {
+    const long long r = row & ((1LL << rb_shift) - 1), q = row >> rb_shift;      // q = xb * ny + iy
+    const long long xb = q >> ny_shift, iy = q & ((1LL << ny_shift) - 1);
+    return stream_load(src + xb * xb_stride + (long long)(k >> seg_shift) * kt_stride + ((((iy << rb_shift) + r)) << seg_shift) + (k & ((1 << seg_shift) - 1)));
+  }
+  RF_HD void store(long long row, int n, cplx<T> z, double& s1, double& s2) const {
+    const long long r = row & ((1LL << rb_shift) - 1), q = row >> rb_shift;
+    const long long xb = q >> ny_shift, iy = q & ((1LL << ny_shift) - 1);
+    z.x *= scale; z.y *= scale;
+    stream_store(dst + (((((xb << rb_shift) + r) << ny_shift) + iy)) * (long long)M_of + n, z);
     s1 += (double)z.x + (double)z.y;
     s2 += (double)z.x * (double)z.x + (double)z.y * (double)z.y;
   }
@@ -751,7 +813,7 @@ struct RowC2R {
   RF_HD static void emit(int rl, long long row, int idx, const cx* v, const IO& io, cx* lds, Regs& r) {
 #pragma unroll
     for (int m = 0; m < R; ++m) {
-      if (C::NPASS == 1) io.store(row, idx + m, v[m], r.s1, r.s2);
+      if (C::NPASS == 1) io.template store2<C::NRT>(row / C::NRT, rl, idx, m, v[m], r.s1, r.s2);
       else *lds_at(lds, rl, idx + m) = v[m];
     }
   }
@@ -763,7 +825,16 @@ struct RowC2R {
 #pragma unroll
     for (int it = 0; it < C::IT1; ++it) {
       const int w = it * NT + tid;
-      const int rl = w / C::TPR1, q = w % C::TPR1;
+      int rl = w / C::TPR1, q = w % C::TPR1;
+      // gathering IO: 2^sg consecutive k of a row are one segment of the source and the segments of the tile's NRT rows are
+      // adjacent, so thread w takes k-in-segment = w % 2^sg, row = (w >> sg) % NRT, segment = w / (NRT 2^sg): a wave's loads
+      // then cover whole chunks of NRT segments instead of one segment in each of many blocks
+      const int sg = io.gather_seg_shift();
+      if (sg >= 0 && C::TPR1 % (1 << sg) == 0) {
+        rl = (w >> sg) % C::NRT;
+        q = ((w >> sg) / C::NRT << sg) + (w & ((1 << sg) - 1));
+        if (q >= C::TPR1) rl = C::NRT;         // (threads beyond NRT * TPR1: idle, as in the plain mapping)
+      }
       const long long row = tile * C::NRT + rl;
       if (rl < C::NRT && row < nrows) {
         const bool self = (q == 0);
@@ -772,10 +843,10 @@ struct RowC2R {
         const bool has_b = (L >= 2);
         cx A[R], B[R], ZA[R], ZB[R];
 #pragma unroll
-        for (int m = 0; m < R; ++m) A[m] = io.load(row, ja + m * L);
+        for (int m = 0; m < R; ++m) A[m] = io.template load2<C::NRT>(tile, rl, ja, m * L);
         if (has_b) {
 #pragma unroll
-          for (int m = 0; m < R; ++m) B[m] = io.load(row, jb + m * L);
+          for (int m = 0; m < R; ++m) B[m] = io.template load2<C::NRT>(tile, rl, jb, m * L);
         }
 #pragma unroll
         for (int m = 0; m < R; ++m) {
@@ -849,7 +920,7 @@ struct RowC2R {
         }
         DFT<R, DIR>::run(v);
 #pragma unroll
-        for (int m = 0; m < R; ++m) io.store(row, j + m * L, v[m], r.s1, r.s2);
+        for (int m = 0; m < R; ++m) io.template store2<C::NRT>(tile, rl, j, m * L, v[m], r.s1, r.s2);
       }
     }
   }

@@ -40,6 +40,32 @@ hipError_t launch_gather_t(int M, const cplx<T>* src, cplx<T>* dst, long long nr
     default: return hipErrorInvalidValue;
   }
 }
+template <typename T>
+hipError_t launch_xgather_t(int M, const cplx<T>* src, cplx<T>* dst, long long nrows, double scale, int tc, int rb, int ny,
+                            const cplx<T>* tw, double* partials, hipStream_t s, bool po) {
+  XGatherRowIO<T> io; io.src = src; io.dst = dst; io.scale = (T)scale; io.M_of = M;
+  auto pow2 = [](long long v) { return v > 0 && (v & (v - 1)) == 0; };
+  if (!po && (!pow2(tc) || !pow2(rb) || !pow2(ny) || M % tc || nrows % rb)) return hipErrorInvalidValue;
+  io.seg_shift = ilog2ll(tc > 0 ? tc : 1); io.rb_shift = ilog2ll(rb > 0 ? rb : 1); io.ny_shift = ilog2ll(ny > 0 ? ny : 1);
+  io.kt_stride = (long long)ny * rb * tc; io.xb_stride = (long long)(M / (tc > 0 ? tc : 1)) * io.kt_stride;
+  switch (M) {
+#define X(MM) case MM: { using C = typename RowSel<T, MM>::type;                                                           \
+    if (!po && rb % C::NRT) return hipErrorInvalidValue;                   /* whole workgroups per (x block, iy) */              \
+    return launch_one<C, XGatherRowIO<T>>(io, nrows, tw, partials, s, po); }
+    RF_ROW_SIZES(X)
+#undef X
+    default: return hipErrorInvalidValue;
+  }
+}
+// can the gathering z pass of rows of M complex serve tiles of tc columns and x blocks of rb rows?
+template <typename T> bool xgather_ok_t(int M, int tc, int rb) {
+  switch (M) {
+#define X(MM) case MM: { using C = typename RowSel<T, MM>::type; return tc > 0 && rb > 0 && rb % C::NRT == 0 && M % tc == 0; }
+    RF_ROW_SIZES(X)
+#undef X
+    default: return false;
+  }
+}
 template <class C>
 hipError_t launch_fwd_one(const PlainRowFwdIO<typename C::T>& io, long long nrows, const cplx<typename C::T>* tw, hipStream_t s, bool po) {
   const long long ntiles = (nrows + C::NRT - 1) / C::NRT;
@@ -81,6 +107,12 @@ hipError_t launch_row_c2r_gather(int f64, int M, const void* src, void* dst, lon
   if (f64) return launch_gather_t<double>(M, (const cplx<double>*)src, (cplx<double>*)dst, nrows, scale, nzl, seg_stride, (const cplx<double>*)tw, partials, s, po);
   return launch_gather_t<float>(M, (const cplx<float>*)src, (cplx<float>*)dst, nrows, scale, nzl, seg_stride, (const cplx<float>*)tw, partials, s, po);
 }
+hipError_t launch_row_c2r_xgather(int f64, int M, const void* src, void* dst, long long nrows, double scale, int tc, int rb, int ny,
+                                  const void* tw, double* partials, hipStream_t s, bool po) {
+  if (f64) return launch_xgather_t<double>(M, (const cplx<double>*)src, (cplx<double>*)dst, nrows, scale, tc, rb, ny, (const cplx<double>*)tw, partials, s, po);
+  return launch_xgather_t<float>(M, (const cplx<float>*)src, (cplx<float>*)dst, nrows, scale, tc, rb, ny, (const cplx<float>*)tw, partials, s, po);
+}
+bool row_c2r_xgather_ok(int f64, int M, int tc, int rb) { return f64 ? xgather_ok_t<double>(M, tc, rb) : xgather_ok_t<float>(M, tc, rb); }
 hipError_t launch_row_r2c(int f64, int M, void* W, long long nrows, const void* tw, hipStream_t s, bool po) {
   if (f64) return launch_fwd_t<double>(M, (cplx<double>*)W, nrows, (const cplx<double>*)tw, s, po);
   return launch_fwd_t<float>(M, (cplx<float>*)W, nrows, (const cplx<float>*)tw, s, po);

@@ -70,6 +70,11 @@ hipError_t launch_row_c2r(int f64, int M, void* W, long long nrows, double scale
 hipError_t launch_row_c2r_gather(int f64, int M, const void* src, void* dst, long long nrows, double scale, int nzl,
                                  long long seg_stride, const void* tw, double* partials, hipStream_t s,
                                  bool prepare_only = false);
+// z pass reading the blocked intermediate X [x block][kz tile][ny][rb][tc] (rf_fft.h xblock_*_geom) of the slab at `src` and writing
+// the dense rows of W at `dst`; nrows = (x planes of the slab) * ny, in the order (x block, iy, row of the block)
+hipError_t launch_row_c2r_xgather(int f64, int M, const void* src, void* dst, long long nrows, double scale, int tc, int rb, int ny,
+                                  const void* tw, double* partials, hipStream_t s, bool prepare_only = false);
+bool row_c2r_xgather_ok(int f64, int M, int tc, int rb);
 // forward z pass (r2c rows, in place: nz reals -> nz/2 complex with (X[0], X[nz/2]) packed in element 0)
 hipError_t launch_row_r2c(int f64, int M, void* W, long long nrows, const void* tw, hipStream_t s,
                           bool prepare_only = false);

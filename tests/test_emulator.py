@@ -279,11 +279,12 @@ def test_slack_cell_lookup_of_resident_float32_deviates():
 
 
 @pytest.mark.parametrize("shape,dtype", [((64, 64, 64), np.complex64), ((128, 64, 64), np.complex64), ((64, 128, 128), np.complex64),
-                                         ((256, 256, 32), np.complex64), ((32, 32, 32), np.complex128), ((16, 32, 64), np.complex128),
-                                         ((512, 16, 64), np.complex64), ((512, 512, 32), np.complex64), ((1024, 1024, 16), np.complex64)])
+                                         ((256, 256, 32), np.complex64), ((64, 64, 128), np.complex128), ((128, 128, 64), np.complex128), ((32, 32, 32), np.complex128),
+                                         ((512, 16, 64), np.complex64), ((512, 512, 64), np.complex64), ((1024, 1024, 64), np.complex64)])
 def test_transposed_intermediate_is_bit_identical(shape, dtype, default_power):
-    """The x -> y hand-off through the transposed scratch array [kz tile][ny][nx][TC] (contiguous x-pass tiles, out-of-place y
-    pass; rf_capi.hip queue_xy, RF_FLAG_TRANSPOSED_INTERMEDIATE) only moves data: fields are bit-identical to the in-place passes."""
+    """The blocked intermediate X [x block][kz tile][ny][rb][TC] (x pass stores contiguous chunks, y pass in place on X, z pass
+    gathers X -> W; rf_capi.hip queue_xyz, RF_FLAG_TRANSPOSED_INTERMEDIATE) only moves data: fields are bit-identical to the
+    passes on the plain layout."""
     nx, ny, nz = shape
     L = emu_util.lib()
     applies = L.emu_xpose_applies(int(dtype == np.complex128), nx, ny, nz)
@@ -302,12 +303,41 @@ def test_transposed_intermediate_is_bit_identical(shape, dtype, default_power):
         finally:
             L.emu_set_xposed(old)
             L.emu_set_rowblock(oldrb)
-    if (nx, ny) != (512, 16):
-        assert applies == 1            # (x and y tiles of different widths: the product keeps the in-place passes)
-    else:
-        assert applies == 0
+    # (512, 16, 64): x and y tiles of different widths; (32, 32, 32) float64: fewer x rows than the z pass's rows per workgroup
+    assert applies == (0 if shape in ((512, 16, 64), (32, 32, 32)) else 1)
     for v in (1, 2, 3):
         for a, b in zip(res[v], res[0]):
-            assert np.array_equal(a[0], b[0]) and a[1] == b[1] and a[2] == b[2]
+            assert np.array_equal(a[0], b[0])
+            # (the moments are summed in a different order: the z pass deals its rows to threads differently when it gathers)
+            assert abs(a[1] - b[1]) <= 1e-9 * max(1.0, a[0].size ** 0.5) * float(np.abs(a[0]).max()) and abs(a[2] - b[2]) <= 1e-12 * b[2]
     ref = np.fft.irfftn(ks.astype(np.complex128), s=(nx, ny, nz), axes=(0, 1, 2))
     assert np.max(np.abs(res[1][0][0] - ref)) <= (4e-6 if dtype == np.complex64 else 1e-13) * ref.std()
+
+
+@pytest.mark.parametrize("M,nx,ny,tc,rb,dtype", [(512, 16, 4, 8, 8, np.complex64), (512, 64, 2, 8, 64, np.complex64), (1024, 8, 4, 8, 4, np.complex64),
+                                                (256, 32, 2, 16, 16, np.complex64), (512, 8, 2, 8, 8, np.complex128), (128, 64, 2, 8, 32, np.complex64),
+                                                (512, 64, 2, 32, 64, np.complex64)])
+def test_gathering_z_pass(M, nx, ny, tc, rb, dtype):
+    """RowC2R with XGatherRowIO (z pass reading the blocked intermediate, threads dealt so that a wave reads whole chunks of
+    NRT segments) against the plain z pass on the same rows: identical outputs."""
+    import ctypes
+    L = emu_util.lib()
+    rng = np.random.RandomState(M + nx)
+    Wk = (rng.normal(size=(nx, ny, M)) + 1j * rng.normal(size=(nx, ny, M))).astype(dtype)      # packed rows (slot 0 = DC + i Nyquist)
+    # X[xb][kt][iy][r][c] = Wk[xb * rb + r][iy][kt * tc + c]
+    X = np.ascontiguousarray(Wk.reshape(nx // rb, rb, ny, M // tc, tc).transpose(0, 3, 2, 1, 4))
+    rt = np.float32 if dtype == np.complex64 else np.float64
+    out = np.zeros((nx, ny, 2 * M), rt)
+    s1, s2 = ctypes.c_double(), ctypes.c_double()
+    rc = L.emu_row_c2r_xgather(int(dtype == np.complex128), M, nx, ny, tc, rb, X.ctypes.data_as(ctypes.c_void_p),
+                               out.ctypes.data_as(ctypes.c_void_p), ctypes.c_double(0.5), ctypes.byref(s1), ctypes.byref(s2))
+    assert rc == 0, rc
+    # reference: the c2r of a row of packed data = irfft of the half spectrum with (DC, Nyquist) unpacked, unnormalised * scale
+    half = np.empty((nx, ny, M + 1), np.complex128)
+    half[..., 1:M] = Wk[..., 1:]
+    half[..., 0] = Wk[..., 0].real
+    half[..., M] = Wk[..., 0].imag
+    ref = np.fft.irfft(half, n=2 * M, axis=-1) * (2 * M) * 0.5
+    assert np.max(np.abs(out - ref)) <= (2e-6 if dtype == np.complex64 else 1e-13) * np.abs(ref).max()
+    assert abs(s1.value - out.astype(np.float64).sum()) <= 1e-6 * out.size * np.abs(out).max()
+    assert abs(s2.value - (out.astype(np.float64) ** 2).sum()) <= 1e-6 * s2.value
