@@ -309,23 +309,32 @@ def main():
     pass_ms = np.array([kern[0] + kern[4], kern[1], kern[2]])
     alg = [sweep, 2 * sweep, 2 * sweep]
     dom = int(np.argmax(pass_ms))
-    achieved = alg[dom] / (pass_ms[dom] * 1e-3) / 1e9
+    achieved = alg[dom] / (pass_ms[dom] * 1e-3) / 1e9          # = bytes per launch / mean launch duration (both divided by the launches)
     # HBM bytes per launch of that kernel from the committed rocprofv3 --pmc passes (profiles/), if they
     # were taken on this grid; bench.py itself cannot run the profiler
-    traffic, traffic_source = None, None
+    # (per LAUNCH, like `achieved`: the y and z passes are nslab launches each when they run slab by slab; the x pass is its
+    # two launches together)
+    nslab, slab_planes = plan.yz_slabs()
+    launches = [1, nslab, nslab]
+    traffic, traffic_source, pass_traffic = None, None, {}
+    keys = [["FastGenColIOT<0, 0,", "FastGenColIOT<0, 1,"], ["PlainColIO", "XposeColIO"], ["row_c2r_kernel"]]
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
-        keys = [["FastGenColIOT<0, 0, 0>", "FastGenColIOT<0, 1, 0>"], ["PlainColIO"], ["row_c2r_kernel"]][dom]
-        if (nx, ny, nz) == (1024, 1024, 1024) and args.gpus == 1:
-            tot = 0.0
-            for name, v in tj["kernels"].items():
-                if any(k in name for k in keys):
-                    tot += v["total"]
-            if tot > 0:
-                traffic = tot
-                traffic_source = "NOT measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes committed as %s" % (tj.get("source") or tj.get("note") or "profiles/traffic_latest.json")
-    except Exception:
-        traffic = None
+    except Exception as e:                               # no committed profile: say so instead of a silent null
+        tj, traffic_source = None, "profiles/traffic_latest.json not readable (%s)" % e
+    if tj is not None:
+        if (nx, ny, nz) == tuple(tj.get("grid", (1024, 1024, 1024))) and args.gpus == 1:
+            for i, k in enumerate(("x", "y", "z")):
+                tot = sum(v["total"] for name, v in tj["kernels"].items() if any(key in name for key in keys[i]))
+                pass_traffic[k] = tot if tot > 0 else None
+            traffic = pass_traffic[("x", "y", "z")[dom]]
+            src = tj.get("source") or tj.get("note") or "profiles/traffic_latest.json"
+            traffic_source = ("NOT measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes committed as %s" % src if traffic
+                              else "no kernel of %s matched %r" % (src, keys[dom]))
+            if traffic and tj.get("yz_slabs") not in (None, nslab):
+                traffic_source += " (taken with %s y / z launches per realisation, this run has %d)" % (tj.get("yz_slabs"), nslab)
+        else:
+            traffic_source = "the committed PMC passes are for a %s grid on one GPU, not this run's" % (tj.get("grid", [1024, 1024, 1024]),)
     out = {
         "metric": "Mcells/s for N^3 delta(x) realisation",
         "value": round(cells * args.steps / wall / 1e6, 1),
@@ -343,12 +352,18 @@ def main():
                      "kernel_ms": {"x": round(float(kern[0]), 4), "y": round(float(kern[1]), 4),
                                    "z": round(float(kern[2]), 4), "reduce": round(float(kern[3]), 4),
                                    "x_kz0_tiles": round(float(kern[4]), 4)},
+                     "kernel_ms_note": "HIP-event intervals around each pass of EAGER realisations in this process (they include the "
+                                       "launch gaps, and y / z are the sums over their %d launches of %d x planes): their sum is "
+                                       "larger than ms_per_step, which is the graph replay" % (nslab, slab_planes),
+                     "launches_per_realisation": {"x": 2, "y": nslab, "z": nslab, "reduce": 1},
+                     "traffic_bytes_per_launch": pass_traffic,
                      "pass_frac_of_hbm_peak": {k: round(alg[i] / (pass_ms[i] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                                                for i, k in enumerate(("x", "y", "z"))}},
         "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "traffic_source": traffic_source,
-                     "algorithmic_bytes_per_launch": alg[dom], "avg_ms": round(float(pass_ms[dom]), 4),
+                     "algorithmic_bytes_per_launch": alg[dom] / launches[dom], "avg_ms": round(float(pass_ms[dom]) / launches[dom], 5),
+                     "launches_per_realisation": launches[dom],
                      "whole_pipeline_frac": round(5 * sweep * args.steps / wall / 1e9 / HBM_PEAK_GBS, 4)},
     }
     out["config"]["parity"] = ("native stream = this repo's own definition (no reference counterpart): the kernel instantiations "

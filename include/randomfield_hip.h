@@ -182,6 +182,10 @@ int rf_elapsed_ms(rf_plan* plan, float* ms);
 /* GPU time of each kernel of the last rf_realise, 5 floats: x pass (main kernel), y pass, z pass, reduce,
  * and the small x-pass launch that repairs the kz = 0 tiles (0 when the x pass is a single launch) */
 int rf_kernel_ms(rf_plan* plan, float* ms5);
+/* (when the y and z passes run slab by slab -- RF_FLAG_YZ_SLAB_PLANES -- ms5[1] and ms5[2] are the sums over their launches)
+ * How the y / z passes of this plan are launched: *nslab launches each, over *planes x planes (1 and nx: whole-grid passes).
+ * No reference counterpart: the reference's FFT is one library call (transform.py:303-315). */
+int rf_yz_slabs(rf_plan* plan, int* nslab, int* planes);
 
 /* ---- multi-GPU: one process per GPU, RCCL all-to-all between the y and z passes.
  * The 128-byte unique id comes from rank 0 and is distributed by the host

@@ -71,6 +71,7 @@ SIGNATURES = {
     "rf_sync": (ctypes.c_int, [ctypes.c_void_p]),
     "rf_elapsed_ms": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]),
     "rf_kernel_ms": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]),
+    "rf_yz_slabs": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "rf_comm_unique_id": (ctypes.c_int, [ctypes.c_void_p]),
     "rf_comm_init": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "rf_comm_allreduce_f64": (ctypes.c_int, [ctypes.c_void_p, _c_dp, ctypes.c_int, ctypes.c_int]),
@@ -461,6 +462,12 @@ class DevicePlan(object):
         ms = ctypes.c_float()
         check(self._lib.rf_elapsed_ms(self._h, ctypes.byref(ms)), "rf_elapsed_ms")
         return ms.value
+
+    def yz_slabs(self):
+        """(launches, x planes per launch) of the y and z passes (rf_yz_slabs)."""
+        n, b = ctypes.c_int(), ctypes.c_int()
+        check(self._lib.rf_yz_slabs(self._h, ctypes.byref(n), ctypes.byref(b)), "rf_yz_slabs")
+        return n.value, b.value
 
     def kernel_ms(self):
         ms = (ctypes.c_float * 5)()      # x (main kernel), y, z, reduce, x kz=0 repair launch

@@ -489,19 +489,22 @@ int slab_batch(rf_plan* p, const uint64_t* seeds, int n) {
 
 // x planes per slab of the y / z passes of a single-rank plan (0: whole-grid passes).  The y pass of a slab leaves it in the
 // 256 MiB Infinity Cache for the z pass that follows at once; slabs much smaller than the cache make the launches too small
-// (1024^3 float32, MI355X: 4.85 ms whole grid, 4.56 ms with 64-plane = 256 MiB slabs, 4.79 ms with 32, 5.6 ms with 16).
+// (1024^3 float32, MI355X, 20 realisations per graph: 4.74 ms whole grid, 4.53-4.57 ms with 64-plane = 256 MiB slabs, 4.66 with 56,
+// 4.70 with 72 ... 128, 4.74 with 48, 5.6 ms with 16; 2048^3: 44.5 -> 43.7-43.9 ms; 512^3: 0.545 -> 0.537 ms).
 int yz_slab_planes(const rf_plan* p) {
   if (p->nranks > 1 || p->force_slab || p->generic || p->unpacked || p->yz_slab == 0) return 0;
   const long long plane = (long long)p->ny * p->nzl * (long long)p->csize;
   long long B = p->yz_slab;
   if (B < 0) {
+    if (p->f64) return 0;      // float64 passes: within 1 % of the whole-grid launches at every slab size measured (9.32-9.53 against 9.41 ms)
     static const long long target = [] { const char* e = getenv("RF_YZ_SLAB_MB"); return (e && atoll(e) > 0 ? atoll(e) : 256LL) << 20; }();
     B = 1;
     while (2 * B * plane <= target) B *= 2;
   }
-  if (B >= p->nx || p->nx % B) return 0;
-  // whole z-pass workgroups per slab, at the offsets the whole-grid launch would give them
-  if (row_c2r_tiles(p->f64, (int)p->nzc, B * p->ny) * (p->nx / B) != p->npartials) return 0;
+  if (B >= p->nx) return 0;
+  // whole z-pass workgroups per slab (the last slab may be smaller), at the offsets the whole-grid launch would give them
+  const long long tiles1 = row_c2r_tiles(p->f64, (int)p->nzc, p->ny);
+  if (tiles1 <= 0 || tiles1 * p->nx != p->npartials) return 0;
   return (int)B;
 }
 
@@ -515,23 +518,24 @@ int queue_yz(rf_plan* p, void* W, hipStream_t s, double* stats_out, bool timed) 
   const long long rb = xpose_row_block(p), tc = col_tile_cols(p->f64, p->ny);
   const ColGeom gy = xp ? xblock_y_geom(p->nx, p->ny, nzl, tc, rb) : ColGeom{nzl, (long long)p->ny * nzl, nzl};
   long long B = yz_slab_planes(p);
-  if (xp && B > 0 && B % rb) B = 0;                          // a slab of X is whole x blocks
+  if (xp && B > 0 && (B % rb || (B & (B - 1)) || p->nx % B)) B = 0;      // a slab of X is whole x blocks, a power of two of them
   if (B <= 0) B = p->nx;
-  const int nslab = (int)(p->nx / B);
-  const long long plane = (long long)p->ny * nzl * (long long)p->csize, tiles_per_slab = p->npartials / nslab;
+  const int nslab = (int)((p->nx + B - 1) / B);
+  const long long plane = (long long)p->ny * nzl * (long long)p->csize, tiles_per_plane = p->npartials / p->nx;
   if (timed) {
     while ((int)p->slab_ev.size() < 2 * nslab) { hipEvent_t e; RF_HIP(hipEventCreate(&e)); p->slab_ev.push_back(e); }
     p->slab_timed = nslab;
   }
   for (int i = 0; i < nslab; ++i) {
-    char* Ws = (char*)W + (long long)i * B * plane;
-    char* Xs = xp ? (char*)p->X + (long long)i * B * plane : nullptr;        // (x blocks are contiguous and as large as their planes)
-    if (xp) RF_HIP(launch_col_xpose(p->f64, p->ny, Xs, gy, Xs, gy, B * nzl, p->tw_y, s));
-    else RF_HIP(launch_col_plain(p->f64, p->ny, +1, Ws, gy, B * nzl, p->tw_y, s));
+    const long long x0 = (long long)i * B, nb = x0 + B <= p->nx ? B : p->nx - x0;      // planes [x0, x0 + nb)
+    char* Ws = (char*)W + x0 * plane;
+    char* Xs = xp ? (char*)p->X + x0 * plane : nullptr;        // (x blocks are contiguous and as large as their planes)
+    if (xp) RF_HIP(launch_col_xpose(p->f64, p->ny, Xs, gy, Xs, gy, nb * nzl, p->tw_y, s));
+    else RF_HIP(launch_col_plain(p->f64, p->ny, +1, Ws, gy, nb * nzl, p->tw_y, s));
     if (timed) RF_HIP(hipEventRecord(p->slab_ev[2 * i], s));
-    double* part = p->partials + 2 * i * tiles_per_slab;
-    if (xp) RF_HIP(launch_row_c2r_xgather(p->f64, (int)p->nzc, Xs, Ws, B * p->ny, scale, (int)tc, (int)rb, p->ny, p->tw_z, part, s));
-    else RF_HIP(launch_row_c2r(p->f64, (int)p->nzc, Ws, B * p->ny, scale, p->tw_z, part, s));
+    double* part = p->partials + 2 * x0 * tiles_per_plane;
+    if (xp) RF_HIP(launch_row_c2r_xgather(p->f64, (int)p->nzc, Xs, Ws, nb * p->ny, scale, (int)tc, (int)rb, p->ny, p->tw_z, part, s));
+    else RF_HIP(launch_row_c2r(p->f64, (int)p->nzc, Ws, nb * p->ny, scale, p->tw_z, part, s));
     if (timed) RF_HIP(hipEventRecord(p->slab_ev[2 * i + 1], s));
   }
   if (timed) { RF_HIP(hipEventRecord(p->ev[2], s)); RF_HIP(hipEventRecord(p->ev[3], s)); }   // (rf_kernel_ms sums the slab events)
@@ -1413,6 +1417,16 @@ int rf_kernel_ms(rf_plan* p, float* ms5) {
     RF_HIP(hipEventElapsedTime(&ms5[4], p->ev[0], p->ev[5]));
     RF_HIP(hipEventElapsedTime(&ms5[0], p->ev[5], p->ev[1]));
   }
+  return 0;
+}
+
+int rf_yz_slabs(rf_plan* p, int* nslab, int* planes) {
+  RF_REQUIRE(p && nslab && planes, "null argument");
+  RF_REQUIRE(!p->unpacked, "this call does not apply to an unpacked c2c plan");
+  long long B = yz_slab_planes(p);
+  if (p->X && xpose_ok(p) && B > 0 && (B % xpose_row_block(p) || (B & (B - 1)) || p->nx % B)) B = 0;
+  *planes = B > 0 ? (int)B : p->nxl;
+  *nslab = B > 0 ? (int)((p->nx + B - 1) / B) : 1;
   return 0;
 }
 

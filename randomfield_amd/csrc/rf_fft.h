@@ -502,11 +502,27 @@ struct ColFFT {
   RF_HD static void* lds_io(cx* lds) { return lds + (C::TILE_BYTES + C::TW_BYTES) / (int)sizeof(cx); }
   static constexpr bool HAS_PROLOGUE = (C::NPASS >= 2) || (IO::LDS_EXTRA > 0);
 
-  // prologue: stage the twiddle table (and the IO's own tables) in LDS; a barrier follows
+  // The twiddle table goes global -> registers at the very start of the kernel (tw_fetch: loads issued, not waited for) and
+  // registers -> LDS after pass 1 (tw_stage), in front of the barrier that precedes its first use: its trip to L2 / HBM runs
+  // under pass 1 instead of in front of it (two dependent round trips per workgroup before the first useful instruction).
+  static constexpr int TWPT = (C::NPASS >= 2 ? ceil_div(N, C::NT) : 0);      // table entries per thread
+  struct TwRegs { cx v[cmax(TWPT, 1)]; };
+  RF_HD static void tw_fetch(int tid, const cx* tw, TwRegs& t) {
+#pragma unroll
+    for (int k = 0; k < TWPT; ++k) t.v[k] = tw[(tid + k * C::NT) & (N - 1)];       // (N is a power of two: no branch, no undefined slot)
+  }
+  RF_HD static void tw_stage(int tid, cx* lds, const TwRegs& t) {
+    cx* l = lds_tw(lds);
+#pragma unroll
+    for (int k = 0; k < TWPT; ++k)
+      if (tid + k * C::NT < N) l[tid + k * C::NT] = t.v[k];
+  }
+  // prologue (emulator; the kernels call the pieces): stage the twiddle table and the IO's own tables in LDS; a barrier follows
   RF_HD static void prologue(int tid, IO& io, const cx* tw, cx* lds) {
     if (C::NPASS >= 2) {
-      cx* l = lds_tw(lds);
-      for (int i = tid; i < N; i += C::NT) l[i] = tw[i];
+      TwRegs t;
+      tw_fetch(tid, tw, t);
+      tw_stage(tid, lds, t);
     }
     io.prologue(tid, C::NT, lds_io(lds));
   }
@@ -802,10 +818,26 @@ struct RowC2R {
 
   RF_HD static cx* lds_at(cx* lds, int rl, int i) { return lds + (long long)rl * C::RS + pad16(i); }
   RF_HD static cx* lds_tw(cx* lds) { return lds + C::TILE_BYTES / (int)sizeof(cx); }
-  // prologue: stage the twiddle table in LDS (a barrier follows)
-  RF_HD static void prologue(int tid, const cx* tw, cx* lds) {
+  // The twiddle table (needed by pass 1 already: the untangle) goes global -> registers (tw_fetch), then the row data
+  // (pass_first_load), then registers -> LDS (tw_stage) and a barrier: both trips to memory are in flight together, and the
+  // older one -- the small table -- is the one that is waited for first (loads retire in order).
+  static constexpr int TWPT = ceil_div(2 * M, NT);
+  struct TwRegs { cx v[TWPT]; };
+  RF_HD static void tw_fetch(int tid, const cx* tw, TwRegs& t) {
+#pragma unroll
+    for (int k = 0; k < TWPT; ++k) t.v[k] = tw[(tid + k * NT) & (2 * M - 1)];       // (M is a power of two: no branch, no undefined slot)
+  }
+  RF_HD static void tw_stage(int tid, cx* lds, const TwRegs& t) {
     cx* l = lds_tw(lds);
-    for (int i = tid; i < 2 * M; i += NT) l[i] = tw[i];
+#pragma unroll
+    for (int k = 0; k < TWPT; ++k)
+      if (tid + k * NT < 2 * M) l[tid + k * NT] = t.v[k];
+  }
+  // prologue (emulator; the kernel calls the pieces): stage the twiddle table in LDS (a barrier follows)
+  RF_HD static void prologue(int tid, const cx* tw, cx* lds) {
+    TwRegs t;
+    tw_fetch(tid, tw, t);
+    tw_stage(tid, lds, t);
   }
 
   // pass 1 outputs: LDS (NPASS > 1) or global (NPASS == 1)
@@ -818,23 +850,48 @@ struct RowC2R {
     }
   }
 
-  // pass 1: global -> untangle -> R1 butterflies of the mirror pair -> LDS
-  RF_HD static void pass_first(int tid, long long tile, long long nrows, const IO& io, const cx* tw, cx* lds, Regs& r) {
+  // which (row of the tile, butterfly pair) thread `w` of pass 1 owns
+  RF_HD static void first_owner(int w, const IO& io, int& rl, int& q) {
+    rl = w / C::TPR1;
+    q = w % C::TPR1;
+    // gathering IO: 2^sg consecutive k of a row are one segment of the source and the segments of the tile's NRT rows are
+    // adjacent, so thread w takes k-in-segment = w % 2^sg, row = (w >> sg) % NRT, segment = w / (NRT 2^sg): a wave's loads
+    // then cover whole chunks of NRT segments instead of one segment in each of many blocks
+    const int sg = io.gather_seg_shift();
+    if (sg >= 0 && C::TPR1 % (1 << sg) == 0) {
+      rl = (w >> sg) % C::NRT;
+      q = ((w >> sg) / C::NRT << sg) + (w & ((1 << sg) - 1));
+      if (q >= C::TPR1) rl = C::NRT;         // (threads beyond NRT * TPR1: idle, as in the plain mapping)
+    }
+  }
+  struct In { cx A[C::IT1][C::R1], B[C::IT1][C::R1]; };
+  // pass 1, first half: the mirror pair's inputs global -> registers
+  RF_HD static void pass_first_load(int tid, long long tile, long long nrows, const IO& io, In& in) {
+    constexpr int R = C::R1, L = C::L1;
+#pragma unroll
+    for (int it = 0; it < C::IT1; ++it) {
+      int rl, q;
+      first_owner(it * NT + tid, io, rl, q);
+      const long long row = tile * C::NRT + rl;
+      if (rl < C::NRT && row < nrows) {
+        const int ja = q, jb = (q == 0) ? L / 2 : L - q;
+#pragma unroll
+        for (int m = 0; m < R; ++m) in.A[it][m] = io.template load2<C::NRT>(tile, rl, ja, m * L);
+        if (L >= 2) {
+#pragma unroll
+          for (int m = 0; m < R; ++m) in.B[it][m] = io.template load2<C::NRT>(tile, rl, jb, m * L);
+        }
+      }
+    }
+  }
+  // pass 1, second half: untangle -> R1 butterflies of the mirror pair -> LDS
+  RF_HD static void pass_first_compute(int tid, long long tile, long long nrows, const IO& io, const cx* tw, cx* lds, Regs& r, const In& in) {
     constexpr int R = C::R1, L = C::L1;
     r.s1 = 0; r.s2 = 0;
 #pragma unroll
     for (int it = 0; it < C::IT1; ++it) {
-      const int w = it * NT + tid;
-      int rl = w / C::TPR1, q = w % C::TPR1;
-      // gathering IO: 2^sg consecutive k of a row are one segment of the source and the segments of the tile's NRT rows are
-      // adjacent, so thread w takes k-in-segment = w % 2^sg, row = (w >> sg) % NRT, segment = w / (NRT 2^sg): a wave's loads
-      // then cover whole chunks of NRT segments instead of one segment in each of many blocks
-      const int sg = io.gather_seg_shift();
-      if (sg >= 0 && C::TPR1 % (1 << sg) == 0) {
-        rl = (w >> sg) % C::NRT;
-        q = ((w >> sg) / C::NRT << sg) + (w & ((1 << sg) - 1));
-        if (q >= C::TPR1) rl = C::NRT;         // (threads beyond NRT * TPR1: idle, as in the plain mapping)
-      }
+      int rl, q;
+      first_owner(it * NT + tid, io, rl, q);
       const long long row = tile * C::NRT + rl;
       if (rl < C::NRT && row < nrows) {
         const bool self = (q == 0);
@@ -843,11 +900,7 @@ struct RowC2R {
         const bool has_b = (L >= 2);
         cx A[R], B[R], ZA[R], ZB[R];
 #pragma unroll
-        for (int m = 0; m < R; ++m) A[m] = io.template load2<C::NRT>(tile, rl, ja, m * L);
-        if (has_b) {
-#pragma unroll
-          for (int m = 0; m < R; ++m) B[m] = io.template load2<C::NRT>(tile, rl, jb, m * L);
-        }
+        for (int m = 0; m < R; ++m) { A[m] = in.A[it][m]; B[m] = in.B[it][m]; }
 #pragma unroll
         for (int m = 0; m < R; ++m) {
           const cx ta = tw[ja + m * L];
@@ -870,6 +923,12 @@ struct RowC2R {
         }
       }
     }
+  }
+  // pass 1: global -> untangle -> R1 butterflies of the mirror pair -> LDS
+  RF_HD static void pass_first(int tid, long long tile, long long nrows, const IO& io, const cx* tw, cx* lds, Regs& r) {
+    In in;
+    pass_first_load(tid, tile, nrows, io, in);
+    pass_first_compute(tid, tile, nrows, io, tw, lds, r, in);
   }
 
   RF_HD static void pass_mid_read(int tid, const cx* tw, cx* lds, Regs& r) {

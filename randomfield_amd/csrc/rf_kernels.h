@@ -40,12 +40,17 @@ __global__ __launch_bounds__(C::NT, (col_min_waves<C, IO>())) void col_kernel(IO
   tile = io.remap_tile(tile);                                                     // (identity except for XposeColIO)
   const cx* ltw = tw;
   io.bind_seed();
-  if (F::HAS_PROLOGUE) {
-    F::prologue(tid, io, tw, lds);          // twiddles (+ the IO's tables) -> LDS
-    if (C::NPASS >= 2) ltw = F::lds_tw(lds);
-    if (IO::LDS_EXTRA > 0) __syncthreads(); // pass 1 reads the IO tables; the twiddles are first read after the next barrier
+  typename F::TwRegs twr;
+  if (IO::LDS_EXTRA > 0) {
+    io.prologue(tid, C::NT, F::lds_io(lds));          // the IO's tables -> LDS: pass 1 reads them
+    __syncthreads();
   }
+  if (C::NPASS >= 2) F::tw_fetch(tid, tw, twr);       // twiddles global -> registers: issued here, landed under pass 1
   F::pass_first(tid, tile, io, lds);
+  if (C::NPASS >= 2) {
+    F::tw_stage(tid, lds, twr);                       // -> LDS, in front of the barrier that precedes their first use
+    ltw = F::lds_tw(lds);
+  }
   if (C::NPASS == 3) {
     typename F::Regs r;
     __syncthreads();
@@ -75,10 +80,22 @@ __global__ __launch_bounds__(C::NT) void row_c2r_kernel(IO io, const cplx<typena
 #endif
   const long long tile = RF_Z_REVERSE ? (long long)gridDim.x - 1 - blockIdx.x : (long long)blockIdx.x;
   typename F::Regs r;
-  F::prologue(tid, tw, lds);                 // twiddles -> LDS
+  typename F::TwRegs twr;
   const cx* ltw = F::lds_tw(lds);
-  __syncthreads();
-  F::pass_first(tid, tile, nrows, io, ltw, lds, r);
+  F::tw_fetch(tid, tw, twr);                 // twiddles global -> registers
+  if constexpr (sizeof(typename C::T) == 4) {
+    // ... then the rows global -> registers: both trips to memory in flight together; the (older) table loads are waited for first
+    typename F::In in;
+    F::pass_first_load(tid, tile, nrows, io, in);
+    F::tw_stage(tid, lds, twr);              // twiddles -> LDS
+    __syncthreads();
+    F::pass_first_compute(tid, tile, nrows, io, ltw, lds, r, in);
+  } else {
+    // (float64: holding the 16 complex128 inputs across the barrier spills -- 72 / 136 bytes of scratch; one trip after the other)
+    F::tw_stage(tid, lds, twr);
+    __syncthreads();
+    F::pass_first(tid, tile, nrows, io, ltw, lds, r);
+  }
   if (C::NPASS == 3) {
     __syncthreads();
     F::pass_mid_read(tid, ltw, lds, r);

@@ -1252,3 +1252,42 @@ def test_reference_stream_float32_copies(hip, dpower):
     assert np.max(np.abs(_slab_side_array(plans, slab_pot, nz // 2) - kref / k2)) <= 2e-6 * np.max(np.abs(kref / k2))
     for p in plans:
         p.close()
+
+
+@pytest.mark.parametrize("shape,dtype", [((256, 256, 256), np.complex64), ((512, 512, 512), np.complex64), ((1024, 1024, 64), np.complex64),
+                                         ((64, 2048, 128), np.complex64), ((2048, 64, 256), np.complex64), ((128, 128, 256), np.complex128),
+                                         ((1024, 16, 2048), np.complex128), ((512, 256, 1024), np.complex64)])
+def test_slabs_and_blocked_intermediate_only_move_data(hip, dpower, shape, dtype):
+    """The y / z passes slab by slab (RF_FLAG_YZ_SLAB_PLANES) and the blocked intermediate of the x pass (RF_FLAG_TRANSPOSED_INTERMEDIATE:
+    contiguous x-pass chunks, y pass in place on them, gathering z pass) change where data sits between the passes, not the
+    field (slabs: not one bit of it): native realisation, uploaded k space and the graph-replayed batch against the whole-grid in-place passes."""
+    k, Pk = dpower
+    nx, ny, nz = shape
+    plan = make_plan(hip, shape, dtype, k, Pk)
+    rng = np.random.RandomState(5)
+    ks = (rng.normal(size=(nx, ny, nz // 2 + 1)) + 1j * rng.normal(size=(nx, ny, nz // 2 + 1))).astype(dtype)
+    cpu_ref.symmetrize_packed(ks)
+    seeds = np.array([11, 12, 13], np.uint64)
+    res = {}
+    for xp, planes in ((0, 0), (0, -1), (0, max(1, nx // 4)), (1, 0), (1, max(1, nx // 4)), (1, -1), (0, max(1, nx // 16))):
+        plan.set_transposed_intermediate(bool(xp))
+        plan.set_yz_slab_planes(planes)
+        plan.realise(seed=99)
+        a = plan.download_real()
+        ma = plan.moments()
+        plan.upload_k(ks)
+        plan.execute_c2r()
+        b = plan.download_real()
+        rms = plan.realise_batch(seeds)
+        c = plan.download_real()
+        res[(xp, planes)] = (a, b, c, ma, rms)
+    a0, b0, c0, m0, r0 = res[(0, 0)]
+    assert np.max(np.abs(b0 - np.fft.irfftn(ks.astype(np.complex128), s=shape, axes=(0, 1, 2)))) <= (2e-5 if dtype == np.complex64 else 1e-12) * b0.std()
+    for key, (a, b, c, ma, rms) in res.items():
+        if key[0] == 0:          # slabs: the same kernels on sub-ranges
+            assert np.array_equal(a, a0) and np.array_equal(b, b0) and np.array_equal(c, c0), key
+        else:                    # blocked intermediate: the same arithmetic in other kernel instantiations (the compiler may
+            for u, v in ((a, a0), (b, b0), (c, c0)):                       # contract a few multiply-adds differently)
+                assert np.max(np.abs(u - v)) <= (1e-6 if dtype == np.complex64 else 1e-14) * v.std(), key
+        assert abs(ma[1] - m0[1]) <= 1e-9 * m0[1] and np.max(np.abs(rms - r0)) <= 1e-9 * r0.max(), key
+    plan.close()

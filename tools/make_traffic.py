@@ -2,7 +2,7 @@
 """Turn the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs) into per-kernel HBM
 bytes per launch, with the gfx950 corrections of MI355X_MICROARCH.md (HBM section): both counters are in
 KiB; FETCH_SIZE reports exactly half of the bytes of wide (16 B/lane) coalesced reads, so it is doubled.
-usage: tools/make_traffic.py <fetch.csv> <write.csv> <out.json> [note]"""
+usage: tools/make_traffic.py <fetch.csv> <write.csv> <out.json> [note] [y/z launches per realisation]"""
 import collections
 import csv
 import json
@@ -28,6 +28,7 @@ def main():
         commit = "unknown"
     out = {"note": note, "source": "profiles/traffic_latest.json (%s) @ commit %s" % (note, commit), "unit": "bytes per launch",
            "correction": "read = 2 * FETCH_SIZE * 1024 (gfx950 wide-read under-count), write = WRITE_SIZE * 1024",
+           "grid": [1024, 1024, 1024], "yz_slabs": int(sys.argv[5]) if len(sys.argv) > 5 else None,
            "kernels": {}}
     for k in sorted(set(fetch) | set(write)):
         if "rf::" not in k:
