@@ -1,13 +1,23 @@
 #!/bin/bash
 # usage (on the GPU box, from the repo root): bash tools/profile_round.sh <tag>
-# bench line + rocprofv3 kernel stats + the two PMC passes (separate runs) -> gpurun_out/prof_<tag>/
+# bench line + rocprofv3 kernel stats + the two PMC passes (separate runs) + SQ counters -> gpurun_out/prof_<tag>/
 set -e
 tag=${1:-x}
 out=gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
-python3 bench.py --steps 10 --warmup 2 > $out/bench.json
-rocprofv3 --kernel-trace --stats -d $out/stats -o stats --output-format csv -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-other-configs > $out/bench_stats_run.json
+python3 bench.py --steps 20 --warmup 5 > $out/bench.json
+rocprofv3 --kernel-trace --stats -d $out/stats -o stats --output-format csv -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs > $out/bench_stats_run.json
 rocprofv3 --pmc FETCH_SIZE -d $out/fetch -o fetch --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs > /dev/null
 rocprofv3 --pmc WRITE_SIZE -d $out/write -o write --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs > /dev/null
-find $out -name "*.csv" | head -20
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT -d $out/sqa -o a --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs > /dev/null
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_WAVES -d $out/sqb -o b --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs > /dev/null
+python3 tools/pmc_summary.py $(find $out/sqa -name "*counter_collection.csv") > $out/pmc_sq_a.txt
+python3 tools/pmc_summary.py $(find $out/sqb -name "*counter_collection.csv") > $out/pmc_sq_b.txt
+python3 tools/pmc_summary.py $(find $out/fetch -name "*counter_collection.csv") > $out/pmc_fetch_size.txt
+python3 tools/pmc_summary.py $(find $out/write -name "*counter_collection.csv") > $out/pmc_write_size.txt
+nslab=$(python3 -c "import json;print(json.load(open('$out/bench.json'))['pipeline']['launches_per_realisation']['y'])")
+python3 tools/make_traffic.py $(find $out/fetch -name "*counter_collection.csv") $(find $out/write -name "*counter_collection.csv") $out/traffic.json "$tag" $nslab > $out/traffic.txt
+cp $(find $out/stats -name "*kernel_stats.csv") $out/kernel_stats.csv
+rm -rf $out/fetch $out/write $out/sqa $out/sqb $out/stats
+ls $out
