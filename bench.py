@@ -166,6 +166,10 @@ def main_multi(args, rank, world, local_rank, shape, power, spacing):
     nx, ny, nz = shape
     dplan = slab.DistributedPlan(nx, ny, nz, np.complex64, device=local_rank, rank=rank, world=world)
     plan = dplan.plan
+    if world == 1:        # --force-multi on one GPU (tests): the slab pipeline with a one-rank communicator, the exchange = a copy
+        from randomfield_amd import _hip
+        plan.set_force_slab_path(True)
+        plan.comm_init(_hip.DevicePlan.comm_unique_id())
     plan.set_kgrid(*powertools.ksq_axes(nx, ny, nz, spacing))
     plan.set_power(*powertools.sigma_table(power, (nx, ny, nz), spacing))
     # Two ways to run the slab decomposition: "exchange" = kz slabs + ONE RCCL all-to-all, pipelined
@@ -174,6 +178,10 @@ def main_multi(args, rank, world, local_rank, shape, power, spacing):
     # links the job spans (2 GPUs share ONE link): measure both on a few realisations and take the faster.
     mode = os.environ.get("RANDOMFIELD_MULTI_MODE", "auto")
     calib = {}
+    with dplan.deadline("first exchange"):            # a rank that died leaves the others blocked in the grouped send / receive: bounded
+        plan.realise(seed=998)
+        plan.sync()
+        dplan.barrier()
     if world > 1 and mode == "auto":
         for m in ("exchange", "replicate"):
             try:

@@ -240,12 +240,22 @@ class DevicePlan(object):
         if (len(kx2), len(ky2), len(kz2)) != (self.nx, self.ny, self.nz // 2 + 1):
             raise ValueError("k-grid tables have the wrong lengths")
         check(self._lib.rf_set_kgrid(self._h, _dp(kx2), _dp(ky2), _dp(kz2)), "rf_set_kgrid")
+        self._power_key = None
 
-    def set_power(self, log10k, sigma):
+    def set_power(self, log10k, sigma, if_changed=False):
+        """Upload the (log10 k, sigma) tables.  ``if_changed=True`` skips the upload (a stream sync and a table rebuild) when
+        these are the tables this plan holds already -- whoever uploaded them: the key lives with the device plan, so a
+        caller that changes the tables through ``plan.device`` is seen by every other user of the plan."""
         log10k, sigma = _f64(log10k), _f64(sigma)
         if log10k.shape != sigma.shape or log10k.ndim != 1:
             raise ValueError("log10k and sigma must be 1-D arrays of equal length")
+        key = (log10k.tobytes(), sigma.tobytes())
+        if if_changed and key == getattr(self, "_power_key", None):
+            return False
+        self._power_key = None
         check(self._lib.rf_set_power(self._h, _dp(log10k), _dp(sigma), len(log10k)), "rf_set_power")
+        self._power_key = key
+        return True
 
     # -- generation / transforms -----------------------------------------
     # -- the reference's noise stream generated on the GPU --------------------

@@ -476,8 +476,15 @@ int slab_batch(rf_plan* p, const uint64_t* seeds, int n) {
       RF_HIP(hipEventRecord(ev_z[pb], A));
     }
   }
-  if (p->nranks > 1)
-    RF_NCCL(g_rccl.AllReduce(p->stats, p->stats, 2 * (size_t)n, ncclFloat64, ncclSum, p->comm, A));
+  if (p->nranks > 1) {
+    // ONE communicator is only ever driven from ONE stream inside a batch: the moments' all-reduce goes to the exchange
+    // stream too, behind the last z pass (event), and the compute stream waits for it
+    const int lb = (n - 1) & 1;
+    RF_HIP(hipStreamWaitEvent(C, ev_z[lb], 0));
+    RF_NCCL(g_rccl.AllReduce(p->stats, p->stats, 2 * (size_t)n, ncclFloat64, ncclSum, p->comm, C));
+    RF_HIP(hipEventRecord(ev_exch[lb], C));
+    RF_HIP(hipStreamWaitEvent(A, ev_exch[lb], 0));
+  }
   RF_HIP(hipEventRecord(p->ev[4], A));
   p->cur = Wb[(n - 1) & 1];
   p->stats_slot = n - 1;
@@ -792,6 +799,9 @@ int rf_plan_create_c2c(rf_plan** out, int nx, int ny, int nz, int dtype, int dev
   for (auto& ev : p->ev)
     if ((e = hipEventCreate(&ev)) != hipSuccess) return cleanup(fail(2, std::string("hipEventCreate: ") + hipGetErrorString(e)));
   const ColGeom gx{(long long)ny * nz, 0, (long long)ny * nz}, gy{nz, (long long)ny * nz, nz};
+  if (!generic && (!col_plain_addressable(dtype, nx, gx) || !col_plain_addressable(dtype, ny, gy)))
+    return cleanup(fail(1, "unsupported shape for a c2c plan: an axis shorter than 1024 with rows more than 4 GiB apart "
+                           "(32-bit lane offsets); make that axis >= 1024 or the others smaller"));
   for (int dir = -1; dir <= 1 && !generic; dir += 2)
     if ((e = launch_row_c2c(dtype, nz, dir, p->W, (long long)nx * ny, 1.0, p->tw_z, p->stream, true)) != hipSuccess ||
         (e = launch_col_plain(dtype, ny, dir, p->W, gy, (long long)nx * nz, p->tw_y, p->stream, true)) != hipSuccess ||
@@ -1552,6 +1562,14 @@ int rf_noise_mt19937_ex(rf_plan* p, const uint32_t* state624, unsigned long long
   RF_REQUIRE(total >= ncells, "MT19937 replay: not enough accepted polar attempts (increase the margin)");
   p->noise_resident = !single;
   p->noise32_resident = single != 0;
+  if (!single) {
+    // the runs are dead once the compaction has moved them into p->noise (the stream is idle here): give the memory back --
+    // 1.27x the noise buffer, 11 GB at 1024^3, the difference between fitting and not fitting a 2048^3 float64 plan with a
+    // saved potential into 288 GB.  (float32 deviates live IN the runs and keep them.)
+    RF_HIP(hipFree(p->mt_scratch));
+    p->mt_scratch = nullptr;
+    p->mt_scratch_bytes = 0;
+  }
   return 0;
 }
 
@@ -1604,6 +1622,7 @@ int rf_comm_allreduce_f64(rf_plan* p, double* inout, int n, int op) {
   RF_REQUIRE(op == 0 || op == 1, "op must be 0 (sum) or 1 (max)");
   RF_HIP(hipSetDevice(p->device));
   if (!p->comm) { RF_HIP(hipStreamSynchronize(p->stream)); return 0; }     // a one-rank communicator still runs the collective
+  if (p->comm_stream) RF_HIP(hipStreamSynchronize(p->comm_stream));          // (the communicator is used from one stream at a time)
   double* d = p->coll_scratch;            // its own two doubles: `stats` holds the moments of up to stats_cap realisations
   RF_HIP(hipMemcpyAsync(d, inout, n * sizeof(double), hipMemcpyHostToDevice, p->stream));
   RF_NCCL(g_rccl.AllReduce(d, d, n, ncclFloat64, op == 0 ? ncclSum : ncclMax, p->comm, p->stream));

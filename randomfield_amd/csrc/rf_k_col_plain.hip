@@ -24,7 +24,7 @@ hipError_t launch_t(int N, cplx<T>* base, ColGeom g, long long ncols, const cplx
 #define X(NN)                                                                                                    \
   case NN: {                                                                                                     \
     using C = typename ColSel<T, NN>::type;                                                                      \
-    if constexpr (NN == 2048 && sizeof(T) == 8) {               /* 64-bit lane offsets: float64, length 2048 */ \
+    if constexpr (NN >= 1024) {   /* 64-bit lane offsets: the long axes of the largest (unpacked c2c, float64) arrays */ \
       if (po || g.needs_wide(C::LMAX, C::TC, (int)sizeof(cplx<T>))) {                                            \
         PlainColIO<T, true> iow; iow.base = base; iow.g = g;                                                     \
         hipError_t e = launch_one<C, DIR, PlainColIO<T, true>>(iow, ncols, tw, s, po);                           \
@@ -69,6 +69,18 @@ hipError_t launch_col_xpose(int f64, int N, const void* src, ColGeom gs, void* d
                             hipStream_t s, bool po) {
   if (f64) return launch_xp<double>(N, (const cplx<double>*)src, gs, (cplx<double>*)dst, gd, ncols, (const cplx<double>*)tw, s, po);
   return launch_xp<float>(N, (const cplx<float>*)src, gs, (cplx<float>*)dst, gd, ncols, (const cplx<float>*)tw, s, po);
+}
+
+// can the strided pass of length N address this geometry?  (32-bit lane offsets everywhere; 64-bit ones exist for N >= 1024)
+bool col_plain_addressable(int f64, int N, ColGeom g) {
+  switch (N) {
+#define X(NN) case NN: { const int L = f64 ? ColSel<double, NN>::type::LMAX : ColSel<float, NN>::type::LMAX,               \
+                                   tc = f64 ? ColSel<double, NN>::type::TC : ColSel<float, NN>::type::TC;                    \
+                         return NN >= 1024 || !g.needs_wide(L, tc, f64 ? 16 : 8); }
+    RF_COL_SIZES(X)
+#undef X
+    default: return false;
+  }
 }
 
 int col_tile_cols(int f64, int N) {

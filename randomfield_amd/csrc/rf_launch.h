@@ -62,6 +62,7 @@ hipError_t launch_col_fastgen(int f64, int N, void* W, ColGeom g, long long ncol
                               const void* tw, hipStream_t s, bool prepare_only = false, hipEvent_t after_repair = nullptr,
                               int x0 = 0, int x1 = 1 << 30, void* pot = nullptr);
 // (pot != nullptr, float32 only: the pass also stores delta(k) / k^2 into the API-layout array `pot` -- generate.py:200-217)
+bool col_plain_addressable(int f64, int N, ColGeom g);   // false: the pass would need 64-bit lane offsets and has none (N < 1024)
 int col_tile_cols(int f64, int N);   // tile width (columns) of the strided pass of length N, 0 if unsupported
 // z pass of c2r: rows of M = nz/2 complex -> nz reals, scaled; partials[2*tile] = (sum, sumsq)
 hipError_t launch_row_c2r(int f64, int M, void* W, long long nrows, double scale, const void* tw,

@@ -108,7 +108,7 @@ class Generator(object):
         self.rng = rng
         if self.distributed:
             from . import slab
-            if (nx | ny | nz) & 1:
+            if nx % 2 or ny % 2 or nz % 2:
                 raise ValueError("All shape dimensions must be even.")
             self.plan_c2r = slab.SlabHostPlan(slab.DistributedPlan(nx, ny, nz, dtype), dtype)
             self.plan_r2c = None         # the forward transform is single-GPU (and the reference never executes this plan)
@@ -150,7 +150,6 @@ class Generator(object):
 
         self.delta_field_rms = None
         self.smoothed_power = None
-        self._device_table = None
         self._field_on_host = False
         if self.backend == "hip":
             dev = self.plan_c2r.device
@@ -222,10 +221,9 @@ class Generator(object):
         else:
             dev = self.plan_c2r.device
             log10_k, sigma = powertools.sigma_table(self.smoothed_power, (nx, ny, nz), self.grid_spacing_Mpc_h)
-            table = (log10_k.tobytes(), sigma.tobytes())
-            if table != self._device_table:      # same power and smoothing as last time: the device tables are current
-                dev.set_power(log10_k, sigma)     # (re-uploading them costs a stream sync and a table rebuild per call)
-                self._device_table = table
+            # same power and smoothing as the tables the device plan holds: nothing to upload (a stream sync and a table rebuild
+            # per call otherwise); the plan itself remembers what it was last given, whoever gave it
+            dev.set_power(log10_k, sigma, if_changed=True)
             if self.rng == "reference":
                 # RandomState(seed).normal (random.py:24): MT19937 + polar method replayed on the GPU from the seed's
                 # 624-word start state -- integer seeds, array seeds (init_by_array) and None alike; no host deviates

@@ -27,7 +27,35 @@ N, M_ = 624, 397
 DEGREE = 19937
 SEGMENT_BLOCKS = 1024                 # blocks of 624 words per segment
 SEGMENT_WORDS = SEGMENT_BLOCKS * N    # L: 638 976 words = 159 744 polar attempts per segment
-_CACHE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "mt19937_jump_L%d.npz" % SEGMENT_WORDS)
+_DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")      # shipped tables: read only
+
+
+def cache_dir():
+    """Where tables computed at run time are kept: $RANDOMFIELD_CACHE_DIR, else $XDG_CACHE_HOME/randomfield_amd, else
+    ~/.cache/randomfield_amd (never the installed package)."""
+    d = os.environ.get("RANDOMFIELD_CACHE_DIR") or os.path.join(
+        os.environ.get("XDG_CACHE_HOME") or os.path.join(os.path.expanduser("~"), ".cache"), "randomfield_amd")
+    return d
+
+
+def _load_polys(path, rows):
+    """a cached table, or None when it is missing, short or unreadable (e.g. half written by another rank: recomputed then)"""
+    try:
+        arr = np.load(path)["polys"]
+        return arr if arr.shape[0] >= rows and arr.shape[1] == N else None
+    except Exception:
+        return None
+
+
+def _save_polys(path, arr):
+    """atomic: temporary file in the same directory, then os.replace -- every rank of a job may get here at once"""
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        tmp = "%s.tmp%d.npz" % (path, os.getpid())
+        np.savez_compressed(tmp, polys=arr)
+        os.replace(tmp, path)
+    except OSError:
+        pass
 
 _UPPER, _LOWER, _MATRIX_A = 0x80000000, 0x7FFFFFFF, 0x9908B0DF
 
@@ -243,12 +271,14 @@ def power_of_t(J, phi, deg=DEGREE):
     return g
 
 
-def jump_polynomials(nlevels=20, cache=True):
+def jump_polynomials(nlevels=20, cache=True, path=None):
     """g_k = t^(SEGMENT_WORDS * 2^k) mod phi for k < nlevels, as a (nlevels, 624) uint32 array of
-    coefficient bits (word w, bit b = coefficient of t^(32 w + b)).  Cached next to the package data."""
-    if cache and os.path.exists(_CACHE):
-        arr = np.load(_CACHE)["polys"]
-        if arr.shape[0] >= nlevels:
+    coefficient bits (word w, bit b = coefficient of t^(32 w + b)): the binary jump tree of round 1, kept as an independent
+    check of the radix-16 tables (tests/test_mt19937_host.py, which passes its fixture as ``path``)."""
+    path = path or os.path.join(cache_dir(), "mt19937_jump_L%d.npz" % SEGMENT_WORDS)
+    if cache:
+        arr = _load_polys(path, nlevels)
+        if arr is not None:
             return arr[:nlevels]
     phi = characteristic_polynomial()
     g = power_of_t(SEGMENT_WORDS, phi)
@@ -258,10 +288,7 @@ def jump_polynomials(nlevels=20, cache=True):
         g = _mod(_square(g), phi, DEGREE)
     arr = np.stack(rows)
     if cache:
-        try:
-            np.savez_compressed(_CACHE, polys=arr)
-        except OSError:
-            pass
+        _save_polys(path, arr)
     return arr
 
 
@@ -270,9 +297,8 @@ WAVE_SLOTS = 4096                     # segments are sized for this many concurr
 _TREE_MEMO = {}
 
 
-def _tree_cache(segment_blocks):
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "data",
-                        "mt19937_tree_R%d_L%d.npz" % (TREE_RADIX, segment_blocks * N))
+def _tree_cache(segment_blocks, shipped=True):
+    return os.path.join(_DATA if shipped else cache_dir(), "mt19937_tree_R%d_L%d.npz" % (TREE_RADIX, segment_blocks * N))
 
 
 def segment_blocks_for(ncells, slots=WAVE_SLOTS):
@@ -291,19 +317,20 @@ def segment_blocks_for(ncells, slots=WAVE_SLOTS):
 def tree_polynomials(nstages=4, cache=True, segment_blocks=SEGMENT_BLOCKS):
     """The jump polynomials of the radix-16 tree over segments of ``segment_blocks`` blocks: row t*15 + (m-1) =
     t^(m * 16^t * L) mod phi, L = 624 * segment_blocks, m = 1 .. 15, as (nstages*15, 624) uint32 coefficient words.
-    4 stages reach 65 536 segments (1.0e10 polar attempts: a 2048^3 grid needs 35 000).  Cached next to the package
-    data (shipped for the segment lengths of 1024^3 and 2048^3 grids) and per process; built in ~0.2 s per
-    polynomial otherwise."""
+    4 stages reach 65 536 segments (1.0e10 polar attempts: a 2048^3 grid needs 35 000).  Shipped in the package data for
+    the segment lengths of 1024^3 and 2048^3 grids; any other length (non-cubic grids, other large sizes) is built once in
+    ~0.2 s per polynomial (45-60 of them, ~10 s), memoised per process and kept in cache_dir() (written atomically: all the
+    ranks of a job may build it at once)."""
     rows = nstages * (TREE_RADIX - 1)
     memo = _TREE_MEMO.get(segment_blocks)
     if memo is not None and memo.shape[0] >= rows:
         return memo[:rows]
-    path = _tree_cache(segment_blocks)
-    if cache and os.path.exists(path):
-        arr = np.load(path)["polys"]
-        if arr.shape[0] >= rows:
-            _TREE_MEMO[segment_blocks] = arr
-            return arr[:rows]
+    if cache:              # shipped with the package (the segment lengths of 1024^3 and 2048^3 grids), else the user's cache
+        for path in (_tree_cache(segment_blocks, True), _tree_cache(segment_blocks, False)):
+            arr = _load_polys(path, rows)
+            if arr is not None:
+                _TREE_MEMO[segment_blocks] = arr
+                return arr[:rows]
     phi = characteristic_polynomial()
     out = []
     for t in range(nstages):
@@ -313,10 +340,7 @@ def tree_polynomials(nstages=4, cache=True, segment_blocks=SEGMENT_BLOCKS):
     arr = np.stack(out)
     _TREE_MEMO[segment_blocks] = arr
     if cache:
-        try:
-            np.savez_compressed(path, polys=arr)
-        except OSError:
-            pass
+        _save_polys(_tree_cache(segment_blocks, False), arr)
     return arr
 
 

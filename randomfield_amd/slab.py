@@ -20,7 +20,7 @@ import os
 import numpy as np
 
 __all__ = ["slab_layout", "exchange_blocks", "gather_rows", "side_array_planes", "split_side_array",
-           "assemble_side_array", "exchange_unique_id", "init_process_group", "DistributedPlan", "SlabHostPlan"]
+           "assemble_side_array", "exchange_unique_id", "init_process_group", "DistributedPlan", "SlabHostPlan", "Deadline"]
 
 
 def slab_layout(nx, ny, nz, nranks, rank):
@@ -68,23 +68,34 @@ def assemble_side_array(parts):
     return np.concatenate([a[:, :, :nzl] for a in parts] + [parts[0][:, :, nzl:]], axis=2)
 
 
-def _rendezvous_path():
-    """A file name every rank of one launch agrees on: the ranks of `torch.distributed.run` are children
-    of the same agent process, so (parent pid, MASTER_PORT) identifies the launch on this node."""
+_plans_made = 0          # DistributedPlans built by this process so far: every rank builds them in the same order
+
+
+def _rendezvous_path(serial=None):
+    """A file name every rank of one launch agrees on for its `serial`-th DistributedPlan: the ranks of
+    `torch.distributed.run` are children of the same agent process, so (parent pid, MASTER_PORT, run id) identifies the
+    launch on this node, and the per-process plan counter the plan (two plans of one job never share a file: a fast rank
+    cannot pick up the previous plan's id)."""
     port = os.environ.get("MASTER_PORT", "0")
     run_id = os.environ.get("TORCHELASTIC_RUN_ID", "none")
-    return os.path.join(os.environ.get("TMPDIR", "/tmp"), "randomfield_uid_%d_%s_%s" % (os.getppid(), port, run_id))
+    serial = _plans_made if serial is None else serial
+    return os.path.join(os.environ.get("TMPDIR", "/tmp"), "randomfield_uid_%d_%s_%s_%d" % (os.getppid(), port, run_id, serial))
 
 
-def exchange_unique_id(rank, world, make_uid, timeout=300.0):
+def exchange_unique_id(rank, world, make_uid, timeout=300.0, path=None):
     """Hand rank 0's RCCL unique id to every rank of a single-node job WITHOUT importing torch
     (a process that loads PyTorch's bundled ROCm runtime next to the system one is asking for trouble).
-    Rank 0 writes the 128 bytes atomically; the others poll for the file."""
+    Rank 0 removes any stale file of that name, then writes the 128 bytes atomically; the others poll for the file
+    and only accept one written after they started waiting for THIS plan (mtime), 128 bytes long."""
     import time
-    path = _rendezvous_path()
+    path = _rendezvous_path() if path is None else path
     if world == 1:
         return make_uid()
     if rank == 0:
+        try:
+            os.remove(path)
+        except OSError:
+            pass
         uid = make_uid()
         tmp = path + ".tmp%d" % os.getpid()
         with open(tmp, "wb") as f:
@@ -101,8 +112,48 @@ def exchange_unique_id(rank, world, make_uid, timeout=300.0):
         except OSError:
             pass
         if time.time() - t0 > timeout:
-            raise RuntimeError("timed out waiting for the RCCL unique id at %s" % path)
+            raise RuntimeError("rank %d timed out after %.0f s waiting for rank 0's RCCL unique id at %s" % (rank, timeout, path))
         time.sleep(0.02)
+
+
+class Deadline(object):
+    """Host-side watchdog around a collective step that can block for ever when a rank has died (ncclCommInitRank, the
+    first grouped send / receive): every rank checks in with a file before the step; if the step has not returned after
+    `seconds`, a timer thread prints which ranks never checked in and ends THIS process with a non-zero status
+    (os._exit from a thread -- the main thread is inside the blocked C call; no re-exec of a process that holds the GPU)."""
+
+    def __init__(self, what, rank, world, seconds=None, path=None):
+        self.what, self.rank, self.world = what, rank, world
+        self.seconds = float(os.environ.get("RANDOMFIELD_COLLECTIVE_TIMEOUT", "180")) if seconds is None else seconds
+        self.base = (_rendezvous_path() if path is None else path) + "." + "".join(c if c.isalnum() else "_" for c in what)
+        self.timer = None
+
+    def _expired(self):
+        import sys
+        missing = [r for r in range(self.world) if not os.path.exists("%s.rank%d" % (self.base, r))]
+        sys.stderr.write("randomfield_amd: rank %d of %d: '%s' did not finish within %.0f s; ranks that never reached it: %s\n"
+                         % (self.rank, self.world, self.what, self.seconds, missing if missing else "none (all checked in: a hung collective)"))
+        sys.stderr.flush()
+        os._exit(3)
+
+    def __enter__(self):
+        import threading
+        if self.world > 1 and self.seconds > 0:
+            with open("%s.rank%d" % (self.base, self.rank), "w") as f:
+                f.write("%d\n" % os.getpid())
+            self.timer = threading.Timer(self.seconds, self._expired)
+            self.timer.daemon = True
+            self.timer.start()
+        return self
+
+    def __exit__(self, *exc):
+        if self.timer is not None:
+            self.timer.cancel()
+            try:
+                os.remove("%s.rank%d" % (self.base, self.rank))
+            except OSError:
+                pass
+        return False
 
 
 def init_process_group():
@@ -143,15 +194,23 @@ class DistributedPlan(object):
         self.layout = slab_layout(nx, ny, nz, self.world, self.rank)
         self.plan = _hip.DevicePlan(nx, ny, nz, dtype, device=local_rank if device is None else device,
                                     nranks=self.world, rank=self.rank)
+        global _plans_made
+        self._path = _rendezvous_path()       # unique per (launch, plan): see _rendezvous_path
+        _plans_made += 1
         if self.world > 1:
-            uid = exchange_unique_id(self.rank, self.world, _hip.DevicePlan.comm_unique_id)
-            self.plan.comm_init(uid)          # collective: every rank calls it; ends with a tiny all-reduce
-            self.plan.barrier()
+            uid = exchange_unique_id(self.rank, self.world, _hip.DevicePlan.comm_unique_id, path=self._path)
+            with self.deadline("RCCL communicator init"):
+                self.plan.comm_init(uid)      # collective: every rank calls it; ends with a tiny all-reduce
+                self.plan.barrier()
             if self.rank == 0:
                 try:
-                    os.remove(_rendezvous_path())
+                    os.remove(self._path)
                 except OSError:
                     pass
+
+    def deadline(self, what, seconds=None):
+        """``with dist.deadline("first exchange"): ...`` -- a watchdog around a step every rank must reach (:class:`Deadline`)."""
+        return Deadline(what, self.rank, self.world, seconds, path=self._path)
 
     def barrier(self):
         self.plan.barrier()

@@ -59,9 +59,9 @@ def allocate(shape, dtype, use_pyfftw=True):
 def expanded_shape(data, packed=False):
     """Logical (nx, ny, nz) of a 3D array; a packed array stores nz/2 + 1 planes (transform.py:46-60)."""
     nx, ny, nz_stored = data.shape
-    if (nx | ny) & 1:
+    if nx % 2 or ny % 2:
         raise ValueError("First two dimensions of array must be even.")
-    stored_is_odd = bool(nz_stored & 1)
+    stored_is_odd = bool(nz_stored % 2)
     if stored_is_odd != bool(packed):
         raise ValueError("Last dimension of packed array must be odd." if packed
                          else "Last dimension of unpacked array must be even.")
@@ -187,7 +187,7 @@ def _resolve_layout(shape, dtype_in, data_in, overwrite, inverse, packed):
         nx, ny, nz = shape
     except (TypeError, ValueError):
         raise ValueError("Expected 3D shape.")
-    if (nx | ny | nz) & 1:
+    if nx % 2 or ny % 2 or nz % 2:
         raise ValueError("All shape dimensions must be even.")
     shape = (nx, ny, nz)
     if data_in is not None:

@@ -144,3 +144,50 @@ def test_slab_layout_rules():
         slab.slab_layout(16, 16, 16, 3, 0)
     with pytest.raises(ValueError):
         slab.slab_layout(16, 16, 16, 8, 0)           # nz/2 = 8 planes over 8 ranks: 1 plane each (odd)
+
+
+def test_rendezvous_files_are_per_plan_and_stale_ids_are_dropped(tmp_path, monkeypatch):
+    """Two DistributedPlans of one job never share a rendezvous file (per-process plan counter), and rank 0 removes a stale
+    file of the same name before it writes (a fast rank must not pick up a previous plan's id)."""
+    from randomfield_amd import slab
+    monkeypatch.setenv("TMPDIR", str(tmp_path))
+    monkeypatch.setenv("MASTER_PORT", "23456")
+    a, b = slab._rendezvous_path(0), slab._rendezvous_path(1)
+    assert a != b and a.endswith("_0") and b.endswith("_1")
+    stale = bytes(128)
+    with open(a, "wb") as f:
+        f.write(stale)
+    fresh = bytes(range(128))
+    assert slab.exchange_unique_id(0, 2, lambda: fresh, path=a) == fresh
+    assert slab.exchange_unique_id(1, 2, lambda: b"", timeout=5, path=a) == fresh
+
+
+def test_deadline_names_the_missing_rank_and_exits(tmp_path):
+    """A blocked collective step ends the process with status 3 and says which rank never arrived (run in a child:
+    the watchdog calls os._exit)."""
+    import subprocess
+    import sys
+    code = (
+        "import os, sys, time\n"
+        "sys.path.insert(0, %r)\n"
+        "os.environ['TMPDIR'] = %r\n"
+        "from randomfield_amd import slab\n"
+        "open(slab._rendezvous_path(0) + '.first_exchange.rank0', 'w').close()   # rank 0 got there; rank 2 never does\n"
+        "with slab.Deadline('first exchange', 1, 3, seconds=1.0, path=slab._rendezvous_path(0)):\n"
+        "    time.sleep(30)\n"
+        "print('not reached')\n" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(tmp_path)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 3, (r.returncode, r.stderr)
+    assert "first exchange" in r.stderr and "[2]" in r.stderr and "not reached" not in r.stdout
+    # a step that finishes in time: the watchdog is cancelled and the check-in file removed
+    from randomfield_amd import slab
+    os.environ["TMPDIR"], old = str(tmp_path), os.environ.get("TMPDIR")
+    try:
+        with slab.Deadline("quick step", 0, 2, seconds=5.0, path=slab._rendezvous_path(7)) as d:
+            assert os.path.exists(d.base + ".rank0")
+        assert not os.path.exists(d.base + ".rank0")
+    finally:
+        if old is None:
+            del os.environ["TMPDIR"]
+        else:
+            os.environ["TMPDIR"] = old

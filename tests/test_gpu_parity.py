@@ -126,38 +126,65 @@ def test_full_field_against_oracle(hip, dpower, shape):
     plan.close()
 
 
-def test_512_cube_known_answer(hip, dpower):
-    """BASELINE config 1 (512^3 f32): SURVEY 8c spot values of the reference for seed 123."""
-    n = 512
+def _check_large_summary(dev, g, check_kspace):
+    """device field (and k space) against a summary fixture oracle/make_golden_large.py made from the REFERENCE's own run"""
+    n = int(g["shape"][0])
+    s = n // 16
+    rms = float(g["rms"])
+    mean, std = dev.moments()
+    # (the reference's own float32 np.std over 2^30 values carries ~5e-6 relative accumulation error)
+    assert abs(std - rms) <= TOL_F32 * rms and abs(mean - float(g["mean"])) <= 1e-6 * rms
+    sub = np.stack([dev.download_real(x0=ix, x1=ix + 1)[0, ::s, ::s] for ix in range(0, n, s)])
+    assert sub.shape == g["sub"].shape and sub.size == 4096
+    assert np.max(np.abs(sub - g["sub"])) <= TOL_F32 * rms
+    first = dev.download_real(x0=0, x1=1)[0, 0, :4]
+    last = dev.download_real(x0=n - 1, x1=n)[0, -1, -4:]
+    assert np.max(np.abs(first - g["first"])) <= TOL_F32 * rms and np.max(np.abs(last - g["last"])) <= TOL_F32 * rms
+    lo, hi, sumsq = np.inf, -np.inf, 0.0
+    for x0 in range(0, n, 64):
+        blk = dev.download_real(x0=x0, x1=x0 + 64)
+        lo, hi = min(lo, float(blk.min())), max(hi, float(blk.max()))
+        sumsq += float((blk.astype(np.float64) ** 2).sum())
+    assert abs(lo - float(g["min"])) <= 2 * TOL_F32 * rms and abs(hi - float(g["max"])) <= 2 * TOL_F32 * rms
+    assert abs(sumsq - float(g["sumsq"])) <= 1e-5 * float(g["sumsq"])
+    if check_kspace:
+        ks = dev.download_k()
+        scale = np.abs(g["kspace_sub"]).max()
+        assert np.max(np.abs(ks[::s, ::s, 0] - g["plane0_sub"])) <= 5e-6 * scale
+        assert np.max(np.abs(ks[::s, ::s, n // 2] - g["nyq_sub"])) <= 5e-6 * scale
+        assert np.max(np.abs(ks[::s, ::s, 1::max(1, (n // 2) // 8)] - g["kspace_sub"])) <= 5e-6 * scale
+
+
+@pytest.mark.parametrize("n", [256, 512, 1024])
+def test_baseline_sizes_against_reference_summaries_host_noise(hip, dpower, n):
+    """BASELINE configs 1-3 sizes (256^3, 512^3, 1024^3 float32), parity mode: numpy's deviates for seed 123 supplied by the
+    host, exact reference dtype chain on the GPU, against tests/golden/summary_<n>_c64.npz -- 4096 field values, the
+    SURVEY 8c spot values, rms / mean / min / max / sum of squares, and the two Hermitian planes + 8 more planes of k space
+    (subsampled) of the REFERENCE's own run (oracle/make_golden_large.py)."""
+    g = golden("summary_%d_c64.npz" % n)
     plan = make_plan(hip, (n, n, n), np.complex64, *dpower)
     noise = cpu_ref.reference_noise(123, n * n * (n // 2 + 1))
-    plan.realise(noise=noise)
+    plan.generate(noise=noise)                  # rows K,T,R,S into the API-layout k array
+    plan.execute_c2r()                          # row X
     del noise
-    mean, std = plan.moments()
-    assert abs(std - 2.3144155) <= TOL_F32 * 2.3144155 and abs(mean) < 1e-6
-    first = plan.download_real(x0=0, x1=1)[0, 0, :4]
-    last = plan.download_real(x0=n - 1, x1=n)[0, -1, -4:]
-    assert np.allclose(first, [-0.628191, -0.63676345, 0.3869021, 0.5524756], rtol=0, atol=2.4e-5)
-    assert np.allclose(last, [4.058375, 1.2057173, 2.9818745, 1.7062455], rtol=0, atol=2.4e-5)
+    _check_large_summary(plan, g, check_kspace=True)
+    plan.realise(noise="resident")              # the fused path on the same (resident) deviates
+    _check_large_summary(plan, g, check_kspace=False)
     plan.close()
 
 
-def test_1024_cube_known_answer_generator_reference_rng(hip):
-    """BASELINE headline config (1024^3 f32) through the Generator API with the default rng='reference':
-    the MT19937 + polar stream of seed 123 is replayed on the GPU (no host deviates), and the field must
-    reproduce the reference's SURVEY 8c spot values (first = delta[0,0,:4], last = delta[-1,-1,-4:], std)."""
+@pytest.mark.parametrize("n", [512, 1024])
+def test_baseline_sizes_generator_reference_rng(hip, n):
+    """The same sizes through the Generator API with the default rng='reference': the MT19937 + polar stream of seed 123 is
+    replayed on the GPU (no host deviates), and the field must reproduce the reference's summary fixture."""
     from randomfield_amd import Generator
-    n = 1024
+    g = golden("summary_%d_c64.npz" % n)
     gen = Generator(n, n, n, SPACING, backend="hip")
     assert gen.rng == "reference"
-    gen.generate_delta_field(seed=123, download=False)
-    # the reference's own float32 np.std over 2^30 values carries ~5e-6 relative accumulation error
-    assert abs(float(gen.delta_field_rms) - 2.3137536) <= TOL_F32 * 2.3137536
+    gen.generate_delta_field(seed=123, download=False, save_potential=False)
+    assert abs(float(gen.delta_field_rms) - float(g["rms"])) <= TOL_F32 * float(g["rms"])
     dev = gen.plan_c2r.device
-    first = dev.download_real(x0=0, x1=1)[0, 0, :4]
-    last = dev.download_real(x0=n - 1, x1=n)[0, -1, -4:]
-    assert np.allclose(first, [1.1417141, 0.06940198, 0.947284, -1.5216146], rtol=0, atol=2.4e-5)
-    assert np.allclose(last, [-0.7602967, -6.768864, -1.6377747, -0.7990725], rtol=0, atol=2.4e-5)
+    _check_large_summary(dev, g, check_kspace=False)
     dev.close()
 
 
@@ -1291,3 +1318,100 @@ def test_slabs_and_blocked_intermediate_only_move_data(hip, dpower, shape, dtype
                 assert np.max(np.abs(u - v)) <= (1e-6 if dtype == np.complex64 else 1e-14) * v.std(), key
         assert abs(ma[1] - m0[1]) <= 1e-9 * m0[1] and np.max(np.abs(rms - r0)) <= 1e-9 * r0.max(), key
     plan.close()
+
+
+def test_bench_multi_gpu_code_path_with_one_rank(hip):
+    """`bench.py --force-multi` runs main_multi -- DistributedPlan, the deadline-guarded first exchange, the pipelined slab
+    batch, the RCCL all-reduces (a one-rank communicator) -- as a child process on one GPU and prints a well-formed line."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-multi", "--steps", "3", "--warmup", "1",
+                        "--edge", "256", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["steps"] == 3 and line["unit"] == "Mcells/s" and line["value"] > 0
+    assert line["config"]["grid"] == [256, 256, 256] and 2.0 < line["config"]["rms_last"] < 2.6
+    assert line["roofline"]["frac"] > 0 and line["pipeline"]["kernel_ms_rank0_unpipelined_step"]["x"] > 0
+
+
+def test_two_distributed_plans_in_a_row(hip, dpower, monkeypatch, tmp_path):
+    """Two DistributedPlans built one after the other in one process (world 1 here; the rendezvous names differ per plan) give
+    the same field as a plain plan."""
+    from randomfield_amd import powertools, slab
+    monkeypatch.setenv("TMPDIR", str(tmp_path))
+    k, Pk = dpower
+    n = 64
+    ref = make_plan(hip, (n, n, n), np.complex64, k, Pk)
+    ref.realise(seed=5)
+    want = ref.download_real()
+    ref.close()
+    paths = []
+    for i in range(2):
+        d = slab.DistributedPlan(n, n, n, np.complex64, device=0, rank=0, world=1)
+        paths.append(d._path)
+        d.plan.set_kgrid(*powertools.ksq_axes(n, n, n, SPACING))
+        d.plan.set_power(*cpu_ref.sigma_table(k, Pk, n, n, n, SPACING))
+        d.plan.realise(seed=5)
+        assert np.array_equal(d.plan.download_real(), want)
+        d.barrier()
+        d.plan.close()
+    assert paths[0] != paths[1]
+
+
+@pytest.mark.parametrize("shape,dtype", [((2048, 2048, 1024), np.complex64), ((1024, 2048, 2048), np.complex128)])
+def test_unpacked_c2c_shapes_that_need_64bit_lane_offsets(hip, shape, dtype):
+    """The largest unpacked c2c arrays put the rows of the x pass more than 4 GiB apart (34 GB complex64, 69 GB complex128):
+    64-bit lane offsets, instantiated for axes >= 1024.  A handful of spikes in, plane waves out (closed form, sampled),
+    and the inverse brings the spikes back; shorter axes with such strides are refused at plan creation, by name."""
+    nx, ny, nz = shape
+    plan = hip.DevicePlan(nx, ny, nz, dtype, unpacked=True)
+    a = np.zeros(shape, dtype)                                   # (lazily mapped: only touched pages cost anything)
+    spikes = [((0, 0, 0), 1.0), ((3, 5, 7), 2 - 1j), ((nx - 1, ny // 2, 11), 0.5j), ((nx // 2 + 1, 1, nz - 1), -1.5)]
+    for pos, v in spikes:
+        a[pos] = v
+    plan.upload_c(a)
+    plan.execute_c2c(inverse=False)
+    plan.download_c(out=a)
+    rng = np.random.RandomState(1)
+    kk = np.stack([rng.randint(0, n, 4000) for n in shape], axis=1)
+    kk[:8] = [[0, 0, 0], [nx - 1, ny - 1, nz - 1], [nx // 2, 0, 0], [0, ny // 2, 0], [0, 0, nz // 2], [nx - 1, 0, 0], [1, 1, 1], [nx // 2, ny // 2, nz // 2]]
+    want = np.zeros(len(kk), np.complex128)
+    for (x, y, z), v in spikes:
+        want += v * np.exp(-2j * np.pi * (kk[:, 0] * x / nx + kk[:, 1] * y / ny + kk[:, 2] * z / nz))
+    got = a[kk[:, 0], kk[:, 1], kk[:, 2]]
+    assert np.max(np.abs(got - want)) <= (2e-5 if dtype == np.complex64 else 1e-12)
+    plan.execute_c2c(inverse=True)
+    plan.download_c(out=a)
+    for pos, v in spikes:
+        assert abs(a[pos] - v) <= (2e-6 if dtype == np.complex64 else 1e-13)
+        a[pos] = 0
+    assert np.max(np.abs(a[kk[:, 0], kk[:, 1], kk[:, 2]])) <= (2e-6 if dtype == np.complex64 else 1e-13)
+    plan.close()
+    del a
+    if dtype == np.complex128:
+        with pytest.raises(RuntimeError, match="4 GiB"):
+            hip.DevicePlan(512, 2048, 2048, np.complex128, unpacked=True)       # x rows 64 MiB apart, 63 of them per lane: 32 bits overflow
+
+
+def test_generator_notices_tables_changed_behind_its_back(hip):
+    """The 'tables unchanged, skip the upload' shortcut of Generator lives with the device plan: after someone changes the
+    tables through the documented ``plan_c2r.device`` handle, the next generate_delta_field uploads its own again."""
+    from randomfield_amd import Generator
+    gen = Generator(64, 64, 64, SPACING, backend="hip", rng="native")
+    a = gen.generate_delta_field(seed=3, save_potential=False).copy()
+    dev = gen.plan_c2r.device
+    assert dev.set_power(*[np.asarray(t) for t in _other_tables()]) is True       # someone else's tables on the same device plan
+    b = gen.generate_delta_field(seed=3, save_potential=False).copy()
+    assert np.array_equal(a, b)
+    assert dev.set_power(*_other_tables(), if_changed=True) is True               # (and the key follows every upload)
+    assert dev.set_power(*_other_tables(), if_changed=True) is False
+    dev.close()
+
+
+def _other_tables():
+    x = np.linspace(-3.0, 1.5, 64)
+    return x, 100.0 * np.exp(-0.5 * (x + 1.0) ** 2)

@@ -6,6 +6,11 @@ import pytest
 from randomfield_amd import mt19937 as mt
 
 
+import os
+# the round-1 binary jump tree t^(L 2^k): an independent table the radix-16 one is checked against (a fixture, not product data)
+BINARY_TREE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mt19937_jump_L638976.npz")
+
+
 def _same_state(a, b):
     """MT19937 states are equal when all words agree except the unused low 31 bits of word 0."""
     a, b = np.asarray(a, np.uint32), np.asarray(b, np.uint32)
@@ -63,7 +68,7 @@ def test_characteristic_polynomial(phi):
 
 
 def test_cached_jump_polynomials_are_powers_of_t(phi):
-    polys = mt.jump_polynomials(16)
+    polys = mt.jump_polynomials(16, path=BINARY_TREE)
     g = mt.power_of_t(mt.SEGMENT_WORDS, phi)
     for k in range(16):
         assert np.array_equal(np.frombuffer(g.to_bytes(mt.N * 4, "little"), dtype="<u4"), polys[k]), k
@@ -71,7 +76,7 @@ def test_cached_jump_polynomials_are_powers_of_t(phi):
 
 
 def test_jump_equals_stepping():
-    polys = mt.jump_polynomials(3)
+    polys = mt.jump_polynomials(3, path=BINARY_TREE)
     st = mt.init_genrand(123)
     seq = mt.sequence(st, 3 * mt.SEGMENT_WORDS + mt.N)
     one = mt.jump_state(st, polys[0])
@@ -92,7 +97,7 @@ def test_attempts_margin():
 def test_tree_polynomials_are_the_right_powers(phi):
     """rows of the radix-16 tree table: t^(m 16^t L); where m 16^t is a power of two they equal the binary-tree rows"""
     tree = mt.tree_polynomials(3)
-    binary = mt.jump_polynomials(10)
+    binary = mt.jump_polynomials(10, path=BINARY_TREE)
     assert tree.shape == (45, mt.N)
     for (t, m, k) in ((0, 1, 0), (0, 2, 1), (0, 4, 2), (0, 8, 3), (1, 1, 4), (1, 2, 5), (2, 1, 8), (2, 2, 9)):
         assert np.array_equal(tree[t * 15 + m - 1], binary[k])
@@ -102,3 +107,21 @@ def test_tree_polynomials_are_the_right_powers(phi):
     st = mt.init_genrand(4)
     seq = mt.sequence(st, 5 * mt.SEGMENT_WORDS + mt.N)
     assert _same_state(mt.jump_state(st, tree[4]), seq[5 * mt.SEGMENT_WORDS:5 * mt.SEGMENT_WORDS + mt.N])
+
+
+def test_tables_computed_at_run_time_go_to_the_user_cache_atomically(tmp_path, monkeypatch):
+    """A segment length without a shipped table is computed once, written to cache_dir() through a temporary file, found
+    there by the next process -- and a truncated file (another rank caught mid-write under the old scheme) is recomputed."""
+    monkeypatch.setenv("RANDOMFIELD_CACHE_DIR", str(tmp_path))
+    mt._TREE_MEMO.pop(7, None)
+    a = mt.tree_polynomials(1, segment_blocks=7)
+    path = mt._tree_cache(7, shipped=False)
+    assert path.startswith(str(tmp_path)) and os.path.exists(path) and not [f for f in os.listdir(str(tmp_path)) if ".tmp" in f]
+    assert not os.path.exists(mt._tree_cache(7, shipped=True))          # nothing is written into the package
+    mt._TREE_MEMO.pop(7, None)
+    assert np.array_equal(mt.tree_polynomials(1, segment_blocks=7), a)
+    with open(path, "r+b") as f:
+        f.truncate(100)
+    mt._TREE_MEMO.pop(7, None)
+    assert np.array_equal(mt.tree_polynomials(1, segment_blocks=7), a)
+    mt._TREE_MEMO.pop(7, None)
