@@ -148,6 +148,15 @@ int rf_moments(rf_plan* plan, double* mean, double* std);
  * a_z[iz] = sqrt(log t), b_z[iz] = sqrt(t), t = 1 + (sigma*growth[iz])^2 (host, float64);
  * field <- exp(field / sigma * a_z) / b_z with the reference's four roundings. */
 int rf_lognormal(rf_plan* plan, const double* a_z, const double* b_z, int nz, double sigma);
+/* The same two rows fused into the realisation (single-GPU plans, power-of-two axes): generate_delta_field(save_potential=False)
+ * followed by convert_delta_to_density(apply_lognormal_transform=True) (generate.py:191-199,218-219,266-273) as ONE call of five
+ * sweeps.  sigma = np.std(delta) (generate.py:219) is obtained before the last pass from the y pass's output (Parseval; the mean
+ * is 0 because the DC mode is), the tables are formed on the device and the map runs in the z pass's epilogue as
+ * exp(delta * (a_z / sigma)) * (density_z / b_z): within a few ulp of exp's argument of the reference's four statements (1e-15
+ * relative for float64 fields; rf_lognormal / rf_scale_z are the rounding-exact, unfused forms).  rf_set_z_tables: growth_z (nz) and, optionally, the mean-density factor (generate.py:273),
+ * once per plan.  *sigma_out (optional; blocks) = the rms of the Gaussian field; rf_moments afterwards describes the DENSITY. */
+int rf_set_z_tables(rf_plan* plan, const double* growth_z, const double* density_z_or_null, int nz);
+int rf_realise_lognormal(rf_plan* plan, uint64_t seed, int mode, const double* noise_or_null, double* sigma_out);
 int rf_scale_z(rf_plan* plan, const double* factor_z, int nz);
 /* field <- field * mul_z[iz] + add (generate.py:271-272 non-lognormal branch) */
 int rf_affine_z(rf_plan* plan, const double* mul_z, int nz, double add);

@@ -71,6 +71,9 @@ SIGNATURES = {
     "rf_sync": (ctypes.c_int, [ctypes.c_void_p]),
     "rf_elapsed_ms": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]),
     "rf_kernel_ms": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]),
+    "rf_set_z_tables": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.c_int]),
+    "rf_realise_lognormal": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.POINTER(ctypes.c_double),
+                                            ctypes.POINTER(ctypes.c_double)]),
     "rf_yz_slabs": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "rf_comm_unique_id": (ctypes.c_int, [ctypes.c_void_p]),
     "rf_comm_init": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
@@ -357,6 +360,20 @@ class DevicePlan(object):
         m, s = ctypes.c_double(), ctypes.c_double()
         check(self._lib.rf_moments(self._h, ctypes.byref(m), ctypes.byref(s)), "rf_moments")
         return m.value, s.value
+
+    def set_z_tables(self, growth_z, density_z=None):
+        """growth(z) and, optionally, the mean-density factor (nz,) of fused lognormal realisations (rf_set_z_tables)."""
+        g = _f64(np.broadcast_to(np.asarray(growth_z, np.float64), (self.nz,)))
+        d = None if density_z is None else _f64(np.broadcast_to(np.asarray(density_z, np.float64), (self.nz,)))
+        check(self._lib.rf_set_z_tables(self._h, _dp(g), _dp(d) if d is not None else None, self.nz), "rf_set_z_tables")
+
+    def realise_lognormal(self, seed=0, noise=None, want_sigma=True):
+        """Gaussian realisation + lognormal map (+ density factor) in one call of five sweeps; returns the Gaussian field's rms."""
+        mode, ptr, keep = self._noise_arg(noise)
+        sig = ctypes.c_double(0.0)
+        check(self._lib.rf_realise_lognormal(self._h, ctypes.c_uint64(int(seed) & (2 ** 64 - 1)), mode, ptr,
+                                             ctypes.byref(sig) if want_sigma else None), "rf_realise_lognormal")
+        return sig.value if want_sigma else None
 
     def lognormal(self, a_z, b_z, sigma):
         a_z, b_z = _f64(a_z), _f64(b_z)

@@ -165,6 +165,53 @@ template <typename T, bool WIDE = false> struct PlainColIO {
   RF_HD static void sched_fence(int = 0) {}      // loads of one butterfly are meant to be issued back to back
   static constexpr bool ROLLED_LOAD = false;
   RF_HD long long remap_tile(long long t) const { return t; }
+  static constexpr bool HAS_FINISH = false;
+};
+
+// y pass of the c2r transform that also accumulates  S = sum over its OUTPUT Y(x, y, kz) of w(kz) |Y|^2  (w = 1 for slot kz = 0,
+// which holds the two REAL planes kz = 0 and nz/2 as A0 + i Anyq, so |slot|^2 = A0^2 + Anyq^2; w = 2 for every other kz: its
+// conjugate half of k space).  Y is the unnormalised inverse transform over (kx, ky), so by Parseval S = nx ny sum_k |delta_k|^2
+// over the FULL k space, and for the real field delta(x) = (1 / N3) sum_k delta_k e^{ikx}, N3 = nx ny nz:
+//     sum_x delta(x)^2 = S / (nx ny N3),    mean = 0 (the DC mode is 0)    =>    rms = sqrt(S / (nx ny)) / N3
+// -- the field's rms is known BEFORE the z pass runs, so that pass can apply the lognormal map (cosmotools.py:206-221,
+// generate.py:266-273) in its epilogue instead of two more sweeps and a host round trip.  One partial per workgroup (tile),
+// float64, fixed order: deterministic.
+template <typename T> struct AccColIO {
+  cplx<T>* base;
+  ColGeom g;
+  double* partials;              // [ntiles]
+  int kz0, nzl;                  // the kz planes of this rank's columns: column C = hi * nzl + (kz - kz0)
+  mutable double acc = 0.0;
+  RF_HD V16<T> load(long long C0, int cl, int rb, int ro) const { return v16_load<T>(g.at<false>(base, C0, cl, rb, ro)); }
+  RF_HD void store(long long C0, int cl, int rb, int ro, const V16<T>& v) const {
+#pragma unroll
+    for (int c = 0; c < V16<T>::CPL; ++c) {
+      const int kz = kz0 + (int)((C0 + cl + c) & (long long)(nzl - 1));
+      const double re = (double)v.c[c].x, im = (double)v.c[c].y;
+      acc += (kz == 0 ? 1.0 : 2.0) * (re * re + im * im);
+    }
+    v16_store<T>(g.at<false>(base, C0, cl, rb, ro), v);
+  }
+  static constexpr int FIX_MODE = 0;
+  RF_HD bool needs_fix(long long) const { return false; }
+  RF_HD cplx<T> fix_value(long long, int, int) const { return cplx<T>(); }
+  static constexpr int LDS_EXTRA = 0;
+  RF_HD void prologue(int, int, void*) {}
+  RF_HD void bind_seed() {}
+  RF_HD static void sched_fence(int = 0) {}
+  static constexpr bool ROLLED_LOAD = false;
+  RF_HD long long remap_tile(long long t) const { return t; }
+  static constexpr bool HAS_FINISH = true;
+  // workgroup sum of `acc` -> partials[tile]; `red` = NT / 64 doubles of LDS the workgroup no longer needs, `sync` = its barrier
+  template <class Sync> RF_HD void finish(int tid, int nthreads, double* red, long long tile, double wave_sum, Sync sync) const {
+    if ((tid & 63) == 0) red[tid >> 6] = wave_sum;
+    sync();
+    if (tid == 0) {
+      double a = 0;
+      for (int w = 0; w < nthreads / 64; ++w) a += red[w];
+      partials[tile] = a;
+    }
+  }
 };
 
 // Strided pass with separate load and store geometries and its own tile order: the y pass of the c2r transform on the blocked
@@ -179,6 +226,7 @@ template <typename T> struct XposeColIO {
   // line when tc cells are 64 bytes) and the kz tiles of one ix are whole blocks apart, so in dispatch order ix is the fast
   // index: t = ((kg * nhi + hi) << grp_shift) + kl  ->  hi * tiles_per_run + (kg << grp_shift) + kl  (grp_shift = 0 in the product).
   int grp_shift = 0, nhi_shift = 0, tpr_shift = 0;
+  static constexpr bool HAS_FINISH = false;
   RF_HD long long remap_tile(long long t) const {
     const long long kl = t & ((1LL << grp_shift) - 1), r = t >> grp_shift;
     const long long hi = r & ((1LL << nhi_shift) - 1), kg = r >> nhi_shift;
@@ -287,6 +335,7 @@ template <typename T, bool WIDE = false> struct GenColIO {
   // replicated R times: the load loop stays rolled and parks its values in the thread's own LDS slots
   static constexpr bool ROLLED_LOAD = true;
   RF_HD long long remap_tile(long long t) const { return t; }
+  static constexpr bool HAS_FINISH = false;
 };
 
 // x pass fused with the fast float32 native generation (one Philox call per lane load)
@@ -393,6 +442,7 @@ struct FastGenColIOT {
   // symmetrised (kz=0, kz=nz/2) pair (cold path: one lane in four of one tile in nz/16)
   static constexpr bool ROLLED_LOAD = false;
   RF_HD long long remap_tile(long long t) const { return t; }
+  static constexpr bool HAS_FINISH = false;
   static constexpr int FIX_MODE = FIX;
   RF_HD bool needs_fix(long long C) const { return FIX != 0 && kz0 + (int)((unsigned)C & (unsigned)(nzl - 1)) == 0; }
   RF_HD cplx<float> fix_value(long long C, int rb, int ro) const {
@@ -460,6 +510,7 @@ struct FastGenColIO64 {
   }
   static constexpr bool ROLLED_LOAD = false;
   RF_HD long long remap_tile(long long t) const { return t; }
+  static constexpr bool HAS_FINISH = false;
   static constexpr int FIX_MODE = FIX;
   RF_HD bool needs_fix(long long C) const { return FIX != 0 && kz0 + (int)((unsigned)C & (unsigned)(nzl - 1)) == 0; }
   RF_HD cplx<double> fix_value(long long C, int rb, int ro) const {
@@ -804,6 +855,39 @@ template <typename T> struct XGatherRowIO {
     s1 += (double)z.x + (double)z.y;
     s2 += (double)z.x * (double)z.x + (double)z.y * (double)z.y;
   }
+};
+
+// z pass with the lognormal map in its epilogue: rho = exp(delta * Ap_z) * Bp_z with the float64 tables Ap = sqrt(log t) / sigma,
+// Bp = density / sqrt(t), t = 1 + (sigma growth_z)^2, formed on the device from the y pass's Parseval sum (AccColIO,
+// lognormal_tables_kernel).  The reference does the same map as four in-place numpy statements with a rounding to the array
+// dtype after each (cosmotools.py:216-220, then generate.py:273); here the two divisions are folded into the tables (a float64
+// division costs ~15 instructions per element and the pass has 2 x 10^9 of them): the result is within a few ulp of the
+// argument of exp of the reference's chain (<= 1e-15 relative for float64 fields, 3e-7 for float32 ones; rf_lognormal is the
+// rounding-exact, unfused form).  Element n of a row holds the reals z = 2n, 2n + 1; the tables are 16 KB, L1-resident.
+RF_HD float exp_t(float x) { return expf(x); }
+RF_HD double exp_t(double x) { return exp(x); }
+template <typename T> struct LognormalRowIO {
+  cplx<T>* base;
+  T scale;                       // 1 / (nx ny nz)
+  int M_of;
+  const double* Ap;              // [2 M] sqrt(log t_z) / sigma
+  const double* Bp;              // [2 M] density_z / sqrt(t_z)
+  RF_HD int gather_seg_shift() const { return -1; }
+  RF_HD T map(T d, int z) const {
+    d = (T)((double)d * Ap[z]);
+    d = exp_t(d);
+    return (T)((double)d * Bp[z]);
+  }
+  RF_HD cplx<T> load(long long row, int k) const { return stream_load(base + row * (long long)M_of + k); }
+  RF_HD void store(long long row, int n, cplx<T> z, double& s1, double& s2) const {
+    z.x = map(z.x * scale, 2 * n);
+    z.y = map(z.y * scale, 2 * n + 1);
+    stream_store(base + row * (long long)M_of + n, z);
+    s1 += (double)z.x + (double)z.y;
+    s2 += (double)z.x * (double)z.x + (double)z.y * (double)z.y;
+  }
+  template <int NRT> RF_HD cplx<T> load2(long long tile, int rl, int kb, int ko) const { return load(tile * NRT + rl, kb + ko); }
+  template <int NRT> RF_HD void store2(long long tile, int rl, int nb, int no, cplx<T> z, double& s1, double& s2) const { store(tile * NRT + rl, nb + no, z, s1, s2); }
 };
 
 // tw = exp(+2 pi i q / (2M)), q in [0, 2M): t_k = tw[k], w_M^q = tw[2q]

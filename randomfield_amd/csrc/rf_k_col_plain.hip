@@ -63,7 +63,30 @@ hipError_t launch_xp(int N, const cplx<T>* src, ColGeom gs, cplx<T>* dst, ColGeo
     default: return hipErrorInvalidValue;
   }
 }
+// inverse pass in place + the Parseval partials (AccColIO)
+template <typename T>
+hipError_t launch_acc_t(int N, cplx<T>* base, ColGeom g, long long ncols, int kz0, int nzl, double* partials, const cplx<T>* tw, hipStream_t s, bool po) {
+  AccColIO<T> io; io.base = base; io.g = g; io.partials = partials; io.kz0 = kz0; io.nzl = nzl;
+  if (!po && (nzl <= 0 || (nzl & (nzl - 1)))) return hipErrorInvalidValue;
+  switch (N) {
+#define X(NN)                                                                                                    \
+  case NN: {                                                                                                     \
+    using C = typename ColSel<T, NN>::type;                                                                      \
+    if (!po && g.needs_wide(C::LMAX, C::TC, (int)sizeof(cplx<T>))) return hipErrorInvalidValue;                  \
+    return launch_one<C, +1, AccColIO<T>>(io, ncols, tw, s, po);                                                 \
+  }
+    RF_COL_SIZES(X)
+#undef X
+    default: return hipErrorInvalidValue;
+  }
+}
 }  // namespace
+
+hipError_t launch_col_plain_acc(int f64, int N, void* base, ColGeom g, long long ncols, int kz0, int nzl, double* partials, const void* tw,
+                                hipStream_t s, bool po) {
+  if (f64) return launch_acc_t<double>(N, (cplx<double>*)base, g, ncols, kz0, nzl, partials, (const cplx<double>*)tw, s, po);
+  return launch_acc_t<float>(N, (cplx<float>*)base, g, ncols, kz0, nzl, partials, (const cplx<float>*)tw, s, po);
+}
 
 hipError_t launch_col_xpose(int f64, int N, const void* src, ColGeom gs, void* dst, ColGeom gd, long long ncols, const void* tw,
                             hipStream_t s, bool po) {

@@ -40,6 +40,36 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const double* __re
   }
 }
 
+// sigma of the field from the y pass's Parseval partials (AccColIO), and the tables of the fused lognormal map that depend on it
+// (cosmotools.py:216: t = 1 + (sigma growth_z)^2): Ap = sqrt(log t) / sigma, Bp = density / sqrt(t).  One workgroup; fixed
+// summation order.  `sigma_as_float`: the reference's sigma is np.std of the array, a float32 for float32 data -- same here.
+__global__ __launch_bounds__(256) void lognormal_tables_kernel(const double* __restrict__ partials, long long n, double norm,
+                                                               const double* __restrict__ growth, const double* __restrict__ density,
+                                                               int nz, int sigma_as_float,
+                                                               double* __restrict__ sig, double* __restrict__ Ap, double* __restrict__ Bp) {
+  __shared__ double red[4];
+  __shared__ double sh_sigma;
+  double a = 0;
+  for (long long i = threadIdx.x; i < n; i += blockDim.x) a += partials[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double sigma = sqrt((red[0] + red[1] + red[2] + red[3]) * norm);
+    if (sigma_as_float) sigma = (double)(float)sigma;
+    sh_sigma = sigma;
+    sig[0] = sigma;
+  }
+  __syncthreads();
+  const double sigma = sh_sigma;
+  for (int z = threadIdx.x; z < nz; z += blockDim.x) {
+    const double g = sigma * growth[z], t = g * g + 1.0;      // np.square(sigma * growth) + 1
+    Ap[z] = sqrt(log(t)) / sigma;
+    Bp[z] = (density ? density[z] : 1.0) / sqrt(t);
+  }
+}
+
 // streaming (non-temporal) vector accesses of the elementwise maps: every element is read once and written once
 template <typename T, int VEC> struct MapVec {
   typedef T vt __attribute__((ext_vector_type(VEC)));
@@ -275,6 +305,12 @@ hipError_t launch_reduce_partials(const double* partials, long long n, double* s
   const long long chunk = (n + nb - 1) / nb;
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(nb), dim3(256), 0, s, partials, n, scratch, chunk);
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, s, (const double*)scratch, (long long)nb, stats, (long long)nb);
+  return hipGetLastError();
+}
+
+hipError_t launch_lognormal_tables(const double* partials, long long n, double norm, const double* growth, const double* density, int nz,
+                                   int sigma_as_float, double* sig, double* A, double* B, hipStream_t s) {
+  hipLaunchKernelGGL(lognormal_tables_kernel, dim3(1), dim3(256), 0, s, partials, n, norm, growth, density, nz, sigma_as_float, sig, A, B);
   return hipGetLastError();
 }
 

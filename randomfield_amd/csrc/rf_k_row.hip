@@ -66,6 +66,17 @@ template <typename T> bool xgather_ok_t(int M, int tc, int rb) {
     default: return false;
   }
 }
+template <typename T>
+hipError_t launch_lognormal_t(int M, cplx<T>* W, long long nrows, double scale, const double* Ap, const double* Bp,
+                              const cplx<T>* tw, double* partials, hipStream_t s, bool po) {
+  LognormalRowIO<T> io; io.base = W; io.scale = (T)scale; io.M_of = M; io.Ap = Ap; io.Bp = Bp;
+  switch (M) {
+#define X(MM) case MM: return launch_one<typename RowSel<T, MM>::type, LognormalRowIO<T>>(io, nrows, tw, partials, s, po);
+    RF_ROW_SIZES(X)
+#undef X
+    default: return hipErrorInvalidValue;
+  }
+}
 template <class C>
 hipError_t launch_fwd_one(const PlainRowFwdIO<typename C::T>& io, long long nrows, const cplx<typename C::T>* tw, hipStream_t s, bool po) {
   const long long ntiles = (nrows + C::NRT - 1) / C::NRT;
@@ -111,6 +122,11 @@ hipError_t launch_row_c2r_xgather(int f64, int M, const void* src, void* dst, lo
                                   const void* tw, double* partials, hipStream_t s, bool po) {
   if (f64) return launch_xgather_t<double>(M, (const cplx<double>*)src, (cplx<double>*)dst, nrows, scale, tc, rb, ny, (const cplx<double>*)tw, partials, s, po);
   return launch_xgather_t<float>(M, (const cplx<float>*)src, (cplx<float>*)dst, nrows, scale, tc, rb, ny, (const cplx<float>*)tw, partials, s, po);
+}
+hipError_t launch_row_c2r_lognormal(int f64, int M, void* W, long long nrows, double scale, const double* Ap, const double* Bp,
+                                    const void* tw, double* partials, hipStream_t s, bool po) {
+  if (f64) return launch_lognormal_t<double>(M, (cplx<double>*)W, nrows, scale, Ap, Bp, (const cplx<double>*)tw, partials, s, po);
+  return launch_lognormal_t<float>(M, (cplx<float>*)W, nrows, scale, Ap, Bp, (const cplx<float>*)tw, partials, s, po);
 }
 bool row_c2r_xgather_ok(int f64, int M, int tc, int rb) { return f64 ? xgather_ok_t<double>(M, tc, rb) : xgather_ok_t<float>(M, tc, rb); }
 hipError_t launch_row_r2c(int f64, int M, void* W, long long nrows, const void* tw, hipStream_t s, bool po) {

@@ -62,6 +62,13 @@ __global__ __launch_bounds__(C::NT, (col_min_waves<C, IO>())) void col_kernel(IO
     __syncthreads();
     F::pass_last(tid, tile, io, ltw, lds);
   }
+  if constexpr (IO::HAS_FINISH) {            // (AccColIO: the workgroup's sum of w |Y|^2 -> partials[tile])
+    double a = io.acc;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off);
+    __syncthreads();                         // the LDS tile is no longer read
+    io.finish(tid, C::NT, reinterpret_cast<double*>(rf_smem), tile, a, [] { __syncthreads(); });
+  }
 }
 
 // z pass: c2r rows + per-workgroup (sum, sum of squares) partials

@@ -76,6 +76,17 @@ hipError_t launch_row_c2r_gather(int f64, int M, const void* src, void* dst, lon
 hipError_t launch_row_c2r_xgather(int f64, int M, const void* src, void* dst, long long nrows, double scale, int tc, int rb, int ny,
                                   const void* tw, double* partials, hipStream_t s, bool prepare_only = false);
 bool row_c2r_xgather_ok(int f64, int M, int tc, int rb);
+// y pass (inverse, in place) that also leaves the Parseval partials of its output, one per tile (rf_fft.h AccColIO): columns
+// C = hi * nzl + (kz - kz0)
+hipError_t launch_col_plain_acc(int f64, int N, void* base, ColGeom g, long long ncols, int kz0, int nzl, double* partials, const void* tw,
+                                hipStream_t s, bool prepare_only = false);
+// sig[0] = sigma = sqrt(norm * sum of the n partials) (rounded to float32 first when sigma_as_float), Ap[z] = sqrt(log t) / sigma,
+// Bp[z] = density[z] / sqrt(t) (density may be null: 1), t = 1 + (sigma growth[z])^2
+hipError_t launch_lognormal_tables(const double* partials, long long n, double norm, const double* growth, const double* density, int nz,
+                                   int sigma_as_float, double* sig, double* Ap, double* Bp, hipStream_t s);
+// z pass with rho = exp(delta Ap_z) Bp_z in its epilogue (rf_fft.h LognormalRowIO)
+hipError_t launch_row_c2r_lognormal(int f64, int M, void* W, long long nrows, double scale, const double* Ap, const double* Bp,
+                                    const void* tw, double* partials, hipStream_t s, bool prepare_only = false);
 // forward z pass (r2c rows, in place: nz reals -> nz/2 complex with (X[0], X[nz/2]) packed in element 0)
 hipError_t launch_row_r2c(int f64, int M, void* W, long long nrows, const void* tw, hipStream_t s,
                           bool prepare_only = false);

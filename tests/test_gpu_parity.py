@@ -969,6 +969,54 @@ def test_config5_float64_lognormal_full_size(hip, dpower):
         assert got.dtype == np.float64 and np.all(got > 0)
         assert np.max(np.abs(got - want) / want) <= 1e-12
         assert abs(got.mean() - 1.0) < 0.02
+    # the same configuration fused (rf_realise_lognormal): sigma from the y pass (Parseval), the map in the z pass's epilogue
+    dens = 1.0 + 0.25 * np.arange(n) / n
+    plan.set_z_tables(growth, dens)
+    sigma = plan.realise_lognormal(seed=5)
+    assert abs(sigma - std) <= 1e-13 * std                      # device sigma (Parseval) == rf_moments' sigma of the Gaussian field
+    mean_rho, std_rho = plan.moments()                           # (now the moments of the density field)
+    for x, g in before.items():
+        got = plan.download_real(x0=x, x1=x + 1)
+        want = cpu_ref.scale_z(cpu_ref.lognormal(g.copy(), growth, sigma=sigma), dens)
+        assert got.dtype == np.float64 and np.all(got > 0)
+        assert np.max(np.abs(got - want) / want) <= 1e-12
+    assert abs(mean_rho - dens.mean()) < 0.02
+    plan.close()
+
+
+@pytest.mark.parametrize("shape,dtype", [((64, 64, 128), np.complex64), ((64, 64, 128), np.complex128), ((256, 256, 256), np.complex64),
+                                         ((16, 32, 64), np.complex128), ((512, 256, 1024), np.complex64)])
+def test_fused_lognormal_realisation(hip, dpower, shape, dtype):
+    """rf_realise_lognormal == rf_realise -> rf_moments -> rf_lognormal -> rf_scale_z: sigma from Parseval equals the rms of
+    the Gaussian field (float64: 1e-13; float32: the float32 rounding of it), and the density field equals the oracle's map
+    of the unfused Gaussian field (float64: 1e-12; float32: 3e-6 = an ulp of expf and of its argument), with native and with host-supplied deviates."""
+    k, Pk = dpower
+    nx, ny, nz = shape
+    f64 = dtype == np.complex128
+    plan = make_plan(hip, shape, dtype, k, Pk)
+    growth = np.exp(-0.5 * np.arange(nz) / nz)
+    dens = 0.5 + np.arange(nz) / nz
+    for noise in (None, cpu_ref.reference_noise(11, nx * ny * (nz // 2 + 1))):
+        for density in (None, dens):
+            plan.realise(seed=21, noise=noise)
+            delta = plan.download_real()
+            mean, std = plan.moments()
+            plan.set_z_tables(growth, density)
+            sigma = plan.realise_lognormal(seed=21, noise=noise)
+            rho = plan.download_real()
+            if f64:
+                assert abs(sigma - std) <= 1e-13 * std
+            else:
+                assert abs(sigma - std) <= 1e-6 * std and sigma == float(np.float32(sigma))    # np.std of float32 data is a float32
+            want = cpu_ref.lognormal(delta.copy(), growth, sigma=delta.dtype.type(sigma))
+            if density is not None:
+                want = cpu_ref.scale_z(want, density)
+            assert rho.dtype == delta.dtype and np.all(rho > 0)
+            assert np.max(np.abs(rho - want) / want) <= (1e-12 if f64 else 3e-6)     # (float32: expf ulp + |x| * float32 rounding of the field)
+            m2, s2 = plan.moments()
+            assert abs(m2 - rho.astype(np.float64).mean()) <= 1e-9 and abs(s2 - rho.astype(np.float64).std()) <= 1e-6 * s2
+    with pytest.raises(RuntimeError):
+        hip.DevicePlan(16, 16, 16).realise_lognormal(seed=1)         # tables first
     plan.close()
 
 
