@@ -162,6 +162,8 @@ class DevicePlan(object):
         self.nx, self.ny, self.nz = int(nx), int(ny), int(nz)
         self.nranks, self.rank = int(nranks), int(rank)
         self.nx_local = self.nx // self.nranks          # x planes of the real-space field held by this rank
+        # power-of-two axes run on the tiled kernels (rf_shape_supported == 1); any other even shape on the generic ones
+        self.tiled = int(load().rf_shape_supported(self.nx, self.ny, self.nz)) == 1
         self.complex_dtype = dtype
         self.real_dtype = np.dtype(np.float32 if dtype == np.complex64 else np.float64)
         self._h = ctypes.c_void_p()

@@ -253,6 +253,45 @@ class Generator(object):
             print("Delta field has standard deviation {0:.3f}.".format(self.delta_field_rms))
         return delta
 
+    def generate_density_field(self, smoothing_length_Mpc_h=0., seed=None, *, download=True):
+        """
+        ``generate_delta_field(save_potential=False)`` followed by ``convert_delta_to_density(apply_lognormal_transform=True)``
+        (generate.py:191-199,218-219 and 266-273) as ONE device call (an extension; the reference has no such method).
+
+        On a single-GPU hip plan with power-of-two axes the rms of the Gaussian field is taken from the transform's second
+        pass (Parseval) and the lognormal map and the mean-density factor run in the epilogue of the last pass
+        (``rf_realise_lognormal``): five sweeps of the array instead of seven, no host round trip for sigma.  The result is
+        the reference's density field up to a few ulp in the argument of ``exp``.  Everywhere else (numpy backend, multi-GPU
+        plans, generic shapes) the two reference calls run one after the other.  ``delta_field_rms`` is set as usual.
+        """
+        growth = self._need_table("growth_function")
+        density = self._need_table("mean_matter_density")
+        dev = self.plan_c2r.device if self.backend == "hip" else None
+        fused = dev is not None and not self.distributed and dev.nranks == 1 and dev.tiled
+        if not fused:
+            self.generate_delta_field(smoothing_length_Mpc_h, seed, save_potential=False, download=False) if self.backend == "hip" \
+                else self.generate_delta_field(smoothing_length_Mpc_h, seed, save_potential=False)
+            return self.convert_delta_to_density(apply_lognormal_transform=True, download=download)
+        nx, ny, nz = self.plan_c2r.shape
+        self.smoothed_power = powertools.filter_power(self.power, smoothing_length_Mpc_h)
+        log10_k, sigma = powertools.sigma_table(self.smoothed_power, (nx, ny, nz), self.grid_spacing_Mpc_h)
+        dev.set_power(log10_k, sigma, if_changed=True)
+        tables = (np.asarray(growth, np.float64).tobytes(), np.asarray(density, np.float64).tobytes())
+        if getattr(dev, "_z_tables_key", None) != tables:
+            dev.set_z_tables(growth, density)
+            dev._z_tables_key = tables
+        if self.rng == "reference":
+            dev.reference_noise(seed, single=self.plan_c2r.data_out.dtype == np.float32)
+            rms = dev.realise_lognormal(0, "resident")
+        else:
+            rms = dev.realise_lognormal(self._native_seed(seed), None)
+        self.potential = None
+        self.delta_field_rms = self.plan_c2r.data_out.dtype.type(rms)
+        self._field_on_host = False
+        if self.verbose:
+            print("Delta field has standard deviation {0:.3f}.".format(self.delta_field_rms))
+        return self.download_field() if download else None
+
     def download_field(self):
         """Copy the device-resident field into the plan's host buffer and return the view."""
         if self.backend == "hip" and not self._field_on_host:

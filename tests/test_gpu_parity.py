@@ -1477,3 +1477,23 @@ def test_generator_notices_tables_changed_behind_its_back(hip):
 def _other_tables():
     x = np.linspace(-3.0, 1.5, 64)
     return x, 100.0 * np.exp(-0.5 * (x + 1.0) ** 2)
+
+
+def test_generator_density_field_fused(hip, dpower):
+    """Generator.generate_density_field == generate_delta_field(save_potential=False) + convert_delta_to_density(), through the
+    fused device call on a tiled single-GPU plan (and through the two reference calls on a generic shape)."""
+    from randomfield_amd import Generator
+    for shape, rng in (((64, 64, 128), "native"), ((64, 64, 128), "reference"), ((40, 60, 80), "native")):
+        nz = shape[2]
+        kw = dict(growth_function=np.exp(-0.4 * np.arange(nz) / nz), mean_matter_density=1.0 + 0.5 * np.arange(nz) / nz, rng=rng, backend="hip")
+        a = Generator(*shape, SPACING, **kw)
+        a.generate_delta_field(seed=77, save_potential=False)
+        want = a.convert_delta_to_density().copy()
+        rms = float(a.delta_field_rms)
+        a.plan_c2r.device.close()
+        b = Generator(*shape, SPACING, **kw)
+        got = b.generate_density_field(seed=77)
+        assert got.shape == shape and got.dtype == np.float32 and np.all(got > 0)
+        assert abs(float(b.delta_field_rms) - rms) <= 1e-6 * rms
+        assert np.max(np.abs(got - want) / want) <= 3e-6
+        b.plan_c2r.device.close()
