@@ -127,6 +127,12 @@ def other_configs(power, spacing, device):
     t = _timed(reference_rng, plan.sync)
     out["1024^3 f32 rng='reference' (same field as the reference for the same seed)"] = entry(
         1024, t, 20 * (1 + 2 / 1024), ms_mt19937_replay=round(state["rng"] * 1e3, 3))
+    # ten of them back to back: the replay of seed i + 1 on a second stream under the y / z passes of seed i
+    batch = [next(seeds) for _ in range(10)]
+    plan.realise_batch_reference(batch[:2], want_rms=False)
+    t = _timed(lambda: plan.realise_batch_reference(batch, want_rms=False), plan.sync, reps=3, warm=0) / len(batch)
+    out["1024^3 f32 rng='reference', 10 back to back (rf_realise_batch_reference)"] = entry(
+        1024, t, 20 * (1 + 2 / 1024), note="per realisation; includes the host-side seeding of the ten MT19937 states")
     plan.close()
     # the reference API's default call: Generator.generate_delta_field(save_potential=True), field kept on the device
     for rng in ("native", "reference"):

@@ -103,6 +103,11 @@ int rf_noise_mt19937(rf_plan* plan, const uint32_t* state624, unsigned long long
  * generation pass locates them.  rf_realise / rf_realise_potential with RF_NOISE_RESIDENT use whichever copy is resident; rf_generate,
  * rf_download_noise and float64 plans need the float64 ones (single = 0, = rf_noise_mt19937). */
 int rf_noise_mt19937_ex(rf_plan* plan, const uint32_t* state624, unsigned long long* accepted, int single);
+/* n same-seed realisations back to back (random.py:24-28 for each seed; single-GPU complex64 plans on the fast generation path):
+ * the replay of seed i + 1 runs on a second stream under the y / z passes of seed i.  states = n x 624 words (MT19937 start
+ * states, e.g. numpy's init_genrand / init_by_array of each seed); rms_out (n, optional) = np.std of every field.  The field of
+ * the last seed is the plan's current field; every field equals what rf_noise_mt19937_ex(single) + rf_realise(RESIDENT) gives. */
+int rf_realise_batch_reference(rf_plan* plan, const uint32_t* states, int n, double* rms_out);
 /* copy deviates [first, first+count) of the device noise buffer to the host (tests) */
 int rf_download_noise(rf_plan* plan, double* host, unsigned long long first, unsigned long long count);
 

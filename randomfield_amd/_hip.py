@@ -74,6 +74,7 @@ SIGNATURES = {
     "rf_set_z_tables": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.c_int]),
     "rf_realise_lognormal": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.POINTER(ctypes.c_double),
                                             ctypes.POINTER(ctypes.c_double)]),
+    "rf_realise_batch_reference": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32), ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
     "rf_yz_slabs": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "rf_comm_unique_id": (ctypes.c_int, [ctypes.c_void_p]),
     "rf_comm_init": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
@@ -270,6 +271,28 @@ class DevicePlan(object):
         array of integers (``init_by_array``) or None.  Afterwards pass ``noise='resident'``.
         ``single=True`` (complex64 plans) keeps float32 copies of the deviates instead of the float64 values: the fused
         ``realise`` / ``realise_potential`` read half as many bytes; ``generate`` and ``download_noise`` need float64."""
+        self._mt_prepare()
+        from . import mt19937
+        state = np.ascontiguousarray(mt19937.seed_state(seed), np.uint32)
+        acc = ctypes.c_ulonglong(0)
+        check(self._lib.rf_noise_mt19937_ex(self._h, state.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)),
+                                            ctypes.byref(acc), 1 if single else 0), "rf_noise_mt19937_ex")
+        return acc.value
+
+    def realise_batch_reference(self, seeds, want_rms=True):
+        """``len(seeds)`` same-seed realisations back to back (random.py:24-28 per seed): the MT19937 replay of seed i + 1 runs
+        on a second stream under the y / z passes of seed i (rf_realise_batch_reference).  complex64 plans, fast generation
+        path.  The field of the last seed stays on the device; returns the rms of every field."""
+        self._mt_prepare()
+        from . import mt19937
+        states = np.ascontiguousarray(np.stack([np.asarray(mt19937.seed_state(sd), np.uint32) for sd in seeds]), np.uint32)
+        rms = np.empty(len(states), np.float64) if want_rms else None
+        check(self._lib.rf_realise_batch_reference(self._h, states.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), len(states),
+                                                   _dp(rms) if want_rms else None), "rf_realise_batch_reference")
+        return rms
+
+    def _mt_prepare(self):
+        """upload the jump table of the MT19937 replay for this grid (once per plan)"""
         from . import mt19937
         if not getattr(self, "_mt_ready", False):
             # segment length for this grid's stream (a whole multiple of the GPU's wave slots on large grids), the stages
@@ -290,11 +313,6 @@ class DevicePlan(object):
                                            npos.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), stride,
                                            bps, mt19937.TREE_RADIX), "rf_mt_set_jump")
             self._mt_ready = True
-        state = np.ascontiguousarray(mt19937.seed_state(seed), np.uint32)
-        acc = ctypes.c_ulonglong(0)
-        check(self._lib.rf_noise_mt19937_ex(self._h, state.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)),
-                                            ctypes.byref(acc), 1 if single else 0), "rf_noise_mt19937_ex")
-        return acc.value
 
     def lensing_potential(self, cot_z, spacing, i_min):
         """psi of the real field on the device into the auxiliary buffer (generate.py:352-416)."""

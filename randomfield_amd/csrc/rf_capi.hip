@@ -112,6 +112,8 @@ struct rf_plan {
   // y and z passes slab by slab of x planes: -1 = automatic (slabs of about the Infinity Cache's size),
   // 0 = whole-grid passes, > 0 = this many x planes per slab (RF_FLAG_YZ_SLAB_PLANES)
   int yz_slab = -1;
+  hipStream_t aux_stream = nullptr;       // rf_realise_batch_reference: the stream the MT19937 replays run on
+  hipEvent_t bev[2] = {nullptr, nullptr}; // ... replay finished / generation pass has read the runs
   std::vector<hipEvent_t> slab_ev;        // timed runs: after y(i), after z(i)
   int slab_timed = 0;                     // slabs of the last timed run (0: whole-grid passes, ev[2] / ev[3] apply)
   void* P = nullptr;                      // lazy: saved potential, API layout
@@ -880,6 +882,9 @@ int rf_plan_destroy(rf_plan* p) {
   for (auto& ev : p->ev)
     if (ev) (void)hipEventDestroy(ev);
   for (auto& ev : p->slab_ev) (void)hipEventDestroy(ev);
+  for (auto& ev : p->bev)
+    if (ev) (void)hipEventDestroy(ev);
+  if (p->aux_stream) (void)hipStreamDestroy(p->aux_stream);
   if (p->own_stream) (void)hipStreamDestroy(p->own_stream);
   delete p;
   return 0;
@@ -1555,6 +1560,85 @@ int rf_noise_mt19937(rf_plan* p, const uint32_t* state624, unsigned long long* a
   return rf_noise_mt19937_ex(p, state624, accepted, 0);
 }
 
+namespace {
+// sizes of one replay of RandomState(seed).normal for this plan's grid (rf_k_mt.hip)
+struct MtGeom {
+  unsigned long long ncells, attempts, cap;
+  long long total_blocks;
+  int nseg, stages;
+  size_t need;          // bytes of the runs: nseg * cap pairs
+};
+int mt_geom(rf_plan* p, int single, MtGeom& g) {
+  g.ncells = (unsigned long long)p->nx * p->ny * (p->nzc + 1);
+  // polar attempts to generate: acceptance pi/4, margin of 10 sigma + 1024 (mt19937.attempts_needed)
+  const double pa = 0.78539816339744830962;
+  g.attempts = (unsigned long long)std::ceil((double)g.ncells / pa + 10.0 * std::sqrt((double)g.ncells * (1 - pa)) / pa + 1024.0);
+  g.total_blocks = (long long)((4 * g.attempts + 623) / 624);
+  g.nseg = (int)((g.total_blocks + p->mt_bps - 1) / p->mt_bps);
+  // stages of the radix-R jump tree: stage t needs the R - 1 polynomials t^(m R^t L), rows t (R - 1) .. of the table
+  const int R = p->mt_radix;
+  g.stages = 0;
+  long long reach = 1;
+  while (reach < g.nseg) { reach *= R; ++g.stages; }
+  RF_REQUIRE(g.stages * (R - 1) <= (int)p->mt_npos.size(), "grid too large for the uploaded jump table");
+  g.cap = (unsigned long long)p->mt_bps * (624 / 4);
+  g.need = (size_t)g.nseg * g.cap * (single ? 2 * sizeof(float) : 2 * sizeof(double));
+  return 0;
+}
+int mt_ensure_buffers(rf_plan* p, const MtGeom& g) {
+  const size_t nstates = (size_t)g.nseg;
+  if (p->mt_states_cap < nstates) {
+    if (p->mt_states) RF_HIP(hipFree(p->mt_states));
+    p->mt_states = nullptr;
+    RF_HIP(hipMalloc((void**)&p->mt_states, nstates * 624 * sizeof(uint32_t)));
+    p->mt_states_cap = nstates;
+  }
+  if (p->mt_seg_cap < (size_t)g.nseg + 1) {
+    if (p->mt_counts) RF_HIP(hipFree(p->mt_counts));
+    if (p->mt_offsets) RF_HIP(hipFree(p->mt_offsets));
+    p->mt_counts = p->mt_offsets = nullptr;
+    RF_HIP(hipMalloc((void**)&p->mt_counts, ((size_t)g.nseg + 1) * sizeof(unsigned long long)));
+    RF_HIP(hipMalloc((void**)&p->mt_offsets, ((size_t)g.nseg + 1) * sizeof(unsigned long long)));
+    if (p->mt_pairs) RF_HIP(hipFree(p->mt_pairs));
+    p->mt_pairs = nullptr;
+    RF_HIP(hipMalloc((void**)&p->mt_pairs, 2 * ((size_t)g.nseg + 3) * sizeof(unsigned long long)));     // + sentinel pairs
+    p->mt_seg_cap = (size_t)g.nseg + 1;
+  }
+  if (p->mt_scratch_bytes < g.need) {
+    if (p->mt_scratch) RF_HIP(hipFree(p->mt_scratch));
+    p->mt_scratch = nullptr; p->mt_scratch_bytes = 0;
+    RF_HIP(hipMalloc(&p->mt_scratch, g.need));
+    p->mt_scratch_bytes = g.need;
+  }
+  return 0;
+}
+// the replay itself on stream s, from the start state in p->mt_states[0 .. 624): jump tree, ONE generation pass, scan (and the
+// move into cell order for float64 deviates).  No host synchronisation.
+int mt_queue(rf_plan* p, const MtGeom& g, int single, hipStream_t s) {
+  const int R = p->mt_radix;
+  // jump tree: stage t turns the start states of segments [0, R^t) into those of [R^t, R^(t+1))
+  long long dist = 1;
+  for (int t = 0; t < g.stages; ++t, dist *= R) {
+    const int nsrc = (int)(dist < g.nseg ? dist : g.nseg);
+    RF_HIP(launch_mt_jump(p->mt_states, p->mt_pos + (size_t)t * (R - 1) * p->mt_stride, p->mt_npos_dev + 2 * t * (R - 1), p->mt_stride, nsrc,
+                          dist, R - 1, g.nseg, s));
+  }
+  // ONE generation pass: every segment writes its accepted pairs densely into its own run of the scratch array
+  // (capacity = its attempts) and counts them; a scan of the counts gives each run its first cell, and a copy kernel
+  // moves the runs into place.  (Round 1 generated every block twice -- a count pass, then a fill pass that knew the
+  // offsets: 2.5 + 3.3 ms against 3.3 + 1.x ms for fill + move.)  A kz-slab rank replays the WHOLE stream (where a
+  // deviate goes depends on every earlier acceptance) and keeps the deviates of its own planes while moving.
+  RF_HIP(launch_mt_polar(single != 0, p->mt_states, g.nseg, p->mt_bps, g.total_blocks, p->mt_counts, p->mt_scratch, g.cap, s));
+  RF_HIP(launch_mt_scan(p->mt_counts, p->mt_offsets, g.nseg, s, p->mt_pairs));
+  // float64 deviates are moved into cell order (and cut to this rank's planes); float32 ones stay in the segments' runs:
+  // the generation pass finds cell c through the scan (slack_cell), which saves the 1.7 ms copy per 1024^3
+  if (!single)
+    RF_HIP(launch_mt_compact(false, p->mt_scratch, p->mt_counts, p->mt_offsets, g.nseg, g.cap, p->noise, g.ncells, (int)p->nzc + 1,
+                             (int)p->nzl + 1, p->kz0, s));
+  return 0;
+}
+}  // namespace
+
 int rf_noise_mt19937_ex(rf_plan* p, const uint32_t* state624, unsigned long long* accepted, int single) {
   RF_REQUIRE(p && state624, "null argument");
   // `single` is a request: plans without the fast float32 generation pass (float64, generic shapes, exact-generation
@@ -1565,74 +1649,22 @@ int rf_noise_mt19937_ex(rf_plan* p, const uint32_t* state624, unsigned long long
   RF_HIP(hipSetDevice(p->device));
   if (!single)
     if (int rc = ensure_noise(p)) return rc;
-  const unsigned long long ncells = (unsigned long long)p->nx * p->ny * (p->nzc + 1);
-  // polar attempts to generate: acceptance pi/4, margin of 10 sigma + 1024 (mt19937.attempts_needed)
-  const double pa = 0.78539816339744830962;
-  const unsigned long long attempts = (unsigned long long)std::ceil((double)ncells / pa + 10.0 * std::sqrt((double)ncells * (1 - pa)) / pa + 1024.0);
-  const long long total_blocks = (long long)((4 * attempts + 623) / 624);
-  const int nseg = (int)((total_blocks + p->mt_bps - 1) / p->mt_bps);
-  // stages of the radix-R jump tree: stage t needs the R - 1 polynomials t^(m R^t L), rows t (R - 1) .. of the table
-  const int R = p->mt_radix;
-  int stages = 0;
-  long long reach = 1;
-  while (reach < nseg) { reach *= R; ++stages; }
-  RF_REQUIRE(stages * (R - 1) <= (int)p->mt_npos.size(), "grid too large for the uploaded jump table");
-  const size_t nstates = (size_t)nseg;
-  if (p->mt_states_cap < nstates) {
-    if (p->mt_states) RF_HIP(hipFree(p->mt_states));
-    p->mt_states = nullptr;
-    RF_HIP(hipMalloc((void**)&p->mt_states, nstates * 624 * sizeof(uint32_t)));
-    p->mt_states_cap = nstates;
-  }
-  if (p->mt_seg_cap < (size_t)nseg + 1) {
-    if (p->mt_counts) RF_HIP(hipFree(p->mt_counts));
-    if (p->mt_offsets) RF_HIP(hipFree(p->mt_offsets));
-    p->mt_counts = p->mt_offsets = nullptr;
-    RF_HIP(hipMalloc((void**)&p->mt_counts, ((size_t)nseg + 1) * sizeof(unsigned long long)));
-    RF_HIP(hipMalloc((void**)&p->mt_offsets, ((size_t)nseg + 1) * sizeof(unsigned long long)));
-    if (p->mt_pairs) RF_HIP(hipFree(p->mt_pairs));
-    p->mt_pairs = nullptr;
-    RF_HIP(hipMalloc((void**)&p->mt_pairs, 2 * ((size_t)nseg + 3) * sizeof(unsigned long long)));     // + sentinel pairs
-    p->mt_seg_cap = (size_t)nseg + 1;
-  }
+  MtGeom g;
+  if (int rc = mt_geom(p, single, g)) return rc;
+  if (int rc = mt_ensure_buffers(p, g)) return rc;
   hipStream_t s = p->stream;
   RF_HIP(hipMemcpyAsync(p->mt_states, state624, 624 * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-  // jump tree: stage t turns the start states of segments [0, R^t) into those of [R^t, R^(t+1))
-  long long dist = 1;
-  for (int t = 0; t < stages; ++t, dist *= R) {
-    const int nsrc = (int)(dist < nseg ? dist : nseg);
-    RF_HIP(launch_mt_jump(p->mt_states, p->mt_pos + (size_t)t * (R - 1) * p->mt_stride, p->mt_npos_dev + 2 * t * (R - 1), p->mt_stride, nsrc,
-                          dist, R - 1, nseg, s));
-  }
-  // ONE generation pass: every segment writes its accepted pairs densely into its own run of the scratch array
-  // (capacity = its attempts) and counts them; a scan of the counts gives each run its first cell, and a copy kernel
-  // moves the runs into place.  (Round 1 generated every block twice -- a count pass, then a fill pass that knew the
-  // offsets: 2.5 + 3.3 ms against 3.3 + 1.x ms for fill + move.)  A kz-slab rank replays the WHOLE stream (where a
-  // deviate goes depends on every earlier acceptance) and keeps the deviates of its own planes while moving.
-  const unsigned long long cap = (unsigned long long)p->mt_bps * (624 / 4);
-  const size_t pair = single ? 2 * sizeof(float) : 2 * sizeof(double), need = (size_t)nseg * cap * pair;
-  if (p->mt_scratch_bytes < need) {
-    if (p->mt_scratch) RF_HIP(hipFree(p->mt_scratch));
-    p->mt_scratch = nullptr; p->mt_scratch_bytes = 0;
-    RF_HIP(hipMalloc(&p->mt_scratch, need));
-    p->mt_scratch_bytes = need;
-  }
-  RF_HIP(launch_mt_polar(single != 0, p->mt_states, nseg, p->mt_bps, total_blocks, p->mt_counts, p->mt_scratch, cap, s));
-  RF_HIP(launch_mt_scan(p->mt_counts, p->mt_offsets, nseg, s, p->mt_pairs));
-  // float64 deviates are moved into cell order (and cut to this rank's planes); float32 ones stay in the segments' runs:
-  // the generation pass finds cell c through the scan (slack_cell), which saves the 1.7 ms copy per 1024^3
-  if (!single)
-    RF_HIP(launch_mt_compact(false, p->mt_scratch, p->mt_counts, p->mt_offsets, nseg, cap, p->noise, ncells, (int)p->nzc + 1,
-                             (int)p->nzl + 1, p->kz0, s));
+  if (int rc = mt_queue(p, g, single, s)) return rc;
+  const int nseg = g.nseg;
   unsigned long long total = 0, full = 0;
   RF_HIP(hipMemcpyAsync(&total, p->mt_offsets + nseg, sizeof(total), hipMemcpyDeviceToHost, s));
   RF_HIP(hipMemcpyAsync(&full, p->mt_offsets + (nseg > 1 ? nseg - 1 : 1), sizeof(full), hipMemcpyDeviceToHost, s));
   RF_HIP(hipStreamSynchronize(s));
   p->nseg = nseg;
-  p->seg_cap = cap;
+  p->seg_cap = g.cap;
   p->seg_inv = full > 0 ? (double)(nseg > 1 ? nseg - 1 : 1) / (double)full : 0.0;     // the last segment may be a short one
   if (accepted) *accepted = total;
-  RF_REQUIRE(total >= ncells, "MT19937 replay: not enough accepted polar attempts (increase the margin)");
+  RF_REQUIRE(total >= g.ncells, "MT19937 replay: not enough accepted polar attempts (increase the margin)");
   p->noise_resident = !single;
   p->noise32_resident = single != 0;
   if (!single) {
@@ -1642,6 +1674,97 @@ int rf_noise_mt19937_ex(rf_plan* p, const uint32_t* state624, unsigned long long
     RF_HIP(hipFree(p->mt_scratch));
     p->mt_scratch = nullptr;
     p->mt_scratch_bytes = 0;
+  }
+  return 0;
+}
+
+// Same-seed realisations back to back (random.py:24-28 for n seeds): the replay of seed i + 1 (VALU / LDS-bound, second stream)
+// runs under the y and z passes of seed i (HBM-bound); ONE set of runs -- the replay of seed i + 1 starts when the generation
+// pass of seed i has read them, the generation pass of seed i + 1 when the replay has finished.  complex64 plans with the fast
+// generation path (float32 pairs).  states: n x 624 words (mt19937.seed_state); rms_out: n, optional.
+int rf_realise_batch_reference(rf_plan* p, const uint32_t* states, int n, double* rms_out) {
+  RF_REQUIRE(p && states, "null argument");
+  RF_REQUIRE(!p->unpacked, "this call does not apply to an unpacked c2c plan");
+  RF_REQUIRE(n >= 1, "need at least one seed");
+  RF_REQUIRE(p->have_kgrid && p->have_power, "rf_set_kgrid and rf_set_power must be called first");
+  RF_REQUIRE(p->mt_pos && !p->mt_npos.empty(), "rf_mt_set_jump must be called first");
+  RF_REQUIRE(p->nranks == 1 && !p->force_slab && !p->generic && !p->f64 && p->have_fast && !p->exact_gen,
+             "rf_realise_batch_reference is for single-GPU complex64 plans on the fast generation path; loop rf_noise_mt19937 + rf_realise otherwise");
+  RF_HIP(hipSetDevice(p->device));
+  MtGeom g;
+  if (int rc = mt_geom(p, 1, g)) return rc;
+  if (int rc = mt_ensure_buffers(p, g)) return rc;
+  if (int rc = ensure_x(p)) return rc;
+  RF_HIP(hipStreamSynchronize(p->stream));
+  if (p->stats_cap < n) {
+    drop_graphs(p);
+    if (p->stats) RF_HIP(hipFree(p->stats));
+    p->stats = nullptr;
+    RF_HIP(hipMalloc((void**)&p->stats, 2 * (size_t)(n + 64) * sizeof(double)));
+    p->stats_cap = n + 64;
+  }
+  if (!p->aux_stream) {
+    RF_HIP(hipStreamCreateWithFlags(&p->aux_stream, hipStreamNonBlocking));
+    for (auto& e : p->bev) RF_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  // all start states and the per-seed accepted totals live on the device for the length of the batch
+  uint32_t* dstates = nullptr;
+  unsigned long long* dtotals = nullptr;
+  RF_HIP(hipMalloc((void**)&dstates, (size_t)n * 624 * sizeof(uint32_t)));
+  RF_HIP(hipMalloc((void**)&dtotals, (size_t)n * sizeof(unsigned long long)));
+  auto release = [&](int rc) { (void)hipFree(dstates); (void)hipFree(dtotals); return rc; };
+  if (hipMemcpy(dstates, states, (size_t)n * 624 * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) return release(fail(2, "upload of the start states failed"));
+  hipStream_t S = p->stream, R = p->aux_stream;
+  p->nseg = g.nseg;
+  p->seg_cap = g.cap;
+  // first guess of a cell's segment from the EXPECTED acceptances per segment (the exact mean needs a round trip to the host per
+  // seed): binomial drift over all segments is a tenth of a segment, slack_cell corrects +-1
+  p->seg_inv = 1.0 / ((double)g.cap * 0.78539816339744830962);
+  p->noise_resident = false;
+  p->noise32_resident = true;
+  int rc = 0;
+  auto replay = [&](int i) -> int {
+    RF_HIP(hipMemcpyAsync(p->mt_states, dstates + (size_t)i * 624, 624 * sizeof(uint32_t), hipMemcpyDeviceToDevice, R));
+    if (int r = mt_queue(p, g, 1, R)) return r;
+    RF_HIP(hipMemcpyAsync(dtotals + i, p->mt_offsets + g.nseg, sizeof(unsigned long long), hipMemcpyDeviceToDevice, R));
+    RF_HIP(hipEventRecord(p->bev[0], R));
+    return 0;
+  };
+  RF_HIP(hipEventRecord(p->ev[0], S));
+  RF_HIP(hipEventRecord(p->bev[1], S));
+  RF_HIP(hipStreamWaitEvent(R, p->bev[1], 0));          // (whatever ran on the main stream before the batch has finished with the runs)
+  if ((rc = replay(0))) return release(rc);
+  for (int i = 0; i < n && !rc; ++i) {
+    RF_HIP(hipStreamWaitEvent(S, p->bev[0], 0));        // the runs of seed i are complete
+    p->resident_fast = true;
+    const bool xp = p->X && xpose_ok(p);
+    rc = queue_x(p, make_gen(p, 0, RF_NOISE_RESIDENT, false), nullptr, xp ? p->X : p->W, S, false);
+    p->resident_fast = false;
+    if (rc) break;
+    RF_HIP(hipEventRecord(p->bev[1], S));               // the generation pass of seed i has read the runs
+    if (i + 1 < n) {
+      RF_HIP(hipStreamWaitEvent(R, p->bev[1], 0));
+      if ((rc = replay(i + 1))) break;
+    }
+    rc = queue_yz(p, p->W, S, p->stats + 2 * i, false);
+  }
+  if (rc) { (void)hipStreamSynchronize(R); (void)hipStreamSynchronize(S); return release(rc); }
+  RF_HIP(hipEventRecord(p->ev[4], S));
+  std::vector<unsigned long long> totals((size_t)n);
+  std::vector<double> st(2 * (size_t)n);
+  RF_HIP(hipStreamSynchronize(R));
+  RF_HIP(hipMemcpyAsync(st.data(), p->stats, st.size() * sizeof(double), hipMemcpyDeviceToHost, S));
+  RF_HIP(hipStreamSynchronize(S));
+  if (hipMemcpy(totals.data(), dtotals, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return release(fail(2, "download of the accepted counts failed"));
+  release(0);
+  for (int i = 0; i < n; ++i) RF_REQUIRE(totals[i] >= g.ncells, "MT19937 replay: not enough accepted polar attempts (increase the margin)");
+  p->cur = p->W; p->timed = false; p->real_valid = true; p->stats_valid = true; p->stats_slot = n - 1; p->k_valid = false;
+  if (rms_out) {
+    const double cnt = (double)p->nx * p->ny * p->nz;
+    for (int i = 0; i < n; ++i) {
+      const double m = st[2 * i] / cnt, v = st[2 * i + 1] / cnt - m * m;
+      rms_out[i] = v > 0 ? std::sqrt(v) : 0.0;
+    }
   }
   return 0;
 }

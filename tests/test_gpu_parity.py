@@ -1497,3 +1497,33 @@ def test_generator_density_field_fused(hip, dpower):
         assert abs(float(b.delta_field_rms) - rms) <= 1e-6 * rms
         assert np.max(np.abs(got - want) / want) <= 3e-6
         b.plan_c2r.device.close()
+
+
+@pytest.mark.parametrize("shape", [(64, 64, 64), (256, 256, 256), (128, 64, 512)])
+def test_batched_reference_stream_realisations(hip, dpower, shape):
+    """rf_realise_batch_reference: n same-seed realisations with the MT19937 replay of seed i + 1 running under the passes of
+    seed i (second stream, one set of runs) give, seed by seed, the field of rf_noise_mt19937_ex(single) + rf_realise(RESIDENT)
+    -- and that field is the reference's (oracle chain on numpy's own deviates)."""
+    k, Pk = dpower
+    nx, ny, nz = shape
+    plan = make_plan(hip, shape, np.complex64, k, Pk)
+    seeds = [123, 7, 2 ** 32 - 1, 5]
+    want, rms_want = [], []
+    for sd in seeds:
+        plan.reference_noise(sd, single=True)
+        plan.realise(noise="resident")
+        want.append(plan.download_real())
+        rms_want.append(plan.moments()[1])
+    for n in (1, len(seeds)):
+        rms = plan.realise_batch_reference(seeds[:n])
+        assert np.array_equal(plan.download_real(), want[n - 1])            # the last seed's field is the current one
+        assert np.max(np.abs(rms - np.array(rms_want[:n]))) <= 1e-12 * max(rms_want)
+    # every field of a batch, not only the last: batches that END at each seed
+    for n in (2, 3):
+        plan.realise_batch_reference(seeds[:n], want_rms=False)
+        assert np.array_equal(plan.download_real(), want[n - 1])
+    ref, rms0 = cpu_ref.generate_delta_field(nx, ny, nz, SPACING, k, Pk, seed=123, double_fft=True)
+    assert np.max(np.abs(want[0] - ref)) <= TOL_F32 * rms0
+    plan.realise(seed=3)                                                    # (the plan goes back to other work afterwards)
+    assert abs(plan.moments()[1] - rms0) < 0.2 * rms0
+    plan.close()
