@@ -116,7 +116,8 @@ struct rf_plan {
   hipEvent_t bev[2] = {nullptr, nullptr}; // ... replay finished / generation pass has read the runs
   std::vector<hipEvent_t> slab_ev;        // timed runs: after y(i), after z(i)
   int slab_timed = 0;                     // slabs of the last timed run (0: whole-grid passes, ev[2] / ev[3] apply)
-  void* P = nullptr;                      // lazy: saved potential, API layout
+  void* P = nullptr;                      // lazy: saved potential, API layout (= P_base + an offset chosen by ensure_p)
+  void* P_base = nullptr;                 // the allocation P lives in
   size_t w_bytes = 0, k_bytes = 0, p_bytes = 0;      // field buffer, k-space side array, potential array (padded rows)
   int ppitch = 0;                         // cells per row of the potential array: nzl + 1, rounded up to even on float32 plans
   void *tw_x = nullptr, *tw_y = nullptr, *tw_z = nullptr;
@@ -202,6 +203,24 @@ void drop_graphs(rf_plan* p) {
 
 int ensure_k(rf_plan* p) {
   if (!p->K) RF_HIP(hipMalloc(&p->K, p->k_bytes));
+  return 0;
+}
+
+// The saved potential is written by a second store stream of the generation pass, row for row next to the field's.  The time of
+// that pass is bimodal -- 5.2 or 5.75 ms for the whole default call at 1024^3 -- and tools/pot_offset.py shows what decides it:
+// NOT the virtual addresses (45 plans at identical virtual addresses of both arrays and 15 offsets of the potential inside its
+// allocation, 256 B ... 4 MiB: either mode at every offset, the same offset in both modes) but the physical pages the driver
+// happens to back them with, which user space neither sees nor chooses.  RF_POT_OFFSET (bytes) moves the array inside a slightly
+// larger allocation for that measurement; the product uses offset 0.
+int ensure_p(rf_plan* p) {
+  if (p->P) return 0;
+  size_t off = 0, window = 0;
+  if (const char* e = getenv("RF_POT_OFFSET")) { off = (size_t)atoll(e) & ~(size_t)255; window = 8u << 20; }
+  if (off >= window) off = 0;
+  RF_HIP(hipMalloc(&p->P_base, p->p_bytes + window));
+  p->P = (char*)p->P_base + off;
+  if (getenv("RANDOMFIELD_DEBUG"))
+    fprintf(stderr, "ensure_p: W %p P_base %p offset %zu (P - W) mod 4 MiB = %zu\n", p->W, p->P_base, off, ((size_t)p->P - (size_t)p->W) % (4u << 20));
   return 0;
 }
 
@@ -871,7 +890,7 @@ int rf_plan_destroy(rf_plan* p) {
   if (p->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(p->comm);
   if (p->comm_stream) { (void)hipStreamSynchronize(p->comm_stream); (void)hipStreamDestroy(p->comm_stream); }
   for (auto& e : p->pev) if (e) (void)hipEventDestroy(e);
-  void* bufs[] = {p->W, p->R, p->W2, p->R2, p->K, p->P, p->G, p->tw_x, p->tw_y, p->tw_z, p->kx2, p->ky2, p->kz2, p->xt, p->st, p->sl, p->bin,
+  void* bufs[] = {p->W, p->R, p->W2, p->R2, p->K, p->P_base, p->G, p->tw_x, p->tw_y, p->tw_z, p->kx2, p->ky2, p->kz2, p->xt, p->st, p->sl, p->bin,
                   p->X, p->lntab, p->ypart, p->noise, p->mt_scratch, p->mt_pos, p->mt_npos_dev, p->mt_states, p->mt_counts, p->mt_offsets, p->mt_pairs, p->partials, p->stats, p->seeds_dev, p->ztab, p->frec, p->coll_scratch};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -1076,7 +1095,7 @@ static int potential_forward(rf_plan* p, uint64_t seed, int mode, const double* 
     if (whole) return rf_execute_c2r(p);
     return queue_xy(p, make_gen(p, 0, RF_NOISE_NATIVE, false), p->K, p->W, p->stream, false);
   }
-  if (!p->P) RF_HIP(hipMalloc(&p->P, p->p_bytes));
+  if (int rc = ensure_p(p)) return rc;
   p->timed = whole;
   p->pot_target = p->P;
   p->resident_fast = (mode == RF_NOISE_RESIDENT);
@@ -1389,7 +1408,7 @@ int rf_save_potential(rf_plan* p) {
   RF_REQUIRE(p->K && p->k_valid, "no k-space data");
   RF_REQUIRE(p->have_kgrid, "rf_set_kgrid must be called first");
   RF_HIP(hipSetDevice(p->device));
-  if (!p->P) RF_HIP(hipMalloc(&p->P, p->p_bytes));
+  if (int rc = ensure_p(p)) return rc;
   RF_HIP(launch_save_potential(p->f64, p->K, p->P, p->nx, p->ny, p->nz, p->kx2, p->ky2, p->kz2, p->nzl + 1, p->kz0, p->ppitch, p->stream));
   return 0;
 }
