@@ -71,6 +71,32 @@ __global__ __launch_bounds__(C::NT, (col_min_waves<C, IO>())) void col_kernel(IO
   }
 }
 
+// EXPERIMENT (RF_Z_XLANE = 1): the exchange between the middle and the last radix-8 stage of the z pass
+// through the wave's cross-lane network instead of the LDS row image.  With M / 8 = 64 a wave owns a row in both stages: stage-2
+// thread j = 8a + b leaves elements i = 64a + b + 8m (m = 0..7), stage-3 thread j' = b + 8p wants i = j' + 64m' -- element p of
+// lane b + 8m': an 8 x 8 transpose between the register index and lane bits 3..5, done as three butterfly exchanges
+// (__shfl_xor by 8, 16, 32: ds_bpermute / DPP), 24 32-bit exchanges per thread instead of 8 ds_write_b64 + 8 ds_read_b64 and
+// two barriers.
+#ifndef RF_Z_XLANE
+#define RF_Z_XLANE 0
+#endif
+template <typename T>
+__device__ __forceinline__ void xlane_transpose8(cplx<T>* v, int lane) {
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const bool hi = (lane >> (3 + k)) & 1;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      if (e & (1 << k)) continue;
+      const int f = e | (1 << k);
+      // lanes with the bit clear keep v[e] and trade v[f] for the partner's v[e]; lanes with it set keep v[f] and trade v[e]
+      const T sx = hi ? v[e].x : v[f].x, sy = hi ? v[e].y : v[f].y;
+      const T rx = __shfl_xor(sx, 8 << k), ry = __shfl_xor(sy, 8 << k);
+      if (hi) { v[e].x = rx; v[e].y = ry; } else { v[f].x = rx; v[f].y = ry; }
+    }
+  }
+}
+
 // z pass: c2r rows + per-workgroup (sum, sum of squares) partials
 template <class C, class IO>
 __global__ __launch_bounds__(C::NT) void row_c2r_kernel(IO io, const cplx<typename C::T>* __restrict__ tw,
@@ -103,15 +129,36 @@ __global__ __launch_bounds__(C::NT) void row_c2r_kernel(IO io, const cplx<typena
     __syncthreads();
     F::pass_first(tid, tile, nrows, io, ltw, lds, r);
   }
-  if (C::NPASS == 3) {
+  constexpr bool xlane = RF_Z_XLANE && C::NPASS == 3 && C::R2 == 8 && C::RL == 8 && C::M / 8 == 64 && sizeof(typename C::T) == 4 && C::NT % 64 == 0;
+  if constexpr (xlane) {
     __syncthreads();
-    F::pass_mid_read(tid, ltw, lds, r);
-    __syncthreads();
-    F::pass_mid_write(tid, lds, r);
-  }
-  if (C::NPASS >= 2) {
-    __syncthreads();
-    F::pass_last(tid, tile, nrows, io, ltw, lds, r);
+    F::pass_mid_read(tid, ltw, lds, r);            // stage 2: LDS -> registers -> DFT8 (r.v[it][m])
+#pragma unroll
+    for (int it = 0; it < C::IT2; ++it) {
+      const int w = it * C::NT + tid, rl = w / 64, j = w % 64;
+      if (rl < C::NRT) {
+        xlane_transpose8(r.v[it], tid & 63);       // -> the inputs of stage-3 thread j
+        cx v[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) v[m] = m > 0 ? cmul(r.v[it][m], ltw[2 * m * j]) : r.v[it][0];
+        DFT<8, +1>::run(v);
+        if (tile * C::NRT + rl < nrows) {
+#pragma unroll
+          for (int m = 0; m < 8; ++m) io.template store2<C::NRT>(tile, rl, j, m * 64, v[m], r.s1, r.s2);
+        }
+      }
+    }
+  } else {
+    if (C::NPASS == 3) {
+      __syncthreads();
+      F::pass_mid_read(tid, ltw, lds, r);
+      __syncthreads();
+      F::pass_mid_write(tid, lds, r);
+    }
+    if (C::NPASS >= 2) {
+      __syncthreads();
+      F::pass_last(tid, tile, nrows, io, ltw, lds, r);
+    }
   }
   // workgroup reduction of the moments: wave shuffle, then one slot per wave in LDS
   double s1 = r.s1, s2 = r.s2;
