@@ -389,6 +389,65 @@ int generic_c2c_impl(int nx, int ny, int nz, int dir, cplx<T>* D) {
   return 0;
 }
 
+// rf_realise_lognormal on an uploaded k-space array: x pass, the accumulating y pass (AccColIO: one Parseval partial per tile),
+// sigma and the tables as lognormal_tables_kernel forms them, the z pass with the map in its epilogue (LognormalRowIO)
+template <typename T>
+int c2r_lognormal_impl(int nx, int ny, int nz, const cplx<T>* kspace, const double* growth, const double* density, cplx<T>* W,
+                       double* sigma_out, double* s1, double* s2) {
+  const long long nzc = nz / 2;
+  GenColIO<T> gio;
+  gio.base = W; gio.g = ColGeom{(long long)ny * nzc, 0, (long long)ny * nzc};
+  memset(&gio.gp, 0, sizeof(gio.gp)); gio.gp.nx = nx; gio.gp.ny = ny; gio.gp.nz = nz; gio.gp.zpitch = nz / 2 + 1;
+  gio.kspace = kspace; gio.kz0 = 0; gio.nzl = (int)nzc;
+  int rc = dispatch_col<T, +1, GenColIO<T>, GenSel>(nx, gio, (long long)ny * nzc);
+  if (rc) return rc;
+  // y pass with the accumulator: run tile by tile so that every "thread"'s acc is collected (the kernel's finish())
+  const int tc = tile_cols<T>(ny, false);
+  double S = 0;
+  {
+    auto tw = make_twiddles<T>(ny);
+    const long long ncols = (long long)nx * nzc;
+    if (ncols % tc) return -2;
+    switch (ny) {
+#define X(NN) case NN: { using C = typename ColSel<T, NN>::type; using IO = AccColIO<T>; using F = ColFFT<C, +1, IO>;                 \
+      std::vector<cplx<T>> lds((size_t)(C::LDS_BYTES + IO::LDS_EXTRA) / sizeof(cplx<T>) + 1);                                       \
+      std::vector<typename F::Regs> regs(C::NT);                                                                                    \
+      for (long long tile = 0; tile < ncols / C::TC; ++tile) {                                                                      \
+        IO io0; io0.base = W; io0.g = ColGeom{nzc, (long long)ny * nzc, nzc}; io0.partials = nullptr; io0.kz0 = 0; io0.nzl = (int)nzc; \
+        std::vector<IO> ios(C::NT, io0);                                                                                            \
+        const cplx<T>* ltw = tw.data();                                                                                             \
+        if (F::HAS_PROLOGUE) { for (int t = 0; t < C::NT; ++t) F::prologue(t, ios[t], tw.data(), lds.data()); if (C::NPASS >= 2) ltw = F::lds_tw(lds.data()); } \
+        for (int t = 0; t < C::NT; ++t) F::pass_first(t, tile, ios[t], lds.data());                                                 \
+        if (C::NPASS == 3) { for (int t = 0; t < C::NT; ++t) F::pass_mid_read(t, ltw, lds.data(), regs[t]);                        \
+                             for (int t = 0; t < C::NT; ++t) F::pass_mid_write(t, lds.data(), regs[t]); }                          \
+        if (C::NPASS >= 2) for (int t = 0; t < C::NT; ++t) F::pass_last(t, tile, ios[t], ltw, lds.data());                          \
+        double a = 0; for (int t = 0; t < C::NT; ++t) a += ios[t].acc;                                                              \
+        S += a;                                                                                                                     \
+      } break; }
+      RF_COL_SIZES(X)
+#undef X
+      default: return -1;
+    }
+  }
+  const double n3 = (double)nx * ny * nz;
+  double sigma = std::sqrt(S / ((double)nx * ny * n3 * n3));
+  if (sizeof(T) == 4) sigma = (double)(float)sigma;
+  std::vector<double> Ap(nz), Bp(nz);
+  for (int z = 0; z < nz; ++z) {
+    const double g = sigma * growth[z], t = g * g + 1.0;
+    Ap[z] = std::sqrt(std::log(t)) / sigma;
+    Bp[z] = (density ? density[z] : 1.0) / std::sqrt(t);
+  }
+  *sigma_out = sigma;
+  auto twz = make_twiddles<T>(2 * (int)nzc);
+  LognormalRowIO<T> zio; zio.base = W; zio.scale = (T)(1.0 / n3); zio.M_of = (int)nzc; zio.Ap = Ap.data(); zio.Bp = Bp.data();
+  switch ((int)nzc) {
+#define X(MM) case MM: run_row_c2r<typename RowSel<T, MM>::type, LognormalRowIO<T>>(zio, (long long)nx * ny, twz.data(), s1, s2); return 0;
+    RF_ROW_SIZES(X)
+#undef X
+    default: return -1;
+  }
+}
 }  // namespace
 
 extern "C" {
@@ -420,6 +479,12 @@ int emu_generic_r2c(int f64, int nx, int ny, int nz, const void* W, void* K) {
 }
 int emu_generic_c2c(int f64, int nx, int ny, int nz, int dir, void* D) {
   return f64 ? generic_c2c_impl<double>(nx, ny, nz, dir, (cplx<double>*)D) : generic_c2c_impl<float>(nx, ny, nz, dir, (cplx<float>*)D);
+}
+
+int emu_c2r_lognormal(int f64, int nx, int ny, int nz, const void* kspace, const double* growth, const double* density, void* W,
+                      double* sigma_out, double* s1, double* s2) {
+  return f64 ? c2r_lognormal_impl<double>(nx, ny, nz, (const cplx<double>*)kspace, growth, density, (cplx<double>*)W, sigma_out, s1, s2)
+             : c2r_lognormal_impl<float>(nx, ny, nz, (const cplx<float>*)kspace, growth, density, (cplx<float>*)W, sigma_out, s1, s2);
 }
 
 // fused realisation with the fast native generation (float32 arithmetic; f64 != 0: float64 plan, values widened);

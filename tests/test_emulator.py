@@ -341,3 +341,32 @@ def test_gathering_z_pass(M, nx, ny, tc, rb, dtype):
     assert np.max(np.abs(out - ref)) <= (2e-6 if dtype == np.complex64 else 1e-13) * np.abs(ref).max()
     assert abs(s1.value - out.astype(np.float64).sum()) <= 1e-6 * out.size * np.abs(out).max()
     assert abs(s2.value - (out.astype(np.float64) ** 2).sum()) <= 1e-6 * s2.value
+
+
+@pytest.mark.parametrize("shape,dtype", [((16, 16, 32), np.complex64), ((32, 16, 64), np.complex128), ((64, 64, 64), np.complex64)])
+def test_fused_lognormal_pipeline(shape, dtype):
+    """The phase functions behind rf_realise_lognormal on the CPU: the accumulating y pass (AccColIO) gives, by Parseval, the rms
+    of the field the z pass is about to produce, and the z pass's epilogue (LognormalRowIO) maps it like the reference's
+    apply_lognormal_transform followed by the density factor (cosmotools.py:206-221, generate.py:273)."""
+    import ctypes
+    nx, ny, nz = shape
+    L = emu_util.lib()
+    rng = np.random.RandomState(9)
+    ks = (rng.normal(size=(nx, ny, nz // 2 + 1)) + 1j * rng.normal(size=(nx, ny, nz // 2 + 1))).astype(dtype) * 40
+    cpu_ref.symmetrize_packed(ks)
+    delta, _, _ = emu_util.c2r(ks)
+    growth = np.exp(-0.5 * np.arange(nz) / nz)
+    dens = 0.5 + np.arange(nz) / nz
+    rt = np.float32 if dtype == np.complex64 else np.float64
+    out = np.zeros((nx, ny, nz), rt)
+    sig, s1, s2 = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+    dp = ctypes.POINTER(ctypes.c_double)
+    rc = L.emu_c2r_lognormal(int(dtype == np.complex128), nx, ny, nz, ks.ctypes.data_as(ctypes.c_void_p), growth.ctypes.data_as(dp),
+                             dens.ctypes.data_as(dp), out.ctypes.data_as(ctypes.c_void_p), ctypes.byref(sig), ctypes.byref(s1), ctypes.byref(s2))
+    assert rc == 0, rc
+    std = delta.astype(np.float64).std()
+    assert abs(delta.astype(np.float64).mean()) < 1e-6 * std              # DC mode 0 -> mean 0: the Parseval sum is the variance
+    assert abs(sig.value - std) <= (2e-6 if rt == np.float32 else 1e-13) * std
+    want = cpu_ref.scale_z(cpu_ref.lognormal(delta.copy(), growth, sigma=rt(sig.value)), dens)
+    assert np.all(out > 0) and np.max(np.abs(out - want) / want) <= (3e-6 if rt == np.float32 else 1e-12)
+    assert abs(s1.value - out.astype(np.float64).sum()) <= 1e-6 * out.size * np.abs(out).max()
