@@ -790,18 +790,31 @@ template <typename T> struct GatherRowIO {
   int M_of;                      // nz / 2
   int nzl;                       // kz planes per source rank
   long long seg_stride;          // complex elements between two source blocks = nxl * ny * nzl
-  // (tile, row of the tile, lane's element, uniform element offset): the split lets a gathering IO keep its address arithmetic
-  // on the scalar unit; here it is just row = tile * NRT + rl, element = kb + ko
-  template <int NRT> RF_HD cplx<T> load2(long long tile, int rl, int kb, int ko) const { return load(tile * NRT + rl, kb + ko); }
-  template <int NRT> RF_HD void store2(long long tile, int rl, int nb, int no, cplx<T> z, double& s1, double& s2) const { store(tile * NRT + rl, nb + no, z, s1, s2); }
+  // (tile, row of the tile, lane's element, uniform element offset): the source block and the tile's row base are workgroup
+  // uniform (scalar unit); nzl is a power of two (shift / mask instead of a division per element); streaming accesses like the
+  // plain z pass (every byte is touched once)
+  RF_HD int nzl_shift() const { return 31 - __builtin_clz((unsigned)nzl); }
+  template <int NRT> RF_HD cplx<T> load2(long long tile, int rl, int kb, int ko) const {
+    const int sh = nzl_shift(), mask = nzl - 1;
+    const cplx<T>* ub = src + (long long)(ko >> sh) * seg_stride + tile * (long long)(NRT * nzl);
+    const int kl = kb + (ko & mask);                       // (< nzl whenever nzl >= the pass's L: the block index is uniform then)
+    return stream_load(ub + ((long long)(kl >> sh) * seg_stride + (long long)(rl * nzl + (kl & mask))));
+  }
+  template <int NRT> RF_HD void store2(long long tile, int rl, int nb, int no, cplx<T> z, double& s1, double& s2) const {
+    cplx<T>* ub = dst + tile * (long long)(NRT * M_of) + no;
+    z.x *= scale; z.y *= scale;
+    stream_store(reinterpret_cast<cplx<T>*>((size_t)ub + (size_t)((uint32_t)(rl * M_of + nb) * (uint32_t)sizeof(cplx<T>))), z);
+    s1 += (double)z.x + (double)z.y;
+    s2 += (double)z.x * (double)z.x + (double)z.y * (double)z.y;
+  }
   RF_HD int gather_seg_shift() const { return -1; }
   RF_HD cplx<T> load(long long row, int k) const {
-    const int g = k / nzl, kk = k - g * nzl;
-    return src[(long long)g * seg_stride + row * (long long)nzl + kk];
+    const int g = k >> nzl_shift(), kk = k & (nzl - 1);
+    return stream_load(src + ((long long)g * seg_stride + row * (long long)nzl + kk));
   }
   RF_HD void store(long long row, int n, cplx<T> z, double& s1, double& s2) const {
     z.x *= scale; z.y *= scale;
-    dst[row * (long long)M_of + n] = z;
+    stream_store(dst + (row * (long long)M_of + n), z);
     s1 += (double)z.x + (double)z.y;
     s2 += (double)z.x * (double)z.x + (double)z.y * (double)z.y;
   }

@@ -33,6 +33,7 @@ template <typename T>
 hipError_t launch_gather_t(int M, const cplx<T>* src, cplx<T>* dst, long long nrows, double scale, int nzl,
                            long long seg_stride, const cplx<T>* tw, double* partials, hipStream_t s, bool po) {
   GatherRowIO<T> io; io.src = src; io.dst = dst; io.scale = (T)scale; io.M_of = M; io.nzl = nzl; io.seg_stride = seg_stride;
+  if (!po && (nzl <= 0 || (nzl & (nzl - 1)))) return hipErrorInvalidValue;       // (the kernel splits k by shift and mask)
   switch (M) {
 #define X(MM) case MM: return launch_one<typename RowSel<T, MM>::type, GatherRowIO<T>>(io, nrows, tw, partials, s, po);
     RF_ROW_SIZES(X)
