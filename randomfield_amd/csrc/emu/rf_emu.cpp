@@ -44,6 +44,50 @@ void run_col_pass(const IO& io_in, long long ncols, const cplx<typename C::T>* t
   }
 }
 
+// a pass of length 2 C1::N through Col2 (col2_kernel's phases, a loop boundary for each of its barriers); tw2 = the 2 C1::N-point table
+template <class C1, int DIR, class IO>
+void run_col2_pass(const IO& io_in, long long ncols, const cplx<typename C1::T>* tw2) {
+  using X = Col2<C1, DIR, IO>;
+  using F = typename X::F;
+  using cx = cplx<typename C1::T>;
+  std::vector<cx> lds((size_t)(C1::LDS_BYTES + IO::LDS_EXTRA) / sizeof(cx));
+  std::vector<typename F::Regs> regs(C1::NT);
+  std::vector<typename F::TwRegs> twr(C1::NT);
+  std::vector<typename X::Park> pk(C1::NT);
+  std::vector<IO> ios(C1::NT, io_in);
+  for (auto& io : ios) io.bind_seed();
+  const long long ntiles = ncols / C1::TC;
+  for (long long t0 = 0; t0 < ntiles; ++t0) {
+    const long long tile = io_in.remap_tile(t0);
+    if (IO::LDS_EXTRA > 0) for (int t = 0; t < C1::NT; ++t) ios[t].prologue(t, C1::NT, F::lds_io(lds.data()));
+    for (int t = 0; t < C1::NT; ++t) X::tw_fetch(t, tw2, twr[t]);
+    const cx* ltw = F::lds_tw(lds.data());
+    for (int phase = 0; phase < 2; ++phase) {
+      for (int t = 0; t < C1::NT; ++t) ios[t].set_phase(phase);
+      for (int t = 0; t < C1::NT; ++t) F::pass_first(t, tile, ios[t], lds.data());
+      if (phase == 0) for (int t = 0; t < C1::NT; ++t) F::tw_stage(t, lds.data(), twr[t]);
+      if (C1::NPASS == 3) {
+        for (int t = 0; t < C1::NT; ++t) F::pass_mid_read(t, ltw, lds.data(), regs[t]);
+        for (int t = 0; t < C1::NT; ++t) F::pass_mid_write(t, lds.data(), regs[t]);
+      }
+      if (phase == 0) for (int t = 0; t < C1::NT; ++t) X::last_park(t, ltw, lds.data(), pk[t]);
+      else for (int t = 0; t < C1::NT; ++t) X::last_combine(t, tile, ios[t], ltw, tw2, lds.data(), pk[t]);
+    }
+  }
+}
+// the product's rule (rf_k_col_plain.hip / rf_k_col_gen.hip): float32 passes of length 2048 run through Col2
+template <typename T, int DIR>
+bool pair_pass_2048(int N, cplx<T>* base, ColGeom g, long long ncols) {
+  if (N != 2048 || sizeof(T) != 4) return false;
+  if constexpr (sizeof(T) == 4) {
+    using C1 = GenSel<float, 1024>::type;
+    auto tw2 = make_twiddles<float>(2048);
+    Pair2ColIO<float> io; io.base = base; io.g = g; io.gin = g; io.gin.row_stride = 2 * g.row_stride; io.par_off = g.row_stride;
+    run_col2_pass<C1, DIR, Pair2ColIO<float>>(io, ncols, tw2.data());
+  }
+  return true;
+}
+
 template <typename T, int DIR, class IO, template <typename, int> class SEL = ColSel>
 int dispatch_col(int N, const IO& io, long long ncols) {
   auto tw = make_twiddles<T>(N);
@@ -62,7 +106,7 @@ int dispatch_col(int N, const IO& io, long long ncols) {
 // The product's hand-off of the x pass's output through the blocked intermediate X [x block][kz tile][ny][rb][tc] (rf_capi.hip
 // queue_xyz / queue_yz): y pass in place on X, z pass gathering X -> W.  g_xposed mirrors RF_FLAG_TRANSPOSED_INTERMEDIATE; the
 // rule for when it applies is the product's xpose_ok().
-int g_xposed = 1;
+int g_xposed = 0;          // (the product's default: RF_FLAG_TRANSPOSED_INTERMEDIATE is off)
 int g_rowblock = 64;
 template <typename T> int tile_cols(int N, bool gen) {
   switch (N) {
@@ -319,11 +363,28 @@ int realise_fast_impl(int nx, int ny, int nz, const GenHost& h, uint64_t seed, d
     if (rc) return rc;
     return xposed_yz<T>(nx, ny, nz, X.data(), W, s1, s2);
   }
-  rc = dispatch_col<T, +1, IO, GenSel>(nx, io, (long long)ny * nzc);
-  if (rc) return rc;
-  PlainColIO<T> pio; pio.base = W; pio.g = ColGeom{nzc, (long long)ny * nzc, nzc};
-  rc = dispatch_col<T, +1>(ny, pio, (long long)nx * nzc);
-  if (rc) return rc;
+  bool x_done = false;
+  if constexpr (sizeof(T) == 4) {
+    if (nx == 2048 && ((long long)ny * nzc) % 8 == 0) {      // the library's x pass at this length: Col2 over the 1024-point configuration
+      using C1 = GenSel<float, 1024>::type;
+      using IO2 = FastGenColIOT<0, 1, 0, 0, 0, 2>;
+      IO2 io2;
+      io2.base = W; io2.g = io.g; io2.kz0 = 0; io2.nzl = (int)nzc; io2.rec = nullptr; io2.gp = io.gp; io2.pot = nullptr;
+      auto tw2 = make_twiddles<float>(2048);
+      run_col2_pass<C1, +1, IO2>(io2, (long long)ny * nzc, tw2.data());
+      x_done = true;
+    }
+  }
+  if (!x_done) {
+    rc = dispatch_col<T, +1, IO, GenSel>(nx, io, (long long)ny * nzc);
+    if (rc) return rc;
+  }
+  const ColGeom gy{nzc, (long long)ny * nzc, nzc};
+  if (!pair_pass_2048<T, +1>(ny, W, gy, (long long)nx * nzc)) {
+    PlainColIO<T> pio; pio.base = W; pio.g = gy;
+    rc = dispatch_col<T, +1>(ny, pio, (long long)nx * nzc);
+    if (rc) return rc;
+  }
   return dispatch_row_c2r<T>((int)nzc, W, (long long)nx * ny, 1.0 / ((double)nx * ny * nz), s1, s2);
 }
 
@@ -600,6 +661,10 @@ int emu_col_fft(int f64, int N, int dir, void* data, long long ncols, long long 
   if (f64) {
     PlainColIO<double> io; io.base = (cplx<double>*)data; io.g = g;
     return dir > 0 ? dispatch_col<double, +1>(N, io, ncols) : dispatch_col<double, -1>(N, io, ncols);
+  }
+  if (N == 2048 && ncols % 8 == 0) {                    // as the library does at this length: two 1024-point transforms per tile
+    if (dir > 0) pair_pass_2048<float, +1>(N, (cplx<float>*)data, g, ncols); else pair_pass_2048<float, -1>(N, (cplx<float>*)data, g, ncols);
+    return 0;
   }
   PlainColIO<float> io; io.base = (cplx<float>*)data; io.g = g;
   return dir > 0 ? dispatch_col<float, +1>(N, io, ncols) : dispatch_col<float, -1>(N, io, ncols);

@@ -351,8 +351,13 @@ template <typename T, bool WIDE = false> struct GenColIO {
 // rng='reference'): same float32 |k| and sigma arithmetic, the draw replaced by two 16-byte loads per lane.  The field
 // then differs from the exact-chain kernel's by the float32 sigma rounding only (<= 1e-6 relative, far inside the
 // 1e-5 * rms parity tolerance) and the pass is HBM-bound (12.9 GB) instead of latency-bound on table lookups.
-template <int AB = 0, int FIX = 1, int SLAB = 0, int POT = 0, int SRC = 0>
+// XS: 1 = row r of the pass is mode ix = r; 2 = the pass is one HALF of a transform of twice its length (Col2 below: rows of the
+// even / odd modes ix = 2 r + xp, xp = the phase set_phase() selects) -- native generation without the potential store only.
+template <int AB = 0, int FIX = 1, int SLAB = 0, int POT = 0, int SRC = 0, int XS = 1>
 struct FastGenColIOT {
+  static_assert(XS == 1 || (XS == 2 && SLAB == 0 && POT == 0 && SRC == 0), "half-transform rows: native generation only");
+  int xp = 0;
+  RF_HD void set_phase(int p) { xp = p; }
   cplx<float>* base;
   ColGeom g;
   FastGenParams gp;
@@ -392,11 +397,13 @@ struct FastGenColIOT {
     // nzl = (nz/2) / ranks is a power of two (the launcher checks it): shift and mask instead of a 64-bit division
     const int iy = (int)((unsigned)C >> nzl_shift()), kz = kz0 + (int)((unsigned)C & (unsigned)(nzl - 1));   // lane, m-invariant
     const uint64_t half_plane = ((uint64_t)gp.ny * (uint64_t)(gp.nz / 2)) >> 1;        // counters per unit of ix
-    const uint64_t ctr_l = (uint64_t)rb * half_plane + (((uint64_t)iy * (uint64_t)(gp.nz / 2) + (uint64_t)kz) >> 1);
-    const uint64_t ctr_u = pin_uniform((uint64_t)ro * half_plane);
-    // signed fftfreq index: rb < L <= nx/2, so the wrap depends on ro alone
-    const int ro_s = ro >= (gp.nx >> 1) ? ro - gp.nx : ro;
-    const float kx = (float)(rb + ro_s) * gp.dkx, ky = (float)fast_signed_index(iy, gp.ny) * gp.dky;
+    // mode index ix = XS (rb + ro) + xp = (lane part rbt) + (uniform part rot)
+    const int rbt = XS * rb, rot = XS * ro + (XS == 2 ? xp : 0);
+    const uint64_t ctr_l = (uint64_t)rbt * half_plane + (((uint64_t)iy * (uint64_t)(gp.nz / 2) + (uint64_t)kz) >> 1);
+    const uint64_t ctr_u = pin_uniform((uint64_t)rot * half_plane);
+    // signed fftfreq index: XS rb < XS L <= nx/2 and XS ro is a multiple of XS L, so the wrap depends on ro alone
+    const int ro_s = XS * ro >= (gp.nx >> 1) ? rot - gp.nx : rot;
+    const float kx = (float)(rbt + ro_s) * gp.dkx, ky = (float)fast_signed_index(iy, gp.ny) * gp.dky;
     const float kxy = fmaf(kx, kx, ky * ky);                                           // == fast_kxy2(gp, rb + ro, iy)
     const float k2a = fast_k2(gp, kxy, kz), k2b = fast_k2(gp, kxy, kz + 1);
     if (SRC == 0) {
@@ -450,7 +457,7 @@ struct FastGenColIOT {
     const int iy = (int)((unsigned)C >> nzl_shift());
     cplx<float> p0, pn;
     const cplx<float> packed = SRC != 0 ? fast_fix_kz0_noise<SRC == 0 ? 1 : SRC>(gp, rec, rb + ro, iy, p0, pn)
-                                        : fast_fix_kz0(gp, rec, seed, rb + ro, iy, p0, pn);
+                                        : fast_fix_kz0(gp, rec, seed, XS * (rb + ro) + (XS == 2 ? xp : 0), iy, p0, pn);
     if (POT) {
       cplx<float>* row = pot + ((long long)(rb + ro) * gp.ny + iy) * gp.ppitch;   // only the rank with kz0 = 0 gets here: slot 0 = plane 0
       row[0] = p0;
@@ -706,6 +713,110 @@ struct ColFFT {
         last_butterfly(j, lp, tw, lds, out);
 #pragma unroll
         for (int m = 0; m < R; ++m) io.store(C0, cl, j, m * L, out[m]);
+      }
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------
+// Col2: a strided transform of length 2 N1 as TWO transforms of length N1 per tile, one after the other, + one radix-2 step in
+// registers (decimation in time):  out[x] = E[x mod N1] + w^x O[x mod N1],  E / O = the length-N1 transforms of the even / odd
+// input rows, w = exp(DIR 2 pi i / 2 N1).  Phase 0 transforms the even rows and PARKS the last pass's outputs (R V16 per thread:
+// 32 registers for float32) instead of storing them; phase 1 transforms the odd rows, and its last pass combines and stores rows
+// x and x + N1.  The tile in LDS is the N1-point one (64 KB at N1 = 1024): two 512-thread workgroups share a CU, where the
+// whole-column 2048-point tile (152 KB) allows one workgroup whose sixteen waves load / generate, transform and store in lock
+// step.  The combine's twiddle w^(j + m L) = w^j * exp(DIR 2 pi i m / 2 R): one table entry per thread,
+// the rest are the constant 16th roots of unity (R = 8).
+// ---------------------------------------------------------------------------
+// in-place pass over an array whose rows 2 r + phase feed phase `phase`: load geometry gin (row stride doubled), store geometry g
+template <typename T> struct Pair2ColIO {
+  cplx<T>* base;
+  ColGeom gin, g;
+  long long par_off;             // elements between row 2r and row 2r + 1 (the plain row stride)
+  int phase = 0;
+  RF_HD void set_phase(int p) { phase = p; }
+  RF_HD V16<T> load(long long C0, int cl, int rb, int ro) const { return v16_load<T>(gin.at<false>(base + (long long)phase * par_off, C0, cl, rb, ro)); }
+  RF_HD void store(long long C0, int cl, int rb, int ro, const V16<T>& v) const { v16_store<T>(g.at<false>(base, C0, cl, rb, ro), v); }
+  static constexpr int FIX_MODE = 0;
+  RF_HD bool needs_fix(long long) const { return false; }
+  RF_HD cplx<T> fix_value(long long, int, int) const { return cplx<T>(); }
+  static constexpr int LDS_EXTRA = 0;
+  RF_HD void prologue(int, int, void*) {}
+  RF_HD void bind_seed() {}
+  RF_HD static void sched_fence(int = 0) {}
+  static constexpr bool ROLLED_LOAD = false;
+  RF_HD long long remap_tile(long long t) const { return t; }
+  static constexpr bool HAS_FINISH = false;
+};
+
+// exp(DIR * 2 pi i m / 16), m in [0, 8)
+template <int DIR, typename T> RF_HD cplx<T> w16_half(int m) {
+  const T c1 = (T)0.92387953251128675613, s1 = (T)0.38268343236508977173, r = (T)0.70710678118654752440;
+  T cs, sn;
+  switch (m) {
+    case 0: cs = 1; sn = 0; break;
+    case 1: cs = c1; sn = s1; break;
+    case 2: cs = r; sn = r; break;
+    case 3: cs = s1; sn = c1; break;
+    case 4: cs = 0; sn = 1; break;
+    case 5: cs = -s1; sn = c1; break;
+    case 6: cs = -r; sn = r; break;
+    default: cs = -c1; sn = s1; break;
+  }
+  return mk<T>(cs, DIR > 0 ? sn : -sn);
+}
+
+template <class C1, int DIR, class IO>
+struct Col2 {
+  using F = ColFFT<C1, DIR, IO>;
+  using T = typename C1::T;
+  using cx = cplx<T>;
+  using V = V16<T>;
+  static constexpr int N1 = C1::N, R = C1::RL, L = N1 / R, CPL = C1::CPL, LPR = C1::LPR, BPI = C1::BPI;
+  static_assert(C1::NPASS >= 2 && R == 8, "Col2 combines behind a radix-8 last pass through LDS");
+  struct Park { V out[C1::ITL][R]; };
+  // tw2 = exp(+2 pi i q / 2 N1), q in [0, 2 N1): the N1-point table is every second entry
+  RF_HD static void tw_fetch(int tid, const cx* tw2, typename F::TwRegs& t) {
+#pragma unroll
+    for (int k = 0; k < F::TWPT; ++k) t.v[k] = tw2[2 * ((tid + k * C1::NT) & (N1 - 1))];
+  }
+  // phase 0, last pass: LDS -> butterfly -> registers
+  RF_HD static void last_park(int tid, const cx* tw, cx* lds, Park& pk) {
+    const int lp = tid % LPR, jl = tid / LPR;
+#pragma unroll
+    for (int it = 0; it < C1::ITL; ++it) {
+      const int j = it * BPI + jl;
+      if (j < L) F::last_butterfly(j, lp, tw, lds, pk.out[it]);
+    }
+  }
+  // phase 1, last pass: LDS -> butterfly -> radix-2 step with the parked half -> rows x and x + N1
+  RF_HD static void last_combine(int tid, long long tile, const IO& io, const cx* tw, const cx* tw2, cx* lds, const Park& pk) {
+    const int lp = tid % LPR, jl = tid / LPR;
+    const long long C0 = tile * C1::TC;
+    const int cl = lp * CPL;
+#pragma unroll
+    for (int it = 0; it < C1::ITL; ++it) {
+      const int j = it * BPI + jl;
+      if (j < L) {
+        V odd[R];
+        F::last_butterfly(j, lp, tw, lds, odd);
+        const cx wj = tw_dir<DIR>(tw2[j]);
+#pragma unroll
+        for (int m = 0; m < R; ++m) {
+          const cx w = m == 0 ? wj : cmul(wj, w16_half<DIR, T>(m));      // w^(j + m L)
+          V lo, hi;
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) {
+            const cx t = cmul(odd[m].c[c], w), e = pk.out[it][m].c[c];
+            lo.c[c] = e + t;
+            hi.c[c] = e - t;
+          }
+          io.store(C0, cl, j, m * L, lo);
+          io.store(C0, cl, j, m * L + N1, hi);
+#if defined(__HIP_DEVICE_COMPILE__)
+          __builtin_amdgcn_sched_barrier(0);       // one row pair at a time: hoisting all sixteen results in front of the stores spills
+#endif
+        }
       }
     }
   }

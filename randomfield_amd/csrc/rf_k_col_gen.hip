@@ -22,6 +22,45 @@ hipError_t launch_one(const IO& io_in, long long ncols, const cplx<typename C::T
   return hipGetLastError();
 }
 
+// the same through col2_kernel: a pass of length 2 C1::N as two C1 transforms per tile (rf_fft.h Col2); tw2 = the 2 C1::N-point table
+template <class C1, class IO>
+hipError_t launch_one2(const IO& io_in, long long ncols, const cplx<typename C1::T>* tw2, hipStream_t s, bool prepare_only,
+                       long long ntiles_sub = -1, long long tile_mul = 1, long long tile_add = 0, int skip_period = 0) {
+  if (ncols % C1::TC || io_in.g.inner <= 0 || (io_in.g.inner & (io_in.g.inner - 1))) return hipErrorInvalidValue;
+  const IO& io = io_in;
+  const long long ntiles = ntiles_sub >= 0 ? ntiles_sub : ncols / C1::TC;
+  auto k = col2_kernel<C1, +1, IO>;
+  constexpr int lds_bytes = C1::LDS_BYTES + IO::LDS_EXTRA;
+  static LdsAttrLatch latch;
+  if (hipError_t e = latch.ensure((const void*)k, lds_bytes); e != hipSuccess) return e;
+  if (prepare_only) return hipSuccess;
+  hipLaunchKernelGGL(k, dim3((unsigned)ntiles), dim3(C1::NT), lds_bytes, s, io, tw2, ntiles, tile_mul, tile_add, skip_period);
+  return hipGetLastError();
+}
+
+// fast float32 generation + x pass of length 2 C1::N through Col2 (native generator, whole grid or kz slab; no potential store,
+// no resident deviates, no x-slab restriction: those keep the whole-column kernel)
+template <class C1, class IO0, class IO1>
+hipError_t launch_fast_one2(const FastGenParams& gp, cplx<float>* W, ColGeom g, long long ncols, int kz0, int nzl,
+                            const cplx<float>* tw2, hipStream_t s, bool po, hipEvent_t after_repair) {
+  if (nzl <= 0 || (nzl & (nzl - 1)) || ncols >= (1LL << 31) || g.needs_wide(C1::LMAX, C1::TC, (int)sizeof(cplx<float>)) || !g.rows_ok(C1::N / C1::RL, C1::NPASS))
+    return hipErrorInvalidValue;
+  IO0 io0; io0.base = W; io0.g = g; io0.gp = gp; io0.kz0 = kz0; io0.nzl = nzl; io0.rec = nullptr; io0.pot = nullptr;
+  IO1 io1; io1.base = W; io1.g = g; io1.gp = gp; io1.kz0 = kz0; io1.nzl = nzl; io1.rec = nullptr; io1.pot = nullptr;
+  const bool split = nzl > C1::TC && nzl % C1::TC == 0;
+  const long long tiles_per_iy = nzl / C1::TC, ntiles = ncols / C1::TC;
+  if (po) {
+    hipError_t e = launch_one2<C1, IO0>(io0, ncols, tw2, s, true);
+    return e != hipSuccess ? e : launch_one2<C1, IO1>(io1, ncols, tw2, s, true);
+  }
+  if (!split) return launch_one2<C1, IO1>(io1, ncols, tw2, s, false);
+  if (kz0 != 0) return launch_one2<C1, IO0>(io0, ncols, tw2, s, false);
+  hipError_t e = launch_one2<C1, IO1>(io1, ncols, tw2, s, false, ncols / nzl, tiles_per_iy, 0);
+  if (e != hipSuccess || tiles_per_iy >= (1LL << 30) || ntiles >= (1LL << 31)) return e != hipSuccess ? e : hipErrorInvalidValue;
+  if (after_repair && (e = hipEventRecord(after_repair, s)) != hipSuccess) return e;
+  return launch_one2<C1, IO0>(io0, ncols, tw2, s, false, ntiles - ntiles / tiles_per_iy, 1, 0, (int)tiles_per_iy);
+}
+
 template <typename T>
 hipError_t launch_t(int N, cplx<T>* W, ColGeom g, long long ncols, const GenParams& gp, const cplx<T>* kspace,
                     int kz0, int nzl, const cplx<T>* tw, hipStream_t s, bool po) {
@@ -151,6 +190,15 @@ hipError_t launch_col_fastgen(int f64, int N, void* W, ColGeom g, long long ncol
 #ifndef RF_GEN_AB
 #define RF_GEN_AB 0                    // ablation mask of the benchmarked kernel (rf_core.h fast_gen_pair_at); 0 in the product
 #endif
+#ifndef RF_COL2_2048
+#define RF_COL2_2048 1                 // length-2048 float32 passes as two 1024-point transforms per tile (Col2); 0 = the whole-column kernels
+#endif
+  if (RF_COL2_2048 && N == 2048 && !f64 && (!slab || po)) {
+    using C1 = GenSel<float, 1024>::type;
+    hipError_t e = launch_fast_one2<C1, FastGenColIOT<RF_GEN_AB, 0, 0, 0, 0, 2>, FastGenColIOT<RF_GEN_AB, 1, 0, 0, 0, 2>>(
+        gp, (cplx<float>*)W, g, ncols, kz0, nzl, (const cplx<float>*)tw, s, po, after_repair);
+    if (!po || e != hipSuccess) return e;
+  }
 #define X(NN) case NN: return launch_fast_one<typename GenSel<float, NN>::type, FastGenColIOT<RF_GEN_AB, 0, 0>, FastGenColIOT<RF_GEN_AB, 1, 0>, cplx<float>>(gp, (cplx<float>*)W, g, ncols, kz0, nzl, (const cplx<float>*)tw, s, po, after_repair, x0, x1);
   RF_FAST(float, 0, 0)
 #undef X

@@ -40,6 +40,23 @@ hipError_t launch_t(int N, cplx<T>* base, ColGeom g, long long ncols, const cplx
     default: return hipErrorInvalidValue;
   }
 }
+// a pass of length 2 C1::N in place as two C1 transforms per tile (rf_fft.h Col2 / Pair2ColIO); tw2 = the 2 C1::N-point table
+template <class C1, int DIR>
+hipError_t launch_pair(cplx<typename C1::T>* base, ColGeom g, long long ncols, const cplx<typename C1::T>* tw2, hipStream_t s, bool po) {
+  using T = typename C1::T;
+  using IO = Pair2ColIO<T>;
+  if (ncols % C1::TC || g.inner <= 0 || (g.inner & (g.inner - 1))) return hipErrorInvalidValue;
+  IO io; io.base = base; io.g = g; io.gin = g; io.gin.row_stride = 2 * g.row_stride; io.par_off = g.row_stride;
+  const long long ntiles = ncols / C1::TC;
+  auto k = col2_kernel<C1, DIR, IO>;
+  constexpr int lds_bytes = C1::LDS_BYTES + IO::LDS_EXTRA;
+  static LdsAttrLatch latch;
+  if (hipError_t e = latch.ensure((const void*)k, lds_bytes); e != hipSuccess) return e;
+  if (po) return hipSuccess;
+  hipLaunchKernelGGL(k, dim3((unsigned)ntiles), dim3(C1::NT), lds_bytes, s, io, tw2, ntiles, 1LL, 0LL, 0);
+  return hipGetLastError();
+}
+
 // inverse pass out of place: src (geometry gs) -> dst (geometry gd)
 template <typename T>
 hipError_t launch_xp(int N, const cplx<T>* src, ColGeom gs, cplx<T>* dst, ColGeom gd, long long ncols, const cplx<T>* tw, hipStream_t s, bool po) {
@@ -117,6 +134,21 @@ int col_tile_cols(int f64, int N) {
 
 hipError_t launch_col_plain(int f64, int N, int dir, void* base, ColGeom g, long long ncols, const void* tw,
                             hipStream_t s, bool po) {
+#ifndef RF_COL2_2048
+#define RF_COL2_2048 1                 // length-2048 float32 passes as two 1024-point transforms per tile (Col2); 0 = the whole-column kernels
+#endif
+  if (RF_COL2_2048 && N == 2048 && !f64) {
+    // (the radix-8-first 1024-point configuration: with 32 parked registers the 16-first one would not fit 128 VGPRs)
+    using C1 = GenSel<float, 1024>::type;
+    ColGeom gin = g;
+    gin.row_stride = 2 * g.row_stride;
+    const bool fits = !gin.needs_wide(C1::LMAX, C1::TC, 8) && !g.needs_wide(C1::LMAX, C1::TC, 8) && g.row_shift >= 30 && g.hi_shift >= 62 && g.sub_shift == 0;
+    if (po || fits) {
+      hipError_t e = dir > 0 ? launch_pair<C1, +1>((cplx<float>*)base, g, ncols, (const cplx<float>*)tw, s, po)
+                             : launch_pair<C1, -1>((cplx<float>*)base, g, ncols, (const cplx<float>*)tw, s, po);
+      if (!po || e != hipSuccess) return e;
+    }
+  }
   if (f64) return dir > 0 ? launch_t<double, +1>(N, (cplx<double>*)base, g, ncols, (const cplx<double>*)tw, s, po)
                           : launch_t<double, -1>(N, (cplx<double>*)base, g, ncols, (const cplx<double>*)tw, s, po);
   return dir > 0 ? launch_t<float, +1>(N, (cplx<float>*)base, g, ncols, (const cplx<float>*)tw, s, po)

@@ -71,6 +71,57 @@ __global__ __launch_bounds__(C::NT, (col_min_waves<C, IO>())) void col_kernel(IO
   }
 }
 
+// strided pass of length 2 C1::N as two C1 transforms per tile + a radix-2 step in registers (rf_fft.h Col2)
+// (the kernel WITH the kz = 0 repair needs ~260 registers with the parked half: it runs few tiles, so it gets the budget of two
+// waves per SIMD -- one workgroup per CU -- instead of spilling 336 bytes per thread)
+template <class C1, int DIR, class IO>
+__global__ __launch_bounds__(C1::NT, (IO::FIX_MODE != 0 ? 2 : col_min_waves<C1, IO>())) void col2_kernel(IO io, const cplx<typename C1::T>* __restrict__ tw2,
+                                                                             long long ntiles, long long tile_mul,
+                                                                             long long tile_add, int skip_period) {
+  using X = Col2<C1, DIR, IO>;
+  using F = typename X::F;
+  using cx = cplx<typename C1::T>;
+  extern __shared__ __attribute__((aligned(16))) char rf_smem[];
+  cx* lds = reinterpret_cast<cx*>(rf_smem);
+  const int tid = threadIdx.x;
+  long long tile = xcd_tile(blockIdx.x, ntiles) * tile_mul + tile_add;
+  if (skip_period > 0) {
+    const unsigned t = (unsigned)tile;
+    tile = (long long)(t + t / (unsigned)(skip_period - 1) + 1u);
+  }
+  io.bind_seed();
+  typename F::TwRegs twr;
+  typename X::Park pk;
+  if (IO::LDS_EXTRA > 0) {
+    io.prologue(tid, C1::NT, F::lds_io(lds));
+    __syncthreads();
+  }
+  X::tw_fetch(tid, tw2, twr);
+  const cx* ltw = F::lds_tw(lds);
+#pragma unroll
+  for (int phase = 0; phase < 2; ++phase) {
+    io.set_phase(phase);
+    if (phase == 1) __syncthreads();                 // the tile in LDS is free again
+    // both phases run the same passes on the same LDS addresses: hidden from the optimiser (an opaque copy of the thread index
+    // per phase), or it keeps the first phase's ~40 addresses and twiddles live through the whole kernel, next to the 32 parked
+    // registers, and spills (248 bytes of scratch per thread, 2.8x slower on MI355X)
+    int t = tid;
+    asm volatile("" : "+v"(t));
+    F::pass_first(t, tile, io, lds);
+    if (phase == 0) F::tw_stage(tid, lds, twr);
+    if (C1::NPASS == 3) {
+      typename F::Regs r;
+      __syncthreads();
+      F::pass_mid_read(t, ltw, lds, r);
+      __syncthreads();
+      F::pass_mid_write(t, lds, r);
+    }
+    __syncthreads();
+    if (phase == 0) X::last_park(t, ltw, lds, pk);
+    else X::last_combine(t, tile, io, ltw, tw2, lds, pk);
+  }
+}
+
 // EXPERIMENT (RF_Z_XLANE = 1): the exchange between the middle and the last radix-8 stage of the z pass
 // through the wave's cross-lane network instead of the LDS row image.  With M / 8 = 64 a wave owns a row in both stages: stage-2
 // thread j = 8a + b leaves elements i = 64a + b + 8m (m = 0..7), stage-3 thread j' = b + 8p wants i = j' + 64m' -- element p of

@@ -150,6 +150,22 @@ def test_fast_native_generation_matches_oracle(shape, default_power):
         assert np.max(np.abs(out - ref)) <= 2e-5 * rms
 
 
+@pytest.mark.parametrize("shape", [(2048, 8, 16), (8, 2048, 16), (2048, 8, 64)])
+def test_length_2048_passes_as_two_half_transforms(shape, default_power):
+    """Float32 x / y passes of length 2048 run as two 1024-point transforms per tile (Col2 in rf_fft.h: even rows
+    first, last-pass outputs parked in registers, odd rows second, one radix-2 combine): generation's row -> mode
+    mapping, the parked combine and the half-table twiddle fetch, against the oracle chain."""
+    nx, ny, nz = shape
+    k, Pk = default_power["k"], default_power["Pk"]
+    xt, st = cpu_ref.sigma_table(k, Pk, nx, ny, nz, 2.5)
+    out, s1, s2 = emu_util.realise_fast(nx, ny, nz, 2.5, xt, st, seed=41)
+    noise = cpu_ref.native_noise(41, nx, ny, nz, np.complex64)
+    ref, rms = cpu_ref.generate_delta_field(nx, ny, nz, 2.5, k, Pk, noise=noise, double_fft=True)
+    assert np.max(np.abs(out - ref)) <= 3e-5 * rms        # (same 2.2e-5 at (1024, 16, 64): Box-Muller angle rounding)
+    n = out.size
+    assert abs(np.sqrt(s2 / n - (s1 / n) ** 2) - rms) <= 1e-5 * rms
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("M", ROW_SIZES)
 def test_row_r2c_all_sizes(M, dtype):
@@ -287,7 +303,9 @@ def test_transposed_intermediate_is_bit_identical(shape, dtype, default_power):
     passes on the plain layout."""
     nx, ny, nz = shape
     L = emu_util.lib()
+    old = L.emu_set_xposed(1)                    # (off by default, like the product's flag)
     applies = L.emu_xpose_applies(int(dtype == np.complex128), nx, ny, nz)
+    L.emu_set_xposed(old)
     k, Pk = default_power["k"], default_power["Pk"]
     xt, st = cpu_ref.sigma_table(k, Pk, nx, ny, nz, 2.5)
     rng = np.random.RandomState(nx + ny + nz)
