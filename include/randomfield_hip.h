@@ -108,6 +108,26 @@ int rf_noise_mt19937_ex(rf_plan* plan, const uint32_t* state624, unsigned long l
  * states, e.g. numpy's init_genrand / init_by_array of each seed); rms_out (n, optional) = np.std of every field.  The field of
  * the last seed is the plan's current field; every field equals what rf_noise_mt19937_ex(single) + rf_realise(RESIDENT) gives. */
 int rf_realise_batch_reference(rf_plan* plan, const uint32_t* states, int n, double* rms_out);
+/* ---- the same stream shared between the ranks of a kz-slab job (random.py:24-28 is ONE sequential stream; the reference is
+ * single-process, so there is no reference interface to mirror beyond that definition).  rf_noise_mt19937_ex on a multi-rank
+ * plan replays the whole stream on every rank; these calls replay 1/P of it per rank and exchange the deviates once:
+ *   rf_mt_share_segments  the stream's segment count and this rank's range [first, first + count)
+ *   rf_mt_share_begin     jump to segment `first`, replay the local segments; counts_out[count] = accepted pairs per segment
+ *   rf_mt_share_gather    every rank's counts into counts_all[nseg_total], in segment order (an integer all-reduce over RCCL;
+ *                         virtual ranks: concatenate on the host instead)
+ *   rf_mt_share_pack      scan counts_all, pack the local pairs by destination rank
+ *   rf_mt_share_exchange  one all-to-all over RCCL on the plan's stream (rf_comm_init first); rf_mt_share_exchange_local: the
+ *                         same between n virtual ranks living on one device (tests)
+ *   rf_mt_share_finish    the plan's resident float64 deviates are this rank's planes of the stream (then RF_NOISE_RESIDENT)
+ * single = 1 (complex64 plans): pairs travel as float32 (8 B per cell, the volume of the field's own exchange), rounded as
+ * rf_noise_mt19937_ex(single = 1) rounds them; single = 0: the exact float64 deviates, bit for bit those of the replicated replay. */
+int rf_mt_share_segments(rf_plan* plan, int* nseg_total, int* seg_first, int* seg_count);
+int rf_mt_share_begin(rf_plan* plan, const uint32_t* state624, int single, unsigned long long* counts_out);
+int rf_mt_share_gather(rf_plan* plan, unsigned long long* counts_all);
+int rf_mt_share_pack(rf_plan* plan, const unsigned long long* counts_all);
+int rf_mt_share_exchange(rf_plan* plan);
+int rf_mt_share_exchange_local(rf_plan** plans, int n);
+int rf_mt_share_finish(rf_plan* plan, unsigned long long* accepted);
 /* copy deviates [first, first+count) of the device noise buffer to the host (tests) */
 int rf_download_noise(rf_plan* plan, double* host, unsigned long long first, unsigned long long count);
 

@@ -44,6 +44,13 @@ SIGNATURES = {
                                         ctypes.POINTER(ctypes.c_ulonglong)]),
     "rf_noise_mt19937_ex": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32),
                                            ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]),
+    "rf_mt_share_segments": (ctypes.c_int, [ctypes.c_void_p] + [ctypes.POINTER(ctypes.c_int)] * 3),
+    "rf_mt_share_begin": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32), ctypes.c_int, ctypes.POINTER(ctypes.c_ulonglong)]),
+    "rf_mt_share_gather": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_ulonglong)]),
+    "rf_mt_share_pack": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_ulonglong)]),
+    "rf_mt_share_exchange": (ctypes.c_int, [ctypes.c_void_p]),
+    "rf_mt_share_exchange_local": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int]),
+    "rf_mt_share_finish": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_ulonglong)]),
     "rf_download_noise": (ctypes.c_int, [ctypes.c_void_p, _c_dp, ctypes.c_ulonglong, ctypes.c_ulonglong]),
     "rf_execute_c2r": (ctypes.c_int, [ctypes.c_void_p]),
     "rf_execute_r2c": (ctypes.c_int, [ctypes.c_void_p]),
@@ -279,6 +286,64 @@ class DevicePlan(object):
                                             ctypes.byref(acc), 1 if single else 0), "rf_noise_mt19937_ex")
         return acc.value
 
+    # -- the same stream shared between the ranks of a kz-slab job (rf_mt_share_*) ---------------
+    def share_segments(self):
+        """(segments of the whole stream, this rank's first segment, this rank's number of segments)"""
+        self._mt_prepare()
+        a, b, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        check(self._lib.rf_mt_share_segments(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)), "rf_mt_share_segments")
+        return a.value, b.value, c.value
+
+    def share_begin(self, seed, single=False):
+        """Replay this rank's segments of ``RandomState(seed).normal``; returns their accepted-pair counts."""
+        from . import mt19937
+        _, _, count = self.share_segments()
+        state = np.ascontiguousarray(mt19937.seed_state(seed), np.uint32)
+        counts = np.zeros(count, np.uint64)
+        check(self._lib.rf_mt_share_begin(self._h, state.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), 1 if single else 0,
+                                          counts.ctypes.data_as(ctypes.POINTER(ctypes.c_ulonglong))), "rf_mt_share_begin")
+        return counts
+
+    def share_gather(self):
+        nseg, _, _ = self.share_segments()
+        counts = np.zeros(nseg, np.uint64)
+        check(self._lib.rf_mt_share_gather(self._h, counts.ctypes.data_as(ctypes.POINTER(ctypes.c_ulonglong))), "rf_mt_share_gather")
+        return counts
+
+    def share_pack(self, counts_all):
+        counts_all = np.ascontiguousarray(counts_all, np.uint64)
+        nseg, _, _ = self.share_segments()
+        if counts_all.shape != (nseg,):
+            raise ValueError("counts_all must hold one count per segment of the stream (%d)" % nseg)
+        check(self._lib.rf_mt_share_pack(self._h, counts_all.ctypes.data_as(ctypes.POINTER(ctypes.c_ulonglong))), "rf_mt_share_pack")
+
+    def share_exchange(self):
+        check(self._lib.rf_mt_share_exchange(self._h), "rf_mt_share_exchange")
+
+    def share_finish(self):
+        acc = ctypes.c_ulonglong(0)
+        check(self._lib.rf_mt_share_finish(self._h, ctypes.byref(acc)), "rf_mt_share_finish")
+        return acc.value
+
+    def reference_noise_shared(self, seed, single=False):
+        """Collective over the plan's communicator: ``RandomState(seed).normal(size=2*M)`` replayed ONCE by all ranks together
+        (each rank 1/P of the stream, one all-to-all of deviates) instead of once per rank (:meth:`reference_noise`).
+        Afterwards pass ``noise='resident'``."""
+        self.share_begin(seed, single)
+        self.share_pack(self.share_gather())
+        self.share_exchange()
+        return self.share_finish()
+
+    @staticmethod
+    def reference_noise_shared_local(plans, seed, single=False):
+        """The same between virtual ranks on one device (tests): ``plans`` = ranks 0..n-1 of one n-rank job."""
+        counts = np.concatenate([p.share_begin(seed, single) for p in plans])
+        for p in plans:
+            p.share_pack(counts)
+        arr = (ctypes.c_void_p * len(plans))(*[p._h.value for p in plans])
+        check(load().rf_mt_share_exchange_local(arr, len(plans)), "rf_mt_share_exchange_local")
+        return [p.share_finish() for p in plans]
+
     def realise_batch_reference(self, seeds, want_rms=True):
         """``len(seeds)`` same-seed realisations back to back (random.py:24-28 per seed): the MT19937 replay of seed i + 1 runs
         on a second stream under the y / z passes of seed i (rf_realise_batch_reference).  complex64 plans, fast generation
@@ -291,13 +356,21 @@ class DevicePlan(object):
                                                    _dp(rms) if want_rms else None), "rf_realise_batch_reference")
         return rms
 
+    def set_mt_segment_blocks(self, blocks):
+        """Override the replay's segment length (blocks of 624 words; default: :func:`mt19937.segment_blocks_for`).  Small
+        grids have a single default segment; the shared replay needs at least one segment per rank (tests use short ones).
+        Every rank of a job must choose the same value, before the first replay."""
+        if getattr(self, "_mt_ready", False):
+            raise ValueError("the jump table of this plan has been uploaded already")
+        self._mt_bps = int(blocks)
+
     def _mt_prepare(self):
         """upload the jump table of the MT19937 replay for this grid (once per plan)"""
         from . import mt19937
         if not getattr(self, "_mt_ready", False):
             # segment length for this grid's stream (a whole multiple of the GPU's wave slots on large grids), the stages
             # of the radix-16 jump tree it needs, and their polynomials' set-bit positions
-            bps = mt19937.segment_blocks_for(self.nx * self.ny * (self.nz // 2 + 1))
+            bps = getattr(self, "_mt_bps", None) or mt19937.segment_blocks_for(self.nx * self.ny * (self.nz // 2 + 1))
             blocks = -(-4 * mt19937.attempts_needed(self.nx * self.ny * (self.nz // 2 + 1)) // 624)
             nseg, stages = -(-blocks // bps), 1
             while mt19937.TREE_RADIX ** stages < nseg:

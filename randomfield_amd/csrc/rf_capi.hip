@@ -154,6 +154,16 @@ struct rf_plan {
   size_t mt_states_cap = 0, mt_seg_cap = 0;
   void* mt_scratch = nullptr;          // one-pass replay: every segment's accepted pairs, densely from slot seg * (attempts per segment)
   size_t mt_scratch_bytes = 0;
+  // distributed replay (rf_mt_share_*): this rank replays segments [sh_first, sh_first + sh_nloc) of the one stream
+  void *mt_send = nullptr, *mt_recv = nullptr;   // pairs packed by destination rank / stream of this rank as received (float32 mode)
+  size_t mt_send_bytes = 0, mt_recv_bytes = 0;
+  long long* mt_sbase = nullptr;                 // device, [nranks]: see mt_share_pack_kernel
+  unsigned long long* mt_first = nullptr;        // device: first stream cell of every local segment
+  size_t mt_first_cap = 0;
+  int sh_state = 0;                              // 0 idle, 1 replayed (begin), 2 packed, 3 exchanged
+  int sh_single = 0, sh_first = 0, sh_nloc = 0;
+  unsigned long long sh_total = 0;
+  std::vector<unsigned long long> sh_sendoff, sh_sendcnt, sh_recvoff, sh_recvcnt;      // pairs, per peer
   double* partials = nullptr;
   long long npartials = 0;
   double* stats = nullptr;                // [2 * stats_cap] (sum, sumsq) per realisation
@@ -891,7 +901,7 @@ int rf_plan_destroy(rf_plan* p) {
   if (p->comm_stream) { (void)hipStreamSynchronize(p->comm_stream); (void)hipStreamDestroy(p->comm_stream); }
   for (auto& e : p->pev) if (e) (void)hipEventDestroy(e);
   void* bufs[] = {p->W, p->R, p->W2, p->R2, p->K, p->P_base, p->G, p->tw_x, p->tw_y, p->tw_z, p->kx2, p->ky2, p->kz2, p->xt, p->st, p->sl, p->bin,
-                  p->X, p->lntab, p->ypart, p->noise, p->mt_scratch, p->mt_pos, p->mt_npos_dev, p->mt_states, p->mt_counts, p->mt_offsets, p->mt_pairs, p->partials, p->stats, p->seeds_dev, p->ztab, p->frec, p->coll_scratch};
+                  p->X, p->lntab, p->ypart, p->noise, p->mt_scratch, p->mt_send, p->mt_recv, p->mt_sbase, p->mt_first, p->mt_pos, p->mt_npos_dev, p->mt_states, p->mt_counts, p->mt_offsets, p->mt_pairs, p->partials, p->stats, p->seeds_dev, p->ztab, p->frec, p->coll_scratch};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   for (int i = 0; i < 2; ++i) {
@@ -1694,6 +1704,245 @@ int rf_noise_mt19937_ex(rf_plan* p, const uint32_t* state624, unsigned long long
     p->mt_scratch = nullptr;
     p->mt_scratch_bytes = 0;
   }
+  return 0;
+}
+
+/* ---- one stream, P ranks: the replay of RandomState(seed).normal shared between the ranks of a kz-slab job -----------------
+ * rf_noise_mt19937_ex on a multi-rank plan replays the WHOLE stream on every rank (where a deviate goes depends on every
+ * earlier acceptance).  Here rank r replays only segments [r nseg / P, (r + 1) nseg / P): (1) rf_mt_share_begin jumps to its first
+ * segment (one jump per radix-16 digit), grows the local tree, runs the generation pass and returns its per-segment counts; (2) the
+ * host gathers all counts (a few thousand integers) and hands them to rf_mt_share_pack, which scans them -- now every rank knows
+ * which cells every rank holds -- and packs the local pairs by destination (kz slab); (3) ONE all-to-all of deviates, 8 B per
+ * cell in float32 mode: the same volume as the field's exchange (rf_mt_share_exchange over RCCL, or rf_mt_share_exchange_local
+ * between virtual ranks on one device); (4) rf_mt_share_finish leaves them as the plan's resident float64 deviates, the form
+ * rf_realise(RF_NOISE_RESIDENT) and the other consumers already read on multi-rank plans.  Per rank: 1/P of the replay's time
+ * and of its scratch.  float64 mode moves the exact deviates (16 B per cell) and gives bit for bit what the replicated
+ * replay gives; float32 mode (complex64 plans) rounds the Box-Muller factor as rf_noise_mt19937_ex(single = 1) does. */
+namespace {
+inline int sh_seg_begin(int r, int nseg, int nranks) { return (int)((long long)r * nseg / nranks); }
+}
+int rf_mt_share_segments(rf_plan* p, int* nseg_total, int* seg_first, int* seg_count) {
+  RF_REQUIRE(p, "null plan");
+  RF_REQUIRE(!p->unpacked && !p->generic, "the distributed replay serves packed plans on the tiled kernels");
+  RF_REQUIRE(p->mt_pos && !p->mt_npos.empty(), "rf_mt_set_jump must be called first");
+  MtGeom g;
+  if (int rc = mt_geom(p, 1, g)) return rc;
+  const int a = sh_seg_begin(p->rank, g.nseg, p->nranks), b = sh_seg_begin(p->rank + 1, g.nseg, p->nranks);
+  if (nseg_total) *nseg_total = g.nseg;
+  if (seg_first) *seg_first = a;
+  if (seg_count) *seg_count = b - a;
+  return 0;
+}
+
+int rf_mt_share_begin(rf_plan* p, const uint32_t* state624, int single, unsigned long long* counts_out) {
+  RF_REQUIRE(p && state624 && counts_out, "null argument");
+  RF_REQUIRE(!p->unpacked && !p->generic, "the distributed replay serves packed plans on the tiled kernels");
+  RF_REQUIRE(!p->replicate, "replicated-generation plans draw native deviates only");
+  RF_REQUIRE(p->mt_pos && !p->mt_npos.empty(), "rf_mt_set_jump must be called first");
+  RF_REQUIRE(p->nranks >= 1 && p->nranks <= 64, "unsupported number of ranks");
+  if (single && p->f64) single = 0;                      // float64 cells: keep the exact deviates
+  RF_HIP(hipSetDevice(p->device));
+  p->sh_state = 0;
+  if (int rc = ensure_noise(p)) return rc;
+  MtGeom g;
+  if (int rc = mt_geom(p, single, g)) return rc;
+  const int first = sh_seg_begin(p->rank, g.nseg, p->nranks), nloc = sh_seg_begin(p->rank + 1, g.nseg, p->nranks) - first;
+  RF_REQUIRE(nloc >= 1, "more ranks than segments: use rf_noise_mt19937_ex on this grid");
+  MtGeom gl = g;
+  gl.nseg = nloc + 8;                                     // + slots for the jump to the first segment
+  gl.need = (size_t)nloc * g.cap * (single ? 2 * sizeof(float) : 2 * sizeof(double));
+  if (int rc = mt_ensure_buffers(p, gl)) return rc;
+  hipStream_t s = p->stream;
+  const int R = p->mt_radix;
+  // the start state of segment `first`: one jump per non-zero radix-R digit of `first` (digit d of weight R^t: polynomial
+  // t (R - 1) + d - 1 of the table), hopping through the spare slots behind the local states
+  int slot = nloc;
+  RF_HIP(hipMemcpyAsync(p->mt_states + (size_t)slot * 624, state624, 624 * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+  {
+    int rest = first;
+    for (int t = 0; rest > 0; ++t, rest /= R) {
+      const int d = rest % R;
+      if (d == 0) continue;
+      RF_REQUIRE(t < g.stages && slot + 1 < nloc + 8, "segment index beyond the uploaded jump table");
+      const int row = t * (R - 1) + d - 1;
+      RF_HIP(launch_mt_jump(p->mt_states + (size_t)slot * 624, p->mt_pos + (size_t)row * p->mt_stride, p->mt_npos_dev + 2 * row, p->mt_stride,
+                            1, 1, 1, 2, s));
+      ++slot;
+    }
+  }
+  RF_HIP(hipMemcpyAsync(p->mt_states, p->mt_states + (size_t)slot * 624, 624 * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+  // the local tree and the generation pass over the local segments (mt_queue with a shifted origin)
+  long long dist = 1;
+  for (int t = 0; dist < nloc; ++t, dist *= R) {
+    const int nsrc = (int)(dist < nloc ? dist : nloc);
+    RF_HIP(launch_mt_jump(p->mt_states, p->mt_pos + (size_t)t * (R - 1) * p->mt_stride, p->mt_npos_dev + 2 * t * (R - 1), p->mt_stride, nsrc,
+                          dist, R - 1, nloc, s));
+  }
+  RF_HIP(launch_mt_polar(single != 0, p->mt_states, nloc, p->mt_bps, g.total_blocks - (long long)first * p->mt_bps, p->mt_counts, p->mt_scratch, g.cap, s));
+  RF_HIP(hipMemcpyAsync(counts_out, p->mt_counts, (size_t)nloc * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+  RF_HIP(hipStreamSynchronize(s));
+  p->sh_single = single; p->sh_first = first; p->sh_nloc = nloc;
+  p->noise_resident = false;                              // (p->noise is about to be overwritten)
+  p->noise32_resident = false;                            // (the runs in mt_scratch are this rank's share only)
+  p->sh_state = 1;
+  return 0;
+}
+
+// every rank's per-segment counts, in segment order, on every rank: an integer sum over the communicator of arrays that are zero
+// outside the rank's own range (a few thousand values; also the first collective after the local replays)
+int rf_mt_share_gather(rf_plan* p, unsigned long long* counts_all) {
+  RF_REQUIRE(p && counts_all, "null argument");
+  RF_REQUIRE(p->sh_state == 1, "rf_mt_share_begin must be called first");
+  RF_REQUIRE(p->nranks == 1 || p->comm != nullptr, "rf_comm_init has not been called on this multi-rank plan");
+  RF_HIP(hipSetDevice(p->device));
+  MtGeom g;
+  if (int rc = mt_geom(p, p->sh_single, g)) return rc;
+  if (p->comm_stream) RF_HIP(hipStreamSynchronize(p->comm_stream));          // (the communicator is used from one stream at a time)
+  unsigned long long* tmp = nullptr;
+  RF_HIP(hipMalloc((void**)&tmp, (size_t)g.nseg * sizeof(unsigned long long)));
+  hipStream_t s = p->stream;
+  hipError_t e = hipMemsetAsync(tmp, 0, (size_t)g.nseg * sizeof(unsigned long long), s);
+  if (e == hipSuccess) e = hipMemcpyAsync(tmp + p->sh_first, p->mt_counts, (size_t)p->sh_nloc * sizeof(unsigned long long), hipMemcpyDeviceToDevice, s);
+  if (e == hipSuccess && p->comm && g_rccl.AllReduce(tmp, tmp, (size_t)g.nseg, ncclUint64, ncclSum, p->comm, s) != ncclSuccess) e = hipErrorUnknown;
+  if (e == hipSuccess) e = hipMemcpyAsync(counts_all, tmp, (size_t)g.nseg * sizeof(unsigned long long), hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  (void)hipFree(tmp);
+  RF_HIP(e);
+  return 0;
+}
+
+int rf_mt_share_pack(rf_plan* p, const unsigned long long* counts_all) {
+  RF_REQUIRE(p && counts_all, "null argument");
+  RF_REQUIRE(p->sh_state == 1, "rf_mt_share_begin must be called first");
+  RF_HIP(hipSetDevice(p->device));
+  MtGeom g;
+  if (int rc = mt_geom(p, p->sh_single, g)) return rc;
+  const int P = p->nranks, nzl = (int)p->nzl, nzh = (int)p->nzc + 1;
+  std::vector<unsigned long long> off((size_t)g.nseg + 1);
+  off[0] = 0;
+  for (int i = 0; i < g.nseg; ++i) {
+    RF_REQUIRE(counts_all[i] <= g.cap, "a segment cannot hold more pairs than attempts: the gathered counts are corrupt");
+    off[i + 1] = off[i] + counts_all[i];
+  }
+  RF_REQUIRE(off[g.nseg] >= g.ncells, "MT19937 replay: not enough accepted polar attempts (increase the margin)");
+  p->sh_total = off[g.nseg];
+  // first cell of every rank's share, and the index in "stream q" (rows of nzl + 1 pairs: q's planes, then the Nyquist plane) of
+  // the first stream-q cell at or behind stream cell c
+  std::vector<unsigned long long> cb((size_t)P + 1);
+  for (int r = 0; r <= P; ++r) {
+    const unsigned long long c = off[sh_seg_begin(r, g.nseg, P)];
+    cb[r] = c < g.ncells ? c : g.ncells;
+  }
+  cb[P] = g.ncells;
+  auto fq = [&](int q, unsigned long long c) -> unsigned long long {
+    const unsigned long long col = c / (unsigned)nzh;
+    long long k = (long long)(c - col * (unsigned)nzh) - (long long)q * nzl;
+    k = k < 0 ? 0 : (k > nzl ? nzl : k);
+    return col * (unsigned)(nzl + 1) + (unsigned long long)k;
+  };
+  const int me = p->rank;
+  p->sh_sendoff.assign(P + 1, 0); p->sh_sendcnt.assign(P, 0); p->sh_recvoff.assign(P, 0); p->sh_recvcnt.assign(P, 0);
+  std::vector<long long> sbase(P);
+  for (int q = 0; q < P; ++q) {
+    p->sh_sendcnt[q] = fq(q, cb[me + 1]) - fq(q, cb[me]);
+    p->sh_sendoff[q + 1] = p->sh_sendoff[q] + p->sh_sendcnt[q];
+    sbase[q] = (long long)p->sh_sendoff[q] - (long long)fq(q, cb[me]);
+    p->sh_recvoff[q] = fq(me, cb[q]);                     // (q = the sending rank here)
+    p->sh_recvcnt[q] = fq(me, cb[q + 1]) - fq(me, cb[q]);
+  }
+  const size_t es = p->sh_single ? 2 * sizeof(float) : 2 * sizeof(double);
+  const size_t send_bytes = (size_t)(p->sh_sendoff[P] > 0 ? p->sh_sendoff[P] : 1) * es;
+  const size_t recv_pairs = (size_t)p->nx * p->ny * (nzl + 1);
+  if (p->mt_send_bytes < send_bytes) {
+    if (p->mt_send) RF_HIP(hipFree(p->mt_send));
+    p->mt_send = nullptr; p->mt_send_bytes = 0;
+    const size_t want = send_bytes + send_bytes / 64;    // (the shares differ from seed to seed by the counts' binomial noise)
+    RF_HIP(hipMalloc(&p->mt_send, want));
+    p->mt_send_bytes = want;
+  }
+  if (p->sh_single && p->mt_recv_bytes < recv_pairs * es) {
+    if (p->mt_recv) RF_HIP(hipFree(p->mt_recv));
+    p->mt_recv = nullptr; p->mt_recv_bytes = 0;
+    RF_HIP(hipMalloc(&p->mt_recv, recv_pairs * es));
+    p->mt_recv_bytes = recv_pairs * es;
+  }
+  if (!p->mt_sbase) RF_HIP(hipMalloc((void**)&p->mt_sbase, 64 * sizeof(long long)));
+  if (p->mt_first_cap < (size_t)p->sh_nloc) {
+    if (p->mt_first) RF_HIP(hipFree(p->mt_first));
+    p->mt_first = nullptr; p->mt_first_cap = 0;
+    RF_HIP(hipMalloc((void**)&p->mt_first, (size_t)p->sh_nloc * sizeof(unsigned long long)));
+    p->mt_first_cap = (size_t)p->sh_nloc;
+  }
+  hipStream_t s = p->stream;
+  RF_HIP(hipMemcpyAsync(p->mt_sbase, sbase.data(), (size_t)P * sizeof(long long), hipMemcpyHostToDevice, s));
+  RF_HIP(hipMemcpyAsync(p->mt_first, off.data() + p->sh_first, (size_t)p->sh_nloc * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
+  RF_HIP(launch_mt_share_pack(p->sh_single != 0, p->mt_scratch, p->mt_counts, p->mt_first, p->sh_nloc, g.cap, p->mt_send, g.ncells, nzh, nzl, P,
+                              p->mt_sbase, s));
+  RF_HIP(hipStreamSynchronize(s));                        // (sbase / off are host temporaries)
+  p->sh_state = 2;
+  return 0;
+}
+
+namespace {
+// where rank p's stream arrives: the resident deviates themselves (float64) or the float32 staging buffer
+inline char* sh_recv_base(rf_plan* p) { return p->sh_single ? (char*)p->mt_recv : (char*)p->noise; }
+}
+
+int rf_mt_share_exchange(rf_plan* p) {
+  RF_REQUIRE(p, "null plan");
+  RF_REQUIRE(p->sh_state == 2, "rf_mt_share_pack must be called first");
+  RF_REQUIRE(p->nranks == 1 || p->comm != nullptr, "rf_comm_init has not been called on this multi-rank plan");
+  RF_HIP(hipSetDevice(p->device));
+  const size_t es = p->sh_single ? 2 * sizeof(float) : 2 * sizeof(double);
+  hipStream_t s = p->stream;
+  const int me = p->rank;
+  RF_HIP(hipMemcpyAsync(sh_recv_base(p) + p->sh_recvoff[me] * es, (const char*)p->mt_send + p->sh_sendoff[me] * es, p->sh_sendcnt[me] * es,
+                        hipMemcpyDeviceToDevice, s));
+  if (p->nranks > 1) {
+    RF_NCCL(g_rccl.GroupStart());
+    for (int h = 0; h < p->nranks; ++h) {
+      if (h == me) continue;
+      if (p->sh_sendcnt[h]) RF_NCCL(g_rccl.Send((const char*)p->mt_send + p->sh_sendoff[h] * es, p->sh_sendcnt[h] * es, ncclUint8, h, p->comm, s));
+      if (p->sh_recvcnt[h]) RF_NCCL(g_rccl.Recv(sh_recv_base(p) + p->sh_recvoff[h] * es, p->sh_recvcnt[h] * es, ncclUint8, h, p->comm, s));
+    }
+    RF_NCCL(g_rccl.GroupEnd());
+  }
+  p->sh_state = 3;
+  return 0;
+}
+
+int rf_mt_share_exchange_local(rf_plan** plans, int n) {
+  RF_REQUIRE(plans && n >= 1, "null argument");
+  for (int g = 0; g < n; ++g) {
+    RF_REQUIRE(plans[g] && plans[g]->nranks == n && plans[g]->rank == g, "plans must be ranks 0..n-1 of one n-rank job");
+    RF_REQUIRE(plans[g]->device == plans[0]->device, "virtual ranks must live on one device");
+    RF_REQUIRE(plans[g]->sh_state == 2 && plans[g]->sh_single == plans[0]->sh_single, "rf_mt_share_pack must have run on every plan (same mode)");
+    RF_HIP(hipStreamSynchronize(plans[g]->stream));
+  }
+  const size_t es = plans[0]->sh_single ? 2 * sizeof(float) : 2 * sizeof(double);
+  for (int g = 0; g < n; ++g)        // sender g, receiver h
+    for (int h = 0; h < n; ++h) {
+      RF_REQUIRE(plans[g]->sh_sendcnt[h] == plans[h]->sh_recvcnt[g], "send / receive counts disagree");
+      if (plans[g]->sh_sendcnt[h])
+        RF_HIP(hipMemcpy(sh_recv_base(plans[h]) + plans[h]->sh_recvoff[g] * es, (const char*)plans[g]->mt_send + plans[g]->sh_sendoff[h] * es,
+                         plans[g]->sh_sendcnt[h] * es, hipMemcpyDeviceToDevice));
+    }
+  RF_HIP(hipDeviceSynchronize());       // (see rf_slab_exchange_local)
+  for (int g = 0; g < n; ++g) plans[g]->sh_state = 3;
+  return 0;
+}
+
+int rf_mt_share_finish(rf_plan* p, unsigned long long* accepted) {
+  RF_REQUIRE(p, "null plan");
+  RF_REQUIRE(p->sh_state == 3, "the exchange must have run first");
+  RF_HIP(hipSetDevice(p->device));
+  if (p->sh_single)
+    RF_HIP(launch_mt_share_widen(p->mt_recv, p->noise, (long long)p->nx * p->ny * (p->nzl + 1), p->stream));
+  RF_HIP(hipStreamSynchronize(p->stream));
+  p->noise_resident = true;
+  p->noise32_resident = false;
+  p->sh_state = 0;
+  if (accepted) *accepted = p->sh_total;
   return 0;
 }
 

@@ -295,6 +295,47 @@ __global__ __launch_bounds__(256) void mt_compact_kernel(const PAIR* __restrict_
   }
 }
 
+
+// ---- distributed replay (one stream, P ranks; rf_capi.hip rf_mt_share_*) ----------------------------------------------------
+// Every rank replays a contiguous range of segments; the pairs a kz-slab rank q needs (its nzl planes of every row and the Nyquist
+// plane, which every rank's side array carries) are "stream q": the cells (col, kz) with kz in q's planes or kz = nz/2, in stream
+// order -- index col * (nzl + 1) + slot, slot = kz - q nzl (Nyquist plane: nzl), which is also the layout of the plan's resident
+// deviates.  Pack: pair i of local segment seg is cell first[seg] + i; it goes to send[sbase[q] + index in stream q], sbase[q] =
+// start of q's region in the send buffer minus the stream-q index of this rank's first cell, so the regions are dense (a device
+// array of P entries).  PAIR = float2 or double2.
+template <typename PAIR>
+__global__ __launch_bounds__(256) void mt_share_pack_kernel(const PAIR* __restrict__ scratch, const unsigned long long* __restrict__ counts,
+                                                            const unsigned long long* __restrict__ first_cell, unsigned long long cap,
+                                                            PAIR* __restrict__ send, unsigned long long ncells, int nzh, int nzl, int nranks,
+                                                            const long long* __restrict__ sbase) {
+  const unsigned long long seg = blockIdx.x, n = counts[seg], first = first_cell[seg];
+  const unsigned long long lo = (unsigned long long)blockIdx.y * MT_COMPACT_CHUNK;
+  if (lo >= n) return;
+  const unsigned long long hi = lo + MT_COMPACT_CHUNK < n ? lo + MT_COMPACT_CHUNK : n;
+  const PAIR* src = scratch + seg * cap;
+  for (unsigned long long i = lo + threadIdx.x; i < hi; i += 256) {
+    const unsigned long long cell = first + i;
+    if (cell >= ncells) break;
+    const unsigned long long col = cell / (unsigned)nzh;
+    const int kz = (int)(cell - col * (unsigned)nzh);
+    const long long rowbase = (long long)col * (nzl + 1);
+    const PAIR v = src[i];
+    if (kz == nzh - 1) {
+      for (int q = 0; q < nranks; ++q) send[sbase[q] + rowbase + nzl] = v;
+    } else {
+      const int q = kz / nzl;
+      send[sbase[q] + rowbase + (kz - q * nzl)] = v;
+    }
+  }
+}
+// stream q as received, float32 pairs -> the plan's resident float64 deviates (same layout; float64 streams are received in place)
+__global__ __launch_bounds__(256) void mt_share_widen_kernel(const float2* __restrict__ recv, double2* __restrict__ noise, long long n) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float2 v = recv[i];
+  noise[i] = make_double2((double)v.x, (double)v.y);
+}
+
 }  // namespace
 
 hipError_t launch_mt_compact(bool single, const void* scratch, const unsigned long long* counts, const unsigned long long* offsets,
@@ -331,6 +372,21 @@ hipError_t launch_mt_polar(bool single, const uint32_t* states, int nseg, int bl
 }
 hipError_t launch_mt_scan(const unsigned long long* counts, unsigned long long* offsets, int n, hipStream_t s, unsigned long long* pairs) {
   hipLaunchKernelGGL(mt_scan_kernel, dim3(1), dim3(64), 0, s, counts, offsets, n, pairs);
+  return hipGetLastError();
+}
+
+hipError_t launch_mt_share_pack(bool single, const void* scratch, const unsigned long long* counts, const unsigned long long* first_cell,
+                                int nseg, unsigned long long cap, void* send, unsigned long long ncells, int nzh, int nzl, int nranks,
+                                const long long* sbase_dev, hipStream_t s) {
+  if (nseg <= 0 || nzl <= 0 || nranks <= 0) return hipErrorInvalidValue;
+  const dim3 grid((unsigned)nseg, (unsigned)((cap + MT_COMPACT_CHUNK - 1) / MT_COMPACT_CHUNK));
+  if (single) hipLaunchKernelGGL(mt_share_pack_kernel<float2>, grid, dim3(256), 0, s, (const float2*)scratch, counts, first_cell, cap, (float2*)send, ncells, nzh, nzl, nranks, sbase_dev);
+  else hipLaunchKernelGGL(mt_share_pack_kernel<double2>, grid, dim3(256), 0, s, (const double2*)scratch, counts, first_cell, cap, (double2*)send, ncells, nzh, nzl, nranks, sbase_dev);
+  return hipGetLastError();
+}
+hipError_t launch_mt_share_widen(const void* recv, double* noise, long long npairs, hipStream_t s) {
+  if (npairs <= 0 || (npairs + 255) / 256 >= (1LL << 31)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(mt_share_widen_kernel, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, s, (const float2*)recv, (double2*)noise, npairs);
   return hipGetLastError();
 }
 

@@ -135,6 +135,11 @@ hipError_t launch_mt_compact(bool single, const void* scratch, const unsigned lo
 // (pairs, optional: [2 n] = (offsets[i], offsets[i + 1]) -- what the generation pass loads with one 16-byte access)
 hipError_t launch_mt_scan(const unsigned long long* counts, unsigned long long* offsets, int n, hipStream_t s,
                           unsigned long long* pairs = nullptr);
+// distributed replay: pack the local segments' pairs by destination rank / widen a received float32 stream into the resident deviates
+hipError_t launch_mt_share_pack(bool single, const void* scratch, const unsigned long long* counts, const unsigned long long* first_cell,
+                                int nseg, unsigned long long cap, void* send, unsigned long long ncells, int nzh, int nzl, int nranks,
+                                const long long* sbase_dev, hipStream_t s);
+hipError_t launch_mt_share_widen(const void* recv, double* noise, long long npairs, hipStream_t s);
 
 // non-power-of-two grids (rf_generic.h, rf_k_generic.hip); root = exp(2 pi i t / n) tables as made by make_twiddles
 // complex pass along one axis: line l starts at (l / inner) * outer + l % inner, elements `stride` apart; src == dst allowed

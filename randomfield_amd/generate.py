@@ -230,7 +230,12 @@ class Generator(object):
                 if seed is None and self.distributed:
                     seed = self.plan_c2r.agree_on(int.from_bytes(os.urandom(4), "little"))
                 # (a complex64 plan keeps float32 copies of the deviates: its cells sigma * g are float32 anyway)
-                dev.reference_noise(seed, single=self.plan_c2r.data_out.dtype == np.float32)
+                single = self.plan_c2r.data_out.dtype == np.float32
+                if self.distributed and dev.nranks > 1 and dev.tiled and dev.share_segments()[0] >= dev.nranks:
+                    # one stream, P ranks: each replays 1/P of it, one all-to-all of deviates (rf_mt_share_*)
+                    dev.reference_noise_shared(seed, single=single)
+                else:
+                    dev.reference_noise(seed, single=single)
                 noise = "resident"
                 dseed = 0
             else:

@@ -20,7 +20,7 @@ import os
 import numpy as np
 
 __all__ = ["slab_layout", "exchange_blocks", "gather_rows", "side_array_planes", "split_side_array",
-           "assemble_side_array", "exchange_unique_id", "init_process_group", "DistributedPlan", "SlabHostPlan", "Deadline"]
+           "assemble_side_array", "shared_replay_layout", "shared_replay_pack", "exchange_unique_id", "init_process_group", "DistributedPlan", "SlabHostPlan", "Deadline"]
 
 
 def slab_layout(nx, ny, nz, nranks, rank):
@@ -66,6 +66,45 @@ def assemble_side_array(parts):
     """The (nx, ny, nz/2 + 1) array from every rank's share (the Nyquist plane is taken from rank 0)."""
     nzl = parts[0].shape[2] - 1
     return np.concatenate([a[:, :, :nzl] for a in parts] + [parts[0][:, :, nzl:]], axis=2)
+
+
+def shared_replay_layout(counts, nx, ny, nz, nranks):
+    """The arithmetic of the shared replay of the reference's stream (``rf_mt_share_pack`` in rf_capi.hip; random.py:24-28 is
+    one sequential stream of cells in (ix, iy, kz) order, kz = 0 .. nz/2).  ``counts[s]`` = accepted pairs of segment s;
+    rank r replays segments [r S / P, (r + 1) S / P) and therefore holds the stream cells [cell_begin[r], cell_begin[r + 1]).
+    Rank q needs "stream q": of every row its own nz/(2P) planes and the Nyquist plane, in stream order -- rows of
+    nzl + 1 pairs, the layout of the rank's side arrays (:func:`side_array_planes`).  Returns the cell ranges and, in pairs,
+    ``sendcnt[r][q]`` / ``sendoff[r][q]`` (rank r's send buffer, one dense region per destination) and ``recvoff[q][r]`` (where
+    rank r's pairs start in stream q)."""
+    counts = np.asarray(counts, np.uint64).astype(object)
+    nseg, nzh, nzl = len(counts), nz // 2 + 1, nz // 2 // nranks
+    ncells = nx * ny * nzh
+    off = [0]
+    for c in counts:
+        off.append(off[-1] + int(c))
+    if off[-1] < ncells:
+        raise ValueError("the segments hold fewer accepted pairs than the grid has cells")
+    seg_begin = [r * nseg // nranks for r in range(nranks + 1)]
+    cb = [min(off[b], ncells) for b in seg_begin]
+    cb[-1] = ncells
+
+    def fq(q, c):               # stream-q cells in front of stream cell c
+        col, kz = divmod(c, nzh)
+        return col * (nzl + 1) + min(max(kz - q * nzl, 0), nzl)
+
+    sendcnt = [[fq(q, cb[r + 1]) - fq(q, cb[r]) for q in range(nranks)] for r in range(nranks)]
+    sendoff = [[sum(row[:q]) for q in range(nranks)] for row in sendcnt]
+    recvoff = [[fq(q, cb[r]) for r in range(nranks)] for q in range(nranks)]
+    return dict(seg_begin=seg_begin, cell_begin=cb, sendcnt=sendcnt, sendoff=sendoff, recvoff=recvoff, nzl=nzl, nzh=nzh,
+                stream_pairs=nx * ny * (nzl + 1))
+
+
+def shared_replay_pack(pairs, first_cell, nz, nranks):
+    """Rank-side packing: ``pairs`` (n, 2) are the stream cells first_cell .. first_cell + n; returns one array per destination
+    rank (its planes' cells in stream order; a Nyquist cell goes to every rank)."""
+    nzh, nzl = nz // 2 + 1, nz // 2 // nranks
+    kz = (first_cell + np.arange(len(pairs))) % nzh
+    return [pairs[((kz >= q * nzl) & (kz < (q + 1) * nzl)) | (kz == nzh - 1)] for q in range(nranks)]
 
 
 _plans_made = 0          # DistributedPlans built by this process so far: every rank builds them in the same order

@@ -112,6 +112,92 @@ def test_slab_exchange_processes(tmp_path, world, shape):
         assert abs(np.sqrt(g["stats"][1] / n - (g["stats"][0] / n) ** 2) - rms) < 1e-12 * rms
 
 
+def _share_worker(rank, world, port, shape, counts, out_dir):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from oracle import cpu_ref
+    from randomfield_amd import slab
+    d, r, w, lr = slab.init_process_group()
+    nx, ny, nz = shape
+    # what the GPU path gathers with an integer all-reduce: every rank's counts, zero outside its own segments
+    nseg = len(counts)
+    mine = torch.zeros(nseg, dtype=torch.int64)
+    a, b = rank * nseg // world, (rank + 1) * nseg // world
+    mine[a:b] = torch.tensor(counts[a:b], dtype=torch.int64)
+    dist.all_reduce(mine)
+    assert mine.tolist() == list(counts)
+    lay = slab.shared_replay_layout(mine.numpy(), nx, ny, nz, world)
+    # this rank "replays" its share: cells [cell_begin[rank], cell_begin[rank + 1]) of numpy's stream
+    stream = cpu_ref.reference_noise(11, nx * ny * (nz // 2 + 1)).reshape(-1, 2)
+    c0, c1 = lay["cell_begin"][rank], lay["cell_begin"][rank + 1]
+    send = slab.shared_replay_pack(stream[c0:c1], c0, nz, world)
+    assert [len(x) for x in send] == lay["sendcnt"][rank]
+    recv = np.full((lay["stream_pairs"], 2), np.nan)
+    ops, keep = [], []
+    for h in range(world):
+        n = lay["sendcnt"][h][rank]                 # what rank h sends to me
+        lo = lay["recvoff"][rank][h]
+        if h == rank:
+            recv[lo:lo + n] = send[rank]
+            continue
+        if len(send[h]):
+            keep.append(torch.from_numpy(np.ascontiguousarray(send[h])))
+            ops.append(dist.P2POp(dist.isend, keep[-1], h))
+        if n:
+            buf = torch.empty((n, 2), dtype=torch.float64)
+            keep.append((buf, lo, n))
+            ops.append(dist.P2POp(dist.irecv, buf, h))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    for item in keep:
+        if isinstance(item, tuple):
+            recv[item[1]:item[1] + item[2]] = item[0].numpy()
+    np.save(os.path.join(out_dir, "share%d.npy" % rank), recv)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,shape,nseg", [(2, (8, 8, 16), 5), (4, (4, 6, 32), 11)])
+def test_shared_replay_exchange_processes(tmp_path, world, shape, nseg):
+    """The shared replay of the reference's stream (rf_mt_share_*): segments dealt to ranks, counts all-reduced, pairs packed by
+    destination and exchanged point to point over gloo; every rank ends up with its planes (+ the Nyquist plane) of
+    RandomState(seed).normal, i.e. its side array of the single-process stream."""
+    pytest.importorskip("torch")
+    import torch.multiprocessing as mp
+    from oracle import cpu_ref
+    from randomfield_amd import slab
+    nx, ny, nz = shape
+    ncells = nx * ny * (nz // 2 + 1)
+    rng = np.random.RandomState(world)
+    cuts = np.sort(rng.choice(np.arange(1, ncells + 40), nseg - 1, replace=False))       # uneven segments, a tail nobody needs
+    counts = np.diff(np.concatenate([[0], cuts, [ncells + 40]])).tolist()
+    mp.spawn(_share_worker, args=(world, _free_port(), shape, counts, str(tmp_path)), nprocs=world, join=True)
+    full = cpu_ref.reference_noise(11, ncells).reshape(nx, ny, nz // 2 + 1, 2)
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), "share%d.npy" % r)).reshape(nx, ny, nz // 2 // world + 1, 2)
+        assert np.array_equal(got, slab.split_side_array(full, world, r))
+
+
+def test_shared_replay_layout_rules():
+    from randomfield_amd import slab
+    nx, ny, nz, P = 4, 4, 16, 4
+    ncells = nx * ny * 9
+    lay = slab.shared_replay_layout([50, 30, 40, 44], nx, ny, nz, P)
+    assert lay["cell_begin"] == [0, 50, 80, 120, ncells] and lay["seg_begin"] == [0, 1, 2, 3, 4]
+    for q in range(P):          # every stream is complete and contiguous: rank r's pairs start where rank r - 1's ended
+        ends = [lay["recvoff"][q][r] + lay["sendcnt"][r][q] for r in range(P)]
+        assert lay["recvoff"][q][0] == 0 and ends[:-1] == lay["recvoff"][q][1:] and ends[-1] == lay["stream_pairs"]
+    with pytest.raises(ValueError):
+        slab.shared_replay_layout([10, 10], nx, ny, nz, 2)
+    # fewer segments than ranks: the empty-handed ranks send nothing
+    lay = slab.shared_replay_layout([ncells + 3], nx, ny, nz, 2)
+    assert lay["cell_begin"] == [0, 0, ncells] and sum(lay["sendcnt"][0]) == 0
+
+
 def test_unique_id_file_handoff(tmp_path, monkeypatch):
     """The torch-free unique-id hand-off used on the GPU path: rank 0 writes, the others read."""
     import threading

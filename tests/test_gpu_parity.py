@@ -1292,6 +1292,70 @@ def test_distributed_generator_single_rank(hip, monkeypatch):
         assert dist.generate_delta_field(seed=None, save_potential=False).shape == (32, 32, nz)   # agreed seed path
 
 
+@pytest.mark.parametrize("nranks,single", [(2, False), (4, False), (4, True), (8, True)])
+def test_shared_reference_stream_small(hip, dpower, nranks, single):
+    """rf_mt_share_*: ONE replay of RandomState(seed).normal shared by the ranks of a kz-slab job (each rank jumps to its own range
+    of segments, replays it, one all-to-all of deviates) against numpy's stream itself and against the oracle's field.  Short
+    segments (16 blocks) so that a 32 x 32 x 128 stream has 35 of them: ranks whose first segment has one, two and zero non-zero
+    radix-16 digits, shares that end inside rows, and a last rank whose share ends with the stream's unused tail."""
+    k, Pk = dpower
+    shape = (32, 32, 128)
+    nx, ny, nz = shape
+    plans = _slab_plans(hip, shape, np.complex64, k, Pk, nranks)
+    for p in plans:
+        p.set_mt_segment_blocks(16)
+    nseg, first, count = plans[-1].share_segments()
+    assert nseg == 35 and first + count == nseg and plans[0].share_segments()[1] == 0
+    for seed in (321, 7):                                               # (the second seed reuses every buffer)
+        noise = cpu_ref.reference_noise(seed, nx * ny * (nz // 2 + 1))
+        ref, rms = cpu_ref.generate_delta_field(nx, ny, nz, SPACING, k, Pk, noise=noise, double_fft=True)
+        acc = hip.DevicePlan.reference_noise_shared_local(plans, seed, single=single)
+        assert len(set(acc)) == 1 and acc[0] >= nx * ny * (nz // 2 + 1)
+        parts = [p.download_noise().reshape(p.k_shape + (2,)) for p in plans]
+        got = _slab_side_array(plans, lambda p: parts[plans.index(p)], nz // 2)
+        err = np.max(np.abs(got.reshape(-1) - noise) / np.maximum(np.abs(noise), 1e-300))
+        assert err <= (3e-7 if single else 1e-14)
+        for q in parts[1:]:                                             # every rank carries the Nyquist plane
+            assert np.array_equal(q[:, :, -1], parts[0][:, :, -1])
+        field = _slab_run(hip, plans, noise="resident")
+        assert np.max(np.abs(field - ref)) <= TOL_F32 * rms
+    for p in plans:
+        p.close()
+
+
+@pytest.mark.parametrize("shape,dtype,nranks", [((256, 256, 256), np.complex64, 8), ((128, 64, 256), np.complex128, 4)])
+def test_shared_reference_stream_equals_replicated_replay(hip, dpower, shape, dtype, nranks):
+    """Default segment length (68 / 9 segments): the shared replay in float64 mode leaves bit for bit the deviates that the
+    replicated replay (every rank replays everything: rf_noise_mt19937_ex on a multi-rank plan) leaves, float32 mode the same
+    values rounded as the single-rank float32 replay rounds them; fields agree with the single-rank field of the same seed."""
+    k, Pk = dpower
+    nx, ny, nz = shape
+    seed = 20260101
+    one = make_plan(hip, shape, dtype, k, Pk)
+    one.reference_noise(seed)
+    one.realise(noise="resident")
+    ref, rms = one.download_real(), one.moments()[1]
+    one.close()
+    plans = _slab_plans(hip, shape, dtype, k, Pk, nranks)
+    for p in plans:
+        p.reference_noise(seed)                                         # replicated: float64 deviates of the own planes
+    want = [p.download_noise() for p in plans]
+    hip.DevicePlan.reference_noise_shared_local(plans, seed, single=False)
+    for p, w in zip(plans, want):
+        assert np.array_equal(p.download_noise(), w)
+    field = _slab_run(hip, plans, noise="resident")
+    assert np.max(np.abs(field - ref)) <= (2e-6 if dtype == np.complex64 else 1e-12) * rms
+    if dtype == np.complex64:
+        hip.DevicePlan.reference_noise_shared_local(plans, seed, single=True)
+        for p, w in zip(plans, want):
+            g = p.download_noise()
+            assert np.array_equal(g, g.astype(np.float32)) and np.max(np.abs(g - w) / np.maximum(np.abs(w), 1e-30)) <= 3e-7
+        field = _slab_run(hip, plans, noise="resident")
+        assert np.max(np.abs(field - ref)) <= 3e-6 * rms
+    for p in plans:
+        p.close()
+
+
 def test_reference_stream_float32_copies(hip, dpower):
     """rf_noise_mt19937_ex(single = 1): the replayed numpy stream kept as float32 pairs (what Generator(complex64,
     rng='reference') uses).  Accept / reject is still float64, so every deviate lands in the same cell; the field, the
