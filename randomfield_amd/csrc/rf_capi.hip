@@ -1697,12 +1697,16 @@ int rf_noise_mt19937_ex(rf_plan* p, const uint32_t* state624, unsigned long long
   p->noise_resident = !single;
   p->noise32_resident = single != 0;
   if (!single) {
-    // the runs are dead once the compaction has moved them into p->noise (the stream is idle here): give the memory back --
-    // 1.27x the noise buffer, 11 GB at 1024^3, the difference between fitting and not fitting a 2048^3 float64 plan with a
-    // saved potential into 288 GB.  (float32 deviates live IN the runs and keep them.)
-    RF_HIP(hipFree(p->mt_scratch));
-    p->mt_scratch = nullptr;
-    p->mt_scratch_bytes = 0;
+    // the runs are dead once the compaction has moved them into p->noise (the stream is idle here).  They are 1.27x the noise
+    // buffer -- 11 GB at 1024^3, the difference between fitting and not fitting a 2048^3 float64 plan with a saved potential
+    // into 288 GB -- so they are given back when the device is getting full; otherwise they stay for the next seed (allocating
+    // and releasing 11 GB costs ~0.5 s per call, a hundred times the replay).  (float32 deviates live IN the runs and keep them.)
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < total_b / 3) {
+      RF_HIP(hipFree(p->mt_scratch));
+      p->mt_scratch = nullptr;
+      p->mt_scratch_bytes = 0;
+    }
   }
   return 0;
 }

@@ -500,6 +500,12 @@ def test_slab_float64_and_rccl_single_rank(hip, dpower):
     one.barrier()
     one.realise(seed=3)
     assert np.array_equal(one.download_real(), ref)
+    # the shared replay's collective calls on that communicator (integer all-reduce of the counts, own-block copy): one rank
+    # holds every segment, and the deviates must be those of the plain replay
+    one.reference_noise(77)
+    want = one.download_noise()
+    assert one.reference_noise_shared(77) >= 32 * 32 * 33
+    assert np.array_equal(one.download_noise(), want)
     one.close()
 
 
@@ -1352,6 +1358,37 @@ def test_shared_reference_stream_equals_replicated_replay(hip, dpower, shape, dt
             assert np.array_equal(g, g.astype(np.float32)) and np.max(np.abs(g - w) / np.maximum(np.abs(w), 1e-30)) <= 3e-7
         field = _slab_run(hip, plans, noise="resident")
         assert np.max(np.abs(field - ref)) <= 3e-6 * rms
+    for p in plans:
+        p.close()
+
+
+def test_shared_reference_stream_headline_size_against_reference_summary(hip, dpower):
+    """1024^3 over 8 virtual kz-slab ranks, seed 123, the stream replayed ONCE by the eight ranks together (4093 segments, 511-512
+    per rank; float32 transport): 4096 field values, the spot values and the rms of the REFERENCE's own run
+    (tests/golden/summary_1024_c64.npz, oracle/make_golden_large.py)."""
+    g = golden("summary_1024_c64.npz")
+    n, P = 1024, 8
+    k, Pk = dpower
+    plans = _slab_plans(hip, (n, n, n), np.complex64, k, Pk, P)
+    nseg = plans[0].share_segments()[0]
+    assert nseg >= 4000 and sum(p.share_segments()[2] for p in plans) == nseg
+    acc = hip.DevicePlan.reference_noise_shared_local(plans, 123, single=True)
+    assert acc[0] >= n * n * (n // 2 + 1)
+    for p in plans:
+        p.slab_forward(noise="resident")
+    hip.DevicePlan.slab_exchange_local(plans)
+    tot = np.zeros(2)
+    for p in plans:
+        p.slab_backward()
+        tot += np.array(p.slab_stats())
+    rms = float(g["rms"])
+    cells = float(n) ** 3
+    assert abs(np.sqrt(tot[1] / cells - (tot[0] / cells) ** 2) - rms) <= TOL_F32 * rms
+    nxl, s = n // P, n // 16
+    row = lambda ix: plans[ix // nxl].download_real(x0=ix % nxl, x1=ix % nxl + 1)[0]
+    sub = np.stack([row(ix)[::s, ::s] for ix in range(0, n, s)])
+    assert np.max(np.abs(sub - g["sub"])) <= TOL_F32 * rms
+    assert np.max(np.abs(row(0)[0, :4] - g["first"])) <= TOL_F32 * rms and np.max(np.abs(row(n - 1)[-1, -4:] - g["last"])) <= TOL_F32 * rms
     for p in plans:
         p.close()
 
