@@ -232,8 +232,14 @@ class Generator(object):
                 # (a complex64 plan keeps float32 copies of the deviates: its cells sigma * g are float32 anyway)
                 single = self.plan_c2r.data_out.dtype == np.float32
                 if self.distributed and dev.nranks > 1 and dev.tiled and dev.share_segments()[0] >= dev.nranks:
-                    # one stream, P ranks: each replays 1/P of it, one all-to-all of deviates (rf_mt_share_*)
-                    dev.reference_noise_shared(seed, single=single)
+                    # one stream, P ranks: each replays 1/P of it, one all-to-all of deviates (rf_mt_share_*); the first
+                    # time round under the watchdog that names a rank which never arrived (slab.Deadline)
+                    if getattr(self, "_shared_replay_ran", False):
+                        dev.reference_noise_shared(seed, single=single)
+                    else:
+                        with self.plan_c2r.dist.deadline("first shared replay of the reference stream"):
+                            dev.reference_noise_shared(seed, single=single)
+                        self._shared_replay_ran = True
                 else:
                     dev.reference_noise(seed, single=single)
                 noise = "resident"
