@@ -167,6 +167,13 @@ def other_configs(power, spacing, device):
                                           unfused=entry(1024, t_unfused, 56 * (1 + 2 / 1024),
                                                         note="rf_realise + rf_moments (host round trip) + rf_lognormal: 56 (1 + 2/nz) B/cell"))
     plan.close()
+    # config 4's grid on ONE GPU (34 GB): its per-GPU kernels at full axis length -- the length-2048 strided passes run as two
+    # 1024-point transforms per tile; the 8-GPU job itself is `bench.py --gpus 8`
+    plan = plan_for(2048, np.complex64)
+    t = _timed(lambda: plan.realise(seed=next(seeds)), plan.sync, reps=3, warm=1)
+    out["2048^3 f32 on one GPU"] = entry(2048, t, 20 * (1 + 2 / 2048), kernel_ms=dict(zip(("x", "y", "z", "reduce", "x_kz0_tiles"),
+                                                                                        [round(float(v), 3) for v in plan.kernel_ms()])))
+    plan.close()
     return out
 
 

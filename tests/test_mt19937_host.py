@@ -109,6 +109,27 @@ def test_tree_polynomials_are_the_right_powers(phi):
     assert _same_state(mt.jump_state(st, tree[4]), seq[5 * mt.SEGMENT_WORDS:5 * mt.SEGMENT_WORDS + mt.N])
 
 
+def test_digitwise_jump_to_a_rank_first_segment(tmp_path, monkeypatch):
+    """The shared replay (rf_mt_share_begin) reaches segment s from the seed's state with one jump per non-zero radix-16 digit
+    of s: digit d of weight 16^t uses row t*15 + d - 1 of the tree table.  Short segments (16 blocks) so that stepping the
+    generator to the target is cheap: s = 17 (two digits), 32 (one digit of weight 16), 9 (one digit)."""
+    monkeypatch.setenv("RANDOMFIELD_CACHE_DIR", str(tmp_path))
+    blocks = 16
+    tree = mt.tree_polynomials(2, cache=False, segment_blocks=blocks)
+    L = blocks * mt.N
+    st = mt.init_genrand(2026)
+    seq = mt.sequence(st, 33 * L + mt.N)
+    for s in (17, 32, 9):
+        cur, rest, t = st, s, 0
+        while rest:
+            d = rest % 16
+            if d:
+                cur = mt.jump_state(cur, tree[t * 15 + d - 1])
+            rest //= 16
+            t += 1
+        assert _same_state(cur, seq[s * L:s * L + mt.N])
+
+
 def test_tables_computed_at_run_time_go_to_the_user_cache_atomically(tmp_path, monkeypatch):
     """A segment length without a shipped table is computed once, written to cache_dir() through a temporary file, found
     there by the next process -- and a truncated file (another rank caught mid-write under the old scheme) is recomputed."""
