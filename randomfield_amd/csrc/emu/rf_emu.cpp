@@ -375,6 +375,17 @@ int realise_fast_impl(int nx, int ny, int nz, const GenHost& h, uint64_t seed, d
       x_done = true;
     }
   }
+  if constexpr (sizeof(T) == 8) {
+    if (nx == 1024 && ((long long)ny * nzc) % 8 == 0) {      // float64, length 1024: Col2 over the 512-point configuration
+      using C1 = GenSel<double, 512>::type;
+      using IO2 = FastGenColIO64<1, 0, 0, 2>;
+      IO2 io2;
+      io2.base = W; io2.g = io.g; io2.kz0 = 0; io2.nzl = (int)nzc; io2.rec = nullptr; io2.gp = io.gp; io2.pot = nullptr;
+      auto tw2 = make_twiddles<double>(1024);
+      run_col2_pass<C1, +1, IO2>(io2, (long long)ny * nzc, tw2.data());
+      x_done = true;
+    }
+  }
   if (!x_done) {
     rc = dispatch_col<T, +1, IO, GenSel>(nx, io, (long long)ny * nzc);
     if (rc) return rc;

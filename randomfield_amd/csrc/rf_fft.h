@@ -476,8 +476,11 @@ using FastGenColIO = FastGenColIOT<0, 1>;   // (emulator)
 // The same fast generation for float64 plans (native generator only: parity / reference-noise mode keeps the exact
 // float64 chain of GenColIO).  The deviates and sigma are formed in float32 -- hardware log / sin / cos, LDS
 // records -- and widened; the transform itself is float64.  One complex128 per lane (CPL = 1).
-template <int FIX = 1, int SLAB = 0, int POT = 0>
+template <int FIX = 1, int SLAB = 0, int POT = 0, int XS = 1>
 struct FastGenColIO64 {
+  static_assert(XS == 1 || (XS == 2 && SLAB == 0 && POT == 0), "half-transform rows: plain generation only");
+  int xp = 0;
+  RF_HD void set_phase(int p) { xp = p; }
   cplx<double>* base;
   ColGeom g;
   FastGenParams gp;
@@ -499,10 +502,12 @@ struct FastGenColIO64 {
     const uint64_t seed = gp.seed;                                                      // bind_seed() ran first
     const int iy = (int)((unsigned)C >> nzl_shift()), kz = kz0 + (int)((unsigned)C & (unsigned)(nzl - 1));   // lane, m-invariant
     const uint64_t plane = (uint64_t)gp.ny * (uint64_t)(gp.nz / 2);                    // noise cells per unit of ix
-    const uint64_t ci_l = (uint64_t)rb * plane + (uint64_t)iy * (uint64_t)(gp.nz / 2) + (uint64_t)kz;
-    const uint64_t ci_u = pin_uniform((uint64_t)ro * plane);
-    const int ro_s = ro >= (gp.nx >> 1) ? ro - gp.nx : ro;
-    const float kx = (float)(rb + ro_s) * gp.dkx, ky = (float)fast_signed_index(iy, gp.ny) * gp.dky;
+    // mode index ix = XS (rb + ro) + xp = (lane part rbt) + (uniform part rot), as in FastGenColIOT
+    const int rbt = XS * rb, rot = XS * ro + (XS == 2 ? xp : 0);
+    const uint64_t ci_l = (uint64_t)rbt * plane + (uint64_t)iy * (uint64_t)(gp.nz / 2) + (uint64_t)kz;
+    const uint64_t ci_u = pin_uniform((uint64_t)rot * plane);
+    const int ro_s = XS * ro >= (gp.nx >> 1) ? rot - gp.nx : rot;
+    const float kx = (float)(rbt + ro_s) * gp.dkx, ky = (float)fast_signed_index(iy, gp.ny) * gp.dky;
     const float k2 = fast_k2(gp, fmaf(kx, kx, ky * ky), kz);
     const cplx<float> c = fast_gen_one(gp, rec, seed, ci_l + ci_u, k2);
     V16<double> v;
@@ -524,7 +529,7 @@ struct FastGenColIO64 {
     const uint64_t seed = gp.seed;                                                      // bind_seed() ran first
     cplx<float> p0, pn;
     const int iy = (int)((unsigned)C >> nzl_shift());
-    const cplx<float> c = fast_fix_kz0(gp, rec, seed, rb + ro, iy, p0, pn);
+    const cplx<float> c = fast_fix_kz0(gp, rec, seed, XS * (rb + ro) + (XS == 2 ? xp : 0), iy, p0, pn);
     if (POT) {
       cplx<double>* row = pot + ((long long)(rb + ro) * gp.ny + iy) * gp.ppitch;      // only the rank with kz0 = 0 gets here
       row[0] = mk<double>((double)p0.x, (double)p0.y);

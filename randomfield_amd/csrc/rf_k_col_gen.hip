@@ -41,9 +41,9 @@ hipError_t launch_one2(const IO& io_in, long long ncols, const cplx<typename C1:
 // fast float32 generation + x pass of length 2 C1::N through Col2 (native generator, whole grid or kz slab; no potential store,
 // no resident deviates, no x-slab restriction: those keep the whole-column kernel)
 template <class C1, class IO0, class IO1>
-hipError_t launch_fast_one2(const FastGenParams& gp, cplx<float>* W, ColGeom g, long long ncols, int kz0, int nzl,
-                            const cplx<float>* tw2, hipStream_t s, bool po, hipEvent_t after_repair) {
-  if (nzl <= 0 || (nzl & (nzl - 1)) || ncols >= (1LL << 31) || g.needs_wide(C1::LMAX, C1::TC, (int)sizeof(cplx<float>)) || !g.rows_ok(C1::N / C1::RL, C1::NPASS))
+hipError_t launch_fast_one2(const FastGenParams& gp, cplx<typename C1::T>* W, ColGeom g, long long ncols, int kz0, int nzl,
+                            const cplx<typename C1::T>* tw2, hipStream_t s, bool po, hipEvent_t after_repair) {
+  if (nzl <= 0 || (nzl & (nzl - 1)) || ncols >= (1LL << 31) || g.needs_wide(C1::LMAX, C1::TC, (int)sizeof(cplx<typename C1::T>)) || !g.rows_ok(C1::N / C1::RL, C1::NPASS))
     return hipErrorInvalidValue;
   IO0 io0; io0.base = W; io0.g = g; io0.gp = gp; io0.kz0 = kz0; io0.nzl = nzl; io0.rec = nullptr; io0.pot = nullptr;
   IO1 io1; io1.base = W; io1.g = g; io1.gp = gp; io1.kz0 = kz0; io1.nzl = nzl; io1.rec = nullptr; io1.pot = nullptr;
@@ -171,6 +171,15 @@ hipError_t launch_col_fastgen(int f64, int N, void* W, ColGeom g, long long ncol
   switch (N) {                                                                                                           \
     RF_COL_SIZES(X)                                                                                                       \
     default: return hipErrorInvalidValue;                                                                                \
+  }
+#ifndef RF_COL2_F64_1024
+#define RF_COL2_F64_1024 1             // the float64 generation pass of length 1024 as two 512-point transforms per tile (Col2): two workgroups per CU
+#endif
+  if (RF_COL2_F64_1024 && f64 && N == 1024 && (!slab || po)) {
+    using C1 = GenSel<double, 512>::type;
+    hipError_t e = launch_fast_one2<C1, FastGenColIO64<0, 0, 0, 2>, FastGenColIO64<1, 0, 0, 2>>(
+        gp, (cplx<double>*)W, g, ncols, kz0, nzl, (const cplx<double>*)tw, s, po, after_repair);
+    if (!po || e != hipSuccess) return e;
   }
   if (f64) {
     if (slab || po) {

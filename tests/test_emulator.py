@@ -166,6 +166,22 @@ def test_length_2048_passes_as_two_half_transforms(shape, default_power):
     assert abs(np.sqrt(s2 / n - (s1 / n) ** 2) - rms) <= 1e-5 * rms
 
 
+def test_float64_length_1024_generation_as_two_half_transforms(default_power):
+    """float64 plans run the length-1024 generation pass as two 512-point transforms per tile (Col2 with FastGenColIO64<…, XS = 2>:
+    64 KB tiles, two workgroups per CU instead of one): against the oracle's float64 restatement of the native stream."""
+    nx, ny, nz = 1024, 8, 32
+    k, Pk = default_power["k"], default_power["Pk"]
+    xt, st = cpu_ref.sigma_table(k, Pk, nx, ny, nz, 2.5)
+    out, s1, s2 = emu_util.realise_fast(nx, ny, nz, 2.5, xt, st, seed=17, dtype=np.float64)
+    noise = cpu_ref.native_noise(17, nx, ny, nz, np.complex128)
+    ref, rms = cpu_ref.generate_delta_field(nx, ny, nz, 2.5, k, Pk, noise=noise, dtype=np.complex128)
+    assert np.max(np.abs(out - ref)) <= 3e-5 * rms      # (float32 Box-Muller / sigma arithmetic, widened: as the float32 plans)
+    out32, t1, t2 = emu_util.realise_fast(nx, ny, nz, 2.5, xt, st, seed=17)
+    assert np.max(np.abs(out - out32)) <= 3e-6 * rms    # the same deviates through the float32 transform
+    n = out.size
+    assert abs(np.sqrt(s2 / n - (s1 / n) ** 2) - rms) <= 1e-5 * rms
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("M", ROW_SIZES)
 def test_row_r2c_all_sizes(M, dtype):

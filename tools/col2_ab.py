@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """1024^3 float32 pipeline of a library variant: graph-replayed batch time, eager per-pass times, rms (development tool).
-usage: tools/col2_ab.py [variant.so] [rounds]"""
+usage: tools/col2_ab.py [variant.so | -] [rounds] [f32 | f64]"""
 import os
 import sys
 import time
@@ -14,8 +14,9 @@ if len(sys.argv) > 1 and sys.argv[1] != "-":
     _hip.LIB_PATH = os.path.abspath(sys.argv[1])
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 n, K = 1024, 20
+dt = np.complex128 if len(sys.argv) > 3 and sys.argv[3] == "f64" else np.complex64
 power = powertools.load_default_power()
-plan = _hip.DevicePlan(n, n, n, np.complex64)
+plan = _hip.DevicePlan(n, n, n, dt)
 plan.set_kgrid(*powertools.ksq_axes(n, n, n, 2.5))
 plan.set_power(*powertools.sigma_table(power, (n, n, n), 2.5))
 seeds = np.arange(K, dtype=np.uint64)
