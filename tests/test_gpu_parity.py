@@ -914,7 +914,7 @@ def test_lensing_kernel_closed_form(hip, K):
 
 
 @pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
-@pytest.mark.parametrize("shape", [(64, 32, 128), (1024, 8, 32), (512, 16, 64), (16, 16, 16)])
+@pytest.mark.parametrize("shape", [(64, 32, 128), (1024, 8, 32), (512, 16, 64), (16, 16, 16), (2048, 8, 32)])
 def test_fused_potential_store_native(hip, dpower, shape, dtype):
     """rf_realise_potential = the reference's default generate_delta_field(save_potential=True) (generate.py:191-219) with
     the native generator: delta(k)/k**2 written by the generation pass itself.  The field must be the one rf_realise
@@ -1192,7 +1192,8 @@ def _slab_side_array(plans, getter, nzc):
 
 @pytest.mark.parametrize("nranks", [2, 4])
 @pytest.mark.parametrize("shape,dtype,exact", [((64, 32, 128), np.complex64, False), ((32, 64, 64), np.complex64, True),
-                                                ((32, 16, 64), np.complex128, False), ((32, 16, 64), np.complex128, True)])
+                                                ((32, 16, 64), np.complex128, False), ((32, 16, 64), np.complex128, True),
+                                                ((2048, 8, 128), np.complex64, False), ((1024, 8, 128), np.complex128, False)])
 def test_slab_ranks_default_call_and_newtonian_potential(hip, dpower, shape, dtype, exact, nranks):
     """generate_delta_field(save_potential=True) + calculate_newtonian_potential (generate.py:200-217, 282-350) on kz-slab
     ranks: field, saved potential (every rank keeps its planes of delta(k)/k**2; fused second store stream of the
