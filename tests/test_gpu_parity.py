@@ -489,6 +489,13 @@ def test_slab_float64_and_rccl_single_rank(hip, dpower):
     field, s1, s2 = _virtual_rank_field(hip, shape, np.complex128, k, Pk, 4, seed=3, exact=True)
     assert np.max(np.abs(field - ref_exact)) <= 1e-13 * ref_exact.std()
     one.set_exact_generation(False)
+    # nx = 1024: the float64 generation pass as two 512-point transforms per tile (Col2), whole grid and on kz slabs
+    big = make_plan(hip, (1024, 8, 128), np.complex128, k, Pk)
+    big.realise(seed=3)
+    bref = big.download_real()
+    big.close()
+    field, s1, s2 = _virtual_rank_field(hip, (1024, 8, 128), np.complex128, k, Pk, 4, seed=3)
+    assert np.max(np.abs(field - bref)) <= 1e-6 * bref.std()
     # the RCCL library loads, a communicator initialises and a collective runs (1 rank: all a 1-GPU box allows)
     import sys
     if "torch" in sys.modules:
