@@ -133,7 +133,8 @@ int rf_download_noise(rf_plan* plan, double* host, unsigned long long first, uns
 
 /* ---- row X: Plan.execute (transform.py:303-315) ------------------------- */
 int rf_execute_c2r(rf_plan* plan);               /* k buffer -> real field, numpy normalisation 1/(nx ny nz) */
-int rf_execute_r2c(rf_plan* plan);               /* real field -> k buffer, unnormalised */
+int rf_execute_r2c(rf_plan* plan);               /* real field -> k buffer, unnormalised (transform.py:278-301's reverse plan); on a multi-rank
+                                                  * plan: rows on the x slab, the all-to-all in the other direction, columns on the kz slab */
 
 /* ---- unpacked complex-to-complex plans: Plan(packed=False) (transform.py:207-213,266-270; the reference's
  * tests/test_transform.py:180-298).  One device buffer [nx][ny][nz] complex, transformed in place.
@@ -241,6 +242,11 @@ int rf_slab_forward_ex(rf_plan* plan, uint64_t seed, int mode, const double* noi
 int rf_slab_exchange_local(rf_plan** plans, int n);
 int rf_slab_backward(rf_plan* plan);
 int rf_slab_stats(rf_plan* plan, double* sum, double* sumsq);
+/* the multi-rank forward transform (rf_execute_r2c) in the same separate steps: rows = z pass on the x slab + cut into send
+ * blocks; the reverse all-to-all between virtual ranks; cols = forward y and x passes on the kz slab + the k-space side array */
+int rf_slab_r2c_rows(rf_plan* plan);
+int rf_slab_exchange_local_reverse(rf_plan** plans, int n);
+int rf_slab_r2c_cols(rf_plan* plan);
 
 #ifdef __cplusplus
 }

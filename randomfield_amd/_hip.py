@@ -90,6 +90,9 @@ SIGNATURES = {
     "rf_slab_forward_ex": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, _c_dp, ctypes.c_int]),
     "rf_slab_exchange_local": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int]),
     "rf_slab_backward": (ctypes.c_int, [ctypes.c_void_p]),
+    "rf_slab_r2c_rows": (ctypes.c_int, [ctypes.c_void_p]),
+    "rf_slab_r2c_cols": (ctypes.c_int, [ctypes.c_void_p]),
+    "rf_slab_exchange_local_reverse": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int]),
     "rf_slab_stats": (ctypes.c_int, [ctypes.c_void_p, _c_dp, _c_dp]),
 }
 
@@ -509,7 +512,8 @@ class DevicePlan(object):
 
     def upload_real(self, data, padded=False):
         nzp = self.nz + 2 if padded else self.nz
-        if data.shape != (self.nx, self.ny, nzp) or data.dtype != self.real_dtype or not data.flags.c_contiguous:
+        # (a multi-rank plan takes its own nx / ranks planes)
+        if data.shape != (self.nx_local, self.ny, nzp) or data.dtype != self.real_dtype or not data.flags.c_contiguous:
             raise ValueError("upload_real: wrong shape, dtype or layout")
         check(self._lib.rf_upload_real(self._h, data.ctypes.data_as(ctypes.c_void_p),
                                        LAYOUT_PADDED if padded else LAYOUT_DENSE), "rf_upload_real")
@@ -568,6 +572,19 @@ class DevicePlan(object):
 
     def slab_backward(self):
         check(self._lib.rf_slab_backward(self._h), "rf_slab_backward")
+
+    def slab_r2c_rows(self):
+        """Multi-rank forward transform, first half: z pass on this rank's x slab, rows cut into the send blocks."""
+        check(self._lib.rf_slab_r2c_rows(self._h), "rf_slab_r2c_rows")
+
+    def slab_r2c_cols(self):
+        """... second half: forward y and x passes on this rank's kz slab, result in the k-space side array."""
+        check(self._lib.rf_slab_r2c_cols(self._h), "rf_slab_r2c_cols")
+
+    @staticmethod
+    def slab_exchange_local_reverse(plans):
+        arr = (ctypes.c_void_p * len(plans))(*[p._h.value for p in plans])
+        check(load().rf_slab_exchange_local_reverse(arr, len(plans)), "rf_slab_exchange_local_reverse")
 
     def slab_stats(self):
         a, b = ctypes.c_double(), ctypes.c_double()

@@ -1036,13 +1036,51 @@ int rf_execute_c2r(rf_plan* p) {
   return queue_c2r(p, make_gen(p, 0, RF_NOISE_NATIVE, false), p->K);
 }
 
+namespace {
+// multi-rank forward transform, x-slab half: z pass on the local rows, in place, then the rows cut into the P send blocks
+// [nxl][ny][nzl] of R (block g = the kz planes of rank g) -- the reverse of what the gathering z pass reads
+int queue_r2c_slab_rows(rf_plan* p, hipStream_t s) {
+  const long long nrows = (long long)p->nxl * p->ny;
+  RF_HIP(launch_row_r2c(p->f64, (int)p->nzc, p->W, nrows, p->tw_z, s));
+  const size_t seg = (size_t)p->nzl * p->csize, blk = (size_t)nrows * seg;
+  for (int g = 0; g < p->nranks; ++g)
+    RF_HIP(hipMemcpy2DAsync((char*)p->R + g * blk, seg, (const char*)p->W + g * seg, (size_t)p->nzc * p->csize, seg, (size_t)nrows,
+                            hipMemcpyDeviceToDevice, s));
+  return 0;
+}
+// kz-slab half: forward y and x passes on [nx][ny][nzl] (the blocks as they arrived: x is the slowest axis), then the side array
+int queue_r2c_slab_cols(rf_plan* p, hipStream_t s) {
+  const long long nzl = p->nzl;
+  const ColGeom gx{(long long)p->ny * nzl, 0, (long long)p->ny * nzl}, gy{nzl, (long long)p->ny * nzl, nzl};
+  RF_HIP(launch_col_plain(p->f64, p->ny, -1, p->W, gy, (long long)p->nx * nzl, p->tw_y, s));
+  RF_HIP(launch_col_plain(p->f64, p->nx, -1, p->W, gx, (long long)p->ny * nzl, p->tw_x, s));
+  RF_HIP(launch_unpack_kspace(p->f64, p->W, p->K, p->nx, p->ny, (int)nzl, p->kz0, s));
+  p->real_valid = false;      // the field buffer now holds packed k space
+  p->stats_valid = false;
+  p->k_valid = true;
+  p->aux_valid = false;
+  return 0;
+}
+}  // namespace
+
 int rf_execute_r2c(rf_plan* p) {
   RF_REQUIRE(p, "null plan");
   RF_REQUIRE(!p->unpacked, "this call does not apply to an unpacked c2c plan");
-  RF_REQUIRE(p->nranks == 1, "rf_execute_r2c is single-GPU only");
   RF_REQUIRE(p->real_valid && p->cur == p->W, "no real-space field on the device: call rf_upload_real (or a c2r) first");
   RF_HIP(hipSetDevice(p->device));
   if (int rc = ensure_k(p)) return rc;
+  if (p->nranks > 1) {
+    // transform.py:278-301 on x-slab / kz-slab ranks: rows, the all-to-all in the other direction (block g of R -> rank g,
+    // arriving as block h of W: the same grouped send / receive with the buffers swapped), columns
+    RF_REQUIRE(!p->generic && !p->replicate, "the multi-rank forward transform runs on the tiled kernels of exchange-mode plans");
+    RF_HIP(hipEventRecord(p->ev[0], p->stream));
+    if (int rc = queue_r2c_slab_rows(p, p->stream)) return rc;
+    if (int rc = queue_exchange_rccl(p, p->R, p->W, p->stream)) return rc;
+    if (int rc = queue_r2c_slab_cols(p, p->stream)) return rc;
+    RF_HIP(hipEventRecord(p->ev[4], p->stream));
+    p->timed = false;
+    return 0;
+  }
   const long long nzc = p->nzc;
   const ColGeom gx{(long long)p->ny * nzc, 0, (long long)p->ny * nzc}, gy{nzc, (long long)p->ny * nzc, nzc};
   RF_HIP(hipEventRecord(p->ev[0], p->stream));
@@ -1060,7 +1098,7 @@ int rf_execute_r2c(rf_plan* p) {
   RF_HIP(launch_row_r2c(p->f64, (int)nzc, p->W, (long long)p->nx * p->ny, p->tw_z, p->stream));     // z, in place
   RF_HIP(launch_col_plain(p->f64, p->ny, -1, p->W, gy, (long long)p->nx * nzc, p->tw_y, p->stream));   // y forward
   RF_HIP(launch_col_plain(p->f64, p->nx, -1, p->W, gx, (long long)p->ny * nzc, p->tw_x, p->stream));   // x forward
-  RF_HIP(launch_unpack_kspace(p->f64, p->W, p->K, p->nx, p->ny, p->nz, p->stream));
+  RF_HIP(launch_unpack_kspace(p->f64, p->W, p->K, p->nx, p->ny, (int)nzc, 0, p->stream));
   RF_HIP(hipEventRecord(p->ev[4], p->stream));
   p->timed = false;
   p->real_valid = false;      // the field buffer now holds packed k space
@@ -1460,12 +1498,13 @@ int rf_download_k(rf_plan* p, void* host) {
 int rf_upload_real(rf_plan* p, const void* host, int layout) {
   RF_REQUIRE(p && host, "null argument");
   RF_REQUIRE(!p->unpacked, "this call does not apply to an unpacked c2c plan");
-  RF_REQUIRE(p->nranks == 1, "rf_upload_real is single-GPU only");
+  RF_REQUIRE(!p->replicate || p->nranks == 1, "replicated-generation plans keep no exchange buffers");
   RF_HIP(hipSetDevice(p->device));
   const size_t rsize = p->csize / 2;
   const size_t width = (size_t)p->nz * rsize;
   const size_t hpitch = layout == RF_LAYOUT_PADDED ? (size_t)(p->nz + 2) * rsize : width;
-  RF_HIP(hipMemcpy2DAsync(p->W, width, host, hpitch, width, (size_t)p->nx * p->ny, hipMemcpyHostToDevice, p->stream));
+  // (a multi-rank plan takes its own nx / ranks planes)
+  RF_HIP(hipMemcpy2DAsync(p->W, width, host, hpitch, width, (size_t)p->nxl * p->ny, hipMemcpyHostToDevice, p->stream));
   RF_HIP(hipStreamSynchronize(p->stream));
   p->cur = p->W;
   p->real_valid = true;
@@ -2149,6 +2188,44 @@ int rf_slab_exchange_local(rf_plan** plans, int n) {
   // plans' streams do not synchronise with the null stream: without this the gathering z pass of a large grid read
   // blocks that had not arrived yet (caught by the full-size config-4 test; small grids happened to win the race)
   RF_HIP(hipDeviceSynchronize());
+  return 0;
+}
+
+// the multi-rank forward transform in separate steps (virtual ranks): rows on the x slab, rf_slab_exchange_local_reverse, columns
+int rf_slab_r2c_rows(rf_plan* p) {
+  RF_REQUIRE(p, "null plan");
+  RF_REQUIRE(!p->unpacked && !p->generic, "this call applies to packed plans on the tiled kernels");
+  RF_REQUIRE(p->nranks > 1, "rf_slab_* are for multi-rank plans");
+  RF_REQUIRE(p->real_valid && p->cur == p->W, "no real-space field on the device: call rf_upload_real (or a c2r) first");
+  RF_HIP(hipSetDevice(p->device));
+  if (int rc = queue_r2c_slab_rows(p, p->stream)) return rc;
+  p->real_valid = false;
+  RF_HIP(hipStreamSynchronize(p->stream));
+  return 0;
+}
+int rf_slab_exchange_local_reverse(rf_plan** plans, int n) {
+  RF_REQUIRE(plans && n >= 1, "null argument");
+  for (int g = 0; g < n; ++g) {
+    RF_REQUIRE(plans[g] && plans[g]->nranks == n && plans[g]->rank == g, "plans must be ranks 0..n-1 of one n-rank job");
+    RF_REQUIRE(plans[g]->device == plans[0]->device, "virtual ranks must live on one device");
+    RF_HIP(hipStreamSynchronize(plans[g]->stream));
+  }
+  const rf_plan* p0 = plans[0];
+  const size_t blk = (size_t)p0->nxl * p0->ny * p0->nzl * p0->csize;
+  for (int h = 0; h < n; ++h)        // sender h (x slab), receiver g (kz slab): block g of R_h -> block h of W_g
+    for (int g = 0; g < n; ++g)
+      RF_HIP(hipMemcpy((char*)plans[g]->W + h * blk, (const char*)plans[h]->R + g * blk, blk, hipMemcpyDeviceToDevice));
+  RF_HIP(hipDeviceSynchronize());       // (see rf_slab_exchange_local)
+  return 0;
+}
+int rf_slab_r2c_cols(rf_plan* p) {
+  RF_REQUIRE(p, "null plan");
+  RF_REQUIRE(!p->unpacked && !p->generic, "this call applies to packed plans on the tiled kernels");
+  RF_REQUIRE(p->nranks > 1, "rf_slab_* are for multi-rank plans");
+  RF_HIP(hipSetDevice(p->device));
+  if (int rc = ensure_k(p)) return rc;
+  if (int rc = queue_r2c_slab_cols(p, p->stream)) return rc;
+  RF_HIP(hipStreamSynchronize(p->stream));
   return 0;
 }
 

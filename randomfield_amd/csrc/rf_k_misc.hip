@@ -162,19 +162,22 @@ __global__ __launch_bounds__(256) void scale_copy_kernel(const cplx<T>* __restri
 
 // after the forward x and y passes slot kz = 0 holds C = A0 + i A_nyq with A0, A_nyq Hermitian in (kx, ky):
 // A0(k) = (C(k) + conj C(-k)) / 2,  A_nyq(k) = (C(k) - conj C(-k)) / (2i)
+// W: [nx][ny][nzl] (this rank's kz planes kz0 .. kz0 + nzl; one rank: nzl = nz/2, kz0 = 0);  K: the side array [nx][ny][nzl + 1]
+// (own planes, then the Nyquist plane -- filled by the rank that owns kz = 0, zero on the others, which never read it)
 template <typename T>
 __global__ __launch_bounds__(256) void unpack_kspace_kernel(const cplx<T>* __restrict__ W, cplx<T>* __restrict__ K,
-                                                            int nx, int ny, int nz) {
-  const int nzc = nz / 2, nzh = nzc + 1;
+                                                            int nx, int ny, int nzl, int kz0) {
+  const int nzh = nzl + 1;
   const long long total = (long long)nx * ny * nzh;
   for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += (long long)gridDim.x * blockDim.x) {
     const int iz = (int)(c % nzh);
     const long long col = c / nzh;
     const int iy = (int)(col % ny), ix = (int)(col / ny);
-    if (iz > 0 && iz < nzc) { K[c] = W[col * nzc + iz]; continue; }
-    const cplx<T> a = W[col * nzc];
+    if (iz < nzl && kz0 + iz > 0) { K[c] = W[col * nzl + iz]; continue; }
+    if (kz0 != 0) { K[c] = mk<T>((T)0, (T)0); continue; }           // the Nyquist slot of a rank that does not hold it
+    const cplx<T> a = W[col * nzl];
     const long long mcol = (long long)((nx - ix) % nx) * ny + (ny - iy) % ny;
-    const cplx<T> b = W[mcol * nzc];
+    const cplx<T> b = W[mcol * nzl];
     if (iz == 0) K[c] = mk<T>((T)0.5 * (a.x + b.x), (T)0.5 * (a.y - b.y));
     else         K[c] = mk<T>((T)0.5 * (a.y + b.y), (T)0.5 * (b.x - a.x));
   }
@@ -288,10 +291,10 @@ hipError_t launch_gen_kspace(int f64, void* K, const GenParams& gp, hipStream_t 
   return hipGetLastError();
 }
 
-hipError_t launch_unpack_kspace(int f64, const void* W, void* K, int nx, int ny, int nz, hipStream_t s) {
-  const long long total = (long long)nx * ny * (nz / 2 + 1);
-  if (f64) hipLaunchKernelGGL(unpack_kspace_kernel<double>, dim3(grid_for(total, 256)), dim3(256), 0, s, (const cplx<double>*)W, (cplx<double>*)K, nx, ny, nz);
-  else hipLaunchKernelGGL(unpack_kspace_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, s, (const cplx<float>*)W, (cplx<float>*)K, nx, ny, nz);
+hipError_t launch_unpack_kspace(int f64, const void* W, void* K, int nx, int ny, int nzl, int kz0, hipStream_t s) {
+  const long long total = (long long)nx * ny * (nzl + 1);
+  if (f64) hipLaunchKernelGGL(unpack_kspace_kernel<double>, dim3(grid_for(total, 256)), dim3(256), 0, s, (const cplx<double>*)W, (cplx<double>*)K, nx, ny, nzl, kz0);
+  else hipLaunchKernelGGL(unpack_kspace_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, s, (const cplx<float>*)W, (cplx<float>*)K, nx, ny, nzl, kz0);
   return hipGetLastError();
 }
 

@@ -95,7 +95,7 @@ hipError_t launch_row_r2c(int f64, int M, void* W, long long nrows, const void* 
 hipError_t launch_row_c2c(int f64, int M, int dir, void* W, long long nrows, double scale, const void* tw, hipStream_t s,
                           bool prepare_only = false);
 // packed device array [nx][ny][nz/2] -> API layout [nx][ny][nz/2+1] (separates the kz = 0 and nz/2 planes)
-hipError_t launch_unpack_kspace(int f64, const void* W, void* K, int nx, int ny, int nz, hipStream_t s);
+hipError_t launch_unpack_kspace(int f64, const void* W, void* K, int nx, int ny, int nzl, int kz0, hipStream_t s);
 long long row_c2r_tiles(int f64, int M, long long nrows);
 
 // rows K,T,R,S into an API-layout k array [nx][ny][nz/2+1]

@@ -83,7 +83,31 @@ def _worker(rank, world, port, shape, out_dir):
     # global rms through a 2-double all-reduce
     st = torch.tensor([delta.sum(), (delta ** 2).sum()], dtype=torch.float64)
     dist.all_reduce(st)
-    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), delta=delta, stats=st.numpy(), x0=lay["x0"], phi=phi, share=share)
+    # the forward transform on slab ranks (rf_execute_r2c, transform.py:278-301): rows on the x slab, the same blocks the other
+    # way (block g of the x-slab rank -> kz-slab rank g), columns on the kz slab, slot kz = 0 untangled into the two real planes
+    nzl, nxl = lay["nzl"], lay["nxl"]
+    rows = np.fft.rfft(delta, axis=2)
+    pk = rows[:, :, :nzc].copy()
+    pk[:, :, 0] = rows[:, :, 0].real + 1j * rows[:, :, nzc].real
+    send = [torch.from_numpy(np.ascontiguousarray(pk[:, :, g * nzl:(g + 1) * nzl]).view(np.float64)) for g in range(world)]
+    recv = [torch.empty_like(send[0]) for _ in range(world)]
+    recv[rank].copy_(send[rank])
+    ops = []
+    for h in range(world):
+        if h != rank:
+            ops.append(dist.P2POp(dist.isend, send[h], h))
+            ops.append(dist.P2POp(dist.irecv, recv[h], h))
+    for req in dist.batch_isend_irecv(ops):
+        req.wait()
+    cols = np.fft.fft(np.fft.fft(np.concatenate([t.numpy().view(np.complex128) for t in recv], axis=0), axis=1), axis=0)
+    kshare = np.zeros((nx, ny, nzl + 1), np.complex128)
+    kshare[:, :, :nzl] = cols
+    if rank == 0:
+        c = cols[:, :, 0]
+        cm = np.conj(np.roll(c[::-1, ::-1], (1, 1), axis=(0, 1)))          # conj C(-kx, -ky)
+        kshare[:, :, 0] = 0.5 * (c + cm)
+        kshare[:, :, nzl] = (c - cm) / 2j
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), delta=delta, stats=st.numpy(), x0=lay["x0"], phi=phi, share=share, kshare=kshare)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -110,6 +134,12 @@ def test_slab_exchange_processes(tmp_path, world, shape):
         assert np.allclose(g["phi"], phi_ref[x0:x0 + nx // world], rtol=0, atol=1e-12 * phi_ref.std())
         n = ref.size
         assert abs(np.sqrt(g["stats"][1] / n - (g["stats"][0] / n) ** 2) - rms) < 1e-12 * rms
+    fwd = np.fft.rfftn(ref, axes=(0, 1, 2))
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))["kshare"]
+        want = slab.split_side_array(fwd, world, r)
+        keep = slice(None) if r == 0 else slice(0, want.shape[2] - 1)          # (only rank 0 fills the Nyquist slot)
+        assert np.allclose(got[:, :, keep], want[:, :, keep], rtol=0, atol=1e-10 * np.abs(fwd).max())
 
 
 def _share_worker(rank, world, port, shape, counts, out_dir):

@@ -1279,6 +1279,36 @@ def test_slab_ranks_reference_stream(hip, dpower, nranks):
         p.close()
 
 
+@pytest.mark.parametrize("shape,dtype,nranks", [((32, 16, 64), np.complex64, 2), ((64, 32, 128), np.complex64, 4), ((32, 16, 64), np.complex128, 4),
+                                                 ((1024, 8, 256), np.complex64, 8), ((16, 2048, 64), np.complex64, 2)])
+def test_forward_r2c_on_slab_ranks(hip, shape, dtype, nranks):
+    """rf_execute_r2c on multi-rank plans (transform.py:278-301's reverse plan): every rank uploads its x slab, runs the z pass
+    on its rows, the all-to-all goes the other way (x slabs -> kz slabs; device copies between virtual ranks), the y and x passes
+    run on the kz slab and every rank ends up with its planes (+ the Nyquist plane on rank 0) of np.fft.rfftn.  Then the way back
+    through the ordinary inverse pipeline: c2r(r2c(x)) = x."""
+    nx, ny, nz = shape
+    rt, tol = (np.float32, 3e-6) if dtype == np.complex64 else (np.float64, 1e-13)
+    rng = np.random.RandomState(nx + nz)
+    f = rng.normal(size=shape).astype(rt)
+    ref = np.fft.rfftn(f.astype(np.float64), axes=(0, 1, 2))
+    plans = [hip.DevicePlan(nx, ny, nz, dtype, nranks=nranks, rank=r) for r in range(nranks)]
+    nxl = nx // nranks
+    for r, p in enumerate(plans):
+        p.upload_real(np.ascontiguousarray(f[r * nxl:(r + 1) * nxl]))
+        p.slab_r2c_rows()
+    hip.DevicePlan.slab_exchange_local_reverse(plans)
+    for p in plans:
+        p.slab_r2c_cols()
+    got = _slab_side_array(plans, lambda p: p.download_k(), nz // 2)
+    assert got.shape == ref.shape and np.max(np.abs(got - ref)) <= 10 * tol * np.abs(ref).std() * np.sqrt(np.log2(f.size))
+    for p in plans[1:]:
+        assert np.all(p.download_k()[:, :, -1] == 0)              # (the Nyquist slot of the ranks that do not own it)
+    back = _slab_run(hip, plans, source="kspace")
+    assert np.max(np.abs(back - f)) <= 20 * tol * f.std()
+    for p in plans:
+        p.close()
+
+
 def test_distributed_generator_single_rank(hip, monkeypatch):
     """Generator(distributed=True) with WORLD_SIZE = 1: the per-rank plumbing (SlabHostPlan window, agreed seeds, local
     potential / lensing downloads) gives the ordinary Generator's results.  With more ranks the same calls run the slab
