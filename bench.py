@@ -135,15 +135,28 @@ def other_configs(power, spacing, device):
         1024, t, 20 * (1 + 2 / 1024), note="per realisation; includes the host-side seeding of the ten MT19937 states")
     plan.close()
     # the reference API's default call: Generator.generate_delta_field(save_potential=True), field kept on the device
+    # (default: delta(k)/k**2 is not written but formed again inside calculate_newtonian_potential's generation pass -- from the
+    # seed, or from the replayed deviates still on the device; store_potential=True writes it at generation time as the reference
+    # does.  Both are timed, each also together with the call that uses the potential.)
     for rng in ("native", "reference"):
-        gen = Generator(1024, 1024, 1024, spacing, power=power, rng=rng)
-        dev = gen.plan_c2r.device
-        t = _timed(lambda: gen.generate_delta_field(seed=next(seeds), save_potential=True, download=False), dev.sync, reps=5, warm=3)
-        out["1024^3 f32 Generator.generate_delta_field(save_potential=True), rng='%s'" % rng] = entry(1024, t, 20 * (1 + 2 / 1024))
-        t = _timed(lambda: gen.generate_delta_field(seed=next(seeds), save_potential=False, download=False), dev.sync)
-        out["1024^3 f32 Generator.generate_delta_field(save_potential=False), rng='%s'" % rng] = entry(1024, t, 20 * (1 + 2 / 1024))
-        dev.close()
-        del gen
+        for store in (False, True):
+            gen = Generator(1024, 1024, 1024, spacing, power=power, rng=rng, store_potential=store)
+            dev = gen.plan_c2r.device
+            how = "potential stored at generation time (store_potential=True)" if store else "potential regenerated on demand (default)"
+            key = "1024^3 f32 Generator.generate_delta_field(save_potential=True), rng='%s'%s" % (rng, ", store_potential=True" if store else "")
+            t = _timed(lambda: gen.generate_delta_field(seed=next(seeds), save_potential=True, download=False), dev.sync, reps=5, warm=3)
+
+            def both():
+                gen.generate_delta_field(seed=next(seeds), save_potential=True, download=False)
+                gen.calculate_newtonian_potential(light_cone=False, scale=-1.5, download=False)
+            t2 = _timed(both, dev.sync, reps=3, warm=1)
+            out[key] = entry(1024, t, (28 if store else 20) * (1 + 2 / 1024), note=how,
+                             ms_with_calculate_newtonian_potential=round(t2 * 1e3, 3))
+            if not store:
+                t = _timed(lambda: gen.generate_delta_field(seed=next(seeds), save_potential=False, download=False), dev.sync)
+                out["1024^3 f32 Generator.generate_delta_field(save_potential=False), rng='%s'" % rng] = entry(1024, t, 20 * (1 + 2 / 1024))
+            dev.close()
+            del gen
     # (last: after this 17 GB plan has been freed, the allocator hands later plans memory on which the strided store
     # streams of the default call run 20 % slower -- tools/frag_probe.py: 5.7 ms fresh, 6.8 ms after a float64 plan)
     # config 4's dtype on one GPU, and config 5: float64 + lognormal map (rows D and L: moments, then the per-z map)

@@ -131,6 +131,13 @@ int rf_mt_share_finish(rf_plan* plan, unsigned long long* accepted);
 /* copy deviates [first, first+count) of the device noise buffer to the host (tests) */
 int rf_download_noise(rf_plan* plan, double* host, unsigned long long first, unsigned long long count);
 
+/* calculate_newtonian_potential (generate.py:333-343) without a stored potential: the inverse transform of scale * delta(k) / k^2
+ * with delta(k) regenerated inside the generation pass exactly as rf_realise(seed, mode) produces it (native generator: keyed by
+ * (seed, cell); RF_NOISE_RESIDENT: the replayed stream still on the device).  rf_can_regenerate_potential: 1 if the plan and
+ * mode allow it (fast generation pass; float32 replayed deviates), else use rf_realise_potential + rf_load_potential. */
+int rf_can_regenerate_potential(rf_plan* plan, int mode);
+int rf_realise_scaled_potential(rf_plan* plan, uint64_t seed, int mode, double scale);
+
 /* ---- row X: Plan.execute (transform.py:303-315) ------------------------- */
 int rf_execute_c2r(rf_plan* plan);               /* k buffer -> real field, numpy normalisation 1/(nx ny nz) */
 int rf_execute_r2c(rf_plan* plan);               /* real field -> k buffer, unnormalised (transform.py:278-301's reverse plan); on a multi-rank

@@ -52,6 +52,8 @@ SIGNATURES = {
     "rf_mt_share_exchange_local": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int]),
     "rf_mt_share_finish": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_ulonglong)]),
     "rf_download_noise": (ctypes.c_int, [ctypes.c_void_p, _c_dp, ctypes.c_ulonglong, ctypes.c_ulonglong]),
+    "rf_can_regenerate_potential": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "rf_realise_scaled_potential": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_double]),
     "rf_execute_c2r": (ctypes.c_int, [ctypes.c_void_p]),
     "rf_execute_r2c": (ctypes.c_int, [ctypes.c_void_p]),
     "rf_plan_create_c2c": (ctypes.c_int, [_c_void_pp] + [ctypes.c_int] * 5),
@@ -435,6 +437,20 @@ class DevicePlan(object):
         mode, ptr, keep = self._noise_arg(noise)
         check(self._lib.rf_realise_potential(self._h, ctypes.c_uint64(int(seed) & (2 ** 64 - 1)), mode, ptr),
               "rf_realise_potential")
+
+    def can_regenerate_potential(self, noise=None):
+        """May ``realise_scaled_potential`` stand in for a stored potential (fast generation pass; native generator or the
+        replayed stream resident as float32 pairs)?"""
+        if noise is not None and not (isinstance(noise, str) and noise == "resident"):
+            return False
+        return bool(self._lib.rf_can_regenerate_potential(self._h, NOISE_RESIDENT if noise is not None else NOISE_NATIVE))
+
+    def realise_scaled_potential(self, seed=0, noise=None, scale=1.0):
+        """calculate_newtonian_potential without a stored potential: the inverse transform of ``scale * delta(k)/k**2`` with
+        delta(k) regenerated as ``realise(seed, noise)`` generates it (rf_realise_scaled_potential)."""
+        mode, ptr, keep = self._noise_arg(noise)
+        check(self._lib.rf_realise_scaled_potential(self._h, ctypes.c_uint64(int(seed) & (2 ** 64 - 1)), mode, float(scale)),
+              "rf_realise_scaled_potential")
 
     def realise_batch(self, seeds, want_rms=True):
         seeds = np.ascontiguousarray(seeds, dtype=np.uint64)

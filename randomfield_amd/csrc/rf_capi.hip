@@ -176,6 +176,8 @@ struct rf_plan {
   hipEvent_t seeds_ev[2] = {nullptr, nullptr};
   int seeds_pin_cap = 0, seeds_turn = 0;
   bool resident_fast = false;             // the current call draws from the device-resident deviates (RF_NOISE_RESIDENT)
+  bool emit_potential = false;            // the current call transforms emit_pscale * delta(k) / k^2 instead of delta(k) (rf_realise_scaled_potential)
+  double emit_pscale = 0.0;
   void* pot_target = nullptr;             // non-null while rf_realise_potential queues its x pass: where delta(k)/k^2 goes
   double* coll_scratch = nullptr;         // 2 doubles on the device for host-side all-reduces (never aliases `stats`)
   double* ztab = nullptr;                 // 2 * nz doubles for lognormal / affine tables
@@ -314,7 +316,9 @@ FastGenParams make_fast(rf_plan* p, uint64_t seed, bool seed_from_dev, const uin
   f.rec = p->frec; f.nbins = p->fnbins; f.u_scale = p->fu_scale; f.u_off = p->fu_off;
   f.seed = seed; f.seed_dev = seed_from_dev ? seed_ptr : nullptr;
   f.noise = nullptr; f.noise32 = nullptr;
+  f.seg_off = nullptr; f.seg_cap = 0; f.seg_inv = 0; f.nseg = 0;
   f.zpitch = p->nzl + 1; f.zoff = p->kz0; f.ppitch = p->ppitch;
+  f.pscale = p->emit_pscale; f.emit_potential = p->emit_potential ? 1 : 0;
   return f;
 }
 
@@ -1122,6 +1126,36 @@ int rf_realise(rf_plan* p, uint64_t seed, int mode, const double* noise_host) {
   if (rc) return rc;
   if (mode == RF_NOISE_EXTERNAL) RF_HIP(hipStreamSynchronize(p->stream));
   return 0;
+}
+
+// calculate_newtonian_potential (generate.py:333-343) WITHOUT a stored potential: the inverse transform of scale * delta(k) / k^2,
+// with delta(k) regenerated inside the x pass exactly as rf_realise(seed, mode) generates it -- the native generator is keyed by
+// (seed, cell), the replayed reference stream is still resident -- so generate_delta_field(save_potential=True) need not write
+// 4.3 GB per 1024^3 "in case" and the later load + transform reads nothing.  Every cell is rounded as its stored copy and the
+// scaled copy of that would be.  Needs the fast generation pass (rf_can_regenerate_potential); returns the real field in place of
+// the current one, like rf_load_potential + rf_execute_c2r.
+int rf_can_regenerate_potential(rf_plan* p, int mode) {
+  if (!p || p->unpacked || p->generic || !p->have_fast || p->exact_gen || (p->replicate && p->nranks > 1)) return 0;
+  if (mode == RF_NOISE_NATIVE) return 1;
+  if (mode == RF_NOISE_RESIDENT) return (p->noise32_resident && !p->f64) ? 1 : 0;
+  return 0;
+}
+
+int rf_realise_scaled_potential(rf_plan* p, uint64_t seed, int mode, double scale) {
+  RF_REQUIRE(p, "null plan");
+  RF_REQUIRE(!p->unpacked, "this call does not apply to an unpacked c2c plan");
+  RF_REQUIRE(p->have_kgrid && p->have_power, "rf_set_kgrid and rf_set_power must be called first");
+  RF_REQUIRE(rf_can_regenerate_potential(p, mode), "this plan / noise mode stores its potential (rf_realise_potential): nothing to regenerate from");
+  RF_HIP(hipSetDevice(p->device));
+  if (int rc = upload_noise(p, mode, nullptr)) return rc;
+  p->timed = true;
+  p->resident_fast = (mode == RF_NOISE_RESIDENT);
+  p->emit_potential = true;
+  p->emit_pscale = p->f64 ? scale : (double)(float)scale;
+  const int rc = queue_c2r(p, make_gen(p, seed, mode, false), nullptr);
+  p->emit_potential = false;
+  p->resident_fast = false;
+  return rc;
 }
 
 // generate_delta_field(save_potential=True) (generate.py:191-219): the field as rf_realise, plus delta(k) / k^2 in the

@@ -432,6 +432,10 @@ struct FastGenParams {
   unsigned long long seg_cap;          // attempts (= slots) per segment
   double seg_inv;                      // 1 / (accepted pairs of a full segment): first guess of a cell's segment
   int nseg;
+  // POT = 2 kernels: the pass emits pscale * delta(k) / k^2 instead of delta(k) -- the saved potential of generate.py:200-217
+  // regenerated from the seed (or the resident deviates) when calculate_newtonian_potential asks for it, never stored
+  double pscale;          // (float32 plans round it to float32, as the scaled copy of the stored potential does)
+  int emit_potential;     // host side: selects those kernels
 };
 enum { FAST_LDS_BINS = 512 };
 

@@ -343,7 +343,8 @@ template <typename T, bool WIDE = false> struct GenColIO {
 // guard costs the ordinary kernel nothing.
 // FIX: 1 = this kernel repairs the kz = 0 slot (rolled loop through LDS); 0 = it does not (the tiles that
 // hold kz = 0 are then re-run by a FIX = 1 launch).  An out-of-line call was measured 3x slower (scratch).
-// POT: 1 = the pass also stores delta(k) / k^2 (0 at DC) of every generated cell into `pot`, an API-layout array
+// POT: 2 = the pass transforms pscale * delta(k) / k^2 instead of delta(k) (the saved potential regenerated on demand: each
+// cell rounded as the stored one and its scaled copy would be); 1 = the pass also stores delta(k) / k^2 (0 at DC) of every generated cell into `pot`, an API-layout array
 // [nx][ny][nz/2+1] -- the save_potential=True branch of generate_delta_field (generate.py:200-217) without ever
 // materialising delta(k) itself.  (Rows of nz/2+1 cells are only 8-byte aligned: two 8-byte stores per lane.)
 // SRC: 0 = native Philox + Box-Muller draws; 1 = deviates resident in device memory as float64 (2 = as float32 pairs;
@@ -355,7 +356,7 @@ template <typename T, bool WIDE = false> struct GenColIO {
 // even / odd modes ix = 2 r + xp, xp = the phase set_phase() selects) -- native generation without the potential store only.
 template <int AB = 0, int FIX = 1, int SLAB = 0, int POT = 0, int SRC = 0, int XS = 1>
 struct FastGenColIOT {
-  static_assert(XS == 1 || (XS == 2 && SLAB == 0 && POT == 0 && SRC == 0), "half-transform rows: native generation only");
+  static_assert(XS == 1 || (XS == 2 && SLAB == 0 && POT != 1 && SRC == 0), "half-transform rows: native generation, no potential store");
   int xp = 0;
   RF_HD void set_phase(int p) { xp = p; }
   cplx<float>* base;
@@ -431,7 +432,12 @@ struct FastGenColIOT {
       v.c[0] = mk<float>(sa * ga.x, sa * ga.y);
       v.c[1] = mk<float>(sb * gb.x, sb * gb.y);
     }
-    if (POT) {
+    if (POT == 2) {
+      const float ra = fast_rcp(k2a), rb2 = fast_rcp(k2b), ps = (float)gp.pscale;      // (slot kz = 0, where k2a may be 0, is replaced by fix_value())
+      v.c[0] = mk<float>((v.c[0].x * ra) * ps, (v.c[0].y * ra) * ps);
+      v.c[1] = mk<float>((v.c[1].x * rb2) * ps, (v.c[1].y * rb2) * ps);
+    }
+    if (POT == 1) {
       // row (ix, iy) of the API layout; the slot kz = 0 (Hermitian planes) is written by fix_value() instead
       // rows of gp.ppitch (even) cells: the pair (kz even, kz + 1) is one aligned 16-byte store
       const int nzp = gp.ppitch, sl = kz - gp.zoff;
@@ -458,10 +464,14 @@ struct FastGenColIOT {
     cplx<float> p0, pn;
     const cplx<float> packed = SRC != 0 ? fast_fix_kz0_noise<SRC == 0 ? 1 : SRC>(gp, rec, rb + ro, iy, p0, pn)
                                         : fast_fix_kz0(gp, rec, seed, XS * (rb + ro) + (XS == 2 ? xp : 0), iy, p0, pn);
-    if (POT) {
+    if (POT == 1) {
       cplx<float>* row = pot + ((long long)(rb + ro) * gp.ny + iy) * gp.ppitch;   // only the rank with kz0 = 0 gets here: slot 0 = plane 0
       row[0] = p0;
       row[gp.zpitch - 1] = pn;
+    }
+    if (POT == 2) {           // (plane kz = 0) + i (plane kz = nz/2) of the scaled potential
+      const float ps = (float)gp.pscale;
+      return mk<float>(p0.x * ps - pn.y * ps, p0.y * ps + pn.x * ps);
     }
     return packed;
   }
@@ -478,7 +488,7 @@ using FastGenColIO = FastGenColIOT<0, 1>;   // (emulator)
 // records -- and widened; the transform itself is float64.  One complex128 per lane (CPL = 1).
 template <int FIX = 1, int SLAB = 0, int POT = 0, int XS = 1>
 struct FastGenColIO64 {
-  static_assert(XS == 1 || (XS == 2 && SLAB == 0 && POT == 0), "half-transform rows: plain generation only");
+  static_assert(XS == 1 || (XS == 2 && SLAB == 0 && POT != 1), "half-transform rows: no x-slab restriction, no potential store");
   int xp = 0;
   RF_HD void set_phase(int p) { xp = p; }
   cplx<double>* base;
@@ -512,7 +522,11 @@ struct FastGenColIO64 {
     const cplx<float> c = fast_gen_one(gp, rec, seed, ci_l + ci_u, k2);
     V16<double> v;
     v.c[0] = mk<double>((double)c.x, (double)c.y);
-    if (POT && !(FIX != 0 && kz == 0)) {          // (slot kz = 0: the two Hermitian planes, written by fix_value())
+    if (POT == 2) {
+      const float r = fast_rcp(k2);
+      v.c[0] = mk<double>((double)(c.x * r) * gp.pscale, (double)(c.y * r) * gp.pscale);
+    }
+    if (POT == 1 && !(FIX != 0 && kz == 0)) {          // (slot kz = 0: the two Hermitian planes, written by fix_value())
       const float r = fast_rcp(k2);
       V16<double> q;
       q.c[0] = mk<double>((double)(c.x * r), (double)(c.y * r));
@@ -530,10 +544,14 @@ struct FastGenColIO64 {
     cplx<float> p0, pn;
     const int iy = (int)((unsigned)C >> nzl_shift());
     const cplx<float> c = fast_fix_kz0(gp, rec, seed, XS * (rb + ro) + (XS == 2 ? xp : 0), iy, p0, pn);
-    if (POT) {
+    if (POT == 1) {
       cplx<double>* row = pot + ((long long)(rb + ro) * gp.ny + iy) * gp.ppitch;      // only the rank with kz0 = 0 gets here
       row[0] = mk<double>((double)p0.x, (double)p0.y);
       row[gp.zpitch - 1] = mk<double>((double)pn.x, (double)pn.y);
+    }
+    if (POT == 2) {
+      const double ps = gp.pscale;
+      return mk<double>((double)p0.x * ps - (double)pn.y * ps, (double)p0.y * ps + (double)pn.x * ps);
     }
     return mk<double>((double)c.x, (double)c.y);
   }

@@ -3,6 +3,12 @@
 #include "rf_launch.h"
 
 
+#ifndef RF_COL2_2048
+#define RF_COL2_2048 1                 // length-2048 float32 passes as two 1024-point transforms per tile (Col2); 0 = the whole-column kernels
+#endif
+#ifndef RF_COL2_F64_1024
+#define RF_COL2_F64_1024 1             // the float64 generation pass of length 1024 as two 512-point transforms per tile (Col2): two workgroups per CU
+#endif
 namespace rf {
 namespace {
 // runs tiles  b * tile_mul + tile_add,  b in [0, ntiles)
@@ -120,6 +126,44 @@ hipError_t launch_col_fastgen(int f64, int N, void* W, ColGeom g, long long ncol
                               const void* tw, hipStream_t s, bool po, hipEvent_t after_repair, int x0, int x1, void* pot) {
   if (!col_fastgen_supported(f64, N)) return po ? hipSuccess : hipErrorInvalidValue;    // the caller keeps the exact kernel
   const bool slab = x0 > 0 || x1 < N;          // replicated-generation mode: the SLAB instantiations guard their stores
+  if (gp.emit_potential || po) {               // POT = 2: the pass transforms pscale * delta(k) / k^2 (rf_realise_scaled_potential)
+    if (gp.emit_potential && (slab || pot || gp.noise)) return hipErrorInvalidValue;
+    if (!f64) {
+      if (gp.noise32 || po)                    // ... of the replayed deviates (float32 pairs in the replay's runs)
+        switch (N) {
+#define X(NN) case NN: { hipError_t e = launch_fast_one<typename GenSel<float, NN>::type, FastGenColIOT<0, 0, 0, 2, 2>, FastGenColIOT<0, 1, 0, 2, 2>, cplx<float>>(gp, (cplx<float>*)W, g, ncols, kz0, nzl, (const cplx<float>*)tw, s, po, after_repair, x0, x1); if (!po || e != hipSuccess) return e; break; }
+          RF_COL_SIZES(X)
+#undef X
+          default: return hipErrorInvalidValue;
+        }
+      if (RF_COL2_2048 && N == 2048) {
+        using C1 = GenSel<float, 1024>::type;
+        hipError_t e = launch_fast_one2<C1, FastGenColIOT<0, 0, 0, 2, 0, 2>, FastGenColIOT<0, 1, 0, 2, 0, 2>>(
+            gp, (cplx<float>*)W, g, ncols, kz0, nzl, (const cplx<float>*)tw, s, po, after_repair);
+        if (!po || e != hipSuccess) return e;
+      }
+      switch (N) {
+#define X(NN) case NN: { hipError_t e = launch_fast_one<typename GenSel<float, NN>::type, FastGenColIOT<0, 0, 0, 2>, FastGenColIOT<0, 1, 0, 2>, cplx<float>>(gp, (cplx<float>*)W, g, ncols, kz0, nzl, (const cplx<float>*)tw, s, po, after_repair, x0, x1); if (!po || e != hipSuccess) return e; break; }
+        RF_COL_SIZES(X)
+#undef X
+        default: return hipErrorInvalidValue;
+      }
+    } else {
+      if (gp.noise32 && !po) return hipErrorInvalidValue;
+      if (RF_COL2_F64_1024 && N == 1024) {
+        using C1 = GenSel<double, 512>::type;
+        hipError_t e = launch_fast_one2<C1, FastGenColIO64<0, 0, 2, 2>, FastGenColIO64<1, 0, 2, 2>>(
+            gp, (cplx<double>*)W, g, ncols, kz0, nzl, (const cplx<double>*)tw, s, po, after_repair);
+        if (!po || e != hipSuccess) return e;
+      }
+      switch (N) {
+#define X(NN) case NN: { if (!col_fastgen_supported(1, NN)) { if (po) break; return hipErrorInvalidValue; } hipError_t e = launch_fast_one<typename GenSel<double, NN>::type, FastGenColIO64<0, 0, 2>, FastGenColIO64<1, 0, 2>, cplx<double>>(gp, (cplx<double>*)W, g, ncols, kz0, nzl, (const cplx<double>*)tw, s, po, after_repair, x0, x1); if (!po || e != hipSuccess) return e; break; }
+        RF_COL_SIZES(X)
+#undef X
+        default: return hipErrorInvalidValue;
+      }
+    }
+  }
   if ((gp.noise || po) && !f64) {              // resident float64 deviates (rng='reference') through the fast float32 sigma path
     if (gp.noise && (slab || pot)) return hipErrorInvalidValue;
     switch (N) {
@@ -172,9 +216,6 @@ hipError_t launch_col_fastgen(int f64, int N, void* W, ColGeom g, long long ncol
     RF_COL_SIZES(X)                                                                                                       \
     default: return hipErrorInvalidValue;                                                                                \
   }
-#ifndef RF_COL2_F64_1024
-#define RF_COL2_F64_1024 1             // the float64 generation pass of length 1024 as two 512-point transforms per tile (Col2): two workgroups per CU
-#endif
   if (RF_COL2_F64_1024 && f64 && N == 1024 && (!slab || po)) {
     using C1 = GenSel<double, 512>::type;
     hipError_t e = launch_fast_one2<C1, FastGenColIO64<0, 0, 0, 2>, FastGenColIO64<1, 0, 0, 2>>(
@@ -198,9 +239,6 @@ hipError_t launch_col_fastgen(int f64, int N, void* W, ColGeom g, long long ncol
   }
 #ifndef RF_GEN_AB
 #define RF_GEN_AB 0                    // ablation mask of the benchmarked kernel (rf_core.h fast_gen_pair_at); 0 in the product
-#endif
-#ifndef RF_COL2_2048
-#define RF_COL2_2048 1                 // length-2048 float32 passes as two 1024-point transforms per tile (Col2); 0 = the whole-column kernels
 #endif
   if (RF_COL2_2048 && N == 2048 && !f64 && (!slab || po)) {
     using C1 = GenSel<float, 1024>::type;

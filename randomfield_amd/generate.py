@@ -43,6 +43,25 @@ class _DevicePotential(object):
         return dev.download_k()
 
 
+class _RegeneratedPotential(object):
+    """The saved potential of a ``generate_delta_field(save_potential=True)`` call that was NOT written to memory: the native
+    generator is keyed by (seed, cell) and the replayed reference stream stays resident on the device, so delta(k)/k**2 is
+    formed again inside the generation pass when :meth:`Generator.calculate_newtonian_potential` asks for it
+    (rf_realise_scaled_potential) -- the default call writes 20 instead of 28 B/cell and the later transform reads nothing."""
+
+    def __init__(self, generator, seed, noise):
+        self._generator, self.seed, self.noise = generator, seed, noise
+
+    def download(self):
+        """Host copy (nx, ny, nz/2+1) of the potential.  Runs the storing form of the call (rf_realise_potential) with the same
+        seed: the plan's field buffer holds the delta field again afterwards."""
+        dev = self._generator.plan_c2r.device
+        dev.realise_potential(self.seed, self.noise)
+        dev.load_potential(1.0)
+        self._generator._field_on_host = False
+        return dev.download_k()
+
+
 class Generator(object):
     """
     Manage random field generation for a specified geometry.
@@ -92,13 +111,20 @@ class Generator(object):
         them): k space is split by kz planes, the field by x planes, and every method works on this rank's
         ``nx / WORLD_SIZE`` planes of the field (``data_out`` has that many; see :mod:`randomfield_amd.slab`).  All ranks
         must make the same calls with the same arguments; ``seed=None`` is agreed between the ranks.
+    store_potential : bool, optional
+        hip backend: ``generate_delta_field(save_potential=True)`` normally does not write delta(k)/k**2 to memory when it can be
+        formed again on demand from the seed (``rng='native'``) or from the replayed deviates still on the device (complex64,
+        ``rng='reference'``): :meth:`calculate_newtonian_potential` then regenerates it inside its generation pass.  ``True``
+        stores it at generation time as the reference does (generate.py:200-217).  The results agree to float32 rounding.
     """
 
     def __init__(self, nx, ny, nz, grid_spacing_Mpc_h, num_plot_sections=4, cosmology=None, power=None,
                  verbose=False, *, backend=None, dtype=np.complex64, rng="reference", growth_function=None,
-                 mean_matter_density=None, redshifts=None, transverse_distance=None, curvature_K=0.0, distributed=False):
+                 mean_matter_density=None, redshifts=None, transverse_distance=None, curvature_K=0.0, distributed=False,
+                 store_potential=False):
         self.backend = transform.resolve_backend(backend)
         self.distributed = bool(distributed)
+        self.store_potential = bool(store_potential)
         if self.distributed and self.backend != "hip":
             raise ValueError("distributed=True needs backend='hip'.")
         if rng not in ("reference", "native"):
@@ -250,8 +276,13 @@ class Generator(object):
             if save_potential:
                 # generate.py:200-217.  Native noise: delta(k)/k**2 is a second store stream of the generation pass;
                 # otherwise the library runs rows K,T,R,S -> k-space, the division, and the c2r transform.
-                dev.realise_potential(dseed, noise)
-                self.potential = _DevicePotential(self)
+                if not self.store_potential and dev.can_regenerate_potential(noise):
+                    # nothing to store: the potential can be formed again from the seed / the resident deviates on demand
+                    dev.realise(dseed, noise)
+                    self.potential = _RegeneratedPotential(self, dseed, noise)
+                else:
+                    dev.realise_potential(dseed, noise)
+                    self.potential = _DevicePotential(self)
             else:
                 dev.realise(dseed, noise)           # fused: k-space never materialised
                 self.potential = None
@@ -383,8 +414,11 @@ class Generator(object):
                 field /= 1 + self._need_table("redshifts")
             return field
         dev = self.plan_c2r.device
-        dev.load_potential(scale)
-        dev.execute_c2r()
+        if isinstance(self.potential, _RegeneratedPotential):
+            dev.realise_scaled_potential(self.potential.seed, self.potential.noise, scale)
+        else:
+            dev.load_potential(scale)
+            dev.execute_c2r()
         if factor is not None:
             dev.scale_z(factor)
         self._field_on_host = False

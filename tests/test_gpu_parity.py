@@ -934,8 +934,9 @@ def test_fused_potential_store_native(hip, dpower, shape, dtype):
     d0 = plan.download_real()
     std = plan.moments()[1]
     plan.realise_potential(seed=77)
-    # same cells, same draws; another kernel instantiation may contract multiply-adds differently
-    assert np.max(np.abs(plan.download_real() - d0)) <= 1e-6 * std
+    # same cells, same draws; another kernel instantiation may contract multiply-adds differently (and at nx = 2048 / float64
+    # nx = 1024 the plain call transforms x as two half-length transforms, the storing call as one: FFT rounding, 2e-6)
+    assert np.max(np.abs(plan.download_real() - d0)) <= 2e-6 * std
     plan.realise_potential(seed=77)
     d1 = plan.download_real()
     plan.realise_potential(seed=77)
@@ -955,6 +956,67 @@ def test_fused_potential_store_native(hip, dpower, shape, dtype):
     want = np.fft.irfftn(-2.0 * ref, s=(nx, ny, nz), axes=(0, 1, 2))
     assert np.max(np.abs(phi - want)) <= 1e-5 * want.std()
     plan.close()
+
+
+@pytest.mark.parametrize("shape,dtype", [((64, 32, 128), np.complex64), ((1024, 8, 32), np.complex64), ((2048, 8, 32), np.complex64),
+                                         ((512, 16, 64), np.complex128), ((1024, 8, 32), np.complex128), ((16, 16, 16), np.complex64)])
+def test_regenerated_potential_equals_stored_one(hip, dpower, shape, dtype):
+    """rf_realise_scaled_potential: calculate_newtonian_potential (generate.py:333-343) with delta(k)/k**2 formed again inside the
+    generation pass instead of read from a stored array -- against the stored route (rf_realise_potential, rf_load_potential,
+    rf_execute_c2r), which the tests above pin to the oracle.  Native generator on float32 and float64 plans, and the replayed
+    reference stream (float32 pairs) on float32 plans."""
+    k, Pk = dpower
+    nx, ny, nz = shape
+    plan = make_plan(hip, shape, dtype, k, Pk)
+    scale = -2.5e-3
+    for noise in (None, "resident"):
+        if noise is not None:
+            if dtype == np.complex128:
+                assert not plan.can_regenerate_potential("resident")          # float64 plans keep float64 deviates: stored route
+                continue
+            plan.reference_noise(99, single=True)
+        assert plan.can_regenerate_potential(noise)
+        plan.realise_potential(seed=77, noise=noise)
+        plan.load_potential(scale)
+        plan.execute_c2r()
+        want = plan.download_real()
+        plan.realise(seed=5, noise=noise)                                     # (something else in the field buffer)
+        plan.realise_scaled_potential(seed=77, noise=noise, scale=scale)
+        got = plan.download_real()
+        # (float64 plans draw in float32 arithmetic: two kernel instantiations may round a few deviates differently in the last
+        # float32 bit -- measured 1.5e-11 of the rms; the transform itself is float64)
+        assert np.max(np.abs(got - want)) <= (2e-6 if dtype == np.complex64 else 1e-9) * want.std()
+        assert abs(plan.moments()[1] - want.std()) <= 1e-5 * want.std()
+    plan.set_exact_generation(True)
+    assert not plan.can_regenerate_potential(None)
+    with pytest.raises(RuntimeError):
+        plan.realise_scaled_potential(seed=77, scale=scale)
+    plan.close()
+
+
+def test_generator_regenerates_the_potential_on_demand(hip):
+    """Generator: the default call (save_potential=True) without the store, calculate_newtonian_potential from the seed (native)
+    or the resident deviates (reference), against Generator(store_potential=True); potential.download() still delivers
+    delta(k)/k**2."""
+    from randomfield_amd import Generator
+    from randomfield_amd.generate import _RegeneratedPotential, _DevicePotential
+    nz = 64
+    z = np.linspace(0, 0.1, nz)
+    kw = dict(growth_function=np.exp(-z), mean_matter_density=1 + z, redshifts=z, transverse_distance=np.arange(nz) * 2.5)
+    for rng_kind in ("native", "reference"):
+        lazy = Generator(32, 64, nz, 2.5, rng=rng_kind, **kw)
+        eager = Generator(32, 64, nz, 2.5, rng=rng_kind, store_potential=True, **kw)
+        a = lazy.generate_delta_field(seed=11).copy()
+        b = eager.generate_delta_field(seed=11).copy()
+        assert isinstance(lazy.potential, _RegeneratedPotential) and isinstance(eager.potential, _DevicePotential)
+        assert np.max(np.abs(a - b)) <= 1e-6 * b.std()
+        pa, pb = lazy.calculate_newtonian_potential(scale=-1.5).copy(), eager.calculate_newtonian_potential(scale=-1.5).copy()
+        assert np.max(np.abs(pa - pb)) <= 2e-6 * pb.std()
+        assert np.max(np.abs(lazy.calculate_lensing_potential() - eager.calculate_lensing_potential())) <= 1e-5 * np.abs(pb).max() * nz
+        ka, kb = lazy.potential.download(), eager.potential.download()
+        assert np.max(np.abs(ka - kb)) <= 2e-6 * np.abs(kb).max()
+        lazy.plan_c2r.device.close()
+        eager.plan_c2r.device.close()
 
 
 def test_config5_float64_lognormal_full_size(hip, dpower):
