@@ -134,9 +134,11 @@ int rf_download_noise(rf_plan* plan, double* host, unsigned long long first, uns
 /* calculate_newtonian_potential (generate.py:333-343) without a stored potential: the inverse transform of scale * delta(k) / k^2
  * with delta(k) regenerated inside the generation pass exactly as rf_realise(seed, mode) produces it (native generator: keyed by
  * (seed, cell); RF_NOISE_RESIDENT: the replayed stream still on the device).  rf_can_regenerate_potential: 1 if the plan and
- * mode allow it (fast generation pass; float32 replayed deviates), else use rf_realise_potential + rf_load_potential. */
+ * mode allow it (fast generation pass; float32 replayed deviates), else use rf_realise_potential + rf_load_potential.
+ * factor_z (optional): plane z of the result times factor_z[z], the light-cone weighting G(z)/(1+z) of generate.py:344-347, applied
+ * in the z pass's store (= rf_scale_z on the finished field, without its sweep). */
 int rf_can_regenerate_potential(rf_plan* plan, int mode);
-int rf_realise_scaled_potential(rf_plan* plan, uint64_t seed, int mode, double scale);
+int rf_realise_scaled_potential(rf_plan* plan, uint64_t seed, int mode, double scale, const double* factor_z /* nz, or NULL */);
 
 /* ---- row X: Plan.execute (transform.py:303-315) ------------------------- */
 int rf_execute_c2r(rf_plan* plan);               /* k buffer -> real field, numpy normalisation 1/(nx ny nz) */

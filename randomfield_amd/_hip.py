@@ -53,7 +53,7 @@ SIGNATURES = {
     "rf_mt_share_finish": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_ulonglong)]),
     "rf_download_noise": (ctypes.c_int, [ctypes.c_void_p, _c_dp, ctypes.c_ulonglong, ctypes.c_ulonglong]),
     "rf_can_regenerate_potential": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
-    "rf_realise_scaled_potential": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_double]),
+    "rf_realise_scaled_potential": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_double, _c_dp]),
     "rf_execute_c2r": (ctypes.c_int, [ctypes.c_void_p]),
     "rf_execute_r2c": (ctypes.c_int, [ctypes.c_void_p]),
     "rf_plan_create_c2c": (ctypes.c_int, [_c_void_pp] + [ctypes.c_int] * 5),
@@ -445,12 +445,18 @@ class DevicePlan(object):
             return False
         return bool(self._lib.rf_can_regenerate_potential(self._h, NOISE_RESIDENT if noise is not None else NOISE_NATIVE))
 
-    def realise_scaled_potential(self, seed=0, noise=None, scale=1.0):
+    def realise_scaled_potential(self, seed=0, noise=None, scale=1.0, factor_z=None):
         """calculate_newtonian_potential without a stored potential: the inverse transform of ``scale * delta(k)/k**2`` with
-        delta(k) regenerated as ``realise(seed, noise)`` generates it (rf_realise_scaled_potential)."""
+        delta(k) regenerated as ``realise(seed, noise)`` generates it (rf_realise_scaled_potential); ``factor_z`` (nz values,
+        optional): plane z times factor_z[z], applied in the z pass's store."""
         mode, ptr, keep = self._noise_arg(noise)
-        check(self._lib.rf_realise_scaled_potential(self._h, ctypes.c_uint64(int(seed) & (2 ** 64 - 1)), mode, float(scale)),
-              "rf_realise_scaled_potential")
+        fz = None
+        if factor_z is not None:
+            fz = _f64(factor_z)
+            if fz.shape != (self.nz,):
+                raise ValueError("factor_z must hold nz values")
+        check(self._lib.rf_realise_scaled_potential(self._h, ctypes.c_uint64(int(seed) & (2 ** 64 - 1)), mode, float(scale),
+                                                    _dp(fz) if fz is not None else None), "rf_realise_scaled_potential")
 
     def realise_batch(self, seeds, want_rms=True):
         seeds = np.ascontiguousarray(seeds, dtype=np.uint64)

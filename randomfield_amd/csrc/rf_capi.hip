@@ -178,6 +178,7 @@ struct rf_plan {
   bool resident_fast = false;             // the current call draws from the device-resident deviates (RF_NOISE_RESIDENT)
   bool emit_potential = false;            // the current call transforms emit_pscale * delta(k) / k^2 instead of delta(k) (rf_realise_scaled_potential)
   double emit_pscale = 0.0;
+  const double* zscale = nullptr;         // the current call's z pass multiplies plane z by zscale[z] (device table: ztab)
   void* pot_target = nullptr;             // non-null while rf_realise_potential queues its x pass: where delta(k)/k^2 goes
   double* coll_scratch = nullptr;         // 2 doubles on the device for host-side all-reduces (never aliases `stats`)
   double* ztab = nullptr;                 // 2 * nz doubles for lognormal / affine tables
@@ -582,6 +583,7 @@ int queue_yz(rf_plan* p, void* W, hipStream_t s, double* stats_out, bool timed) 
     if (timed) RF_HIP(hipEventRecord(p->slab_ev[2 * i], s));
     double* part = p->partials + 2 * x0 * tiles_per_plane;
     if (xp) RF_HIP(launch_row_c2r_xgather(p->f64, (int)p->nzc, Xs, Ws, nb * p->ny, scale, (int)tc, (int)rb, p->ny, p->tw_z, part, s));
+    else if (p->zscale) RF_HIP(launch_row_c2r_zscale(p->f64, (int)p->nzc, Ws, nb * p->ny, scale, p->zscale, p->tw_z, part, s));
     else RF_HIP(launch_row_c2r(p->f64, (int)p->nzc, Ws, nb * p->ny, scale, p->tw_z, part, s));
     if (timed) RF_HIP(hipEventRecord(p->slab_ev[2 * i + 1], s));
   }
@@ -793,6 +795,7 @@ int rf_plan_create(rf_plan** out, int nx, int ny, int nz, int dtype, int device,
         (e = launch_col_plain_acc(dtype, ny, p->W, gy, (long long)nx * nzl, 0, (int)nzl, nullptr, p->tw_y, p->stream, true)) != hipSuccess ||
         (e = launch_row_c2r_lognormal(dtype, (int)nzc, p->W, (long long)p->nxl * ny, 1.0, nullptr, nullptr, p->tw_z, p->partials, p->stream, true)) != hipSuccess ||
         (e = launch_row_c2r(dtype, (int)nzc, p->W, (long long)p->nxl * ny, 1.0, p->tw_z, p->partials, p->stream, true)) != hipSuccess ||
+        (e = launch_row_c2r_zscale(dtype, (int)nzc, p->W, (long long)p->nxl * ny, 1.0, nullptr, p->tw_z, p->partials, p->stream, true)) != hipSuccess ||
         (e = launch_row_c2r_xgather(dtype, (int)nzc, p->W, p->W, (long long)p->nxl * ny, 1.0, 8, 8, ny, p->tw_z, p->partials, p->stream, true)) != hipSuccess ||
         (e = launch_row_r2c(dtype, (int)nzc, p->W, (long long)p->nxl * ny, p->tw_z, p->stream, true)) != hipSuccess ||
         (e = launch_col_plain(dtype, ny, -1, p->W, gy, (long long)nx * nzl, p->tw_y, p->stream, true)) != hipSuccess ||
@@ -1141,7 +1144,7 @@ int rf_can_regenerate_potential(rf_plan* p, int mode) {
   return 0;
 }
 
-int rf_realise_scaled_potential(rf_plan* p, uint64_t seed, int mode, double scale) {
+int rf_realise_scaled_potential(rf_plan* p, uint64_t seed, int mode, double scale, const double* factor_z) {
   RF_REQUIRE(p, "null plan");
   RF_REQUIRE(!p->unpacked, "this call does not apply to an unpacked c2c plan");
   RF_REQUIRE(p->have_kgrid && p->have_power, "rf_set_kgrid and rf_set_power must be called first");
@@ -1152,10 +1155,22 @@ int rf_realise_scaled_potential(rf_plan* p, uint64_t seed, int mode, double scal
   p->resident_fast = (mode == RF_NOISE_RESIDENT);
   p->emit_potential = true;
   p->emit_pscale = p->f64 ? scale : (double)(float)scale;
-  const int rc = queue_c2r(p, make_gen(p, seed, mode, false), nullptr);
+  // the light-cone factor per plane z (generate.py:344-347): in the z pass's own store where the plan runs the plain single-rank
+  // passes, else by the sweep rf_scale_z would make -- the same two roundings either way
+  const bool fuse_z = factor_z && p->nranks == 1 && !p->force_slab && !(p->X && xpose_ok(p));
+  if (factor_z) RF_HIP(hipMemcpyAsync(p->ztab, factor_z, (size_t)p->nz * sizeof(double), hipMemcpyHostToDevice, p->stream));
+  p->zscale = fuse_z ? p->ztab : nullptr;
+  int rc = queue_c2r(p, make_gen(p, seed, mode, false), nullptr);
+  p->zscale = nullptr;
   p->emit_potential = false;
   p->resident_fast = false;
-  return rc;
+  if (rc) return rc;
+  if (factor_z && !fuse_z) {
+    RF_HIP(launch_affine_z(p->f64, p->cur, (long long)p->nxl * p->ny, p->nz, p->ztab, 0.0, p->stream));
+    p->stats_valid = false;
+  }
+  if (factor_z) RF_HIP(hipStreamSynchronize(p->stream));     // (factor_z is the caller's memory)
+  return 0;
 }
 
 // generate_delta_field(save_potential=True) (generate.py:191-219): the field as rf_realise, plus delta(k) / k^2 in the

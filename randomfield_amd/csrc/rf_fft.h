@@ -1037,6 +1037,26 @@ template <typename T> struct LognormalRowIO {
   template <int NRT> RF_HD void store2(long long tile, int rl, int nb, int no, cplx<T> z, double& s1, double& s2) const { store(tile * NRT + rl, nb + no, z, s1, s2); }
 };
 
+// z pass whose store multiplies plane z by a per-z factor (float64 table, the rounding of rf_scale_z on the stored field): the
+// light-cone weighting G(z) / (1 + z) of calculate_newtonian_potential (generate.py:344-347) without a sweep of its own
+template <typename T> struct ScaleZRowIO {
+  cplx<T>* base;
+  T scale;                       // 1 / (nx ny nz)
+  int M_of;
+  const double* Sz;              // [2 M]
+  RF_HD int gather_seg_shift() const { return -1; }
+  RF_HD cplx<T> load(long long row, int k) const { return stream_load(base + row * (long long)M_of + k); }
+  RF_HD void store(long long row, int n, cplx<T> z, double& s1, double& s2) const {
+    z.x = (T)((double)(z.x * scale) * Sz[2 * n]);
+    z.y = (T)((double)(z.y * scale) * Sz[2 * n + 1]);
+    stream_store(base + row * (long long)M_of + n, z);
+    s1 += (double)z.x + (double)z.y;
+    s2 += (double)z.x * (double)z.x + (double)z.y * (double)z.y;
+  }
+  template <int NRT> RF_HD cplx<T> load2(long long tile, int rl, int kb, int ko) const { return load(tile * NRT + rl, kb + ko); }
+  template <int NRT> RF_HD void store2(long long tile, int rl, int nb, int no, cplx<T> z, double& s1, double& s2) const { store(tile * NRT + rl, nb + no, z, s1, s2); }
+};
+
 // tw = exp(+2 pi i q / (2M)), q in [0, 2M): t_k = tw[k], w_M^q = tw[2q]
 template <class C, class IO>
 struct RowC2R {

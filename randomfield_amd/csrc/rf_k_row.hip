@@ -78,6 +78,16 @@ hipError_t launch_lognormal_t(int M, cplx<T>* W, long long nrows, double scale, 
     default: return hipErrorInvalidValue;
   }
 }
+template <typename T>
+hipError_t launch_zscale_t(int M, cplx<T>* W, long long nrows, double scale, const double* Sz, const cplx<T>* tw, double* partials, hipStream_t s, bool po) {
+  ScaleZRowIO<T> io; io.base = W; io.scale = (T)scale; io.M_of = M; io.Sz = Sz;
+  switch (M) {
+#define X(MM) case MM: return launch_one<typename RowSel<T, MM>::type, ScaleZRowIO<T>>(io, nrows, tw, partials, s, po);
+    RF_ROW_SIZES(X)
+#undef X
+    default: return hipErrorInvalidValue;
+  }
+}
 template <class C>
 hipError_t launch_fwd_one(const PlainRowFwdIO<typename C::T>& io, long long nrows, const cplx<typename C::T>* tw, hipStream_t s, bool po) {
   const long long ntiles = (nrows + C::NRT - 1) / C::NRT;
@@ -128,6 +138,11 @@ hipError_t launch_row_c2r_lognormal(int f64, int M, void* W, long long nrows, do
                                     const void* tw, double* partials, hipStream_t s, bool po) {
   if (f64) return launch_lognormal_t<double>(M, (cplx<double>*)W, nrows, scale, Ap, Bp, (const cplx<double>*)tw, partials, s, po);
   return launch_lognormal_t<float>(M, (cplx<float>*)W, nrows, scale, Ap, Bp, (const cplx<float>*)tw, partials, s, po);
+}
+hipError_t launch_row_c2r_zscale(int f64, int M, void* W, long long nrows, double scale, const double* Sz, const void* tw, double* partials,
+                                 hipStream_t s, bool po) {
+  if (f64) return launch_zscale_t<double>(M, (cplx<double>*)W, nrows, scale, Sz, (const cplx<double>*)tw, partials, s, po);
+  return launch_zscale_t<float>(M, (cplx<float>*)W, nrows, scale, Sz, (const cplx<float>*)tw, partials, s, po);
 }
 bool row_c2r_xgather_ok(int f64, int M, int tc, int rb) { return f64 ? xgather_ok_t<double>(M, tc, rb) : xgather_ok_t<float>(M, tc, rb); }
 hipError_t launch_row_r2c(int f64, int M, void* W, long long nrows, const void* tw, hipStream_t s, bool po) {

@@ -87,6 +87,9 @@ hipError_t launch_lognormal_tables(const double* partials, long long n, double n
 // z pass with rho = exp(delta Ap_z) Bp_z in its epilogue (rf_fft.h LognormalRowIO)
 hipError_t launch_row_c2r_lognormal(int f64, int M, void* W, long long nrows, double scale, const double* Ap, const double* Bp,
                                     const void* tw, double* partials, hipStream_t s, bool prepare_only = false);
+// the z pass with a per-z factor applied in its store (ScaleZRowIO)
+hipError_t launch_row_c2r_zscale(int f64, int M, void* W, long long nrows, double scale, const double* Sz, const void* tw, double* partials,
+                                 hipStream_t s, bool po = false);
 // forward z pass (r2c rows, in place: nz reals -> nz/2 complex with (X[0], X[nz/2]) packed in element 0)
 hipError_t launch_row_r2c(int f64, int M, void* W, long long nrows, const void* tw, hipStream_t s,
                           bool prepare_only = false);

@@ -415,7 +415,8 @@ class Generator(object):
             return field
         dev = self.plan_c2r.device
         if isinstance(self.potential, _RegeneratedPotential):
-            dev.realise_scaled_potential(self.potential.seed, self.potential.noise, scale)
+            dev.realise_scaled_potential(self.potential.seed, self.potential.noise, scale, factor_z=factor)
+            factor = None           # (applied by the z pass itself)
         else:
             dev.load_potential(scale)
             dev.execute_c2r()

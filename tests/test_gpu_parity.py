@@ -987,6 +987,14 @@ def test_regenerated_potential_equals_stored_one(hip, dpower, shape, dtype):
         # float32 bit -- measured 1.5e-11 of the rms; the transform itself is float64)
         assert np.max(np.abs(got - want)) <= (2e-6 if dtype == np.complex64 else 1e-9) * want.std()
         assert abs(plan.moments()[1] - want.std()) <= 1e-5 * want.std()
+        # the light-cone factor per plane z in the z pass's store: what rf_scale_z makes of the finished field (same roundings
+        # on paper; the z pass is another kernel instantiation, so the last float32 bit of its butterflies may differ)
+        fz = np.exp(-0.01 * np.arange(nz)) / (1 + 0.002 * np.arange(nz))
+        plan.scale_z(fz)
+        two_steps = plan.download_real()
+        plan.realise_scaled_potential(seed=77, noise=noise, scale=scale, factor_z=fz)
+        assert np.max(np.abs(plan.download_real() - two_steps)) <= (1e-6 if dtype == np.complex64 else 1e-13) * two_steps.std()
+        assert abs(plan.moments()[1] - two_steps.astype(np.float64).std()) <= 1e-5 * two_steps.std()
     plan.set_exact_generation(True)
     assert not plan.can_regenerate_potential(None)
     with pytest.raises(RuntimeError):
