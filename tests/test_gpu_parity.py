@@ -667,7 +667,7 @@ def test_unpacked_c2c_plan_against_numpy(hip, shape):
         transform.Plan((8, 8, 4096), dtype_in=np.complex64, packed=False, backend="hip")    # nz beyond the row kernels
 
 
-@pytest.mark.parametrize("shape", [(8, 8, 16), (16, 8, 64), (8, 16, 256), (4 * 2, 8, 2048)])
+@pytest.mark.parametrize("shape", [(8, 8, 16), (16, 8, 64), (8, 16, 256), (4 * 2, 8, 2048), (8, 8, 512), (8, 8, 1024)])
 def test_lensing_potential_kernel_against_oracle(hip, shape):
     """rf_lensing_potential (generate.py:352-416 as one prefix scan per row) against the oracle's restatement of
     the reference's slice loop + scipy.integrate.simps(even='avg'), float32 and float64, flat and curved."""
