@@ -34,6 +34,8 @@ void run_col_pass(const IO& io_in, long long ncols, const cplx<typename C::T>* t
       for (int t = 0; t < C::NT; ++t) F::prologue(t, ios[t], tw, lds.data());
       if (C::NPASS >= 2) ltw = F::lds_tw(lds.data());
     }
+    if (IO::FIX_MODE == 2 && C::NPASS >= 2 && ios[0].needs_fix(tile * C::TC))          // (the kernel's uniform branch + barrier)
+      for (int t = 0; t < C::NT; ++t) F::fix_prepare(t, tile, ios[t], lds.data());
     for (int t = 0; t < C::NT; ++t) F::pass_first(t, tile, ios[t], lds.data());
     if (C::NPASS == 3) {
       for (int t = 0; t < C::NT; ++t) F::pass_mid_read(t, ltw, lds.data(), regs[t]);
@@ -64,6 +66,8 @@ void run_col2_pass(const IO& io_in, long long ncols, const cplx<typename C1::T>*
     const cx* ltw = F::lds_tw(lds.data());
     for (int phase = 0; phase < 2; ++phase) {
       for (int t = 0; t < C1::NT; ++t) ios[t].set_phase(phase);
+      if (IO::FIX_MODE == 2 && ios[0].needs_fix(tile * C1::TC))
+        for (int t = 0; t < C1::NT; ++t) F::fix_prepare(t, tile, ios[t], lds.data());
       for (int t = 0; t < C1::NT; ++t) F::pass_first(t, tile, ios[t], lds.data());
       if (phase == 0) for (int t = 0; t < C1::NT; ++t) F::tw_stage(t, lds.data(), twr[t]);
       if (C1::NPASS == 3) {
@@ -364,10 +368,12 @@ int realise_fast_impl(int nx, int ny, int nz, const GenHost& h, uint64_t seed, d
     return xposed_yz<T>(nx, ny, nz, X.data(), W, s1, s2);
   }
   bool x_done = false;
+  // (where the library splits the pass -- kz runs of more than one whole tile -- its repair launch is the FIX = 2 kernel; the
+  // emulator runs that kernel over every tile: tiles without kz = 0 skip the repair phase, as the FIX = 0 launch does)
   if constexpr (sizeof(T) == 4) {
     if (nx == 2048 && ((long long)ny * nzc) % 8 == 0) {      // the library's x pass at this length: Col2 over the 1024-point configuration
       using C1 = GenSel<float, 1024>::type;
-      using IO2 = FastGenColIOT<0, 1, 0, 0, 0, 2>;
+      using IO2 = FastGenColIOT<0, 2, 0, 0, 0, 2>;
       IO2 io2;
       io2.base = W; io2.g = io.g; io2.kz0 = 0; io2.nzl = (int)nzc; io2.rec = nullptr; io2.gp = io.gp; io2.pot = nullptr;
       auto tw2 = make_twiddles<float>(2048);
@@ -378,11 +384,22 @@ int realise_fast_impl(int nx, int ny, int nz, const GenHost& h, uint64_t seed, d
   if constexpr (sizeof(T) == 8) {
     if (nx == 1024 && ((long long)ny * nzc) % 8 == 0) {      // float64, length 1024: Col2 over the 512-point configuration
       using C1 = GenSel<double, 512>::type;
-      using IO2 = FastGenColIO64<1, 0, 0, 2>;
+      using IO2 = FastGenColIO64<2, 0, 0, 2>;
       IO2 io2;
       io2.base = W; io2.g = io.g; io2.kz0 = 0; io2.nzl = (int)nzc; io2.rec = nullptr; io2.gp = io.gp; io2.pot = nullptr;
       auto tw2 = make_twiddles<double>(1024);
       run_col2_pass<C1, +1, IO2>(io2, (long long)ny * nzc, tw2.data());
+      x_done = true;
+    }
+  }
+  if (!x_done && (nx == 512 || nx == 1024)) {               // the long whole-column passes: FIX = 2 where the library splits
+    using IOC = typename IO::template with_fix<2>;
+    const int tc = tile_cols<T>(nx, true);
+    if (nzc > tc && nzc % tc == 0) {
+      IOC ioc;
+      ioc.base = W; ioc.g = io.g; ioc.kz0 = 0; ioc.nzl = (int)nzc; ioc.rec = nullptr; ioc.gp = io.gp; ioc.pot = nullptr;
+      rc = dispatch_col<T, +1, IOC, GenSel>(nx, ioc, (long long)ny * nzc);
+      if (rc) return rc;
       x_done = true;
     }
   }

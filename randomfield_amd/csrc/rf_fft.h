@@ -341,8 +341,9 @@ template <typename T, bool WIDE = false> struct GenColIO {
 // x pass fused with the fast float32 native generation (one Philox call per lane load)
 // SLAB: 1 = only rows [x0, x1) are stored (replicated-generation mode); a separate instantiation so that the
 // guard costs the ordinary kernel nothing.
-// FIX: 1 = this kernel repairs the kz = 0 slot (rolled loop through LDS); 0 = it does not (the tiles that
-// hold kz = 0 are then re-run by a FIX = 1 launch).  An out-of-line call was measured 3x slower (scratch).
+// FIX: 1 = this kernel repairs the kz = 0 slot (rolled loop through LDS); 2 = the same with the repair values computed by all
+// lanes in a phase of their own (ColFFT::fix_prepare: tiles whose first column is the only kz = 0 one); 0 = it does not (the tiles that
+// hold kz = 0 are then re-run by a FIX = 1 / 2 launch).  An out-of-line call was measured 3x slower (scratch).
 // POT: 2 = the pass transforms pscale * delta(k) / k^2 instead of delta(k) (the saved potential regenerated on demand: each
 // cell rounded as the stored one and its scaled copy would be); 1 = the pass also stores delta(k) / k^2 (0 at DC) of every generated cell into `pot`, an API-layout array
 // [nx][ny][nz/2+1] -- the save_potential=True branch of generate_delta_field (generate.py:200-217) without ever
@@ -457,6 +458,7 @@ struct FastGenColIOT {
   RF_HD long long remap_tile(long long t) const { return t; }
   static constexpr bool HAS_FINISH = false;
   static constexpr int FIX_MODE = FIX;
+  template <int F2> using with_fix = FastGenColIOT<AB, F2, SLAB, POT, SRC, XS>;
   RF_HD bool needs_fix(long long C) const { return FIX != 0 && kz0 + (int)((unsigned)C & (unsigned)(nzl - 1)) == 0; }
   RF_HD cplx<float> fix_value(long long C, int rb, int ro) const {
     const uint64_t seed = gp.seed;                                                      // bind_seed() ran first
@@ -538,6 +540,7 @@ struct FastGenColIO64 {
   RF_HD long long remap_tile(long long t) const { return t; }
   static constexpr bool HAS_FINISH = false;
   static constexpr int FIX_MODE = FIX;
+  template <int F2> using with_fix = FastGenColIO64<F2, SLAB, POT, XS>;
   RF_HD bool needs_fix(long long C) const { return FIX != 0 && kz0 + (int)((unsigned)C & (unsigned)(nzl - 1)) == 0; }
   RF_HD cplx<double> fix_value(long long C, int rb, int ro) const {
     const uint64_t seed = gp.seed;                                                      // bind_seed() ran first
@@ -608,6 +611,28 @@ struct ColFFT {
     io.prologue(tid, C::NT, lds_io(lds));
   }
 
+  // FIX_MODE == 2 (tiles whose first column is the only one with kz = 0: kz runs of whole tiles): the Hermitian repair values of
+  // that column, computed by ALL the lanes of a butterfly's lane group -- the R rows dealt to its LPR lanes -- and parked in the
+  // owning lane's LDS output slots.  In pass_first itself (FIX_MODE == 1) the owning lane alone evaluates all R of them while
+  // the other three quarters of its wave idle: two extra Philox calls, Box-Muller pairs and sigma lookups per row, 2.5x the time
+  // of an ordinary tile.  The caller tests needs_fix(tile's first column) -- uniform -- and puts a barrier behind this.
+  RF_HD static void fix_prepare(int tid, long long tile, const IO& io, cx* lds) {
+    constexpr int R = C::R1, L = N / R, RPL = (R + LPR - 1) / LPR;
+    const int lp = tid % LPR, jl = tid / LPR;
+    const long long C0 = tile * C::TC;
+#pragma unroll
+    for (int it = 0; it < C::IT1; ++it) {
+      const int j = it * BPI + jl;
+      if (j < L) {
+#pragma unroll 1
+        for (int q = 0; q < RPL; ++q) {
+          const int m = lp * RPL + q;
+          if (m < R) lds_at(lds, j * R + m, 0)->c[0] = io.fix_value(C0, j, m * L);
+        }
+      }
+    }
+  }
+
   // pass 1: global -> R1 butterfly -> LDS (or straight back to global when N == R1)
   RF_HD static void pass_first(int tid, long long tile, const IO& io, cx* lds) {
     constexpr int R = C::R1, L = N / R;
@@ -638,7 +663,13 @@ struct ColFFT {
             IO::sched_fence(m);
           }
         }
-        if (IO::FIX_MODE != 0 && io.needs_fix(Ccol)) {
+        if (IO::FIX_MODE == 2 && C::NPASS > 1) {
+          // parked in this lane's own, still unused LDS output slots by fix_prepare() (a barrier ago)
+          if (io.needs_fix(Ccol)) {
+#pragma unroll
+            for (int m = 0; m < R; ++m) v[0][m] = lds_at(lds, j * R + m, lp)->c[0];
+          }
+        } else if (IO::FIX_MODE != 0 && io.needs_fix(Ccol)) {
           if (C::NPASS == 1) {
 #pragma unroll
             for (int m = 0; m < R; ++m) v[0][m] = io.fix_value(Ccol, j, m * L);

@@ -55,13 +55,17 @@ hipError_t launch_fast_one2(const FastGenParams& gp, cplx<typename C1::T>* W, Co
   IO1 io1; io1.base = W; io1.g = g; io1.gp = gp; io1.kz0 = kz0; io1.nzl = nzl; io1.rec = nullptr; io1.pot = nullptr;
   const bool split = nzl > C1::TC && nzl % C1::TC == 0;
   const long long tiles_per_iy = nzl / C1::TC, ntiles = ncols / C1::TC;
+  // the split launch's repair kernel computes the repair values with all lanes (FIX = 2, ColFFT::fix_prepare)
+  using IOC = typename IO1::template with_fix<2>;
+  IOC ioc; ioc.base = W; ioc.g = g; ioc.gp = gp; ioc.kz0 = kz0; ioc.nzl = nzl; ioc.rec = nullptr; ioc.pot = nullptr;
   if (po) {
     hipError_t e = launch_one2<C1, IO0>(io0, ncols, tw2, s, true);
+    if (e == hipSuccess) e = launch_one2<C1, IOC>(ioc, ncols, tw2, s, true);
     return e != hipSuccess ? e : launch_one2<C1, IO1>(io1, ncols, tw2, s, true);
   }
   if (!split) return launch_one2<C1, IO1>(io1, ncols, tw2, s, false);
   if (kz0 != 0) return launch_one2<C1, IO0>(io0, ncols, tw2, s, false);
-  hipError_t e = launch_one2<C1, IO1>(io1, ncols, tw2, s, false, ncols / nzl, tiles_per_iy, 0);
+  hipError_t e = launch_one2<C1, IOC>(ioc, ncols, tw2, s, false, ncols / nzl, tiles_per_iy, 0);
   if (e != hipSuccess || tiles_per_iy >= (1LL << 30) || ntiles >= (1LL << 31)) return e != hipSuccess ? e : hipErrorInvalidValue;
   if (after_repair && (e = hipEventRecord(after_repair, s)) != hipSuccess) return e;
   return launch_one2<C1, IO0>(io0, ncols, tw2, s, false, ntiles - ntiles / tiles_per_iy, 1, 0, (int)tiles_per_iy);
@@ -109,14 +113,19 @@ hipError_t launch_fast_one(const FastGenParams& gp, CT* W, ColGeom g, long long 
   IO1 io1; io1.base = base; io1.g = g; io1.gp = gp; io1.kz0 = kz0; io1.nzl = nzl; io1.rec = nullptr; io1.x0 = x0; io1.x1 = x1; io1.pot = pot;
   const bool split = nzl > C::TC && nzl % C::TC == 0;
   const long long tiles_per_iy = nzl / C::TC, ntiles = ncols / C::TC;
+  // the split launch's repair kernel of the long passes computes the repair values with all lanes (FIX = 2, ColFFT::fix_prepare)
+  constexpr bool coop = C::N >= 512 && C::NPASS >= 2;
+  using IOC = typename IO1::template with_fix<coop ? 2 : 1>;
+  IOC ioc; ioc.base = base; ioc.g = g; ioc.gp = gp; ioc.kz0 = kz0; ioc.nzl = nzl; ioc.rec = nullptr; ioc.x0 = x0; ioc.x1 = x1; ioc.pot = pot;
   if (po) {
     hipError_t e = launch_one<C, IO0>(io0, ncols, tw, s, true);
+    if (e == hipSuccess && coop) e = launch_one<C, IOC>(ioc, ncols, tw, s, true);
     return e != hipSuccess ? e : launch_one<C, IO1>(io1, ncols, tw, s, true);
   }
   if (!split) return launch_one<C, IO1>(io1, ncols, tw, s, false);
   if (kz0 != 0) return launch_one<C, IO0>(io0, ncols, tw, s, false);   // only the slab that owns kz = 0 needs the repair
   // first the (few) tiles that hold slot kz = 0, with the repair; then every other tile without it
-  hipError_t e = launch_one<C, IO1>(io1, ncols, tw, s, false, ncols / nzl, tiles_per_iy, 0);
+  hipError_t e = launch_one<C, IOC>(ioc, ncols, tw, s, false, ncols / nzl, tiles_per_iy, 0);
   if (e != hipSuccess || tiles_per_iy >= (1LL << 30) || ntiles >= (1LL << 31)) return e != hipSuccess ? e : hipErrorInvalidValue;
   if (after_repair && (e = hipEventRecord(after_repair, s)) != hipSuccess) return e;
   return launch_one<C, IO0>(io0, ncols, tw, s, false, ntiles - ntiles / tiles_per_iy, 1, 0, (int)tiles_per_iy);

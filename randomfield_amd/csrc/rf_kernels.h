@@ -46,6 +46,9 @@ __global__ __launch_bounds__(C::NT, (col_min_waves<C, IO>())) void col_kernel(IO
     __syncthreads();
   }
   if (C::NPASS >= 2) F::tw_fetch(tid, tw, twr);       // twiddles global -> registers: issued here, landed under pass 1
+  if (IO::FIX_MODE == 2 && C::NPASS >= 2) {           // the kz = 0 column's repair values, by every lane (uniform branch)
+    if (io.needs_fix(tile * C::TC)) { F::fix_prepare(tid, tile, io, lds); __syncthreads(); }
+  }
   F::pass_first(tid, tile, io, lds);
   if (C::NPASS >= 2) {
     F::tw_stage(tid, lds, twr);                       // -> LDS, in front of the barrier that precedes their first use
@@ -107,6 +110,9 @@ __global__ __launch_bounds__(C1::NT, (IO::FIX_MODE != 0 ? 2 : col_min_waves<C1, 
     // registers, and spills (248 bytes of scratch per thread, 2.8x slower on MI355X)
     int t = tid;
     asm volatile("" : "+v"(t));
+    if (IO::FIX_MODE == 2) {
+      if (io.needs_fix(tile * C1::TC)) { F::fix_prepare(t, tile, io, lds); __syncthreads(); }
+    }
     F::pass_first(t, tile, io, lds);
     if (phase == 0) F::tw_stage(tid, lds, twr);
     if (C1::NPASS == 3) {
