@@ -44,7 +44,7 @@ def main():
         M = nx * ny * (nz // 2 + 1)
         field = None
         for _ in range(rng.randint(2, 7)):
-            op = rng.choice(["ext", "native", "gen", "r2c", "lognormal", "affine", "potential", "rpot", "batch", "mt", "mt32", "lens"])
+            op = rng.choice(["ext", "native", "gen", "r2c", "lognormal", "affine", "potential", "rpot", "batch", "mt", "mt32", "lens", "regen"])
             counts[op] = counts.get(op, 0) + 1
             if op == "ext":
                 seed = int(rng.randint(1, 10 ** 6))
@@ -112,6 +112,21 @@ def main():
                 kref = cpu_ref.generate_kspace(nx, ny, nz, SPACING, k, Pk, noise=noise, dtype=np.complex128)
                 pref = cpu_ref.potential_kspace(kref, SPACING)
                 assert np.max(np.abs(got - pref)) <= 2e-5 * max(np.max(np.abs(pref)), 1e-30), ("rpot potential", shape, ct)
+            elif op == "regen":
+                # calculate_newtonian_potential with the potential formed again inside the generation pass (+ the light-cone
+                # factor in the z pass's store), against the oracle's delta(k)/k^2 transformed by numpy
+                seed = int(rng.randint(1, 2 ** 31))
+                if p.can_regenerate_potential(None):
+                    scale = -float(rng.rand() + 0.5)
+                    fz = 1.0 / (1.0 + 0.01 * np.arange(nz)) if rng.rand() < 0.5 else None
+                    p.realise_scaled_potential(seed=seed, scale=scale, factor_z=fz)
+                    field = p.download_real()
+                    noise = cpu_ref.native_noise(seed, nx, ny, nz, ct)
+                    kref = cpu_ref.generate_kspace(nx, ny, nz, SPACING, k, Pk, noise=noise, dtype=np.complex128)
+                    want = np.fft.irfftn(scale * cpu_ref.potential_kspace(kref, SPACING), s=shape, axes=(0, 1, 2))
+                    if fz is not None:
+                        want = want * fz
+                    assert np.max(np.abs(field - want)) <= 3e-5 * max(want.std(), 1e-30), ("regen", shape, ct)
             elif op == "potential":
                 seed = int(rng.randint(1, 10 ** 6))
                 noise = cpu_ref.reference_noise(seed, M)
