@@ -10,7 +10,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from randomfield_amd import _hip, powertools   # noqa: E402
 
-if len(sys.argv) > 1:
+if len(sys.argv) > 1 and sys.argv[1] != "-":
     _hip.LIB_PATH = os.path.abspath(sys.argv[1])
 n = 1024
 power = powertools.load_default_power()
