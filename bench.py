@@ -248,6 +248,25 @@ def main_multi(args, rank, world, local_rank, shape, power, spacing):
     wall = time.perf_counter() - t0
     wall = float(dplan.allreduce([wall], op="max")[0])
     mean, std = plan.moments()
+    rccl_ranks = plan.comm_size()                      # what RCCL itself says the communicator spans (ncclCommCount)
+    # the N = 1 equivalent in the SAME job: every rank times the per-GPU cube (edge^3, what `--gpus 1` runs: `steps` realisations
+    # replayed from one hipGraph) alone on its own GPU, no communicator involved; slowest and fastest rank reported
+    from randomfield_amd import _hip
+    e = args.edge
+    single = _hip.DevicePlan(e, e, e, np.complex64, device=local_rank)
+    single.set_kgrid(*powertools.ksq_axes(e, e, e, spacing))
+    single.set_power(*powertools.sigma_table(power, (e, e, e), spacing))
+    single.realise_batch_prepare(args.steps)
+    single.realise_batch(np.arange(1000, 1000 + max(args.warmup, 1), dtype=np.uint64), want_rms=False)
+    single.sync()
+    dplan.barrier()
+    t0 = time.perf_counter()
+    single.realise_batch(np.arange(123, 123 + args.steps, dtype=np.uint64), want_rms=False)
+    single.sync()
+    t_single = (time.perf_counter() - t0) / args.steps * 1e3
+    single.close()
+    t_single_max = float(dplan.allreduce([t_single], op="max")[0])
+    t_single_min = -float(dplan.allreduce([-t_single], op="max")[0])
     cells = float(nx) * ny * nz
     sweep = 8.0 * nx * ny * (nz // 2 + 1)
     xgmi_bytes = (world - 1) / world * sweep / world if mode == "exchange" else 0.0     # all-to-all egress per GPU
@@ -263,8 +282,14 @@ def main_multi(args, rank, world, local_rank, shape, power, spacing):
                                   "kz-slab generation + ONE RCCL all-to-all per realisation, overlapped with the next "
                                   "realisation's generation" if mode == "exchange" else
                                   "replicated generation: every rank generates all of k space and keeps its x slab, no all-to-all"),
-                   "grid": [nx, ny, nz], "rms_last": round(std, 6), "multi_gpu_mode": mode,
+                   "grid": [nx, ny, nz], "rms_last": round(std, 6), "multi_gpu_mode": mode, "rccl_ranks": rccl_ranks,
+                   "launcher": "bench.py's own child ranks" if os.environ.get("RANDOMFIELD_LAUNCH_NONCE", "").startswith("bench-") else "external (torch.distributed.run)",
                    "mode_calibration_ms_per_step": {k: round(v, 3) for k, v in calib.items()}},
+        "single_gpu_equivalent": {"ms_per_step": round(t_single_max, 4), "ms_per_step_fastest_rank": round(t_single_min, 4),
+                                  "grid": [e, e, e], "Mcells_s": round(float(e) ** 3 / t_single_max / 1e3, 1),
+                                  "speedup_of_this_job": round(cells * args.steps / wall / (float(e) ** 3 / (t_single_max * 1e-3)), 3),
+                                  "note": "every rank alone on its own GPU in this same job (%d^3, %d realisations from one hipGraph, "
+                                          "as `--gpus 1`); slowest rank quoted" % (e, args.steps)},
         "pipeline": {"algorithmic_GBs": round(5 * sweep * args.steps / wall / 1e9, 1),
                      "frac_of_hbm_peak": round(5 * sweep * args.steps / wall / 1e9 / (HBM_PEAK_GBS * world), 4),
                      "kernel_ms_rank0_unpipelined_step": {"x": round(float(kern[0]), 4), "y": round(float(kern[1]), 4),
@@ -282,6 +307,55 @@ def main_multi(args, rank, world, local_rank, shape, power, spacing):
         print(json.dumps(out))
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` outside any launcher: start N fresh ranks of this script (one per GPU, RANK = LOCAL_RANK = r)
+    with the environment `torch.distributed.run` would give them, relay rank 0's standard output (the ONE JSON line) and
+    return the worst exit status.  Nothing in this process has loaded HIP: the ranks are children, never an exec.  A rank that
+    fails takes the job down: the others are given RANDOMFIELD_COLLECTIVE_TIMEOUT seconds (their own watchdog,
+    slab.Deadline) and are then terminated by pid."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:                    # a free port for MASTER_PORT (names the rendezvous; nothing listens on it)
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    base = dict(os.environ)
+    base.update({"WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
+                 "RANDOMFIELD_LAUNCH_NONCE": "bench-%d-%d" % (os.getpid(), time.time_ns()),
+                 "HSA_ENABLE_IPC_MODE_LEGACY": base.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+    procs = []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))      # only rank 0 speaks on stdout
+    grace = float(os.environ.get("RANDOMFIELD_COLLECTIVE_TIMEOUT", "180")) + 30.0
+    out0, failed_at, codes = b"", None, [None] * n
+    import threading
+    box = {}
+    reader = threading.Thread(target=lambda: box.setdefault("out", procs[0].stdout.read()))
+    reader.daemon = True
+    reader.start()
+    while any(c is None for c in codes):
+        for r, p in enumerate(procs):
+            if codes[r] is None:
+                codes[r] = p.poll()
+                if codes[r] not in (None, 0) and failed_at is None:
+                    failed_at = time.time()
+                    sys.stderr.write("bench.py: rank %d exited with status %d; waiting up to %.0f s for the others\n" % (r, codes[r], grace))
+        if failed_at is not None and time.time() - failed_at > grace:
+            for r, p in enumerate(procs):
+                if codes[r] is None:
+                    p.terminate()                    # exactly the pids started above
+        time.sleep(0.05)
+    reader.join(10)
+    out0 = box.get("out", b"")
+    sys.stdout.write(out0.decode("utf-8", "replace"))
+    sys.stdout.flush()
+    worst = max((abs(c) for c in codes), default=0)
+    if worst:
+        sys.stderr.write("bench.py: exit statuses of the %d ranks: %r\n" % (n, codes))
+    return worst
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -294,14 +368,22 @@ def main():
     ap.add_argument("--force-multi", action="store_true", help="debug: run the N>1 code path with one rank")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # a plain `python bench.py --gpus N`: no launcher has prepared RANK / WORLD_SIZE, so this process becomes the launcher.
+        # It starts the N ranks as CHILDREN (never an exec) before anything here has touched HIP, and relays rank 0's line.
+        sys.exit(launch_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("RANDOMFIELD_BENCH_STUB_CHILD"):
+        # test hook (tests/test_bench_launcher.py, no GPU): a rank that only reports how it was started
+        print(json.dumps({"stub": True, "rank": rank, "world": world, "local_rank": local_rank, "gpus": args.gpus, "steps": args.steps,
+                          "warmup": args.warmup, "master": [os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT")],
+                          "nonce": os.environ.get("RANDOMFIELD_LAUNCH_NONCE"), "ipc_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}))
+        sys.stdout.flush()
+        sys.exit(int(os.environ.get("RANDOMFIELD_BENCH_STUB_RC_RANK%d" % rank, "0")))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
-                     % (args.gpus, args.gpus))
-        args.gpus = world
+        args.gpus = world                            # the launcher's world size is what runs
 
     from randomfield_amd import _hip, powertools
     _hip.require_gpu()                              # no GPU / no library -> loud failure, never a CPU run

@@ -236,6 +236,9 @@ int rf_yz_slabs(rf_plan* plan, int* nslab, int* planes);
  * (torch.distributed / a file / MPI ...).  No-op requirement for nranks == 1. */
 int rf_comm_unique_id(void* id128);
 int rf_comm_init(rf_plan* plan, const void* id128);
+/* ranks of the plan's communicator as RCCL counts them (ncclCommCount); 0 before rf_comm_init.  What a benchmark line states
+ * as "did RCCL see N ranks" (the reference has no distributed code: SURVEY.md section 8e). */
+int rf_comm_size(rf_plan* plan, int* nranks);
 /* host-side all-reduce of 1 or 2 doubles over the plan's communicator (op 0 = sum, 1 = max), after all
  * queued work of the plan: doubles as a barrier.  With one rank it only synchronises the stream. */
 int rf_comm_allreduce_f64(rf_plan* plan, double* inout, int n, int op);

@@ -87,6 +87,7 @@ SIGNATURES = {
     "rf_yz_slabs": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "rf_comm_unique_id": (ctypes.c_int, [ctypes.c_void_p]),
     "rf_comm_init": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "rf_comm_size": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]),
     "rf_comm_allreduce_f64": (ctypes.c_int, [ctypes.c_void_p, _c_dp, ctypes.c_int, ctypes.c_int]),
     "rf_slab_forward": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, _c_dp]),
     "rf_slab_forward_ex": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, _c_dp, ctypes.c_int]),
@@ -181,6 +182,10 @@ class DevicePlan(object):
         self.real_dtype = np.dtype(np.float32 if dtype == np.complex64 else np.float64)
         self._h = ctypes.c_void_p()
         self.unpacked = bool(unpacked)
+        # what a result that is formed again on demand (generate._RegeneratedPotential) depends on: bumped whenever the resident
+        # deviates / the power and k tables of this device plan change, whoever changes them
+        self.noise_epoch = 0
+        self.power_epoch = 0
         if self.unpacked:
             if nranks != 1:
                 raise ValueError("unpacked c2c plans are single-GPU")
@@ -242,7 +247,9 @@ class DevicePlan(object):
         check(self._lib.rf_plan_set_flag(self._h, 2, int(bool(on))), "rf_plan_set_flag")
 
     def set_transposed_intermediate(self, on=True):
-        """x pass -> contiguous tiles in a scratch array, y pass transposes back (default on; off = one in-place buffer)."""
+        """Default OFF (one in-place buffer).  On: the x pass stores contiguous chunks into a blocked scratch array of the field's
+        size, the y pass runs in place there and the z pass gathers from it into the field buffer (RF_FLAG_TRANSPOSED_INTERMEDIATE:
+        5 % faster at 2048^3 float32, slower at 1024^3, twice the device memory)."""
         check(self._lib.rf_plan_set_flag(self._h, 8, int(bool(on))), "rf_plan_set_flag")
 
     def set_yz_slab_planes(self, planes=-1):
@@ -259,6 +266,7 @@ class DevicePlan(object):
             raise ValueError("k-grid tables have the wrong lengths")
         check(self._lib.rf_set_kgrid(self._h, _dp(kx2), _dp(ky2), _dp(kz2)), "rf_set_kgrid")
         self._power_key = None
+        self.power_epoch += 1
 
     def set_power(self, log10k, sigma, if_changed=False):
         """Upload the (log10 k, sigma) tables.  ``if_changed=True`` skips the upload (a stream sync and a table rebuild) when
@@ -271,6 +279,7 @@ class DevicePlan(object):
         if if_changed and key == getattr(self, "_power_key", None):
             return False
         self._power_key = None
+        self.power_epoch += 1
         check(self._lib.rf_set_power(self._h, _dp(log10k), _dp(sigma), len(log10k)), "rf_set_power")
         self._power_key = key
         return True
@@ -287,6 +296,7 @@ class DevicePlan(object):
         from . import mt19937
         state = np.ascontiguousarray(mt19937.seed_state(seed), np.uint32)
         acc = ctypes.c_ulonglong(0)
+        self.noise_epoch += 1
         check(self._lib.rf_noise_mt19937_ex(self._h, state.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)),
                                             ctypes.byref(acc), 1 if single else 0), "rf_noise_mt19937_ex")
         return acc.value
@@ -305,6 +315,7 @@ class DevicePlan(object):
         _, _, count = self.share_segments()
         state = np.ascontiguousarray(mt19937.seed_state(seed), np.uint32)
         counts = np.zeros(count, np.uint64)
+        self.noise_epoch += 1
         check(self._lib.rf_mt_share_begin(self._h, state.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), 1 if single else 0,
                                           counts.ctypes.data_as(ctypes.POINTER(ctypes.c_ulonglong))), "rf_mt_share_begin")
         return counts
@@ -357,6 +368,7 @@ class DevicePlan(object):
         from . import mt19937
         states = np.ascontiguousarray(np.stack([np.asarray(mt19937.seed_state(sd), np.uint32) for sd in seeds]), np.uint32)
         rms = np.empty(len(states), np.float64) if want_rms else None
+        self.noise_epoch += 1
         check(self._lib.rf_realise_batch_reference(self._h, states.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), len(states),
                                                    _dp(rms) if want_rms else None), "rf_realise_batch_reference")
         return rms
@@ -422,6 +434,7 @@ class DevicePlan(object):
         noise = _f64(noise).reshape(-1)
         if noise.size != 2 * self.nx * self.ny * (self.nz // 2 + 1):
             raise ValueError("noise must hold 2*nx*ny*(nz/2+1) float64 deviates")
+        self.noise_epoch += 1                  # host deviates replace the resident ones
         return NOISE_EXTERNAL, _dp(noise), noise
 
     def generate(self, seed=0, noise=None):
@@ -569,6 +582,12 @@ class DevicePlan(object):
     def comm_init(self, unique_id):
         buf = ctypes.create_string_buffer(bytes(unique_id), 128)
         check(self._lib.rf_comm_init(self._h, buf), "rf_comm_init")
+
+    def comm_size(self):
+        """Ranks of the plan's RCCL communicator as RCCL counts them (0: no communicator yet)."""
+        n = ctypes.c_int(0)
+        check(self._lib.rf_comm_size(self._h, ctypes.byref(n)), "rf_comm_size")
+        return n.value
 
     def allreduce(self, values, op="sum"):
         """All-reduce 1 or 2 host doubles over the plan's RCCL communicator (also a barrier)."""

@@ -46,6 +46,7 @@ struct Rccl {
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -71,6 +72,7 @@ int load_rccl() {
   RF_SYM(GetUniqueId, "ncclGetUniqueId")
   RF_SYM(CommInitRank, "ncclCommInitRank")
   RF_SYM(CommDestroy, "ncclCommDestroy")
+  RF_SYM(CommCount, "ncclCommCount")
   RF_SYM(GroupStart, "ncclGroupStart")
   RF_SYM(GroupEnd, "ncclGroupEnd")
   RF_SYM(Send, "ncclSend")
@@ -641,6 +643,7 @@ int queue_c2r(rf_plan* p, const GenParams& gp, const void* kspace) {
     p->stats_valid = true;
     return 0;
   }
+  p->slab_timed = 0;                            // (set again by queue_yz when this call runs the y / z passes slab by slab, timed)
   if (p->timed) RF_HIP(hipEventRecord(p->ev[0], p->stream));
   if (p->nranks == 1 && !p->force_slab) {       // one GPU: x pass, then the y / z passes (slab by slab on large grids)
     if (int rc = queue_xyz(p, gp, kspace, p->W, p->stream, p->stats, p->timed)) return rc;
@@ -1157,7 +1160,10 @@ int rf_realise_scaled_potential(rf_plan* p, uint64_t seed, int mode, double scal
   p->emit_pscale = p->f64 ? scale : (double)(float)scale;
   // the light-cone factor per plane z (generate.py:344-347): in the z pass's own store where the plan runs the plain single-rank
   // passes, else by the sweep rf_scale_z would make -- the same two roundings either way
-  const bool fuse_z = factor_z && p->nranks == 1 && !p->force_slab && !(p->X && xpose_ok(p));
+  // (decided from the plan's FLAG: the blocked intermediate X is allocated lazily inside queue_c2r, and its gathering z pass has no
+  // per-z factor -- testing p->X here dropped the factor on the first call after RF_FLAG_TRANSPOSED_INTERMEDIATE was set)
+  if (int rc = ensure_x(p)) return rc;
+  const bool fuse_z = factor_z && p->nranks == 1 && !p->force_slab && !xpose_ok(p);
   if (factor_z) RF_HIP(hipMemcpyAsync(p->ztab, factor_z, (size_t)p->nz * sizeof(double), hipMemcpyHostToDevice, p->stream));
   p->zscale = fuse_z ? p->ztab : nullptr;
   int rc = queue_c2r(p, make_gen(p, seed, mode, false), nullptr);
@@ -2067,22 +2073,30 @@ int rf_realise_batch_reference(rf_plan* p, const uint32_t* states, int n, double
     RF_HIP(hipStreamCreateWithFlags(&p->aux_stream, hipStreamNonBlocking));
     for (auto& e : p->bev) RF_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
-  // all start states and the per-seed accepted totals live on the device for the length of the batch
-  uint32_t* dstates = nullptr;
-  unsigned long long* dtotals = nullptr;
-  RF_HIP(hipMalloc((void**)&dstates, (size_t)n * 624 * sizeof(uint32_t)));
-  RF_HIP(hipMalloc((void**)&dtotals, (size_t)n * sizeof(unsigned long long)));
-  auto release = [&](int rc) { (void)hipFree(dstates); (void)hipFree(dtotals); return rc; };
-  if (hipMemcpy(dstates, states, (size_t)n * 624 * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) return release(fail(2, "upload of the start states failed"));
+  // all start states and the per-seed accepted totals live on the device for the length of the batch (released on every path)
+  struct DevTmp {
+    void* ptr = nullptr;
+    ~DevTmp() { if (ptr) (void)hipFree(ptr); }
+  } dstates_mem, dtotals_mem;
+  RF_HIP(hipMalloc(&dstates_mem.ptr, (size_t)n * 624 * sizeof(uint32_t)));
+  RF_HIP(hipMalloc(&dtotals_mem.ptr, (size_t)n * sizeof(unsigned long long)));
+  uint32_t* dstates = (uint32_t*)dstates_mem.ptr;
+  unsigned long long* dtotals = (unsigned long long*)dtotals_mem.ptr;
+  RF_HIP(hipMemcpy(dstates, states, (size_t)n * 624 * sizeof(uint32_t), hipMemcpyHostToDevice));
   hipStream_t S = p->stream, R = p->aux_stream;
+  // whatever deviates were resident are about to be overwritten; the plan claims the new ones (and a field) only once every
+  // replay of the batch has been checked
+  p->noise_resident = false;
+  p->noise32_resident = false;
+  p->real_valid = false;
+  p->stats_valid = false;
   p->nseg = g.nseg;
   p->seg_cap = g.cap;
   // first guess of a cell's segment from the EXPECTED acceptances per segment (the exact mean needs a round trip to the host per
   // seed): binomial drift over all segments is a tenth of a segment, slack_cell corrects +-1
   p->seg_inv = 1.0 / ((double)g.cap * 0.78539816339744830962);
-  p->noise_resident = false;
-  p->noise32_resident = true;
-  int rc = 0;
+  // both streams are drained before any return from here on: the temporaries above must not be freed under a running kernel
+  auto drain = [&](int rc) { (void)hipStreamSynchronize(R); (void)hipStreamSynchronize(S); return rc; };
   auto replay = [&](int i) -> int {
     RF_HIP(hipMemcpyAsync(p->mt_states, dstates + (size_t)i * 624, 624 * sizeof(uint32_t), hipMemcpyDeviceToDevice, R));
     if (int r = mt_queue(p, g, 1, R)) return r;
@@ -2090,34 +2104,47 @@ int rf_realise_batch_reference(rf_plan* p, const uint32_t* states, int n, double
     RF_HIP(hipEventRecord(p->bev[0], R));
     return 0;
   };
-  RF_HIP(hipEventRecord(p->ev[0], S));
-  RF_HIP(hipEventRecord(p->bev[1], S));
-  RF_HIP(hipStreamWaitEvent(R, p->bev[1], 0));          // (whatever ran on the main stream before the batch has finished with the runs)
-  if ((rc = replay(0))) return release(rc);
-  for (int i = 0; i < n && !rc; ++i) {
-    RF_HIP(hipStreamWaitEvent(S, p->bev[0], 0));        // the runs of seed i are complete
-    p->resident_fast = true;
-    const bool xp = p->X && xpose_ok(p);
-    rc = queue_x(p, make_gen(p, 0, RF_NOISE_RESIDENT, false), nullptr, xp ? p->X : p->W, S, false);
-    p->resident_fast = false;
-    if (rc) break;
-    RF_HIP(hipEventRecord(p->bev[1], S));               // the generation pass of seed i has read the runs
-    if (i + 1 < n) {
-      RF_HIP(hipStreamWaitEvent(R, p->bev[1], 0));
-      if ((rc = replay(i + 1))) break;
+  auto issue = [&]() -> int {
+    RF_HIP(hipEventRecord(p->ev[0], S));
+    RF_HIP(hipEventRecord(p->bev[1], S));
+    RF_HIP(hipStreamWaitEvent(R, p->bev[1], 0));          // (whatever ran on the main stream before the batch has finished with the runs)
+    if (int rc = replay(0)) return rc;
+    for (int i = 0; i < n; ++i) {
+      RF_HIP(hipStreamWaitEvent(S, p->bev[0], 0));        // the runs of seed i are complete
+      p->resident_fast = true;
+      p->noise32_resident = true;                         // (queue_x selects the float32-pair kernel by it; cleared again on failure)
+      const bool xp = p->X && xpose_ok(p);
+      const int rc = queue_x(p, make_gen(p, 0, RF_NOISE_RESIDENT, false), nullptr, xp ? p->X : p->W, S, false);
+      p->resident_fast = false;
+      if (rc) return rc;
+      RF_HIP(hipEventRecord(p->bev[1], S));               // the generation pass of seed i has read the runs
+      if (i + 1 < n) {
+        RF_HIP(hipStreamWaitEvent(R, p->bev[1], 0));
+        if (int rc2 = replay(i + 1)) return rc2;
+      }
+      if (int rc3 = queue_yz(p, p->W, S, p->stats + 2 * i, false)) return rc3;
     }
-    rc = queue_yz(p, p->W, S, p->stats + 2 * i, false);
-  }
-  if (rc) { (void)hipStreamSynchronize(R); (void)hipStreamSynchronize(S); return release(rc); }
-  RF_HIP(hipEventRecord(p->ev[4], S));
+    RF_HIP(hipEventRecord(p->ev[4], S));
+    return 0;
+  };
   std::vector<unsigned long long> totals((size_t)n);
   std::vector<double> st(2 * (size_t)n);
-  RF_HIP(hipStreamSynchronize(R));
-  RF_HIP(hipMemcpyAsync(st.data(), p->stats, st.size() * sizeof(double), hipMemcpyDeviceToHost, S));
-  RF_HIP(hipStreamSynchronize(S));
-  if (hipMemcpy(totals.data(), dtotals, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return release(fail(2, "download of the accepted counts failed"));
-  release(0);
-  for (int i = 0; i < n; ++i) RF_REQUIRE(totals[i] >= g.ncells, "MT19937 replay: not enough accepted polar attempts (increase the margin)");
+  int rc = issue();
+  if (!rc) {
+    hipError_t e = hipStreamSynchronize(R);
+    if (e == hipSuccess) e = hipMemcpyAsync(st.data(), p->stats, st.size() * sizeof(double), hipMemcpyDeviceToHost, S);
+    if (e == hipSuccess) e = hipStreamSynchronize(S);
+    if (e == hipSuccess) e = hipMemcpy(totals.data(), dtotals, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = fail(2, std::string("rf_realise_batch_reference: ") + hipGetErrorString(e));
+  }
+  if (!rc)
+    for (int i = 0; i < n && !rc; ++i)
+      if (totals[i] < g.ncells) rc = fail(1, "MT19937 replay: not enough accepted polar attempts (increase the margin)");
+  if (rc) {
+    p->noise32_resident = false;
+    return drain(rc);
+  }
+  p->noise32_resident = true;                             // the last seed's deviates, as float32 pairs in the runs
   p->cur = p->W; p->timed = false; p->real_valid = true; p->stats_valid = true; p->stats_slot = n - 1; p->k_valid = false;
   if (rms_out) {
     const double cnt = (double)p->nx * p->ny * p->nz;
@@ -2168,6 +2195,15 @@ int rf_comm_init(rf_plan* p, const void* id128) {
   RF_HIP(hipMemsetAsync(p->coll_scratch, 0, 2 * sizeof(double), p->stream));
   RF_NCCL(g_rccl.AllReduce(p->coll_scratch, p->coll_scratch, 2, ncclFloat64, ncclSum, p->comm, p->stream));
   RF_HIP(hipStreamSynchronize(p->stream));
+  return 0;
+}
+
+// ranks of the plan's RCCL communicator as RCCL itself counts them (ncclCommCount); 0 = no communicator (rf_comm_init has not run)
+int rf_comm_size(rf_plan* p, int* nranks) {
+  RF_REQUIRE(p && nranks, "null argument");
+  *nranks = 0;
+  if (!p->comm) return 0;
+  RF_NCCL(g_rccl.CommCount(p->comm, nranks));
   return 0;
 }
 

@@ -51,10 +51,28 @@ class _RegeneratedPotential(object):
 
     def __init__(self, generator, seed, noise):
         self._generator, self.seed, self.noise = generator, seed, noise
+        dev = generator.plan_c2r.device
+        # the device state this potential is a function of: the power / k tables, and (replayed stream) the resident deviates
+        self._epochs = (dev.power_epoch, dev.noise_epoch if noise is not None else None)
+
+    def check_current(self):
+        """Raise unless the device plan still holds what the delta field was made from.  The reference's stored
+        ``self.potential`` cannot change behind the caller's back; a regenerated one could, if somebody replaced the resident
+        deviates (``reference_noise``, a same-seed batch, host deviates) or the power tables (``set_power``) through
+        ``plan_c2r.device`` in between -- the result would silently belong to another field."""
+        dev = self._generator.plan_c2r.device
+        now = (dev.power_epoch, dev.noise_epoch if self.noise is not None else None)
+        if now != self._epochs:
+            what = "power / k tables" if now[0] != self._epochs[0] else "resident deviates"
+            raise RuntimeError("The saved potential of the last generate_delta_field() call can no longer be formed: the device "
+                               "plan's {0} have changed since.  Generate the field again, or use "
+                               "Generator(store_potential=True) to keep delta(k)/k**2 in memory.".format(what))
 
     def download(self):
         """Host copy (nx, ny, nz/2+1) of the potential.  Runs the storing form of the call (rf_realise_potential) with the same
-        seed: the plan's field buffer holds the delta field again afterwards."""
+        seed.  Side effect: the plan's FIELD buffer is overwritten with the delta field of that seed again -- whatever
+        ``convert_delta_to_density`` / ``calculate_newtonian_potential`` had left there is gone (download the field first)."""
+        self.check_current()
         dev = self._generator.plan_c2r.device
         dev.realise_potential(self.seed, self.noise)
         dev.load_potential(1.0)
@@ -415,6 +433,7 @@ class Generator(object):
             return field
         dev = self.plan_c2r.device
         if isinstance(self.potential, _RegeneratedPotential):
+            self.potential.check_current()
             dev.realise_scaled_potential(self.potential.seed, self.potential.noise, scale, factor_z=factor)
             factor = None           # (applied by the z pass itself)
         else:

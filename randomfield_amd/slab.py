@@ -16,6 +16,7 @@ with gloo is used by the CPU tests only.)
 from __future__ import annotations
 
 import os
+import time
 
 import numpy as np
 
@@ -108,46 +109,93 @@ def shared_replay_pack(pairs, first_cell, nz, nranks):
 
 
 _plans_made = 0          # DistributedPlans built by this process so far: every rank builds them in the same order
+_T_IMPORT = time.time()
+
+
+def _proc_start_ticks(pid):
+    """Start time of process `pid` in clock ticks since boot (field 22 of /proc/<pid>/stat), or 0 when it cannot be read.
+    (pid, start ticks) names a process for the lifetime of the machine: pids are reused, the pair is not."""
+    try:
+        with open("/proc/%d/stat" % pid, "rb") as f:
+            stat = f.read().decode("ascii", "replace")
+        return int(stat[stat.rindex(")") + 2:].split()[19])
+    except (OSError, ValueError, IndexError):
+        return 0
+
+
+def _process_start_time():
+    """When THIS process started, seconds since the epoch (boot time has 1 s resolution; never later than the truth by more
+    than that).  Falls back to the time this module was imported."""
+    try:
+        ticks = _proc_start_ticks(os.getpid())
+        with open("/proc/stat", "rb") as f:
+            for line in f:
+                if line.startswith(b"btime"):
+                    return int(line.split()[1]) + ticks / float(os.sysconf("SC_CLK_TCK"))
+    except (OSError, ValueError):
+        pass
+    return _T_IMPORT
+
+
+
+def launch_nonce():
+    """A string every rank of ONE launch agrees on without talking to the others, and that no other launch on this node
+    shares: ``RANDOMFIELD_LAUNCH_NONCE`` when the launcher sets it (``bench.py --gpus N`` does, for the ranks it starts itself),
+    else the launcher PROCESS -- the ranks of ``torch.distributed.run`` are children of one agent process, so its (pid, start
+    time) identifies the launch -- plus MASTER_PORT and the elastic run id."""
+    env = os.environ.get("RANDOMFIELD_LAUNCH_NONCE")
+    if env:
+        return "".join(c if (c.isalnum() or c in "-.") else "_" for c in env)
+    ppid = os.getppid()
+    return "%d.%d.%s.%s" % (ppid, _proc_start_ticks(ppid), os.environ.get("MASTER_PORT", "0"),
+                            "".join(c if c.isalnum() else "_" for c in os.environ.get("TORCHELASTIC_RUN_ID", "none")))
 
 
 def _rendezvous_path(serial=None):
-    """A file name every rank of one launch agrees on for its `serial`-th DistributedPlan: the ranks of
-    `torch.distributed.run` are children of the same agent process, so (parent pid, MASTER_PORT, run id) identifies the
-    launch on this node, and the per-process plan counter the plan (two plans of one job never share a file: a fast rank
-    cannot pick up the previous plan's id)."""
-    port = os.environ.get("MASTER_PORT", "0")
-    run_id = os.environ.get("TORCHELASTIC_RUN_ID", "none")
+    """A file name every rank of one launch agrees on for its `serial`-th DistributedPlan: the launch's nonce
+    (:func:`launch_nonce`) and the per-process plan counter (two plans of one job never share a file: a fast rank cannot pick
+    up the previous plan's id)."""
     serial = _plans_made if serial is None else serial
-    return os.path.join(os.environ.get("TMPDIR", "/tmp"), "randomfield_uid_%d_%s_%s_%d" % (os.getppid(), port, run_id, serial))
+    return os.path.join(os.environ.get("TMPDIR", "/tmp"), "randomfield_uid_%s_%d" % (launch_nonce(), serial))
 
 
-def exchange_unique_id(rank, world, make_uid, timeout=300.0, path=None):
+def exchange_unique_id(rank, world, make_uid, timeout=300.0, path=None, not_before=None):
     """Hand rank 0's RCCL unique id to every rank of a single-node job WITHOUT importing torch
     (a process that loads PyTorch's bundled ROCm runtime next to the system one is asking for trouble).
-    Rank 0 removes any stale file of that name, then writes the 128 bytes atomically; the others poll for the file
-    and only accept one written after they started waiting for THIS plan (mtime), 128 bytes long."""
-    import time
+    Rank 0 removes any stale file of that name, then writes the 128 bytes, followed by the launch's nonce, atomically.  The
+    others poll for the file and accept it only if (a) it is 128 bytes + THIS launch's nonce and (b) it was written after this
+    process started (mtime >= `not_before`, default: the process's own start time minus the clock's 2 s of slack).  (a) rejects
+    the file of any other launch; (b) the one case (a) cannot see -- a launcher without a nonce of its own that starts job
+    after job from ONE long-lived parent with the same MASTER_PORT, where a crashed job's file has this job's name: a rank
+    that gets here before rank 0 has removed that file would otherwise read a dead communicator's id and sit in
+    ncclCommInitRank until the watchdog (:class:`Deadline`) ends it."""
     path = _rendezvous_path() if path is None else path
     if world == 1:
         return make_uid()
+    tag = b"|" + launch_nonce().encode("ascii", "replace")
     if rank == 0:
         try:
             os.remove(path)
         except OSError:
             pass
         uid = make_uid()
+        if len(uid) != 128:
+            raise ValueError("an RCCL unique id is 128 bytes, got %d" % len(uid))
         tmp = path + ".tmp%d" % os.getpid()
         with open(tmp, "wb") as f:
-            f.write(uid)
+            f.write(uid + tag)
         os.replace(tmp, path)
         return uid
+    if not_before is None:
+        not_before = _process_start_time() - 2.0
     t0 = time.time()
     while True:
         try:
             with open(path, "rb") as f:
-                uid = f.read()
-            if len(uid) == 128:
-                return uid
+                mtime = os.fstat(f.fileno()).st_mtime
+                blob = f.read()
+            if len(blob) == 128 + len(tag) and blob[128:] == tag and mtime >= not_before:
+                return blob[:128]
         except OSError:
             pass
         if time.time() - t0 > timeout:

@@ -278,6 +278,54 @@ def test_rendezvous_files_are_per_plan_and_stale_ids_are_dropped(tmp_path, monke
     assert slab.exchange_unique_id(1, 2, lambda: b"", timeout=5, path=a) == fresh
 
 
+def test_a_rank_never_accepts_another_launch_or_an_older_file(tmp_path, monkeypatch):
+    """What exchange_unique_id promises its non-zero ranks: a file of this name is the id of THIS launch only if it carries the
+    launch's nonce and was written after the process started.  A crashed launch's file (other nonce), an untagged file and a
+    file of this very name left by an earlier job of the same long-lived launcher (same nonce, old mtime) are all ignored until
+    rank 0 replaces them."""
+    import threading
+    import time
+    from randomfield_amd import slab
+    monkeypatch.setenv("TMPDIR", str(tmp_path))
+    monkeypatch.setenv("MASTER_PORT", "34567")
+    # the nonce: the launcher's own when it sets one, else (parent pid, parent start, port, run id) -- a new launcher process
+    # or port is a new name, so files of other launches are not even looked at
+    n0 = slab.launch_nonce()
+    assert n0.startswith("%d." % os.getppid()) and ".34567." in n0
+    monkeypatch.setenv("MASTER_PORT", "34568")
+    assert slab.launch_nonce() != n0
+    monkeypatch.setenv("RANDOMFIELD_LAUNCH_NONCE", "job-17/a b")
+    assert slab.launch_nonce() == "job-17_a_b" and "job-17_a_b" in slab._rendezvous_path(3)
+    path = slab._rendezvous_path(0)
+    dead, fresh = bytes([7]) * 128, bytes(range(128))
+    got = {}
+
+    def reader():
+        got["uid"] = slab.exchange_unique_id(1, 2, lambda: b"", timeout=20, path=path)
+
+    def run_with(stale_bytes, age):
+        with open(path, "wb") as f:
+            f.write(stale_bytes)
+        if age:
+            os.utime(path, (time.time() - age, time.time() - age))
+        got.clear()
+        t = threading.Thread(target=reader)
+        t.start()
+        time.sleep(0.3)
+        assert t.is_alive() and not got, "the stale file was accepted"
+        assert slab.exchange_unique_id(0, 2, lambda: fresh, path=path) == fresh
+        t.join(10)
+        assert got == {"uid": fresh}
+
+    run_with(dead, 0)                                                # no tag at all (the pre-round-4 format)
+    run_with(dead + b"|some-other-launch", 0)                        # another launch's nonce
+    run_with(dead + b"|" + slab.launch_nonce().encode(), 3600.0)     # this name and nonce, but written an hour before we started
+    # (the guard is the process's own start time: a file written after it is taken at once)
+    assert slab._process_start_time() <= time.time() and time.time() - slab._process_start_time() < 3600
+    with pytest.raises(ValueError):
+        slab.exchange_unique_id(0, 2, lambda: b"short", path=path)
+
+
 def test_deadline_names_the_missing_rank_and_exits(tmp_path):
     """A blocked collective step ends the process with status 3 and says which rank never arrived (run in a child:
     the watchdog calls os._exit)."""

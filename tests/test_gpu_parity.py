@@ -1002,6 +1002,36 @@ def test_regenerated_potential_equals_stored_one(hip, dpower, shape, dtype):
     plan.close()
 
 
+def test_light_cone_factor_survives_a_flag_set_just_before_the_call(hip, dpower):
+    """rf_realise_scaled_potential(factor_z) decides where the per-z factor is applied (the plain z pass's store, or a sweep behind
+    the gathering z pass of the blocked intermediate) from the plan's FLAG, not from whether the lazily allocated intermediate
+    exists yet: with RF_FLAG_TRANSPOSED_INTERMEDIATE set straight before the call -- the plan's first use of it -- the factor used
+    to be dropped silently (the result was the z = 0 potential)."""
+    k, Pk = dpower
+    n = 64
+    scale = -2.5e-3
+    fz = np.exp(-0.01 * np.arange(n)) / (1 + 0.002 * np.arange(n))
+    plan = make_plan(hip, (n, n, n), np.complex64, k, Pk)
+    plan.realise_scaled_potential(seed=77, scale=scale, factor_z=fz)
+    want = plan.download_real()
+    plan.realise_scaled_potential(seed=77, scale=scale)
+    plain = plan.download_real()
+    assert np.max(np.abs(want - plain * fz.astype(np.float32))) <= 1e-6 * want.std()
+    plan.close()
+    for first_call in (True, False):
+        plan = make_plan(hip, (n, n, n), np.complex64, k, Pk)
+        if not first_call:
+            plan.realise(seed=1)                                   # (the plan has run without the intermediate before)
+        plan.set_transposed_intermediate(True)
+        plan.realise_scaled_potential(seed=77, scale=scale, factor_z=fz)
+        got = plan.download_real()
+        assert np.max(np.abs(got - want)) <= 2e-6 * want.std(), "light-cone factor lost (first call: %s)" % first_call
+        plan.set_transposed_intermediate(False)                    # and back: fused into the plain z pass again
+        plan.realise_scaled_potential(seed=77, scale=scale, factor_z=fz)
+        assert np.max(np.abs(plan.download_real() - want)) <= 2e-6 * want.std()
+        plan.close()
+
+
 def test_generator_regenerates_the_potential_on_demand(hip):
     """Generator: the default call (save_potential=True) without the store, calculate_newtonian_potential from the seed (native)
     or the resident deviates (reference), against Generator(store_potential=True); potential.download() still delivers
@@ -1608,6 +1638,9 @@ def test_bench_multi_gpu_code_path_with_one_rank(hip):
     assert line["n_gpus"] == 1 and line["steps"] == 3 and line["unit"] == "Mcells/s" and line["value"] > 0
     assert line["config"]["grid"] == [256, 256, 256] and 2.0 < line["config"]["rms_last"] < 2.6
     assert line["roofline"]["frac"] > 0 and line["pipeline"]["kernel_ms_rank0_unpipelined_step"]["x"] > 0
+    # what RCCL itself says the communicator spans, and the N = 1 equivalent timed in the same job
+    assert line["config"]["rccl_ranks"] == 1 and line["config"]["launcher"].startswith("external")
+    assert line["single_gpu_equivalent"]["grid"] == [256, 256, 256] and line["single_gpu_equivalent"]["ms_per_step"] > 0
 
 
 def test_two_distributed_plans_in_a_row(hip, dpower, monkeypatch, tmp_path):
@@ -1681,6 +1714,36 @@ def test_generator_notices_tables_changed_behind_its_back(hip):
     assert dev.set_power(*_other_tables(), if_changed=True) is True               # (and the key follows every upload)
     assert dev.set_power(*_other_tables(), if_changed=True) is False
     dev.close()
+
+
+def test_regenerated_potential_refuses_a_changed_device_state(hip):
+    """A potential that is formed again on demand is a function of the seed, the power tables and (rng='reference') the resident
+    deviates.  The reference's stored array cannot change behind the caller's back; ours says so instead of returning the
+    potential of some other field when somebody has replaced any of those through ``plan_c2r.device``."""
+    from randomfield_amd import Generator
+    from randomfield_amd.generate import _RegeneratedPotential
+    for rng in ("native", "reference"):
+        gen = Generator(64, 64, 64, SPACING, backend="hip", rng=rng)
+        dev = gen.plan_c2r.device
+        gen.generate_delta_field(seed=3)
+        assert isinstance(gen.potential, _RegeneratedPotential)
+        want = gen.calculate_newtonian_potential(light_cone=False, scale=-1.5).copy()
+        assert np.array_equal(gen.calculate_newtonian_potential(light_cone=False, scale=-1.5), want)      # repeatable while nothing changes
+        dev.set_power(*[np.asarray(t) for t in _other_tables()])                     # other tables on the same device plan
+        with pytest.raises(RuntimeError, match="power"):
+            gen.calculate_newtonian_potential(light_cone=False, scale=-1.5)
+        with pytest.raises(RuntimeError, match="power"):
+            gen.potential.download()
+        gen.generate_delta_field(seed=3)                                             # a new field: its potential is current again
+        assert np.max(np.abs(gen.calculate_newtonian_potential(light_cone=False, scale=-1.5) - want)) <= 1e-6 * want.std()
+        if rng == "reference":
+            dev.reference_noise(4, single=True)                                      # somebody replays another seed's stream
+            with pytest.raises(RuntimeError, match="deviates"):
+                gen.calculate_newtonian_potential(light_cone=False, scale=-1.5)
+        else:
+            dev.reference_noise(4, single=True)                                      # (irrelevant to the native generator)
+            gen.calculate_newtonian_potential(light_cone=False, scale=-1.5)
+        dev.close()
 
 
 def _other_tables():

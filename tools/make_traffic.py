@@ -28,13 +28,13 @@ def main():
         commit = "unknown"
     out = {"note": note, "source": "profiles/traffic_latest.json (%s) @ commit %s" % (note, commit), "unit": "bytes per launch",
            "correction": "read = 2 * FETCH_SIZE * 1024 (gfx950 wide-read under-count), write = WRITE_SIZE * 1024",
-           "grid": [1024, 1024, 1024], "yz_slabs": int(sys.argv[5]) if len(sys.argv) > 5 else None,
+           "grid": [int(v) for v in sys.argv[6].split("x")] if len(sys.argv) > 6 else [1024, 1024, 1024], "yz_slabs": int(sys.argv[5]) if len(sys.argv) > 5 else None,
            "kernels": {}}
     for k in sorted(set(fetch) | set(write)):
         if "rf::" not in k:
             continue
         rd, wr = 2 * fetch.get(k, 0.0) * 1024, write.get(k, 0.0) * 1024
-        short = k.split("(")[0].replace("void ", "")
+        short = k.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
         out["kernels"][short] = {"read": rd, "write": wr, "total": rd + wr}
     json.dump(out, open(sys.argv[3], "w"), indent=1)
     for k, v in out["kernels"].items():

@@ -8,7 +8,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in rows:
     name = r["Kernel_Name"]
-    short = name.split("(")[0].replace("void rf::", "").replace("rf::", "")[:100]
+    short = name.replace("(anonymous namespace)::", "").split("(")[0].replace("void rf::", "").replace("rf::", "")[:100]
     acc[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, cs in acc.items():
     print(k)
