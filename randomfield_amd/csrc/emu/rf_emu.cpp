@@ -34,8 +34,6 @@ void run_col_pass(const IO& io_in, long long ncols, const cplx<typename C::T>* t
       for (int t = 0; t < C::NT; ++t) F::prologue(t, ios[t], tw, lds.data());
       if (C::NPASS >= 2) ltw = F::lds_tw(lds.data());
     }
-    if (IO::FIX_MODE == 2 && C::NPASS >= 2 && ios[0].needs_fix(tile * C::TC))          // (the kernel's uniform branch + barrier)
-      for (int t = 0; t < C::NT; ++t) F::fix_prepare(t, tile, ios[t], lds.data());
     for (int t = 0; t < C::NT; ++t) F::pass_first(t, tile, ios[t], lds.data());
     if (C::NPASS == 3) {
       for (int t = 0; t < C::NT; ++t) F::pass_mid_read(t, ltw, lds.data(), regs[t]);
@@ -66,8 +64,6 @@ void run_col2_pass(const IO& io_in, long long ncols, const cplx<typename C1::T>*
     const cx* ltw = F::lds_tw(lds.data());
     for (int phase = 0; phase < 2; ++phase) {
       for (int t = 0; t < C1::NT; ++t) ios[t].set_phase(phase);
-      if (IO::FIX_MODE == 2 && ios[0].needs_fix(tile * C1::TC))
-        for (int t = 0; t < C1::NT; ++t) F::fix_prepare(t, tile, ios[t], lds.data());
       for (int t = 0; t < C1::NT; ++t) F::pass_first(t, tile, ios[t], lds.data());
       if (phase == 0) for (int t = 0; t < C1::NT; ++t) F::tw_stage(t, lds.data(), twr[t]);
       if (C1::NPASS == 3) {
@@ -345,6 +341,18 @@ int c2r_impl(int nx, int ny, int nz, const GenHost* gen, const cplx<T>* kspace, 
   return dispatch_row_c2r<T>((int)nzc, W, (long long)nx * ny, 1.0 / ((double)nx * ny * nz), s1, s2);
 }
 
+// fix_fill_kernel (rf_kernels.h): the repaired kz = 0 slot of every mode (ix, iy) into the side buffer the FIX = 3 launch reads
+template <class IOF, class CT>
+void fill_fix_buffer(IOF iof, std::vector<CT>& buf) {
+  const int nx = iof.gp.nx, ny = iof.gp.ny;
+  buf.resize((size_t)nx * ny);
+  std::vector<char> lds(IOF::LDS_EXTRA + 16);
+  iof.bind_seed();
+  iof.prologue(0, 1, lds.data());
+  for (int iy = 0; iy < ny; ++iy)
+    for (int ix = 0; ix < nx; ++ix) buf[(size_t)iy * nx + ix] = iof.fix_value((long long)iy * iof.nzl, ix, 0);
+}
+
 template <typename T, class IO>
 int realise_fast_impl(int nx, int ny, int nz, const GenHost& h, uint64_t seed, double xlo, double xhi, double dkx,
                       cplx<T>* W, double* s1, double* s2) {
@@ -358,7 +366,7 @@ int realise_fast_impl(int nx, int ny, int nz, const GenHost& h, uint64_t seed, d
   f.nx = nx; f.ny = ny; f.nz = nz; f.dkx = (float)dkx; f.dky = (float)std::sqrt(h.gp.ky2[1]); f.dkz = (float)std::sqrt(h.gp.kz2[1]);
   f.rec = rec.data(); f.nbins = (int)rec.size();
   f.u_scale = (float)(0.5 * std::log10(2.0) / dx); f.u_off = (float)(-x0 / dx);
-  f.seed = seed; f.seed_dev = nullptr; f.noise = nullptr; f.noise32 = nullptr; f.seg_off = nullptr; f.seg_cap = 0; f.seg_inv = 0; f.nseg = 0; f.zpitch = nz / 2 + 1; f.zoff = 0; f.ppitch = nz / 2 + 2;
+  f.seed = seed; f.seed_dev = nullptr; f.noise = nullptr; f.noise32 = nullptr; f.rowtab = nullptr; f.seg_cap = 0; f.zpitch = nz / 2 + 1; f.zoff = 0; f.ppitch = nz / 2 + 2;
   int rc;
   if (xpose_ok<T>(nx, ny, nzc)) {
     std::vector<cplx<T>> X((size_t)nx * ny * nzc);
@@ -368,14 +376,20 @@ int realise_fast_impl(int nx, int ny, int nz, const GenHost& h, uint64_t seed, d
     return xposed_yz<T>(nx, ny, nz, X.data(), W, s1, s2);
   }
   bool x_done = false;
-  // (where the library splits the pass -- kz runs of more than one whole tile -- its repair launch is the FIX = 2 kernel; the
-  // emulator runs that kernel over every tile: tiles without kz = 0 skip the repair phase, as the FIX = 0 launch does)
+  // (where the library splits the pass -- kz runs of more than one whole tile -- its repair launch is the FIX = 3 kernel behind
+  // fix_fill_kernel; the emulator runs that kernel over every tile: tiles without kz = 0 take nothing from the side buffer, as
+  // the FIX = 0 launch does)
+  std::vector<cplx<T>> fixbuf;
   if constexpr (sizeof(T) == 4) {
     if (nx == 2048 && ((long long)ny * nzc) % 8 == 0) {      // the library's x pass at this length: Col2 over the 1024-point configuration
       using C1 = GenSel<float, 1024>::type;
-      using IO2 = FastGenColIOT<0, 2, 0, 0, 0, 2>;
+      using IO2 = FastGenColIOT<0, 3, 0, 0, 0, 2>;
       IO2 io2;
       io2.base = W; io2.g = io.g; io2.kz0 = 0; io2.nzl = (int)nzc; io2.rec = nullptr; io2.gp = io.gp; io2.pot = nullptr;
+      typename IO2::fill_io iof;
+      iof.base = W; iof.g = io.g; iof.kz0 = 0; iof.nzl = (int)nzc; iof.rec = nullptr; iof.gp = io.gp; iof.pot = nullptr;
+      fill_fix_buffer(iof, fixbuf);
+      io2.fixbuf = fixbuf.data();
       auto tw2 = make_twiddles<float>(2048);
       run_col2_pass<C1, +1, IO2>(io2, (long long)ny * nzc, tw2.data());
       x_done = true;
@@ -384,20 +398,28 @@ int realise_fast_impl(int nx, int ny, int nz, const GenHost& h, uint64_t seed, d
   if constexpr (sizeof(T) == 8) {
     if (nx == 1024 && ((long long)ny * nzc) % 8 == 0) {      // float64, length 1024: Col2 over the 512-point configuration
       using C1 = GenSel<double, 512>::type;
-      using IO2 = FastGenColIO64<2, 0, 0, 2>;
+      using IO2 = FastGenColIO64<3, 0, 0, 2>;
       IO2 io2;
       io2.base = W; io2.g = io.g; io2.kz0 = 0; io2.nzl = (int)nzc; io2.rec = nullptr; io2.gp = io.gp; io2.pot = nullptr;
+      typename IO2::fill_io iof;
+      iof.base = W; iof.g = io.g; iof.kz0 = 0; iof.nzl = (int)nzc; iof.rec = nullptr; iof.gp = io.gp; iof.pot = nullptr;
+      fill_fix_buffer(iof, fixbuf);
+      io2.fixbuf = fixbuf.data();
       auto tw2 = make_twiddles<double>(1024);
       run_col2_pass<C1, +1, IO2>(io2, (long long)ny * nzc, tw2.data());
       x_done = true;
     }
   }
-  if (!x_done && (nx == 512 || nx == 1024)) {               // the long whole-column passes: FIX = 2 where the library splits
-    using IOC = typename IO::template with_fix<2>;
+  if (!x_done && (nx == 512 || nx == 1024)) {               // the long whole-column passes: FIX = 3 where the library splits
+    using IOC = typename IO::template with_fix<3>;
     const int tc = tile_cols<T>(nx, true);
     if (nzc > tc && nzc % tc == 0) {
       IOC ioc;
       ioc.base = W; ioc.g = io.g; ioc.kz0 = 0; ioc.nzl = (int)nzc; ioc.rec = nullptr; ioc.gp = io.gp; ioc.pot = nullptr;
+      typename IOC::fill_io iof;
+      iof.base = W; iof.g = io.g; iof.kz0 = 0; iof.nzl = (int)nzc; iof.rec = nullptr; iof.gp = io.gp; iof.pot = nullptr;
+      fill_fix_buffer(iof, fixbuf);
+      ioc.fixbuf = fixbuf.data();
       rc = dispatch_col<T, +1, IOC, GenSel>(nx, ioc, (long long)ny * nzc);
       if (rc) return rc;
       x_done = true;
@@ -541,20 +563,22 @@ int c2r_lognormal_impl(int nx, int ny, int nz, const cplx<T>* kspace, const doub
 
 extern "C" {
 
-// slack_cell (rf_core.h): where the generation pass finds the float32 deviate pair of stream cell c when the pairs were left
-// in the replay's per-segment runs.  pairs = (first cell, first cell of the next segment) per segment; out[i] = slot index.
-int emu_slack_lookup(const unsigned long long* pairs, int nseg, unsigned long long cap, double inv, const unsigned long long* cells,
-                     int n, unsigned long long* out, int* seg_out) {
+// The row table of resident float32 deviates (rf_core.h make_rowloc / row_pair; mt_rowtab_kernel builds it on the device): where
+// the generation pass finds the pair of cell kz of the row whose first stream cell is rows[i].  first = exclusive scan of the
+// per-segment counts, nseg + 1 entries.  out[i * nzh + kz] = slot index in the runs; returns the "row spans more than two
+// segments" flag.
+int emu_row_lookup(const unsigned long long* first, int nseg, unsigned long long cap, unsigned nzh, const unsigned long long* rows, int n,
+                   unsigned long long* out) {
   FastGenParams g;
   memset(&g, 0, sizeof g);
   std::vector<cplx<float>> dummy(1);
-  g.noise32 = dummy.data(); g.seg_off = pairs; g.seg_cap = cap; g.seg_inv = inv; g.nseg = nseg;
+  g.noise32 = dummy.data(); g.seg_cap = cap;
+  int bad = 0;
   for (int i = 0; i < n; ++i) {
-    unsigned long long o1;
-    const cplx<float>* p = slack_cell(g, cells[i], seg_out[i], o1);
-    out[i] = (unsigned long long)(p - g.noise32);
+    const RowLoc e = make_rowloc(first, nseg, rows[i], nzh, &bad);
+    for (unsigned kz = 0; kz < nzh; ++kz) out[(size_t)i * nzh + kz] = (unsigned long long)(row_pair(g, e, (int)kz) - g.noise32);
   }
-  return 0;
+  return bad;
 }
 
 // the generic (any even shape) transforms: API-layout half spectrum <-> dense real field; c2c in place

@@ -144,15 +144,17 @@ struct rf_plan {
   // the two forms (float64 in cell order / float32 in segment order) is valid at a time.
   bool noise32_resident = false;
   unsigned long long seg_cap = 0;
-  double seg_inv = 0;
   int nseg = 0;
+  void* mt_rowtab = nullptr;           // float32 form: where each row (ix, iy) of the stream starts in the runs (rf_core.h RowLoc, 8 B x nx ny)
+  int* mt_flags = nullptr;             // device word: bit 0 = a row spans more than two segments (mt_rowtab_kernel)
+  void* fixbuf = nullptr;              // nx * ny complex: the repaired kz = 0 slots of the fast generation pass (fix_fill_kernel)
   // MT19937 replay (rf_noise_mt19937): jump-polynomial bit positions per tree level, scratch
   uint32_t* mt_pos = nullptr;          // set-bit positions of the jump polynomials, widened to 32 bits (scalar loads)
   std::vector<int> mt_npos;
   int mt_stride = 0, mt_bps = 0, mt_radix = 2;   // positions per polynomial (padded), blocks of 624 words per segment, tree radix
   int* mt_npos_dev = nullptr;
   uint32_t* mt_states = nullptr;
-  unsigned long long *mt_counts = nullptr, *mt_offsets = nullptr, *mt_pairs = nullptr;
+  unsigned long long *mt_counts = nullptr, *mt_offsets = nullptr;
   size_t mt_states_cap = 0, mt_seg_cap = 0;
   void* mt_scratch = nullptr;          // one-pass replay: every segment's accepted pairs, densely from slot seg * (attempts per segment)
   size_t mt_scratch_bytes = 0;
@@ -319,7 +321,7 @@ FastGenParams make_fast(rf_plan* p, uint64_t seed, bool seed_from_dev, const uin
   f.rec = p->frec; f.nbins = p->fnbins; f.u_scale = p->fu_scale; f.u_off = p->fu_off;
   f.seed = seed; f.seed_dev = seed_from_dev ? seed_ptr : nullptr;
   f.noise = nullptr; f.noise32 = nullptr;
-  f.seg_off = nullptr; f.seg_cap = 0; f.seg_inv = 0; f.nseg = 0;
+  f.rowtab = nullptr; f.seg_cap = 0;
   f.zpitch = p->nzl + 1; f.zoff = p->kz0; f.ppitch = p->ppitch;
   f.pscale = p->emit_pscale; f.emit_potential = p->emit_potential ? 1 : 0;
   return f;
@@ -366,6 +368,9 @@ int build_fast(rf_plan* p) {
   RF_HIP(hipMalloc((void**)&p->frec, rec.size() * sizeof(FastRec)));
   RF_HIP(hipMemcpy(p->frec, rec.data(), rec.size() * sizeof(FastRec), hipMemcpyHostToDevice));
   p->fnbins = (int)rec.size();
+  // side buffer of the repaired kz = 0 slots (one complex per mode (ix, iy): 8 MB at 1024^2 float32), filled and read inside the
+  // generation pass by the rank that owns kz = 0 -- every rank in replicated-generation mode
+  if (!p->fixbuf) RF_HIP(hipMalloc(&p->fixbuf, (size_t)p->nx * p->ny * p->csize));
   p->have_fast = true;
   return 0;
 }
@@ -398,13 +403,13 @@ int queue_x(rf_plan* p, const GenParams& gp, const void* kspace, void* W, hipStr
   FastGenParams fgp = make_fast(p, gp.seed, gp.seed_dev != nullptr, gp.seed_dev);
   if (fast_noise && p->noise32_resident) {
     fgp.noise32 = reinterpret_cast<const cplx<float>*>(p->mt_scratch);      // (a later float64 replay reuses the scratch: it clears noise32_resident)
-    fgp.seg_off = p->mt_pairs; fgp.seg_cap = p->seg_cap; fgp.seg_inv = p->seg_inv; fgp.nseg = p->nseg;
+    fgp.rowtab = reinterpret_cast<const RowLoc*>(p->mt_rowtab); fgp.seg_cap = p->seg_cap;
   }
   else if (fast_noise) fgp.noise = gp.noise;
   if (fast)
     RF_HIP(launch_col_fastgen(p->f64, p->nx, W, gx, (long long)p->ny * nzl, fgp,
                               kz0, (int)nzl, p->tw_x, sx, false, timed ? p->ev[5] : nullptr,
-                              rep ? p->rank * p->nxl : 0, rep ? (p->rank + 1) * p->nxl : 1 << 30, p->pot_target));
+                              rep ? p->rank * p->nxl : 0, rep ? (p->rank + 1) * p->nxl : 1 << 30, p->pot_target, p->fixbuf));
   else
     RF_HIP(launch_col_gen(p->f64, p->nx, W, gx, (long long)p->ny * nzl, gp, kspace, kz0, (int)nzl, p->tw_x, sx));
   return 0;
@@ -911,7 +916,7 @@ int rf_plan_destroy(rf_plan* p) {
   if (p->comm_stream) { (void)hipStreamSynchronize(p->comm_stream); (void)hipStreamDestroy(p->comm_stream); }
   for (auto& e : p->pev) if (e) (void)hipEventDestroy(e);
   void* bufs[] = {p->W, p->R, p->W2, p->R2, p->K, p->P_base, p->G, p->tw_x, p->tw_y, p->tw_z, p->kx2, p->ky2, p->kz2, p->xt, p->st, p->sl, p->bin,
-                  p->X, p->lntab, p->ypart, p->noise, p->mt_scratch, p->mt_send, p->mt_recv, p->mt_sbase, p->mt_first, p->mt_pos, p->mt_npos_dev, p->mt_states, p->mt_counts, p->mt_offsets, p->mt_pairs, p->partials, p->stats, p->seeds_dev, p->ztab, p->frec, p->coll_scratch};
+                  p->X, p->lntab, p->ypart, p->noise, p->mt_scratch, p->mt_send, p->mt_recv, p->mt_sbase, p->mt_first, p->mt_pos, p->mt_npos_dev, p->mt_states, p->mt_counts, p->mt_offsets, p->mt_rowtab, p->mt_flags, p->fixbuf, p->partials, p->stats, p->seeds_dev, p->ztab, p->frec, p->coll_scratch};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   for (int i = 0; i < 2; ++i) {
@@ -1722,11 +1727,10 @@ int mt_ensure_buffers(rf_plan* p, const MtGeom& g) {
     p->mt_counts = p->mt_offsets = nullptr;
     RF_HIP(hipMalloc((void**)&p->mt_counts, ((size_t)g.nseg + 1) * sizeof(unsigned long long)));
     RF_HIP(hipMalloc((void**)&p->mt_offsets, ((size_t)g.nseg + 1) * sizeof(unsigned long long)));
-    if (p->mt_pairs) RF_HIP(hipFree(p->mt_pairs));
-    p->mt_pairs = nullptr;
-    RF_HIP(hipMalloc((void**)&p->mt_pairs, 2 * ((size_t)g.nseg + 3) * sizeof(unsigned long long)));     // + sentinel pairs
     p->mt_seg_cap = (size_t)g.nseg + 1;
   }
+  if (!p->mt_rowtab) RF_HIP(hipMalloc(&p->mt_rowtab, (size_t)p->nx * p->ny * sizeof(RowLoc)));
+  if (!p->mt_flags) RF_HIP(hipMalloc((void**)&p->mt_flags, sizeof(int)));
   if (p->mt_scratch_bytes < g.need) {
     if (p->mt_scratch) RF_HIP(hipFree(p->mt_scratch));
     p->mt_scratch = nullptr; p->mt_scratch_bytes = 0;
@@ -1752,9 +1756,13 @@ int mt_queue(rf_plan* p, const MtGeom& g, int single, hipStream_t s) {
   // offsets: 2.5 + 3.3 ms against 3.3 + 1.x ms for fill + move.)  A kz-slab rank replays the WHOLE stream (where a
   // deviate goes depends on every earlier acceptance) and keeps the deviates of its own planes while moving.
   RF_HIP(launch_mt_polar(single != 0, p->mt_states, g.nseg, p->mt_bps, g.total_blocks, p->mt_counts, p->mt_scratch, g.cap, s));
-  RF_HIP(launch_mt_scan(p->mt_counts, p->mt_offsets, g.nseg, s, p->mt_pairs));
+  RF_HIP(launch_mt_scan(p->mt_counts, p->mt_offsets, g.nseg, s));
   // float64 deviates are moved into cell order (and cut to this rank's planes); float32 ones stay in the segments' runs:
   // the generation pass finds cell c through the scan (slack_cell), which saves the 1.7 ms copy per 1024^3
+  if (single) {
+    RF_HIP(hipMemsetAsync(p->mt_flags, 0, sizeof(int), s));
+    RF_HIP(launch_mt_rowtab(p->mt_offsets, g.nseg, p->mt_rowtab, p->nx, p->ny, (int)p->nzc + 1, p->mt_flags, s));
+  }
   if (!single)
     RF_HIP(launch_mt_compact(false, p->mt_scratch, p->mt_counts, p->mt_offsets, g.nseg, g.cap, p->noise, g.ncells, (int)p->nzc + 1,
                              (int)p->nzl + 1, p->kz0, s));
@@ -1774,20 +1782,30 @@ int rf_noise_mt19937_ex(rf_plan* p, const uint32_t* state624, unsigned long long
     if (int rc = ensure_noise(p)) return rc;
   MtGeom g;
   if (int rc = mt_geom(p, single, g)) return rc;
+  // the float32 form locates a row's pairs through a table that allows ONE segment boundary per row: segments (cap attempts,
+  // ~0.785 cap pairs) must be longer than a row by a wide margin, or the float64 form (moved into cell order) serves
+  if (single && g.cap < 4ull * (unsigned long long)(p->nzc + 1)) {
+    single = 0;
+    if (int rc = ensure_noise(p)) return rc;
+    if (int rc = mt_geom(p, single, g)) return rc;
+  }
   if (int rc = mt_ensure_buffers(p, g)) return rc;
   hipStream_t s = p->stream;
   RF_HIP(hipMemcpyAsync(p->mt_states, state624, 624 * sizeof(uint32_t), hipMemcpyHostToDevice, s));
   if (int rc = mt_queue(p, g, single, s)) return rc;
   const int nseg = g.nseg;
-  unsigned long long total = 0, full = 0;
+  unsigned long long total = 0;
+  int flags = 0;
+  p->noise_resident = false;
+  p->noise32_resident = false;
   RF_HIP(hipMemcpyAsync(&total, p->mt_offsets + nseg, sizeof(total), hipMemcpyDeviceToHost, s));
-  RF_HIP(hipMemcpyAsync(&full, p->mt_offsets + (nseg > 1 ? nseg - 1 : 1), sizeof(full), hipMemcpyDeviceToHost, s));
+  if (single) RF_HIP(hipMemcpyAsync(&flags, p->mt_flags, sizeof(flags), hipMemcpyDeviceToHost, s));
   RF_HIP(hipStreamSynchronize(s));
   p->nseg = nseg;
   p->seg_cap = g.cap;
-  p->seg_inv = full > 0 ? (double)(nseg > 1 ? nseg - 1 : 1) / (double)full : 0.0;     // the last segment may be a short one
   if (accepted) *accepted = total;
   RF_REQUIRE(total >= g.ncells, "MT19937 replay: not enough accepted polar attempts (increase the margin)");
+  RF_REQUIRE(!(flags & 1), "MT19937 replay: a segment holds fewer deviate pairs than a row of the grid has cells (segment length too short for the float32 form)");
   p->noise_resident = !single;
   p->noise32_resident = single != 0;
   if (!single) {
@@ -2059,6 +2077,7 @@ int rf_realise_batch_reference(rf_plan* p, const uint32_t* states, int n, double
   RF_HIP(hipSetDevice(p->device));
   MtGeom g;
   if (int rc = mt_geom(p, 1, g)) return rc;
+  RF_REQUIRE(g.cap >= 4ull * (unsigned long long)(p->nzc + 1), "the replay's segments are too short for the float32 form on this grid: loop rf_noise_mt19937 + rf_realise");
   if (int rc = mt_ensure_buffers(p, g)) return rc;
   if (int rc = ensure_x(p)) return rc;
   RF_HIP(hipStreamSynchronize(p->stream));
@@ -2077,11 +2096,13 @@ int rf_realise_batch_reference(rf_plan* p, const uint32_t* states, int n, double
   struct DevTmp {
     void* ptr = nullptr;
     ~DevTmp() { if (ptr) (void)hipFree(ptr); }
-  } dstates_mem, dtotals_mem;
+  } dstates_mem, dtotals_mem, dflags_mem;
   RF_HIP(hipMalloc(&dstates_mem.ptr, (size_t)n * 624 * sizeof(uint32_t)));
   RF_HIP(hipMalloc(&dtotals_mem.ptr, (size_t)n * sizeof(unsigned long long)));
+  RF_HIP(hipMalloc(&dflags_mem.ptr, (size_t)n * sizeof(int)));
   uint32_t* dstates = (uint32_t*)dstates_mem.ptr;
   unsigned long long* dtotals = (unsigned long long*)dtotals_mem.ptr;
+  int* dflags = (int*)dflags_mem.ptr;
   RF_HIP(hipMemcpy(dstates, states, (size_t)n * 624 * sizeof(uint32_t), hipMemcpyHostToDevice));
   hipStream_t S = p->stream, R = p->aux_stream;
   // whatever deviates were resident are about to be overwritten; the plan claims the new ones (and a field) only once every
@@ -2092,15 +2113,13 @@ int rf_realise_batch_reference(rf_plan* p, const uint32_t* states, int n, double
   p->stats_valid = false;
   p->nseg = g.nseg;
   p->seg_cap = g.cap;
-  // first guess of a cell's segment from the EXPECTED acceptances per segment (the exact mean needs a round trip to the host per
-  // seed): binomial drift over all segments is a tenth of a segment, slack_cell corrects +-1
-  p->seg_inv = 1.0 / ((double)g.cap * 0.78539816339744830962);
   // both streams are drained before any return from here on: the temporaries above must not be freed under a running kernel
   auto drain = [&](int rc) { (void)hipStreamSynchronize(R); (void)hipStreamSynchronize(S); return rc; };
   auto replay = [&](int i) -> int {
     RF_HIP(hipMemcpyAsync(p->mt_states, dstates + (size_t)i * 624, 624 * sizeof(uint32_t), hipMemcpyDeviceToDevice, R));
     if (int r = mt_queue(p, g, 1, R)) return r;
     RF_HIP(hipMemcpyAsync(dtotals + i, p->mt_offsets + g.nseg, sizeof(unsigned long long), hipMemcpyDeviceToDevice, R));
+    RF_HIP(hipMemcpyAsync(dflags + i, p->mt_flags, sizeof(int), hipMemcpyDeviceToDevice, R));
     RF_HIP(hipEventRecord(p->bev[0], R));
     return 0;
   };
@@ -2128,6 +2147,7 @@ int rf_realise_batch_reference(rf_plan* p, const uint32_t* states, int n, double
     return 0;
   };
   std::vector<unsigned long long> totals((size_t)n);
+  std::vector<int> flags((size_t)n);
   std::vector<double> st(2 * (size_t)n);
   int rc = issue();
   if (!rc) {
@@ -2135,11 +2155,14 @@ int rf_realise_batch_reference(rf_plan* p, const uint32_t* states, int n, double
     if (e == hipSuccess) e = hipMemcpyAsync(st.data(), p->stats, st.size() * sizeof(double), hipMemcpyDeviceToHost, S);
     if (e == hipSuccess) e = hipStreamSynchronize(S);
     if (e == hipSuccess) e = hipMemcpy(totals.data(), dtotals, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(flags.data(), dflags, (size_t)n * sizeof(int), hipMemcpyDeviceToHost);
     if (e != hipSuccess) rc = fail(2, std::string("rf_realise_batch_reference: ") + hipGetErrorString(e));
   }
   if (!rc)
-    for (int i = 0; i < n && !rc; ++i)
+    for (int i = 0; i < n && !rc; ++i) {
       if (totals[i] < g.ncells) rc = fail(1, "MT19937 replay: not enough accepted polar attempts (increase the margin)");
+      else if (flags[i] & 1) rc = fail(1, "MT19937 replay: a segment holds fewer deviate pairs than a row of the grid has cells");
+    }
   if (rc) {
     p->noise32_resident = false;
     return drain(rc);

@@ -8,6 +8,9 @@
 #ifndef RF_COL2_2048
 #define RF_COL2_2048 1                 // length-2048 float32 passes as two 1024-point transforms per tile (Col2); 0 = the whole-column kernels
 #endif
+#ifndef RF_FIX_MERGED
+#define RF_FIX_MERGED 0                // 1 = the tiles that hold kz = 0 run inside ONE launch of the FIX = 3 kernel over all tiles (a uniform branch: 8 loads
+#endif                                 // from the side buffer); 0 = as a launch of their own in front of the FIX = 0 kernel's (measured: DESIGN.md 3.2)
 #ifndef RF_COL2_F64_1024
 #define RF_COL2_F64_1024 1             // the float64 generation pass of length 1024 as two 512-point transforms per tile (Col2): two workgroups per CU
 #endif
@@ -47,20 +50,29 @@ hipError_t launch_one2(const IO& io_in, long long ncols, const cplx<typename C1:
   return hipGetLastError();
 }
 
+// the side buffer of repaired kz = 0 slots for a FIX = 3 launch: out[iy * nx + ix], one thread per mode (rf_kernels.h fix_fill_kernel)
+template <class IOF, class CT>
+hipError_t launch_fix_fill(const IOF& iof, CT* out, hipStream_t s) {
+  const long long n = (long long)iof.gp.nx * iof.gp.ny;
+  hipLaunchKernelGGL((fix_fill_kernel<IOF, CT>), dim3((unsigned)((n + 255) / 256)), dim3(256), IOF::LDS_EXTRA, s, iof, out, iof.gp.nx, iof.gp.ny);
+  return hipGetLastError();
+}
+
 // fast float32 generation + x pass of length 2 C1::N through Col2 (native generator, whole grid or kz slab; no potential store,
 // no resident deviates, no x-slab restriction: those keep the whole-column kernel)
 template <class C1, class IO0, class IO1>
 hipError_t launch_fast_one2(const FastGenParams& gp, cplx<typename C1::T>* W, ColGeom g, long long ncols, int kz0, int nzl,
-                            const cplx<typename C1::T>* tw2, hipStream_t s, bool po, hipEvent_t after_repair) {
+                            const cplx<typename C1::T>* tw2, hipStream_t s, bool po, hipEvent_t after_repair, cplx<typename C1::T>* fixbuf) {
   if (nzl <= 0 || (nzl & (nzl - 1)) || ncols >= (1LL << 31) || g.needs_wide(C1::LMAX, C1::TC, (int)sizeof(cplx<typename C1::T>)) || !g.rows_ok(C1::N / C1::RL, C1::NPASS))
     return hipErrorInvalidValue;
   IO0 io0; io0.base = W; io0.g = g; io0.gp = gp; io0.kz0 = kz0; io0.nzl = nzl; io0.rec = nullptr; io0.pot = nullptr;
   IO1 io1; io1.base = W; io1.g = g; io1.gp = gp; io1.kz0 = kz0; io1.nzl = nzl; io1.rec = nullptr; io1.pot = nullptr;
   const bool split = nzl > C1::TC && nzl % C1::TC == 0;
   const long long tiles_per_iy = nzl / C1::TC, ntiles = ncols / C1::TC;
-  // the split launch's repair kernel computes the repair values with all lanes (FIX = 2, ColFFT::fix_prepare)
-  using IOC = typename IO1::template with_fix<2>;
-  IOC ioc; ioc.base = W; ioc.g = g; ioc.gp = gp; ioc.kz0 = kz0; ioc.nzl = nzl; ioc.rec = nullptr; ioc.pot = nullptr;
+  // the split launch's repair kernel takes the repaired slots from the side buffer (FIX = 3, filled by fix_fill_kernel just before)
+  using IOC = typename IO1::template with_fix<3>;
+  using IOF = typename IO1::fill_io;
+  IOC ioc; ioc.base = W; ioc.g = g; ioc.gp = gp; ioc.kz0 = kz0; ioc.nzl = nzl; ioc.rec = nullptr; ioc.pot = nullptr; ioc.fixbuf = fixbuf;
   if (po) {
     hipError_t e = launch_one2<C1, IO0>(io0, ncols, tw2, s, true);
     if (e == hipSuccess) e = launch_one2<C1, IOC>(ioc, ncols, tw2, s, true);
@@ -68,7 +80,14 @@ hipError_t launch_fast_one2(const FastGenParams& gp, cplx<typename C1::T>* W, Co
   }
   if (!split) return launch_one2<C1, IO1>(io1, ncols, tw2, s, false);
   if (kz0 != 0) return launch_one2<C1, IO0>(io0, ncols, tw2, s, false);
-  hipError_t e = launch_one2<C1, IOC>(ioc, ncols, tw2, s, false, ncols / nzl, tiles_per_iy, 0);
+  if (!fixbuf) return hipErrorInvalidValue;
+  IOF iof; iof.base = W; iof.g = g; iof.gp = gp; iof.kz0 = kz0; iof.nzl = nzl; iof.rec = nullptr; iof.pot = nullptr;
+  hipError_t e = launch_fix_fill(iof, fixbuf, s);
+  if (RF_FIX_MERGED) {
+    if (e == hipSuccess && after_repair) e = hipEventRecord(after_repair, s);
+    return e != hipSuccess ? e : launch_one2<C1, IOC>(ioc, ncols, tw2, s, false);
+  }
+  if (e == hipSuccess) e = launch_one2<C1, IOC>(ioc, ncols, tw2, s, false, ncols / nzl, tiles_per_iy, 0);
   if (e != hipSuccess || tiles_per_iy >= (1LL << 30) || ntiles >= (1LL << 31)) return e != hipSuccess ? e : hipErrorInvalidValue;
   if (after_repair && (e = hipEventRecord(after_repair, s)) != hipSuccess) return e;
   return launch_one2<C1, IO0>(io0, ncols, tw2, s, false, ntiles - ntiles / tiles_per_iy, 1, 0, (int)tiles_per_iy);
@@ -79,7 +98,7 @@ hipError_t launch_fast_one2(const FastGenParams& gp, cplx<typename C1::T>* W, Co
 // it is needed; every other tile by the kernel WITHOUT it (skip_period = tiles per iy).
 template <class C, class IO0, class IO1, class CT>
 hipError_t launch_fast_one(const FastGenParams& gp, CT* W, ColGeom g, long long ncols, int kz0, int nzl,
-                           const CT* tw, hipStream_t s, bool po, hipEvent_t after_repair, int x0, int x1, CT* pot = nullptr) {
+                           const CT* tw, hipStream_t s, bool po, hipEvent_t after_repair, int x0, int x1, CT* fixbuf, CT* pot = nullptr) {
   // the slab-restricted instantiations test the workgroup-uniform row offset m * L of the last pass: the slab
   // boundaries must be multiples of L = N / (radix of the last pass)
   if (nzl <= 0 || (nzl & (nzl - 1)) || ncols >= (1LL << 31) || g.needs_wide(C::LMAX, C::TC, (int)sizeof(CT))) return hipErrorInvalidValue;   // the IO splits a column index by shift and mask
@@ -90,19 +109,37 @@ hipError_t launch_fast_one(const FastGenParams& gp, CT* W, ColGeom g, long long 
   IO1 io1; io1.base = base; io1.g = g; io1.gp = gp; io1.kz0 = kz0; io1.nzl = nzl; io1.rec = nullptr; io1.x0 = x0; io1.x1 = x1; io1.pot = pot;
   const bool split = nzl > C::TC && nzl % C::TC == 0;
   const long long tiles_per_iy = nzl / C::TC, ntiles = ncols / C::TC;
-  // the split launch's repair kernel of the long passes computes the repair values with all lanes (FIX = 2, ColFFT::fix_prepare)
-  constexpr bool coop = C::N >= 512 && C::NPASS >= 2;
-  using IOC = typename IO1::template with_fix<coop ? 2 : 1>;
+  // the split launch's repair kernel of the long passes takes the repaired slots from the side buffer (FIX = 3); the short passes
+  // (a few tiles, one pass) keep the owning lane's own repair
+  constexpr bool side = C::N >= 512 && C::NPASS >= 2;
+  using IOC = typename IO1::template with_fix<side ? 3 : 1>;
+  using IOF = typename IO1::fill_io;
   IOC ioc; ioc.base = base; ioc.g = g; ioc.gp = gp; ioc.kz0 = kz0; ioc.nzl = nzl; ioc.rec = nullptr; ioc.x0 = x0; ioc.x1 = x1; ioc.pot = pot;
+  if constexpr (side) ioc.fixbuf = fixbuf;
   if (po) {
     hipError_t e = launch_one<C, IO0>(io0, ncols, tw, s, true);
-    if (e == hipSuccess && coop) e = launch_one<C, IOC>(ioc, ncols, tw, s, true);
+    if (e == hipSuccess && side) e = launch_one<C, IOC>(ioc, ncols, tw, s, true);
     return e != hipSuccess ? e : launch_one<C, IO1>(io1, ncols, tw, s, true);
   }
   if (!split) return launch_one<C, IO1>(io1, ncols, tw, s, false);
   if (kz0 != 0) return launch_one<C, IO0>(io0, ncols, tw, s, false);   // only the slab that owns kz = 0 needs the repair
   // first the (few) tiles that hold slot kz = 0, with the repair; then every other tile without it
-  hipError_t e = launch_one<C, IOC>(ioc, ncols, tw, s, false, ncols / nzl, tiles_per_iy, 0);
+  hipError_t e = hipSuccess;
+  if constexpr (side) {
+    if (!fixbuf) return hipErrorInvalidValue;
+    IOF iof; iof.base = base; iof.g = g; iof.gp = gp; iof.kz0 = kz0; iof.nzl = nzl; iof.rec = nullptr; iof.x0 = x0; iof.x1 = x1; iof.pot = pot;
+    e = launch_fix_fill(iof, fixbuf, s);
+    if (RF_FIX_MERGED == 1) {
+      if (e == hipSuccess && after_repair) e = hipEventRecord(after_repair, s);
+      return e != hipSuccess ? e : launch_one<C, IOC>(ioc, ncols, tw, s, false);
+    }
+    if (RF_FIX_MERGED == 2) {        // experiment: the lean kernel over ALL tiles (64 per ky row, no skipping), then the kz = 0 tiles again with the repair
+      if (e == hipSuccess) e = launch_one<C, IO0>(io0, ncols, tw, s, false);
+      if (e == hipSuccess && after_repair) e = hipEventRecord(after_repair, s);
+      return e != hipSuccess ? e : launch_one<C, IOC>(ioc, ncols, tw, s, false, ncols / nzl, tiles_per_iy, 0);
+    }
+  }
+  if (e == hipSuccess) e = launch_one<C, IOC>(ioc, ncols, tw, s, false, ncols / nzl, tiles_per_iy, 0);
   if (e != hipSuccess || tiles_per_iy >= (1LL << 30) || ntiles >= (1LL << 31)) return e != hipSuccess ? e : hipErrorInvalidValue;
   if (after_repair && (e = hipEventRecord(after_repair, s)) != hipSuccess) return e;
   return launch_one<C, IO0>(io0, ncols, tw, s, false, ntiles - ntiles / tiles_per_iy, 1, 0, (int)tiles_per_iy);
@@ -112,5 +149,5 @@ hipError_t launch_fast_one(const FastGenParams& gp, CT* W, ColGeom g, long long 
 
 // the float64 branches of launch_col_fastgen (rf_k_col_gen64.hip)
 hipError_t launch_col_fastgen64(int N, void* W, ColGeom g, long long ncols, const FastGenParams& gp, int kz0, int nzl,
-                                const void* tw, hipStream_t s, bool po, hipEvent_t after_repair, int x0, int x1, void* pot);
+                                const void* tw, hipStream_t s, bool po, hipEvent_t after_repair, int x0, int x1, void* pot, void* fixbuf);
 }  // namespace rf

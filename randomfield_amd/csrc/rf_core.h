@@ -409,6 +409,13 @@ struct FastRec {          // 16 bytes per bin of the uniform acceleration grid i
   float ds;               // slope change at the knot, per bin width
 };                        // sigma(f) = v0 + sa * f + ds * max(f - fs, 0),  f in [0, 1) the position inside the bin
 
+// (where the float32 deviate pairs of one row of the stream live: see make_rowloc / row_pair below)
+struct RowLoc {
+  uint32_t off;                 // in-segment slot of the row's cell kz = 0
+  uint32_t seg_n;               // (seg << 11) | nfirst,  1 <= nfirst <= nz/2 + 1 <= 1025
+};
+enum { ROWLOC_NBITS = 11 };
+
 struct FastGenParams {
   int nx, ny, nz;
   float dkx, dky, dkz;    // k_axis(i) = dk_axis * signed fftfreq index (2 pi / (n spacing)): the kernels form |k|^2
@@ -425,13 +432,12 @@ struct FastGenParams {
   int ppitch;             // row pitch (cells) of the POTENTIAL array: zpitch rounded up to even for float32 plans, so that the
                           // generation pass stores a cell pair (kz even, kz + 1) with one aligned 16-byte store
   // SRC = 2 kernels: the same deviates as float32 pairs (g_re, g_im), read where the one-pass replay left them -- every
-  // MT19937 segment's accepted pairs densely from slot seg * seg_cap of `noise32`, cell c of the stream in the segment
-  // with seg_off[seg] <= c < seg_off[seg + 1] (exclusive scan of the per-segment counts).  No copy into cell order.
+  // MT19937 segment's accepted pairs densely from slot seg * seg_cap of `noise32`.  No copy into cell order: `rowtab` (built from
+  // the scan of the per-segment counts by mt_rowtab_kernel, one 8-byte entry per row (ix, iy) of the stream, index iy * nx + ix so
+  // that the rows of one x-pass tile are neighbours) says where a row's nz/2 + 1 consecutive stream cells start.
   const cplx<float>* noise32;
-  const unsigned long long* seg_off;   // [2 nseg]: (first cell of segment s, first cell of segment s + 1) pairs -- one 16-byte load
-  unsigned long long seg_cap;          // attempts (= slots) per segment
-  double seg_inv;                      // 1 / (accepted pairs of a full segment): first guess of a cell's segment
-  int nseg;
+  const RowLoc* rowtab;
+  unsigned long long seg_cap;          // attempts (= slots) per segment (< 2^32)
   // POT = 2 kernels: the pass emits pscale * delta(k) / k^2 instead of delta(k) -- the saved potential of generate.py:200-217
   // regenerated from the seed (or the resident deviates) when calculate_newtonian_potential asks for it, never stored
   double pscale;          // (float32 plans round it to float32, as the scaled copy of the stored potential does)
@@ -558,16 +564,6 @@ RF_HD cplx<float> fast_fix_kz0(const FastGenParams& g, const FastRec* rec, uint6
 // The same slot from resident deviates (the reference's stream, e.g. replayed MT19937): cell = sigma * (g_re + i g_im)
 // with the float64 product rounded once (random.py:28), symmetrised as above.  SRC = 1: float64 deviates; SRC = 2: the
 // float32 copies (float32 plans: the product is then formed in float32, 6e-8 relative from the once-rounded one).
-struct U64Pair { unsigned long long lo, hi; };
-RF_HD U64Pair v16_load_any(const unsigned long long* p) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  typedef unsigned long long u2 __attribute__((ext_vector_type(2)));
-  const u2 v = *reinterpret_cast<const __attribute__((address_space(1))) u2*>((const __attribute__((address_space(1))) unsigned long long*)p);
-  return U64Pair{v.x, v.y};
-#else
-  return U64Pair{p[0], p[1]};
-#endif
-}
 // one float32 deviate pair through a GLOBAL-address-space pointer: its address comes out of selects, the compiler cannot
 // infer where it points and would emit flat_load -- counted on lgkmcnt too, so that the LDS reads of the sigma lookup
 // would wait for the deviates' trip to HBM
@@ -580,41 +576,51 @@ RF_HD cplx<float> load_pair_global(const cplx<float>* p) {
   return *p;
 #endif
 }
-// Where the pair of stream cell c lives (SRC = 2): the segment is guessed from the mean acceptance count (the counts are
-// binomial: the guess is off by at most one segment) and corrected against the scan; o1 = first cell of the next segment.
-RF_HD const cplx<float>* slack_cell(const FastGenParams& g, unsigned long long c, int& seg, unsigned long long& o1) {
-  int s = (int)(((double)(unsigned)(c >> 32) * 4294967296.0 + (double)(unsigned)c) * g.seg_inv);
-  const int top = g.nseg - 2 > 1 ? g.nseg - 2 : 1;
-  s = s < 1 ? 1 : (s > top ? top : s);
-  // the four boundaries around the guess with two independent 16-byte loads (no load inside a loop in the common case:
-  // the table loads of all the rows of a butterfly go out together): b0 <= b1 <= b2 <= b3 = first cells of s-1 .. s+2
-  // (the table has a sentinel pair behind the last segment)
-  const U64Pair lo = v16_load_any(g.seg_off + 2 * (s - 1)), hi = v16_load_any(g.seg_off + 2 * (s + 1));
-  const unsigned long long b0 = lo.lo, b1 = lo.hi, b2 = hi.lo, b3 = hi.hi;
-  unsigned long long o0;
-  if (c >= b0 && c < b3) {
-    const bool below = c < b1, above = c >= b2;
-    s = s - (below ? 1 : 0) + (above ? 1 : 0);
-    o0 = below ? b0 : (above ? b2 : b1);
-    o1 = below ? b1 : (above ? b3 : b2);
-  } else {            // a guess more than one segment off: never seen (binomial counts), but walk there if it happens
-    U64Pair pr = v16_load_any(g.seg_off + 2 * s);
-    while (c < pr.lo) pr = v16_load_any(g.seg_off + 2 * --s);
-    while (c >= pr.hi) pr = v16_load_any(g.seg_off + 2 * ++s);
-    o0 = pr.lo;
-    o1 = pr.hi;
+// Where the pairs of one row of the stream live (SRC = 2).  Stream cell c = (ix ny + iy) (nz/2 + 1) + kz; the cells of segment s
+// are [first[s], first[s + 1]) (exclusive scan of the per-segment counts) and sit densely from slot s * cap.  A row is nz/2 + 1
+// consecutive cells, far fewer than a segment holds (the builder checks it): its first `nfirst` cells lie in segment `seg` from
+// in-segment slot `off`, the others -- a segment boundary falls inside one row in a few hundred -- at the start of segment seg + 1.
+// entry of the row whose first cell is c.  first: [nseg + 1] with first[nseg] = total accepted pairs.  Rows that reach beyond the
+// total (a failed replay: the host reports it) point at the start of segment 0 -- in bounds, never used.  *bad is set when a row
+// would span more than two segments (segments shorter than a row: the host refuses such a replay geometry).
+RF_HD RowLoc make_rowloc(const unsigned long long* first, int nseg, unsigned long long c, unsigned nzh, int* bad) {
+  RowLoc e;
+  e.off = 0; e.seg_n = nzh;
+  if (c + nzh > first[nseg]) return e;
+  int lo = 0, hi = nseg - 1;
+  while (lo < hi) {                                   // largest s with first[s] <= c
+    const int mid = (lo + hi + 1) >> 1;
+    if (first[mid] <= c) lo = mid; else hi = mid - 1;
   }
-  seg = s;
-  return g.noise32 + (unsigned long long)s * g.seg_cap + (c - o0);
+  const unsigned long long left = first[lo + 1] - c;  // cells of segment lo from c on (>= 1)
+  const unsigned nfirst = left < nzh ? (unsigned)left : nzh;
+  if (nfirst < nzh && first[lo + 2 <= nseg ? lo + 2 : nseg] < c + nzh) *bad = 1;
+  e.off = (uint32_t)(c - first[lo]);
+  e.seg_n = ((uint32_t)lo << ROWLOC_NBITS) | nfirst;
+  return e;
+}
+RF_HD RowLoc load_rowloc(const RowLoc* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef unsigned u2 __attribute__((ext_vector_type(2)));
+  const u2 v = *(const __attribute__((address_space(1))) u2*)p;      // one global_load_dwordx2 (not a flat load: see load_pair_global)
+  RowLoc e; e.off = v.x; e.seg_n = v.y;
+  return e;
+#else
+  return *p;
+#endif
+}
+// address of the pair of cell kz of the row
+RF_HD const cplx<float>* row_pair(const FastGenParams& g, RowLoc e, int kz) {
+  const uint32_t nfirst = e.seg_n & ((1u << ROWLOC_NBITS) - 1u), seg = e.seg_n >> ROWLOC_NBITS, cap = (uint32_t)g.seg_cap;
+  const uint32_t slot = (uint32_t)kz < nfirst ? e.off + (uint32_t)kz : cap + ((uint32_t)kz - nfirst);
+  return g.noise32 + ((unsigned long long)seg * cap + slot);
 }
 
 template <int SRC>
 RF_HD cplx<float> fast_noise_cell(const FastGenParams& g, const FastRec* rec, int ix, int iy, int kz, float k2) {
   if (SRC == 2) {
-    int seg;
-    unsigned long long o1;
     const float s = fast_sigma(g, rec, k2);
-    const cplx<float> d = load_pair_global(slack_cell(g, ((unsigned long long)ix * g.ny + iy) * (unsigned)(g.nz / 2 + 1) + (unsigned)kz, seg, o1));
+    const cplx<float> d = load_pair_global(row_pair(g, load_rowloc(g.rowtab + ((long long)iy * g.nx + ix)), kz));
     return mk<float>(s * d.x, s * d.y);
   }
   const long long c = ((long long)ix * g.ny + iy) * g.zpitch + side_slot(g, kz);

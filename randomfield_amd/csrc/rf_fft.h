@@ -19,6 +19,7 @@
 // Device-internal layout: W[nx][ny][nz/2] complex == [nx][ny][nz]
 // real; slot kz=0 of the complex view carries (kz=0 plane) + i (kz=nz/2 plane).
 #pragma once
+#include <type_traits>
 #include "rf_core.h"
 
 namespace rf {
@@ -341,9 +342,12 @@ template <typename T, bool WIDE = false> struct GenColIO {
 // x pass fused with the fast float32 native generation (one Philox call per lane load)
 // SLAB: 1 = only rows [x0, x1) are stored (replicated-generation mode); a separate instantiation so that the
 // guard costs the ordinary kernel nothing.
-// FIX: 1 = this kernel repairs the kz = 0 slot (rolled loop through LDS); 2 = the same with the repair values computed by all
-// lanes in a phase of their own (ColFFT::fix_prepare: tiles whose first column is the only kz = 0 one); 0 = it does not (the tiles that
-// hold kz = 0 are then re-run by a FIX = 1 / 2 launch).  An out-of-line call was measured 3x slower (scratch).
+// FIX: 1 = this kernel repairs the kz = 0 slot itself (the owning lane, rolled loop through LDS: short passes, and the emulator's
+// reference form); 3 = it takes the repaired slots from a side buffer [ny][nx] that fix_fill_kernel (rf_kernels.h: one thread per
+// mode, every lane busy, the same fix_value() arithmetic) has filled just before -- 8 extra loads per owning lane instead of two
+// Philox calls, Box-Muller pairs and sigma lookups per row in a kernel that then needs 128 - 244 registers and runs its tiles
+// 2.5 - 19x slower than an ordinary one (rounds 1 - 3: FIX = 1, then FIX = 2 = the values computed by all lanes in a phase of
+// their own); 0 = it does not repair (the tiles that hold kz = 0 are run by a FIX = 1 / 3 launch first).
 // POT: 2 = the pass transforms pscale * delta(k) / k^2 instead of delta(k) (the saved potential regenerated on demand: each
 // cell rounded as the stored one and its scaled copy would be); 1 = the pass also stores delta(k) / k^2 (0 at DC) of every generated cell into `pot`, an API-layout array
 // [nx][ny][nz/2+1] -- the save_potential=True branch of generate_delta_field (generate.py:200-217) without ever
@@ -392,7 +396,7 @@ struct FastGenColIOT {
   // Cell pair (kz, kz + 1) of column (ix = rb + ro, iy).  What does not depend on m (= ro / L) is a common
   // subexpression of the R unrolled loads, and what does not depend on the lane runs on the scalar ALU: the
   // Philox counter is (lane part) + (uniform part), two vector adds per load instead of a 64-bit multiply chain.
-  RF_HD V16<float> load(long long C0, int cl, int rb, int ro) const {
+  RF_HD V16<float> load_impl(long long C0, int cl, int rb, int ro, const V16<float>* raw) const {
     V16<float> v;
     const long long C = C0 + cl;
     const uint64_t seed = gp.seed;                                                      // bind_seed() ran first
@@ -419,16 +423,17 @@ struct FastGenColIOT {
       v.c[0] = mk<float>((float)(sa * ga.c[0].x), (float)(sa * ga.c[0].y));
       v.c[1] = mk<float>((float)(sb * gb.c[0].x), (float)(sb * gb.c[0].y));
     } else {
-      // float32 pairs where the one-pass replay left them (rf_core.h slack_cell): cells c and c + 1 of the stream are
-      // neighbours unless a segment ends between them
-      // stream cell c = (scalar part of the row offset m L) + (lane part, the same for all R rows of a butterfly): a 64-bit
-      // multiply chain per lane and row made this pass 0.6 ms slower than the addresses themselves cost
-      const unsigned nzh = (unsigned)(gp.nz / 2 + 1);
-      const unsigned long long c = pin_uniform_ll((unsigned long long)ro * gp.ny * nzh) + (unsigned)((rb * gp.ny + iy) * nzh + kz);
-      int seg;
-      unsigned long long o1;
-      const cplx<float>* d = slack_cell(gp, c, seg, o1);
-      const cplx<float> ga = load_pair_global(d), gb = load_pair_global(c + 1 < o1 ? d + 1 : gp.noise32 + (unsigned long long)(seg + 1) * gp.seg_cap);
+      // float32 pairs where the one-pass replay left them: the row's entry of the row table (rf_core.h RowLoc; index iy nx + ix =
+      // a lane part that is the same for all R rows of a butterfly + the uniform row offset) says where its cells start; cells kz
+      // and kz + 1 are neighbours unless a segment ends between them
+      RowLoc e;
+      if (raw) { e.off = 0; e.seg_n = 0; }
+      else if (AB & 64) { e.off = (uint32_t)(iy * gp.nx + rb + ro); e.seg_n = (uint32_t)(gp.nz / 2 + 1); }      // (ablation builds only)
+      else e = load_rowloc((gp.rowtab + ro) + (uint32_t)(iy * gp.nx + rb));
+      cplx<float> ga, gb;
+      if (raw) { ga = raw->c[0]; gb = raw->c[1]; }                                       // (loaded by preload() at the top of the kernel)
+      else if (AB & 16) { ga = mk<float>((float)e.off, (float)e.seg_n); gb = mk<float>((float)kz, (float)e.off); }
+      else { ga = load_pair_global(row_pair(gp, e, kz)); gb = load_pair_global(row_pair(gp, e, kz + 1)); }
       const float sa = fast_sigma(gp, rec, k2a), sb = fast_sigma(gp, rec, k2b);
       v.c[0] = mk<float>(sa * ga.x, sa * ga.y);
       v.c[1] = mk<float>(sb * gb.x, sb * gb.y);
@@ -452,6 +457,23 @@ struct FastGenColIOT {
     }
     return v;
   }
+#ifndef RF_SRC2_PRELOAD
+#define RF_SRC2_PRELOAD 1
+#endif
+  // SRC = 2: the memory half of load() -- the row's table entry, then its two deviate pairs -- for the kernel to issue before it
+  // stages any table (col_kernel): three dependent round trips (records, row table, pairs) become two that overlap the staging
+  static constexpr bool HAS_PRELOAD = (SRC == 2 && XS == 1 && RF_SRC2_PRELOAD != 0);
+  RF_HD V16<float> preload(long long C0, int cl, int rb, int ro) const {
+    V16<float> v;
+    const long long C = C0 + cl;
+    const int iy = (int)((unsigned)C >> nzl_shift()), kz = kz0 + (int)((unsigned)C & (unsigned)(nzl - 1));
+    const RowLoc e = load_rowloc((gp.rowtab + ro) + (uint32_t)(iy * gp.nx + rb));
+    v.c[0] = load_pair_global(row_pair(gp, e, kz));
+    v.c[1] = load_pair_global(row_pair(gp, e, kz + 1));
+    return v;
+  }
+  RF_HD V16<float> load_pre(long long C0, int cl, int rb, int ro, const V16<float>& raw) const { return load_impl(C0, cl, rb, ro, &raw); }
+  RF_HD V16<float> load(long long C0, int cl, int rb, int ro) const { return load_impl(C0, cl, rb, ro, nullptr); }
   // the lane that owns slot kz = 0 replaces its provisional first cell of every row by the packed,
   // symmetrised (kz=0, kz=nz/2) pair (cold path: one lane in four of one tile in nz/16)
   static constexpr bool ROLLED_LOAD = false;
@@ -459,8 +481,16 @@ struct FastGenColIOT {
   static constexpr bool HAS_FINISH = false;
   static constexpr int FIX_MODE = FIX;
   template <int F2> using with_fix = FastGenColIOT<AB, F2, SLAB, POT, SRC, XS>;
+  using fill_io = FastGenColIOT<AB, 1, SLAB, POT, SRC, 1>;      // the IO whose fix_value() fix_fill_kernel evaluates (mode index = row)
+  const cplx<float>* fixbuf = nullptr;                          // FIX = 3: [ny][nx] repaired slots kz = 0, left by fix_fill_kernel
   RF_HD bool needs_fix(long long C) const { return FIX != 0 && kz0 + (int)((unsigned)C & (unsigned)(nzl - 1)) == 0; }
+  // FIX = 3: the repaired slot of mode (XS (rb + ro) + xp, iy) from the side buffer (lane part + uniform part, as load())
+  RF_HD cplx<float> fix_load(long long C, int rb, int ro) const {
+    const int iy = (int)((unsigned)C >> nzl_shift());
+    return load_pair_global((fixbuf + (XS * ro + (XS == 2 ? xp : 0))) + (uint32_t)(iy * gp.nx + XS * rb));
+  }
   RF_HD cplx<float> fix_value(long long C, int rb, int ro) const {
+    if (FIX == 3) return fix_load(C, rb, ro);
     const uint64_t seed = gp.seed;                                                      // bind_seed() ran first
     const int iy = (int)((unsigned)C >> nzl_shift());
     cplx<float> p0, pn;
@@ -480,6 +510,7 @@ struct FastGenColIOT {
   RF_HD void store(long long C0, int cl, int rb, int ro, const V16<float>& v) const {
     // x0, x1 are multiples of the last pass's row stride L (the launcher checks it) and rb < L: the test is uniform
     if (SLAB && (ro < x0 || ro >= x1)) return;
+    if ((AB & 32) && v.c[0].x != 12345.678f) return;                                    // (ablation builds only: no stores)
     v16_store<float>(g.at<false>(base, C0, cl, rb, ro), v);
   }
 };
@@ -541,8 +572,15 @@ struct FastGenColIO64 {
   static constexpr bool HAS_FINISH = false;
   static constexpr int FIX_MODE = FIX;
   template <int F2> using with_fix = FastGenColIO64<F2, SLAB, POT, XS>;
+  using fill_io = FastGenColIO64<1, SLAB, POT, 1>;
+  const cplx<double>* fixbuf = nullptr;                         // FIX = 3: see FastGenColIOT
   RF_HD bool needs_fix(long long C) const { return FIX != 0 && kz0 + (int)((unsigned)C & (unsigned)(nzl - 1)) == 0; }
+  RF_HD cplx<double> fix_load(long long C, int rb, int ro) const {
+    const int iy = (int)((unsigned)C >> nzl_shift());
+    return v16_load<double>((fixbuf + (XS * ro + (XS == 2 ? xp : 0))) + (uint32_t)(iy * gp.nx + XS * rb)).c[0];
+  }
   RF_HD cplx<double> fix_value(long long C, int rb, int ro) const {
+    if (FIX == 3) return fix_load(C, rb, ro);
     const uint64_t seed = gp.seed;                                                      // bind_seed() ran first
     cplx<float> p0, pn;
     const int iy = (int)((unsigned)C >> nzl_shift());
@@ -563,6 +601,11 @@ struct FastGenColIO64 {
     v16_store<double>(g.at<false>(base, C0, cl, rb, ro), v);
   }
 };
+
+// Does the IO split its load into an early memory part and a late arithmetic part (preload() / load_pre())?  Only the deviate-reading
+// generation pass does: its loads are issued at the very top of the kernel, in front of the table staging and its barrier.
+template <class IO, class = void> struct io_has_preload { static constexpr bool value = false; };
+template <class IO> struct io_has_preload<IO, typename std::enable_if<IO::HAS_PRELOAD>::type> { static constexpr bool value = true; };
 
 // ---------------------------------------------------------------------------
 // Column FFT phases.  `tw` = exp(+2 pi i q / N), q in [0, N).
@@ -611,30 +654,30 @@ struct ColFFT {
     io.prologue(tid, C::NT, lds_io(lds));
   }
 
-  // FIX_MODE == 2 (tiles whose first column is the only one with kz = 0: kz runs of whole tiles): the Hermitian repair values of
-  // that column, computed by ALL the lanes of a butterfly's lane group -- the R rows dealt to its LPR lanes -- and parked in the
-  // owning lane's LDS output slots.  In pass_first itself (FIX_MODE == 1) the owning lane alone evaluates all R of them while
-  // the other three quarters of its wave idle: two extra Philox calls, Box-Muller pairs and sigma lookups per row, 2.5x the time
-  // of an ordinary tile.  The caller tests needs_fix(tile's first column) -- uniform -- and puts a barrier behind this.
-  RF_HD static void fix_prepare(int tid, long long tile, const IO& io, cx* lds) {
-    constexpr int R = C::R1, L = N / R, RPL = (R + LPR - 1) / LPR;
-    const int lp = tid % LPR, jl = tid / LPR;
-    const long long C0 = tile * C::TC;
+  // the early memory half of pass 1 for IOs that split their load (io_has_preload): what preload() returns, kept in registers
+  static constexpr bool PRELOAD = io_has_preload<IO>::value;
+  struct PreRegs { V v[PRELOAD ? C::IT1 : 1][PRELOAD ? C::R1 : 1]; };
+  RF_HD static void preload(int tid, long long tile, const IO& io, PreRegs& pre) {
+    if constexpr (PRELOAD) {
+      constexpr int R = C::R1, L = N / R;
+      const int lp = tid % LPR, jl = tid / LPR;
+      const long long C0 = tile * C::TC;
 #pragma unroll
-    for (int it = 0; it < C::IT1; ++it) {
-      const int j = it * BPI + jl;
-      if (j < L) {
-#pragma unroll 1
-        for (int q = 0; q < RPL; ++q) {
-          const int m = lp * RPL + q;
-          if (m < R) lds_at(lds, j * R + m, 0)->c[0] = io.fix_value(C0, j, m * L);
+      for (int it = 0; it < C::IT1; ++it) {
+        const int j = it * BPI + jl;
+        if (j < L) {
+#pragma unroll
+          for (int m = 0; m < R; ++m) pre.v[it][m] = io.preload(C0, lp * CPL, j, m * L);
         }
       }
     }
   }
-
-  // pass 1: global -> R1 butterfly -> LDS (or straight back to global when N == R1)
   RF_HD static void pass_first(int tid, long long tile, const IO& io, cx* lds) {
+    PreRegs none;
+    pass_first(tid, tile, io, lds, none, false);
+  }
+  // pass 1: global -> R1 butterfly -> LDS (or straight back to global when N == R1)
+  RF_HD static void pass_first(int tid, long long tile, const IO& io, cx* lds, const PreRegs& pre, bool have_pre) {
     constexpr int R = C::R1, L = N / R;
     const int lp = tid % LPR, jl = tid / LPR;
     const long long C0 = tile * C::TC;                       // workgroup-uniform
@@ -645,6 +688,7 @@ struct ColFFT {
       const int j = it * BPI + jl;
       if (j < L) {
         cx v[CPL][R];
+        constexpr bool PRE = (IO::FIX_MODE == 3);
         if (IO::ROLLED_LOAD && C::NPASS > 1) {
 #pragma unroll 1
           for (int m = 0; m < R; ++m) *lds_at(lds, j * R + m, lp) = io.load(C0, cl, j, m * L);
@@ -657,17 +701,21 @@ struct ColFFT {
         } else {
 #pragma unroll
           for (int m = 0; m < R; ++m) {
-            V x = io.load(C0, cl, j, m * L);
+            V x;
+            if constexpr (PRELOAD) x = have_pre ? io.load_pre(C0, cl, j, m * L, pre.v[it][m]) : io.load(C0, cl, j, m * L);
+            else x = io.load(C0, cl, j, m * L);
 #pragma unroll
             for (int c = 0; c < CPL; ++c) v[c][m] = x.c[c];
             IO::sched_fence(m);
           }
         }
-        if (IO::FIX_MODE == 2 && C::NPASS > 1) {
-          // parked in this lane's own, still unused LDS output slots by fix_prepare() (a barrier ago)
+        if (PRE) {
+          // FIX_MODE == 3: the owning lane (one in LPR, of one tile in nz / 16) replaces its first cell of every row by the repaired
+          // slot from the side buffer -- straight into the butterfly's registers, behind the generation: holding the eight values
+          // across it costs sixteen more registers than the kernels have (28 - 256 bytes of scratch per thread when tried)
           if (io.needs_fix(Ccol)) {
 #pragma unroll
-            for (int m = 0; m < R; ++m) v[0][m] = lds_at(lds, j * R + m, lp)->c[0];
+            for (int m = 0; m < R; ++m) v[0][m] = io.fix_value(Ccol, j, m * L);
           }
         } else if (IO::FIX_MODE != 0 && io.needs_fix(Ccol)) {
           if (C::NPASS == 1) {

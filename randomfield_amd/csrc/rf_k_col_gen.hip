@@ -31,15 +31,15 @@ hipError_t launch_t(int N, cplx<T>* W, ColGeom g, long long ncols, const GenPara
 }  // namespace
 
 hipError_t launch_col_fastgen(int f64, int N, void* W, ColGeom g, long long ncols, const FastGenParams& gp, int kz0, int nzl,
-                              const void* tw, hipStream_t s, bool po, hipEvent_t after_repair, int x0, int x1, void* pot) {
+                              const void* tw, hipStream_t s, bool po, hipEvent_t after_repair, int x0, int x1, void* pot, void* fixbuf) {
   if (!col_fastgen_supported(f64, N)) return po ? hipSuccess : hipErrorInvalidValue;    // the caller keeps the exact kernel
-  if (f64) return launch_col_fastgen64(N, W, g, ncols, gp, kz0, nzl, tw, s, po, after_repair, x0, x1, pot);
+  if (f64) return launch_col_fastgen64(N, W, g, ncols, gp, kz0, nzl, tw, s, po, after_repair, x0, x1, pot, fixbuf);
   const bool slab = x0 > 0 || x1 < N;          // replicated-generation mode: the SLAB instantiations guard their stores
   if (gp.emit_potential || po) {               // POT = 2: the pass transforms pscale * delta(k) / k^2 (rf_realise_scaled_potential)
     if (gp.emit_potential && (slab || pot || gp.noise)) return hipErrorInvalidValue;
     if (gp.noise32 || po)                      // ... of the replayed deviates (float32 pairs in the replay's runs)
       switch (N) {
-#define X(NN) case NN: { hipError_t e = launch_fast_one<typename GenSel<float, NN>::type, FastGenColIOT<0, 0, 0, 2, 2>, FastGenColIOT<0, 1, 0, 2, 2>, cplx<float>>(gp, (cplx<float>*)W, g, ncols, kz0, nzl, (const cplx<float>*)tw, s, po, after_repair, x0, x1); if (!po || e != hipSuccess) return e; break; }
+#define X(NN) case NN: { hipError_t e = launch_fast_one<typename GenSel<float, NN>::type, FastGenColIOT<0, 0, 0, 2, 2>, FastGenColIOT<0, 1, 0, 2, 2>, cplx<float>>(gp, (cplx<float>*)W, g, ncols, kz0, nzl, (const cplx<float>*)tw, s, po, after_repair, x0, x1, (cplx<float>*)fixbuf); if (!po || e != hipSuccess) return e; break; }
         RF_COL_SIZES(X)
 #undef X
         default: return hipErrorInvalidValue;
@@ -47,11 +47,11 @@ hipError_t launch_col_fastgen(int f64, int N, void* W, ColGeom g, long long ncol
     if (RF_COL2_2048 && N == 2048) {
       using C1 = GenSel<float, 1024>::type;
       hipError_t e = launch_fast_one2<C1, FastGenColIOT<0, 0, 0, 2, 0, 2>, FastGenColIOT<0, 1, 0, 2, 0, 2>>(
-          gp, (cplx<float>*)W, g, ncols, kz0, nzl, (const cplx<float>*)tw, s, po, after_repair);
+          gp, (cplx<float>*)W, g, ncols, kz0, nzl, (const cplx<float>*)tw, s, po, after_repair, (cplx<float>*)fixbuf);
       if (!po || e != hipSuccess) return e;
     }
     switch (N) {
-#define X(NN) case NN: { hipError_t e = launch_fast_one<typename GenSel<float, NN>::type, FastGenColIOT<0, 0, 0, 2>, FastGenColIOT<0, 1, 0, 2>, cplx<float>>(gp, (cplx<float>*)W, g, ncols, kz0, nzl, (const cplx<float>*)tw, s, po, after_repair, x0, x1); if (!po || e != hipSuccess) return e; break; }
+#define X(NN) case NN: { hipError_t e = launch_fast_one<typename GenSel<float, NN>::type, FastGenColIOT<0, 0, 0, 2>, FastGenColIOT<0, 1, 0, 2>, cplx<float>>(gp, (cplx<float>*)W, g, ncols, kz0, nzl, (const cplx<float>*)tw, s, po, after_repair, x0, x1, (cplx<float>*)fixbuf); if (!po || e != hipSuccess) return e; break; }
       RF_COL_SIZES(X)
 #undef X
       default: return hipErrorInvalidValue;
@@ -60,24 +60,27 @@ hipError_t launch_col_fastgen(int f64, int N, void* W, ColGeom g, long long ncol
   if (gp.noise || po) {                        // resident float64 deviates (rng='reference') through the fast float32 sigma path
     if (gp.noise && (slab || pot)) return hipErrorInvalidValue;
     switch (N) {
-#define X(NN) case NN: { hipError_t e = launch_fast_one<typename GenSel<float, NN>::type, FastGenColIOT<0, 0, 0, 0, 1>, FastGenColIOT<0, 1, 0, 0, 1>, cplx<float>>(gp, (cplx<float>*)W, g, ncols, kz0, nzl, (const cplx<float>*)tw, s, po, after_repair, x0, x1); if (!po || e != hipSuccess) return e; break; }
+#define X(NN) case NN: { hipError_t e = launch_fast_one<typename GenSel<float, NN>::type, FastGenColIOT<0, 0, 0, 0, 1>, FastGenColIOT<0, 1, 0, 0, 1>, cplx<float>>(gp, (cplx<float>*)W, g, ncols, kz0, nzl, (const cplx<float>*)tw, s, po, after_repair, x0, x1, (cplx<float>*)fixbuf); if (!po || e != hipSuccess) return e; break; }
       RF_COL_SIZES(X)
 #undef X
       default: return hipErrorInvalidValue;
     }
   }
+#ifndef RF_SRC2_AB
+#define RF_SRC2_AB 0                   // ablation mask of the deviate-reading kernel (16: no pair loads, 32: no stores, 64: no table loads); 0 in the product
+#endif
   if (gp.noise32 || po) {                      // resident float32 deviates, without / with the potential store
     if (gp.noise32 && slab) return hipErrorInvalidValue;
     if (!pot || po)
       switch (N) {
-#define X(NN) case NN: { hipError_t e = launch_fast_one<typename GenSel<float, NN>::type, FastGenColIOT<0, 0, 0, 0, 2>, FastGenColIOT<0, 1, 0, 0, 2>, cplx<float>>(gp, (cplx<float>*)W, g, ncols, kz0, nzl, (const cplx<float>*)tw, s, po, after_repair, x0, x1); if (!po || e != hipSuccess) return e; break; }
+#define X(NN) case NN: { hipError_t e = launch_fast_one<typename GenSel<float, NN>::type, FastGenColIOT<RF_SRC2_AB, 0, 0, 0, 2>, FastGenColIOT<RF_SRC2_AB, 1, 0, 0, 2>, cplx<float>>(gp, (cplx<float>*)W, g, ncols, kz0, nzl, (const cplx<float>*)tw, s, po, after_repair, x0, x1, (cplx<float>*)fixbuf); if (!po || e != hipSuccess) return e; break; }
         RF_COL_SIZES(X)
 #undef X
         default: return hipErrorInvalidValue;
       }
     if (pot || po)
       switch (N) {
-#define X(NN) case NN: { hipError_t e = launch_fast_one<typename GenSel<float, NN>::type, FastGenColIOT<0, 0, 0, 1, 2>, FastGenColIOT<0, 1, 0, 1, 2>, cplx<float>>(gp, (cplx<float>*)W, g, ncols, kz0, nzl, (const cplx<float>*)tw, s, po, after_repair, x0, x1, (cplx<float>*)pot); if (!po || e != hipSuccess) return e; break; }
+#define X(NN) case NN: { hipError_t e = launch_fast_one<typename GenSel<float, NN>::type, FastGenColIOT<0, 0, 0, 1, 2>, FastGenColIOT<0, 1, 0, 1, 2>, cplx<float>>(gp, (cplx<float>*)W, g, ncols, kz0, nzl, (const cplx<float>*)tw, s, po, after_repair, x0, x1, (cplx<float>*)fixbuf, (cplx<float>*)pot); if (!po || e != hipSuccess) return e; break; }
         RF_COL_SIZES(X)
 #undef X
         default: return hipErrorInvalidValue;
@@ -86,7 +89,7 @@ hipError_t launch_col_fastgen(int f64, int N, void* W, ColGeom g, long long ncol
   if (pot || po) {                             // generation + potential store (save_potential=True), whole grid
     if (slab && pot) return hipErrorInvalidValue;
     switch (N) {
-#define X(NN) case NN: { hipError_t e = launch_fast_one<typename GenSel<float, NN>::type, FastGenColIOT<0, 0, 0, 1>, FastGenColIOT<0, 1, 0, 1>, cplx<float>>(gp, (cplx<float>*)W, g, ncols, kz0, nzl, (const cplx<float>*)tw, s, po, after_repair, x0, x1, (cplx<float>*)pot); if (!po || e != hipSuccess) return e; break; }
+#define X(NN) case NN: { hipError_t e = launch_fast_one<typename GenSel<float, NN>::type, FastGenColIOT<0, 0, 0, 1>, FastGenColIOT<0, 1, 0, 1>, cplx<float>>(gp, (cplx<float>*)W, g, ncols, kz0, nzl, (const cplx<float>*)tw, s, po, after_repair, x0, x1, (cplx<float>*)fixbuf, (cplx<float>*)pot); if (!po || e != hipSuccess) return e; break; }
       RF_COL_SIZES(X)
 #undef X
       default: return hipErrorInvalidValue;
@@ -94,7 +97,7 @@ hipError_t launch_col_fastgen(int f64, int N, void* W, ColGeom g, long long ncol
   }
   if (slab || po) {
     switch (N) {
-#define X(NN) case NN: { hipError_t e = launch_fast_one<typename GenSel<float, NN>::type, FastGenColIOT<0, 0, 1>, FastGenColIOT<0, 1, 1>, cplx<float>>(gp, (cplx<float>*)W, g, ncols, kz0, nzl, (const cplx<float>*)tw, s, po, after_repair, x0, x1); if (!po || e != hipSuccess) return e; break; }
+#define X(NN) case NN: { hipError_t e = launch_fast_one<typename GenSel<float, NN>::type, FastGenColIOT<0, 0, 1>, FastGenColIOT<0, 1, 1>, cplx<float>>(gp, (cplx<float>*)W, g, ncols, kz0, nzl, (const cplx<float>*)tw, s, po, after_repair, x0, x1, (cplx<float>*)fixbuf); if (!po || e != hipSuccess) return e; break; }
       RF_COL_SIZES(X)
 #undef X
       default: return hipErrorInvalidValue;
@@ -106,11 +109,11 @@ hipError_t launch_col_fastgen(int f64, int N, void* W, ColGeom g, long long ncol
   if (RF_COL2_2048 && N == 2048 && (!slab || po)) {
     using C1 = GenSel<float, 1024>::type;
     hipError_t e = launch_fast_one2<C1, FastGenColIOT<RF_GEN_AB, 0, 0, 0, 0, 2>, FastGenColIOT<RF_GEN_AB, 1, 0, 0, 0, 2>>(
-        gp, (cplx<float>*)W, g, ncols, kz0, nzl, (const cplx<float>*)tw, s, po, after_repair);
+        gp, (cplx<float>*)W, g, ncols, kz0, nzl, (const cplx<float>*)tw, s, po, after_repair, (cplx<float>*)fixbuf);
     if (!po || e != hipSuccess) return e;
   }
   switch (N) {
-#define X(NN) case NN: return launch_fast_one<typename GenSel<float, NN>::type, FastGenColIOT<RF_GEN_AB, 0, 0>, FastGenColIOT<RF_GEN_AB, 1, 0>, cplx<float>>(gp, (cplx<float>*)W, g, ncols, kz0, nzl, (const cplx<float>*)tw, s, po, after_repair, x0, x1);
+#define X(NN) case NN: return launch_fast_one<typename GenSel<float, NN>::type, FastGenColIOT<RF_GEN_AB, 0, 0>, FastGenColIOT<RF_GEN_AB, 1, 0>, cplx<float>>(gp, (cplx<float>*)W, g, ncols, kz0, nzl, (const cplx<float>*)tw, s, po, after_repair, x0, x1, (cplx<float>*)fixbuf);
     RF_COL_SIZES(X)
 #undef X
     default: return hipErrorInvalidValue;

@@ -5,7 +5,7 @@
 namespace rf {
 
 hipError_t launch_col_fastgen64(int N, void* W, ColGeom g, long long ncols, const FastGenParams& gp, int kz0, int nzl,
-                                const void* tw, hipStream_t s, bool po, hipEvent_t after_repair, int x0, int x1, void* pot) {
+                                const void* tw, hipStream_t s, bool po, hipEvent_t after_repair, int x0, int x1, void* pot, void* fixbuf) {
   if (!col_fastgen_supported(1, N)) return po ? hipSuccess : hipErrorInvalidValue;
   const bool slab = x0 > 0 || x1 < N;          // replicated-generation mode: the SLAB instantiations guard their stores
   if (gp.noise || (gp.noise32 && !po)) return hipErrorInvalidValue;     // resident deviates: the exact kernel serves float64 plans
@@ -14,11 +14,11 @@ hipError_t launch_col_fastgen64(int N, void* W, ColGeom g, long long ncols, cons
     if (RF_COL2_F64_1024 && N == 1024) {
       using C1 = GenSel<double, 512>::type;
       hipError_t e = launch_fast_one2<C1, FastGenColIO64<0, 0, 2, 2>, FastGenColIO64<1, 0, 2, 2>>(
-          gp, (cplx<double>*)W, g, ncols, kz0, nzl, (const cplx<double>*)tw, s, po, after_repair);
+          gp, (cplx<double>*)W, g, ncols, kz0, nzl, (const cplx<double>*)tw, s, po, after_repair, (cplx<double>*)fixbuf);
       if (!po || e != hipSuccess) return e;
     }
     switch (N) {
-#define X(NN) case NN: { if (!col_fastgen_supported(1, NN)) { if (po) break; return hipErrorInvalidValue; } hipError_t e = launch_fast_one<typename GenSel<double, NN>::type, FastGenColIO64<0, 0, 2>, FastGenColIO64<1, 0, 2>, cplx<double>>(gp, (cplx<double>*)W, g, ncols, kz0, nzl, (const cplx<double>*)tw, s, po, after_repair, x0, x1); if (!po || e != hipSuccess) return e; break; }
+#define X(NN) case NN: { if (!col_fastgen_supported(1, NN)) { if (po) break; return hipErrorInvalidValue; } hipError_t e = launch_fast_one<typename GenSel<double, NN>::type, FastGenColIO64<0, 0, 2>, FastGenColIO64<1, 0, 2>, cplx<double>>(gp, (cplx<double>*)W, g, ncols, kz0, nzl, (const cplx<double>*)tw, s, po, after_repair, x0, x1, (cplx<double>*)fixbuf); if (!po || e != hipSuccess) return e; break; }
       RF_COL_SIZES(X)
 #undef X
       default: return hipErrorInvalidValue;
@@ -27,7 +27,7 @@ hipError_t launch_col_fastgen64(int N, void* W, ColGeom g, long long ncols, cons
   if (pot || po) {                             // the second store stream: delta(k) / k^2, values widened
     if (slab && pot) return hipErrorInvalidValue;
     switch (N) {
-#define X(NN) case NN: { if (!col_fastgen_supported(1, NN)) { if (po) break; return hipErrorInvalidValue; } hipError_t e = launch_fast_one<typename GenSel<double, NN>::type, FastGenColIO64<0, 0, 1>, FastGenColIO64<1, 0, 1>, cplx<double>>(gp, (cplx<double>*)W, g, ncols, kz0, nzl, (const cplx<double>*)tw, s, po, after_repair, x0, x1, (cplx<double>*)pot); if (!po || e != hipSuccess) return e; break; }
+#define X(NN) case NN: { if (!col_fastgen_supported(1, NN)) { if (po) break; return hipErrorInvalidValue; } hipError_t e = launch_fast_one<typename GenSel<double, NN>::type, FastGenColIO64<0, 0, 1>, FastGenColIO64<1, 0, 1>, cplx<double>>(gp, (cplx<double>*)W, g, ncols, kz0, nzl, (const cplx<double>*)tw, s, po, after_repair, x0, x1, (cplx<double>*)fixbuf, (cplx<double>*)pot); if (!po || e != hipSuccess) return e; break; }
       RF_COL_SIZES(X)
 #undef X
       default: return hipErrorInvalidValue;
@@ -36,19 +36,19 @@ hipError_t launch_col_fastgen64(int N, void* W, ColGeom g, long long ncols, cons
   if (RF_COL2_F64_1024 && N == 1024 && (!slab || po)) {
     using C1 = GenSel<double, 512>::type;
     hipError_t e = launch_fast_one2<C1, FastGenColIO64<0, 0, 0, 2>, FastGenColIO64<1, 0, 0, 2>>(
-        gp, (cplx<double>*)W, g, ncols, kz0, nzl, (const cplx<double>*)tw, s, po, after_repair);
+        gp, (cplx<double>*)W, g, ncols, kz0, nzl, (const cplx<double>*)tw, s, po, after_repair, (cplx<double>*)fixbuf);
     if (!po || e != hipSuccess) return e;
   }
   if (slab || po) {
     switch (N) {
-#define X(NN) case NN: { if (!col_fastgen_supported(1, NN)) { if (po) break; return hipErrorInvalidValue; } hipError_t e = launch_fast_one<typename GenSel<double, NN>::type, FastGenColIO64<0, 1>, FastGenColIO64<1, 1>, cplx<double>>(gp, (cplx<double>*)W, g, ncols, kz0, nzl, (const cplx<double>*)tw, s, po, after_repair, x0, x1); if (!po || e != hipSuccess) return e; break; }
+#define X(NN) case NN: { if (!col_fastgen_supported(1, NN)) { if (po) break; return hipErrorInvalidValue; } hipError_t e = launch_fast_one<typename GenSel<double, NN>::type, FastGenColIO64<0, 1>, FastGenColIO64<1, 1>, cplx<double>>(gp, (cplx<double>*)W, g, ncols, kz0, nzl, (const cplx<double>*)tw, s, po, after_repair, x0, x1, (cplx<double>*)fixbuf); if (!po || e != hipSuccess) return e; break; }
       RF_COL_SIZES(X)
 #undef X
       default: return hipErrorInvalidValue;
     }
   }
   switch (N) {
-#define X(NN) case NN: { if (!col_fastgen_supported(1, NN)) return po ? hipSuccess : hipErrorInvalidValue; return launch_fast_one<typename GenSel<double, NN>::type, FastGenColIO64<0, 0>, FastGenColIO64<1, 0>, cplx<double>>(gp, (cplx<double>*)W, g, ncols, kz0, nzl, (const cplx<double>*)tw, s, po, after_repair, x0, x1); }
+#define X(NN) case NN: { if (!col_fastgen_supported(1, NN)) return po ? hipSuccess : hipErrorInvalidValue; return launch_fast_one<typename GenSel<double, NN>::type, FastGenColIO64<0, 0>, FastGenColIO64<1, 0>, cplx<double>>(gp, (cplx<double>*)W, g, ncols, kz0, nzl, (const cplx<double>*)tw, s, po, after_repair, x0, x1, (cplx<double>*)fixbuf); }
     RF_COL_SIZES(X)
 #undef X
     default: return hipErrorInvalidValue;

@@ -12,7 +12,7 @@
 //   2. mt_polar_kernel: every segment (1024 blocks of 624 outputs, one WAVE each) generates its outputs ONCE, writes the
 //      deviates of its accepted attempts densely into its own run of a scratch array and counts them;
 //   3. an exclusive scan of the counts gives each run the index of its first cell; float64 runs are moved into cell order
-//      by mt_compact_kernel, float32 runs are read in place by the generation pass (rf_core.h slack_cell).
+//      by mt_compact_kernel, float32 runs are read in place by the generation pass through a row table (mt_rowtab_kernel, rf_core.h RowLoc).
 #include <hip/hip_runtime.h>
 #include "rf_launch.h"
 #include "rf_core.h"
@@ -243,8 +243,7 @@ __global__ __launch_bounds__(256) void mt_polar_kernel(const uint32_t* __restric
 }
 
 // exclusive scan of the per-segment counts by ONE wave: lane l owns a contiguous chunk, wave scan across lanes
-__global__ __launch_bounds__(64) void mt_scan_kernel(const unsigned long long* __restrict__ counts, unsigned long long* __restrict__ offsets, int n,
-                                                    unsigned long long* __restrict__ pairs) {
+__global__ __launch_bounds__(64) void mt_scan_kernel(const unsigned long long* __restrict__ counts, unsigned long long* __restrict__ offsets, int n) {
   const int lane = threadIdx.x;
   const int per = (n + 63) / 64, lo = lane * per, hi = lo + per < n ? lo + per : n;
   unsigned long long sum = 0;
@@ -258,13 +257,22 @@ __global__ __launch_bounds__(64) void mt_scan_kernel(const unsigned long long* _
   unsigned long long run = inc - sum;
   for (int i = lo; i < hi; ++i) {
     offsets[i] = run;
-    if (pairs) { pairs[2 * i] = run; pairs[2 * i + 1] = run + counts[i]; }     // (first cell, first cell of the next segment)
     run += counts[i];
   }
-  if (lane == 63) {
-    offsets[n] = inc;                                  // total number of accepted attempts
-    if (pairs) pairs[2 * n] = pairs[2 * n + 1] = pairs[2 * n + 2] = pairs[2 * n + 3] = inc;   // two sentinel pairs (slack_cell)
-  }
+  if (lane == 63) offsets[n] = inc;                    // total number of accepted attempts
+}
+
+// The row table of the float32 form (rf_core.h RowLoc): the generation pass reads the pairs where the segments left them, and
+// entry iy * nx + ix says where the nz/2 + 1 cells of row (ix, iy) start.  One thread per row, a binary search in the scan (32 KB at
+// 1024^3: L2-resident).  flags[0] |= 1 when a row spans more than two segments (segments shorter than a row).
+__global__ __launch_bounds__(256) void mt_rowtab_kernel(const unsigned long long* __restrict__ offsets, int nseg, RowLoc* __restrict__ tab,
+                                                        int nx, int ny, int nzh, int* __restrict__ flags) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long long)nx * ny) return;
+  const int iy = (int)(e / nx), ix = (int)(e - (long long)iy * nx);
+  int bad = 0;
+  tab[e] = make_rowloc(offsets, nseg, ((unsigned long long)ix * ny + iy) * (unsigned)nzh, (unsigned)nzh, &bad);
+  if (bad) atomicOr(flags, 1);
 }
 
 // pairs [0, counts[seg]) of segment seg's scratch run -> cells offsets[seg] + i of the stream (cells >= ncells are
@@ -370,8 +378,15 @@ hipError_t launch_mt_polar(bool single, const uint32_t* states, int nseg, int bl
   else hipLaunchKernelGGL(mt_polar_kernel<false>, dim3(grid), dim3(256), 0, s, states, blocks_per_segment, total_blocks, nseg, counts, (double*)runs, cap);
   return hipGetLastError();
 }
-hipError_t launch_mt_scan(const unsigned long long* counts, unsigned long long* offsets, int n, hipStream_t s, unsigned long long* pairs) {
-  hipLaunchKernelGGL(mt_scan_kernel, dim3(1), dim3(64), 0, s, counts, offsets, n, pairs);
+hipError_t launch_mt_scan(const unsigned long long* counts, unsigned long long* offsets, int n, hipStream_t s) {
+  hipLaunchKernelGGL(mt_scan_kernel, dim3(1), dim3(64), 0, s, counts, offsets, n);
+  return hipGetLastError();
+}
+
+hipError_t launch_mt_rowtab(const unsigned long long* offsets, int nseg, void* tab, int nx, int ny, int nzh, int* flags, hipStream_t s) {
+  if (nseg < 1 || nzh >= (1 << ROWLOC_NBITS) || nseg >= (1 << (32 - ROWLOC_NBITS))) return hipErrorInvalidValue;
+  const long long n = (long long)nx * ny;
+  hipLaunchKernelGGL(mt_rowtab_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, offsets, nseg, (RowLoc*)tab, nx, ny, nzh, flags);
   return hipGetLastError();
 }
 

@@ -41,15 +41,14 @@ __global__ __launch_bounds__(C::NT, (col_min_waves<C, IO>())) void col_kernel(IO
   const cx* ltw = tw;
   io.bind_seed();
   typename F::TwRegs twr;
+  typename F::PreRegs pre;
+  F::preload(tid, tile, io, pre);                     // (IOs that read memory in pass 1 AND stage tables: their loads go out first)
   if (IO::LDS_EXTRA > 0) {
     io.prologue(tid, C::NT, F::lds_io(lds));          // the IO's tables -> LDS: pass 1 reads them
     __syncthreads();
   }
   if (C::NPASS >= 2) F::tw_fetch(tid, tw, twr);       // twiddles global -> registers: issued here, landed under pass 1
-  if (IO::FIX_MODE == 2 && C::NPASS >= 2) {           // the kz = 0 column's repair values, by every lane (uniform branch)
-    if (io.needs_fix(tile * C::TC)) { F::fix_prepare(tid, tile, io, lds); __syncthreads(); }
-  }
-  F::pass_first(tid, tile, io, lds);
+  F::pass_first(tid, tile, io, lds, pre, true);
   if (C::NPASS >= 2) {
     F::tw_stage(tid, lds, twr);                       // -> LDS, in front of the barrier that precedes their first use
     ltw = F::lds_tw(lds);
@@ -74,11 +73,31 @@ __global__ __launch_bounds__(C::NT, (col_min_waves<C, IO>())) void col_kernel(IO
   }
 }
 
+// The repaired slots kz = 0 of every mode (ix, iy) -- (plane kz = 0) + i (plane kz = nz/2), each Hermitian-symmetrised
+// (transform.py:141-158; rf_core.h fast_fix_kz0) -- into the side buffer out[iy * nx + ix] that the FIX = 3 launch of the generation
+// pass reads.  IOF = the pass's IO with FIX = 1 and rows = modes (fill_io): the SAME fix_value() the pass itself would evaluate,
+// including the potential's two planes when POT = 1 -- but by one thread per mode, all lanes busy, in a kernel of its own
+// (nx ny threads: 10 - 40 us; the repair inside the pass cost 0.05 ms per 1024^3 realisation and 0.25 ms on rank 0 of 2048^3 / 8).
+template <class IOF, class CT>
+__global__ __launch_bounds__(256) void fix_fill_kernel(IOF io, CT* __restrict__ out, int nx, int ny) {
+  extern __shared__ __attribute__((aligned(16))) char rf_smem[];
+  io.bind_seed();
+  if (IOF::LDS_EXTRA > 0) {
+    io.prologue(threadIdx.x, 256, rf_smem);            // the sigma records -> LDS
+    __syncthreads();
+  }
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long long)nx * ny) return;
+  const int iy = (int)(e / nx), ix = (int)(e - (long long)iy * nx);
+  out[e] = io.fix_value((long long)iy * io.nzl, ix, 0);
+}
+
 // strided pass of length 2 C1::N as two C1 transforms per tile + a radix-2 step in registers (rf_fft.h Col2)
-// (the kernel WITH the kz = 0 repair needs ~260 registers with the parked half: it runs few tiles, so it gets the budget of two
-// waves per SIMD -- one workgroup per CU -- instead of spilling 336 bytes per thread)
+// (a kernel that computes the kz = 0 repair itself -- FIX = 1 -- needs ~260 registers with the parked half: it gets the budget of
+// two waves per SIMD instead of spilling 336 bytes per thread; the product's repair launch reads the repaired slots from a side
+// buffer -- FIX = 3 -- and keeps the ordinary budget)
 template <class C1, int DIR, class IO>
-__global__ __launch_bounds__(C1::NT, (IO::FIX_MODE != 0 ? 2 : col_min_waves<C1, IO>())) void col2_kernel(IO io, const cplx<typename C1::T>* __restrict__ tw2,
+__global__ __launch_bounds__(C1::NT, (IO::FIX_MODE == 1 ? 2 : col_min_waves<C1, IO>())) void col2_kernel(IO io, const cplx<typename C1::T>* __restrict__ tw2,
                                                                              long long ntiles, long long tile_mul,
                                                                              long long tile_add, int skip_period) {
   using X = Col2<C1, DIR, IO>;
@@ -110,9 +129,6 @@ __global__ __launch_bounds__(C1::NT, (IO::FIX_MODE != 0 ? 2 : col_min_waves<C1, 
     // registers, and spills (248 bytes of scratch per thread, 2.8x slower on MI355X)
     int t = tid;
     asm volatile("" : "+v"(t));
-    if (IO::FIX_MODE == 2) {
-      if (io.needs_fix(tile * C1::TC)) { F::fix_prepare(t, tile, io, lds); __syncthreads(); }
-    }
     F::pass_first(t, tile, io, lds);
     if (phase == 0) F::tw_stage(tid, lds, twr);
     if (C1::NPASS == 3) {

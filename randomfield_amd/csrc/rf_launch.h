@@ -60,7 +60,9 @@ bool col_replicate_supported(int f64, int N, int nranks);   // can the x pass of
 // the default keeps every row.
 hipError_t launch_col_fastgen(int f64, int N, void* W, ColGeom g, long long ncols, const FastGenParams& gp, int kz0, int nzl,
                               const void* tw, hipStream_t s, bool prepare_only = false, hipEvent_t after_repair = nullptr,
-                              int x0 = 0, int x1 = 1 << 30, void* pot = nullptr);
+                              int x0 = 0, int x1 = 1 << 30, void* pot = nullptr, void* fixbuf = nullptr);
+// (fixbuf: nx * ny complex of the plan's dtype -- the side buffer of repaired kz = 0 slots the pass fills and reads when it runs the
+// kz = 0 tiles as a launch of their own: rf_kernels.h fix_fill_kernel; required for N >= 512 on the rank that owns kz = 0)
 // (pot != nullptr, float32 only: the pass also stores delta(k) / k^2 into the API-layout array `pot` -- generate.py:200-217)
 bool col_plain_addressable(int f64, int N, ColGeom g);   // false: the pass would need 64-bit lane offsets and has none (N < 1024)
 int col_tile_cols(int f64, int N);   // tile width (columns) of the strided pass of length N, 0 if unsupported
@@ -135,9 +137,10 @@ hipError_t launch_mt_compact(bool single, const void* scratch, const unsigned lo
                              hipStream_t s);
 // (single: `noise` is an array of float32 pairs instead of float64 pairs)
 // (nzh = nz/2 + 1 cells per row of the stream; zpitch / zoff: the noise buffer's rows, see GenParams)
-// (pairs, optional: [2 n] = (offsets[i], offsets[i + 1]) -- what the generation pass loads with one 16-byte access)
-hipError_t launch_mt_scan(const unsigned long long* counts, unsigned long long* offsets, int n, hipStream_t s,
-                          unsigned long long* pairs = nullptr);
+hipError_t launch_mt_scan(const unsigned long long* counts, unsigned long long* offsets, int n, hipStream_t s);
+// float32 form: the row table the generation pass locates its pairs with (rf_core.h RowLoc; tab: nx * ny entries of 8 bytes, index
+// iy * nx + ix; offsets: the scan, nseg + 1 entries; flags[0] |= 1 if a row would span more than two segments)
+hipError_t launch_mt_rowtab(const unsigned long long* offsets, int nseg, void* tab, int nx, int ny, int nzh, int* flags, hipStream_t s);
 // distributed replay: pack the local segments' pairs by destination rank / widen a received float32 stream into the resident deviates
 hipError_t launch_mt_share_pack(bool single, const void* scratch, const unsigned long long* counts, const unsigned long long* first_cell,
                                 int nseg, unsigned long long cap, void* send, unsigned long long ncells, int nzh, int nzl, int nranks,

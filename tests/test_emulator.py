@@ -280,34 +280,48 @@ def test_generic_c2r_reproduces_reference_fields(name):
     assert abs(np.sqrt(s2 / n - (s1 / n) ** 2) - float(g["rms"])) <= 10 * tol * float(g["rms"])
 
 
-def test_slack_cell_lookup_of_resident_float32_deviates():
-    """rng='reference' on complex64 plans: the generation pass locates the pair of stream cell c in the replay's per-segment
-    runs (rf_core.h slack_cell: guess the segment from the mean count, correct against the scan).  Against
-    numpy.searchsorted, with a good guess, a deliberately bad one, a short last segment and a single segment."""
+def test_row_table_of_resident_float32_deviates():
+    """rng='reference' on complex64 plans: the generation pass reads the deviate pairs where the replay's segments left them.  A
+    table with one entry per row (ix, iy) of the stream (rf_core.h make_rowloc, built on the device by mt_rowtab_kernel) says
+    where the row's nz/2 + 1 consecutive cells start: `nfirst` of them in segment `seg` from slot `off`, the rest at the start of
+    the next segment.  Against numpy.searchsorted cell by cell: rows inside a segment, rows cut by a boundary at every
+    position, a short last segment, a single segment; rows beyond the stream point somewhere harmless; segments shorter than a
+    row are flagged."""
     import ctypes
     lib = emu_util.lib()
     rng = np.random.RandomState(4)
     u64p = ctypes.POINTER(ctypes.c_ulonglong)
-    for nseg, mean, last in ((4300, 125463, 30000), (7, 1000, 1000), (1, 500, 500), (2, 3, 1)):
+    for nseg, mean, last, nzh in ((4300, 125463, 30000, 513), (7, 3000, 2500, 1025), (1, 5000, 5000, 33), (3, 700, 650, 129)):
         counts = rng.binomial(int(mean / 0.7854) + 1, 0.7854, size=nseg).astype(np.uint64)
         counts[-1] = last
-        off = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64)
-        pairs = np.stack([off[:-1], off[1:]], axis=1).reshape(-1)
-        pairs = np.ascontiguousarray(np.concatenate([pairs, [off[-1]] * 4]).astype(np.uint64))     # + two sentinel pairs
+        first = np.ascontiguousarray(np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64))
         cap = int(mean / 0.7854) + 8
-        total = int(off[-1])
-        cells = np.unique(np.concatenate([rng.randint(0, total, size=2000), off[:-1], off[1:] - 1])).astype(np.uint64)
-        cells = np.ascontiguousarray(cells[cells < total])
-        want_seg = np.searchsorted(off, cells, side="right") - 1
-        want = want_seg.astype(np.uint64) * np.uint64(cap) + (cells - off[want_seg])
-        full = float(off[nseg - 1]) / (nseg - 1) if nseg > 1 else float(total)
-        for inv in (1.0 / full, 0.7 / full, 1.6 / full):          # the library's guess, and two bad ones
-            out = np.zeros(len(cells), np.uint64)
-            seg = np.zeros(len(cells), np.int32)
-            lib.emu_slack_lookup(pairs.ctypes.data_as(u64p), nseg, ctypes.c_ulonglong(cap), ctypes.c_double(inv),
-                                 cells.ctypes.data_as(u64p), len(cells), out.ctypes.data_as(u64p),
-                                 seg.ctypes.data_as(ctypes.POINTER(ctypes.c_int)))
-            assert np.array_equal(seg, want_seg) and np.array_equal(out, want)
+        total = int(first[-1])
+        nrows = total // nzh
+        # rows whose cells straddle every segment boundary, plus random ones, plus the first and the last whole row
+        near = np.concatenate([np.arange(int(b) // nzh - 1, int(b) // nzh + 2) for b in first[1:-1]]) if nseg > 1 else np.array([], np.int64)
+        rows = np.unique(np.concatenate([rng.randint(0, nrows, size=300), near, [0, nrows - 1]]))
+        rows = rows[(rows >= 0) & (rows < nrows)]
+        starts = np.ascontiguousarray((rows * nzh).astype(np.uint64))
+        out = np.zeros(len(rows) * nzh, np.uint64)
+        bad = lib.emu_row_lookup(first.ctypes.data_as(u64p), nseg, ctypes.c_ulonglong(cap), nzh, starts.ctypes.data_as(u64p), len(rows),
+                                 out.ctypes.data_as(u64p))
+        assert bad == 0
+        cells = (starts[:, None] + np.arange(nzh, dtype=np.uint64)[None, :]).reshape(-1)
+        seg = np.searchsorted(first, cells, side="right") - 1
+        want = seg.astype(np.uint64) * np.uint64(cap) + (cells - first[seg])
+        assert np.array_equal(out, want)
+        assert nseg == 1 or len(np.unique(seg.reshape(len(rows), nzh).max(1) - seg.reshape(len(rows), nzh).min(1))) == 2   # both kinds of row were tested
+        # a row that reaches beyond the last accepted pair (a failed replay: the host reports it): in bounds, at the start of the runs
+        beyond = np.array([total - nzh + 1], np.uint64)
+        o2 = np.zeros(nzh, np.uint64)
+        lib.emu_row_lookup(first.ctypes.data_as(u64p), nseg, ctypes.c_ulonglong(cap), nzh, beyond.ctypes.data_as(u64p), 1, o2.ctypes.data_as(u64p))
+        assert np.array_equal(o2, np.arange(nzh, dtype=np.uint64))
+    # segments shorter than a row: flagged (the library then keeps the float64 form, or refuses)
+    first = np.ascontiguousarray(np.array([0, 40, 70, 130, 400], np.uint64))
+    out = np.zeros(100, np.uint64)
+    starts = np.array([0], np.uint64)
+    assert lib.emu_row_lookup(first.ctypes.data_as(u64p), 4, ctypes.c_ulonglong(300), 100, starts.ctypes.data_as(u64p), 1, out.ctypes.data_as(u64p)) == 1
 
 
 @pytest.mark.parametrize("shape,dtype", [((64, 64, 64), np.complex64), ((128, 64, 64), np.complex64), ((64, 128, 128), np.complex64),
