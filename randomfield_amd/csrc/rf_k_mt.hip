@@ -203,6 +203,7 @@ __global__ __launch_bounds__(256) void mt_polar_kernel(const uint32_t* __restric
       const int a = 64 * it + lane;
       bool acc = false;
       double x1 = 0, x2 = 0, r2 = 0;
+      float g0 = 0, g1 = 0;                                    // F32: (f x2, f x1) of an accepted attempt
       if (a < MT_N / 4) {
         // the attempt's four words with ONE 16-byte LDS read (four 4-byte reads at a lane stride of 16 bytes are
         // 4-way bank conflicts); the compiler barrier keeps it behind the volatile in-place regeneration above,
@@ -210,26 +211,57 @@ __global__ __launch_bounds__(256) void mt_polar_kernel(const uint32_t* __restric
         asm volatile("" ::: "memory");
         typedef unsigned u4 __attribute__((ext_vector_type(4)));
         const u4 raw = *reinterpret_cast<const u4*>(const_cast<const uint32_t*>(lds[wave]) + 4 * a);
-        const uint32_t w0 = mt_temper(raw.x), w1 = mt_temper(raw.y);
-        const uint32_t w2 = mt_temper(raw.z), w3 = mt_temper(raw.w);
+        const uint32_t w0 = mt_temper(raw.x), w2 = mt_temper(raw.z);
         // numpy: u = (a 2^26 + b) / 2^53 with a = w >> 5, b = w' >> 6, then x = 2 u - 1.  Every step of that is exact in
         // float64 (53-bit integers, powers of two, |x| < 1 with 52 fractional bits), so x = a 2^-26 + (b 2^-52 - 1) in
         // two fused multiply-adds is the same number
-        x1 = fma((double)(w0 >> 5), 0x1p-26, fma((double)(w1 >> 6), 0x1p-52, -1.0));
-        x2 = fma((double)(w2 >> 5), 0x1p-26, fma((double)(w3 >> 6), 0x1p-52, -1.0));
-        r2 = sum_of_squares(x1, x2);                          // no FMA: numpy's C code rounds both products
-        acc = (r2 < 1.0) && (r2 != 0.0);
+        bool exact = true;
+        if (F32) {
+          // float32 form, fast path.  x = (2 a + 1 - 2^27) 2^-27 + (b 2^-25 - 1) 2^-27: the second term is uniform in
+          // [-2^-27, 2^-27) -- below the float32 rounding of x wherever |x| > 1/16 -- and has ZERO MEAN, so it is left out: one
+          // conversion of an odd 28-bit integer, no bias (dropping the always-positive b 2^-52 instead shifts every deviate by
+          // -2^-27, and 10^8 of those add up coherently at the field's origin: 6e-5 of the rms at 512^3), and the second word of
+          // each uniform is not even tempered here.  r2 = x1^2 + x2^2 is then good to ~2e-7.  Whether the attempt is accepted
+          // (0 < r2 < 1 IN FLOAT64, numpy's rounding: it decides which cell every later deviate belongs to) is certain unless r2
+          // lies within 1e-6 of 1 or underflows; and f = sqrt(-2 ln r2 / r2) keeps the float32 accuracy of its inputs unless
+          // ln r2 -> 0.  Both exceptions are the band r2 > 1 - 2^-8 (0.3 % of the attempts): those lanes, and the ones with
+          // r2 < 2^-9, take the float64 path below, which costs the wave its ~60 float64-rate instructions and the other two
+          // temperings only in the iterations where some lane needs it (one in four) instead of always.
+          const float x1f = (float)((int)((w0 >> 4) | 1u) - (1 << 27)) * 0x1p-27f;
+          const float x2f = (float)((int)((w2 >> 4) | 1u) - (1 << 27)) * 0x1p-27f;
+          const float r2f = fmaf(x1f, x1f, x2f * x2f);
+          // (below r2 = 2^-9 -- the 5-sigma deviates -- the left-out +-2^-27 would be more than 2.4e-7 of x: float64 path too)
+          exact = !(r2f <= 0.99609375f && r2f >= 0.001953125f) && r2f < 1.000001f;      // (beyond 1 + 1e-6: rejected for certain)
+          if (!exact) {
+            acc = r2f < 1.0f;
+            const float inv = __builtin_amdgcn_rcpf(r2f);
+            const float f = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(r2f) * inv);      // -2 ln 2 log2 r2 / r2
+            g0 = f * x2f;
+            g1 = f * x1f;
+          }
+        }
+        if (exact) {
+          const uint32_t w1 = mt_temper(raw.y), w3 = mt_temper(raw.w);
+          x1 = fma((double)(w0 >> 5), 0x1p-26, fma((double)(w1 >> 6), 0x1p-52, -1.0));
+          x2 = fma((double)(w2 >> 5), 0x1p-26, fma((double)(w3 >> 6), 0x1p-52, -1.0));
+          r2 = sum_of_squares(x1, x2);                          // no FMA: numpy's C code rounds both products
+          acc = (r2 < 1.0) && (r2 != 0.0);
+          if (F32 && acc) {
+            // log(r2) = log(r2f) + (r2 - r2f) / r2f: the hardware log2 (1 ulp of its result, also where it -> 0) of the
+            // rounded argument, plus the first-order term of the rounding (exact difference in float64)
+            const float r2f = (float)r2, inv = __builtin_amdgcn_rcpf(r2f);
+            const float lg = fmaf(__builtin_amdgcn_logf(r2f), 0.69314718056f, (float)(r2 - (double)r2f) * inv);
+            const float f = __builtin_amdgcn_sqrtf(-2.0f * lg * inv);
+            g0 = f * (float)x2;
+            g1 = f * (float)x1;
+          }
+        }
       }
       const unsigned long long ball = __ballot(acc);
       if (acc) {
         const unsigned long long dst = running + (unsigned long long)__popcll(ball & ((1ull << lane) - 1ull));
         if (F32) {
-          // log(r2) = log(r2f) + (r2 - r2f) / r2f: the hardware log2 (1 ulp of its result, also where it -> 0) of the
-          // rounded argument, plus the first-order term of the rounding (exact difference in float64)
-          const float r2f = (float)r2, inv = __builtin_amdgcn_rcpf(r2f);
-          const float lg = fmaf(__builtin_amdgcn_logf(r2f), 0.69314718056f, (float)(r2 - (double)r2f) * inv);
-          const float f = __builtin_amdgcn_sqrtf(-2.0f * lg * inv);
-          reinterpret_cast<float2*>(runs)[dst] = make_float2(f * (float)x2, f * (float)x1);
+          reinterpret_cast<float2*>(runs)[dst] = make_float2(g0, g1);
         } else {
           const double f = sqrt(-2.0 * log(r2) / r2);
           runs[2 * dst] = f * x2;                             // legacy_gauss returns f*x2 first, then the saved f*x1

@@ -1457,8 +1457,16 @@ def test_shared_reference_stream_small(hip, dpower, nranks, single):
         assert len(set(acc)) == 1 and acc[0] >= nx * ny * (nz // 2 + 1)
         parts = [p.download_noise().reshape(p.k_shape + (2,)) for p in plans]
         got = _slab_side_array(plans, lambda p: parts[plans.index(p)], nz // 2)
-        err = np.max(np.abs(got.reshape(-1) - noise) / np.maximum(np.abs(noise), 1e-300))
-        assert err <= (3e-7 if single else 1e-14)
+        # float64 transport: numpy's values to the last bits.  float32 form: every deviate in ITS cell, to 3e-7 of its value or
+        # 2e-6 absolute -- the replay's fast path (rf_k_mt.hip) works on float32 x1, x2 between r2 = 2^-9 and 1 - 2^-8: the
+        # rounding of r2 = x1^2 + x2^2 (1e-7 absolute, zero mean) is 1e-7 / (1 - r2) of ln r2 there, i.e. up to 1.5e-6 on the
+        # SMALL deviates |g| < 0.13 that come from r2 > 0.99; deviates of order one and the tails keep float32 accuracy
+        dev = np.abs(got.reshape(-1) - noise)
+        if single:
+            assert np.max(dev - 3e-7 * np.abs(noise)) <= 2e-6 and np.sqrt(np.mean(dev ** 2)) <= 2e-7
+            assert np.max((dev / np.maximum(np.abs(noise), 1e-30))[np.abs(noise) > 0.5]) <= 1e-6
+        else:
+            assert np.max(dev / np.maximum(np.abs(noise), 1e-300)) <= 1e-14
         for q in parts[1:]:                                             # every rank carries the Nyquist plane
             assert np.array_equal(q[:, :, -1], parts[0][:, :, -1])
         field = _slab_run(hip, plans, noise="resident")
@@ -1493,7 +1501,7 @@ def test_shared_reference_stream_equals_replicated_replay(hip, dpower, shape, dt
         hip.DevicePlan.reference_noise_shared_local(plans, seed, single=True)
         for p, w in zip(plans, want):
             g = p.download_noise()
-            assert np.array_equal(g, g.astype(np.float32)) and np.max(np.abs(g - w) / np.maximum(np.abs(w), 1e-30)) <= 3e-7
+            assert np.array_equal(g, g.astype(np.float32)) and np.max(np.abs(g - w) - 3e-7 * np.abs(w)) <= 2e-6      # (see test_shared_reference_stream_small)
         field = _slab_run(hip, plans, noise="resident")
         assert np.max(np.abs(field - ref)) <= 3e-6 * rms
     for p in plans:
