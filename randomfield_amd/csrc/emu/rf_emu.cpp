@@ -159,7 +159,7 @@ void run_row_c2r(const IO& io, long long nrows, const cplx<typename C::T>* tw, d
     }
     if (C::NPASS >= 2)
       for (int t = 0; t < C::NT; ++t) F::pass_last(t, tile, nrows, io, ltw, lds.data(), regs[t]);
-    for (int t = 0; t < C::NT; ++t) { a1 += regs[t].s1; a2 += regs[t].s2; }
+    for (int t = 0; t < C::NT; ++t) { a1 += regs[t].mom.sum(); a2 += regs[t].mom.sumsq(); }
   }
   *s1 = a1; *s2 = a2;
 }

@@ -623,6 +623,18 @@ struct ColFFT {
     return reinterpret_cast<V*>(lds + (long long)C::prow(row) * C::TC) + lp;
   }
   RF_HD static cx* lds_col(cx* lds, int row, int t) { return lds + (long long)C::prow(row) * C::TC + t; }
+  // The swizzle row ^ ((row / R1) & 1) flips bit 0 of the row by a bit that, in every pass, depends on the THREAD (or on the unrolled
+  // index m alone) but not on both: the R accesses of a butterfly are then (one of two per-thread bases) + (a compile-time multiple
+  // of the row pitch), i.e. ONE or TWO address registers and immediate offsets on the ds_ instructions.  Written out, because the
+  // compiler does not distribute the XOR over the sum: it spent ~100 of the generation kernel's 1300 vector instructions (lshl_add,
+  // xad, or) on one full address per access.  Conditions (all shipped 3-pass configurations meet them; the generic form otherwise):
+  //   rows j + m L (middle-pass reads, last-pass reads): L a multiple of 2 R1  ->  bit = (j / R1) & 1
+  //   rows j R1 + m (first-pass writes):                                          bit = j & 1, row = j R1 + (m ^ bit)
+  //   rows ob + m R1, ob = (j / R1) R1 R + j % R1 (middle-pass writes), R even:   bit = m & 1, row = (ob ^ bit) + m R1
+  static constexpr bool FOLD_FIRST = C::NPASS >= 2;
+  static constexpr bool FOLD_MIDR = C::NPASS == 3 && (N / cmax(C::R2, 1)) % (2 * C::R1) == 0;
+  static constexpr bool FOLD_MIDW = C::NPASS == 3 && C::R2 % 2 == 0;
+  static constexpr bool FOLD_LAST = C::NPASS >= 2 && (N / C::RL) % (2 * C::R1) == 0;
 
   // LDS carve: [tile][twiddles][IO tables]
   RF_HD static cx* lds_tw(cx* lds) { return lds + C::TILE_BYTES / (int)sizeof(cx); }
@@ -732,12 +744,17 @@ struct ColFFT {
         }
 #pragma unroll
         for (int c = 0; c < CPL; ++c) DFT<R, DIR>::run(v[c]);
+        // (rows j R + m of the swizzled image: row j R + (m ^ (j & 1)) -- two bases, immediate offsets)
+        const int sw1 = j & 1;
+        V* const w_even = reinterpret_cast<V*>(lds + (long long)(j * R + sw1) * C::TC) + lp;
+        V* const w_odd = reinterpret_cast<V*>(lds + (long long)(j * R - sw1) * C::TC) + lp;
 #pragma unroll
         for (int m = 0; m < R; ++m) {
           V x;
 #pragma unroll
           for (int c = 0; c < CPL; ++c) x.c[c] = v[c][m];
           if (C::NPASS == 1) io.store(C0, cl, j * R, m, x);
+          else if (FOLD_FIRST) ((m & 1) ? w_odd : w_even)[m * LPR] = x;
           else *lds_at(lds, j * R + m, lp) = x;
         }
       }
@@ -753,9 +770,10 @@ struct ColFFT {
     for (int it = 0; it < C::IT2; ++it) {
       const int j = it * C::BPM + jl;
       if (j < L) {
+        const cx* const rd = lds + (long long)(j ^ ((j / C::R1) & 1)) * C::TC + t;      // FOLD_MIDR: row (j ^ bit) + m L
 #pragma unroll
         for (int m = 0; m < R; ++m) {
-          cx x = *lds_col(lds, j + m * L, t);
+          cx x = FOLD_MIDR ? rd[(long long)m * L * C::TC] : *lds_col(lds, j + m * L, t);
           if (m > 0) x = cmul(x, tw_dir<DIR>(tw[stockham_tw_index(j, m, Ns, R, N)]));
           r.v[it][m] = x;
         }
@@ -771,8 +789,13 @@ struct ColFFT {
       const int j = it * C::BPM + jl;
       if (j < L) {
         const int ob = stockham_out_base(j, Ns, R);
+        cx* const w0 = lds + (long long)ob * C::TC + t;                               // FOLD_MIDW: row (ob ^ (m & 1)) + m Ns
+        cx* const w1 = lds + (long long)(ob ^ 1) * C::TC + t;
 #pragma unroll
-        for (int m = 0; m < R; ++m) *lds_col(lds, ob + m * Ns, t) = r.v[it][m];
+        for (int m = 0; m < R; ++m) {
+          if (FOLD_MIDW) ((m & 1) ? w1 : w0)[(long long)m * Ns * C::TC] = r.v[it][m];
+          else *lds_col(lds, ob + m * Ns, t) = r.v[it][m];
+        }
       }
     }
   }
@@ -782,9 +805,10 @@ struct ColFFT {
   RF_HD static void last_butterfly(int j, int lp, const cx* tw, cx* lds, V* out) {
     constexpr int R = C::RL, L = N / R;  // Ns == L, out_base(j) == j, twiddle index == m*j
     cx v[CPL][R];
+    const V* const rd = reinterpret_cast<const V*>(lds + (long long)(j ^ ((j / C::R1) & 1)) * C::TC) + lp;     // FOLD_LAST: row (j ^ bit) + m L
 #pragma unroll
     for (int m = 0; m < R; ++m) {
-      V x = *lds_at(lds, j + m * L, lp);
+      V x = FOLD_LAST ? rd[m * L * LPR] : *lds_at(lds, j + m * L, lp);
       if (m > 0) {
         const cx w = tw_dir<DIR>(tw[m * j]);
 #pragma unroll
@@ -974,6 +998,25 @@ template <typename T> RF_HD void stream_store(cplx<T>* p, cplx<T> z) {
   *p = z;
 }
 
+// Per-thread (sum, sum of squares) of the values a thread stores in the z pass.  float32 fields: FOUR float32 accumulators (the real and
+// the imaginary slot of a complex store each have their own pair: 16 values per accumulator at nz = 1024), widened once at the end --
+// the float64 form cost 8 float64-rate instructions per stored complex, a fifth of the pass's vector work, and the pass is not purely
+// HBM-bound (it gained 10 % from cheaper arithmetic alone).  Rounding: 16 fused adds of like-signed squares per accumulator (<= 1e-6
+// relative, unbiased), then 10^7 such partial sums added in float64: the field's rms to ~1e-9.  float64 fields accumulate in float64.
+template <typename T> struct MomAcc;
+template <> struct MomAcc<float> {
+  float a1 = 0, b1 = 0, a2 = 0, b2 = 0;
+  RF_HD void add(cplx<float> z) { a1 += z.x; b1 += z.y; a2 = fmaf(z.x, z.x, a2); b2 = fmaf(z.y, z.y, b2); }
+  RF_HD double sum() const { return (double)a1 + (double)b1; }
+  RF_HD double sumsq() const { return (double)a2 + (double)b2; }
+};
+template <> struct MomAcc<double> {
+  double s1 = 0, s2 = 0;
+  RF_HD void add(cplx<double> z) { s1 += z.x + z.y; s2 += z.x * z.x + z.y * z.y; }
+  RF_HD double sum() const { return s1; }
+  RF_HD double sumsq() const { return s2; }
+};
+
 template <typename T> struct PlainRowIO {
   cplx<T>* base;
   T scale;                       // 1 / (nx ny nz)
@@ -981,14 +1024,13 @@ template <typename T> struct PlainRowIO {
   // (tile, row of the tile, lane's element, uniform element offset): the split lets a gathering IO keep its address arithmetic
   // on the scalar unit; here it is just row = tile * NRT + rl, element = kb + ko
   template <int NRT> RF_HD cplx<T> load2(long long tile, int rl, int kb, int ko) const { return load(tile * NRT + rl, kb + ko); }
-  template <int NRT> RF_HD void store2(long long tile, int rl, int nb, int no, cplx<T> z, double& s1, double& s2) const { store(tile * NRT + rl, nb + no, z, s1, s2); }
+  template <int NRT> RF_HD void store2(long long tile, int rl, int nb, int no, cplx<T> z, MomAcc<T>& mom) const { store(tile * NRT + rl, nb + no, z, mom); }
   RF_HD int gather_seg_shift() const { return -1; }
   RF_HD cplx<T> load(long long row, int k) const { return stream_load(base + row * (long long)M_of + k); }
-  RF_HD void store(long long row, int n, cplx<T> z, double& s1, double& s2) const {
+  RF_HD void store(long long row, int n, cplx<T> z, MomAcc<T>& mom) const {
     z.x *= scale; z.y *= scale;
     stream_store(base + row * (long long)M_of + n, z);
-    s1 += (double)z.x + (double)z.y;
-    s2 += (double)z.x * (double)z.x + (double)z.y * (double)z.y;
+    mom.add(z);
   }
 };
 
@@ -1013,23 +1055,21 @@ template <typename T> struct GatherRowIO {
     const int kl = kb + (ko & mask);                       // (< nzl whenever nzl >= the pass's L: the block index is uniform then)
     return stream_load(ub + ((long long)(kl >> sh) * seg_stride + (long long)(rl * nzl + (kl & mask))));
   }
-  template <int NRT> RF_HD void store2(long long tile, int rl, int nb, int no, cplx<T> z, double& s1, double& s2) const {
+  template <int NRT> RF_HD void store2(long long tile, int rl, int nb, int no, cplx<T> z, MomAcc<T>& mom) const {
     cplx<T>* ub = dst + tile * (long long)(NRT * M_of) + no;
     z.x *= scale; z.y *= scale;
     stream_store(reinterpret_cast<cplx<T>*>((size_t)ub + (size_t)((uint32_t)(rl * M_of + nb) * (uint32_t)sizeof(cplx<T>))), z);
-    s1 += (double)z.x + (double)z.y;
-    s2 += (double)z.x * (double)z.x + (double)z.y * (double)z.y;
+    mom.add(z);
   }
   RF_HD int gather_seg_shift() const { return -1; }
   RF_HD cplx<T> load(long long row, int k) const {
     const int g = k >> nzl_shift(), kk = k & (nzl - 1);
     return stream_load(src + ((long long)g * seg_stride + row * (long long)nzl + kk));
   }
-  RF_HD void store(long long row, int n, cplx<T> z, double& s1, double& s2) const {
+  RF_HD void store(long long row, int n, cplx<T> z, MomAcc<T>& mom) const {
     z.x *= scale; z.y *= scale;
     stream_store(dst + (row * (long long)M_of + n), z);
-    s1 += (double)z.x + (double)z.y;
-    s2 += (double)z.x * (double)z.x + (double)z.y * (double)z.y;
+    mom.add(z);
   }
 };
 
@@ -1058,28 +1098,26 @@ template <typename T> struct XGatherRowIO {
     const uint32_t lane = ((uint32_t)rl << seg_shift) + (uint32_t)(kl >> seg_shift) * (uint32_t)kt_stride + (uint32_t)(kl & mask);
     return stream_load(reinterpret_cast<const cplx<T>*>((size_t)ub + (size_t)(lane * (uint32_t)sizeof(cplx<T>))));
   }
-  template <int NRT> RF_HD void store2(long long tile, int rl, int nb, int no, cplx<T> z, double& s1, double& s2) const {
+  template <int NRT> RF_HD void store2(long long tile, int rl, int nb, int no, cplx<T> z, MomAcc<T>& mom) const {
     const long long t0 = tile * NRT, q = t0 >> rb_shift, r0 = t0 & ((1LL << rb_shift) - 1);
     const long long xb = q >> ny_shift, iy = q & ((1LL << ny_shift) - 1);
     cplx<T>* ub = dst + (((((xb << rb_shift) + r0) << ny_shift) + iy)) * (long long)M_of + no;
     const uint32_t lane = (uint32_t)rl * ((uint32_t)M_of << ny_shift) + (uint32_t)nb;
     z.x *= scale; z.y *= scale;
     stream_store(reinterpret_cast<cplx<T>*>((size_t)ub + (size_t)(lane * (uint32_t)sizeof(cplx<T>))), z);
-    s1 += (double)z.x + (double)z.y;
-    s2 += (double)z.x * (double)z.x + (double)z.y * (double)z.y;
+    mom.add(z);
   }
   RF_HD cplx<T> load(long long row, int k) const {
     const long long r = row & ((1LL << rb_shift) - 1), q = row >> rb_shift;      // q = xb * ny + iy
     const long long xb = q >> ny_shift, iy = q & ((1LL << ny_shift) - 1);
     return stream_load(src + xb * xb_stride + (long long)(k >> seg_shift) * kt_stride + ((((iy << rb_shift) + r)) << seg_shift) + (k & ((1 << seg_shift) - 1)));
   }
-  RF_HD void store(long long row, int n, cplx<T> z, double& s1, double& s2) const {
+  RF_HD void store(long long row, int n, cplx<T> z, MomAcc<T>& mom) const {
     const long long r = row & ((1LL << rb_shift) - 1), q = row >> rb_shift;
     const long long xb = q >> ny_shift, iy = q & ((1LL << ny_shift) - 1);
     z.x *= scale; z.y *= scale;
     stream_store(dst + (((((xb << rb_shift) + r) << ny_shift) + iy)) * (long long)M_of + n, z);
-    s1 += (double)z.x + (double)z.y;
-    s2 += (double)z.x * (double)z.x + (double)z.y * (double)z.y;
+    mom.add(z);
   }
 };
 
@@ -1105,15 +1143,14 @@ template <typename T> struct LognormalRowIO {
     return (T)((double)d * Bp[z]);
   }
   RF_HD cplx<T> load(long long row, int k) const { return stream_load(base + row * (long long)M_of + k); }
-  RF_HD void store(long long row, int n, cplx<T> z, double& s1, double& s2) const {
+  RF_HD void store(long long row, int n, cplx<T> z, MomAcc<T>& mom) const {
     z.x = map(z.x * scale, 2 * n);
     z.y = map(z.y * scale, 2 * n + 1);
     stream_store(base + row * (long long)M_of + n, z);
-    s1 += (double)z.x + (double)z.y;
-    s2 += (double)z.x * (double)z.x + (double)z.y * (double)z.y;
+    mom.add(z);
   }
   template <int NRT> RF_HD cplx<T> load2(long long tile, int rl, int kb, int ko) const { return load(tile * NRT + rl, kb + ko); }
-  template <int NRT> RF_HD void store2(long long tile, int rl, int nb, int no, cplx<T> z, double& s1, double& s2) const { store(tile * NRT + rl, nb + no, z, s1, s2); }
+  template <int NRT> RF_HD void store2(long long tile, int rl, int nb, int no, cplx<T> z, MomAcc<T>& mom) const { store(tile * NRT + rl, nb + no, z, mom); }
 };
 
 // z pass whose store multiplies plane z by a per-z factor (float64 table, the rounding of rf_scale_z on the stored field): the
@@ -1125,15 +1162,14 @@ template <typename T> struct ScaleZRowIO {
   const double* Sz;              // [2 M]
   RF_HD int gather_seg_shift() const { return -1; }
   RF_HD cplx<T> load(long long row, int k) const { return stream_load(base + row * (long long)M_of + k); }
-  RF_HD void store(long long row, int n, cplx<T> z, double& s1, double& s2) const {
+  RF_HD void store(long long row, int n, cplx<T> z, MomAcc<T>& mom) const {
     z.x = (T)((double)(z.x * scale) * Sz[2 * n]);
     z.y = (T)((double)(z.y * scale) * Sz[2 * n + 1]);
     stream_store(base + row * (long long)M_of + n, z);
-    s1 += (double)z.x + (double)z.y;
-    s2 += (double)z.x * (double)z.x + (double)z.y * (double)z.y;
+    mom.add(z);
   }
   template <int NRT> RF_HD cplx<T> load2(long long tile, int rl, int kb, int ko) const { return load(tile * NRT + rl, kb + ko); }
-  template <int NRT> RF_HD void store2(long long tile, int rl, int nb, int no, cplx<T> z, double& s1, double& s2) const { store(tile * NRT + rl, nb + no, z, s1, s2); }
+  template <int NRT> RF_HD void store2(long long tile, int rl, int nb, int no, cplx<T> z, MomAcc<T>& mom) const { store(tile * NRT + rl, nb + no, z, mom); }
 };
 
 // tw = exp(+2 pi i q / (2M)), q in [0, 2M): t_k = tw[k], w_M^q = tw[2q]
@@ -1144,7 +1180,7 @@ struct RowC2R {
   static constexpr int M = C::M, NT = C::NT;
   static constexpr int DIR = +1;
 
-  struct Regs { cx v[C::IT2][cmax(C::R2, 1)]; double s1, s2; };
+  struct Regs { cx v[C::IT2][cmax(C::R2, 1)]; MomAcc<T> mom; };
 
   RF_HD static cx* lds_at(cx* lds, int rl, int i) { return lds + (long long)rl * C::RS + pad16(i); }
   RF_HD static cx* lds_tw(cx* lds) { return lds + C::TILE_BYTES / (int)sizeof(cx); }
@@ -1175,7 +1211,8 @@ struct RowC2R {
   RF_HD static void emit(int rl, long long row, int idx, const cx* v, const IO& io, cx* lds, Regs& r) {
 #pragma unroll
     for (int m = 0; m < R; ++m) {
-      if (C::NPASS == 1) io.template store2<C::NRT>(row / C::NRT, rl, idx, m, v[m], r.s1, r.s2);
+      if (C::NPASS == 1) io.template store2<C::NRT>(row / C::NRT, rl, idx, m, v[m], r.mom);
+      else if (R % 8 == 0) lds_at(lds, rl, idx)[m + (m >> 3)] = v[m];      // (idx is a multiple of R: the padding of idx + m splits, one base + immediates)
       else *lds_at(lds, rl, idx + m) = v[m];
     }
   }
@@ -1217,7 +1254,7 @@ struct RowC2R {
   // pass 1, second half: untangle -> R1 butterflies of the mirror pair -> LDS
   RF_HD static void pass_first_compute(int tid, long long tile, long long nrows, const IO& io, const cx* tw, cx* lds, Regs& r, const In& in) {
     constexpr int R = C::R1, L = C::L1;
-    r.s1 = 0; r.s2 = 0;
+    r.mom = MomAcc<T>();
 #pragma unroll
     for (int it = 0; it < C::IT1; ++it) {
       int rl, q;
@@ -1268,9 +1305,10 @@ struct RowC2R {
       const int w = it * NT + tid;
       const int rl = w / L, j = w % L;
       if (rl < C::NRT) {
+        const cx* const rd = lds_at(lds, rl, j);                              // L % 8 == 0: pad16(j + m L) = pad16(j) + m (L + L / 8)
 #pragma unroll
         for (int m = 0; m < R; ++m) {
-          cx x = *lds_at(lds, rl, j + m * L);
+          cx x = (L % 8 == 0) ? rd[m * (L + L / 8)] : *lds_at(lds, rl, j + m * L);
           if (m > 0) x = cmul(x, tw[2 * stockham_tw_index(j, m, Ns, R, M)]);
           r.v[it][m] = x;
         }
@@ -1286,8 +1324,12 @@ struct RowC2R {
       const int rl = w / L, j = w % L;
       if (rl < C::NRT) {
         const int ob = stockham_out_base(j, Ns, R);
+        cx* const wr = lds_at(lds, rl, ob);                                   // Ns % 8 == 0: pad16(ob + m Ns) = pad16(ob) + m (Ns + Ns / 8)
 #pragma unroll
-        for (int m = 0; m < R; ++m) *lds_at(lds, rl, ob + m * Ns) = r.v[it][m];
+        for (int m = 0; m < R; ++m) {
+          if (Ns % 8 == 0) wr[m * (Ns + Ns / 8)] = r.v[it][m];
+          else *lds_at(lds, rl, ob + m * Ns) = r.v[it][m];
+        }
       }
     }
   }
@@ -1301,15 +1343,16 @@ struct RowC2R {
       const long long row = tile * C::NRT + rl;
       if (rl < C::NRT && row < nrows) {
         cx v[R];
+        const cx* const rd = lds_at(lds, rl, j);
 #pragma unroll
         for (int m = 0; m < R; ++m) {
-          cx x = *lds_at(lds, rl, j + m * L);
+          cx x = (L % 8 == 0) ? rd[m * (L + L / 8)] : *lds_at(lds, rl, j + m * L);
           if (m > 0) x = cmul(x, tw[2 * m * j]);
           v[m] = x;
         }
         DFT<R, DIR>::run(v);
 #pragma unroll
-        for (int m = 0; m < R; ++m) io.template store2<C::NRT>(tile, rl, j, m * L, v[m], r.s1, r.s2);
+        for (int m = 0; m < R; ++m) io.template store2<C::NRT>(tile, rl, j, m * L, v[m], r.mom);
       }
     }
   }

@@ -93,11 +93,11 @@ __global__ __launch_bounds__(256) void fix_fill_kernel(IOF io, CT* __restrict__ 
 }
 
 // strided pass of length 2 C1::N as two C1 transforms per tile + a radix-2 step in registers (rf_fft.h Col2)
-// (a kernel that computes the kz = 0 repair itself -- FIX = 1 -- needs ~260 registers with the parked half: it gets the budget of
-// two waves per SIMD instead of spilling 336 bytes per thread; the product's repair launch reads the repaired slots from a side
-// buffer -- FIX = 3 -- and keeps the ordinary budget)
+// (the kernels that repair the kz = 0 slot -- FIX = 1 computes it, FIX = 3 loads it from the side buffer -- hold the eight values next
+// to the parked half: 140 - 260 registers.  They run few tiles and get the budget of two waves per SIMD instead of 190 - 300 bytes
+// of scratch per thread at four)
 template <class C1, int DIR, class IO>
-__global__ __launch_bounds__(C1::NT, (IO::FIX_MODE == 1 ? 2 : col_min_waves<C1, IO>())) void col2_kernel(IO io, const cplx<typename C1::T>* __restrict__ tw2,
+__global__ __launch_bounds__(C1::NT, (IO::FIX_MODE != 0 ? 2 : col_min_waves<C1, IO>())) void col2_kernel(IO io, const cplx<typename C1::T>* __restrict__ tw2,
                                                                              long long ntiles, long long tile_mul,
                                                                              long long tile_add, int skip_period) {
   using X = Col2<C1, DIR, IO>;
@@ -127,8 +127,18 @@ __global__ __launch_bounds__(C1::NT, (IO::FIX_MODE == 1 ? 2 : col_min_waves<C1, 
     // both phases run the same passes on the same LDS addresses: hidden from the optimiser (an opaque copy of the thread index
     // per phase), or it keeps the first phase's ~40 addresses and twiddles live through the whole kernel, next to the 32 parked
     // registers, and spills (248 bytes of scratch per thread, 2.8x slower on MI355X)
-    int t = tid;
-    asm volatile("" : "+v"(t));
+    // (the copy is opaque, its RANGE is not: masked back to [0, NT), so that t / LPR, t % TC ... stay single shifts and masks --
+    // without the mask the compiler treats t as an arbitrary signed integer and spends ~630 of the kernel's 3079 vector
+    // instructions on sign-correct divisions and un-folded LDS addresses)
+    unsigned tu = (unsigned)tid;
+    asm volatile("" : "+v"(tu));
+#ifndef RF_COL2_MASK_PHASES
+#define RF_COL2_MASK_PHASES 0          // bit p: phase p of a FLOAT32 pass sees the masked index.  None: at 122 registers next to the 32 parked ones the folded
+#endif                                 // addresses cost 12 - 60 bytes of scratch per thread and the 2048^3 x pass runs 9 % SLOWER (12.4 -> 13.6 ms); the float64
+                                       // generation pass (104 registers) takes the mask in both phases: 2.63 -> 2.47 ms per 1024^3
+    constexpr int mask_phases = sizeof(typename C1::T) == 8 ? 3 : (RF_COL2_MASK_PHASES & 3);
+    const int t = ((mask_phases >> phase) & 1) ? (int)(tu & (unsigned)(C1::NT - 1)) : (int)tu;
+    static_assert((C1::NT & (C1::NT - 1)) == 0, "the thread count of a Col2 pass is a power of two");
     F::pass_first(t, tile, io, lds);
     if (phase == 0) F::tw_stage(tid, lds, twr);
     if (C1::NPASS == 3) {
@@ -217,7 +227,7 @@ __global__ __launch_bounds__(C::NT) void row_c2r_kernel(IO io, const cplx<typena
         DFT<8, +1>::run(v);
         if (tile * C::NRT + rl < nrows) {
 #pragma unroll
-          for (int m = 0; m < 8; ++m) io.template store2<C::NRT>(tile, rl, j, m * 64, v[m], r.s1, r.s2);
+          for (int m = 0; m < 8; ++m) io.template store2<C::NRT>(tile, rl, j, m * 64, v[m], r.mom);
         }
       }
     }
@@ -234,7 +244,7 @@ __global__ __launch_bounds__(C::NT) void row_c2r_kernel(IO io, const cplx<typena
     }
   }
   // workgroup reduction of the moments: wave shuffle, then one slot per wave in LDS
-  double s1 = r.s1, s2 = r.s2;
+  double s1 = r.mom.sum(), s2 = r.mom.sumsq();
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     s1 += __shfl_down(s1, off);

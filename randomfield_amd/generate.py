@@ -155,7 +155,8 @@ class Generator(object):
             if nx % 2 or ny % 2 or nz % 2:
                 raise ValueError("All shape dimensions must be even.")
             self.plan_c2r = slab.SlabHostPlan(slab.DistributedPlan(nx, ny, nz, dtype), dtype)
-            self.plan_r2c = None         # the forward transform is single-GPU (and the reference never executes this plan)
+            # generate.py:79-80: the forward plan over the same memory (here: this rank's window of the field in, its kz planes out)
+            self.plan_r2c = self.plan_c2r.create_reverse_plan(reuse_output=True, overwrite=True)
         else:
             self.plan_c2r = transform.Plan(shape=(nx, ny, nz), dtype_in=dtype, packed=True, overwrite=True,
                                            inverse=True, use_pyfftw=True, backend=self.backend)

@@ -21,7 +21,7 @@ import time
 import numpy as np
 
 __all__ = ["slab_layout", "exchange_blocks", "gather_rows", "side_array_planes", "split_side_array",
-           "assemble_side_array", "shared_replay_layout", "shared_replay_pack", "exchange_unique_id", "init_process_group", "DistributedPlan", "SlabHostPlan", "Deadline"]
+           "assemble_side_array", "shared_replay_layout", "shared_replay_pack", "exchange_unique_id", "launch_nonce", "init_process_group", "DistributedPlan", "SlabHostPlan", "SlabHostReversePlan", "Deadline"]
 
 
 def slab_layout(nx, ny, nz, nranks, rank):
@@ -329,3 +329,53 @@ class SlabHostPlan(object):
     def agree_on(self, value):
         """The same integer on every rank (max over ranks; exact below 2**53)."""
         return int(self.dist.allreduce([float(value)], op="max")[0])
+
+    def execute(self):
+        """There is no host-side k space to transform on a slab rank (it lives on the devices, split by kz planes):
+        use :class:`randomfield_amd.generate.Generator` or the device plan."""
+        raise RuntimeError("A slab rank's c2r plan has no host k-space input: drive it through Generator / plan.device.")
+
+    def create_reverse_plan(self, reuse_output=True, overwrite=True):
+        """The forward (r2c) plan over the same device plan (transform.py:278-301, as ``Generator`` builds it at
+        generate.py:79-80): its input is this rank's window of the real-space field -- ``reuse_output`` shares our
+        ``data_out_padded`` memory -- and its output this rank's share of k space, ``(nx, ny, nz/(2 ranks) + 1)`` complex:
+        the rank's own kz planes, then the Nyquist plane (:func:`side_array_planes`; :func:`assemble_side_array` puts the
+        ranks' shares together).  ``execute()`` is collective: rows on the x slab, the all-to-all in the other direction,
+        columns on the kz slab (rf_execute_r2c)."""
+        if reuse_output and not overwrite:
+            return SlabHostReversePlan(self, self.data_out, padded=False)
+        if reuse_output:
+            return SlabHostReversePlan(self, self.data_out_padded, padded=True)
+        nxl, ny, nz = self.data_out.shape
+        return SlabHostReversePlan(self, np.empty((nxl, ny, nz + 2 if overwrite else nz), self.data_out.dtype), padded=bool(overwrite),
+                                   owns_input=True)
+
+
+class SlabHostReversePlan(object):
+    """``transform.Plan(inverse=False, packed=True)`` for one rank of a multi-GPU job (see :meth:`SlabHostPlan.create_reverse_plan`)."""
+
+    def __init__(self, forward_of, real_buffer, padded, owns_input=False):
+        self.dist, self.device, self.shape = forward_of.dist, forward_of.device, forward_of.shape
+        self.inverse, self.packed, self.overwrite, self.backend = False, True, bool(padded), "hip"
+        nz = self.shape[2]
+        if padded:
+            self.data_in_padded = real_buffer
+            self.data_in = real_buffer[:, :, :nz]
+        else:
+            self.data_in = real_buffer
+        self._padded = bool(padded)
+        # this rank's share of k space (host memory of its own: an x slab of reals and a kz slab of complex numbers have
+        # different shapes, so the reference's in-place aliasing of the two sides has no counterpart here)
+        self.data_out = np.empty(self.device.k_shape, self.device.complex_dtype)
+        self.nbytes_allocated = self.data_out.nbytes + (real_buffer.nbytes if owns_input else 0)
+
+    def execute(self):
+        """Collective over the plan's ranks; returns this rank's share of k space (``data_out``)."""
+        dev = self.device
+        if self._padded:
+            dev.upload_real(self.data_in_padded, padded=True)
+        else:
+            dev.upload_real(np.ascontiguousarray(self.data_in), padded=False)
+        dev.execute_r2c()
+        dev.download_k(self.data_out)
+        return self.data_out

@@ -356,8 +356,11 @@ def test_transposed_intermediate_is_bit_identical(shape, dtype, default_power):
     for v in (1, 2, 3):
         for a, b in zip(res[v], res[0]):
             assert np.array_equal(a[0], b[0])
-            # (the moments are summed in a different order: the z pass deals its rows to threads differently when it gathers)
-            assert abs(a[1] - b[1]) <= 1e-9 * max(1.0, a[0].size ** 0.5) * float(np.abs(a[0]).max()) and abs(a[2] - b[2]) <= 1e-12 * b[2]
+            # (the moments are summed in a different order: the z pass deals its rows to threads differently when it gathers; float32
+            # fields accumulate 16 - 32 values per thread in float32 before the float64 reduction: rf_fft.h MomAcc)
+            f32 = dtype == np.complex64
+            assert abs(a[1] - b[1]) <= (1e-6 if f32 else 1e-9) * max(1.0, a[0].size ** 0.5) * float(np.abs(a[0]).max())
+            assert abs(a[2] - b[2]) <= (1e-6 if f32 else 1e-12) * b[2]
     ref = np.fft.irfftn(ks.astype(np.complex128), s=(nx, ny, nz), axes=(0, 1, 2))
     assert np.max(np.abs(res[1][0][0] - ref)) <= (4e-6 if dtype == np.complex64 else 1e-13) * ref.std()
 

@@ -1422,10 +1422,20 @@ def test_distributed_generator_single_rank(hip, monkeypatch):
     for rng_kind in ("reference", "native"):
         one = Generator(32, 32, nz, 2.5, rng=rng_kind, **kw)
         dist = Generator(32, 32, nz, 2.5, rng=rng_kind, distributed=True, **kw)
-        assert dist.plan_c2r.data_out.shape == (32, 32, nz) and dist.plan_r2c is None
+        assert dist.plan_c2r.data_out.shape == (32, 32, nz)
         a = one.generate_delta_field(seed=5).copy()
         b = dist.generate_delta_field(seed=5).copy()
         assert np.array_equal(a, b) and one.delta_field_rms == dist.delta_field_rms
+        # generate.py:79-80: the forward plan over the same memory.  On a slab rank it takes the rank's window of the field
+        # (aliasing the c2r plan's output, as the reference's pair of plans does) and returns the rank's kz planes + Nyquist
+        r2c = dist.plan_r2c
+        assert r2c is not None and not r2c.inverse and r2c.data_in_padded is dist.plan_c2r.data_out_padded
+        assert r2c.data_out.shape == (32, 32, nz // 2 + 1) and r2c.data_out.dtype == np.complex64
+        ks = r2c.execute()
+        assert ks is r2c.data_out and np.max(np.abs(ks - np.fft.rfftn(b.astype(np.float64)))) <= 2e-5 * np.abs(ks).max()
+        assert np.max(np.abs(ks - one.plan_r2c.execute())) <= 1e-6 * np.abs(ks).max()
+        with pytest.raises(RuntimeError):
+            dist.plan_c2r.execute()
         assert np.array_equal(one.potential.download(), dist.potential.download())
         pa, pb = one.calculate_newtonian_potential(scale=-1.5).copy(), dist.calculate_newtonian_potential(scale=-1.5).copy()
         assert np.array_equal(pa, pb)

@@ -13,7 +13,7 @@ objs=""
 for f in rf_k_col_plain rf_k_col_gen rf_k_col_gen64 rf_k_row rf_k_row_c2c rf_k_misc rf_k_mt rf_k_generic rf_capi; do
   fl=""; [[ $f == rf_k_col_gen || $f == rf_k_mt ]] && fl="-mllvm -amdgpu-sched-strategy=max-ilp"       # (the Makefile's per-file flag)
   if [[ " $files " == *" $f "* ]]; then
-    hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-unused-variable $fl $extra -I$src -c $src/$f.hip -o $out/$f.o &
+    hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-slp-vectorize -Wno-unused-function -Wno-unused-variable $fl $extra -I$src -c $src/$f.hip -o $out/$f.o &
     objs="$objs $out/$f.o"
   else
     objs="$objs $src/$f.o"
