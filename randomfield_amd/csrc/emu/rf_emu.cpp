@@ -75,15 +75,16 @@ void run_col2_pass(const IO& io_in, long long ncols, const cplx<typename C1::T>*
     }
   }
 }
-// the product's rule (rf_k_col_plain.hip / rf_k_col_gen.hip): float32 passes of length 2048 run through Col2
+// the product's rule (rf_k_col_plain.hip / rf_k_col_gen.hip): float32 in-place passes of length 2048 -- and, since round 4, of length
+// 1024 -- run through Col2 (two half-length transforms per tile)
 template <typename T, int DIR>
 bool pair_pass_2048(int N, cplx<T>* base, ColGeom g, long long ncols) {
-  if (N != 2048 || sizeof(T) != 4) return false;
+  if ((N != 2048 && N != 1024) || sizeof(T) != 4 || ncols % 8) return false;
   if constexpr (sizeof(T) == 4) {
-    using C1 = GenSel<float, 1024>::type;
-    auto tw2 = make_twiddles<float>(2048);
+    auto tw2 = make_twiddles<float>(N);
     Pair2ColIO<float> io; io.base = base; io.g = g; io.gin = g; io.gin.row_stride = 2 * g.row_stride; io.par_off = g.row_stride;
-    run_col2_pass<C1, DIR, Pair2ColIO<float>>(io, ncols, tw2.data());
+    if (N == 2048) run_col2_pass<GenSel<float, 1024>::type, DIR, Pair2ColIO<float>>(io, ncols, tw2.data());
+    else run_col2_pass<PairSel1024::type, DIR, Pair2ColIO<float>>(io, ncols, tw2.data());
   }
   return true;
 }
@@ -714,7 +715,7 @@ int emu_col_fft(int f64, int N, int dir, void* data, long long ncols, long long 
     PlainColIO<double> io; io.base = (cplx<double>*)data; io.g = g;
     return dir > 0 ? dispatch_col<double, +1>(N, io, ncols) : dispatch_col<double, -1>(N, io, ncols);
   }
-  if (N == 2048 && ncols % 8 == 0) {                    // as the library does at this length: two 1024-point transforms per tile
+  if ((N == 2048 || N == 1024) && ncols % 8 == 0) {     // as the library does at these lengths: two half-length transforms per tile
     if (dir > 0) pair_pass_2048<float, +1>(N, (cplx<float>*)data, g, ncols); else pair_pass_2048<float, -1>(N, (cplx<float>*)data, g, ncols);
     return 0;
   }

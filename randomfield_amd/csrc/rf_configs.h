@@ -47,6 +47,8 @@ template <> struct GenSel<float, 2048> { using type = ColCfg<float, 2048, RF_GEN
 #define RF_GEN64_1024 8, 8, 16, 8, 1024
 #endif
 template <> struct GenSel<double, 1024> { using type = ColCfg<double, 1024, RF_GEN64_1024>; };
+// the half-length configuration of the float32 in-place pass of length 1024 (rf_k_col_plain.hip RF_Y_COL2_1024; the emulator follows)
+struct PairSel1024 { using type = ColCfg<float, 512, 8, 8, 8, 8, 256>; };
 #define RF_COL_SIZES(X) X(8) X(16) X(32) X(64) X(128) X(256) X(512) X(1024) X(2048)
 
 // ---- contiguous (z) pass: M = nz / 2 ----------------------------------------

@@ -149,6 +149,22 @@ hipError_t launch_col_plain(int f64, int N, int dir, void* base, ColGeom g, long
       if (!po || e != hipSuccess) return e;
     }
   }
+#ifndef RF_Y_COL2_1024
+#define RF_Y_COL2_1024 1               // the float32 in-place pass of length 1024 as two 512-point transforms per 8-column tile (Col2): 256 threads, 36 KB of
+#endif                                 // LDS, 109 registers -- FOUR workgroups per CU where the whole-column kernel (72 KB) has two.  The pass is latency-bound,
+                                       // not HBM-bound (its slab is read once from HBM and handed to the z pass through the Infinity Cache): more tiles in
+                                       // flight per CU, y pass 1.70 -> 1.61 ms per 1024^3 (profiles/r04_ab/ycol2.log)
+  if (RF_Y_COL2_1024 && N == 1024 && !f64) {
+    using C1 = PairSel1024::type;
+    ColGeom gin = g;
+    gin.row_stride = 2 * g.row_stride;
+    const bool fits = !gin.needs_wide(C1::LMAX, C1::TC, 8) && !g.needs_wide(C1::LMAX, C1::TC, 8) && g.row_shift >= 30 && g.hi_shift >= 62 && g.sub_shift == 0;
+    if (po || fits) {
+      hipError_t e = dir > 0 ? launch_pair<C1, +1>((cplx<float>*)base, g, ncols, (const cplx<float>*)tw, s, po)
+                             : launch_pair<C1, -1>((cplx<float>*)base, g, ncols, (const cplx<float>*)tw, s, po);
+      if (!po || e != hipSuccess) return e;
+    }
+  }
   if (f64) return dir > 0 ? launch_t<double, +1>(N, (cplx<double>*)base, g, ncols, (const cplx<double>*)tw, s, po)
                           : launch_t<double, -1>(N, (cplx<double>*)base, g, ncols, (const cplx<double>*)tw, s, po);
   return dir > 0 ? launch_t<float, +1>(N, (cplx<float>*)base, g, ncols, (const cplx<float>*)tw, s, po)

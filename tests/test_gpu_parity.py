@@ -1633,10 +1633,14 @@ def test_slabs_and_blocked_intermediate_only_move_data(hip, dpower, shape, dtype
     for key, (a, b, c, ma, rms) in res.items():
         if key[0] == 0:          # slabs: the same kernels on sub-ranges
             assert np.array_equal(a, a0) and np.array_equal(b, b0) and np.array_equal(c, c0), key
-        else:                    # blocked intermediate: the same arithmetic in other kernel instantiations (the compiler may
-            for u, v in ((a, a0), (b, b0), (c, c0)):                       # contract a few multiply-adds differently)
-                assert np.max(np.abs(u - v)) <= (1e-6 if dtype == np.complex64 else 1e-14) * v.std(), key
-        assert abs(ma[1] - m0[1]) <= 1e-9 * m0[1] and np.max(np.abs(rms - r0)) <= 1e-9 * r0.max(), key
+            assert abs(ma[1] - m0[1]) <= 1e-9 * m0[1] and np.max(np.abs(rms - r0)) <= 1e-9 * r0.max(), key
+        else:                    # blocked intermediate: the same transform in other kernel instantiations -- float32 rounding apart (the
+            # in-place y pass of length 1024 runs as two 512-point transforms per tile, the one on the intermediate as one 1024-point
+            # transform; the gathering z pass deals its rows to other threads, which reorders the float32 partial moments)
+            for u, v in ((a, a0), (b, b0), (c, c0)):
+                assert np.max(np.abs(u - v)) <= (4e-6 if dtype == np.complex64 else 1e-14) * v.std(), key
+            assert abs(ma[1] - m0[1]) <= (1e-6 if dtype == np.complex64 else 1e-9) * m0[1], key
+            assert np.max(np.abs(rms - r0)) <= (1e-6 if dtype == np.complex64 else 1e-9) * r0.max(), key
     plan.close()
 
 
