@@ -89,7 +89,9 @@ def _timed(fn, sync, reps=3, warm=1):
 
 def other_configs(power, spacing, device):
     """The other BASELINE.json configurations and API paths on one GPU (wall time around each call, inputs resident,
-    eager launches): they are parity-test cases, not the bench line, but their rates belong beside it."""
+    eager launches): they are parity-test cases, not the bench line, but their rates belong beside it.  Every entry carries
+    `kernel_ms` (HIP-event intervals around the passes of one more call of the same kind, launch gaps included) and a
+    `roofline` object for its slowest pass: algorithmic bytes of that pass / its time."""
     from randomfield_amd import _hip, cosmotools, powertools, Generator
     out = {}
 
@@ -98,6 +100,23 @@ def other_configs(power, spacing, device):
         plan.set_kgrid(*powertools.ksq_axes(n, n, n, spacing))
         plan.set_power(*powertools.sigma_table(power, (n, n, n), spacing))
         return plan
+
+    def passes(dev, n, itemsize, x_sweeps=1.0, extra=None):
+        """kernel_ms of the device plan's last timed call + the roofline object of its slowest pass.  x_sweeps: sweeps of the
+        packed array the generation pass moves (1 = write only; 2 = it also reads deviates or writes the potential)."""
+        ms = [float(v) for v in dev.kernel_ms()]
+        sweep = itemsize * float(n) * n * (n // 2 + 1)
+        names = ("x pass (generation + FFT)", "y pass (FFT in place)", "z pass (c2r + moments)")
+        t = [ms[0] + ms[4], ms[1], ms[2]]
+        byts = [x_sweeps * sweep, 2 * sweep, 2 * sweep]
+        k = int(np.argmax(t))
+        d = {"kernel_ms": {"x": round(ms[0], 4), "x_kz0_tiles": round(ms[4], 4), "y": round(ms[1], 4), "z": round(ms[2], 4), "reduce": round(ms[3], 4)},
+             "roofline": {"bound": "hbm", "kernel": names[k], "ms": round(t[k], 4), "algorithmic_bytes": byts[k],
+                          "achieved": round(byts[k] / (t[k] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": round(byts[k] / (t[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
+        if extra:
+            d["kernel_ms"].update(extra)
+        return d
 
     def entry(n, t, bytes_per_cell, **extra):
         d = {"ms": round(t * 1e3, 3), "Mcells_s": round(n ** 3 / t / 1e6, 1),
@@ -109,9 +128,10 @@ def other_configs(power, spacing, device):
     # config 1: 512^3 float32, single realisation: one call, once through eager launches and once as a replayed one-realisation graph
     plan = plan_for(512, np.complex64)
     t = _timed(lambda: plan.realise(seed=next(seeds)), plan.sync, reps=5)
+    kp = passes(plan, 512, 8)
     plan.realise_batch_prepare(1)
     tg = _timed(lambda: plan.realise_batch([next(seeds)], want_rms=False), plan.sync, reps=5)
-    out["512^3 f32 single realisation"] = entry(512, min(t, tg), 20 * (1 + 2 / 512), ms_eager=round(t * 1e3, 3), ms_graph=round(tg * 1e3, 3))
+    out["512^3 f32 single realisation"] = entry(512, min(t, tg), 20 * (1 + 2 / 512), ms_eager=round(t * 1e3, 3), ms_graph=round(tg * 1e3, 3), **kp)
     plan.close()
     # the same-seed path: numpy's MT19937 + polar stream replayed on the GPU (kept as float32 pairs, as Generator does for
     # complex64 plans), then the pipeline with the generation pass reading those deviates
@@ -126,7 +146,8 @@ def other_configs(power, spacing, device):
         plan.realise(noise="resident")
     t = _timed(reference_rng, plan.sync)
     out["1024^3 f32 rng='reference' (same field as the reference for the same seed)"] = entry(
-        1024, t, 20 * (1 + 2 / 1024), ms_mt19937_replay=round(state["rng"] * 1e3, 3))
+        1024, t, 20 * (1 + 2 / 1024), ms_mt19937_replay=round(state["rng"] * 1e3, 3),
+        **passes(plan, 1024, 8, x_sweeps=2.0, extra={"mt19937_replay (jump tree + polar pass + scan, wall)": round(state["rng"] * 1e3, 3)}))
     # ten of them back to back: the replay of seed i + 1 on a second stream under the y / z passes of seed i
     batch = [next(seeds) for _ in range(10)]
     plan.realise_batch_reference(batch[:2], want_rms=False)
@@ -145,16 +166,22 @@ def other_configs(power, spacing, device):
             how = "potential stored at generation time (store_potential=True)" if store else "potential regenerated on demand (default)"
             key = "1024^3 f32 Generator.generate_delta_field(save_potential=True), rng='%s'%s" % (rng, ", store_potential=True" if store else "")
             t = _timed(lambda: gen.generate_delta_field(seed=next(seeds), save_potential=True, download=False), dev.sync, reps=5, warm=3)
+            # (per-pass events: one eager call of what the Generator issued -- its native-generator call is a graph replay)
+            noise_arg = "resident" if rng == "reference" else None
+            (dev.realise_potential if store else dev.realise)(seed=next(seeds), noise=noise_arg)
+            kp = passes(dev, 1024, 8, x_sweeps=(2.0 if rng == "reference" else 1.0) + (1.0 if store else 0.0))
 
             def both():
                 gen.generate_delta_field(seed=next(seeds), save_potential=True, download=False)
                 gen.calculate_newtonian_potential(light_cone=False, scale=-1.5, download=False)
             t2 = _timed(both, dev.sync, reps=3, warm=1)
             out[key] = entry(1024, t, (28 if store else 20) * (1 + 2 / 1024), note=how,
-                             ms_with_calculate_newtonian_potential=round(t2 * 1e3, 3))
+                             ms_with_calculate_newtonian_potential=round(t2 * 1e3, 3), **kp)
             if not store:
                 t = _timed(lambda: gen.generate_delta_field(seed=next(seeds), save_potential=False, download=False), dev.sync)
-                out["1024^3 f32 Generator.generate_delta_field(save_potential=False), rng='%s'" % rng] = entry(1024, t, 20 * (1 + 2 / 1024))
+                dev.realise(seed=next(seeds), noise=noise_arg)
+                out["1024^3 f32 Generator.generate_delta_field(save_potential=False), rng='%s'" % rng] = entry(
+                    1024, t, 20 * (1 + 2 / 1024), **passes(dev, 1024, 8, x_sweeps=2.0 if rng == "reference" else 1.0))
             dev.close()
             del gen
     # (last: after this 17 GB plan has been freed, the allocator hands later plans memory on which the strided store
@@ -162,7 +189,7 @@ def other_configs(power, spacing, device):
     # config 4's dtype on one GPU, and config 5: float64 + lognormal map (rows D and L: moments, then the per-z map)
     plan = plan_for(1024, np.complex128)
     t = _timed(lambda: plan.realise(seed=next(seeds)), plan.sync)
-    out["1024^3 f64"] = entry(1024, t, 40 * (1 + 2 / 1024))
+    out["1024^3 f64"] = entry(1024, t, 40 * (1 + 2 / 1024), **passes(plan, 1024, 16))
     growth = np.exp(-0.5 * np.arange(1024) / 1024)
 
     def f64_lognormal():
@@ -178,15 +205,37 @@ def other_configs(power, spacing, device):
                                           note="fused (rf_realise_lognormal): 5 sweeps = 40 (1 + 2/nz) B/cell, sigma by Parseval from the y pass, "
                                                "map in the z pass's epilogue",
                                           unfused=entry(1024, t_unfused, 56 * (1 + 2 / 1024),
-                                                        note="rf_realise + rf_moments (host round trip) + rf_lognormal: 56 (1 + 2/nz) B/cell"))
+                                                        note="rf_realise + rf_moments (host round trip) + rf_lognormal: 56 (1 + 2/nz) B/cell"),
+                                          **passes(plan, 1024, 16))
     plan.close()
     # config 4's grid on ONE GPU (34 GB): its per-GPU kernels at full axis length -- the length-2048 strided passes run as two
     # 1024-point transforms per tile; the 8-GPU job itself is `bench.py --gpus 8`
     plan = plan_for(2048, np.complex64)
     t = _timed(lambda: plan.realise(seed=next(seeds)), plan.sync, reps=3, warm=1)
-    out["2048^3 f32 on one GPU"] = entry(2048, t, 20 * (1 + 2 / 2048), kernel_ms=dict(zip(("x", "y", "z", "reduce", "x_kz0_tiles"),
-                                                                                        [round(float(v), 3) for v in plan.kernel_ms()])))
+    out["2048^3 f32 on one GPU"] = entry(2048, t, 20 * (1 + 2 / 2048), **passes(plan, 2048, 8))
     plan.close()
+    # ... and what ONE rank of that job computes per realisation (virtual rank of 8 on this GPU: the kernels and layouts of
+    # config 4, the all-to-all left out): forward = generation + x + y on the rank's 128 kz planes, backward = the gathering z pass
+    per_rank = {}
+    for r in (0, 3):
+        p = _hip.DevicePlan(2048, 2048, 2048, np.complex64, device=device, nranks=8, rank=r)
+        p.set_kgrid(*powertools.ksq_axes(2048, 2048, 2048, spacing))
+        p.set_power(*powertools.sigma_table(power, (2048, 2048, 2048), spacing))
+        p.slab_forward(seed=1)
+        p.slab_backward()
+        fw, bw = [], []
+        for i in range(4):
+            p.sync()
+            t0 = time.perf_counter()
+            p.slab_forward(seed=2 + i)
+            t1 = time.perf_counter()
+            p.slab_backward()
+            t2 = time.perf_counter()
+            fw.append(t1 - t0)
+            bw.append(t2 - t1)
+        per_rank["rank %d" % r] = {"forward_ms": round(float(np.median(fw)) * 1e3, 3), "backward_ms": round(float(np.median(bw)) * 1e3, 3)}
+        p.close()
+    out["2048^3 / 8 kz slabs, per-rank compute on this GPU (virtual ranks, no exchange)"] = per_rank
     return out
 
 
@@ -425,9 +474,9 @@ def main():
     sweep = 8.0 * nx * ny * (nz // 2 + 1)           # bytes of one sweep of the packed complex64 array
     # kern = [x main kernel, y, z, reduce, x launch over the kz = 0 tiles]; the x pass writes one sweep, of which the
     # main kernel writes all tiles but one per ky row
-    names = ["x pass (generation + FFT, write only; both launches: the kz = 0 tiles with the Hermitian repair + all others)",
+    names = ["x pass (generation + FFT, write only; its three launches: the side buffer of repaired kz = 0 slots, the kz = 0 tiles, all others)",
              "y pass (FFT in place)", "z pass (c2r + moments, in place)"]
-    # the x pass is two launches (the tiles that hold slot kz = 0, then all others): the PASS is what gets compared
+    # the x pass is three launches (side-buffer fill, the tiles that hold slot kz = 0, then all others): the PASS is what gets compared
     pass_ms = np.array([kern[0] + kern[4], kern[1], kern[2]])
     alg = [sweep, 2 * sweep, 2 * sweep]
     dom = int(np.argmax(pass_ms))
@@ -439,7 +488,7 @@ def main():
     nslab, slab_planes = plan.yz_slabs()
     launches = [1, nslab, nslab]
     traffic, traffic_source, pass_traffic = None, None, {}
-    keys = [["FastGenColIOT<0, 0,", "FastGenColIOT<0, 1,"], ["PlainColIO", "XposeColIO"], ["row_c2r_kernel"]]
+    keys = [["FastGenColIOT<0, 0,", "FastGenColIOT<0, 1,", "FastGenColIOT<0, 3,", "fix_fill_kernel"], ["PlainColIO", "XposeColIO", "Pair2ColIO"], ["row_c2r_kernel"]]
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
     except Exception as e:                               # no committed profile: say so instead of a silent null
@@ -477,7 +526,7 @@ def main():
                      "kernel_ms_note": "HIP-event intervals around each pass of EAGER realisations in this process (they include the "
                                        "launch gaps, and y / z are the sums over their %d launches of %d x planes): their sum is "
                                        "larger than ms_per_step, which is the graph replay" % (nslab, slab_planes),
-                     "launches_per_realisation": {"x": 2, "y": nslab, "z": nslab, "reduce": 1},
+                     "launches_per_realisation": {"x": 3, "y": nslab, "z": nslab, "reduce": 1},
                      "traffic_bytes_per_launch": pass_traffic,
                      "pass_frac_of_hbm_peak": {k: round(alg[i] / (pass_ms[i] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                                                for i, k in enumerate(("x", "y", "z"))}},

@@ -1439,18 +1439,22 @@ int rf_realise_lognormal(rf_plan* p, uint64_t seed, int mode, const double* nois
   RF_HIP(hipEventRecord(p->ev[0], s));
   void* Xsave = p->X;
   p->X = nullptr;                                    // plain layout: the accumulating y pass runs in place on W
-  int rc = queue_x(p, gp, nullptr, p->W, s, false);
+  p->slab_timed = 0;
+  int rc = queue_x(p, gp, nullptr, p->W, s, true);   // (timed: rf_kernel_ms reports x, y + tables, z + map, reduce of this call too)
   p->X = Xsave;
   p->resident_fast = false;
   if (rc) return rc;
+  RF_HIP(hipEventRecord(p->ev[1], s));
   RF_HIP(launch_col_plain_acc(p->f64, p->ny, p->W, gy, (long long)p->nx * nzl, p->kz0, (int)nzl, p->ypart, p->tw_y, s));
   // rms = sqrt(S / (nx ny)) / N3  (rf_fft.h AccColIO)
   RF_HIP(launch_lognormal_tables(p->ypart, ntiles, 1.0 / ((double)p->nx * (double)p->ny * n3 * n3), growth, p->ln_density ? dens : nullptr, p->nz,
                                  p->f64 ? 0 : 1, sig, A, B, s));
+  RF_HIP(hipEventRecord(p->ev[2], s));
   RF_HIP(launch_row_c2r_lognormal(p->f64, (int)p->nzc, p->W, (long long)p->nx * p->ny, scale, A, B, p->tw_z, p->partials, s));
+  RF_HIP(hipEventRecord(p->ev[3], s));
   RF_HIP(launch_reduce_partials(p->partials, p->npartials, p->stats, p->partials + 2 * p->npartials, s));
   RF_HIP(hipEventRecord(p->ev[4], s));
-  p->timed = false;
+  p->timed = true;
   p->cur = p->W;
   p->stats_slot = 0;
   p->real_valid = true;

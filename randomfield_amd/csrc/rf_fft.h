@@ -361,7 +361,7 @@ template <typename T, bool WIDE = false> struct GenColIO {
 // even / odd modes ix = 2 r + xp, xp = the phase set_phase() selects) -- native generation without the potential store only.
 template <int AB = 0, int FIX = 1, int SLAB = 0, int POT = 0, int SRC = 0, int XS = 1>
 struct FastGenColIOT {
-  static_assert(XS == 1 || (XS == 2 && SLAB == 0 && POT != 1 && SRC == 0), "half-transform rows: native generation, no potential store");
+  static_assert(XS == 1 || (XS == 2 && SLAB == 0 && POT != 1 && SRC != 1), "half-transform rows: native generation or float32 deviate pairs, no potential store");
   int xp = 0;
   RF_HD void set_phase(int p) { xp = p; }
   cplx<float>* base;
@@ -429,7 +429,7 @@ struct FastGenColIOT {
       RowLoc e;
       if (raw) { e.off = 0; e.seg_n = 0; }
       else if (AB & 64) { e.off = (uint32_t)(iy * gp.nx + rb + ro); e.seg_n = (uint32_t)(gp.nz / 2 + 1); }      // (ablation builds only)
-      else e = load_rowloc((gp.rowtab + ro) + (uint32_t)(iy * gp.nx + rb));
+      else e = load_rowloc((gp.rowtab + rot) + (uint32_t)(iy * gp.nx + rbt));
       cplx<float> ga, gb;
       if (raw) { ga = raw->c[0]; gb = raw->c[1]; }                                       // (loaded by preload() at the top of the kernel)
       else if (AB & 16) { ga = mk<float>((float)e.off, (float)e.seg_n); gb = mk<float>((float)kz, (float)e.off); }
@@ -462,12 +462,12 @@ struct FastGenColIOT {
 #endif
   // SRC = 2: the memory half of load() -- the row's table entry, then its two deviate pairs -- for the kernel to issue before it
   // stages any table (col_kernel): three dependent round trips (records, row table, pairs) become two that overlap the staging
-  static constexpr bool HAS_PRELOAD = (SRC == 2 && XS == 1 && RF_SRC2_PRELOAD != 0);
+  static constexpr bool HAS_PRELOAD = (SRC == 2 && RF_SRC2_PRELOAD != 0);
   RF_HD V16<float> preload(long long C0, int cl, int rb, int ro) const {
     V16<float> v;
     const long long C = C0 + cl;
     const int iy = (int)((unsigned)C >> nzl_shift()), kz = kz0 + (int)((unsigned)C & (unsigned)(nzl - 1));
-    const RowLoc e = load_rowloc((gp.rowtab + ro) + (uint32_t)(iy * gp.nx + rb));
+    const RowLoc e = load_rowloc((gp.rowtab + (XS * ro + (XS == 2 ? xp : 0))) + (uint32_t)(iy * gp.nx + XS * rb));
     v.c[0] = load_pair_global(row_pair(gp, e, kz));
     v.c[1] = load_pair_global(row_pair(gp, e, kz + 1));
     return v;
@@ -494,8 +494,9 @@ struct FastGenColIOT {
     const uint64_t seed = gp.seed;                                                      // bind_seed() ran first
     const int iy = (int)((unsigned)C >> nzl_shift());
     cplx<float> p0, pn;
-    const cplx<float> packed = SRC != 0 ? fast_fix_kz0_noise<SRC == 0 ? 1 : SRC>(gp, rec, rb + ro, iy, p0, pn)
-                                        : fast_fix_kz0(gp, rec, seed, XS * (rb + ro) + (XS == 2 ? xp : 0), iy, p0, pn);
+    const int ixm = XS * (rb + ro) + (XS == 2 ? xp : 0);                                  // the row's mode index
+    const cplx<float> packed = SRC != 0 ? fast_fix_kz0_noise<SRC == 0 ? 1 : SRC>(gp, rec, ixm, iy, p0, pn)
+                                        : fast_fix_kz0(gp, rec, seed, ixm, iy, p0, pn);
     if (POT == 1) {
       cplx<float>* row = pot + ((long long)(rb + ro) * gp.ny + iy) * gp.ppitch;   // only the rank with kz0 = 0 gets here: slot 0 = plane 0
       row[0] = p0;

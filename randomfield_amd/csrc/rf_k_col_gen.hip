@@ -71,6 +71,15 @@ hipError_t launch_col_fastgen(int f64, int N, void* W, ColGeom g, long long ncol
 #endif
   if (gp.noise32 || po) {                      // resident float32 deviates, without / with the potential store
     if (gp.noise32 && slab) return hipErrorInvalidValue;
+#ifndef RF_SRC2_COL2_1024
+#define RF_SRC2_COL2_1024 0            // EXPERIMENT (measured, not adopted: 2.69 against 2.47 ms per 1024^3): the deviate-reading pass of length 1024 as two
+                                       // 512-point transforms per tile (256 threads, 44 KB: three workgroups per CU), as the in-place y pass runs
+#endif
+    if (RF_SRC2_COL2_1024 && N == 1024 && (!pot || po)) {
+      hipError_t e = launch_fast_one2<PairSel1024::type, FastGenColIOT<RF_SRC2_AB, 0, 0, 0, 2, 2>, FastGenColIOT<RF_SRC2_AB, 1, 0, 0, 2, 2>>(
+          gp, (cplx<float>*)W, g, ncols, kz0, nzl, (const cplx<float>*)tw, s, po, after_repair, (cplx<float>*)fixbuf);
+      if (!po || e != hipSuccess) return e;
+    }
     if (!pot || po)
       switch (N) {
 #define X(NN) case NN: { hipError_t e = launch_fast_one<typename GenSel<float, NN>::type, FastGenColIOT<RF_SRC2_AB, 0, 0, 0, 2>, FastGenColIOT<RF_SRC2_AB, 1, 0, 0, 2>, cplx<float>>(gp, (cplx<float>*)W, g, ncols, kz0, nzl, (const cplx<float>*)tw, s, po, after_repair, x0, x1, (cplx<float>*)fixbuf); if (!po || e != hipSuccess) return e; break; }

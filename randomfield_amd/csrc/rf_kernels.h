@@ -139,7 +139,13 @@ __global__ __launch_bounds__(C1::NT, (IO::FIX_MODE != 0 ? 2 : col_min_waves<C1, 
     constexpr int mask_phases = sizeof(typename C1::T) == 8 ? 3 : (RF_COL2_MASK_PHASES & 3);
     const int t = ((mask_phases >> phase) & 1) ? (int)(tu & (unsigned)(C1::NT - 1)) : (int)tu;
     static_assert((C1::NT & (C1::NT - 1)) == 0, "the thread count of a Col2 pass is a power of two");
-    F::pass_first(t, tile, io, lds);
+    if constexpr (F::PRELOAD) {                      // (IOs that read memory in pass 1: this phase's loads go out first)
+      typename F::PreRegs pre;
+      F::preload(t, tile, io, pre);
+      F::pass_first(t, tile, io, lds, pre, true);
+    } else {
+      F::pass_first(t, tile, io, lds);
+    }
     if (phase == 0) F::tw_stage(tid, lds, twr);
     if (C1::NPASS == 3) {
       typename F::Regs r;
