@@ -60,9 +60,13 @@ int rf_plan_nbytes(rf_plan* plan, size_t* nbytes);          /* transform.py:221,
  * buffer.  Measured on MI355X: 5 % faster at 2048^3 float32, slower at 1024^3; twice the device memory.
  * RF_FLAG_YZ_SLAB_PLANES = 16 (single-GPU plans; the value is a count, not a boolean): the y and z passes run slab by slab of
  * `value` x planes, so that the z pass finds what the y pass has just written in the 256 MiB Infinity Cache; -1 (default) picks
- * slabs of about that size, 0 = whole-grid passes. */
+ * slabs of about that size, 0 = whole-grid passes.
+ * RF_FLAG_EXCHANGE_CHUNKS = 32 (multi-rank plans in exchange mode; the value is a count, a power of two): the rank's kz slab is
+ * generated, x- and y-transformed and SENT as `value` sub-slabs, so that inside ONE realisation (one generate_delta_field call,
+ * generate.py:144-230) the all-to-all of sub-slab c runs on a second stream under the forward passes of sub-slab c + 1 instead of
+ * behind all of them; the gathering z pass reads ranks x value segments per row.  1 (default) = one exchange of the whole slab. */
 enum { RF_FLAG_EXACT_GENERATION = 1, RF_FLAG_FORCE_SLAB_PATH = 2, RF_FLAG_REPLICATED_GENERATION = 4, RF_FLAG_TRANSPOSED_INTERMEDIATE = 8,
-       RF_FLAG_YZ_SLAB_PLANES = 16 };
+       RF_FLAG_YZ_SLAB_PLANES = 16, RF_FLAG_EXCHANGE_CHUNKS = 32 };
 int rf_plan_set_flag(rf_plan* plan, int flag, int value);
 /* run on a caller-owned HIP stream (hipStream_t passed as void*); NULL restores the plan's own stream */
 int rf_plan_set_stream(rf_plan* plan, void* hip_stream);

@@ -256,6 +256,11 @@ class DevicePlan(object):
         """x planes per slab of the y / z passes (single-GPU plans): -1 automatic (about the Infinity Cache's size), 0 = whole grid."""
         check(self._lib.rf_plan_set_flag(self._h, 16, int(planes)), "rf_plan_set_flag")
 
+    def set_exchange_chunks(self, chunks=1):
+        """Multi-rank plans: generate / transform / send the rank's kz slab as ``chunks`` sub-slabs (a power of two), the exchange
+        of each overlapped with the forward passes of the next inside one realisation (RF_FLAG_EXCHANGE_CHUNKS)."""
+        check(self._lib.rf_plan_set_flag(self._h, 32, int(chunks)), "rf_plan_set_flag")
+
     def set_stream(self, hip_stream):
         check(self._lib.rf_plan_set_stream(self._h, ctypes.c_void_p(hip_stream or 0)), "rf_plan_set_stream")
 

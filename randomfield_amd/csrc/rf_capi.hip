@@ -101,6 +101,12 @@ struct rf_plan {
   hipStream_t comm_stream = nullptr;      // exchange stream of pipelined slab batches
   hipEvent_t pev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // fwd[2], exch[2], z[2]
   bool force_slab = false;                // single-rank plan routed through the slab pipeline (tests)
+  // RF_FLAG_EXCHANGE_CHUNKS: the rank's kz slab as `xchunks` sub-slabs of nzl / xchunks planes, each generated, x- and y-transformed
+  // and SENT on its own, so that the exchange of sub-slab c runs under the forward passes of sub-slab c + 1 (queue_c2r).  Layout:
+  // W = [chunk][nx][ny][nzl / xchunks]; R = [source rank][chunk][nxl][ny][nzl / xchunks], which is what the gathering z pass reads
+  // anyway with nranks * xchunks segments per row
+  int xchunks = 1;
+  std::vector<hipEvent_t> chunk_ev;       // forward half of chunk c queued (no timing)
   bool replicate = false;                 // multi-rank plan without an exchange: every rank generates all of k space (see queue_x)
   ncclComm_t comm = nullptr;
   size_t csize = 8;                       // bytes per complex element
@@ -381,7 +387,14 @@ int build_fast(rf_plan* p) {
 // full x-FFT and store only its own x slab [rank*nxl, (rank+1)*nxl); the y and z passes are then local and no
 // all-to-all is needed (only the 2-double all-reduce of the moments).  It trades P-fold redundant x-pass arithmetic
 // for the exchange: a win when the exchange is slower than (P-1) x passes -- 2 GPUs share ONE xGMI link.
-int queue_x(rf_plan* p, const GenParams& gp, const void* kspace, void* W, hipStream_t sx, bool timed = false) {
+// sub-slabs of the exchange (1: the whole kz slab at once); only plans that exchange have them
+int slab_chunks(const rf_plan* p) {
+  return (p->xchunks > 1 && (p->nranks > 1 || p->force_slab) && !p->replicate && !p->generic && !p->unpacked) ? p->xchunks : 1;
+}
+size_t chunk_bytes(const rf_plan* p) { return p->w_bytes / (size_t)slab_chunks(p); }
+
+// (kz0c, nzlc >= 0: a sub-slab of this rank's planes instead of all of them -- W then points at the sub-slab's own region)
+int queue_x(rf_plan* p, const GenParams& gp, const void* kspace, void* W, hipStream_t sx, bool timed = false, int kz0c = -1, int nzlc = -1) {
   // resident deviates (the numpy stream replayed by rf_noise_mt19937) take the fast float32 sigma path too; host-supplied
   // deviates (RF_NOISE_EXTERNAL, the parity mode) keep the exact reference dtype chain
   // (float32 copies of the deviates exist for this path only, and it can store the potential too; float64 ones cannot)
@@ -392,8 +405,8 @@ int queue_x(rf_plan* p, const GenParams& gp, const void* kspace, void* W, hipStr
   const bool fast = (!kspace && gp.noise_mode == NOISE_PHILOX && p->have_fast && !p->exact_gen) || fast_noise;
   const bool rep = p->replicate && p->nranks > 1;
   RF_REQUIRE(!rep || fast, "replicated generation needs the native generator (fast path)");
-  const long long nzl = rep ? p->nzc : p->nzl;     // kz planes generated by this rank (nz/2 on one GPU)
-  const int kz0 = rep ? 0 : p->kz0;
+  const long long nzl = nzlc >= 0 ? nzlc : (rep ? p->nzc : p->nzl);     // kz planes generated by this call (nz/2 on one GPU)
+  const int kz0 = kz0c >= 0 ? kz0c : (rep ? 0 : p->kz0);
   // W == p->X: the blocked intermediate [x block][kz tile][ny][rb][TC] -- a tile (all nx rows of TC adjacent kz of one iy) is
   // nx / rb contiguous chunks of rb * TC cells there
   const ColGeom gx = (W == p->X && W != nullptr)
@@ -417,7 +430,24 @@ int queue_x(rf_plan* p, const GenParams& gp, const void* kspace, void* W, hipStr
 
 // x pass (generation or API k-space fused into its load) + y pass of buffer W on stream s.
 // Records ev[1] (after x) and ev[2] (after y) when `timed`.
+// the forward half of ONE sub-slab c of a plan that exchanges in chunks: x pass + y pass on its nzl / xchunks planes (region c of W)
+int queue_xy_chunk(rf_plan* p, const GenParams& gp, const void* kspace, void* W, hipStream_t s, int c) {
+  const int C = slab_chunks(p);
+  const long long nzc_ = p->nzl / C;
+  char* Wc = (char*)W + (size_t)c * chunk_bytes(p);
+  if (int rc = queue_x(p, gp, kspace, Wc, s, false, p->kz0 + c * (int)nzc_, (int)nzc_)) return rc;
+  const ColGeom gy{nzc_, (long long)p->ny * nzc_, nzc_};
+  RF_HIP(launch_col_plain(p->f64, p->ny, +1, Wc, gy, (long long)p->nx * nzc_, p->tw_y, s));
+  return 0;
+}
+
 int queue_xy(rf_plan* p, const GenParams& gp, const void* kspace, void* W, hipStream_t s, bool timed) {
+  if (slab_chunks(p) > 1) {
+    for (int c = 0; c < slab_chunks(p); ++c)
+      if (int rc = queue_xy_chunk(p, gp, kspace, W, s, c)) return rc;
+    if (timed) { RF_HIP(hipEventRecord(p->ev[5], s)); p->repair_timed = false; RF_HIP(hipEventRecord(p->ev[1], s)); RF_HIP(hipEventRecord(p->ev[2], s)); }
+    return 0;
+  }
   const bool rep = p->replicate && p->nranks > 1;
   const long long nzl = rep ? p->nzc : p->nzl, nxp = rep ? p->nxl : p->nx;      // the local array is [nxp][ny][nzl]
   const ColGeom gy{nzl, (long long)p->ny * nzl, nzl};
@@ -433,7 +463,8 @@ int queue_xy(rf_plan* p, const GenParams& gp, const void* kspace, void* W, hipSt
 int queue_z_slab(rf_plan* p, const void* R, void* W, double* stats_out, hipStream_t s) {
   const long long nrows = (long long)p->nxl * p->ny;
   const double scale = 1.0 / ((double)p->nx * (double)p->ny * (double)p->nz);
-  RF_HIP(launch_row_c2r_gather(p->f64, p->nzc, R, W, nrows, scale, p->nzl, nrows * p->nzl, p->tw_z, p->partials, s));
+  const long long nzseg = p->nzl / slab_chunks(p);            // planes per received segment: nranks * chunks of them make a row
+  RF_HIP(launch_row_c2r_gather(p->f64, p->nzc, R, W, nrows, scale, (int)nzseg, nrows * nzseg, p->tw_z, p->partials, s));
   RF_HIP(launch_reduce_partials(p->partials, p->npartials, stats_out, p->partials + 2 * p->npartials, s));
   p->cur = W;
   p->real_valid = true;
@@ -442,18 +473,32 @@ int queue_z_slab(rf_plan* p, const void* R, void* W, double* stats_out, hipStrea
 
 // multi-rank: the single all-to-all between the y and z passes.  Rank g sends to rank h the block
 // [x in slab h][all y][kz in slab g], which is contiguous in W because x is the slowest axis.
-int queue_exchange_rccl(rf_plan* p, const void* W, void* R, hipStream_t s) {
+// (chunk >= 0: sub-slab `chunk` only -- RF_FLAG_EXCHANGE_CHUNKS; -1: everything, all chunks of a chunked plan in ONE group;
+// plain = true: the unchunked block layout whatever the flag says, as the forward transform's reverse exchange uses it)
+int queue_exchange_rccl(rf_plan* p, const void* W, void* R, hipStream_t s, int chunk = -1, bool plain = false) {
   RF_REQUIRE(p->nranks == 1 || p->comm != nullptr, "rf_comm_init has not been called on this multi-rank plan");
-  const size_t blk = (size_t)p->nxl * p->ny * p->nzl * p->csize;
-  RF_HIP(hipMemcpyAsync((char*)R + p->rank * blk, (const char*)W + p->rank * blk, blk, hipMemcpyDeviceToDevice, s));
+  const int C = plain ? 1 : slab_chunks(p);
+  const size_t blk = (size_t)p->nxl * p->ny * p->nzl * p->csize / (size_t)C, cb = p->w_bytes / (size_t)C;
+  const int c0 = chunk >= 0 ? chunk : 0, c1 = chunk >= 0 ? chunk + 1 : C;
+  // block h of sub-slab c of W -> segment (this rank, c) of rank h's R
+  auto src = [&](int c, int h) { return (const char*)W + (size_t)c * cb + (size_t)h * blk; };
+  auto dst = [&](int c, int g) { return (char*)R + ((size_t)g * C + c) * blk; };
+  for (int c = c0; c < c1; ++c)
+    RF_HIP(hipMemcpyAsync(dst(c, p->rank), src(c, p->rank), blk, hipMemcpyDeviceToDevice, s));
   if (p->nranks == 1) return 0;        // forced slab path of a single-rank plan: the own block is everything
   RF_NCCL(g_rccl.GroupStart());
-  for (int h = 0; h < p->nranks; ++h) {
-    if (h == p->rank) continue;
-    RF_NCCL(g_rccl.Send((const char*)W + h * blk, blk, ncclUint8, h, p->comm, s));
-    RF_NCCL(g_rccl.Recv((char*)R + h * blk, blk, ncclUint8, h, p->comm, s));
-  }
+  for (int c = c0; c < c1; ++c)
+    for (int h = 0; h < p->nranks; ++h) {
+      if (h == p->rank) continue;
+      RF_NCCL(g_rccl.Send(src(c, h), blk, ncclUint8, h, p->comm, s));
+      RF_NCCL(g_rccl.Recv(dst(c, h), blk, ncclUint8, h, p->comm, s));
+    }
   RF_NCCL(g_rccl.GroupEnd());
+  return 0;
+}
+
+int ensure_comm_stream(rf_plan* p) {
+  if (!p->comm_stream) RF_HIP(hipStreamCreateWithFlags(&p->comm_stream, hipStreamNonBlocking));
   return 0;
 }
 
@@ -491,7 +536,7 @@ int slab_batch(rf_plan* p, const uint64_t* seeds, int n) {
   if (!p->W2) {
     RF_HIP(hipMalloc(&p->W2, p->w_bytes));
     RF_HIP(hipMalloc(&p->R2, p->w_bytes));
-    RF_HIP(hipStreamCreateWithFlags(&p->comm_stream, hipStreamNonBlocking));
+    if (int rc = ensure_comm_stream(p)) return rc;
     for (auto& e : p->pev) RF_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
   if (p->stats_cap < n) {
@@ -655,6 +700,40 @@ int queue_c2r(rf_plan* p, const GenParams& gp, const void* kspace) {
     p->cur = p->W;
     p->stats_slot = 0;
     p->real_valid = true;
+    p->stats_valid = true;
+    return 0;
+  }
+  if (slab_chunks(p) > 1) {
+    // ONE realisation, exchange overlapped with its own forward half: sub-slab c is generated and x / y-transformed on the plan's
+    // stream, its grouped send / receive goes to the exchange stream behind an event, the forward half of sub-slab c + 1 follows
+    // at once; the gathering z pass waits for the last sub-slab's exchange.  (The communicator is driven from the exchange stream
+    // only, the final all-reduce of the moments too.)
+    const int C = slab_chunks(p);
+    if (int rc = ensure_comm_stream(p)) return rc;
+    while ((int)p->chunk_ev.size() < C + 1) { hipEvent_t e; RF_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); p->chunk_ev.push_back(e); }
+    hipStream_t A = p->stream, X = p->comm_stream;
+    RF_HIP(hipEventRecord(p->chunk_ev[C], A));                 // (whatever used R / the communicator before on the plan's stream)
+    RF_HIP(hipStreamWaitEvent(X, p->chunk_ev[C], 0));
+    for (int c = 0; c < C; ++c) {
+      if (int rc = queue_xy_chunk(p, gp, kspace, p->W, A, c)) return rc;
+      RF_HIP(hipEventRecord(p->chunk_ev[c], A));
+      RF_HIP(hipStreamWaitEvent(X, p->chunk_ev[c], 0));
+      if (int rc = queue_exchange_rccl(p, p->W, p->R, X, c)) return rc;
+    }
+    if (p->timed) { RF_HIP(hipEventRecord(p->ev[5], A)); p->repair_timed = false; RF_HIP(hipEventRecord(p->ev[1], A)); RF_HIP(hipEventRecord(p->ev[2], A)); }
+    RF_HIP(hipEventRecord(p->chunk_ev[C], X));
+    RF_HIP(hipStreamWaitEvent(A, p->chunk_ev[C], 0));
+    if (int rc = queue_z_slab(p, p->R, p->W, p->stats, A)) return rc;
+    if (p->timed) RF_HIP(hipEventRecord(p->ev[3], A));
+    if (p->nranks > 1) {
+      RF_HIP(hipEventRecord(p->chunk_ev[C], A));
+      RF_HIP(hipStreamWaitEvent(X, p->chunk_ev[C], 0));
+      RF_NCCL(g_rccl.AllReduce(p->stats, p->stats, 2, ncclFloat64, ncclSum, p->comm, X));
+      RF_HIP(hipEventRecord(p->chunk_ev[C], X));
+      RF_HIP(hipStreamWaitEvent(A, p->chunk_ev[C], 0));
+    }
+    if (p->timed) RF_HIP(hipEventRecord(p->ev[4], A));
+    p->stats_slot = 0;
     p->stats_valid = true;
     return 0;
   }
@@ -926,6 +1005,7 @@ int rf_plan_destroy(rf_plan* p) {
   for (auto& ev : p->ev)
     if (ev) (void)hipEventDestroy(ev);
   for (auto& ev : p->slab_ev) (void)hipEventDestroy(ev);
+  for (auto& ev : p->chunk_ev) (void)hipEventDestroy(ev);
   for (auto& ev : p->bev)
     if (ev) (void)hipEventDestroy(ev);
   if (p->aux_stream) (void)hipStreamDestroy(p->aux_stream);
@@ -945,8 +1025,22 @@ int rf_plan_set_flag(rf_plan* p, int flag, int value) {
   RF_REQUIRE(p, "null plan");
   RF_REQUIRE(!p->unpacked, "this call does not apply to an unpacked c2c plan");
   RF_REQUIRE(flag == RF_FLAG_EXACT_GENERATION || flag == RF_FLAG_FORCE_SLAB_PATH || flag == RF_FLAG_REPLICATED_GENERATION ||
-             flag == RF_FLAG_TRANSPOSED_INTERMEDIATE || flag == RF_FLAG_YZ_SLAB_PLANES, "unknown flag");
+             flag == RF_FLAG_TRANSPOSED_INTERMEDIATE || flag == RF_FLAG_YZ_SLAB_PLANES || flag == RF_FLAG_EXCHANGE_CHUNKS, "unknown flag");
   RF_HIP(hipStreamSynchronize(p->stream));
+  if (p->comm_stream) RF_HIP(hipStreamSynchronize(p->comm_stream));
+  if (flag == RF_FLAG_EXCHANGE_CHUNKS) {         // sub-slabs of the exchange: 1 (or 0) = the whole kz slab at once
+    const int C = value <= 1 ? 1 : value;
+    RF_REQUIRE(!p->generic && !p->unpacked, "RF_FLAG_EXCHANGE_CHUNKS is for packed plans on the tiled kernels");
+    RF_REQUIRE((C & (C - 1)) == 0 && p->nzl % C == 0, "the number of exchange chunks must be a power of two that divides nz / (2 ranks)");
+    const long long nzc_ = p->nzl / C;
+    RF_REQUIRE(C == 1 || (nzc_ % 2 == 0 && ((long long)p->ny * nzc_) % col_tile_cols(p->f64, p->nx) == 0 &&
+                          ((long long)p->ny * nzc_) % col_gen_tile_cols(p->f64, p->nx) == 0 && ((long long)p->nx * nzc_) % col_tile_cols(p->f64, p->ny) == 0),
+               "too many exchange chunks for this grid: a sub-slab must hold an even number of planes and whole tiles of the x and y passes");
+    p->xchunks = C;
+    drop_graphs(p);
+    p->real_valid = false;                       // (the buffers' layout between the passes changes; nothing resident survives it)
+    return 0;
+  }
   if (flag == RF_FLAG_YZ_SLAB_PLANES) {          // -1 automatic, 0 whole-grid passes, > 0 x planes per slab
     p->yz_slab = value;
     drop_graphs(p);
@@ -1090,7 +1184,7 @@ int rf_execute_r2c(rf_plan* p) {
     RF_REQUIRE(!p->generic && !p->replicate, "the multi-rank forward transform runs on the tiled kernels of exchange-mode plans");
     RF_HIP(hipEventRecord(p->ev[0], p->stream));
     if (int rc = queue_r2c_slab_rows(p, p->stream)) return rc;
-    if (int rc = queue_exchange_rccl(p, p->R, p->W, p->stream)) return rc;
+    if (int rc = queue_exchange_rccl(p, p->R, p->W, p->stream, -1, true)) return rc;
     if (int rc = queue_r2c_slab_cols(p, p->stream)) return rc;
     RF_HIP(hipEventRecord(p->ev[4], p->stream));
     p->timed = false;
@@ -2292,10 +2386,13 @@ int rf_slab_exchange_local(rf_plan** plans, int n) {
     RF_HIP(hipStreamSynchronize(plans[g]->stream));
   }
   const rf_plan* p0 = plans[0];
-  const size_t blk = (size_t)p0->nxl * p0->ny * p0->nzl * p0->csize;
-  for (int g = 0; g < n; ++g)        // sender g, receiver h: block h of W_g -> block g of R_h
+  const int C = slab_chunks(p0);
+  for (int g = 0; g < n; ++g) RF_REQUIRE(slab_chunks(plans[g]) == C, "every rank must use the same number of exchange chunks");
+  const size_t blk = (size_t)p0->nxl * p0->ny * p0->nzl * p0->csize / (size_t)C, cb = p0->w_bytes / (size_t)C;
+  for (int g = 0; g < n; ++g)        // sender g, receiver h: block h of sub-slab c of W_g -> segment (g, c) of R_h
     for (int h = 0; h < n; ++h)
-      RF_HIP(hipMemcpy((char*)plans[h]->R + g * blk, (char*)plans[g]->W + h * blk, blk, hipMemcpyDeviceToDevice));
+      for (int c = 0; c < C; ++c)
+        RF_HIP(hipMemcpy((char*)plans[h]->R + ((size_t)g * C + c) * blk, (char*)plans[g]->W + (size_t)c * cb + (size_t)h * blk, blk, hipMemcpyDeviceToDevice));
   // a device-to-device hipMemcpy may return before the copy has run (it is only ordered on the null stream), and the
   // plans' streams do not synchronise with the null stream: without this the gathering z pass of a large grid read
   // blocks that had not arrived yet (caught by the full-size config-4 test; small grids happened to win the race)

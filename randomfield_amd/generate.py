@@ -155,6 +155,15 @@ class Generator(object):
             if nx % 2 or ny % 2 or nz % 2:
                 raise ValueError("All shape dimensions must be even.")
             self.plan_c2r = slab.SlabHostPlan(slab.DistributedPlan(nx, ny, nz, dtype), dtype)
+            # every call here is ONE realisation: its all-to-all is cut into sub-slabs that travel while the next sub-slab is
+            # still being generated and transformed (RF_FLAG_EXCHANGE_CHUNKS; the batch API pipelines whole realisations instead)
+            if self.plan_c2r.device.nranks > 1:
+                for chunks in (4, 2):
+                    try:
+                        self.plan_c2r.device.set_exchange_chunks(chunks)
+                        break
+                    except RuntimeError:
+                        continue
             # generate.py:79-80: the forward plan over the same memory (here: this rank's window of the field in, its kz planes out)
             self.plan_r2c = self.plan_c2r.create_reverse_plan(reuse_output=True, overwrite=True)
         else:

@@ -875,8 +875,106 @@ def test_config4_shapes_with_virtual_ranks(hip, dpower):
                 assert np.max(np.abs(got - ref[x])) <= 1e-6 * std, "plane %d of rank %d" % (x, r)
     cells = float(n) ** 3
     assert abs(np.sqrt(s2 / cells - (s1 / cells) ** 2) - std) <= 1e-7 * std
+    # the same job with the exchange in 4 sub-slabs per rank (RF_FLAG_EXCHANGE_CHUNKS: what a single generate_delta_field call of
+    # Generator(distributed=True) overlaps with its own forward half): 32-plane sub-slabs generated, transformed and handed over one
+    # by one, 32 segments of 256 B per row in the gathering z pass -- the same cells, the same arithmetic: not one bit differs
+    unchunked = {(r, x): p.download_real(x0=x - r * nxl, x1=x - r * nxl + 1).copy() for r, p in enumerate(plans) for x in planes
+                 if r * nxl <= x < (r + 1) * nxl}
+    for p in plans:
+        p.set_exchange_chunks(4)
+    for p in plans:
+        p.slab_forward(seed=4)
+    hip.DevicePlan.slab_exchange_local(plans)
+    for r, p in enumerate(plans):
+        p.slab_backward()
+        for x in planes:
+            if r * nxl <= x < (r + 1) * nxl:
+                assert np.array_equal(p.download_real(x0=x - r * nxl, x1=x - r * nxl + 1), unchunked[(r, x)]), "plane %d of rank %d, chunked" % (x, r)
     for p in plans:
         p.close()
+
+
+@pytest.mark.parametrize("shape,dtype,nranks,chunks", [((64, 32, 128), np.complex64, 2, 2), ((64, 32, 128), np.complex64, 4, 2), ((32, 64, 256), np.complex64, 2, 8),
+                                                       ((32, 16, 128), np.complex128, 2, 4), ((1024, 16, 256), np.complex64, 4, 2), ((2048, 8, 256), np.complex64, 2, 4)])
+def test_exchange_in_chunks_is_bit_identical(hip, dpower, shape, dtype, nranks, chunks):
+    """RF_FLAG_EXCHANGE_CHUNKS: a rank's kz slab generated, x / y-transformed and exchanged as `chunks` sub-slabs (layout
+    W = [chunk][nx][ny][nzl / chunks], R = [source][chunk][...]) gives the unchunked slab pipeline's field -- native
+    generator, host deviates through the exact chain, uploaded k space and the fused potential store -- and the reverse (r2c)
+    exchange keeps its own block layout."""
+    k, Pk = dpower
+    nx, ny, nz = shape
+    plans = _slab_plans(hip, shape, dtype, k, Pk, nranks)
+    noise = cpu_ref.reference_noise(5, nx * ny * (nz // 2 + 1))
+    want = {}
+    for C in (1, chunks):
+        for p in plans:
+            p.set_exchange_chunks(C)
+        got = {"native": _slab_run(hip, plans, seed=11), "host noise": _slab_run(hip, plans, noise=noise),
+               "potential": _slab_run(hip, plans, seed=11, source="potential")}
+        for p in plans:
+            p.generate(seed=12)
+        got["k space"] = _slab_run(hip, plans, source="kspace")
+        # forward transform of the field just made: rows, reverse exchange (block layout whatever the flag says), columns
+        for p in plans:
+            p.slab_r2c_rows()
+        hip.DevicePlan.slab_exchange_local_reverse(plans)
+        for p in plans:
+            p.slab_r2c_cols()
+        got["r2c"] = _slab_side_array(plans, lambda p: p.download_k(), nz // 2)
+        if C == 1:
+            want = got
+        else:
+            # the same cells through the same arithmetic; bit for bit wherever the same kernel instantiations run (sub-slabs
+            # narrower than an x-pass tile take the kernel that repairs kz = 0 in every tile: float32 rounding apart)
+            for key in want:
+                scale = np.abs(want[key]).max() if key == "r2c" else want[key].std()
+                assert np.max(np.abs(got[key] - want[key])) <= (2e-6 if dtype == np.complex64 else 1e-13) * scale, (key, C)
+            if shape[0] >= 1024:
+                assert np.array_equal(got["native"], want["native"]) and np.array_equal(got["k space"], want["k space"])
+    with pytest.raises(RuntimeError):
+        plans[0].set_exchange_chunks(3)                      # not a power of two
+    with pytest.raises(RuntimeError):
+        plans[0].set_exchange_chunks(1024)                   # sub-slabs thinner than a tile
+    for p in plans:
+        p.close()
+
+
+def test_one_realisation_overlaps_its_own_exchange(hip, dpower):
+    """The single-call path of a plan that exchanges in chunks (queue_c2r: forward half of sub-slab c on the plan's stream, its
+    exchange on the second stream behind an event, the z pass behind the last exchange) on ONE rank through the forced slab
+    path: field and moments of rf_realise, rf_realise_potential + the Newtonian potential, and the pipelined batch equal the
+    plain single-GPU plan's."""
+    k, Pk = dpower
+    shape = (256, 128, 256)
+    plain = make_plan(hip, shape, np.complex64, k, Pk)
+    slab = make_plan(hip, shape, np.complex64, k, Pk)
+    slab.set_force_slab_path(True)
+    slab.set_exchange_chunks(4)
+    for seed in (3, 4):                                      # (the second call reuses events and buffers)
+        plain.realise(seed=seed)
+        slab.realise(seed=seed)
+        std = plain.moments()[1]
+        assert np.max(np.abs(slab.download_real() - plain.download_real())) <= 1e-6 * std
+        assert abs(slab.moments()[1] - std) <= 1e-6 * std
+        assert len(slab.kernel_ms()) == 5
+    plain.realise_potential(seed=9)
+    slab.realise_potential(seed=9)
+    assert np.max(np.abs(slab.download_real() - plain.download_real())) <= 1e-6 * std
+    plain.load_potential(-1.5)
+    slab.load_potential(-1.5)
+    plain.execute_c2r()
+    slab.execute_c2r()
+    a, b = plain.download_real(), slab.download_real()
+    assert np.max(np.abs(a - b)) <= 2e-6 * a.std()
+    rms_ref = plain.realise_batch([5, 6, 7])
+    assert np.allclose(slab.realise_batch([5, 6, 7]), rms_ref, rtol=1e-6, atol=0)
+    assert np.max(np.abs(slab.download_real() - plain.download_real())) <= 1e-6 * std
+    slab.set_exchange_chunks(1)                              # and back
+    slab.realise(seed=3)
+    plain.realise(seed=3)
+    assert np.max(np.abs(slab.download_real() - plain.download_real())) <= 1e-6 * std
+    slab.close()
+    plain.close()
 
 
 def test_collectives_leave_the_moments_alone(hip, dpower):
