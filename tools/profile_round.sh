@@ -20,10 +20,8 @@ nslab=$(python3 -c "import json;print(json.load(open('$out/bench.json'))['pipeli
 python3 tools/make_traffic.py $(find $out/fetch -name "*counter_collection.csv") $(find $out/write -name "*counter_collection.csv") $out/traffic.json "$tag" $nslab > $out/traffic.txt
 cp $(find $out/stats -name "*kernel_stats.csv") $out/kernel_stats.csv
 rm -rf $out/fetch $out/write $out/sqa $out/sqb $out/stats
-# the other two kernel families: 2048^3 on one GPU (length-2048 passes) and the same-seed path (MT19937 replay + generation pass reading deviates)
-rocprofv3 --kernel-trace --stats -d $out/s2048 -o s --output-format csv -- python3 tools/bench2048.py - quick > $out/bench2048.log
-cp $(find $out/s2048 -name "*kernel_stats.csv") $out/kernel_stats_2048.csv
-rocprofv3 --kernel-trace --stats -d $out/sref -o s --output-format csv -- python3 tools/ref_prof.py 1024 single > /dev/null
-cp $(find $out/sref -name "*kernel_stats.csv") $out/kernel_stats_reference_path.csv
-rm -rf $out/s2048 $out/sref
+# every other BASELINE configuration / path: kernel stats, FETCH_SIZE / WRITE_SIZE and the SQ sets per configuration (tools/profile_cfg.sh)
+for c in ref 512 2048 f64 f64ln rank0 rank3; do
+  bash tools/profile_cfg.sh $out $c $c 3
+done
 ls $out
