@@ -143,8 +143,9 @@ template <typename T> ColGeom xposed_x_geom(int nx, int ny, long long nzl) {
 }
 
 template <class C, class IO>
-void run_row_c2r(const IO& io, long long nrows, const cplx<typename C::T>* tw, double* s1, double* s2) {
+void run_row_c2r(const IO& io_in, long long nrows, const cplx<typename C::T>* tw, double* s1, double* s2) {
   using F = RowC2R<C, IO>;
+  IO io = io_in;
   using cx = cplx<typename C::T>;
   std::vector<cx> lds((size_t)C::LDS_BYTES / sizeof(cx));
   std::vector<typename F::Regs> regs(C::NT);
@@ -152,6 +153,8 @@ void run_row_c2r(const IO& io, long long nrows, const cplx<typename C::T>* tw, d
   double a1 = 0, a2 = 0;
   for (long long tile = 0; tile < ntiles; ++tile) {
     for (int t = 0; t < C::NT; ++t) F::prologue(t, tw, lds.data());
+    if constexpr (row_io_wants_stage<IO>::value)           // (as row_c2r_kernel: the IO's table into the tile's spare slots, once per tile)
+      for (int t = 0; t < C::NT; ++t) io.template stage<C>(t, lds.data());
     const cx* ltw = F::lds_tw(lds.data());
     for (int t = 0; t < C::NT; ++t) F::pass_first(t, tile, nrows, io, ltw, lds.data(), regs[t]);
     if (C::NPASS == 3) {
@@ -547,14 +550,15 @@ int c2r_lognormal_impl(int nx, int ny, int nz, const cplx<T>* kspace, const doub
   std::vector<double> Ap(nz), Bp(nz);
   for (int z = 0; z < nz; ++z) {
     const double g = sigma * growth[z], t = g * g + 1.0;
-    Ap[z] = std::sqrt(std::log(t)) / sigma;
+    Ap[z] = std::sqrt(std::log(t)) / sigma * lognormal_ap_unit<T>(1.0 / n3);
     Bp[z] = (density ? density[z] : 1.0) / std::sqrt(t);
   }
   *sigma_out = sigma;
   auto twz = make_twiddles<T>(2 * (int)nzc);
-  LognormalRowIO<T> zio; zio.base = W; zio.scale = (T)(1.0 / n3); zio.M_of = (int)nzc; zio.Ap = Ap.data(); zio.Bp = Bp.data();
   switch ((int)nzc) {
-#define X(MM) case MM: run_row_c2r<typename RowSel<T, MM>::type, LognormalRowIO<T>>(zio, (long long)nx * ny, twz.data(), s1, s2); return 0;
+#define X(MM) case MM: { constexpr int SP = (sizeof(T) == 8 && MM >= 512) ? 1 : 0;              /* as rf_k_row.hip launch_lognormal_t */  \
+    LognormalRowIO<T, SP> zio; zio.base = W; zio.scale = (T)(1.0 / n3); zio.M_of = (int)nzc; zio.Ap = Ap.data(); zio.Bp = Bp.data();       \
+    run_row_c2r<typename RowSel<T, MM>::type, LognormalRowIO<T, SP>>(zio, (long long)nx * ny, twz.data(), s1, s2); return 0; }
     RF_ROW_SIZES(X)
 #undef X
     default: return -1;

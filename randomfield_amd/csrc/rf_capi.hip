@@ -1542,7 +1542,7 @@ int rf_realise_lognormal(rf_plan* p, uint64_t seed, int mode, const double* nois
   RF_HIP(launch_col_plain_acc(p->f64, p->ny, p->W, gy, (long long)p->nx * nzl, p->kz0, (int)nzl, p->ypart, p->tw_y, s));
   // rms = sqrt(S / (nx ny)) / N3  (rf_fft.h AccColIO)
   RF_HIP(launch_lognormal_tables(p->ypart, ntiles, 1.0 / ((double)p->nx * (double)p->ny * n3 * n3), growth, p->ln_density ? dens : nullptr, p->nz,
-                                 p->f64 ? 0 : 1, sig, A, B, s));
+                                 p->f64 ? 0 : 1, p->f64 ? lognormal_ap_unit<double>(scale) : 1.0, sig, A, B, s));
   RF_HIP(hipEventRecord(p->ev[2], s));
   RF_HIP(launch_row_c2r_lognormal(p->f64, (int)p->nzc, p->W, (long long)p->nx * p->ny, scale, A, B, p->tw_z, p->partials, s));
   RF_HIP(hipEventRecord(p->ev[3], s));

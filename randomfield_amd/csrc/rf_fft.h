@@ -21,6 +21,7 @@
 #pragma once
 #include <type_traits>
 #include "rf_core.h"
+#include "rf_exp2_tab.h"
 
 namespace rf {
 
@@ -1131,28 +1132,152 @@ template <typename T> struct XGatherRowIO {
 // rounding-exact, unfused form).  Element n of a row holds the reals z = 2n, 2n + 1; the tables are 16 KB, L1-resident.
 RF_HD float exp_t(float x) { return expf(x); }
 RF_HD double exp_t(double x) { return exp(x); }
-template <typename T> struct LognormalRowIO {
+// float64 plans: exp(t ln2 / 64) for an argument already in units of ln2 / 64 (the table Ap carries the factor 64 / ln2, lognormal_ap_unit):
+// t = k + f, |f| <= 1/2, k = 64 e + j: 2^e * 2^(j/64) * exp(f ln2/64), the middle factor from a 64-entry table in LDS (rf_exp2_tab.h,
+// correctly rounded), the last a degree-5 polynomial (|r| <= 0.0055: the first dropped term is 4e-17).  13 float64-rate instructions
+// and one ds_read_b64 per element where the library's exp takes ~22 (no table: a degree-11 polynomial, range checks); the z pass of a
+// float64 plan issues 16 of them per thread.  |error| <= 1 ulp of the result + the rounding of t (ulp(t) ln2 / 128 <= 6e-16 at
+// |x| = 5.5): the same size as the rounding of the product delta * Ap that both forms share.  Out-of-range arguments saturate through
+// the conversion and ldexp (inf / 0), NaN propagates through r.
+#if defined(__HIP_DEVICE_COMPILE__)
+static __device__ const double rf_exp2_tab[64] = {RF_EXP2_TAB_VALUES};
+#else
+static const double rf_exp2_tab[64] = {RF_EXP2_TAB_VALUES};
+#endif
+// the factor the float64 z pass expects in Ap: 64 / ln 2 (the unit of exp_scaled64) times the transform's 1 / (nx ny nz)
+template <typename T> RF_HD double lognormal_ap_unit(double scale) { return sizeof(T) == 8 ? 0x1.71547652b82fep+6 /* 64 / ln 2 */ * scale : 1.0; }
+RF_HD int exp_k_of(double kf) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (int)kf;                                         // (v_cvt_i32_f64 saturates)
+#else
+  return kf > 1e9 ? 1000000000 : (kf < -1e9 ? -1000000000 : (kf == kf ? (int)kf : 0));
+#endif
+}
+// 2^(k >> 6) * tj * exp(c f), c = ln 2 / 64, tj = 2^((k & 63) / 64)
+RF_HD double exp_finish(double f, double tj, int k) {
+  // exp(c f) - 1 = f (c + f (c^2/2 + f (c^3/6 + f (c^4/24 + f c^5/120))))
+  double q = __builtin_fma(f, 0x1.5d87fe78a6731p-40 /* c^5/120 */, 0x1.3b2ab6fba4e77p-31 /* c^4/24 */);
+  q = __builtin_fma(f, q, 0x1.c6b08d704a0c0p-23 /* c^3/6 */);
+  q = __builtin_fma(f, q, 0x1.ebfbdff82c58fp-15 /* c^2/2 */);
+  q = __builtin_fma(f, q, 0x1.62e42fefa39efp-7 /* c */);
+  return __builtin_ldexp(__builtin_fma(tj, f * q, tj), k >> 6);
+}
+template <int STRIDE = 1> RF_HD double exp_scaled64(double t, const double* tab) {
+  const double kf = __builtin_rint(t);
+  const double f = t - kf;                                // exact
+  const int k = exp_k_of(kf);
+  const double tj = tab ? tab[(k & 63) * STRIDE] : 1.0;    // (tab is never null in the product)
+  return exp_finish(f, tj, k);
+}
+// Where the table lives: the LDS row image skips every ninth complex (pad16), so row 0 of a tile of rows of M >= 512 complex128 has 64
+// unused 16-byte slots at 9 j + 8 -- entry j goes there (stage(), 64 threads, in front of the kernel's first barrier; nothing else
+// ever touches those slots).  Measured at 1024^3 float64 on MI355X (z pass, plain 3.12 ms): the library's exp 3.65, the table read
+// from global memory 3.62 (a 64-lane gather per element), from 512 more bytes of LDS 4.48 (the pass fills a third of the CU's LDS
+// to within one allocation unit: two workgroups per CU instead of three), from the pad slots: see DESIGN.md section 3.9.
+template <typename T, int SPARE = 0> struct LognormalRowIO {
+  static_assert(SPARE == 0 || sizeof(T) == 8, "the exp table is the float64 plans'");
   cplx<T>* base;
   T scale;                       // 1 / (nx ny nz)
   int M_of;
-  const double* Ap;              // [2 M] sqrt(log t_z) / sigma
+  const double* Ap;              // [2 M] sqrt(log t_z) / sigma  (float64 plans: times lognormal_ap_unit)
   const double* Bp;              // [2 M] density_z / sqrt(t_z)
+  const double* etab = nullptr;  // SPARE: rf_exp2_tab in the pad slots of the tile's row 0
+  static constexpr bool WANTS_STAGE = SPARE != 0;
+  static constexpr int ESTRIDE = SPARE ? 18 : 1;        // doubles between two entries
+  template <class C> RF_HD void stage(int tid, void* lds) {
+    static_assert(!SPARE || (C::NPASS >= 2 && C::RS >= 9 * 63 + 8 + 1), "64 pad slots in row 0");
+    double* l = reinterpret_cast<double*>(lds) + 16;
+    if (tid < 64) l[18 * tid] = rf_exp2_tab[tid];
+    etab = l;
+  }
   RF_HD int gather_seg_shift() const { return -1; }
-  RF_HD T map(T d, int z) const {
-    d = (T)((double)d * Ap[z]);
+  RF_HD float map(float d, int z) const {
+    d = (float)((double)d * Ap[z]);
     d = exp_t(d);
-    return (T)((double)d * Bp[z]);
+    return (float)((double)d * Bp[z]);
+  }
+  RF_HD double map(double d, int z) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double* tb = SPARE ? etab : rf_exp2_tab;
+#else
+    const double* tb = (SPARE && etab) ? etab : rf_exp2_tab;        // (the emulator has no staging step)
+    if (!(SPARE && etab)) return exp_scaled64<1>(d * Ap[z], tb) * Bp[z];
+#endif
+#ifdef RF_LN_AB                    // (ablation builds only: bit 0 = uniform table entries, bit 1 = no gather)
+    if (RF_LN_AB & 1) z = 0;
+    if (RF_LN_AB & 2) tb = nullptr;
+#endif
+    return exp_scaled64<ESTRIDE>(d * Ap[z], tb) * Bp[z];
   }
   RF_HD cplx<T> load(long long row, int k) const { return stream_load(base + row * (long long)M_of + k); }
   RF_HD void store(long long row, int n, cplx<T> z, MomAcc<T>& mom) const {
-    z.x = map(z.x * scale, 2 * n);
-    z.y = map(z.y * scale, 2 * n + 1);
+    if (sizeof(T) == 8) {          // (float64 plans: 1 / (nx ny nz) is part of Ap too)
+      z.x = map(z.x, 2 * n);
+      z.y = map(z.y, 2 * n + 1);
+    } else {
+      z.x = map(z.x * scale, 2 * n);
+      z.y = map(z.y * scale, 2 * n + 1);
+    }
     stream_store(base + row * (long long)M_of + n, z);
     mom.add(z);
   }
   template <int NRT> RF_HD cplx<T> load2(long long tile, int rl, int kb, int ko) const { return load(tile * NRT + rl, kb + ko); }
   template <int NRT> RF_HD void store2(long long tile, int rl, int nb, int no, cplx<T> z, MomAcc<T>& mom) const { store(tile * NRT + rl, nb + no, z, mom); }
+  // the last pass of a multi-pass row: the 2 R entries of Ap and Bp first (RowC2R::pass_last), then all R outputs in one call --
+  // for float64 in phases (arguments and table reads of all 2 R elements, then the polynomials, then the stores)
+  static constexpr bool HAS_PRE = true;
+  template <int R> struct Pre { double a[2 * R], b[2 * R]; };
+  template <int R> RF_HD void prefetch(int j, int L, Pre<R>& p) const {
+#pragma unroll
+    for (int m = 0; m < R; ++m) {
+      const int z = 2 * (j + m * L);
+      p.a[2 * m] = Ap[z]; p.a[2 * m + 1] = Ap[z + 1];
+      p.b[2 * m] = Bp[z]; p.b[2 * m + 1] = Bp[z + 1];
+    }
+  }
+  template <int NRT, int R> RF_HD void store_row(long long tile, int rl, int j, int L, const cplx<T>* v, MomAcc<T>& mom, const Pre<R>& p) const {
+    cplx<T>* const out = base + (tile * NRT + rl) * (long long)M_of + j;
+    if constexpr (sizeof(T) == 8) {
+#if defined(__HIP_DEVICE_COMPILE__)
+      const double* tb = SPARE ? etab : rf_exp2_tab;
+      constexpr int ES = ESTRIDE;
+#else
+      const double* tb = (SPARE && etab) ? etab : rf_exp2_tab;
+      const int ES = (SPARE && etab) ? ESTRIDE : 1;
+#endif
+      double f[2 * R], tj[2 * R];
+      int k[2 * R];
+#pragma unroll
+      for (int i = 0; i < 2 * R; ++i) {
+        const double t = ((i & 1) ? v[i / 2].y : v[i / 2].x) * p.a[i];
+        const double kf = __builtin_rint(t);
+        f[i] = t - kf;
+        k[i] = exp_k_of(kf);
+        tj[i] = tb[(k[i] & 63) * ES];
+      }
+#pragma unroll
+      for (int m = 0; m < R; ++m) {
+        cplx<T> z;
+        z.x = (T)(exp_finish(f[2 * m], tj[2 * m], k[2 * m]) * p.b[2 * m]);
+        z.y = (T)(exp_finish(f[2 * m + 1], tj[2 * m + 1], k[2 * m + 1]) * p.b[2 * m + 1]);
+        stream_store(out + m * L, z);
+        mom.add(z);
+      }
+    } else {
+#pragma unroll
+      for (int m = 0; m < R; ++m) {
+        cplx<T> z;
+        z.x = (T)((double)exp_t((T)((double)(v[m].x * scale) * p.a[2 * m])) * p.b[2 * m]);
+        z.y = (T)((double)exp_t((T)((double)(v[m].y * scale) * p.a[2 * m + 1])) * p.b[2 * m + 1]);
+        stream_store(out + m * L, z);
+        mom.add(z);
+      }
+    }
+  }
 };
+// does a row IO stage something into the tile's spare LDS slots at the start of the kernel?
+template <class IO, class = void> struct row_io_wants_stage { static constexpr bool value = false; };
+template <class IO> struct row_io_wants_stage<IO, typename std::enable_if<IO::WANTS_STAGE>::type> { static constexpr bool value = true; };
 
 // z pass whose store multiplies plane z by a per-z factor (float64 table, the rounding of rf_scale_z on the stored field): the
 // light-cone weighting G(z) / (1 + z) of calculate_newtonian_potential (generate.py:344-347) without a sweep of its own
@@ -1171,6 +1296,32 @@ template <typename T> struct ScaleZRowIO {
   }
   template <int NRT> RF_HD cplx<T> load2(long long tile, int rl, int kb, int ko) const { return load(tile * NRT + rl, kb + ko); }
   template <int NRT> RF_HD void store2(long long tile, int rl, int nb, int no, cplx<T> z, MomAcc<T>& mom) const { store(tile * NRT + rl, nb + no, z, mom); }
+  // (the table entries in front of the last pass, as LognormalRowIO)
+  static constexpr bool HAS_PRE = true;
+  template <int R> struct Pre { double s[2 * R]; };
+  template <int R> RF_HD void prefetch(int j, int L, Pre<R>& p) const {
+#pragma unroll
+    for (int m = 0; m < R; ++m) { p.s[2 * m] = Sz[2 * (j + m * L)]; p.s[2 * m + 1] = Sz[2 * (j + m * L) + 1]; }
+  }
+  template <int NRT, int R> RF_HD void store_row(long long tile, int rl, int j, int L, const cplx<T>* v, MomAcc<T>& mom, const Pre<R>& p) const {
+    cplx<T>* const out = base + (tile * NRT + rl) * (long long)M_of + j;
+#pragma unroll
+    for (int m = 0; m < R; ++m) {
+      cplx<T> z;
+      z.x = (T)((double)(v[m].x * scale) * p.s[2 * m]);
+      z.y = (T)((double)(v[m].y * scale) * p.s[2 * m + 1]);
+      stream_store(out + m * L, z);
+      mom.add(z);
+    }
+  }
+};
+
+// does a row IO fetch table entries ahead of the last pass (IO::Pre<R>, prefetch<R>(), store_row<NRT, R>())?
+struct RowNoPre {};
+template <class IO, int R, class = void> struct row_io_pre { static constexpr bool value = false; using type = RowNoPre; };
+template <class IO, int R> struct row_io_pre<IO, R, typename std::enable_if<IO::HAS_PRE>::type> {
+  static constexpr bool value = true;
+  using type = typename IO::template Pre<R>;
 };
 
 // tw = exp(+2 pi i q / (2M)), q in [0, 2M): t_k = tw[k], w_M^q = tw[2q]
@@ -1344,6 +1495,12 @@ struct RowC2R {
       const long long row = tile * C::NRT + rl;
       if (rl < C::NRT && row < nrows) {
         cx v[R];
+        // IOs whose store needs per-z table entries (LognormalRowIO, ScaleZRowIO) fetch the thread's 2 R entries HERE, in front of the
+        // LDS reads and the butterfly, and store the R outputs in one call: written per element (load table -> map -> store) the
+        // epilogue is R round trips in a row -- on gfx950 a load issued behind a store is waited for through the same counter
+        // as the store (vmcnt, in order), so every element waited for the previous element's write to retire
+        typename row_io_pre<IO, R>::type pre;
+        if constexpr (row_io_pre<IO, R>::value) io.template prefetch<R>(j, L, pre);
         const cx* const rd = lds_at(lds, rl, j);
 #pragma unroll
         for (int m = 0; m < R; ++m) {
@@ -1352,8 +1509,12 @@ struct RowC2R {
           v[m] = x;
         }
         DFT<R, DIR>::run(v);
+        if constexpr (row_io_pre<IO, R>::value) {
+          io.template store_row<C::NRT, R>(tile, rl, j, L, v, r.mom, pre);
+        } else {
 #pragma unroll
-        for (int m = 0; m < R; ++m) io.template store2<C::NRT>(tile, rl, j, m * L, v[m], r.mom);
+          for (int m = 0; m < R; ++m) io.template store2<C::NRT>(tile, rl, j, m * L, v[m], r.mom);
+        }
       }
     }
   }

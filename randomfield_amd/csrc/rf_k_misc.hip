@@ -43,20 +43,31 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const double* __re
 // sigma of the field from the y pass's Parseval partials (AccColIO), and the tables of the fused lognormal map that depend on it
 // (cosmotools.py:216: t = 1 + (sigma growth_z)^2): Ap = sqrt(log t) / sigma, Bp = density / sqrt(t).  One workgroup; fixed
 // summation order.  `sigma_as_float`: the reference's sigma is np.std of the array, a float32 for float32 data -- same here.
-__global__ __launch_bounds__(256) void lognormal_tables_kernel(const double* __restrict__ partials, long long n, double norm,
-                                                               const double* __restrict__ growth, const double* __restrict__ density,
-                                                               int nz, int sigma_as_float,
-                                                               double* __restrict__ sig, double* __restrict__ Ap, double* __restrict__ Bp) {
-  __shared__ double red[4];
+// (1024 threads, four independent accumulators each: the ~10^5 partials of a 1024^3 grid are summed with the loads in flight -- the
+// 256-thread serial form took 0.11 ms, a latency chain of 512 dependent loads per thread.)  `ap_unit`: float64 plans hand the z pass
+// Ap in units of ln2 / 64 (rf_fft.h exp_scaled64).
+__global__ __launch_bounds__(1024) void lognormal_tables_kernel(const double* __restrict__ partials, long long n, double norm,
+                                                                const double* __restrict__ growth, const double* __restrict__ density,
+                                                                int nz, int sigma_as_float, double ap_unit,
+                                                                double* __restrict__ sig, double* __restrict__ Ap, double* __restrict__ Bp) {
+  __shared__ double red[16];
   __shared__ double sh_sigma;
-  double a = 0;
-  for (long long i = threadIdx.x; i < n; i += blockDim.x) a += partials[i];
+  double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+  const long long nt = blockDim.x;
+  long long i = threadIdx.x;
+  for (; i + 3 * nt < n; i += 4 * nt) {
+    a0 += partials[i]; a1 += partials[i + nt]; a2 += partials[i + 2 * nt]; a3 += partials[i + 3 * nt];
+  }
+  for (; i < n; i += nt) a0 += partials[i];
+  double a = (a0 + a1) + (a2 + a3);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
   __syncthreads();
   if (threadIdx.x == 0) {
-    double sigma = sqrt((red[0] + red[1] + red[2] + red[3]) * norm);
+    double t = 0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
+    double sigma = sqrt(t * norm);
     if (sigma_as_float) sigma = (double)(float)sigma;
     sh_sigma = sigma;
     sig[0] = sigma;
@@ -65,7 +76,7 @@ __global__ __launch_bounds__(256) void lognormal_tables_kernel(const double* __r
   const double sigma = sh_sigma;
   for (int z = threadIdx.x; z < nz; z += blockDim.x) {
     const double g = sigma * growth[z], t = g * g + 1.0;      // np.square(sigma * growth) + 1
-    Ap[z] = sqrt(log(t)) / sigma;
+    Ap[z] = sqrt(log(t)) / sigma * ap_unit;
     Bp[z] = (density ? density[z] : 1.0) / sqrt(t);
   }
 }
@@ -378,8 +389,8 @@ hipError_t launch_reduce_partials(const double* partials, long long n, double* s
 }
 
 hipError_t launch_lognormal_tables(const double* partials, long long n, double norm, const double* growth, const double* density, int nz,
-                                   int sigma_as_float, double* sig, double* A, double* B, hipStream_t s) {
-  hipLaunchKernelGGL(lognormal_tables_kernel, dim3(1), dim3(256), 0, s, partials, n, norm, growth, density, nz, sigma_as_float, sig, A, B);
+                                   int sigma_as_float, double ap_unit, double* sig, double* A, double* B, hipStream_t s) {
+  hipLaunchKernelGGL(lognormal_tables_kernel, dim3(1), dim3(1024), 0, s, partials, n, norm, growth, density, nz, sigma_as_float, ap_unit, sig, A, B);
   return hipGetLastError();
 }
 

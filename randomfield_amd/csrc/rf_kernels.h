@@ -205,6 +205,7 @@ __global__ __launch_bounds__(C::NT) void row_c2r_kernel(IO io, const cplx<typena
   typename F::TwRegs twr;
   const cx* ltw = F::lds_tw(lds);
   F::tw_fetch(tid, tw, twr);                 // twiddles global -> registers
+  if constexpr (row_io_wants_stage<IO>::value) io.template stage<C>(tid, rf_smem);   // (the IO's table -> spare LDS slots of the tile, in front of the first barrier)
   if constexpr (sizeof(typename C::T) == 4) {
     // ... then the rows global -> registers: both trips to memory in flight together; the (older) table loads are waited for first
     typename F::In in;

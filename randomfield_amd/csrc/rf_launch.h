@@ -85,7 +85,7 @@ hipError_t launch_col_plain_acc(int f64, int N, void* base, ColGeom g, long long
 // sig[0] = sigma = sqrt(norm * sum of the n partials) (rounded to float32 first when sigma_as_float), Ap[z] = sqrt(log t) / sigma,
 // Bp[z] = density[z] / sqrt(t) (density may be null: 1), t = 1 + (sigma growth[z])^2
 hipError_t launch_lognormal_tables(const double* partials, long long n, double norm, const double* growth, const double* density, int nz,
-                                   int sigma_as_float, double* sig, double* Ap, double* Bp, hipStream_t s);
+                                   int sigma_as_float, double ap_unit, double* sig, double* Ap, double* Bp, hipStream_t s);
 // z pass with rho = exp(delta Ap_z) Bp_z in its epilogue (rf_fft.h LognormalRowIO)
 hipError_t launch_row_c2r_lognormal(int f64, int M, void* W, long long nrows, double scale, const double* Ap, const double* Bp,
                                     const void* tw, double* partials, hipStream_t s, bool prepare_only = false);

@@ -394,7 +394,8 @@ def test_gathering_z_pass(M, nx, ny, tc, rb, dtype):
     assert abs(s2.value - (out.astype(np.float64) ** 2).sum()) <= 1e-6 * s2.value
 
 
-@pytest.mark.parametrize("shape,dtype", [((16, 16, 32), np.complex64), ((32, 16, 64), np.complex128), ((64, 64, 64), np.complex64)])
+@pytest.mark.parametrize("shape,dtype", [((16, 16, 32), np.complex64), ((32, 16, 64), np.complex128), ((64, 64, 64), np.complex64),
+                                         ((8, 8, 1024), np.complex128)])     # (rows of 512 complex128: the exp table in the tile's pad slots)
 def test_fused_lognormal_pipeline(shape, dtype):
     """The phase functions behind rf_realise_lognormal on the CPU: the accumulating y pass (AccColIO) gives, by Parseval, the rms
     of the field the z pass is about to produce, and the z pass's epilogue (LognormalRowIO) maps it like the reference's

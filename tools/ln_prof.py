@@ -9,6 +9,8 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from randomfield_amd import _hip, cosmotools, powertools   # noqa: E402
 
+if os.environ.get("RF_LIB"):
+    _hip.LIB_PATH = os.path.abspath(os.environ["RF_LIB"])
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 dt = np.complex64 if len(sys.argv) > 2 and sys.argv[2] == "f32" else np.complex128
 power = powertools.load_default_power()
@@ -37,4 +39,6 @@ for name, fn in (("plain realisation", lambda s: plan.realise(seed=s)), ("unfuse
         plan.sync()
         ts.append((time.perf_counter() - t0) * 1e3)
     print("%s %s %d^3: %s ms" % (name, np.dtype(dt).name, n, " ".join("%.3f" % t for t in ts)), flush=True)
+    if name != "unfused":
+        print("   kernel_ms (x, y, z, reduce):", " ".join("%.3f" % t for t in plan.kernel_ms()), flush=True)
 plan.close()
