@@ -542,19 +542,24 @@ struct FastGenColIO64 {
     rec = l;
   }
   RF_HD void bind_seed() { if (gp.seed_dev) { gp.seed = pin_uniform(*gp.seed_dev); gp.seed_dev = nullptr; } }
-  RF_HD V16<double> load(long long C0, int cl, int rb, int ro) const {
-    const long long C = C0 + cl;
-    const uint64_t seed = gp.seed;                                                      // bind_seed() ran first
-    const int iy = (int)((unsigned)C >> nzl_shift()), kz = kz0 + (int)((unsigned)C & (unsigned)(nzl - 1));   // lane, m-invariant
+  // the cell of row (rb, ro) in column C: its native noise index (lane part + uniform part) and |k|^2
+  RF_HD void cell_of(long long C, int rb, int ro, int& iy, int& kz, uint64_t& ci_l, uint64_t& ci_u, float& k2) const {
+    iy = (int)((unsigned)C >> nzl_shift());
+    kz = kz0 + (int)((unsigned)C & (unsigned)(nzl - 1));                                // lane, m-invariant
     const uint64_t plane = (uint64_t)gp.ny * (uint64_t)(gp.nz / 2);                    // noise cells per unit of ix
     // mode index ix = XS (rb + ro) + xp = (lane part rbt) + (uniform part rot), as in FastGenColIOT
     const int rbt = XS * rb, rot = XS * ro + (XS == 2 ? xp : 0);
-    const uint64_t ci_l = (uint64_t)rbt * plane + (uint64_t)iy * (uint64_t)(gp.nz / 2) + (uint64_t)kz;
-    const uint64_t ci_u = pin_uniform((uint64_t)rot * plane);
+    ci_l = (uint64_t)rbt * plane + (uint64_t)iy * (uint64_t)(gp.nz / 2) + (uint64_t)kz;
+    ci_u = pin_uniform((uint64_t)rot * plane);
     const int ro_s = XS * ro >= (gp.nx >> 1) ? rot - gp.nx : rot;
     const float kx = (float)(rbt + ro_s) * gp.dkx, ky = (float)fast_signed_index(iy, gp.ny) * gp.dky;
-    const float k2 = fast_k2(gp, fmaf(kx, kx, ky * ky), kz);
-    const cplx<float> c = fast_gen_one(gp, rec, seed, ci_l + ci_u, k2);
+    k2 = fast_k2(gp, fmaf(kx, kx, ky * ky), kz);
+  }
+  // the cell's value from its two Philox words (Box-Muller, sigma) + the potential variants
+  RF_HD V16<double> cell_from_words(uint32_t wa, uint32_t wb, float k2, int iy, int kz, int rb, int ro) const {
+    float g0, g1;
+    BoxMuller<float>::run_scaled(wa, wb, fast_sigma(gp, rec, k2), g0, g1);
+    const cplx<float> c = mk<float>(g0, g1);
     V16<double> v;
     v.c[0] = mk<double>((double)c.x, (double)c.y);
     if (POT == 2) {
@@ -568,6 +573,39 @@ struct FastGenColIO64 {
       v16_store<double>((pot + (long long)ro * gp.ny * gp.ppitch) + (uint32_t)((rb * gp.ny + iy) * gp.ppitch + (kz - gp.zoff)), q);
     }
     return v;
+  }
+  RF_HD V16<double> load(long long C0, int cl, int rb, int ro) const {
+    int iy, kz;
+    uint64_t ci_l, ci_u;
+    float k2;
+    cell_of(C0 + cl, rb, ro, iy, kz, ci_l, ci_u, k2);
+    const uint64_t ci = ci_l + ci_u;
+    const PhiloxOut o = philox_native(ci >> 1, 0, gp.seed);                             // bind_seed() ran first
+    const bool odd = (ci & 1u) != 0;
+    return cell_from_words(odd ? o.w[2] : o.w[0], odd ? o.w[3] : o.w[1], k2, iy, kz, rb, ro);
+  }
+  // Two rows at once.  A Philox call serves the cell pair (kz even, kz + 1) of one row, and with one complex128 per lane that pair sits
+  // in the lane pair (2l, 2l + 1): load() has both lanes run the same call and keep half of it.  Here the even lane runs row A's call
+  // and the odd lane row B's; each sends the half its neighbour needs across (one quad-permute DPP move per word) -- one call per lane
+  // and two rows instead of two (230 -> 118 v_mad_u64_u32 per thread in the 1024-point kernel).  Same words, same field.
+  static constexpr bool HAS_LOAD_PAIR = true;
+  RF_HD void load_pair(long long C0, int cl, int rb, int roA, int roB, V16<double>& a, V16<double>& b) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+    int iy, kz, iy2, kz2;
+    uint64_t ci_l, cuA, cuB, ci_l2;
+    float k2A, k2B;
+    cell_of(C0 + cl, rb, roA, iy, kz, ci_l, cuA, k2A);
+    cell_of(C0 + cl, rb, roB, iy2, kz2, ci_l2, cuB, k2B);
+    const bool odd = (kz & 1) != 0;                                                      // (the rest of the noise index is even: nz / 2 is)
+    const PhiloxOut o = philox_native((ci_l + (odd ? cuB : cuA)) >> 1, 0, gp.seed);
+    const uint32_t ra = (uint32_t)__builtin_amdgcn_mov_dpp((int)(odd ? o.w[0] : o.w[2]), 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+    const uint32_t rb2 = (uint32_t)__builtin_amdgcn_mov_dpp((int)(odd ? o.w[1] : o.w[3]), 0xB1, 0xF, 0xF, true);
+    a = cell_from_words(odd ? ra : o.w[0], odd ? rb2 : o.w[1], k2A, iy, kz, rb, roA);
+    b = cell_from_words(odd ? o.w[2] : ra, odd ? o.w[3] : rb2, k2B, iy, kz, rb, roB);
+#else
+    a = load(C0, cl, rb, roA);
+    b = load(C0, cl, rb, roB);
+#endif
   }
   static constexpr bool ROLLED_LOAD = false;
   RF_HD long long remap_tile(long long t) const { return t; }
@@ -606,6 +644,8 @@ struct FastGenColIO64 {
 
 // Does the IO split its load into an early memory part and a late arithmetic part (preload() / load_pre())?  Only the deviate-reading
 // generation pass does: its loads are issued at the very top of the kernel, in front of the table staging and its barrier.
+template <class IO, class = void> struct io_has_load_pair { static constexpr bool value = false; };
+template <class IO> struct io_has_load_pair<IO, typename std::enable_if<IO::HAS_LOAD_PAIR>::type> { static constexpr bool value = true; };
 template <class IO, class = void> struct io_has_preload { static constexpr bool value = false; };
 template <class IO> struct io_has_preload<IO, typename std::enable_if<IO::HAS_PRELOAD>::type> { static constexpr bool value = true; };
 
@@ -713,6 +753,15 @@ struct ColFFT {
             for (int c = 0; c < CPL; ++c) v[c][m] = x.c[c];
           }
         } else {
+          if constexpr (io_has_load_pair<IO>::value && R % 2 == 0 && !PRELOAD) {
+#pragma unroll
+            for (int m = 0; m < R; m += 2) {                 // (IOs that generate two rows for the price of one: FastGenColIO64)
+              V xa, xb;
+              io.load_pair(C0, cl, j, m * L, (m + 1) * L, xa, xb);
+#pragma unroll
+              for (int c = 0; c < CPL; ++c) { v[c][m] = xa.c[c]; v[c][m + 1] = xb.c[c]; }
+            }
+          } else {
 #pragma unroll
           for (int m = 0; m < R; ++m) {
             V x;
@@ -721,6 +770,7 @@ struct ColFFT {
 #pragma unroll
             for (int c = 0; c < CPL; ++c) v[c][m] = x.c[c];
             IO::sched_fence(m);
+          }
           }
         }
         if (PRE) {
