@@ -37,7 +37,7 @@ int rf_version(void);                            /* 100*major + minor */
 const char* rf_last_error(void);
 int rf_device_count(int* count);
 /* is this grid shape supported by the HIP kernels?  1: tiled power-of-two kernels (nx, ny in 8..2048, nz in 16..2048);
- * 2: generic mixed-radix kernels (any other even nx, ny, nz up to 2048 -- the reference's own test shapes (4,6,8) and
+ * 2: generic mixed-radix kernels (any other even nx, ny, nz up to 8192, or 4096 on RF_F64 plans -- the reference's own test shapes (4,6,8) and
  * (40,60,80), transform.py:172-177; single GPU, k space materialised); 0: unsupported */
 int rf_shape_supported(int nx, int ny, int nz);
 
@@ -151,7 +151,7 @@ int rf_execute_r2c(rf_plan* plan);               /* real field -> k buffer, unno
 
 /* ---- unpacked complex-to-complex plans: Plan(packed=False) (transform.py:207-213,266-270; the reference's
  * tests/test_transform.py:180-298).  One device buffer [nx][ny][nz] complex, transformed in place.
- * Power-of-two axes in [8, 2048] run on the tiled kernels, any other even axes up to 2048 on the generic ones.
+ * Power-of-two axes in [8, 2048] run on the tiled kernels, any other even axes up to 8192 (RF_F32) / 4096 (RF_F64) on the generic ones.
  * Only rf_upload_c / rf_download_c / rf_execute_c2c,
  * rf_sync, rf_elapsed_ms, rf_plan_set_stream, rf_plan_nbytes, rf_device_ptr and rf_plan_destroy apply. */
 int rf_plan_create_c2c(rf_plan** plan, int nx, int ny, int nz, int dtype, int device);

@@ -269,10 +269,13 @@ int ensure_x(rf_plan* p) {
   return 0;
 }
 
-// any even shape with axes up to GENERIC_MAX_N (transform.py:172-177 asks for even axes, nothing more)
-bool generic_shape(int nx, int ny, int nz, GenericAxis& ax, GenericAxis& ay, GenericAxis& az_half) {
+// any even shape with axes up to generic_max_axis(dtype) -- 8192 for complex64, 4096 for complex128: a whole line in LDS
+// (transform.py:172-177 asks for even axes, nothing more)
+bool generic_shape(int nx, int ny, int nz, int f64, GenericAxis& ax, GenericAxis& ay, GenericAxis& az_half) {
   if (nx < 2 || ny < 2 || nz < 2 || (nx & 1) || (ny & 1) || (nz & 1)) return false;
-  return generic_factor(nx, ax) && generic_factor(ny, ay) && generic_factor(nz / 2, az_half) && nz <= GENERIC_MAX_N;
+  const int cap = generic_max_axis(f64);
+  if (nx > cap || ny > cap || nz > cap) return false;
+  return generic_factor(nx, ax) && generic_factor(ny, ay) && generic_factor(nz / 2, az_half);
 }
 
 GenParams make_gen(rf_plan* p, uint64_t seed, int mode, bool seed_from_dev) {
@@ -808,7 +811,7 @@ int rf_device_count(int* count) {
 int rf_shape_supported(int nx, int ny, int nz) {
   if (shape_check(nx, ny, nz, 0, nullptr) == 0 && shape_check(nx, ny, nz, 1, nullptr) == 0) return 1;
   GenericAxis a, b, c;
-  return generic_shape(nx, ny, nz, a, b, c) ? 2 : 0;
+  return generic_shape(nx, ny, nz, 0, a, b, c) ? 2 : 0;          // (complex128 plans: axes up to 4096 -- rf_plan_create says so)
 }
 
 int rf_plan_create(rf_plan** out, int nx, int ny, int nz, int dtype, int device, int nranks, int rank) {
@@ -820,8 +823,9 @@ int rf_plan_create(rf_plan** out, int nx, int ny, int nz, int dtype, int device,
   GenericAxis gax, gay, gaz;
   bool generic = false;
   if (shape_check(nx, ny, nz, dtype, &why, nranks)) {
-    generic = nranks == 1 && generic_shape(nx, ny, nz, gax, gay, gaz);
-    if (!generic) return fail(1, "unsupported shape: " + why + (nranks == 1 ? " (and not an even shape with axes <= 2048 either)" : ""));
+    generic = nranks == 1 && generic_shape(nx, ny, nz, dtype == RF_F64, gax, gay, gaz);
+    if (!generic)
+      return fail(1, "unsupported shape: " + why + (nranks == 1 ? " (and not an even shape with axes <= 8192 (complex64) / 4096 (complex128) either)" : ""));
   }
   RF_HIP(hipSetDevice(device));
   rf_plan* p = new rf_plan();
@@ -906,9 +910,10 @@ int rf_plan_create_c2c(rf_plan** out, int nx, int ny, int nz, int dtype, int dev
     generic = ((long long)ny * nz) % tcx || ((long long)nx * nz) % tcy;      // too few columns for a tile
   }
   GenericAxis gax, gay, gaz;
-  if (generic && !(nx >= 2 && ny >= 2 && nz >= 2 && !(nx & 1) && !(ny & 1) && !(nz & 1) && generic_factor(nx, gax) &&
-                   generic_factor(ny, gay) && generic_factor(nz, gaz)))
-    return fail(1, "unsupported shape for a c2c plan: nx, ny, nz must be even and at most 2048");
+  const int gcap = generic_max_axis(dtype == RF_F64);
+  if (generic && !(nx >= 2 && ny >= 2 && nz >= 2 && !(nx & 1) && !(ny & 1) && !(nz & 1) && nx <= gcap && ny <= gcap && nz <= gcap &&
+                   generic_factor(nx, gax) && generic_factor(ny, gay) && generic_factor(nz, gaz)))
+    return fail(1, "unsupported shape for a c2c plan: nx, ny, nz must be even and at most 8192 (complex64) / 4096 (complex128)");
   RF_HIP(hipSetDevice(device));
   rf_plan* p = new rf_plan();
   p->generic = generic;

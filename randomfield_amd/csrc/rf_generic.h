@@ -17,7 +17,10 @@
 
 namespace rf {
 
-enum { GENERIC_MAX_N = 2048, GENERIC_MAX_FACTORS = 12 };
+// An axis is transformed with its whole line (two buffers of n elements) in LDS: 160 KB per workgroup hold lines of up to 8192 complex64
+// or 4096 complex128 (generic_max_axis); beyond 64 KB the kernels' dynamic-LDS attribute is raised (rf_k_generic.hip).
+enum { GENERIC_MAX_N = 8192, GENERIC_MAX_FACTORS = 12, GENERIC_LDS_MAX = 160 * 1024 - 256 };
+inline int generic_max_axis(int f64) { return f64 ? 4096 : 8192; }
 
 struct GenericAxis {
   int n;                                // line length
@@ -188,7 +191,8 @@ RF_HD void generic_row_r2c_block(const T* W, cplx<T>* G, const GenericAxis& ax, 
   }
 }
 
-// lines / rows per block so that the two LDS buffers stay within 64 KB (no function attribute needed)
+// lines / rows per block so that the two LDS buffers stay within 64 KB (no function attribute needed); a single line longer than
+// that (n > 4096 complex64 / 2048 complex128) takes what it needs, up to GENERIC_LDS_MAX
 inline int generic_lines_per_block(int n, int elem_bytes, int want, long long budget = 65536) {
   int tc = want;
   while (tc > 1 && 2LL * n * tc * elem_bytes > budget) tc >>= 1;

@@ -55,6 +55,10 @@ hipError_t axis_t(const void* src, void* dst, const GenericAxis& ax, long long s
   if (nblk <= 0) return hipSuccess;
   if (nblk > 0x7fffffffLL) return hipErrorInvalidValue;
   const size_t lds = 2 * (size_t)ax.n * tc * sizeof(cplx<T>);
+  if (lds > (size_t)GENERIC_LDS_MAX) return hipErrorInvalidValue;
+  static LdsAttrLatch latch;
+  if (lds > 65536)
+    if (hipError_t e = latch.ensure((const void*)generic_axis_kernel<T>, GENERIC_LDS_MAX); e != hipSuccess) return e;
   hipLaunchKernelGGL(generic_axis_kernel<T>, dim3((unsigned)nblk), dim3(256), lds, s, (const cplx<T>*)src, (cplx<T>*)dst, ax, stride,
                      inner, outer, nlines, tc, (const cplx<T>*)root, sign, (T)scale);
   return hipGetLastError();
@@ -81,11 +85,21 @@ hipError_t launch_generic_row_c2r(int f64, const void* G, void* W, const Generic
   if (nblk <= 0 || nblk > 0x7fffffffLL) return hipErrorInvalidValue;
   if (f64) {
     const int tr = rows_per_block<double>(ax.n);
-    hipLaunchKernelGGL(generic_row_c2r_kernel<double>, dim3((unsigned)nblk), dim3(256), 2 * (size_t)ax.n * tr * sizeof(cplx<double>), s,
+    const size_t lds = 2 * (size_t)ax.n * tr * sizeof(cplx<double>);
+    if (lds > (size_t)GENERIC_LDS_MAX) return hipErrorInvalidValue;
+    static LdsAttrLatch latch;
+    if (lds > 49152)
+      if (hipError_t e = latch.ensure((const void*)generic_row_c2r_kernel<double>, GENERIC_LDS_MAX); e != hipSuccess) return e;
+    hipLaunchKernelGGL(generic_row_c2r_kernel<double>, dim3((unsigned)nblk), dim3(256), lds, s,
                        (const cplx<double>*)G, (double*)W, ax, nrows, tr, (const cplx<double>*)root, scale, partials);
   } else {
     const int tr = rows_per_block<float>(ax.n);
-    hipLaunchKernelGGL(generic_row_c2r_kernel<float>, dim3((unsigned)nblk), dim3(256), 2 * (size_t)ax.n * tr * sizeof(cplx<float>), s,
+    const size_t lds = 2 * (size_t)ax.n * tr * sizeof(cplx<float>);
+    if (lds > (size_t)GENERIC_LDS_MAX) return hipErrorInvalidValue;
+    static LdsAttrLatch latch;
+    if (lds > 49152)
+      if (hipError_t e = latch.ensure((const void*)generic_row_c2r_kernel<float>, GENERIC_LDS_MAX); e != hipSuccess) return e;
+    hipLaunchKernelGGL(generic_row_c2r_kernel<float>, dim3((unsigned)nblk), dim3(256), lds, s,
                        (const cplx<float>*)G, (float*)W, ax, nrows, tr, (const cplx<float>*)root, (float)scale, partials);
   }
   return hipGetLastError();
@@ -97,11 +111,21 @@ hipError_t launch_generic_row_r2c(int f64, const void* W, void* G, const Generic
   if (nblk <= 0 || nblk > 0x7fffffffLL) return hipErrorInvalidValue;
   if (f64) {
     const int tr = rows_per_block<double>(ax.n);
-    hipLaunchKernelGGL(generic_row_r2c_kernel<double>, dim3((unsigned)nblk), dim3(256), 2 * (size_t)ax.n * tr * sizeof(cplx<double>), s,
+    const size_t lds = 2 * (size_t)ax.n * tr * sizeof(cplx<double>);
+    if (lds > (size_t)GENERIC_LDS_MAX) return hipErrorInvalidValue;
+    static LdsAttrLatch latch;
+    if (lds > 49152)
+      if (hipError_t e = latch.ensure((const void*)generic_row_r2c_kernel<double>, GENERIC_LDS_MAX); e != hipSuccess) return e;
+    hipLaunchKernelGGL(generic_row_r2c_kernel<double>, dim3((unsigned)nblk), dim3(256), lds, s,
                        (const double*)W, (cplx<double>*)G, ax, nrows, tr, (const cplx<double>*)root);
   } else {
     const int tr = rows_per_block<float>(ax.n);
-    hipLaunchKernelGGL(generic_row_r2c_kernel<float>, dim3((unsigned)nblk), dim3(256), 2 * (size_t)ax.n * tr * sizeof(cplx<float>), s,
+    const size_t lds = 2 * (size_t)ax.n * tr * sizeof(cplx<float>);
+    if (lds > (size_t)GENERIC_LDS_MAX) return hipErrorInvalidValue;
+    static LdsAttrLatch latch;
+    if (lds > 49152)
+      if (hipError_t e = latch.ensure((const void*)generic_row_r2c_kernel<float>, GENERIC_LDS_MAX); e != hipSuccess) return e;
+    hipLaunchKernelGGL(generic_row_r2c_kernel<float>, dim3((unsigned)nblk), dim3(256), lds, s,
                        (const float*)W, (cplx<float>*)G, ax, nrows, tr, (const cplx<float>*)root);
   }
   return hipGetLastError();

@@ -54,10 +54,12 @@ def test_shape_support_query_needs_no_gpu():
     assert _hip.shape_supported(2048, 2048, 2048) and _hip.shape_supported(8, 8, 16)
     lib = _hip.load()
     assert lib.rf_shape_supported(1024, 1024, 1024) == 1          # tiled power-of-two kernels
-    # any other even shape up to 2048 per axis: the generic mixed-radix kernels (the reference's own test shapes)
+    # any other even shape up to 8192 per axis (4096 on complex128 plans: rf_plan_create checks the dtype): the generic mixed-radix
+    # kernels (the reference's own test shapes; axes beyond the tiled kernels' 2048)
     assert lib.rf_shape_supported(4, 6, 8) == 2 and lib.rf_shape_supported(40, 60, 80) == 2
     assert lib.rf_shape_supported(16, 16, 18) == 2 and lib.rf_shape_supported(8, 8, 8) == 2
-    assert not _hip.shape_supported(4096, 16, 16) and not _hip.shape_supported(5, 6, 8) and not _hip.shape_supported(4, 6, 7)
+    assert lib.rf_shape_supported(4096, 16, 16) == 2 and lib.rf_shape_supported(8, 6000, 8192) == 2
+    assert not _hip.shape_supported(16384, 16, 16) and not _hip.shape_supported(5, 6, 8) and not _hip.shape_supported(4, 6, 7)
 
 
 @pytest.mark.skipif(_have_gpu(), reason="checks the no-GPU failure mode")

@@ -242,7 +242,8 @@ def test_fast_sigma_lookup_error_bound(default_power):
         assert np.max(rel) <= 1e-6, "fast sigma lookup off by %.3g relative" % np.max(rel)
 
 
-GENERIC_SHAPES = [(4, 6, 8), (6, 4, 12), (40, 60, 80), (10, 14, 22), (2, 2, 2), (12, 18, 6), (26, 34, 46), (24, 8, 16)]
+GENERIC_SHAPES = [(4, 6, 8), (6, 4, 12), (40, 60, 80), (10, 14, 22), (2, 2, 2), (12, 18, 6), (26, 34, 46), (24, 8, 16),
+                  (4096, 2, 4), (2, 6000, 4), (2, 4, 8192)]          # (axes beyond the tiled kernels: whole lines of up to 8192 complex64)
 
 
 @pytest.mark.parametrize("shape", GENERIC_SHAPES)

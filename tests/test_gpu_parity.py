@@ -401,7 +401,9 @@ def test_errors_are_loud(hip, dpower):
     with pytest.raises(RuntimeError):
         hip.DevicePlan(4, 6, 7)                                      # unsupported shape (odd axis): no silent CPU path
     with pytest.raises(RuntimeError):
-        hip.DevicePlan(4096, 16, 16)                                 # axis longer than any kernel covers
+        hip.DevicePlan(16384, 16, 16)                                # axis longer than any kernel covers
+    with pytest.raises(RuntimeError):
+        hip.DevicePlan(8192, 16, 16, np.complex128)                  # (complex128 lines: up to 4096)
     plan = hip.DevicePlan(16, 16, 16)
     with pytest.raises(RuntimeError):
         plan.realise(seed=1)                                         # tables not set
@@ -414,7 +416,7 @@ def test_errors_are_loud(hip, dpower):
     plan.close()
     from randomfield_amd.transform import Plan
     with pytest.raises(RuntimeError):
-        Plan(shape=(4096, 16, 16), dtype_in=np.complex64)            # hip backend refuses, does not fall back
+        Plan(shape=(16384, 16, 16), dtype_in=np.complex64)           # hip backend refuses, does not fall back
 
 
 def _virtual_rank_field(hip, shape, dtype, k, Pk, nranks, seed=None, noise=None, exact=False):
@@ -664,7 +666,9 @@ def test_unpacked_c2c_plan_against_numpy(hip, shape):
     src = small.data_in.copy()
     assert np.max(np.abs(small.execute() - np.fft.ifftn(src.astype(np.complex128)))) <= 1e-6
     with pytest.raises(RuntimeError):
-        transform.Plan((8, 8, 4096), dtype_in=np.complex64, packed=False, backend="hip")    # nz beyond the row kernels
+        transform.Plan((8, 8, 16384), dtype_in=np.complex64, packed=False, backend="hip")   # nz beyond every kernel
+    with pytest.raises(RuntimeError):
+        transform.Plan((8, 8, 8192), dtype_in=np.complex128, packed=False, backend="hip")   # (complex128: 4096)
 
 
 @pytest.mark.parametrize("shape", [(8, 8, 16), (16, 8, 64), (8, 16, 256), (4 * 2, 8, 2048), (8, 8, 512), (8, 8, 1024)])
@@ -1362,6 +1366,46 @@ def test_generic_shape_plans(hip):
                 src = c.data_in.copy()
                 ref = fn(src.astype(np.complex128))
                 assert np.max(np.abs(c.execute() - ref)) <= 10 * tol * np.abs(ref).std()
+
+
+@pytest.mark.parametrize("shape,ct", [((4096, 8, 16), np.complex64), ((8, 8192, 12), np.complex64), ((6, 8, 8192), np.complex64),
+                                      ((12, 6000, 8), np.complex64), ((4096, 4, 8), np.complex128), ((4, 6, 4096), np.complex128)])
+def test_axes_longer_than_2048(hip, dpower, shape, ct):
+    """transform.py:172-177 accepts any even shape.  Axes beyond the tiled kernels' 2048 run on the generic mixed-radix kernels with
+    the whole line in LDS: up to 8192 complex64 / 4096 complex128 per axis (rf_generic.h).  Packed c2r against numpy's irfftn, the
+    r2c reverse plan, unpacked c2c both ways, and a Generator field against the oracle's realisation of the same deviates."""
+    from randomfield_amd.transform import Plan
+    from randomfield_amd import Generator
+    rng = np.random.RandomState(17)
+    nx, ny, nz = shape
+    tol = 2e-6 if ct == np.complex64 else 1e-14
+    plan = Plan(shape=shape, dtype_in=ct)
+    assert plan.backend == "hip" and not plan.device.tiled
+    rt = plan.data_out.dtype
+    plan.data_in.view(rt).reshape(nx, ny, nz + 2)[:] = rng.normal(size=(nx, ny, nz + 2))
+    ks = plan.data_in.copy()
+    out = plan.execute().copy()
+    ref = np.fft.irfftn(ks.astype(np.complex128), s=shape, axes=(0, 1, 2))
+    assert np.max(np.abs(out - ref)) <= 20 * tol * ref.std()
+    back = plan.create_reverse_plan().execute()
+    kref = np.fft.rfftn(ref)
+    assert np.max(np.abs(back - kref)) <= 40 * tol * np.abs(kref).std()
+    plan.device.close()
+    for inverse, fn in ((True, np.fft.ifftn), (False, np.fft.fftn)):
+        c = Plan(shape=shape, dtype_in=ct, packed=False, inverse=inverse)
+        c.data_in[:] = rng.normal(size=shape) + 1j * rng.normal(size=shape)
+        src = c.data_in.copy()
+        ref = fn(src.astype(np.complex128))
+        assert np.max(np.abs(c.execute() - ref)) <= 20 * tol * np.abs(ref).std()
+        c.device.close()
+    k, Pk = dpower                                   # (the shipped default power: what Generator() loads)
+    gen = Generator(nx, ny, nz, SPACING, backend="hip")
+    if ct == np.complex64:
+        delta = gen.generate_delta_field(seed=4, save_potential=False)
+        want, rms = cpu_ref.generate_delta_field(nx, ny, nz, SPACING, k, Pk, seed=4, double_fft=True)
+        assert delta.shape == shape and np.max(np.abs(delta - want)) <= TOL_F32 * rms
+        assert abs(float(gen.delta_field_rms) - rms) <= TOL_F32 * rms
+        gen.plan_c2r.device.close()
 
 
 # ---- the reference's default call and its own random stream on kz-slab ranks (virtual ranks on one device) --------
