@@ -1759,22 +1759,26 @@ int rf_mt_set_jump(rf_plan* p, int npolys, const uint16_t* pos, const int* npos,
   if (p->mt_npos_dev) RF_HIP(hipFree(p->mt_npos_dev));
   p->mt_pos = nullptr;
   p->mt_npos_dev = nullptr;
-  // device rows: the even positions, padded to a multiple of 8 entries, then the odd ones (the jump kernel reads aligned
-  // 8-byte word pairs: rf_k_mt.hip); two counts per polynomial
-  const int wstride = ((stride + 7) / 8 + 1) * 8;
-  std::vector<uint32_t> wide((size_t)npolys * wstride, 0u);
-  std::vector<int> counts(2 * (size_t)npolys);
+  // device rows (rf_k_mt.hip mt_jump_kernel): four lists, one per class c = position mod 4, each padded to a multiple of 8 entries;
+  // an entry is the byte offset 4 (position - c) of an aligned 16-byte read; the padding points into the block of zero words
+  // behind the 33-block window (33 * 624 words); four padded counts per polynomial
+  const uint32_t null_off = 4u * 33u * 624u;
+  const int wstride = ((stride + 7) / 8 + 4) * 8;
+  std::vector<uint32_t> wide((size_t)npolys * wstride, null_off);
+  std::vector<int> counts(4 * (size_t)npolys);
   for (int l = 0; l < npolys; ++l) {
-    int ne = 0, no = 0;
-    for (int j = 0; j < npos[l]; ++j) ne += (pos[(size_t)l * stride + j] & 1) == 0;
-    const int eoff = (ne + 7) & ~7;
-    RF_REQUIRE(eoff + ((npos[l] - ne + 7) & ~7) <= wstride, "jump table row too long");
-    ne = 0;
+    int n[4] = {0, 0, 0, 0};
+    for (int j = 0; j < npos[l]; ++j) ++n[pos[(size_t)l * stride + j] & 3];
+    int off[4], padded[4];
+    for (int c = 0, o = 0; c < 4; ++c) { padded[c] = (n[c] + 7) & ~7; off[c] = o; o += padded[c]; }
+    RF_REQUIRE(off[3] + padded[3] <= wstride, "jump table row too long");
+    int k[4] = {0, 0, 0, 0};
     for (int j = 0; j < npos[l]; ++j) {
       const uint32_t q = pos[(size_t)l * stride + j];
-      if (q & 1) wide[(size_t)l * wstride + eoff + no++] = q; else wide[(size_t)l * wstride + ne++] = q;
+      const int c = (int)(q & 3u);
+      wide[(size_t)l * wstride + off[c] + k[c]++] = 4u * (q - (uint32_t)c);
     }
-    counts[2 * l] = ne; counts[2 * l + 1] = no;
+    for (int c = 0; c < 4; ++c) counts[4 * l + c] = padded[c];
   }
   RF_HIP(hipMalloc((void**)&p->mt_pos, wide.size() * sizeof(uint32_t)));
   RF_HIP(hipMemcpy(p->mt_pos, wide.data(), wide.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -1850,7 +1854,7 @@ int mt_queue(rf_plan* p, const MtGeom& g, int single, hipStream_t s) {
   long long dist = 1;
   for (int t = 0; t < g.stages; ++t, dist *= R) {
     const int nsrc = (int)(dist < g.nseg ? dist : g.nseg);
-    RF_HIP(launch_mt_jump(p->mt_states, p->mt_pos + (size_t)t * (R - 1) * p->mt_stride, p->mt_npos_dev + 2 * t * (R - 1), p->mt_stride, nsrc,
+    RF_HIP(launch_mt_jump(p->mt_states, p->mt_pos + (size_t)t * (R - 1) * p->mt_stride, p->mt_npos_dev + 4 * t * (R - 1), p->mt_stride, nsrc,
                           dist, R - 1, g.nseg, s));
   }
   // ONE generation pass: every segment writes its accepted pairs densely into its own run of the scratch array
@@ -1984,7 +1988,7 @@ int rf_mt_share_begin(rf_plan* p, const uint32_t* state624, int single, unsigned
       if (d == 0) continue;
       RF_REQUIRE(t < g.stages && slot + 1 < nloc + 8, "segment index beyond the uploaded jump table");
       const int row = t * (R - 1) + d - 1;
-      RF_HIP(launch_mt_jump(p->mt_states + (size_t)slot * 624, p->mt_pos + (size_t)row * p->mt_stride, p->mt_npos_dev + 2 * row, p->mt_stride,
+      RF_HIP(launch_mt_jump(p->mt_states + (size_t)slot * 624, p->mt_pos + (size_t)row * p->mt_stride, p->mt_npos_dev + 4 * row, p->mt_stride,
                             1, 1, 1, 2, s));
       ++slot;
     }
@@ -1994,7 +1998,7 @@ int rf_mt_share_begin(rf_plan* p, const uint32_t* state624, int single, unsigned
   long long dist = 1;
   for (int t = 0; dist < nloc; ++t, dist *= R) {
     const int nsrc = (int)(dist < nloc ? dist : nloc);
-    RF_HIP(launch_mt_jump(p->mt_states, p->mt_pos + (size_t)t * (R - 1) * p->mt_stride, p->mt_npos_dev + 2 * t * (R - 1), p->mt_stride, nsrc,
+    RF_HIP(launch_mt_jump(p->mt_states, p->mt_pos + (size_t)t * (R - 1) * p->mt_stride, p->mt_npos_dev + 4 * t * (R - 1), p->mt_stride, nsrc,
                           dist, R - 1, nloc, s));
   }
   RF_HIP(launch_mt_polar(single != 0, p->mt_states, nloc, p->mt_bps, g.total_blocks - (long long)first * p->mt_bps, p->mt_counts, p->mt_scratch, g.cap, s));

@@ -65,25 +65,41 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
 // reads per lane; as global-memory reads this step took 13 of the replay's 28 ms in round 1).  Building the window
 // is about half of a single jump, and a binary tree spends nine of its thirteen levels waiting for one or a few
 // workgroups: radix 16 needs four launches and shares each window between up to 15 jumps (5.6 -> 2 ms at 1024^3).
-// Thread layout of the XOR loop: MT_JUMP_GROUPS groups of 320 threads, 312 of them active.  Lane u owns the output words
-// 2u and 2u + 1 and reads them as ONE aligned 8-byte LDS access per position: ds_read_b64 moves 256 B/clk, twice what
-// ds_read_b32 / ds_read2_b32 do (MI355X_MICROARCH.md, LDS), and the XOR loop is bound by exactly that.  Alignment needs
-// position + 2u even, so the positions of a polynomial come in two lists: the even ones feed the pair (2u, 2u + 1), the
-// odd ones the pair (2u - 1, 2u) through a base shifted by one word -- two accumulator pairs per lane, recombined
-// with the neighbour lane's at the end (lane 312 exists for its odd pair (623, 624) only).  A group takes every MT_JUMP_GROUPS-th chunk of 8 positions of each list
-// (ds_read_b32 -- and b64 -- need ~4 waves per SIMD for their rate, and the 106 KB window + tables allow one workgroup
-// per CU); the groups' partial XORs are combined through LDS.  History of one jump on a CU: 0.19 ms with one word per
-// lane and 10 waves, 0.14 ms with two words per ds_read2st64_b32 and 15 waves (floor 0.08 ms at 128 B/clk).
-constexpr int MT_JUMP_LANES = 320, MT_JUMP_USED = MT_N / 2, MT_JUMP_GROUPS = 3, MT_JUMP_THREADS = MT_JUMP_LANES * MT_JUMP_GROUPS;
+// Thread layout of the XOR loop (round 4: 16-byte reads): MT_JUMP_GROUPS groups of 160 threads, 157 of them active.  Lane u reads the
+// four window words 4u - c + p .. + 3 of a position p = c (mod 4) as ONE aligned ds_read_b128 (256 B/clk/CU like ds_read_b64, but
+// one address add and one issue slot per 16 bytes instead of per 8: the 8-byte form ran at ~130 B/clk, bound by its 2.25 vector
+// instructions per read): the byte address is 16 u + 4 (p - c), so the positions of a polynomial come in FOUR lists, one per
+// class c, stored as the byte offsets 4 (p - c) -- uniform values, read four at a time as one broadcast -- and every lane keeps
+// one four-word accumulator per class: class c of lane u belongs to the output words 4u - c .. 4u - c + 3 (lane 156 exists for the
+// words 624 - c .. 623 of the classes c > 0).  The lists are padded to whole chunks of 8 with a position inside a block of
+// zero words behind the window, so the loop has no tail.  A group takes every MT_JUMP_GROUPS-th chunk of each list; the groups'
+// (and classes') partial XORs meet in LDS, indexed by output word, in the space the position table occupied.
+// History of one jump on a CU: 0.19 ms with one word per lane and 10 waves, 0.14 ms with ds_read2st64_b32 and 15 waves, 0.087 ms
+// with ds_read_b64, see DESIGN.md section 3.6 for the 16-byte form.
+#ifndef RF_MT_JUMP_GROUPS
+#define RF_MT_JUMP_GROUPS 4
+#endif
+#ifndef RF_MT_JUMP_UNROLL
+#define RF_MT_JUMP_UNROLL 2        // chunks of 8 reads in flight per lane
+#endif
+constexpr int MT_JUMP_LANES = 160, MT_JUMP_USED = MT_N / 4 + 1, MT_JUMP_GROUPS = RF_MT_JUMP_GROUPS, MT_JUMP_THREADS = MT_JUMP_LANES * MT_JUMP_GROUPS;
+constexpr int MT_ZERO_WORDS = 4 * MT_JUMP_LANES;                         // zero block behind the window: the padding position of every class
+constexpr int MT_PART_WORDS = 4 * MT_JUMP_LANES;                          // per (group, class): output words 0 .. 623 (+ slack)
+constexpr int MT_JUMP_POS_BYTES = MT_POS_MAX * (int)sizeof(uint32_t);
+constexpr int MT_JUMP_PART_BYTES = MT_JUMP_GROUPS * 4 * MT_PART_WORDS * (int)sizeof(uint32_t);
+constexpr int MT_JUMP_LDS = (MT_SEQ_WORDS + MT_ZERO_WORDS) * (int)sizeof(uint32_t) +
+                            (MT_JUMP_POS_BYTES > MT_JUMP_PART_BYTES ? MT_JUMP_POS_BYTES : MT_JUMP_PART_BYTES);
+static_assert(MT_JUMP_THREADS >= MT_N && MT_JUMP_THREADS <= 1024, "the window build and the final combine use one thread per state word");
 __global__ __launch_bounds__(MT_JUMP_THREADS) void mt_jump_kernel(const uint32_t* __restrict__ states, const uint32_t* __restrict__ pos,
                                                       const int* __restrict__ npos, int pos_stride, int nsrc, long long dist,
                                                       int nmult, int mult_per_wg, int nseg) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t win[];     // MT_SEQ_WORDS words
+  extern __shared__ __attribute__((aligned(16))) uint32_t win[];     // MT_SEQ_WORDS words + MT_ZERO_WORDS zeros, then positions / partials
   const int t = threadIdx.x;
   const int src = blockIdx.x % nsrc, m0 = 1 + (blockIdx.x / nsrc) * mult_per_wg;
   if ((long long)src + (long long)m0 * dist >= nseg) return;         // uniform: no destination of this workgroup exists
   const uint32_t* st = states + (size_t)src * MT_N;
   if (t < MT_N) win[t] = st[t];
+  if (t < MT_ZERO_WORDS) win[MT_SEQ_WORDS + t] = 0u;
   __syncthreads();
   // x[n + 624] = f(x[n], x[n + 1], x[n + 397]): within a block of 624 new words, words [0, 227) need old words only,
   // [227, 454) need new words [0, 227), [454, 624) need new words [227, 397)
@@ -97,59 +113,63 @@ __global__ __launch_bounds__(MT_JUMP_THREADS) void mt_jump_kernel(const uint32_t
     if (t >= 454 && t < MT_N) nw[t] = mt_f(od[t], od[t + 1], od[t + MT_M]);
     __syncthreads();
   }
-  // the ~10^4 positions of a polynomial are staged in LDS behind the window (16-bit, 8 per 16-byte broadcast read; row
-  // layout in global memory: the even positions, padded to a multiple of 8, then the odd ones -- npos holds both counts)
-  uint16_t* lpos = reinterpret_cast<uint16_t*>(win + MT_SEQ_WORDS);
-  uint32_t* part = win + MT_SEQ_WORDS + MT_POS_MAX / 2;               // GROUPS x 4 x 320 words behind the position table
+  // the ~10^4 positions of a polynomial are staged in LDS behind the window (32-bit byte offsets, four per 16-byte broadcast read;
+  // row layout in global memory: the four class lists one after the other, each padded to a multiple of 8 -- npos holds the four
+  // padded counts)
+  uint32_t* lpos = win + MT_SEQ_WORDS + MT_ZERO_WORDS;
+  uint32_t* part = lpos;                                              // (after the loop: [group][class][output word])
   const int grp = t / MT_JUMP_LANES, u = t - grp * MT_JUMP_LANES;
-  const bool active = u <= MT_JUMP_USED;                              // lane 312: only its odd-list pair (623, 624) is used
-  const uint32_t* w = win + 2 * (active ? u : 1);
-  typedef unsigned u2 __attribute__((ext_vector_type(2)));
-  typedef unsigned short us8 __attribute__((ext_vector_type(8)));
+  const bool active = u < MT_JUMP_USED;
+  typedef unsigned u4 __attribute__((ext_vector_type(4)));
+  const char* wb = reinterpret_cast<const char*>(win) + 16 * (active ? u : 0);
   for (int m = m0; m < m0 + mult_per_wg && m <= nmult; ++m) {
     const long long dst = (long long)src + (long long)m * dist;
     if (dst >= nseg) break;                                           // uniform
     const uint32_t* pm = pos + (size_t)(m - 1) * pos_stride;
-    const int ne = npos[2 * (m - 1)], no = npos[2 * (m - 1) + 1], eoff = (ne + 7) & ~7, total = eoff + ((no + 7) & ~7);
-    __syncthreads();                                                  // the previous multiplier is done with lpos and part
-    for (int i = t; i < total; i += MT_JUMP_THREADS) lpos[i] = (uint16_t)pm[i];
+    const int n0 = npos[4 * (m - 1)], n1 = npos[4 * (m - 1) + 1], n2 = npos[4 * (m - 1) + 2], n3 = npos[4 * (m - 1) + 3];
+    const int total = n0 + n1 + n2 + n3;
+    __syncthreads();                                                  // the previous multiplier is done with the partials
+    for (int i = t; i < total; i += MT_JUMP_THREADS) lpos[i] = pm[i];
     __syncthreads();
-    u2 A = {0u, 0u}, B = {0u, 0u};
+    u4 acc[4];
 #pragma unroll
-    for (int par = 0; par < 2; ++par) {
-      const uint32_t* wb = w - par;                                   // odd positions: the pair one word down, aligned again (position >= 1)
-      const uint16_t* list = lpos + (par ? eoff : 0);
-      const int n = par ? no : ne, full = n >> 3;
-      const us8* lp = reinterpret_cast<const us8*>(list);
-      u2 acc = {0u, 0u};
-#pragma unroll 4
-      for (int j = grp; j < full; j += MT_JUMP_GROUPS) {
-        const us8 q = lp[j];                                          // same address in every lane: broadcast
-#define RF_MT_PAIR(k) (*reinterpret_cast<const u2*>(__builtin_assume_aligned(wb + q.s##k, 8)))
-        const u2 v0 = RF_MT_PAIR(0), v1 = RF_MT_PAIR(1), v2 = RF_MT_PAIR(2), v3 = RF_MT_PAIR(3), v4 = RF_MT_PAIR(4), v5 = RF_MT_PAIR(5),
-                 v6 = RF_MT_PAIR(6), v7 = RF_MT_PAIR(7);
-#undef RF_MT_PAIR
-        acc.x = xor3(xor3(xor3(xor3(acc.x, v0.x, v1.x), v2.x, v3.x), v4.x, v5.x), v6.x, v7.x);
-        acc.y = xor3(xor3(xor3(xor3(acc.y, v0.y, v1.y), v2.y, v3.y), v4.y, v5.y), v6.y, v7.y);
+    for (int c = 0; c < 4; ++c) {
+      const int off = c == 0 ? 0 : (c == 1 ? n0 : (c == 2 ? n0 + n1 : n0 + n1 + n2));
+      const int n = c == 0 ? n0 : (c == 1 ? n1 : (c == 2 ? n2 : n3));
+      const u4* lp = reinterpret_cast<const u4*>(lpos + off);         // (off is a multiple of 8 words)
+      u4 a = {0u, 0u, 0u, 0u};
+#pragma unroll RF_MT_JUMP_UNROLL
+      for (int j = 2 * grp; j < (n >> 2); j += 2 * MT_JUMP_GROUPS) {  // a chunk of 8 positions = two broadcast reads
+        const u4 q0 = lp[j], q1 = lp[j + 1];
+#define RF_MT_QUAD(o) (*reinterpret_cast<const u4*>(__builtin_assume_aligned(wb + (o), 16)))
+        const u4 v0 = RF_MT_QUAD(q0.x), v1 = RF_MT_QUAD(q0.y), v2 = RF_MT_QUAD(q0.z), v3 = RF_MT_QUAD(q0.w), v4 = RF_MT_QUAD(q1.x),
+                 v5 = RF_MT_QUAD(q1.y), v6 = RF_MT_QUAD(q1.z), v7 = RF_MT_QUAD(q1.w);
+#undef RF_MT_QUAD
+        a.x = xor3(xor3(xor3(xor3(a.x, v0.x, v1.x), v2.x, v3.x), v4.x, v5.x), v6.x, v7.x);
+        a.y = xor3(xor3(xor3(xor3(a.y, v0.y, v1.y), v2.y, v3.y), v4.y, v5.y), v6.y, v7.y);
+        a.z = xor3(xor3(xor3(xor3(a.z, v0.z, v1.z), v2.z, v3.z), v4.z, v5.z), v6.z, v7.z);
+        a.w = xor3(xor3(xor3(xor3(a.w, v0.w, v1.w), v2.w, v3.w), v4.w, v5.w), v6.w, v7.w);
       }
-      if (grp == 0)
-        for (int j = full << 3; j < n; ++j) { acc.x ^= wb[list[j]]; acc.y ^= wb[list[j] + 1]; }
-      if (par) B = acc; else A = acc;
+      acc[c] = a;
     }
-    uint32_t* mine = part + grp * 4 * MT_JUMP_LANES + u;
-    mine[0] = A.x; mine[MT_JUMP_LANES] = A.y; mine[2 * MT_JUMP_LANES] = B.x; mine[3 * MT_JUMP_LANES] = B.y;
-    __syncthreads();
-    if (grp == 0 && u < MT_JUMP_USED) {
-      // word 2u = A.x ^ B.y, word 2u + 1 = A.y ^ (B.x of lane u + 1), each summed over the groups
-      uint32_t lo = 0, hi = 0;
+    __syncthreads();                                                  // every group has read its positions: the partials take their place
+    if (active) {
 #pragma unroll
-      for (int g = 0; g < MT_JUMP_GROUPS; ++g) {
-        const uint32_t* pg = part + g * 4 * MT_JUMP_LANES;
-        lo ^= pg[u] ^ pg[3 * MT_JUMP_LANES + u];
-        hi ^= pg[MT_JUMP_LANES + u] ^ pg[2 * MT_JUMP_LANES + u + 1];
+      for (int c = 0; c < 4; ++c) {
+        uint32_t* pc = part + (grp * 4 + c) * MT_PART_WORDS;
+        const int w0 = 4 * u - c;                                     // output word of component 0
+        const uint32_t comp[4] = {acc[c].x, acc[c].y, acc[c].z, acc[c].w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (w0 + k >= 0 && w0 + k < MT_N) pc[w0 + k] = comp[k];
       }
-      u2* out = reinterpret_cast<u2*>(const_cast<uint32_t*>(states) + (size_t)dst * MT_N) + u;
-      *out = u2{lo, hi};
+    }
+    __syncthreads();
+    if (t < MT_N) {
+      uint32_t x = 0;
+#pragma unroll
+      for (int gc = 0; gc < MT_JUMP_GROUPS * 4; ++gc) x ^= part[gc * MT_PART_WORDS + t];
+      const_cast<uint32_t*>(states)[(size_t)dst * MT_N + t] = x;
     }
   }
 }
@@ -390,8 +410,7 @@ hipError_t launch_mt_compact(bool single, const void* scratch, const unsigned lo
 hipError_t launch_mt_jump(uint32_t* states, const uint32_t* pos, const int* npos, int pos_stride, int nsrc, long long dist,
                           int nmult, int nseg, hipStream_t s) {
   if (pos_stride > MT_POS_MAX) return hipErrorInvalidValue;
-  constexpr int lds = MT_SEQ_WORDS * (int)sizeof(uint32_t) + MT_POS_MAX * (int)sizeof(uint16_t) +
-                      MT_JUMP_GROUPS * 4 * MT_JUMP_LANES * (int)sizeof(uint32_t);   // window, positions, partial XORs
+  constexpr int lds = MT_JUMP_LDS;                                                    // window + zeros, positions / partial XORs
   static LdsAttrLatch latch;
   if (hipError_t e = latch.ensure((const void*)mt_jump_kernel, lds); e != hipSuccess) return e;
   // one 82 KB window (+ 24 KB of positions) per CU: share a source's window between as many multipliers as it takes to fit one round
