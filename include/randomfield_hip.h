@@ -112,6 +112,11 @@ int rf_noise_mt19937_ex(rf_plan* plan, const uint32_t* state624, unsigned long l
  * states, e.g. numpy's init_genrand / init_by_array of each seed); rms_out (n, optional) = np.std of every field.  The field of
  * the last seed is the plan's current field; every field equals what rf_noise_mt19937_ex(single) + rf_realise(RESIDENT) gives. */
 int rf_realise_batch_reference(rf_plan* plan, const uint32_t* states, int n, double* rms_out);
+/* does rf_realise_batch_reference serve this plan as it stands (single-GPU complex64 plan on the fast generation path, tables and
+ * jump polynomials set, segments long enough for the float32 form)?  With n = 1 it is also the fastest way to ONE same-seed field --
+ * replay and passes queued back to back, no host synchronisation between them -- and what Generator(rng='reference') calls
+ * (generate.py:191-199 with random.py:24-28 inside).  1 / 0. */
+int rf_can_batch_reference(rf_plan* plan);
 /* ---- the same stream shared between the ranks of a kz-slab job (random.py:24-28 is ONE sequential stream; the reference is
  * single-process, so there is no reference interface to mirror beyond that definition).  rf_noise_mt19937_ex on a multi-rank
  * plan replays the whole stream on every rank; these calls replay 1/P of it per rank and exchange the deviates once:

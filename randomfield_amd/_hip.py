@@ -84,6 +84,7 @@ SIGNATURES = {
     "rf_realise_lognormal": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.POINTER(ctypes.c_double),
                                             ctypes.POINTER(ctypes.c_double)]),
     "rf_realise_batch_reference": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32), ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
+    "rf_can_batch_reference": (ctypes.c_int, [ctypes.c_void_p]),
     "rf_yz_slabs": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "rf_comm_unique_id": (ctypes.c_int, [ctypes.c_void_p]),
     "rf_comm_init": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
@@ -377,6 +378,14 @@ class DevicePlan(object):
         check(self._lib.rf_realise_batch_reference(self._h, states.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), len(states),
                                                    _dp(rms) if want_rms else None), "rf_realise_batch_reference")
         return rms
+
+    def can_batch_reference(self):
+        """Does :meth:`realise_batch_reference` serve this plan (single-GPU complex64 plan on the fast generation path, tables
+        set, segments long enough for float32 pairs)?  With one seed it is also the fastest route to ONE same-seed field."""
+        if self.nranks != 1 or not self.tiled:
+            return False
+        self._mt_prepare()
+        return bool(self._lib.rf_can_batch_reference(self._h))
 
     def set_mt_segment_blocks(self, blocks):
         """Override the replay's segment length (blocks of 624 words; default: :func:`mt19937.segment_blocks_for`).  Small

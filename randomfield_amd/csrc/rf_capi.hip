@@ -629,6 +629,23 @@ int queue_yz(rf_plan* p, void* W, hipStream_t s, double* stats_out, bool timed) 
     while ((int)p->slab_ev.size() < 2 * nslab) { hipEvent_t e; RF_HIP(hipEventCreate(&e)); p->slab_ev.push_back(e); }
     p->slab_timed = nslab;
   }
+  // untimed single-rank float32 realisations at the sizes rf_k_yz.hip serves: the z pass of slab i and the y pass of slab i + 1 share a
+  // launch (the next slab's y tiles fill the CUs the draining z pass leaves idle); timed calls keep one launch per pass and slab, so
+  // that rf_kernel_ms still means what it says
+  static const bool merge_env = [] { const char* e = getenv("RANDOMFIELD_MERGE_YZ"); return !e || atoi(e) != 0; }();
+  if (merge_env && !timed && !xp && !p->zscale && nslab > 1 && p->nx % B == 0 && yz_merged_supported(p->f64, p->ny, (int)p->nzc)) {
+    RF_HIP(launch_col_plain(p->f64, p->ny, +1, W, gy, B * nzl, p->tw_y, s));
+    for (int i = 0; i < nslab; ++i) {
+      char* Ws = (char*)W + (long long)i * B * plane;
+      double* part = p->partials + 2 * (long long)i * B * tiles_per_plane;
+      if (i + 1 < nslab)
+        RF_HIP(launch_yz_merged(p->f64, p->ny, (int)p->nzc, Ws, B * p->ny, scale, p->tw_z, part, Ws + B * plane, gy, B * nzl, p->tw_y, s));
+      else
+        RF_HIP(launch_row_c2r(p->f64, (int)p->nzc, Ws, B * p->ny, scale, p->tw_z, part, s));
+    }
+    RF_HIP(launch_reduce_partials(p->partials, p->npartials, stats_out, p->partials + 2 * p->npartials, s));
+    return 0;
+  }
   for (int i = 0; i < nslab; ++i) {
     const long long x0 = (long long)i * B, nb = x0 + B <= p->nx ? B : p->nx - x0;      // planes [x0, x0 + nb)
     char* Ws = (char*)W + x0 * plane;
@@ -885,6 +902,7 @@ int rf_plan_create(rf_plan** out, int nx, int ny, int nz, int dtype, int device,
         (e = launch_col_xpose(dtype, ny, p->W, gy, p->W, gy, (long long)nx * nzl, p->tw_y, p->stream, true)) != hipSuccess ||
         (e = launch_col_plain_acc(dtype, ny, p->W, gy, (long long)nx * nzl, 0, (int)nzl, nullptr, p->tw_y, p->stream, true)) != hipSuccess ||
         (e = launch_row_c2r_lognormal(dtype, (int)nzc, p->W, (long long)p->nxl * ny, 1.0, nullptr, nullptr, p->tw_z, p->partials, p->stream, true)) != hipSuccess ||
+        (yz_merged_supported(dtype, ny, (int)nzc) && (e = launch_yz_merged(dtype, ny, (int)nzc, p->W, 8, 1.0, p->tw_z, p->partials, p->W, ColGeom{p->nzl, (long long)ny * p->nzl, p->nzl}, 8, p->tw_y, p->stream, true)) != hipSuccess) ||
         (e = launch_row_c2r(dtype, (int)nzc, p->W, (long long)p->nxl * ny, 1.0, p->tw_z, p->partials, p->stream, true)) != hipSuccess ||
         (e = launch_row_c2r_zscale(dtype, (int)nzc, p->W, (long long)p->nxl * ny, 1.0, nullptr, p->tw_z, p->partials, p->stream, true)) != hipSuccess ||
         (e = launch_row_c2r_xgather(dtype, (int)nzc, p->W, p->W, (long long)p->nxl * ny, 1.0, 8, 8, ny, p->tw_z, p->partials, p->stream, true)) != hipSuccess ||
@@ -2284,6 +2302,15 @@ int rf_realise_batch_reference(rf_plan* p, const uint32_t* states, int n, double
     }
   }
   return 0;
+}
+
+int rf_can_batch_reference(rf_plan* p) {
+  if (!p || p->unpacked || p->nranks != 1 || p->force_slab || p->generic || p->f64 || !p->have_fast || p->exact_gen || !p->have_kgrid ||
+      !p->have_power || !p->mt_pos || p->mt_npos.empty())
+    return 0;
+  MtGeom g;
+  if (mt_geom(p, 1, g)) return 0;
+  return g.cap >= 4ull * (unsigned long long)(p->nzc + 1) ? 1 : 0;
 }
 
 int rf_download_noise(rf_plan* p, double* host, unsigned long long first, unsigned long long count) {

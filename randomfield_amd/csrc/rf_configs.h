@@ -49,6 +49,9 @@ template <> struct GenSel<float, 2048> { using type = ColCfg<float, 2048, RF_GEN
 template <> struct GenSel<double, 1024> { using type = ColCfg<double, 1024, RF_GEN64_1024>; };
 // the half-length configuration of the float32 in-place pass of length 1024 (rf_k_col_plain.hip RF_Y_COL2_1024; the emulator follows)
 struct PairSel1024 { using type = ColCfg<float, 512, 8, 8, 8, 8, 256>; };
+#ifndef RF_Y_COL2_1024
+#define RF_Y_COL2_1024 1               // (rf_k_col_plain.hip launch_col_plain, rf_k_yz.hip: the in-place float32 pass of length 1024 in that form)
+#endif
 #define RF_COL_SIZES(X) X(8) X(16) X(32) X(64) X(128) X(256) X(512) X(1024) X(2048)
 
 // ---- contiguous (z) pass: M = nz / 2 ----------------------------------------

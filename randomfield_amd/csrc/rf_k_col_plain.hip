@@ -149,9 +149,8 @@ hipError_t launch_col_plain(int f64, int N, int dir, void* base, ColGeom g, long
       if (!po || e != hipSuccess) return e;
     }
   }
-#ifndef RF_Y_COL2_1024
-#define RF_Y_COL2_1024 1               // the float32 in-place pass of length 1024 as two 512-point transforms per 8-column tile (Col2): 256 threads, 36 KB of
-#endif                                 // LDS, 109 registers -- FOUR workgroups per CU where the whole-column kernel (72 KB) has two.  The pass is latency-bound,
+                                       // RF_Y_COL2_1024 (rf_configs.h): the float32 in-place pass of length 1024 as two 512-point transforms per 8-column tile (Col2): 256 threads, 36 KB of
+                                       // LDS, 109 registers -- FOUR workgroups per CU where the whole-column kernel (72 KB) has two.  The pass is latency-bound,
                                        // not HBM-bound (its slab is read once from HBM and handed to the z pass through the Infinity Cache): more tiles in
                                        // flight per CU, y pass 1.70 -> 1.61 ms per 1024^3 (profiles/r04_ab/ycol2.log)
   if (RF_Y_COL2_1024 && N == 1024 && !f64) {

@@ -96,21 +96,14 @@ __global__ __launch_bounds__(256) void fix_fill_kernel(IOF io, CT* __restrict__ 
 // (the kernels that repair the kz = 0 slot -- FIX = 1 computes it, FIX = 3 loads it from the side buffer -- hold the eight values next
 // to the parked half: 140 - 260 registers.  They run few tiles and get the budget of two waves per SIMD instead of 190 - 300 bytes
 // of scratch per thread at four)
+// one tile of a Col2 pass (the body of col2_kernel; yz_merged_kernel runs it for its y tiles too)
 template <class C1, int DIR, class IO>
-__global__ __launch_bounds__(C1::NT, (IO::FIX_MODE != 0 ? 2 : col_min_waves<C1, IO>())) void col2_kernel(IO io, const cplx<typename C1::T>* __restrict__ tw2,
-                                                                             long long ntiles, long long tile_mul,
-                                                                             long long tile_add, int skip_period) {
+__device__ __forceinline__ void col2_body(IO& io, const cplx<typename C1::T>* __restrict__ tw2, long long tile, char* rf_smem) {
   using X = Col2<C1, DIR, IO>;
   using F = typename X::F;
   using cx = cplx<typename C1::T>;
-  extern __shared__ __attribute__((aligned(16))) char rf_smem[];
   cx* lds = reinterpret_cast<cx*>(rf_smem);
   const int tid = threadIdx.x;
-  long long tile = xcd_tile(blockIdx.x, ntiles) * tile_mul + tile_add;
-  if (skip_period > 0) {
-    const unsigned t = (unsigned)tile;
-    tile = (long long)(t + t / (unsigned)(skip_period - 1) + 1u);
-  }
   io.bind_seed();
   typename F::TwRegs twr;
   typename X::Park pk;
@@ -160,6 +153,19 @@ __global__ __launch_bounds__(C1::NT, (IO::FIX_MODE != 0 ? 2 : col_min_waves<C1, 
   }
 }
 
+template <class C1, int DIR, class IO>
+__global__ __launch_bounds__(C1::NT, (IO::FIX_MODE != 0 ? 2 : col_min_waves<C1, IO>())) void col2_kernel(IO io, const cplx<typename C1::T>* __restrict__ tw2,
+                                                                             long long ntiles, long long tile_mul,
+                                                                             long long tile_add, int skip_period) {
+  extern __shared__ __attribute__((aligned(16))) char rf_smem[];
+  long long tile = xcd_tile(blockIdx.x, ntiles) * tile_mul + tile_add;
+  if (skip_period > 0) {
+    const unsigned t = (unsigned)tile;
+    tile = (long long)(t + t / (unsigned)(skip_period - 1) + 1u);
+  }
+  col2_body<C1, DIR, IO>(io, tw2, tile, rf_smem);
+}
+
 // EXPERIMENT (RF_Z_XLANE = 1): the exchange between the middle and the last radix-8 stage of the z pass
 // through the wave's cross-lane network instead of the LDS row image.  With M / 8 = 64 a wave owns a row in both stages: stage-2
 // thread j = 8a + b leaves elements i = 64a + b + 8m (m = 0..7), stage-3 thread j' = b + 8p wants i = j' + 64m' -- element p of
@@ -186,21 +192,15 @@ __device__ __forceinline__ void xlane_transpose8(cplx<T>* v, int lane) {
   }
 }
 
-// z pass: c2r rows + per-workgroup (sum, sum of squares) partials
+// one tile of the z pass (the body of row_c2r_kernel; yz_merged_kernel runs it for its z tiles): c2r rows + the workgroup's
+// (sum, sum of squares) into partials[2 tile]
 template <class C, class IO>
-__global__ __launch_bounds__(C::NT) void row_c2r_kernel(IO io, const cplx<typename C::T>* __restrict__ tw,
-                                                        long long nrows, double* __restrict__ partials) {
+__device__ __forceinline__ void row_c2r_body(IO& io, const cplx<typename C::T>* __restrict__ tw, long long nrows, double* __restrict__ partials,
+                                             long long tile, char* rf_smem) {
   using F = RowC2R<C, IO>;
   using cx = cplx<typename C::T>;
-  extern __shared__ __attribute__((aligned(16))) char rf_smem[];
   cx* lds = reinterpret_cast<cx*>(rf_smem);
   const int tid = threadIdx.x;
-  // last rows first: the pass before this one wrote the array front to back, so its end is what the 256 MiB Infinity
-  // Cache still holds (measured: DESIGN.md section 3.8)
-#ifndef RF_Z_REVERSE
-#define RF_Z_REVERSE 1
-#endif
-  const long long tile = RF_Z_REVERSE ? (long long)gridDim.x - 1 - blockIdx.x : (long long)blockIdx.x;
   typename F::Regs r;
   typename F::TwRegs twr;
   const cx* ltw = F::lds_tw(lds);
@@ -269,6 +269,20 @@ __global__ __launch_bounds__(C::NT) void row_c2r_kernel(IO io, const cplx<typena
     partials[2 * tile] = a;
     partials[2 * tile + 1] = b;
   }
+}
+
+// z pass: c2r rows + per-workgroup (sum, sum of squares) partials
+template <class C, class IO>
+__global__ __launch_bounds__(C::NT) void row_c2r_kernel(IO io, const cplx<typename C::T>* __restrict__ tw,
+                                                        long long nrows, double* __restrict__ partials) {
+  extern __shared__ __attribute__((aligned(16))) char rf_smem[];
+  // last rows first: the pass before this one wrote the array front to back, so its end is what the 256 MiB Infinity
+  // Cache still holds (measured: DESIGN.md section 3.8)
+#ifndef RF_Z_REVERSE
+#define RF_Z_REVERSE 1
+#endif
+  const long long tile = RF_Z_REVERSE ? (long long)gridDim.x - 1 - blockIdx.x : (long long)blockIdx.x;
+  row_c2r_body<C, IO>(io, tw, nrows, partials, tile, rf_smem);
 }
 
 // forward z pass: r2c rows in place

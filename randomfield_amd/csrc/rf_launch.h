@@ -67,6 +67,10 @@ hipError_t launch_col_fastgen(int f64, int N, void* W, ColGeom g, long long ncol
 bool col_plain_addressable(int f64, int N, ColGeom g);   // false: the pass would need 64-bit lane offsets and has none (N < 1024)
 int col_tile_cols(int f64, int N);   // tile width (columns) of the strided pass of length N, 0 if unsupported
 // z pass of c2r: rows of M = nz/2 complex -> nz reals, scaled; partials[2*tile] = (sum, sumsq)
+// the z pass of one slab (Wz, nrows rows) and the in-place y pass of another (Wy, ncols columns) in one launch (rf_k_yz.hip)
+bool yz_merged_supported(int f64, int ny, int M);
+hipError_t launch_yz_merged(int f64, int ny, int M, void* Wz, long long nrows, double scale, const void* twz, double* partials, void* Wy, ColGeom gy,
+                            long long ncols, const void* twy, hipStream_t s, bool prepare_only = false);
 hipError_t launch_row_c2r(int f64, int M, void* W, long long nrows, double scale, const void* tw,
                           double* partials, hipStream_t s, bool prepare_only = false);
 // z pass of a slab-decomposed plan: rows gathered from P received blocks of nzl kz planes each

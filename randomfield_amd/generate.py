@@ -278,6 +278,7 @@ class Generator(object):
             # same power and smoothing as the tables the device plan holds: nothing to upload (a stream sync and a table rebuild
             # per call otherwise); the plan itself remembers what it was last given, whoever gave it
             dev.set_power(log10_k, sigma, if_changed=True)
+            realised = False
             if self.rng == "reference":
                 # RandomState(seed).normal (random.py:24): MT19937 + polar method replayed on the GPU from the seed's
                 # 624-word start state -- integer seeds, array seeds (init_by_array) and None alike; no host deviates
@@ -294,6 +295,13 @@ class Generator(object):
                         with self.plan_c2r.dist.deadline("first shared replay of the reference stream"):
                             dev.reference_noise_shared(seed, single=single)
                         self._shared_replay_ran = True
+                elif (single and not self.distributed and not (save_potential and self.store_potential)
+                      and dev.can_batch_reference()):
+                    # one device call: the replay and the passes queued back to back (no host synchronisation between them,
+                    # untimed passes: the z pass of a slab shares its launch with the y pass of the next) -- a same-seed
+                    # batch of one (rf_realise_batch_reference); the deviates stay resident as float32 pairs
+                    dev.realise_batch_reference([seed], want_rms=False)
+                    realised = True
                 else:
                     dev.reference_noise(seed, single=single)
                 noise = "resident"
@@ -306,13 +314,15 @@ class Generator(object):
                 # otherwise the library runs rows K,T,R,S -> k-space, the division, and the c2r transform.
                 if not self.store_potential and dev.can_regenerate_potential(noise):
                     # nothing to store: the potential can be formed again from the seed / the resident deviates on demand
-                    self._realise(dev, dseed, noise)
+                    if not realised:
+                        self._realise(dev, dseed, noise)
                     self.potential = _RegeneratedPotential(self, dseed, noise)
                 else:
                     dev.realise_potential(dseed, noise)
                     self.potential = _DevicePotential(self)
             else:
-                self._realise(dev, dseed, noise)    # fused: k-space never materialised
+                if not realised:
+                    self._realise(dev, dseed, noise)    # fused: k-space never materialised
                 self.potential = None
             mean, std = dev.moments()
             self.delta_field_rms = self.plan_c2r.data_out.dtype.type(std)
