@@ -235,6 +235,13 @@ int rf_elapsed_ms(rf_plan* plan, float* ms);
 /* GPU time of each kernel of the last rf_realise, 5 floats: x pass (main kernel), y pass, z pass, reduce,
  * and the small x-pass launch that repairs the kz = 0 tiles (0 when the x pass is a single launch) */
 int rf_kernel_ms(rf_plan* plan, float* ms5);
+/* The z pass of slab s and the y pass of slab s + 1 in ONE launch (the next slab's tiles fill the compute units the draining pass leaves
+ * idle; float32 plans whose y pass is the 1024-point one and whose rows hold 512 complex: the 1024^3 pipeline).  mode 0: never;
+ * 1 (default): untimed calls -- graph-captured batches, rf_realise_batch_reference; 2: timed calls too, with an event behind every
+ * launch: rf_kernel_ms then reports [1] = the first y launch + all merged launches, [2] = the last z launch, and rf_merged_yz_ms the
+ * merged launches' summed duration and number.  (No reference counterpart: launch structure of transform.py:303-315's one call.) */
+int rf_set_merged_yz(rf_plan* plan, int mode);
+int rf_merged_yz_ms(rf_plan* plan, float* sum_ms, int* launches);
 /* (when the y and z passes run slab by slab -- RF_FLAG_YZ_SLAB_PLANES -- ms5[1] and ms5[2] are the sums over their launches)
  * How the y / z passes of this plan are launched: *nslab launches each, over *planes x planes (1 and nx: whole-grid passes).
  * No reference counterpart: the reference's FFT is one library call (transform.py:303-315). */

@@ -85,6 +85,8 @@ SIGNATURES = {
                                             ctypes.POINTER(ctypes.c_double)]),
     "rf_realise_batch_reference": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32), ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
     "rf_can_batch_reference": (ctypes.c_int, [ctypes.c_void_p]),
+    "rf_set_merged_yz": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "rf_merged_yz_ms": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int)]),
     "rf_yz_slabs": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "rf_comm_unique_id": (ctypes.c_int, [ctypes.c_void_p]),
     "rf_comm_init": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
@@ -256,6 +258,17 @@ class DevicePlan(object):
     def set_yz_slab_planes(self, planes=-1):
         """x planes per slab of the y / z passes (single-GPU plans): -1 automatic (about the Infinity Cache's size), 0 = whole grid."""
         check(self._lib.rf_plan_set_flag(self._h, 16, int(planes)), "rf_plan_set_flag")
+
+    def set_merged_yz(self, mode=1):
+        """The z pass of slab s and the y pass of slab s + 1 in one launch (rf_k_yz.hip): 0 never, 1 untimed calls (default),
+        2 timed calls too -- :meth:`merged_yz_ms` then gives the merged launches' average duration."""
+        check(self._lib.rf_set_merged_yz(self._h, int(mode)), "rf_set_merged_yz")
+
+    def merged_yz_ms(self):
+        """(summed duration in ms, number) of the merged launches of the last timed call under ``set_merged_yz(2)``."""
+        ms, n = ctypes.c_float(), ctypes.c_int()
+        check(self._lib.rf_merged_yz_ms(self._h, ctypes.byref(ms), ctypes.byref(n)), "rf_merged_yz_ms")
+        return float(ms.value), int(n.value)
 
     def set_exchange_chunks(self, chunks=1):
         """Multi-rank plans: generate / transform / send the rank's kz slab as ``chunks`` sub-slabs (a power of two), the exchange

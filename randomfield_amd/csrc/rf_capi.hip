@@ -124,6 +124,8 @@ struct rf_plan {
   hipEvent_t bev[2] = {nullptr, nullptr}; // ... replay finished / generation pass has read the runs
   std::vector<hipEvent_t> slab_ev;        // timed runs: after y(i), after z(i)
   int slab_timed = 0;                     // slabs of the last timed run (0: whole-grid passes, ev[2] / ev[3] apply)
+  int yz_merge = 1;                       // rf_set_merged_yz: 0 never, 1 untimed calls (default), 2 timed calls too (events per launch)
+  int slab_merged = 0;                    // slabs of the last timed run that used merged launches: slab_ev = after y(0), after every merged launch, after the last z
   void* P = nullptr;                      // lazy: saved potential, API layout (= P_base + an offset chosen by ensure_p)
   void* P_base = nullptr;                 // the allocation P lives in
   size_t w_bytes = 0, k_bytes = 0, p_bytes = 0;      // field buffer, k-space side array, potential array (padded rows)
@@ -632,9 +634,16 @@ int queue_yz(rf_plan* p, void* W, hipStream_t s, double* stats_out, bool timed) 
   // untimed single-rank float32 realisations at the sizes rf_k_yz.hip serves: the z pass of slab i and the y pass of slab i + 1 share a
   // launch (the next slab's y tiles fill the CUs the draining z pass leaves idle); timed calls keep one launch per pass and slab, so
   // that rf_kernel_ms still means what it says
+  // (rf_set_merged_yz(2) merges timed calls too, with an event behind every launch: rf_merged_yz_ms)
   static const bool merge_env = [] { const char* e = getenv("RANDOMFIELD_MERGE_YZ"); return !e || atoi(e) != 0; }();
-  if (merge_env && !timed && !xp && !p->zscale && nslab > 1 && p->nx % B == 0 && yz_merged_supported(p->f64, p->ny, (int)p->nzc)) {
+  if (merge_env && (timed ? p->yz_merge >= 2 : p->yz_merge >= 1) && !xp && !p->zscale && nslab > 1 && p->nx % B == 0 &&
+      yz_merged_supported(p->f64, p->ny, (int)p->nzc)) {
+    if (timed) {
+      while ((int)p->slab_ev.size() < nslab + 1) { hipEvent_t e; RF_HIP(hipEventCreate(&e)); p->slab_ev.push_back(e); }
+      p->slab_merged = nslab;
+    }
     RF_HIP(launch_col_plain(p->f64, p->ny, +1, W, gy, B * nzl, p->tw_y, s));
+    if (timed) RF_HIP(hipEventRecord(p->slab_ev[0], s));
     for (int i = 0; i < nslab; ++i) {
       char* Ws = (char*)W + (long long)i * B * plane;
       double* part = p->partials + 2 * (long long)i * B * tiles_per_plane;
@@ -642,8 +651,11 @@ int queue_yz(rf_plan* p, void* W, hipStream_t s, double* stats_out, bool timed) 
         RF_HIP(launch_yz_merged(p->f64, p->ny, (int)p->nzc, Ws, B * p->ny, scale, p->tw_z, part, Ws + B * plane, gy, B * nzl, p->tw_y, s));
       else
         RF_HIP(launch_row_c2r(p->f64, (int)p->nzc, Ws, B * p->ny, scale, p->tw_z, part, s));
+      if (timed) RF_HIP(hipEventRecord(p->slab_ev[i + 1], s));
     }
+    if (timed) { RF_HIP(hipEventRecord(p->ev[2], s)); RF_HIP(hipEventRecord(p->ev[3], s)); }
     RF_HIP(launch_reduce_partials(p->partials, p->npartials, stats_out, p->partials + 2 * p->npartials, s));
+    if (timed) RF_HIP(hipEventRecord(p->ev[4], s));
     return 0;
   }
   for (int i = 0; i < nslab; ++i) {
@@ -714,6 +726,7 @@ int queue_c2r(rf_plan* p, const GenParams& gp, const void* kspace) {
     return 0;
   }
   p->slab_timed = 0;                            // (set again by queue_yz when this call runs the y / z passes slab by slab, timed)
+  p->slab_merged = 0;
   if (p->timed) RF_HIP(hipEventRecord(p->ev[0], p->stream));
   if (p->nranks == 1 && !p->force_slab) {       // one GPU: x pass, then the y / z passes (slab by slab on large grids)
     if (int rc = queue_xyz(p, gp, kspace, p->W, p->stream, p->stats, p->timed)) return rc;
@@ -1747,6 +1760,17 @@ int rf_kernel_ms(rf_plan* p, float* ms5) {
     ms5[2] = zs;
     RF_HIP(hipEventElapsedTime(&ms5[3], p->slab_ev[2 * p->slab_timed - 1], p->ev[4]));
   }
+  if (p->slab_merged > 0) {                // merged launches (rf_set_merged_yz(2)): [1] = the first y launch + every merged launch, [2] = the last z launch
+    float t = 0, ys = 0;
+    RF_HIP(hipEventElapsedTime(&ys, p->ev[1], p->slab_ev[0]));
+    for (int i = 1; i < p->slab_merged; ++i) {
+      RF_HIP(hipEventElapsedTime(&t, p->slab_ev[i - 1], p->slab_ev[i]));
+      ys += t;
+    }
+    ms5[1] = ys;
+    RF_HIP(hipEventElapsedTime(&ms5[2], p->slab_ev[p->slab_merged - 1], p->slab_ev[p->slab_merged]));
+    RF_HIP(hipEventElapsedTime(&ms5[3], p->slab_ev[p->slab_merged], p->ev[4]));
+  }
   // the x pass of the fast generation is two launches: the few tiles that hold slot kz = 0 (with the Hermitian
   // repair), then all the others; report them separately so that [0] is the main kernel alone
   ms5[4] = 0.0f;
@@ -1754,6 +1778,35 @@ int rf_kernel_ms(rf_plan* p, float* ms5) {
     RF_HIP(hipEventElapsedTime(&ms5[4], p->ev[0], p->ev[5]));
     RF_HIP(hipEventElapsedTime(&ms5[0], p->ev[5], p->ev[1]));
   }
+  return 0;
+}
+
+// 0: one launch per pass and slab always; 1 (default): untimed calls (graph-captured batches, rf_realise_batch_reference) put the z pass
+// of slab s and the y pass of slab s + 1 into one launch where rf_k_yz.hip serves the shape; 2: timed calls (rf_realise ...) too
+int rf_set_merged_yz(rf_plan* p, int mode) {
+  RF_REQUIRE(p, "null plan");
+  RF_REQUIRE(mode >= 0 && mode <= 2, "mode is 0, 1 or 2");
+  if (p->yz_merge != mode) {
+    RF_HIP(hipSetDevice(p->device));
+    RF_HIP(hipStreamSynchronize(p->stream));
+    drop_graphs(p);                          // (captured batches carry their launches)
+    p->yz_merge = mode;
+  }
+  return 0;
+}
+
+// the merged launches of the last timed call under rf_set_merged_yz(2): their summed duration (HIP events on the plan's stream) and number
+int rf_merged_yz_ms(rf_plan* p, float* sum_ms, int* launches) {
+  RF_REQUIRE(p && sum_ms && launches, "null argument");
+  RF_REQUIRE(p->timed && p->slab_merged > 1, "the last call was not a timed call with merged y / z launches (rf_set_merged_yz(2), a shape rf_k_yz.hip serves)");
+  RF_HIP(hipEventSynchronize(p->ev[4]));
+  float t = 0, sum = 0;
+  for (int i = 1; i < p->slab_merged; ++i) {
+    RF_HIP(hipEventElapsedTime(&t, p->slab_ev[i - 1], p->slab_ev[i]));
+    sum += t;
+  }
+  *sum_ms = sum;
+  *launches = p->slab_merged - 1;
   return 0;
 }
 

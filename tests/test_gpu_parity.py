@@ -1963,3 +1963,35 @@ def test_batched_reference_stream_realisations(hip, dpower, shape):
     plan.realise(seed=3)                                                    # (the plan goes back to other work afterwards)
     assert abs(plan.moments()[1] - rms0) < 0.2 * rms0
     plan.close()
+
+
+def test_merged_yz_launches_give_the_same_field(hip, dpower):
+    """rf_k_yz.hip: the z pass of slab s and the y pass of slab s + 1 in one launch (untimed calls by default, timed calls under
+    set_merged_yz(2)).  Both halves are the product kernels' own bodies: the field must be bit for bit the one-launch-per-pass
+    field, through eager calls, through a graph-replayed batch and with an uploaded k space; rf_merged_yz_ms reports its launches."""
+    k, Pk = dpower
+    shape = (256, 1024, 1024)                        # 4 slabs of 64 planes
+    plan = make_plan(hip, shape, np.complex64, k, Pk)
+    assert plan.yz_slabs() == (4, 64)
+    plan.set_merged_yz(0)
+    plan.realise(seed=77)
+    ref = plan.download_real()
+    m0 = plan.moments()
+    with pytest.raises(RuntimeError):
+        plan.merged_yz_ms()                          # no merged launches in that call
+    plan.set_merged_yz(2)
+    plan.realise(seed=77)
+    assert np.array_equal(plan.download_real(), ref) and plan.moments() == m0
+    ms, n = plan.merged_yz_ms()
+    kern = plan.kernel_ms()
+    assert n == 3 and 0.0 < ms < 50.0 and abs(kern[1] - ms) < kern[1] and kern[2] > 0.0
+    plan.set_merged_yz(1)                            # the default: timed calls one launch per pass, untimed ones merged
+    plan.realise(seed=78)
+    other = plan.download_real()
+    assert not np.array_equal(other, ref)
+    plan.realise_batch(np.array([78, 77], np.uint64), want_rms=False)      # graph replay: merged launches
+    assert np.array_equal(plan.download_real(), ref)
+    plan.set_merged_yz(0)
+    plan.realise_batch(np.array([78], np.uint64), want_rms=False)          # (the captured graphs were dropped with the mode)
+    assert np.array_equal(plan.download_real(), other)
+    plan.close()
