@@ -543,6 +543,7 @@ def main():
                      "kernel_ms_note": "HIP-event intervals around each pass of EAGER realisations in this process (they include the "
                                        "launch gaps, and y / z are the sums over their %d launches of %d x planes): their sum is "
                                        "larger than ms_per_step, which is the graph replay" % (nslab, slab_planes),
+                     "yz_slabs": nslab,
                      "launches_per_realisation": {"x": 3, "y": nslab, "z": nslab, "reduce": 1},
                      "traffic_bytes_per_launch": pass_traffic,
                      "pass_frac_of_hbm_peak": {k: round(alg[i] / (pass_ms[i] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)

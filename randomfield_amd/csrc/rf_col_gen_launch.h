@@ -34,6 +34,22 @@ hipError_t launch_one(const IO& io_in, long long ncols, const cplx<typename C::T
   return hipGetLastError();
 }
 
+// two kinds of tile in one grid (rf_kernels.h col_pair_kernel): workgroups [0, na) = ioa on tiles b * mul_a, then nb workgroups = iob on
+// every tile except those = 0 mod skip_b
+template <class C, class IOA, class IOB>
+hipError_t launch_pair(const IOA& ioa, const IOB& iob, long long ncols, const cplx<typename C::T>* tw, hipStream_t s, bool prepare_only,
+                       long long na, long long mul_a, long long nb, int skip_b) {
+  if (ncols % C::TC || iob.g.inner <= 0 || (iob.g.inner & (iob.g.inner - 1))) return hipErrorInvalidValue;
+  if (!prepare_only && (!iob.g.rows_ok(C::N / C::RL, C::NPASS) || (iob.g.sub_shift > 0 && (1 << iob.g.sub_shift) < C::TC))) return hipErrorInvalidValue;
+  auto k = col_pair_kernel<C, +1, IOA, IOB>;
+  constexpr int la = C::LDS_BYTES + IOA::LDS_EXTRA, lb = C::LDS_BYTES + IOB::LDS_EXTRA, lds_bytes = la > lb ? la : lb;
+  static LdsAttrLatch latch;
+  if (hipError_t e = latch.ensure((const void*)k, lds_bytes); e != hipSuccess) return e;
+  if (prepare_only) return hipSuccess;
+  hipLaunchKernelGGL(k, dim3((unsigned)(na + nb)), dim3(C::NT), lds_bytes, s, ioa, iob, tw, na, mul_a, nb, skip_b);
+  return hipGetLastError();
+}
+
 // the same through col2_kernel: a pass of length 2 C1::N as two C1 transforms per tile (rf_fft.h Col2); tw2 = the 2 C1::N-point table
 template <class C1, class IO>
 hipError_t launch_one2(const IO& io_in, long long ncols, const cplx<typename C1::T>* tw2, hipStream_t s, bool prepare_only,
@@ -83,7 +99,7 @@ hipError_t launch_fast_one2(const FastGenParams& gp, cplx<typename C1::T>* W, Co
   if (!fixbuf) return hipErrorInvalidValue;
   IOF iof; iof.base = W; iof.g = g; iof.gp = gp; iof.kz0 = kz0; iof.nzl = nzl; iof.rec = nullptr; iof.pot = nullptr;
   hipError_t e = launch_fix_fill(iof, fixbuf, s);
-  if (RF_FIX_MERGED) {
+  if (RF_FIX_MERGED == 1) {
     if (e == hipSuccess && after_repair) e = hipEventRecord(after_repair, s);
     return e != hipSuccess ? e : launch_one2<C1, IOC>(ioc, ncols, tw2, s, false);
   }
@@ -119,6 +135,8 @@ hipError_t launch_fast_one(const FastGenParams& gp, CT* W, ColGeom g, long long 
   if (po) {
     hipError_t e = launch_one<C, IO0>(io0, ncols, tw, s, true);
     if (e == hipSuccess && side) e = launch_one<C, IOC>(ioc, ncols, tw, s, true);
+    if constexpr (side && RF_FIX_MERGED == 3)
+      if (e == hipSuccess) e = launch_pair<C, IOC, IO0>(ioc, io0, ncols, tw, s, true, 8, 1, 8, 2);
     return e != hipSuccess ? e : launch_one<C, IO1>(io1, ncols, tw, s, true);
   }
   if (!split) return launch_one<C, IO1>(io1, ncols, tw, s, false);
@@ -137,6 +155,14 @@ hipError_t launch_fast_one(const FastGenParams& gp, CT* W, ColGeom g, long long 
       if (e == hipSuccess) e = launch_one<C, IO0>(io0, ncols, tw, s, false);
       if (e == hipSuccess && after_repair) e = hipEventRecord(after_repair, s);
       return e != hipSuccess ? e : launch_one<C, IOC>(ioc, ncols, tw, s, false, ncols / nzl, tiles_per_iy, 0);
+    }
+  }
+  if constexpr (side && RF_FIX_MERGED == 3) {
+    // the kz = 0 tiles (repair from the side buffer) and all the others in ONE grid (rf_kernels.h col_pair_kernel)
+    const long long na = ncols / nzl, nb = ntiles - ntiles / tiles_per_iy;
+    if (e == hipSuccess && na % 8 == 0 && tiles_per_iy >= 2 && tiles_per_iy < (1LL << 30) && ntiles < (1LL << 31) && na + nb < (1LL << 31)) {
+      if (after_repair && (e = hipEventRecord(after_repair, s)) != hipSuccess) return e;       // (behind the side-buffer fill)
+      return launch_pair<C, IOC, IO0>(ioc, io0, ncols, tw, s, false, na, tiles_per_iy, nb, (int)tiles_per_iy);
     }
   }
   if (e == hipSuccess) e = launch_one<C, IOC>(ioc, ncols, tw, s, false, ncols / nzl, tiles_per_iy, 0);

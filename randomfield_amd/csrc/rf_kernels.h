@@ -23,21 +23,13 @@ constexpr int col_min_waves() {
   return w < 1 ? 1 : (w > 4 ? 4 : w);
 }
 
+// one tile of a strided pass (the body of col_kernel; col_pair_kernel runs two kinds of it in one grid)
 template <class C, int DIR, class IO>
-__global__ __launch_bounds__(C::NT, (col_min_waves<C, IO>())) void col_kernel(IO io, const cplx<typename C::T>* __restrict__ tw,
-                                                                           long long ntiles, long long tile_mul,
-                                                                           long long tile_add, int skip_period) {
+__device__ __forceinline__ void col_body(IO& io, const cplx<typename C::T>* __restrict__ tw, long long tile, char* rf_smem) {
   using F = ColFFT<C, DIR, IO>;
   using cx = cplx<typename C::T>;
-  extern __shared__ __attribute__((aligned(16))) char rf_smem[];
   cx* lds = reinterpret_cast<cx*>(rf_smem);
   const int tid = threadIdx.x;
-  long long tile = xcd_tile(blockIdx.x, ntiles) * tile_mul + tile_add;          // (1, 0) unless a tile subset is run
-  if (skip_period > 0) {                                                          // all tiles except those = 0 mod skip_period
-    const unsigned t = (unsigned)tile;
-    tile = (long long)(t + t / (unsigned)(skip_period - 1) + 1u);
-  }
-  tile = io.remap_tile(tile);                                                     // (identity except for XposeColIO)
   const cx* ltw = tw;
   io.bind_seed();
   typename F::TwRegs twr;
@@ -70,6 +62,35 @@ __global__ __launch_bounds__(C::NT, (col_min_waves<C, IO>())) void col_kernel(IO
     for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off);
     __syncthreads();                         // the LDS tile is no longer read
     io.finish(tid, C::NT, reinterpret_cast<double*>(rf_smem), tile, a, [] { __syncthreads(); });
+  }
+}
+
+template <class C, int DIR, class IO>
+__global__ __launch_bounds__(C::NT, (col_min_waves<C, IO>())) void col_kernel(IO io, const cplx<typename C::T>* __restrict__ tw,
+                                                                           long long ntiles, long long tile_mul,
+                                                                           long long tile_add, int skip_period) {
+  extern __shared__ __attribute__((aligned(16))) char rf_smem[];
+  long long tile = xcd_tile(blockIdx.x, ntiles) * tile_mul + tile_add;          // (1, 0) unless a tile subset is run
+  if (skip_period > 0) {                                                          // all tiles except those = 0 mod skip_period
+    const unsigned t = (unsigned)tile;
+    tile = (long long)(t + t / (unsigned)(skip_period - 1) + 1u);
+  }
+  col_body<C, DIR, IO>(io, tw, io.remap_tile(tile), rf_smem);                     // (remap: identity except for XposeColIO)
+}
+
+// Two kinds of tile of the same pass in ONE grid: workgroups [0, na) run IO `ioa` on the tiles b * mul_a (the generation pass's kz = 0
+// tiles with the Hermitian repair from the side buffer), the others IO `iob` on all tiles except those = 0 mod skip_b.  The kz = 0
+// launch on its own is two rounds of workgroups -- latency, not throughput (0.03 - 0.05 ms per 1024^3 realisation); in front of the
+// main tiles in one grid it costs its share of the throughput.  Each kind keeps its own code: a uniform branch on the workgroup index.
+template <class C, int DIR, class IOA, class IOB>
+__global__ __launch_bounds__(C::NT, (col_min_waves<C, IOB>())) void col_pair_kernel(IOA ioa, IOB iob, const cplx<typename C::T>* __restrict__ tw,
+                                                                                 long long na, long long mul_a, long long nb, int skip_b) {
+  extern __shared__ __attribute__((aligned(16))) char rf_smem[];
+  if ((long long)blockIdx.x < na) {
+    col_body<C, DIR, IOA>(ioa, tw, (long long)blockIdx.x * mul_a, rf_smem);
+  } else {
+    const unsigned t = (unsigned)xcd_tile((long long)blockIdx.x - na, nb);       // (na is a multiple of 8: xcd_tile's assumption holds)
+    col_body<C, DIR, IOB>(iob, tw, (long long)(t + t / (unsigned)(skip_b - 1) + 1u), rf_smem);
   }
 }
 

@@ -3,7 +3,7 @@
 
     python3 tools/cfg_workload.py <case> [reps] [variant library]
 
-cases: 512 | 1024 | ref (1024^3, rng='reference': MT19937 replay + generation pass reading the deviates) | refbatch |
+cases: 512 | 1024 | ref (1024^3, rng='reference': MT19937 replay + generation pass reading the deviates) | refone | refbatch |
        f64 (1024^3 float64) | f64ln (config 5: float64 + lognormal, fused) | 2048 (2048^3 float32 on one GPU) |
        rank0 / rank3 (per-rank compute of the 2048^3 / 8 job, virtual ranks: forward + backward halves)
 Prints one JSON line: wall ms per call (median) and the plan's per-pass event times where the call records them."""
@@ -65,6 +65,9 @@ elif case == "ref":
         plan.realise(noise="resident")
     res = timed(plan, f, reps)
     res.update(split)
+elif case == "refone":              # what Generator(rng='reference') runs: replay + passes as ONE device call (a batch of one seed)
+    plan = make(1024, np.complex64)
+    res = timed(plan, lambda i: plan.realise_batch_reference([300 + i], want_rms=False), reps, kernel_ms=False)
 elif case == "refbatch":
     plan = make(1024, np.complex64)
     seeds = list(range(200, 200 + max(reps, 2)))

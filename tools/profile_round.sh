@@ -16,12 +16,12 @@ python3 tools/pmc_summary.py $(find $out/sqa -name "*counter_collection.csv") > 
 python3 tools/pmc_summary.py $(find $out/sqb -name "*counter_collection.csv") > $out/pmc_sq_b.txt
 python3 tools/pmc_summary.py $(find $out/fetch -name "*counter_collection.csv") > $out/pmc_fetch_size.txt
 python3 tools/pmc_summary.py $(find $out/write -name "*counter_collection.csv") > $out/pmc_write_size.txt
-nslab=$(python3 -c "import json;print(json.load(open('$out/bench.json'))['pipeline']['launches_per_realisation']['y'])")
+nslab=$(python3 -c "import json;print(json.load(open('$out/bench.json'))['pipeline']['yz_slabs'])")
 python3 tools/make_traffic.py $(find $out/fetch -name "*counter_collection.csv") $(find $out/write -name "*counter_collection.csv") $out/traffic.json "$tag" $nslab > $out/traffic.txt
 cp $(find $out/stats -name "*kernel_stats.csv") $out/kernel_stats.csv
 rm -rf $out/fetch $out/write $out/sqa $out/sqb $out/stats
 # every other BASELINE configuration / path: kernel stats, FETCH_SIZE / WRITE_SIZE and the SQ sets per configuration (tools/profile_cfg.sh)
-for c in ref 512 2048 f64 f64ln rank0 rank3; do
+for c in ref refone 512 2048 f64 f64ln rank0 rank3; do
   bash tools/profile_cfg.sh $out $c $c 3
 done
 ls $out
