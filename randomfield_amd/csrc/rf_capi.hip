@@ -193,6 +193,8 @@ struct rf_plan {
   const double* zscale = nullptr;         // the current call's z pass multiplies plane z by zscale[z] (device table: ztab)
   void* pot_target = nullptr;             // non-null while rf_realise_potential queues its x pass: where delta(k)/k^2 goes
   double* coll_scratch = nullptr;         // 2 doubles on the device for host-side all-reduces (never aliases `stats`)
+  void* br_tmp = nullptr;                 // rf_realise_batch_reference: [start states n x 624][accepted totals n][flags n], kept between calls
+  int br_cap = 0;                         // (allocating and freeing them cost a device synchronisation per call: one-seed batches are the Generator's call)
   double* ztab = nullptr;                 // 2 * nz doubles for lognormal / affine tables
   // fused lognormal realisations (rf_realise_lognormal): [growth nz][density nz][A nz][B nz][sigma 8] and the y pass's Parseval partials
   double* lntab = nullptr;
@@ -1031,7 +1033,7 @@ int rf_plan_destroy(rf_plan* p) {
   if (p->comm_stream) { (void)hipStreamSynchronize(p->comm_stream); (void)hipStreamDestroy(p->comm_stream); }
   for (auto& e : p->pev) if (e) (void)hipEventDestroy(e);
   void* bufs[] = {p->W, p->R, p->W2, p->R2, p->K, p->P_base, p->G, p->tw_x, p->tw_y, p->tw_z, p->kx2, p->ky2, p->kz2, p->xt, p->st, p->sl, p->bin,
-                  p->X, p->lntab, p->ypart, p->noise, p->mt_scratch, p->mt_send, p->mt_recv, p->mt_sbase, p->mt_first, p->mt_pos, p->mt_npos_dev, p->mt_states, p->mt_counts, p->mt_offsets, p->mt_rowtab, p->mt_flags, p->fixbuf, p->partials, p->stats, p->seeds_dev, p->ztab, p->frec, p->coll_scratch};
+                  p->X, p->lntab, p->ypart, p->noise, p->mt_scratch, p->mt_send, p->mt_recv, p->mt_sbase, p->mt_first, p->mt_pos, p->mt_npos_dev, p->mt_states, p->mt_counts, p->mt_offsets, p->mt_rowtab, p->mt_flags, p->br_tmp, p->fixbuf, p->partials, p->stats, p->seeds_dev, p->ztab, p->frec, p->coll_scratch};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   for (int i = 0; i < 2; ++i) {
@@ -2270,17 +2272,17 @@ int rf_realise_batch_reference(rf_plan* p, const uint32_t* states, int n, double
     RF_HIP(hipStreamCreateWithFlags(&p->aux_stream, hipStreamNonBlocking));
     for (auto& e : p->bev) RF_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
-  // all start states and the per-seed accepted totals live on the device for the length of the batch (released on every path)
-  struct DevTmp {
-    void* ptr = nullptr;
-    ~DevTmp() { if (ptr) (void)hipFree(ptr); }
-  } dstates_mem, dtotals_mem, dflags_mem;
-  RF_HIP(hipMalloc(&dstates_mem.ptr, (size_t)n * 624 * sizeof(uint32_t)));
-  RF_HIP(hipMalloc(&dtotals_mem.ptr, (size_t)n * sizeof(unsigned long long)));
-  RF_HIP(hipMalloc(&dflags_mem.ptr, (size_t)n * sizeof(int)));
-  uint32_t* dstates = (uint32_t*)dstates_mem.ptr;
-  unsigned long long* dtotals = (unsigned long long*)dtotals_mem.ptr;
-  int* dflags = (int*)dflags_mem.ptr;
+  // all start states and the per-seed accepted totals live on the device for the length of the batch (the plan keeps the block)
+  if (p->br_cap < n) {
+    if (p->br_tmp) RF_HIP(hipFree(p->br_tmp));
+    p->br_tmp = nullptr; p->br_cap = 0;
+    const int cap = n > 16 ? n : 16;
+    RF_HIP(hipMalloc(&p->br_tmp, (size_t)cap * (624 * sizeof(uint32_t) + sizeof(unsigned long long) + sizeof(int) + 4)));
+    p->br_cap = cap;
+  }
+  uint32_t* dstates = (uint32_t*)p->br_tmp;
+  unsigned long long* dtotals = (unsigned long long*)((char*)p->br_tmp + (size_t)p->br_cap * 624 * sizeof(uint32_t));
+  int* dflags = (int*)(dtotals + p->br_cap);
   RF_HIP(hipMemcpy(dstates, states, (size_t)n * 624 * sizeof(uint32_t), hipMemcpyHostToDevice));
   hipStream_t S = p->stream, R = p->aux_stream;
   // whatever deviates were resident are about to be overwritten; the plan claims the new ones (and a field) only once every
@@ -2291,7 +2293,7 @@ int rf_realise_batch_reference(rf_plan* p, const uint32_t* states, int n, double
   p->stats_valid = false;
   p->nseg = g.nseg;
   p->seg_cap = g.cap;
-  // both streams are drained before any return from here on: the temporaries above must not be freed under a running kernel
+  // both streams are drained before any return from here on
   auto drain = [&](int rc) { (void)hipStreamSynchronize(R); (void)hipStreamSynchronize(S); return rc; };
   auto replay = [&](int i) -> int {
     RF_HIP(hipMemcpyAsync(p->mt_states, dstates + (size_t)i * 624, 624 * sizeof(uint32_t), hipMemcpyDeviceToDevice, R));
