@@ -11,12 +11,17 @@
 #ifndef RF_FIX_MERGED
 #define RF_FIX_MERGED 0                // 1 = the tiles that hold kz = 0 run inside ONE launch of the FIX = 3 kernel over all tiles (a uniform branch: 8 loads
 #endif                                 // from the side buffer); 0 = as a launch of their own in front of the FIX = 0 kernel's (measured: DESIGN.md 3.2)
+#ifndef RF_SRC2_PAIR_LAUNCH
+#define RF_SRC2_PAIR_LAUNCH 0          // 1 = the deviate-reading generation pass runs its kz = 0 tiles in the main launch's grid (col_pair_kernel):
+#endif                                 // measured, 9.25 - 9.28 against 9.25 - 9.43 ms per one-call same-seed realisation -- inside the noise; off
 #ifndef RF_COL2_F64_1024
 #define RF_COL2_F64_1024 1             // the float64 generation pass of length 1024 as two 512-point transforms per tile (Col2): two workgroups per CU
 #endif
 
 namespace rf {
 namespace {
+template <class IO, class = void> struct io_noise_src { static constexpr int value = 0; };
+template <class IO> struct io_noise_src<IO, typename std::enable_if<(IO::NOISE_SRC >= 0)>::type> { static constexpr int value = IO::NOISE_SRC; };
 // runs tiles  b * tile_mul + tile_add,  b in [0, ntiles)
 template <class C, class IO>
 hipError_t launch_one(const IO& io_in, long long ncols, const cplx<typename C::T>* tw, hipStream_t s, bool prepare_only,
@@ -135,7 +140,7 @@ hipError_t launch_fast_one(const FastGenParams& gp, CT* W, ColGeom g, long long 
   if (po) {
     hipError_t e = launch_one<C, IO0>(io0, ncols, tw, s, true);
     if (e == hipSuccess && side) e = launch_one<C, IOC>(ioc, ncols, tw, s, true);
-    if constexpr (side && RF_FIX_MERGED == 3)
+    if constexpr (side && (RF_FIX_MERGED == 3 || (RF_FIX_MERGED == 0 && RF_SRC2_PAIR_LAUNCH && io_noise_src<IO0>::value == 2)))
       if (e == hipSuccess) e = launch_pair<C, IOC, IO0>(ioc, io0, ncols, tw, s, true, 8, 1, 8, 2);
     return e != hipSuccess ? e : launch_one<C, IO1>(io1, ncols, tw, s, true);
   }
@@ -157,8 +162,10 @@ hipError_t launch_fast_one(const FastGenParams& gp, CT* W, ColGeom g, long long 
       return e != hipSuccess ? e : launch_one<C, IOC>(ioc, ncols, tw, s, false, ncols / nzl, tiles_per_iy, 0);
     }
   }
-  if constexpr (side && RF_FIX_MERGED == 3) {
-    // the kz = 0 tiles (repair from the side buffer) and all the others in ONE grid (rf_kernels.h col_pair_kernel)
+  // the kz = 0 tiles (repair from the side buffer) and all the others in ONE grid (rf_kernels.h col_pair_kernel): experiments only
+  // (RF_FIX_MERGED = 3: every generation pass; RF_SRC2_PAIR_LAUNCH: the pass that reads the replayed deviates) -- no gain measured
+  constexpr bool pair_launch = side && (RF_FIX_MERGED == 3 || (RF_FIX_MERGED == 0 && RF_SRC2_PAIR_LAUNCH && io_noise_src<IO0>::value == 2));
+  if constexpr (pair_launch) {
     const long long na = ncols / nzl, nb = ntiles - ntiles / tiles_per_iy;
     if (e == hipSuccess && na % 8 == 0 && tiles_per_iy >= 2 && tiles_per_iy < (1LL << 30) && ntiles < (1LL << 31) && na + nb < (1LL << 31)) {
       if (after_repair && (e = hipEventRecord(after_repair, s)) != hipSuccess) return e;       // (behind the side-buffer fill)

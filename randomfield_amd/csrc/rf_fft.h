@@ -363,6 +363,7 @@ template <typename T, bool WIDE = false> struct GenColIO {
 template <int AB = 0, int FIX = 1, int SLAB = 0, int POT = 0, int SRC = 0, int XS = 1>
 struct FastGenColIOT {
   static_assert(XS == 1 || (XS == 2 && SLAB == 0 && POT != 1 && SRC != 1), "half-transform rows: native generation or float32 deviate pairs, no potential store");
+  static constexpr int NOISE_SRC = SRC;      // (0 native, 1 float64 deviates, 2 float32 pairs in the replay's runs)
   int xp = 0;
   RF_HD void set_phase(int p) { xp = p; }
   cplx<float>* base;
