@@ -639,7 +639,7 @@ int queue_yz(rf_plan* p, void* W, hipStream_t s, double* stats_out, bool timed) 
   // (rf_set_merged_yz(2) merges timed calls too, with an event behind every launch: rf_merged_yz_ms)
   static const bool merge_env = [] { const char* e = getenv("RANDOMFIELD_MERGE_YZ"); return !e || atoi(e) != 0; }();
   if (merge_env && (timed ? p->yz_merge >= 2 : p->yz_merge >= 1) && !xp && !p->zscale && nslab > 1 && p->nx % B == 0 &&
-      yz_merged_supported(p->f64, p->ny, (int)p->nzc)) {
+      yz_merged_fits(p->f64, p->ny, (int)p->nzc, gy, B * p->ny, B * nzl)) {
     if (timed) {
       while ((int)p->slab_ev.size() < nslab + 1) { hipEvent_t e; RF_HIP(hipEventCreate(&e)); p->slab_ev.push_back(e); }
       p->slab_merged = nslab;

@@ -53,14 +53,23 @@ hipError_t launch_merged(void* Wz, long long nrows, double scale, const void* tw
 // the 256-thread z pass of rows of 512 complex -- the 1024^3 pipeline
 bool yz_merged_supported(int f64, int ny, int M) { return !f64 && RF_Y_COL2_1024 && ny == 1024 && M == 512; }
 
+// ... and this geometry of the y pass (32-bit lane offsets, plain column layout), this many rows and columns per launch?  (queue_yz asks before
+// it commits to the merged sequence; a plan it does not fit keeps one launch per pass)
+bool yz_merged_fits(int f64, int ny, int M, ColGeom gy, long long nrows, long long ncols) {
+  if (!yz_merged_supported(f64, ny, M)) return false;
+  using C1 = PairSel1024::type;
+  using CR = RowSel<float, 512>::type;
+  ColGeom gin = gy;
+  gin.row_stride = 2 * gy.row_stride;
+  if (gin.needs_wide(C1::LMAX, C1::TC, 8) || gy.needs_wide(C1::LMAX, C1::TC, 8) || gy.row_shift < 30 || gy.hi_shift < 62 || gy.sub_shift != 0) return false;
+  const long long nz_tiles = (nrows + CR::NRT - 1) / CR::NRT;
+  return ncols % C1::TC == 0 && nz_tiles % 8 == 0 && nz_tiles + ncols / C1::TC <= 0x7fffffffLL && gy.inner > 0 && (gy.inner & (gy.inner - 1)) == 0;
+}
+
 hipError_t launch_yz_merged(int f64, int ny, int M, void* Wz, long long nrows, double scale, const void* twz, double* partials, void* Wy, ColGeom gy,
                             long long ncols, const void* twy, hipStream_t s, bool po) {
   if (!yz_merged_supported(f64, ny, M)) return hipErrorInvalidValue;
-  using C1 = PairSel1024::type;
-  ColGeom gin = gy;
-  gin.row_stride = 2 * gy.row_stride;
-  if (!po && (gin.needs_wide(C1::LMAX, C1::TC, 8) || gy.needs_wide(C1::LMAX, C1::TC, 8) || gy.row_shift < 30 || gy.hi_shift < 62 || gy.sub_shift != 0))
-    return hipErrorInvalidValue;
-  return launch_merged<RowSel<float, 512>::type, C1>(Wz, nrows, scale, twz, partials, Wy, gy, ncols, twy, s, po);
+  if (!po && !yz_merged_fits(f64, ny, M, gy, nrows, ncols)) return hipErrorInvalidValue;
+  return launch_merged<RowSel<float, 512>::type, PairSel1024::type>(Wz, nrows, scale, twz, partials, Wy, gy, ncols, twy, s, po);
 }
 }  // namespace rf

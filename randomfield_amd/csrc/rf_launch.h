@@ -69,6 +69,7 @@ int col_tile_cols(int f64, int N);   // tile width (columns) of the strided pass
 // z pass of c2r: rows of M = nz/2 complex -> nz reals, scaled; partials[2*tile] = (sum, sumsq)
 // the z pass of one slab (Wz, nrows rows) and the in-place y pass of another (Wy, ncols columns) in one launch (rf_k_yz.hip)
 bool yz_merged_supported(int f64, int ny, int M);
+bool yz_merged_fits(int f64, int ny, int M, ColGeom gy, long long nrows, long long ncols);
 hipError_t launch_yz_merged(int f64, int ny, int M, void* Wz, long long nrows, double scale, const void* twz, double* partials, void* Wy, ColGeom gy,
                             long long ncols, const void* twy, hipStream_t s, bool prepare_only = false);
 hipError_t launch_row_c2r(int f64, int M, void* W, long long nrows, double scale, const void* tw,
