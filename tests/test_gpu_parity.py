@@ -1995,3 +1995,30 @@ def test_merged_yz_launches_give_the_same_field(hip, dpower):
     plan.realise_batch(np.array([78], np.uint64), want_rms=False)          # (the captured graphs were dropped with the mode)
     assert np.array_equal(plan.download_real(), other)
     plan.close()
+
+
+@pytest.mark.parametrize("shape", [(256, 256, 256), (512, 256, 1024)])
+def test_one_call_same_seed_path_equals_the_two_calls(hip, dpower, shape):
+    """Generator(rng='reference') on a single-GPU complex64 plan runs replay + passes as ONE device call (rf_realise_batch_reference with
+    one seed; rf_can_batch_reference says when).  It must leave the same field, bit for bit, as rf_noise_mt19937_ex(single) followed by
+    rf_realise(RESIDENT) -- random.py:24-28 then generate.py:191-199 -- and the same resident deviates for the regenerated potential."""
+    from randomfield_amd import Generator
+    k, Pk = dpower
+    plan = make_plan(hip, shape, np.complex64, k, Pk)
+    assert plan.can_batch_reference()
+    plan.reference_noise(321, single=True)
+    plan.realise(noise="resident")
+    two = plan.download_real()
+    m_two = plan.moments()
+    rms = plan.realise_batch_reference([321], want_rms=True)
+    assert np.array_equal(plan.download_real(), two) and abs(rms[0] - m_two[1]) <= 1e-12 * m_two[1]
+    assert plan.can_regenerate_potential("resident")
+    plan.close()
+    assert not hip.DevicePlan(*shape, np.complex128).can_batch_reference()          # (float64 plans: the two calls)
+    small = make_plan(hip, (16, 16, 16), np.complex64, k, Pk)
+    assert isinstance(small.can_batch_reference(), bool)                             # (tiny grids may or may not have long enough segments)
+    small.close()
+    nx, ny, nz = shape
+    gen = Generator(nx, ny, nz, SPACING, backend="hip")
+    d = gen.generate_delta_field(seed=321, save_potential=True)
+    assert np.array_equal(d, two) and gen.potential is not None
