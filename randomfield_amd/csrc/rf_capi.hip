@@ -1572,6 +1572,7 @@ int rf_realise_lognormal(rf_plan* p, uint64_t seed, int mode, const double* nois
   void* Xsave = p->X;
   p->X = nullptr;                                    // plain layout: the accumulating y pass runs in place on W
   p->slab_timed = 0;
+  p->slab_merged = 0;
   int rc = queue_x(p, gp, nullptr, p->W, s, true);   // (timed: rf_kernel_ms reports x, y + tables, z + map, reduce of this call too)
   p->X = Xsave;
   p->resident_fast = false;
