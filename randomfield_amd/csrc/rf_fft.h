@@ -588,7 +588,7 @@ struct FastGenColIO64 {
   // Two rows at once.  A Philox call serves the cell pair (kz even, kz + 1) of one row, and with one complex128 per lane that pair sits
   // in the lane pair (2l, 2l + 1): load() has both lanes run the same call and keep half of it.  Here the even lane runs row A's call
   // and the odd lane row B's; each sends the half its neighbour needs across (one quad-permute DPP move per word) -- one call per lane
-  // and two rows instead of two (230 -> 118 v_mad_u64_u32 per thread in the 1024-point kernel).  Same words, same field.
+  // and two rows instead of two (230 -> 109 v_mad_u64_u32 per thread in the 1024-point kernel).  Same words, same field.
   static constexpr bool HAS_LOAD_PAIR = true;
   RF_HD void load_pair(long long C0, int cl, int rb, int roA, int roB, V16<double>& a, V16<double>& b) const {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1185,7 +1185,7 @@ RF_HD float exp_t(float x) { return expf(x); }
 RF_HD double exp_t(double x) { return exp(x); }
 // float64 plans: exp(t ln2 / 64) for an argument already in units of ln2 / 64 (the table Ap carries the factor 64 / ln2, lognormal_ap_unit):
 // t = k + f, |f| <= 1/2, k = 64 e + j: 2^e * 2^(j/64) * exp(f ln2/64), the middle factor from a 64-entry table in LDS (rf_exp2_tab.h,
-// correctly rounded), the last a degree-5 polynomial (|r| <= 0.0055: the first dropped term is 4e-17).  13 float64-rate instructions
+// correctly rounded), the last a degree-5 polynomial (|r| <= 0.0055: the first dropped term is 4e-17).  12 float64-rate instructions
 // and one ds_read_b64 per element where the library's exp takes ~22 (no table: a degree-11 polynomial, range checks); the z pass of a
 // float64 plan issues 16 of them per thread.  |error| <= 1 ulp of the result + the rounding of t (ulp(t) ln2 / 128 <= 6e-16 at
 // |x| = 5.5): the same size as the rounding of the product delta * Ap that both forms share.  Out-of-range arguments saturate through
