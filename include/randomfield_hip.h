@@ -15,6 +15,10 @@
  * layouts: k-space (nx, ny, nz/2+1) complex C-order (transform.py:192), real
  * space (nx, ny, nz) dense or (nx, ny, nz+2) padded (transform.py:227-235).
  * All work is queued on the plan's HIP stream; rf_sync() waits for it.
+ *
+ * THIS header is the consumer surface.  Per-kernel timing, launch-structure knobs and the "virtual rank" entry points that
+ * exist for tests, bench.py and the profiling tools are declared in randomfield_hip_diag.h and are not part of what a
+ * consumer should bind.
  */
 #ifndef RANDOMFIELD_HIP_H
 #define RANDOMFIELD_HIP_H
@@ -33,13 +37,43 @@ enum { RF_NOISE_NATIVE = 0, RF_NOISE_EXTERNAL = 1, RF_NOISE_RESIDENT = 2 };
 enum { RF_LAYOUT_DENSE = 0, RF_LAYOUT_PADDED = 1 };
 
 /* ---- library ---------------------------------------------------------- */
-int rf_version(void);                            /* 100*major + minor */
+/* ABI version of THIS header: RF_ABI_MAJOR changes when an entry point's meaning or signature changes or one is removed, RF_ABI_MINOR on
+ * every addition.  rf_version() returns the RF_ABI_VERSION the loaded library was built from: a consumer compares its major with the
+ * header it was compiled against and asks rf_abi_features() which groups of entry points the build carries.  (History: rounds 1-4 of
+ * this repository returned the constant 1 while the surface grew from ~20 to 70 entry points; 5.0 is the first version that means
+ * something: the consumer surface below + the diagnostics of randomfield_hip_diag.h.) */
+#define RF_ABI_MAJOR 5
+#define RF_ABI_MINOR 1
+#define RF_ABI_VERSION ((RF_ABI_MAJOR << 16) | RF_ABI_MINOR)
+int rf_version(void);                            /* (major << 16) | minor */
+/* bit mask of the groups of entry points this build exports (each bit: every function of the group is present and works as this
+ * header says; a 0 bit: calling one returns an error or the symbol is missing) */
+enum {
+  RF_FEATURE_REALISE = 1 << 0,             /* rf_generate / rf_execute_c2r / rf_realise / rf_realise_batch(_prepare) / rf_moments: rows K..D */
+  RF_FEATURE_R2C = 1 << 1,                 /* rf_execute_r2c, rf_upload_real: the reverse plan (transform.py:278-301) */
+  RF_FEATURE_C2C = 1 << 2,                 /* rf_plan_create_c2c, rf_upload_c, rf_download_c, rf_execute_c2c: Plan(packed=False) */
+  RF_FEATURE_LOGNORMAL = 1 << 3,           /* rf_lognormal, rf_scale_z, rf_affine_z, rf_set_z_tables, rf_realise_lognormal: row L */
+  RF_FEATURE_POTENTIAL = 1 << 4,           /* rf_realise_potential, rf_save_potential, rf_load_potential, rf_realise_scaled_potential,
+                                              rf_can_regenerate_potential: generate.py:200-217, 333-347 */
+  RF_FEATURE_LENSING = 1 << 5,             /* rf_lensing_potential, rf_download_aux: generate.py:352-416 */
+  RF_FEATURE_MT19937 = 1 << 6,             /* rf_mt_set_jump, rf_noise_mt19937(_ex), rf_realise_batch_reference, rf_can_batch_reference:
+                                              random.py:24-28 replayed on the device */
+  RF_FEATURE_MT19937_SHARED = 1 << 7,      /* rf_mt_share_*: that stream shared between kz-slab ranks */
+  RF_FEATURE_MULTI_RANK = 1 << 8,          /* nranks > 1 plans, rf_comm_*: kz slabs + one RCCL all-to-all (librccl is dlopen'ed by rf_comm_*) */
+  RF_FEATURE_GENERIC_SHAPES = 1 << 9,      /* every even shape up to 8192 (complex64) / 4096 (complex128) per axis: rf_shape_supported(_dtype) == 2 */
+  RF_FEATURE_EXCHANGE_CHUNKS = 1 << 10,    /* RF_FLAG_EXCHANGE_CHUNKS */
+  RF_FEATURE_DIAGNOSTICS = 1 << 11         /* the entry points of randomfield_hip_diag.h (timing per kernel, launch structure, virtual ranks) */
+};
+unsigned rf_abi_features(void);
 const char* rf_last_error(void);
 int rf_device_count(int* count);
 /* is this grid shape supported by the HIP kernels?  1: tiled power-of-two kernels (nx, ny in 8..2048, nz in 16..2048);
  * 2: generic mixed-radix kernels (any other even nx, ny, nz up to 8192, or 4096 on RF_F64 plans -- the reference's own test shapes (4,6,8) and
  * (40,60,80), transform.py:172-177; single GPU, k space materialised); 0: unsupported */
 int rf_shape_supported(int nx, int ny, int nz);
+/* the same for ONE dtype (RF_F32 / RF_F64): what rf_plan_create(nx, ny, nz, dtype, ...) on one rank will accept -- rf_shape_supported answers
+ * for complex64 plans on the generic path (axes up to 8192), complex128 plans stop at 4096 */
+int rf_shape_supported_dtype(int nx, int ny, int nz, int dtype);
 
 /* ---- plan: replaces transform.Plan.__init__ / allocate (transform.py:10-43,170-276)
  * One device buffer of nx*ny*nz reals (== nx*ny*nz/2 complex) is the analogue of
@@ -125,8 +159,8 @@ int rf_can_batch_reference(rf_plan* plan);
  *   rf_mt_share_gather    every rank's counts into counts_all[nseg_total], in segment order (an integer all-reduce over RCCL;
  *                         virtual ranks: concatenate on the host instead)
  *   rf_mt_share_pack      scan counts_all, pack the local pairs by destination rank
- *   rf_mt_share_exchange  one all-to-all over RCCL on the plan's stream (rf_comm_init first); rf_mt_share_exchange_local: the
- *                         same between n virtual ranks living on one device (tests)
+ *   rf_mt_share_exchange  one all-to-all over RCCL on the plan's stream (rf_comm_init first); rf_mt_share_exchange_local
+ *                         (randomfield_hip_diag.h): the same between n virtual ranks living on one device (tests)
  *   rf_mt_share_finish    the plan's resident float64 deviates are this rank's planes of the stream (then RF_NOISE_RESIDENT)
  * single = 1 (complex64 plans): pairs travel as float32 (8 B per cell, the volume of the field's own exchange), rounded as
  * rf_noise_mt19937_ex(single = 1) rounds them; single = 0: the exact float64 deviates, bit for bit those of the replicated replay. */
@@ -135,10 +169,7 @@ int rf_mt_share_begin(rf_plan* plan, const uint32_t* state624, int single, unsig
 int rf_mt_share_gather(rf_plan* plan, unsigned long long* counts_all);
 int rf_mt_share_pack(rf_plan* plan, const unsigned long long* counts_all);
 int rf_mt_share_exchange(rf_plan* plan);
-int rf_mt_share_exchange_local(rf_plan** plans, int n);
 int rf_mt_share_finish(rf_plan* plan, unsigned long long* accepted);
-/* copy deviates [first, first+count) of the device noise buffer to the host (tests) */
-int rf_download_noise(rf_plan* plan, double* host, unsigned long long first, unsigned long long count);
 
 /* calculate_newtonian_potential (generate.py:333-343) without a stored potential: the inverse transform of scale * delta(k) / k^2
  * with delta(k) regenerated inside the generation pass exactly as rf_realise(seed, mode) produces it (native generator: keyed by
@@ -232,20 +263,6 @@ int rf_sync(rf_plan* plan);
 /* GPU time (hipEvents on the plan's stream) of the last rf_realise / rf_realise_batch /
  * rf_execute_* call, in milliseconds; blocks until that call has finished. */
 int rf_elapsed_ms(rf_plan* plan, float* ms);
-/* GPU time of each kernel of the last rf_realise, 5 floats: x pass (main kernel), y pass, z pass, reduce,
- * and the small x-pass launch that repairs the kz = 0 tiles (0 when the x pass is a single launch) */
-int rf_kernel_ms(rf_plan* plan, float* ms5);
-/* The z pass of slab s and the y pass of slab s + 1 in ONE launch (the next slab's tiles fill the compute units the draining pass leaves
- * idle; float32 plans whose y pass is the 1024-point one and whose rows hold 512 complex: the 1024^3 pipeline).  mode 0: never;
- * 1 (default): untimed calls -- graph-captured batches, rf_realise_batch_reference; 2: timed calls too, with an event behind every
- * launch: rf_kernel_ms then reports [1] = the first y launch + all merged launches, [2] = the last z launch, and rf_merged_yz_ms the
- * merged launches' summed duration and number.  (No reference counterpart: launch structure of transform.py:303-315's one call.) */
-int rf_set_merged_yz(rf_plan* plan, int mode);
-int rf_merged_yz_ms(rf_plan* plan, float* sum_ms, int* launches);
-/* (when the y and z passes run slab by slab -- RF_FLAG_YZ_SLAB_PLANES -- ms5[1] and ms5[2] are the sums over their launches)
- * How the y / z passes of this plan are launched: *nslab launches each, over *planes x planes (1 and nx: whole-grid passes).
- * No reference counterpart: the reference's FFT is one library call (transform.py:303-315). */
-int rf_yz_slabs(rf_plan* plan, int* nslab, int* planes);
 
 /* ---- multi-GPU: one process per GPU, RCCL all-to-all between the y and z passes.
  * The 128-byte unique id comes from rank 0 and is distributed by the host
@@ -258,23 +275,6 @@ int rf_comm_size(rf_plan* plan, int* nranks);
 /* host-side all-reduce of 1 or 2 doubles over the plan's communicator (op 0 = sum, 1 = max), after all
  * queued work of the plan: doubles as a barrier.  With one rank it only synchronises the stream. */
 int rf_comm_allreduce_f64(rf_plan* plan, double* inout, int n, int op);
-/* The slab pipeline in separate steps, for tests and custom exchanges: forward = generation + x and y
- * passes on this rank's kz slab; backward = z pass on this rank's x slab + local (sum, sumsq).
- * rf_slab_exchange_local performs the all-to-all between n "virtual ranks" that live on ONE device
- * (plain device copies, no RCCL): it checks layouts and kernels where only one GPU is available. */
-int rf_slab_forward(rf_plan* plan, uint64_t seed, int mode, const double* noise_host);
-/* the same forward half fed like rf_realise_potential (generate.py:200-217: the rank's planes of delta(k)/k^2 are
- * kept in its potential buffer) or like rf_execute_c2r (from the rank's k buffer, e.g. after rf_load_potential) */
-enum { RF_SLAB_GENERATE = 0, RF_SLAB_GENERATE_SAVE_POTENTIAL = 1, RF_SLAB_FROM_KSPACE = 2 };
-int rf_slab_forward_ex(rf_plan* plan, uint64_t seed, int mode, const double* noise_host, int source);
-int rf_slab_exchange_local(rf_plan** plans, int n);
-int rf_slab_backward(rf_plan* plan);
-int rf_slab_stats(rf_plan* plan, double* sum, double* sumsq);
-/* the multi-rank forward transform (rf_execute_r2c) in the same separate steps: rows = z pass on the x slab + cut into send
- * blocks; the reverse all-to-all between virtual ranks; cols = forward y and x passes on the kz slab + the k-space side array */
-int rf_slab_r2c_rows(rf_plan* plan);
-int rf_slab_exchange_local_reverse(rf_plan** plans, int n);
-int rf_slab_r2c_cols(rf_plan* plan);
 
 #ifdef __cplusplus
 }

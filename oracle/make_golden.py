@@ -88,6 +88,28 @@ def run_stages(ref, shape, power, dtype, seed=SEED, spacing=SPACING, smoothing=0
                 smoothed_Pk=smoothed["Pk"].copy())
 
 
+AXIS2048_SHAPES = [(2048, 16, 64), (16, 2048, 64), (16, 16, 2048)]
+
+
+def axis2048_strides(shape):
+    """subsampling strides of the real field (x, y, z) and of k space (kx, ky, kz) for the long-axis fixtures: 128 samples along
+    the 2048-point axis, 8 / 16 along the short ones; every kz where nz is short, else every 16th (0 and nz/2 included)"""
+    sd = tuple(16 if n == 2048 else (2 if n == 16 else 4) for n in shape)
+    sk = (sd[0], sd[1], 16 if shape[2] == 2048 else 1)
+    return sd, sk
+
+
+def summarise_axis2048(st, shape):
+    sd, sk = axis2048_strides(shape)
+    d = st["delta"]
+    d64 = d.astype(np.float64)
+    return dict(shape=np.array(shape), spacing=SPACING, seed=SEED, stride_delta=np.array(sd), stride_k=np.array(sk),
+                sub=d[::sd[0], ::sd[1], ::sd[2]].copy(), first=d[0, 0, :4].copy(), last=d[-1, -1, -4:].copy(), rms=st["rms"],
+                mean=np.asarray(d64.mean()), min=np.asarray(d.min()), max=np.asarray(d.max()), sumsq=np.asarray((d64 ** 2).sum()),
+                kspace_sub=st["kspace"][::sk[0], ::sk[1], ::sk[2]].copy(), kspace_absmax=np.asarray(np.max(np.abs(st["kspace"]))),
+                sigma_sub=st["sigma"][::sk[0], ::sk[1], ::sk[2]].copy())
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = load_reference()
@@ -132,6 +154,12 @@ def main():
                 kspace_plane0=st["kspace"][:, :, 0].copy(),
                 kspace_nyq=st["kspace"][:, :, n // 2].copy(),
                 kspace_sub=st["kspace"][::8, ::8, 1::7].copy())
+
+    # --- one axis of 2048 points (the longest the tiled kernels serve; BASELINE config 4's axis length), the other two short:
+    # the reference's run, subsampled (a value of delta depends on every mode of its line, so a subsample pins the whole transform)
+    for shape in AXIS2048_SHAPES:
+        st = run_stages(ref, shape, power, np.complex64)
+        np.savez_compressed(os.path.join(OUT, "axis2048_%dx%dx%d_c64.npz" % shape), **summarise_axis2048(st, shape))
 
     # --- variance test of tests/test_generate.py:24-62 through the reference
     n = 64

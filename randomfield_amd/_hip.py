@@ -24,9 +24,18 @@ LAYOUT_DENSE, LAYOUT_PADDED = 0, 1
 _c_void_pp = ctypes.POINTER(ctypes.c_void_p)
 _c_dp = ctypes.POINTER(ctypes.c_double)
 
-# name -> (restype, argtypes); every symbol of include/randomfield_hip.h
+# the ABI this binding was written against (include/randomfield_hip.h RF_ABI_MAJOR / RF_ABI_MINOR): load() refuses a library of
+# another major version or an older minor one
+ABI_MAJOR, ABI_MINOR = 5, 1
+FEATURES = {"realise": 1 << 0, "r2c": 1 << 1, "c2c": 1 << 2, "lognormal": 1 << 3, "potential": 1 << 4, "lensing": 1 << 5,
+            "mt19937": 1 << 6, "mt19937_shared": 1 << 7, "multi_rank": 1 << 8, "generic_shapes": 1 << 9, "exchange_chunks": 1 << 10,
+            "diagnostics": 1 << 11}
+
+# name -> (restype, argtypes); every symbol of include/randomfield_hip.h (the consumer surface) ...
 SIGNATURES = {
     "rf_version": (ctypes.c_int, []),
+    "rf_abi_features": (ctypes.c_uint, []),
+    "rf_shape_supported_dtype": (ctypes.c_int, [ctypes.c_int] * 4),
     "rf_last_error": (ctypes.c_char_p, []),
     "rf_device_count": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
     "rf_shape_supported": (ctypes.c_int, [ctypes.c_int] * 3),
@@ -49,9 +58,7 @@ SIGNATURES = {
     "rf_mt_share_gather": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_ulonglong)]),
     "rf_mt_share_pack": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_ulonglong)]),
     "rf_mt_share_exchange": (ctypes.c_int, [ctypes.c_void_p]),
-    "rf_mt_share_exchange_local": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int]),
     "rf_mt_share_finish": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_ulonglong)]),
-    "rf_download_noise": (ctypes.c_int, [ctypes.c_void_p, _c_dp, ctypes.c_ulonglong, ctypes.c_ulonglong]),
     "rf_can_regenerate_potential": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "rf_realise_scaled_potential": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_double, _c_dp]),
     "rf_execute_c2r": (ctypes.c_int, [ctypes.c_void_p]),
@@ -79,19 +86,24 @@ SIGNATURES = {
     "rf_device_ptr": (ctypes.c_int, [ctypes.c_void_p, _c_void_pp, _c_void_pp]),
     "rf_sync": (ctypes.c_int, [ctypes.c_void_p]),
     "rf_elapsed_ms": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]),
-    "rf_kernel_ms": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]),
     "rf_set_z_tables": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.c_int]),
     "rf_realise_lognormal": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.POINTER(ctypes.c_double),
                                             ctypes.POINTER(ctypes.c_double)]),
     "rf_realise_batch_reference": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32), ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
     "rf_can_batch_reference": (ctypes.c_int, [ctypes.c_void_p]),
-    "rf_set_merged_yz": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
-    "rf_merged_yz_ms": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int)]),
-    "rf_yz_slabs": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "rf_comm_unique_id": (ctypes.c_int, [ctypes.c_void_p]),
     "rf_comm_init": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "rf_comm_size": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]),
     "rf_comm_allreduce_f64": (ctypes.c_int, [ctypes.c_void_p, _c_dp, ctypes.c_int, ctypes.c_int]),
+}
+# ... and of include/randomfield_hip_diag.h (per-kernel timing, launch structure, virtual ranks: tests, bench.py, tools)
+DIAG_SIGNATURES = {
+    "rf_mt_share_exchange_local": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int]),
+    "rf_download_noise": (ctypes.c_int, [ctypes.c_void_p, _c_dp, ctypes.c_ulonglong, ctypes.c_ulonglong]),
+    "rf_kernel_ms": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]),
+    "rf_set_merged_yz": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "rf_merged_yz_ms": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int)]),
+    "rf_yz_slabs": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "rf_slab_forward": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, _c_dp]),
     "rf_slab_forward_ex": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, _c_dp, ctypes.c_int]),
     "rf_slab_exchange_local": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int]),
@@ -100,6 +112,7 @@ SIGNATURES = {
     "rf_slab_r2c_cols": (ctypes.c_int, [ctypes.c_void_p]),
     "rf_slab_exchange_local_reverse": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int]),
     "rf_slab_stats": (ctypes.c_int, [ctypes.c_void_p, _c_dp, _c_dp]),
+    "rf_slab_set_exchange_standin": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
 }
 
 _lib = None
@@ -119,10 +132,19 @@ def load():
         lib = ctypes.CDLL(LIB_PATH)
     except OSError as exc:  # pragma: no cover - depends on the machine
         raise RuntimeError("randomfield_amd: cannot load %s: %s" % (LIB_PATH, exc))
-    for name, (restype, argtypes) in SIGNATURES.items():
-        fn = getattr(lib, name)          # AttributeError here means header and library disagree
-        fn.restype = restype
-        fn.argtypes = argtypes
+    try:
+        lib.rf_version.restype = ctypes.c_int
+        ver = int(lib.rf_version())
+    except AttributeError:
+        raise RuntimeError("randomfield_amd: %s is not this package's library (no rf_version)" % LIB_PATH)
+    if (ver >> 16) != ABI_MAJOR or (ver & 0xffff) < ABI_MINOR:
+        raise RuntimeError("randomfield_amd: %s has ABI version %d.%d, this binding needs %d.%d or a later minor one: rebuild it "
+                           "(`make -C randomfield_amd/csrc`)" % (LIB_PATH, ver >> 16, ver & 0xffff, ABI_MAJOR, ABI_MINOR))
+    for table in (SIGNATURES, DIAG_SIGNATURES):
+        for name, (restype, argtypes) in table.items():
+            fn = getattr(lib, name)          # AttributeError here means header and library disagree
+            fn.restype = restype
+            fn.argtypes = argtypes
     _lib = lib
     return lib
 
@@ -153,8 +175,25 @@ def require_gpu():
     return n
 
 
-def shape_supported(nx, ny, nz):
-    return bool(load().rf_shape_supported(int(nx), int(ny), int(nz)))
+def shape_supported(nx, ny, nz, dtype=None):
+    """Does the HIP path take this grid?  With a dtype (numpy complex64 / complex128, or RF_F32 / RF_F64) the answer is exactly what
+    rf_plan_create accepts for it on one rank (complex128 plans: generic axes up to 4096, complex64 up to 8192)."""
+    if dtype is None:
+        return bool(load().rf_shape_supported(int(nx), int(ny), int(nz)))
+    code = dtype if dtype in (RF_F32, RF_F64) else (RF_F64 if np.dtype(dtype) in (np.dtype(np.complex128), np.dtype(np.float64)) else RF_F32)
+    return bool(load().rf_shape_supported_dtype(int(nx), int(ny), int(nz), int(code)))
+
+
+def abi_version():
+    """(major, minor) of the loaded library (rf_version)."""
+    v = int(load().rf_version())
+    return v >> 16, v & 0xffff
+
+
+def abi_features():
+    """Names of the entry-point groups the loaded library exports (rf_abi_features)."""
+    bits = int(load().rf_abi_features())
+    return sorted(k for k, b in FEATURES.items() if bits & b)
 
 
 def _dp(a):
@@ -274,6 +313,11 @@ class DevicePlan(object):
         """Multi-rank plans: generate / transform / send the rank's kz slab as ``chunks`` sub-slabs (a power of two), the exchange
         of each overlapped with the forward passes of the next inside one realisation (RF_FLAG_EXCHANGE_CHUNKS)."""
         check(self._lib.rf_plan_set_flag(self._h, 32, int(chunks)), "rf_plan_set_flag")
+
+    def set_exchange_standin(self, workgroups):
+        """Diagnostics (virtual rank of a multi-rank plan, no communicator): realise / realise_batch run the multi-GPU schedule with
+        the all-to-all replaced by a copy kernel of ``workgroups`` workgroups (rf_slab_set_exchange_standin); 0 = off."""
+        check(self._lib.rf_slab_set_exchange_standin(self._h, int(workgroups)), "rf_slab_set_exchange_standin")
 
     def set_stream(self, hip_stream):
         check(self._lib.rf_plan_set_stream(self._h, ctypes.c_void_p(hip_stream or 0)), "rf_plan_set_stream")

@@ -12,6 +12,7 @@
 #include <rccl/rccl.h>
 
 #include "../../include/randomfield_hip.h"
+#include "../../include/randomfield_hip_diag.h"
 #include "rf_host.h"
 #include "rf_launch.h"
 
@@ -101,6 +102,7 @@ struct rf_plan {
   hipStream_t comm_stream = nullptr;      // exchange stream of pipelined slab batches
   hipEvent_t pev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // fwd[2], exch[2], z[2]
   bool force_slab = false;                // single-rank plan routed through the slab pipeline (tests)
+  int standin_wg = 0;                     // rf_slab_set_exchange_standin: workgroups of the copy kernel that stands in for the all-to-all of a rank without a communicator
   // RF_FLAG_EXCHANGE_CHUNKS: the rank's kz slab as `xchunks` sub-slabs of nzl / xchunks planes, each generated, x- and y-transformed
   // and SENT on its own, so that the exchange of sub-slab c runs under the forward passes of sub-slab c + 1 (queue_c2r).  Layout:
   // W = [chunk][nx][ny][nzl / xchunks]; R = [source rank][chunk][nxl][ny][nzl / xchunks], which is what the gathering z pass reads
@@ -483,7 +485,7 @@ int queue_z_slab(rf_plan* p, const void* R, void* W, double* stats_out, hipStrea
 // (chunk >= 0: sub-slab `chunk` only -- RF_FLAG_EXCHANGE_CHUNKS; -1: everything, all chunks of a chunked plan in ONE group;
 // plain = true: the unchunked block layout whatever the flag says, as the forward transform's reverse exchange uses it)
 int queue_exchange_rccl(rf_plan* p, const void* W, void* R, hipStream_t s, int chunk = -1, bool plain = false) {
-  RF_REQUIRE(p->nranks == 1 || p->comm != nullptr, "rf_comm_init has not been called on this multi-rank plan");
+  RF_REQUIRE(p->nranks == 1 || p->comm != nullptr || p->standin_wg > 0, "rf_comm_init has not been called on this multi-rank plan");
   const int C = plain ? 1 : slab_chunks(p);
   const size_t blk = (size_t)p->nxl * p->ny * p->nzl * p->csize / (size_t)C, cb = p->w_bytes / (size_t)C;
   const int c0 = chunk >= 0 ? chunk : 0, c1 = chunk >= 0 ? chunk + 1 : C;
@@ -493,6 +495,19 @@ int queue_exchange_rccl(rf_plan* p, const void* W, void* R, hipStream_t s, int c
   for (int c = c0; c < c1; ++c)
     RF_HIP(hipMemcpyAsync(dst(c, p->rank), src(c, p->rank), blk, hipMemcpyDeviceToDevice, s));
   if (p->nranks == 1) return 0;        // forced slab path of a single-rank plan: the own block is everything
+  if (!p->comm) {
+    // exchange stand-in of a virtual rank (diagnostics): what this rank's RCCL kernels would do to ITS memory and compute units --
+    // read the nranks - 1 blocks it sends, write the nranks - 1 segments it receives -- by a copy kernel of fixed width; the
+    // segments hold this rank's own data for other x slabs (not a field: the timing of the overlapped passes is the point)
+    RF_REQUIRE(p->nranks <= 17, "the exchange stand-in serves up to 17 ranks");
+    for (int c = c0; c < c1; ++c) {
+      const void* sp[16]; void* dp[16];
+      int nb = 0;
+      for (int h = 0; h < p->nranks; ++h) if (h != p->rank) { sp[nb] = src(c, h); dp[nb] = dst(c, h); ++nb; }
+      RF_HIP(launch_exchange_standin(sp, dp, nb, blk, p->standin_wg, s));
+    }
+    return 0;
+  }
   RF_NCCL(g_rccl.GroupStart());
   for (int c = c0; c < c1; ++c)
     for (int h = 0; h < p->nranks; ++h) {
@@ -576,7 +591,7 @@ int slab_batch(rf_plan* p, const uint64_t* seeds, int n) {
       RF_HIP(hipEventRecord(ev_z[pb], A));
     }
   }
-  if (p->nranks > 1) {
+  if (p->nranks > 1 && p->comm) {        // (no communicator: a virtual rank under rf_slab_set_exchange_standin, local moments only)
     // ONE communicator is only ever driven from ONE stream inside a batch: the moments' all-reduce goes to the exchange
     // stream too, behind the last z pass (event), and the compute stream waits for it
     const int lb = (n - 1) & 1;
@@ -643,6 +658,7 @@ int queue_yz(rf_plan* p, void* W, hipStream_t s, double* stats_out, bool timed) 
     if (timed) {
       while ((int)p->slab_ev.size() < nslab + 1) { hipEvent_t e; RF_HIP(hipEventCreate(&e)); p->slab_ev.push_back(e); }
       p->slab_merged = nslab;
+      p->slab_timed = 0;       // (rf_kernel_ms: the merged form's events apply, the per-pass pairs of slab_ev were not recorded by this call)
     }
     RF_HIP(launch_col_plain(p->f64, p->ny, +1, W, gy, B * nzl, p->tw_y, s));
     if (timed) RF_HIP(hipEventRecord(p->slab_ev[0], s));
@@ -760,7 +776,7 @@ int queue_c2r(rf_plan* p, const GenParams& gp, const void* kspace) {
     RF_HIP(hipStreamWaitEvent(A, p->chunk_ev[C], 0));
     if (int rc = queue_z_slab(p, p->R, p->W, p->stats, A)) return rc;
     if (p->timed) RF_HIP(hipEventRecord(p->ev[3], A));
-    if (p->nranks > 1) {
+    if (p->nranks > 1 && p->comm) {
       RF_HIP(hipEventRecord(p->chunk_ev[C], A));
       RF_HIP(hipStreamWaitEvent(X, p->chunk_ev[C], 0));
       RF_NCCL(g_rccl.AllReduce(p->stats, p->stats, 2, ncclFloat64, ncclSum, p->comm, X));
@@ -791,7 +807,7 @@ int queue_c2r(rf_plan* p, const GenParams& gp, const void* kspace) {
     if (int rc = queue_z_slab(p, p->R, p->W, p->stats, p->stream)) return rc;
     if (p->timed) RF_HIP(hipEventRecord(p->ev[3], p->stream));
     // global (sum, sumsq): one 2-double all-reduce
-    if (p->nranks > 1) RF_NCCL(g_rccl.AllReduce(p->stats, p->stats, 2, ncclFloat64, ncclSum, p->comm, p->stream));
+    if (p->nranks > 1 && p->comm) RF_NCCL(g_rccl.AllReduce(p->stats, p->stats, 2, ncclFloat64, ncclSum, p->comm, p->stream));
     if (p->timed) RF_HIP(hipEventRecord(p->ev[4], p->stream));
     p->stats_slot = 0;
     p->stats_valid = true;
@@ -829,7 +845,13 @@ int shape_check(int nx, int ny, int nz, int f64, std::string* why, int nranks = 
 
 extern "C" {
 
-int rf_version(void) { return 1; }
+int rf_version(void) { return RF_ABI_VERSION; }
+
+unsigned rf_abi_features(void) {
+  return RF_FEATURE_REALISE | RF_FEATURE_R2C | RF_FEATURE_C2C | RF_FEATURE_LOGNORMAL | RF_FEATURE_POTENTIAL | RF_FEATURE_LENSING |
+         RF_FEATURE_MT19937 | RF_FEATURE_MT19937_SHARED | RF_FEATURE_MULTI_RANK | RF_FEATURE_GENERIC_SHAPES | RF_FEATURE_EXCHANGE_CHUNKS |
+         RF_FEATURE_DIAGNOSTICS;
+}
 
 const char* rf_last_error(void) { return g_err.c_str(); }
 
@@ -846,6 +868,14 @@ int rf_shape_supported(int nx, int ny, int nz) {
   return generic_shape(nx, ny, nz, 0, a, b, c) ? 2 : 0;          // (complex128 plans: axes up to 4096 -- rf_plan_create says so)
 }
 
+// the same for one dtype: exactly what rf_plan_create on one rank accepts (complex128 plans: generic axes up to 4096)
+int rf_shape_supported_dtype(int nx, int ny, int nz, int dtype) {
+  if (dtype != RF_F32 && dtype != RF_F64) return 0;
+  if (shape_check(nx, ny, nz, dtype, nullptr) == 0) return 1;
+  GenericAxis a, b, c;
+  return generic_shape(nx, ny, nz, dtype == RF_F64, a, b, c) ? 2 : 0;
+}
+
 int rf_plan_create(rf_plan** out, int nx, int ny, int nz, int dtype, int device, int nranks, int rank) {
   RF_REQUIRE(out != nullptr, "plan pointer is null");
   *out = nullptr;
@@ -857,7 +887,7 @@ int rf_plan_create(rf_plan** out, int nx, int ny, int nz, int dtype, int device,
   if (shape_check(nx, ny, nz, dtype, &why, nranks)) {
     generic = nranks == 1 && generic_shape(nx, ny, nz, dtype == RF_F64, gax, gay, gaz);
     if (!generic)
-      return fail(1, "unsupported shape: " + why + (nranks == 1 ? " (and not an even shape with axes <= 8192 (complex64) / 4096 (complex128) either)" : ""));
+      return fail(1, "unsupported shape: " + why + (nranks == 1 ? std::string(" (and not an even shape with axes <= ") + (dtype == RF_F64 ? "4096, the cap of complex128 plans" : "8192, the cap of complex64 plans") + " either: rf_shape_supported_dtype)" : ""));
   }
   RF_HIP(hipSetDevice(device));
   rf_plan* p = new rf_plan();
@@ -1751,7 +1781,7 @@ int rf_kernel_ms(rf_plan* p, float* ms5) {
   RF_REQUIRE(p->timed, "per-kernel times are recorded by rf_realise / rf_execute_c2r only");
   RF_HIP(hipEventSynchronize(p->ev[4]));
   for (int i = 0; i < 4; ++i) RF_HIP(hipEventElapsedTime(&ms5[i], p->ev[i], p->ev[i + 1]));
-  if (p->slab_timed > 0) {                 // y / z passes ran slab by slab: [1], [2] = the sums over their launches
+  if (p->slab_merged == 0 && p->slab_timed > 0) {   // y / z passes ran slab by slab, one launch per pass: [1], [2] = the sums over their launches
     float ys = 0, zs = 0, t = 0;
     for (int i = 0; i < p->slab_timed; ++i) {
       RF_HIP(hipEventElapsedTime(&t, i == 0 ? p->ev[1] : p->slab_ev[2 * i - 1], p->slab_ev[2 * i]));
@@ -2538,6 +2568,21 @@ int rf_slab_backward(rf_plan* p) {
   if (int rc = queue_z_slab(p, p->R, p->W, p->stats, p->stream)) return rc;
   p->stats_slot = 0;
   RF_HIP(hipStreamSynchronize(p->stream));
+  return 0;
+}
+
+// A rank of an n-rank job WITHOUT a communicator (a virtual rank): `workgroups` > 0 lets rf_realise / rf_realise_batch run the real
+// schedule of a multi-GPU rank -- forward half, exchange on the exchange stream under the next forward half, gathering z pass -- with
+// the all-to-all replaced by a copy kernel of that many 256-thread workgroups that reads the blocks the rank would send and writes
+// the segments it would receive (RCCL's footprint in local HBM and on the compute units, without the links).  0 = off.
+int rf_slab_set_exchange_standin(rf_plan* p, int workgroups) {
+  RF_REQUIRE(p, "null plan");
+  RF_REQUIRE(!p->unpacked && !p->generic, "this call applies to packed plans on the tiled kernels");
+  RF_REQUIRE(p->nranks > 1 && p->comm == nullptr, "the exchange stand-in is for a rank of a multi-rank plan without a communicator");
+  RF_REQUIRE(workgroups >= 0 && workgroups <= 4096, "workgroups must be in [0, 4096]");
+  RF_HIP(hipSetDevice(p->device));
+  RF_HIP(hipStreamSynchronize(p->stream));
+  p->standin_wg = workgroups;
   return 0;
 }
 

@@ -7,6 +7,30 @@
 namespace rf {
 namespace {
 
+// Stand-in for the RCCL all-to-all of a kz-slab rank (rf_slab_set_exchange_standin, randomfield_hip_diag.h): nblk blocks of `bytes`
+// bytes each are read from src[b] and written to dst[b] by a FIXED number of workgroups -- the footprint of RCCL's send / receive
+// channels on the compute units (one 256-thread workgroup per channel) and in local HBM (every block read once, every block written
+// once), without the links.  Eight 16-byte loads in flight per thread, then eight stores; grid-stride over the blocks in turn.
+struct StandinBlocks { const char* src[16]; char* dst[16]; };
+__global__ __launch_bounds__(256) void exchange_standin_kernel(StandinBlocks blk, int nblk, unsigned long long bytes) {
+  typedef unsigned u4 __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(1))) u4 gu4;
+  const unsigned long long nvec = bytes / 16, stride = (unsigned long long)gridDim.x * 256;
+  for (int b = 0; b < nblk; ++b) {
+    const gu4* s = (const gu4*)blk.src[b];
+    gu4* d = (gu4*)blk.dst[b];
+    unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 7 * stride < nvec; i += 8 * stride) {
+      u4 v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = __builtin_nontemporal_load(s + i + k * stride);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) __builtin_nontemporal_store(v[k], d + i + k * stride);
+    }
+    for (; i < nvec; i += stride) d[i] = s[i];
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void gen_kspace_kernel(cplx<T>* __restrict__ K, GenParams gp) {
   const int nzh = gp.zpitch;            // this rank's planes + the Nyquist plane (nz/2 + 1 on one rank)
@@ -360,6 +384,15 @@ __global__ __launch_bounds__(256) void lensing_rows_kernel(const T* __restrict__
 }
 
 }  // namespace
+
+hipError_t launch_exchange_standin(const void* const* src, void* const* dst, int nblk, size_t bytes, int workgroups, hipStream_t s) {
+  if (nblk < 0 || nblk > 16 || workgroups < 1 || bytes % 16) return hipErrorInvalidValue;
+  if (nblk == 0) return hipSuccess;
+  StandinBlocks blk;
+  for (int b = 0; b < 16; ++b) { blk.src[b] = b < nblk ? (const char*)src[b] : nullptr; blk.dst[b] = b < nblk ? (char*)dst[b] : nullptr; }
+  hipLaunchKernelGGL(exchange_standin_kernel, dim3((unsigned)workgroups), dim3(256), 0, s, blk, nblk, (unsigned long long)bytes);
+  return hipGetLastError();
+}
 
 hipError_t launch_gen_kspace(int f64, void* K, const GenParams& gp, hipStream_t s) {
   const long long total = (long long)gp.nx * gp.ny * gp.zpitch;

@@ -139,7 +139,7 @@ class Generator(object):
     def __init__(self, nx, ny, nz, grid_spacing_Mpc_h, num_plot_sections=4, cosmology=None, power=None,
                  verbose=False, *, backend=None, dtype=np.complex64, rng="reference", growth_function=None,
                  mean_matter_density=None, redshifts=None, transverse_distance=None, curvature_K=0.0, distributed=False,
-                 store_potential=False):
+                 store_potential=False, exchange_chunks=None):
         self.backend = transform.resolve_backend(backend)
         self.distributed = bool(distributed)
         self.store_potential = bool(store_potential)
@@ -155,15 +155,16 @@ class Generator(object):
             if nx % 2 or ny % 2 or nz % 2:
                 raise ValueError("All shape dimensions must be even.")
             self.plan_c2r = slab.SlabHostPlan(slab.DistributedPlan(nx, ny, nz, dtype), dtype)
-            # every call here is ONE realisation: its all-to-all is cut into sub-slabs that travel while the next sub-slab is
-            # still being generated and transformed (RF_FLAG_EXCHANGE_CHUNKS; the batch API pipelines whole realisations instead)
-            if self.plan_c2r.device.nranks > 1:
-                for chunks in (4, 2):
-                    try:
-                        self.plan_c2r.device.set_exchange_chunks(chunks)
-                        break
-                    except RuntimeError:
-                        continue
+            # every call here is ONE realisation.  Its all-to-all can be cut into sub-slabs that travel while the next sub-slab is
+            # still being generated and transformed (RF_FLAG_EXCHANGE_CHUNKS) -- OPT-IN (`exchange_chunks=` or the environment
+            # variable RANDOMFIELD_EXCHANGE_CHUNKS): the two-stream schedule is verified with virtual ranks and the forced slab
+            # path on one GPU only; the default stays the plain forward -> exchange -> backward sequence on one stream until a
+            # multi-GPU run has shown the same field and a gain
+            chunks = exchange_chunks if exchange_chunks is not None else int(os.environ.get("RANDOMFIELD_EXCHANGE_CHUNKS", "1") or 1)
+            if chunks < 1:
+                raise ValueError("exchange_chunks must be >= 1.")
+            if self.plan_c2r.device.nranks > 1 and chunks > 1:
+                self.plan_c2r.device.set_exchange_chunks(chunks)
             # generate.py:79-80: the forward plan over the same memory (here: this rank's window of the field in, its kz planes out)
             self.plan_r2c = self.plan_c2r.create_reverse_plan(reuse_output=True, overwrite=True)
         else:

@@ -164,7 +164,8 @@ def exchange_unique_id(rank, world, make_uid, timeout=300.0, path=None, not_befo
     (a process that loads PyTorch's bundled ROCm runtime next to the system one is asking for trouble).
     Rank 0 removes any stale file of that name, then writes the 128 bytes, followed by the launch's nonce, atomically.  The
     others poll for the file and accept it only if (a) it is 128 bytes + THIS launch's nonce and (b) it was written after this
-    process started (mtime >= `not_before`, default: the process's own start time minus the clock's 2 s of slack).  (a) rejects
+    process started (mtime >= `not_before`, default: the process's own start time minus the clock's 2 s of slack; not applied
+    when the launcher set RANDOMFIELD_LAUNCH_NONCE, which is unique per launch already).  (a) rejects
     the file of any other launch; (b) the one case (a) cannot see -- a launcher without a nonce of its own that starts job
     after job from ONE long-lived parent with the same MASTER_PORT, where a crashed job's file has this job's name: a rank
     that gets here before rank 0 has removed that file would otherwise read a dead communicator's id and sit in
@@ -187,7 +188,9 @@ def exchange_unique_id(rank, world, make_uid, timeout=300.0, path=None, not_befo
         os.replace(tmp, path)
         return uid
     if not_before is None:
-        not_before = _process_start_time() - 2.0
+        # a launcher-made nonce (one per launch) already rules out every other launch's file: no mtime test then -- it would only
+        # reject a valid id when ranks start staggered by more than the slack, or /tmp's clock is skewed
+        not_before = float("-inf") if os.environ.get("RANDOMFIELD_LAUNCH_NONCE") else _process_start_time() - 2.0
     t0 = time.time()
     while True:
         try:

@@ -13,12 +13,18 @@ from randomfield_amd import _hip
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "randomfield_hip.h")
+DIAG_HEADER = os.path.join(ROOT, "include", "randomfield_hip_diag.h")
 
 
-def _declared_symbols():
-    text = open(HEADER).read()
+def _declared_symbols(header=HEADER):
+    text = open(header).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(rf_[a-z0-9_]+)\s*\(", text)))
+
+
+def _header_macro(name):
+    m = re.search(r"#define\s+%s\s+(\d+)" % name, open(HEADER).read())
+    return int(m.group(1))
 
 
 def _have_gpu():
@@ -34,18 +40,39 @@ def test_library_is_built_in_tree():
 
 
 def test_exports_every_declared_symbol():
+    """Both headers against the library's dynamic symbol table and against the binding: the consumer surface
+    (randomfield_hip.h) and the diagnostics (randomfield_hip_diag.h) are disjoint, each is exported completely, the library
+    exports no rf_ symbol that neither declares, and _hip.py binds exactly the two sets."""
+    import subprocess
     lib = ctypes.CDLL(_hip.LIB_PATH)
-    declared = _declared_symbols()
-    assert len(declared) >= 30
-    for name in declared:
+    declared, diag = _declared_symbols(), _declared_symbols(DIAG_HEADER)
+    assert len(declared) >= 30 and len(diag) >= 10
+    assert not set(declared) & set(diag)
+    for name in declared + diag:
         assert hasattr(lib, name), "library does not export %s" % name
-    # and the Python binding covers the same set
     assert sorted(_hip.SIGNATURES) == declared
+    assert sorted(_hip.DIAG_SIGNATURES) == diag
+    nm = subprocess.run(["nm", "-D", "--defined-only", _hip.LIB_PATH], stdout=subprocess.PIPE, check=True).stdout.decode()
+    exported = sorted(set(re.findall(r"\sT\s+(rf_[a-z0-9_]+)$", nm, flags=re.M)))
+    assert exported == sorted(declared + diag), set(exported) ^ set(declared + diag)
+    # the knobs and virtual-rank steps a consumer should not bind live in the diagnostics header only
+    for name in ("rf_kernel_ms", "rf_set_merged_yz", "rf_merged_yz_ms", "rf_slab_exchange_local", "rf_slab_exchange_local_reverse",
+                 "rf_mt_share_exchange_local", "rf_slab_forward", "rf_slab_backward", "rf_slab_set_exchange_standin"):
+        assert name in diag and name not in declared
 
 
 def test_version_and_error_string():
     lib = _hip.load()
-    assert lib.rf_version() >= 1
+    major, minor = _header_macro("RF_ABI_MAJOR"), _header_macro("RF_ABI_MINOR")
+    assert lib.rf_version() == (major << 16) | minor           # the library was built from THIS header
+    assert _hip.abi_version() == (major, minor) == (_hip.ABI_MAJOR, _hip.ABI_MINOR)
+    assert major >= 5                                          # (rounds 1-4 answered 1 whatever the surface was)
+    # every feature bit the header names is set in this build and known to the binding
+    text = open(HEADER).read()
+    bits = {m.group(1).lower(): int(m.group(2)) for m in re.finditer(r"RF_FEATURE_([A-Z0-9_]+)\s*=\s*1\s*<<\s*(\d+)", text)}
+    assert len(bits) >= 12 and {k: 1 << v for k, v in bits.items()} == _hip.FEATURES
+    assert lib.rf_abi_features() == sum(_hip.FEATURES.values())
+    assert _hip.abi_features() == sorted(_hip.FEATURES)
     assert isinstance(_hip.last_error(), str)
 
 
@@ -60,6 +87,12 @@ def test_shape_support_query_needs_no_gpu():
     assert lib.rf_shape_supported(16, 16, 18) == 2 and lib.rf_shape_supported(8, 8, 8) == 2
     assert lib.rf_shape_supported(4096, 16, 16) == 2 and lib.rf_shape_supported(8, 6000, 8192) == 2
     assert not _hip.shape_supported(16384, 16, 16) and not _hip.shape_supported(5, 6, 8) and not _hip.shape_supported(4, 6, 7)
+    # the dtype-aware query is what rf_plan_create accepts: complex128 plans stop at 4096 on the generic path
+    assert lib.rf_shape_supported_dtype(8, 6000, 8192, _hip.RF_F32) == 2 and lib.rf_shape_supported_dtype(8, 6000, 8192, _hip.RF_F64) == 0
+    assert lib.rf_shape_supported_dtype(4096, 4, 8, _hip.RF_F64) == 2 and lib.rf_shape_supported_dtype(1024, 1024, 1024, _hip.RF_F64) == 1
+    assert lib.rf_shape_supported_dtype(16, 16, 16, 7) == 0
+    assert _hip.shape_supported(4096, 16, 16, np.complex128) and not _hip.shape_supported(8192, 16, 16, np.complex128)
+    assert _hip.shape_supported(8192, 16, 16, np.complex64)
 
 
 @pytest.mark.skipif(_have_gpu(), reason="checks the no-GPU failure mode")

@@ -319,7 +319,19 @@ def test_a_rank_never_accepts_another_launch_or_an_older_file(tmp_path, monkeypa
 
     run_with(dead, 0)                                                # no tag at all (the pre-round-4 format)
     run_with(dead + b"|some-other-launch", 0)                        # another launch's nonce
-    run_with(dead + b"|" + slab.launch_nonce().encode(), 3600.0)     # this name and nonce, but written an hour before we started
+    # this name and nonce, but written an hour before we started: only a launch WITHOUT a launcher-made nonce can meet that (one
+    # long-lived parent starting job after job on one port), and only there does the mtime test apply
+    monkeypatch.delenv("RANDOMFIELD_LAUNCH_NONCE")
+    path = slab._rendezvous_path(0)
+    run_with(dead + b"|" + slab.launch_nonce().encode(), 3600.0)
+    # with a launcher-made nonce (unique per launch) the tag alone decides: ranks started long after rank 0 wrote the id, or a
+    # TMPDIR whose clock is behind, must not wait for the timeout
+    monkeypatch.setenv("RANDOMFIELD_LAUNCH_NONCE", "job-18")
+    path = slab._rendezvous_path(0)
+    with open(path, "wb") as f:
+        f.write(fresh + b"|job-18")
+    os.utime(path, (time.time() - 3600.0, time.time() - 3600.0))
+    assert slab.exchange_unique_id(1, 2, lambda: b"", timeout=5, path=path) == fresh
     # (the guard is the process's own start time: a file written after it is taken at once)
     assert slab._process_start_time() <= time.time() and time.time() - slab._process_start_time() < 3600
     with pytest.raises(ValueError):

@@ -91,6 +91,46 @@ def test_kspace_and_field_against_reference_fixtures(hip, dpower, name):
     plan.close()
 
 
+@pytest.mark.parametrize("shape", [(2048, 16, 64), (16, 2048, 64), (16, 16, 2048)])
+def test_2048_point_axes_against_reference_fixtures(hip, dpower, shape):
+    """The longest axis the tiled kernels serve (BASELINE config 4's axis length), pinned to the REFERENCE's own run of
+    fill_with_log10k .. Plan.execute at (2048,16,64), (16,2048,64), (16,16,2048) (oracle/make_golden.py, subsampled: a value of
+    delta depends on every mode of its line).  Every route through the 2048-point kernels: rows K..S unfused + row X from k space
+    (whole-column x pass reading k space, Col2 y pass, 1024-complex z rows), the fused exact-chain realisation, and the drop-in API
+    with rng='reference' (MT19937 replay on the device + the fast generation pass, Col2 form at nx = 2048)."""
+    from randomfield_amd import Generator
+    g = golden("axis2048_%dx%dx%d_c64.npz" % shape)
+    assert tuple(int(v) for v in g["shape"]) == shape
+    nx, ny, nz = shape
+    sd, sk = (tuple(int(v) for v in g[k]) for k in ("stride_delta", "stride_k"))
+    rms, kmax = float(g["rms"]), float(g["kspace_absmax"])
+    plan = make_plan(hip, shape, np.complex64, *dpower)
+    noise = cpu_ref.reference_noise(int(g["seed"]), nx * ny * (nz // 2 + 1))
+
+    def check_field(d, what):
+        assert d.shape == shape and d.dtype == np.float32
+        assert np.max(np.abs(d[::sd[0], ::sd[1], ::sd[2]] - g["sub"])) <= TOL_F32 * rms, what
+        assert np.max(np.abs(d[0, 0, :4] - g["first"])) <= TOL_F32 * rms and np.max(np.abs(d[-1, -1, -4:] - g["last"])) <= TOL_F32 * rms, what
+        assert abs(float(d.min()) - float(g["min"])) <= 2 * TOL_F32 * rms and abs(float(d.max()) - float(g["max"])) <= 2 * TOL_F32 * rms, what
+
+    plan.generate(noise=noise)
+    ks = plan.download_k()
+    assert np.max(np.abs(ks[::sk[0], ::sk[1], ::sk[2]] - g["kspace_sub"])) <= 5e-7 * kmax
+    assert ks[0, 0, 0] == 0 and cpu_ref.is_hermitian_packed(ks, rtol=0, atol=0)
+    plan.execute_c2r()
+    check_field(plan.download_real(), "rf_generate + rf_execute_c2r")
+    mean, std = plan.moments()
+    assert abs(std - rms) <= TOL_F32 * rms and abs(mean - float(g["mean"])) <= 1e-6 * rms
+    plan.realise(noise=noise)
+    check_field(plan.download_real(), "rf_realise (exact chain, host deviates)")
+    assert abs(plan.moments()[1] - rms) <= TOL_F32 * rms
+    plan.close()
+    gen = Generator(nx, ny, nz, SPACING)                      # rng='reference' is the default: same seed, same field
+    check_field(gen.generate_delta_field(seed=int(g["seed"]), save_potential=False), "Generator(rng='reference')")
+    assert abs(float(gen.delta_field_rms) - rms) <= TOL_F32 * rms
+    gen.plan_c2r.device.close()
+
+
 @pytest.mark.parametrize("n,tag", [(64, "c64"), (128, "c64"), (64, "c128"), (128, "c128")])
 def test_summary_grids(hip, dpower, n, tag):
     g = golden("summary_%d_%s.npz" % (n, tag))
@@ -207,10 +247,11 @@ def test_native_rng_matches_oracle_restatement(hip, dpower):
     """Native Philox4x32-7 + Box-Muller mode, value by value against the oracle's
     restatement of the same counter-based stream.  The default (fast) generation
     forms sigma and the deviates with float32 hardware log / sin / cos on float32
-    AND float64 plans: 2e-5 * rms.  The exact-chain flavour on a float64 plan
+    AND float64 plans: held to north_star's 1e-5 * rms (measured 4 - 8e-6; rounds 1 - 4 allowed 2e-5 here while the
+    bench-instantiation test already held 1e-5).  The exact-chain flavour on a float64 plan
     reproduces the float64 restatement to 1e-11."""
     k, Pk = dpower
-    for dtype, tol in ((np.complex64, 2e-5), (np.complex128, TOL_F64)):
+    for dtype, tol in ((np.complex64, TOL_F32), (np.complex128, TOL_F64)):
         shape = (64, 32, 128)
         nx, ny, nz = shape
         plan = make_plan(hip, shape, dtype, k, Pk)
@@ -218,14 +259,14 @@ def test_native_rng_matches_oracle_restatement(hip, dpower):
         d = plan.download_real()
         noise = cpu_ref.native_noise(2024, nx, ny, nz, dtype)
         ref, rms = cpu_ref.generate_delta_field(nx, ny, nz, SPACING, k, Pk, noise=noise, dtype=dtype, double_fft=True)
-        assert np.max(np.abs(d - ref)) <= 2e-5 * rms
+        assert np.max(np.abs(d - ref)) <= TOL_F32 * rms
         # unfused path (generate -> k-space -> c2r) equals the fused one
         plan.generate(seed=2024)
         ks = plan.download_k()
         kref = cpu_ref.generate_kspace(nx, ny, nz, SPACING, k, Pk, noise=noise, dtype=dtype)
         assert np.max(np.abs(ks - kref)) <= tol * np.max(np.abs(kref))
         plan.execute_c2r()
-        assert np.max(np.abs(plan.download_real() - d)) <= 2e-5 * rms
+        assert np.max(np.abs(plan.download_real() - d)) <= TOL_F32 * rms
         # the fast float32 generation flavour (default) and the exact-chain flavour agree
         plan.set_exact_generation(True)
         plan.realise(seed=2024)
@@ -1994,6 +2035,22 @@ def test_merged_yz_launches_give_the_same_field(hip, dpower):
     plan.set_merged_yz(0)
     plan.realise_batch(np.array([78], np.uint64), want_rms=False)          # (the captured graphs were dropped with the mode)
     assert np.array_equal(plan.download_real(), other)
+    plan.close()
+    # a FRESH plan whose first timed call is already merged: rf_kernel_ms must read the merged form's events only (the per-pass
+    # event pairs of the one-launch-per-pass form were created for this plan but never recorded)
+    plan = make_plan(hip, shape, np.complex64, k, Pk)
+    plan.set_merged_yz(2)
+    plan.realise(seed=77)
+    kern = plan.kernel_ms()
+    ms, n = plan.merged_yz_ms()
+    assert n == 3 and all(v >= 0.0 for v in kern) and 0.0 < ms <= kern[1] and kern[2] > 0.0
+    assert np.array_equal(plan.download_real(), ref)
+    plan.set_merged_yz(1)
+    plan.realise(seed=77)                            # and back to one launch per pass: the per-pass sums again
+    k1 = plan.kernel_ms()
+    assert k1[1] > 0.0 and k1[2] > 0.0
+    with pytest.raises(RuntimeError):
+        plan.merged_yz_ms()
     plan.close()
 
 

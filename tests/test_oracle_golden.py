@@ -64,6 +64,28 @@ def test_summary_grids(n, tag, default_power):
     assert abs(delta.astype(np.float64).mean() - float(g["mean"])) < 1e-6
 
 
+@pytest.mark.parametrize("shape", [(2048, 16, 64), (16, 2048, 64), (16, 16, 2048)])
+def test_2048_point_axes(shape, default_power):
+    """the oracle against the reference's own run with one axis of 2048 points (subsampled fixtures of oracle/make_golden.py):
+    bit exact through symmetrise, <= 2e-6 * rms after the float32 FFT"""
+    g = golden("axis2048_%dx%dx%d_c64.npz" % shape)
+    nx, ny, nz = shape
+    sd, sk = (tuple(int(v) for v in g[k]) for k in ("stride_delta", "stride_k"))
+    data = cpu_ref.fill_log10k(nx, ny, nz, float(g["spacing"]), np.complex64)
+    cpu_ref.tabulate_sigmas(data, default_power["k"], default_power["Pk"], float(g["spacing"]))
+    assert np.array_equal(data.real[::sk[0], ::sk[1], ::sk[2]], g["sigma_sub"])
+    cpu_ref.randomize(data, seed=int(g["seed"]))
+    cpu_ref.symmetrize_packed(data)
+    assert np.array_equal(data[::sk[0], ::sk[1], ::sk[2]], g["kspace_sub"])
+    assert float(np.max(np.abs(data))) == float(g["kspace_absmax"])
+    delta = cpu_ref.c2r(data)
+    rms = float(g["rms"])
+    assert np.max(np.abs(delta[::sd[0], ::sd[1], ::sd[2]] - g["sub"])) <= 2e-6 * rms
+    assert np.max(np.abs(delta[0, 0, :4] - g["first"])) <= 2e-6 * rms and np.max(np.abs(delta[-1, -1, -4:] - g["last"])) <= 2e-6 * rms
+    assert abs(np.std(delta) - rms) <= 2e-6 * rms
+    assert abs(float((delta.astype(np.float64) ** 2).sum()) - float(g["sumsq"])) <= 1e-5 * float(g["sumsq"])
+
+
 def test_survey_known_answers(default_power):
     """SURVEY.md 8c spot values (default P(k), spacing 2.5, seed 123, c64)."""
     expect = {

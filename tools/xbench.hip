@@ -9,14 +9,9 @@
 #include <unistd.h>
 #include <vector>
 #include "rf_kernels.h"
-#include "plane_yz_experiment.h"
 #include "rf_host.h"
 
 using namespace rf;
-#ifndef RF_FUSED_R1
-#define RF_FUSED_R1 16
-#define RF_FUSED_R2 8
-#endif
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
@@ -532,74 +527,6 @@ int main(int argc, char** argv) {
     }
   }
 
-  if (argc >= 2 && strchr(argv[1], 'f')) {
-    // fused y + z passes through L2 / Infinity-Cache resident scratch planes vs the two separate passes
-    using CY = ColCfg<float, 1024, RF_FUSED_R1, RF_FUSED_R2, 8, 8, 512>;
-    using CZ = RowCfg<float, 512, 8, 8, 8, 8, 512>;
-    constexpr int ZR = 16, NS = 3;
-    auto k = plane_yz_kernel<CY, CZ, ZR, NS>;
-    constexpr int TILE = CY::TILE_BYTES > CZ::TILE_BYTES ? CY::TILE_BYTES : CZ::TILE_BYTES;
-    constexpr int lds = TILE + CY::TW_BYTES + CZ::TW_BYTES;
-    CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    cplx<float>* S;
-    const size_t plane = (size_t)NY * nzc * 8;
-    CK(hipMalloc((void**)&S, plane * NS * PlaneCtl::MAX_GROUPS));
-    PlaneCtl* ctl;
-    CK(hipMalloc((void**)&ctl, sizeof(PlaneCtl)));
-    double* partials;
-    CK(hipMalloc((void**)&partials, 2 * sizeof(double) * (size_t)NX * NY));
-    auto twzh = make_twiddles<float>(1024);
-    printf("plane kernel: LDS %d bytes\n", lds);
-    const int dbg_only = getenv("RF_DBG") ? atoi(getenv("RF_DBG")) : -1;
-    const int nxp = getenv("RF_NXP") ? atoi(getenv("RF_NXP")) : NX;
-    for (int dbg : {0, 1, 2, 3})
-    for (int grid : {getenv("RF_GRID") ? atoi(getenv("RF_GRID")) : 512}) {
-      if (dbg_only >= 0 && dbg != dbg_only) continue;
-      char nm[128];
-      snprintf(nm, sizeof nm, "fused y+z (scratch planes in L2 / Infinity Cache), grid=%d, skip=%d (1: no Y work, 2: no Z work)", grid, dbg);
-      if (getenv("RF_MARK")) {
-        // hang hunting: one launch, markers in mapped host memory, the host polls and reports instead of waiting forever
-        unsigned* mark;
-        CK(hipHostMalloc((void**)&mark, 4096 * 4, hipHostMallocMapped));
-        memset(mark, 0xEE, 4096 * 4);
-        CK(hipMemset(ctl, 0, sizeof(PlaneCtl)));
-        hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, 0, W, nxp, S, tw, tw, 1.0f, partials, ctl, dbg, mark);
-        for (int sec = 0; sec < 3; ++sec) {
-          struct timespec ts = {1, 0}; nanosleep(&ts, nullptr);
-          printf("after %d s: hipStreamQuery = %d; markers (is_y<<31 | seq<<12 | item):", sec + 1, (int)hipStreamQuery(0));
-          for (int b = 0; b < grid && b < 16; ++b) printf(" %08x", mark[b]);
-          printf("\n");
-        }
-        if (hipStreamQuery(0) == hipSuccess) {
-          PlaneCtl h;
-          CK(hipMemcpy(&h, ctl, sizeof h, hipMemcpyDeviceToHost));
-          printf("next_plane %u error %u\n", h.next_plane, h.error);
-          for (int g = 0; g < 8; ++g) printf("   group %d: ticket %u claimed %u done_y %u %u %u %u done_z %u %u %u %u planes %d %d %d %d\n", g, h.g[g].ticket, h.g[g].claimed, h.g[g].done_y[0], h.g[g].done_y[1], h.g[g].done_y[2], h.g[g].done_y[3], h.g[g].done_z[0], h.g[g].done_z[1], h.g[g].done_z[2], h.g[g].done_z[3], h.g[g].plane_of[0], h.g[g].plane_of[1], h.g[g].plane_of[2], h.g[g].plane_of[3]);
-        }
-        _exit(0);
-      }
-      report(nm, t.run([&]() {
-        CK(hipMemsetAsync(ctl, 0, sizeof(PlaneCtl), 0));
-        hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, 0, W, nxp, S, tw, tw, 1.0f, partials, ctl, dbg, (unsigned*)nullptr);
-      }), 2 * sweep);
-      PlaneCtl h;
-      CK(hipMemcpy(&h, ctl, sizeof h, hipMemcpyDeviceToHost));
-      int groups = 0; unsigned tickets = 0;
-      for (int g = 0; g < PlaneCtl::MAX_GROUPS; ++g) if (h.g[g].ticket) { ++groups; tickets += h.g[g].ticket; }
-      printf("   planes claimed %u, error %u, groups %d, tickets %u\n", h.next_plane, h.error, groups, tickets);
-      if (h.error) for (int g = 0; g < 8; ++g) printf("   group %d: ticket %u claimed %u done_y %u %u %u %u done_z %u %u %u %u planes %d %d %d %d\n", g, h.g[g].ticket, h.g[g].claimed, h.g[g].done_y[0], h.g[g].done_y[1], h.g[g].done_y[2], h.g[g].done_y[3], h.g[g].done_z[0], h.g[g].done_z[1], h.g[g].done_z[2], h.g[g].done_z[3], h.g[g].plane_of[0], h.g[g].plane_of[1], h.g[g].plane_of[2], h.g[g].plane_of[3]);
-    }
-    {
-      using IO = PlainColIO<float>;
-      IO io; io.base = W; io.g = ColGeom{nzc, (long long)NY * nzc, nzc};
-      report("y pass alone", bench_x<ColCfg<float, 1024, 16, 8, 8, 8, 512>, IO>(t, io, tw, (long long)NX * nzc, 0, 0), 2 * sweep);
-      using CR = RowCfg<float, 512, 8, 8, 8, 8, 256>;
-      PlainRowIO<float> zio; zio.base = W; zio.scale = 1.0f; zio.M_of = 512;
-      auto kz = row_c2r_kernel<CR, PlainRowIO<float>>;
-      const long long nrows = (long long)NX * NY, ntz = nrows / CR::NRT;
-      report("z pass alone", t.run([&]() { hipLaunchKernelGGL(kz, dim3((unsigned)ntz), dim3(CR::NT), CR::LDS_BYTES, 0, zio, tw, nrows, partials); }), 2 * sweep);
-    }
-  }
 
   if (argc >= 2 && strchr(argv[1], 'L')) {
     // length-2048 x pass (one 152 KiB tile per CU): fresh workgroup per tile vs persistent workgroups
@@ -652,41 +579,6 @@ int main(int argc, char** argv) {
     }
   }
 
-  if (argc >= 2 && strchr(argv[1], 'g')) {
-    // fused y + z, v2: one workgroup per item, blockIdx-ordered roles
-    using CY = ColCfg<float, 1024, RF_FUSED_R1, RF_FUSED_R2, 8, 8, 512>;
-    using CZ = RowCfg<float, 512, 8, 8, 8, 8, 512>;
-    constexpr int ZR = 16, NS = 3;
-    auto k = plane_yz_kernel_v2<CY, CZ, ZR, NS>;
-    constexpr int TILE = CY::TILE_BYTES > CZ::TILE_BYTES ? CY::TILE_BYTES : CZ::TILE_BYTES;
-    constexpr int lds = TILE + CY::TW_BYTES + CZ::TW_BYTES;
-    CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    cplx<float>* S;
-    const size_t plane = (size_t)NY * nzc * 8;
-    CK(hipMalloc((void**)&S, plane * NS * 8));
-    PlaneCtl2* ctl;
-    CK(hipMalloc((void**)&ctl, sizeof(PlaneCtl2)));
-    double* partials;
-    CK(hipMalloc((void**)&partials, 2 * sizeof(double) * (size_t)NX * NY));
-    const int nxp = getenv("RF_NXP") ? atoi(getenv("RF_NXP")) : NX;
-    const int nseq = (nxp + 7) / 8;
-    const unsigned grid = 8u * (unsigned)(nseq + 1) * 128u;        // rounds 0 .. nseq: round r holds Y(r) and Z(r - 1)
-    const int dbg_only = getenv("RF_DBG") ? atoi(getenv("RF_DBG")) : -1;
-    for (int dbg : {0, 1, 2, 3}) {
-      if (dbg_only >= 0 && dbg != dbg_only) continue;
-      char nm[160];
-      snprintf(nm, sizeof nm, "fused y+z v2 (one workgroup per item), %d planes, skip=%d (1: no Y work, 2: no Z work)", nxp, dbg);
-      report(nm, t.run([&]() {
-        CK(hipMemsetAsync(ctl, 0, sizeof(PlaneCtl2), 0));
-        hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, 0, W, nxp, S, tw, tw, 1.0f, partials, ctl, dbg);
-      }), 2 * sweep * nxp / NX);
-      PlaneCtl2 h;
-      CK(hipMemcpy(&h, ctl, sizeof h, hipMemcpyDeviceToHost));
-      printf("   error %u, group xcc ids %u %u %u %u %u %u %u %u, done_y[0][0..2] %u %u %u, done_z %u %u %u\n", h.error, h.group_xcc[0], h.group_xcc[1],
-             h.group_xcc[2], h.group_xcc[3], h.group_xcc[4], h.group_xcc[5], h.group_xcc[6], h.group_xcc[7], h.done_y[0][0], h.done_y[0][1],
-             h.done_y[0][2], h.done_z[0][0], h.done_z[0][1], h.done_z[0][2]);
-    }
-  }
   if (do_y) {
     using C = ColCfg<float, 1024, 16, 8, 8, 8, 512>;
     using IO = PlainColIO<float>;
