@@ -229,7 +229,8 @@ def other_configs(power, spacing, device, only=None):
     plan.close()
     # ... and what ONE rank of that job computes per realisation (virtual rank of 8 on this GPU: the kernels and layouts of
     # config 4, the all-to-all left out): forward = generation + x + y on the rank's 128 kz planes, backward = the gathering z pass
-    per_rank = {}
+    per_rank, standin = {}, {}
+    sweep2048 = 8.0 * 2048 * 2048 * (2048 // 2 + 1)
     for r in (0, 3):
         p = _hip.DevicePlan(2048, 2048, 2048, np.complex64, device=device, nranks=8, rank=r)
         p.set_kgrid(*powertools.ksq_axes(2048, 2048, 2048, spacing))
@@ -246,9 +247,40 @@ def other_configs(power, spacing, device, only=None):
             t2 = time.perf_counter()
             fw.append(t1 - t0)
             bw.append(t2 - t1)
-        per_rank["rank %d" % r] = {"forward_ms": round(float(np.median(fw)) * 1e3, 3), "backward_ms": round(float(np.median(bw)) * 1e3, 3)}
+        f_ms, b_ms = float(np.median(fw)) * 1e3, float(np.median(bw)) * 1e3
+        per_rank["rank %d" % r] = {"forward_ms": round(f_ms, 3), "backward_ms": round(b_ms, 3)}
+        # ... and the same rank through the REAL pipelined schedule of the multi-GPU batch (forward half of realisation i + 1 on the
+        # compute stream under the exchange of realisation i on the exchange stream, then the gathering z pass), the all-to-all
+        # replaced by a copy kernel of fixed width -- RCCL's channel footprint -- that reads the 7 blocks the rank would send and
+        # writes the 7 segments it would receive (rf_slab_set_exchange_standin): what the exchange's LOCAL traffic and compute
+        # units cost the passes it overlaps.  The links themselves are not in it.
+        ent = {"forward_plus_backward_ms": round(f_ms + b_ms, 3),
+               "standin_bytes_read": 7.0 / 8.0 * sweep2048 / 8.0, "standin_bytes_written": 7.0 / 8.0 * sweep2048 / 8.0}
+        nreal = 8
+        for w in (16, 32):
+            p.set_exchange_standin(w)
+            p.realise_batch(np.arange(3, dtype=np.uint64), want_rms=False)
+            p.sync()
+            ts = []
+            for k in range(3):
+                t0 = time.perf_counter()
+                p.realise_batch(np.arange(100 * k, 100 * k + nreal, dtype=np.uint64), want_rms=False)
+                p.sync()
+                ts.append((time.perf_counter() - t0) / nreal * 1e3)
+            t0 = time.perf_counter()
+            p.realise(seed=5)                      # one realisation: forward, stand-in, backward in sequence
+            p.sync()
+            seq = (time.perf_counter() - t0) * 1e3
+            t_p = float(np.median(ts))
+            ent["%d workgroups" % w] = {"pipelined_ms_per_realisation": round(t_p, 3),
+                                        "slowdown_vs_forward_plus_backward": round(t_p / (f_ms + b_ms), 4),
+                                        "standin_alone_ms": round(seq - f_ms - b_ms, 3),
+                                        "standin_alone_GBs_each_way": round(7.0 / 8.0 * sweep2048 / 8.0 / max(seq - f_ms - b_ms, 1e-3) / 1e6, 1)}
+        p.set_exchange_standin(0)
+        standin["rank %d" % r] = ent
         p.close()
     out["2048^3 / 8 kz slabs, per-rank compute on this GPU (virtual ranks, no exchange)"] = per_rank
+    out["2048^3 / 8 kz slabs, one virtual rank through the pipelined batch with an exchange stand-in"] = standin
     return out
 
 
@@ -573,6 +605,23 @@ def main():
                      "launches_per_realisation": launches[dom],
                      "whole_pipeline_frac": round(5 * sweep * args.steps / wall / 1e9 / HBM_PEAK_GBS, 4)},
     }
+    # An estimate of the bytes that really cross the HBM pins: `achieved` / `frac` price ALGORITHMIC bytes, but when
+    # the y and z passes run slab by slab the slab goes from the y pass to the z pass through the 256 MiB Infinity Cache and the z pass
+    # overwrites it in place, so per realisation only the x pass's write (S), the y pass's read (S) and the z pass's result (S) reach
+    # HBM: 3 of the 5 sweeps.  No counter on this chip separates Infinity-Cache hits from HBM accesses (FETCH_SIZE / WRITE_SIZE are L2-side
+    # and count the hits: MI355X_MICROARCH.md), hence an estimate: it assumes a perfect hand-off (every line the y pass writes is still
+    # in the cache when the z pass reads it and is overwritten before it is evicted).
+    handoff = nslab > 1
+    hbm_per_pass = [sweep, sweep if handoff else 2 * sweep, sweep if handoff else 2 * sweep]
+    out["roofline"]["hbm_bytes_est"] = hbm_per_pass[dom] / launches[dom]
+    out["roofline"]["frac_hbm_est"] = round(hbm_per_pass[dom] / (pass_ms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    out["pipeline"]["hbm_bytes_est_per_realisation"] = float(sum(hbm_per_pass))
+    out["pipeline"]["frac_hbm_est"] = round(sum(hbm_per_pass) * args.steps / wall / 1e9 / HBM_PEAK_GBS, 4)
+    hbm_note = ("ESTIMATE, not a counter: algorithmic bytes minus what the slab hand-off keeps in the 256 MiB Infinity Cache (the z pass reads "
+                "what the y pass has just written, and overwrites it before it is evicted): x writes S, y reads S, z's result S = 3 of "
+                "the 5 sweeps per realisation reach HBM" if handoff else
+                "no slab hand-off on this grid (whole-grid passes): the estimate equals the algorithmic bytes")
+    out["roofline"]["hbm_bytes_est_note"] = hbm_note
     if merged_ms:
         # the kernel the timed region spends most of its time in: (nslab - 1) merged launches per realisation, each the z pass of one
         # slab (read + write) and the y pass of the next (read + write): 4 sweeps of a slab
@@ -591,7 +640,11 @@ def main():
                                    "each: pipeline.kernel_ms / pass_frac_of_hbm_peak",
                            "unmerged_dominant_pass": {"kernel": names[dom], "frac": round(achieved / HBM_PEAK_GBS, 4),
                                                       "avg_ms": round(float(pass_ms[dom]) / launches[dom], 5)},
-                           "whole_pipeline_frac": round(5 * sweep * args.steps / wall / 1e9 / HBM_PEAK_GBS, 4)}
+                           "whole_pipeline_frac": round(5 * sweep * args.steps / wall / 1e9 / HBM_PEAK_GBS, 4),
+                           # of the launch's four slab sweeps the y half's read and the z half's result cross the HBM pins
+                           "hbm_bytes_est": 2 * sweep / nslab,
+                           "frac_hbm_est": round(2 * sweep / nslab / (merged_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                           "hbm_bytes_est_note": hbm_note}
         out["pipeline"]["launches_per_realisation"] = {"x": 3, "y": 1, "z + y merged": merged_n, "z": 1, "reduce": 1}
     out["config"]["parity"] = ("native stream = this repo's own definition (no reference counterpart): the kernel instantiations "
                                "of this run are value-checked against the oracle's float64 restatement at 1e-5 * rms in "

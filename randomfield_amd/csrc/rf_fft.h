@@ -1185,10 +1185,10 @@ RF_HD float exp_t(float x) { return expf(x); }
 RF_HD double exp_t(double x) { return exp(x); }
 // float64 plans: exp(t ln2 / 64) for an argument already in units of ln2 / 64 (the table Ap carries the factor 64 / ln2, lognormal_ap_unit):
 // t = k + f, |f| <= 1/2, k = 64 e + j: 2^e * 2^(j/64) * exp(f ln2/64), the middle factor from a 64-entry table in LDS (rf_exp2_tab.h,
-// correctly rounded), the last a degree-5 polynomial (|r| <= 0.0055: the first dropped term is 4e-17).  12 float64-rate instructions
+// correctly rounded), the last a degree-4 polynomial (|r| <= 0.0055: the first dropped term is 4e-14; round 4: degree 5).  11 float64-rate instructions
 // and one ds_read_b64 per element where the library's exp takes ~22 (no table: a degree-11 polynomial, range checks); the z pass of a
-// float64 plan issues 16 of them per thread.  |error| <= 1 ulp of the result + the rounding of t (ulp(t) ln2 / 128 <= 6e-16 at
-// |x| = 5.5): the same size as the rounding of the product delta * Ap that both forms share.  Out-of-range arguments saturate through
+// float64 plan issues 16 of them per thread.  |error| <= 4e-14 relative (the dropped term) + 1 ulp of the result + the rounding of t
+// (ulp(t) ln2 / 128 <= 6e-16 at |x| = 5.5, the same size as the rounding of the product delta * Ap that both forms share).  Out-of-range arguments saturate through
 // the conversion and ldexp (inf / 0), NaN propagates through r.
 #if defined(__HIP_DEVICE_COMPILE__)
 static __device__ const double rf_exp2_tab[64] = {RF_EXP2_TAB_VALUES};
@@ -1206,8 +1206,13 @@ RF_HD int exp_k_of(double kf) {
 }
 // 2^(k >> 6) * tj * exp(c f), c = ln 2 / 64, tj = 2^((k & 63) / 64)
 RF_HD double exp_finish(double f, double tj, int k) {
-  // exp(c f) - 1 = f (c + f (c^2/2 + f (c^3/6 + f (c^4/24 + f c^5/120))))
-  double q = __builtin_fma(f, 0x1.5d87fe78a6731p-40 /* c^5/120 */, 0x1.3b2ab6fba4e77p-31 /* c^4/24 */);
+  // exp(c f) - 1 = f (c + f (c^2/2 + f (c^3/6 + f c^4/24))): |c f| <= ln2/128, so the first dropped term (c f)^5/120 is <= 3.9e-14 of
+  // the result -- the fused map is checked against the reference's chain to 1e-12, its tolerance is 1e-11 (rounds 3 - 4 carried the
+  // fifth-order term too: one more float64 fma per element, 2 x 10^9 of them per 1024^3 field)
+#ifndef RF_EXP_DEGREE5
+#define RF_EXP_DEGREE5 0
+#endif
+  double q = RF_EXP_DEGREE5 ? __builtin_fma(f, 0x1.5d87fe78a6731p-40 /* c^5/120 */, 0x1.3b2ab6fba4e77p-31 /* c^4/24 */) : 0x1.3b2ab6fba4e77p-31 /* c^4/24 */;
   q = __builtin_fma(f, q, 0x1.c6b08d704a0c0p-23 /* c^3/6 */);
   q = __builtin_fma(f, q, 0x1.ebfbdff82c58fp-15 /* c^2/2 */);
   q = __builtin_fma(f, q, 0x1.62e42fefa39efp-7 /* c */);

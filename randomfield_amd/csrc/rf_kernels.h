@@ -293,8 +293,20 @@ __device__ __forceinline__ void row_c2r_body(IO& io, const cplx<typename C::T>* 
 }
 
 // z pass: c2r rows + per-workgroup (sum, sum of squares) partials
+// Waves per SIMD the register allocator must leave room for.  The float64 pass of rows of 512 complex allocates 182 VGPRs when left
+// alone: two waves per SIMD, although its LDS footprint (53 KB) admits three workgroups per CU.  Held to three waves (168 VGPRs, 20 - 28
+// bytes of scratch per thread) the passes WITH an epilogue (LognormalRowIO, ScaleZRowIO: row_io_pre) gain -- the fused lognormal z pass
+// 4.00 -> 3.70 ms per 1024^3 float64 on MI355X, profiles/r05_ab/r05_b_ln_*.log -- while the plain pass, which already sits at the copy
+// ceiling, loses 4 % (3.18 -> 3.32 ms) and keeps its registers.  (Rows of 1024 complex128: 184 bytes of scratch at three waves; left alone.)
+#ifndef RF_ROW64_EPILOGUE_WAVES
+#define RF_ROW64_EPILOGUE_WAVES 3
+#endif
 template <class C, class IO>
-__global__ __launch_bounds__(C::NT) void row_c2r_kernel(IO io, const cplx<typename C::T>* __restrict__ tw,
+constexpr int row_min_waves() {
+  return (sizeof(typename C::T) == 8 && C::M == 512 && row_io_pre<IO, C::RL>::value) ? RF_ROW64_EPILOGUE_WAVES : 1;
+}
+template <class C, class IO>
+__global__ __launch_bounds__(C::NT, (row_min_waves<C, IO>())) void row_c2r_kernel(IO io, const cplx<typename C::T>* __restrict__ tw,
                                                         long long nrows, double* __restrict__ partials) {
   extern __shared__ __attribute__((aligned(16))) char rf_smem[];
   // last rows first: the pass before this one wrote the array front to back, so its end is what the 256 MiB Infinity
