@@ -459,6 +459,96 @@ struct FastGenColIOT {
     }
     return v;
   }
+  // ---- sigma shared between the rows +-ix (round 5) ------------------------------------------------------------------------------
+  // |k|^2 of a cell depends on kx^2 only, and the R rows j + m L of a first-pass butterfly are the mirror images (nx - ix) of the
+  // rows of butterfly L - j: thread j's rows m >= R/2 need exactly the sigmas thread L - j computes for its rows R - 1 - m < R/2.
+  // ColFFT::pass_first deals the butterflies to the lanes so that the two sit in the same wave 32 lanes apart (share_row), each
+  // computes the sigma of its first R/2 rows only and the halves change places through the wave's cross-lane network (ds_bpermute,
+  // no LDS space, no barrier): R sigma lookups (11 vector instructions and one 16-byte LDS read each) become R/2 + R/2 exchanges.
+  // The values are bit for bit those of the unshared kernel: kx enters through its square.  Butterfly 0 (rows m L, mirror R - m, row
+  // R/2 L its own mirror) and butterfly L/2 (its own mirror image) take no partner: they source from themselves.  XS = 2, odd phase
+  // (rows of the modes 2 r + 1): the mirror of row r is N1 - 1 - r, i.e. butterfly L - 1 - j, and no butterfly is its own partner.
+#ifndef RF_SIGMA_SHARE
+#define RF_SIGMA_SHARE 1
+#endif
+  // (measured on MI355X, profiles/r05_ab/r05_c_*: the whole-column kernels gain -- x pass of 1024^3 1.186 -> 1.15 ms, 1131 instead of 1198
+  // vector instructions per wave -- the two-phase Col2 form, whose register budget is full with the parked half, loses 4 %: 10.87 -> 11.29 ms
+  // per 2048^3; so XS = 1 only, RF_SIGMA_SHARE = 2 includes the Col2 form)
+  static constexpr bool SIGMA_SHARE = RF_SIGMA_SHARE && SRC == 0 && SLAB == 0 && (AB == 0) && (XS == 1 || RF_SIGMA_SHARE >= 2);
+  // butterfly (row base) of slot jl = tid / LPR when there are S slots per wave: the first S/2 slots of a wave take q = (S/2) w + s, the
+  // others its partner
+  RF_HD int share_row(int jl, int L, int S) const {
+    const int h = S >> 1, w = jl / S, sl = jl & (S - 1), q = h * w + (sl & (h - 1));
+    if (!(sl & h)) return q;
+    if (XS == 2 && xp == 1) return L - 1 - q;
+    return q == 0 ? (L >> 1) : L - q;
+  }
+  RF_HD bool share_self(int j, int L) const { return !(XS == 2 && xp == 1) && (j == 0 || j == (L >> 1)); }
+  // all R rows j + m L of the lane's cell pair; `lane` = the lane's index in its wave
+  template <int R> RF_HD void load_rows(long long C0, int cl, int j, int L, int lane, V16<float>* out) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const long long C = C0 + cl;
+    const uint64_t seed = gp.seed;
+    const int iy = (int)((unsigned)C >> nzl_shift()), kz = kz0 + (int)((unsigned)C & (unsigned)(nzl - 1));
+    const uint64_t half_plane = ((uint64_t)gp.ny * (uint64_t)(gp.nz / 2)) >> 1;
+    const int rbt = XS * j;
+    const uint64_t ctr_l = (uint64_t)rbt * half_plane + (((uint64_t)iy * (uint64_t)(gp.nz / 2) + (uint64_t)kz) >> 1);
+    const float ky = (float)fast_signed_index(iy, gp.ny) * gp.dky, ky2 = ky * ky;
+    float sa[R], sb[R];
+#pragma unroll
+    for (int m = 0; m < R / 2; ++m) {                      // rows below nx / 2: the mode index is the row's own
+      const float kx = (float)(rbt + XS * m * L + (XS == 2 ? xp : 0)) * gp.dkx;
+      const float kxy = fmaf(kx, kx, ky2);
+      sa[m] = fast_sigma(gp, rec, fast_k2(gp, kxy, kz));
+      sb[m] = fast_sigma(gp, rec, fast_k2(gp, kxy, kz + 1));
+    }
+    const int src = (share_self(j, L) ? lane : lane ^ 32) << 2;
+#pragma unroll
+    for (int m = 0; m < R / 2; ++m) {
+      sa[R - 1 - m] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(sa[m])));
+      sb[R - 1 - m] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(sb[m])));
+    }
+    if (j == 0 && !(XS == 2 && xp == 1)) {                 // rows m L: the mirror of row m is row R - m, row R/2 (mode nx / 2) is its own
+      const float kx = (float)(XS * (R / 2) * L) * gp.dkx;
+      const float kxy = fmaf(kx, kx, ky2);
+      sa[R / 2] = fast_sigma(gp, rec, fast_k2(gp, kxy, kz));
+      sb[R / 2] = fast_sigma(gp, rec, fast_k2(gp, kxy, kz + 1));
+#pragma unroll
+      for (int m = R / 2 + 1; m < R; ++m) { sa[m] = sa[R - m]; sb[m] = sb[R - m]; }
+    }
+#pragma unroll
+    for (int m = 0; m < R; ++m) {
+      const int ro = m * L, rot = XS * ro + (XS == 2 ? xp : 0);
+      const uint64_t ctr_u = pin_uniform((uint64_t)rot * half_plane);
+      const PhiloxOut o = philox_native(ctr_l + ctr_u, 0, seed);
+      float g0, g1;
+      BoxMuller<float>::run_scaled(o.w[0], o.w[1], sa[m], g0, g1);
+      out[m].c[0] = mk<float>(g0, g1);
+      BoxMuller<float>::run_scaled(o.w[2], o.w[3], sb[m], g0, g1);
+      out[m].c[1] = mk<float>(g0, g1);
+      if (POT != 0) {
+        const int ro_s = XS * ro >= (gp.nx >> 1) ? rot - gp.nx : rot;
+        const float kx = (float)(rbt + ro_s) * gp.dkx, kxy = fmaf(kx, kx, ky2);
+        const float ra = fast_rcp(fast_k2(gp, kxy, kz)), rb2 = fast_rcp(fast_k2(gp, kxy, kz + 1));
+        if (POT == 2) {
+          const float ps = (float)gp.pscale;
+          out[m].c[0] = mk<float>((out[m].c[0].x * ra) * ps, (out[m].c[0].y * ra) * ps);
+          out[m].c[1] = mk<float>((out[m].c[1].x * rb2) * ps, (out[m].c[1].y * rb2) * ps);
+        } else {
+          const int nzp = gp.ppitch, sl = kz - gp.zoff;
+          cplx<float>* row = (pot + (long long)ro * gp.ny * nzp) + (uint32_t)((j * gp.ny + iy) * nzp);
+          V16<float> q;
+          q.c[0] = mk<float>(out[m].c[0].x * ra, out[m].c[0].y * ra);
+          q.c[1] = mk<float>(out[m].c[1].x * rb2, out[m].c[1].y * rb2);
+          if (FIX != 0 && kz == 0) row[sl + 1] = q.c[1];
+          else v16_store<float>(row + sl, q);
+        }
+      }
+    }
+#else
+    for (int m = 0; m < R; ++m) out[m] = load(C0, cl, j, m * L);      // (the emulator has no lanes: the same values row by row)
+#endif
+  }
 #ifndef RF_SRC2_PRELOAD
 #define RF_SRC2_PRELOAD 1
 #endif
@@ -645,6 +735,8 @@ struct FastGenColIO64 {
 
 // Does the IO split its load into an early memory part and a late arithmetic part (preload() / load_pre())?  Only the deviate-reading
 // generation pass does: its loads are issued at the very top of the kernel, in front of the table staging and its barrier.
+template <class IO, class = void> struct io_sigma_share { static constexpr bool value = false; };
+template <class IO> struct io_sigma_share<IO, typename std::enable_if<IO::SIGMA_SHARE>::type> { static constexpr bool value = true; };
 template <class IO, class = void> struct io_has_load_pair { static constexpr bool value = false; };
 template <class IO> struct io_has_load_pair<IO, typename std::enable_if<IO::HAS_LOAD_PAIR>::type> { static constexpr bool value = true; };
 template <class IO, class = void> struct io_has_preload { static constexpr bool value = false; };
@@ -738,13 +830,29 @@ struct ColFFT {
     const long long C0 = tile * C::TC;                       // workgroup-uniform
     const int cl = lp * CPL;
     const long long Ccol = C0 + cl;
+    // sigma shared between the rows +-ix (IO::load_rows): one iteration covers all L butterflies, whole waves, an even radix
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr bool SHARE = io_sigma_share<IO>::value && C::IT1 == 1 && BPI == L && R % 2 == 0 && 64 % LPR == 0 && 64 / LPR >= 2 &&
+                           C::NT % 64 == 0 && CPL == 2 && !PRELOAD;
+#else
+    constexpr bool SHARE = false;
+#endif
 #pragma unroll
     for (int it = 0; it < C::IT1; ++it) {
-      const int j = it * BPI + jl;
+      int j = it * BPI + jl;
+      if constexpr (SHARE) j = io.share_row(jl, L, 64 / LPR);
       if (j < L) {
         cx v[CPL][R];
         constexpr bool PRE = (IO::FIX_MODE == 3);
-        if (IO::ROLLED_LOAD && C::NPASS > 1) {
+        if constexpr (SHARE) {
+          V rows[R];
+          io.template load_rows<R>(C0, cl, j, L, tid & 63, rows);
+#pragma unroll
+          for (int m = 0; m < R; ++m) {
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) v[c][m] = rows[m].c[c];
+          }
+        } else if (IO::ROLLED_LOAD && C::NPASS > 1) {
 #pragma unroll 1
           for (int m = 0; m < R; ++m) *lds_at(lds, j * R + m, lp) = io.load(C0, cl, j, m * L);
 #pragma unroll
