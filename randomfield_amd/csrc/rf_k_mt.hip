@@ -174,108 +174,130 @@ __global__ __launch_bounds__(MT_JUMP_THREADS) void mt_jump_kernel(const uint32_t
   }
 }
 
-// One WAVE per segment (4 segments per 256-thread workgroup), no workgroup barriers: the 624-word state lives in the
-// wave's own LDS window and is regenerated IN PLACE in 64-lane chunks -- word i needs the old words i, i+1 and either
-// the old word i+397 (i < 227) or the new word i-227, which an earlier chunk has already written (LDS operations of
-// one wave execute in order; `volatile` keeps the compiler from reordering them).
-// The segment generates its outputs ONCE: it writes (f x2, f x1) of its accepted attempts densely from slot seg * cap of the
-// scratch array `runs` (cap = attempts per segment, so a run always fits) and leaves their number in counts[seg]; the scan
-// of the counts tells later stages which cells a run holds (mt_compact_kernel moves float64 runs into cell order, the
-// generation pass reads float32 runs in place).  Round 1 generated every block twice: a count pass, then a fill pass.
-// F32: the pair is written as two float32 -- for float32 plans, whose cells sigma * g are float32 anyway.
-// The accept / reject arithmetic stays in float64 (it decides WHICH cell a deviate belongs to); only
-// f = sqrt(-2 log(r2) / r2) is evaluated in float32 (hardware log2 / rcp / sqrt, 1 ulp each), with the rounding of r2 to
-// float32 compensated to first order so that the relative error stays at the 1e-7 level where log(r2) -> 0.
+// One WAVE per segment (4 segments per 256-thread workgroup), no workgroup barriers.  The segment generates its outputs ONCE: it
+// writes (f x2, f x1) of its accepted attempts densely from slot seg * cap of the scratch array `runs` (cap = attempts per segment,
+// so a run always fits) and leaves their number in counts[seg]; the scan of the counts tells later stages which cells a run holds
+// (mt_compact_kernel moves float64 runs into cell order, the generation pass reads float32 runs in place).  Round 1 generated
+// every block twice: a count pass, then a fill pass.
+//
+// Round 5: TWO blocks per round.  The 624-word state ping-pongs between two windows of the wave's LDS (P <- Q, then Q <- P, in 64-lane
+// chunks: word i needs the old words i, i + 1 and either the old word i + 397 (i < 227) or the new word i - 227, which an earlier
+// chunk has written -- LDS operations of one wave execute in order, `volatile` keeps the compiler from reordering them), and the
+// 2 x 156 polar attempts of the pair are dealt to the lanes together: five wave iterations at 97.5 % of the lanes instead of
+// 2 x three at 81 %.
+//
+// F32: the pair is written as two float32 -- for float32 plans, whose cells sigma * g are float32 anyway.  What decides WHICH cell a
+// deviate belongs to (accept / reject) is never left to a float32 rounding:
+//   fast path, every lane: x = (2a + 1 - 2^27) 2^-27 from the first word of each uniform (the second word's contribution, uniform in
+//     +-2^-27, has zero mean and lies below the float32 rounding of x for |x| > 1/16: dropping the always-positive b 2^-52 instead
+//     shifts every deviate by -2^-27, which adds up coherently at the field's origin: 6e-5 of the rms at 512^3), r2 = x1^2 + x2^2 to ~2e-7,
+//     f = sqrt(-2 ln r2 / r2) with the hardware log2 / rcp / sqrt.  Final for 2^-9 <= r2 <= 1 - 2^-8 (78 % of the attempts) and for
+//     r2 >= 1 + 1e-6 (rejected for certain).
+//   the bands r2 > 1 - 2^-8 (ln r2 -> 0 loses the relative accuracy of r2; acceptance uncertain within 1e-6 of 1) and r2 < 2^-9 (the
+//     5-sigma deviates: the left-out +-2^-27 would be more than 2.4e-7 of x), and every lane of the float64 form: numpy's own float64
+//     arithmetic -- x = a 2^-26 + (b 2^-52 - 1) in two fused multiply-adds (every step of numpy's (a 2^26 + b) / 2^53, 2u - 1 is exact
+//     in float64, so this is the same number), r2 with both products rounded as numpy's C code rounds them, 0 < r2 < 1.  One wave
+//     iteration in four holds such a lane and pays ~60 float64-rate instructions and two more temperings.
+//   (Round 5 replaced the float64 band path by compensated float32 arithmetic -- d = r2 - 1 from the exact squares of the 28-bit
+//   integers by TwoSum / fused-multiply-add residuals, log1p by its series, float64 only for |d| < 2^-11: no acceptance differed over
+//   4e7 modelled attempts, and the replay took exactly as long (3.74 - 3.78 against 3.73 - 3.77 ms per 1024^3, profiles/r05_ab/
+//   r05_d_mt_ab.log): the pass is bound by the latency chain of its in-order LDS regeneration, not by those instructions.  Removed.)
+#ifndef RF_MT_POLAR_PAIRS
+#define RF_MT_POLAR_PAIRS 1            // 0: one block per round (three wave iterations of 156 attempts), as in rounds 1 - 4
+#endif
+typedef __attribute__((address_space(3))) uint32_t mt_lds_u32;
+
+// the next 624 words: nw <- f(od) (od == nw: in place)
+__device__ __forceinline__ void mt_wave_regen(volatile mt_lds_u32* nw, volatile mt_lds_u32* od, int lane) {
+#pragma unroll
+  for (int k = 0; k < 10; ++k) {
+    const int i = 64 * k + lane;
+    if (i < MT_N) {
+      // word 623 follows the same rule with its neighbour wrapped to the (new) word 0: 623 - 227 = 396
+      const uint32_t third = i < MT_N - MT_M ? od[i + MT_M] : nw[i - (MT_N - MT_M)];
+      const uint32_t nxt = i + 1 == MT_N ? nw[0] : od[i + 1];
+      const uint32_t v = mt_f(od[i], nxt, third);
+      nw[i] = v;                                           // (in place: every lane has read before any lane writes -- lock step)
+    }
+  }
+}
+
+// one polar attempt from its four raw (untempered) words: accepted?  F32: (g0, g1) = (f x2, f x1); else (x1, x2, r2) for the float64 store
+template <bool F32>
+__device__ __forceinline__ bool mt_polar_attempt(const unsigned raw_x, const unsigned raw_y, const unsigned raw_z, const unsigned raw_w,
+                                                 float& g0, float& g1, double& x1, double& x2, double& r2) {
+  const uint32_t w0 = mt_temper(raw_x), w2 = mt_temper(raw_z);
+  bool acc = false, exact = true;
+  if (F32) {
+    const int S1 = (int)((w0 >> 4) | 1u) - (1 << 27), S2 = (int)((w2 >> 4) | 1u) - (1 << 27);
+    const float hi1 = (float)S1, hi2 = (float)S2;
+    const float x1f = hi1 * 0x1p-27f, x2f = hi2 * 0x1p-27f;
+    const float r2f = fmaf(x1f, x1f, x2f * x2f);
+    if (r2f <= 0.99609375f && r2f >= 0.001953125f) {                       // the fast path is final
+      exact = false;
+      acc = true;
+      const float inv = __builtin_amdgcn_rcpf(r2f);
+      const float f = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(r2f) * inv);      // -2 ln 2 log2 r2 / r2
+      g0 = f * x2f;
+      g1 = f * x1f;
+    } else if (r2f >= 1.000001f) {                                         // rejected for certain
+      exact = false;
+    }
+  }
+  if (exact) {
+    const uint32_t w1 = mt_temper(raw_y), w3 = mt_temper(raw_w);
+    x1 = fma((double)(w0 >> 5), 0x1p-26, fma((double)(w1 >> 6), 0x1p-52, -1.0));
+    x2 = fma((double)(w2 >> 5), 0x1p-26, fma((double)(w3 >> 6), 0x1p-52, -1.0));
+    r2 = sum_of_squares(x1, x2);                          // no FMA: numpy's C code rounds both products
+    acc = (r2 < 1.0) && (r2 != 0.0);
+    if (F32 && acc) {
+      // log(r2) = log(r2f) + (r2 - r2f) / r2f: the hardware log2 (1 ulp of its result, also where it -> 0) of the
+      // rounded argument, plus the first-order term of the rounding (exact difference in float64)
+      const float r2f = (float)r2, inv = __builtin_amdgcn_rcpf(r2f);
+      const float lg = fmaf(__builtin_amdgcn_logf(r2f), 0.69314718056f, (float)(r2 - (double)r2f) * inv);
+      const float f = __builtin_amdgcn_sqrtf(-2.0f * lg * inv);
+      g0 = f * (float)x2;
+      g1 = f * (float)x1;
+    }
+  }
+  return acc;
+}
+
 template <bool F32>
 __global__ __launch_bounds__(256) void mt_polar_kernel(const uint32_t* __restrict__ states, int blocks_per_segment,
                                                        long long total_blocks, int nseg, unsigned long long* __restrict__ counts,
                                                        double* __restrict__ runs, unsigned long long cap) {
-  __shared__ __attribute__((aligned(16))) uint32_t lds[4][MT_N + 16];
+  constexpr int NWIN = RF_MT_POLAR_PAIRS ? 2 : 1, WIN = MT_N + 16, NATT = MT_N / 4;
+  __shared__ __attribute__((aligned(16))) uint32_t lds[4][NWIN * WIN];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long long seg = (long long)blockIdx.x * 4 + wave;
   if (seg >= nseg) return;                                   // whole waves leave; nobody waits at a barrier
-  // an explicitly LDS-qualified pointer: a plain `volatile uint32_t*` is a GENERIC pointer to the compiler, and every
+  // explicitly LDS-qualified pointers: a plain `volatile uint32_t*` is a GENERIC pointer to the compiler, and every
   // access through it became a flat_load / flat_store (slow path into LDS, and ordered behind this wave's outstanding
   // global stores of deviates through the shared vmcnt counter) instead of ds_read / ds_write
-  typedef __attribute__((address_space(3))) uint32_t lds_u32;
-  volatile lds_u32* mt = (volatile lds_u32*)(&lds[wave][0]);
+  volatile mt_lds_u32* Q = (volatile mt_lds_u32*)(&lds[wave][0]);
+  volatile mt_lds_u32* P = (volatile mt_lds_u32*)(&lds[wave][(NWIN - 1) * WIN]);     // (one window: P == Q, regeneration in place)
   long long nb = total_blocks - seg * blocks_per_segment;
   if (nb > blocks_per_segment) nb = blocks_per_segment;
   const uint32_t* st = states + (size_t)seg * MT_N;
-  for (int i = lane; i < MT_N; i += 64) mt[i] = st[i];
+  for (int i = lane; i < MT_N; i += 64) Q[i] = st[i];
   unsigned long long running = (unsigned long long)seg * cap;      // slot of this segment's next accepted attempt
-  for (long long b = 0; b < nb; ++b) {
-    // regenerate: the outputs of this block are the tempered NEW words
-#pragma unroll
-    for (int k = 0; k < 10; ++k) {
-      const int i = 64 * k + lane;
-      if (i < MT_N) {
-        // word 623 follows the same rule with its neighbour wrapped to the (new) word 0: 623 - 227 = 396
-        const uint32_t third = i < MT_N - MT_M ? mt[i + MT_M] : mt[i - (MT_N - MT_M)];
-        const uint32_t nxt = mt[i + 1 == MT_N ? 0 : i + 1];
-        const uint32_t v = mt_f(mt[i], nxt, third);
-        mt[i] = v;                                           // every lane has read before any lane writes (lock step)
-      }
-    }
-    // polar method: attempt a uses outputs 4a .. 4a+3; 156 attempts per block, in lane order
-#pragma unroll
-    for (int it = 0; it < 3; ++it) {
-      const int a = 64 * it + lane;
+  typedef unsigned u4 __attribute__((ext_vector_type(4)));
+  // the attempts a = first + lane, first = 0, 64, ... < natt, of the windows [P (NATT attempts), then Q]: attempt a uses outputs 4a .. 4a+3
+  auto attempts = [&](int natt) {
+    for (int first = 0; first < natt; first += 64) {
+      const int a = first + lane;
       bool acc = false;
       double x1 = 0, x2 = 0, r2 = 0;
-      float g0 = 0, g1 = 0;                                    // F32: (f x2, f x1) of an accepted attempt
-      if (a < MT_N / 4) {
+      float g0 = 0, g1 = 0;
+      if (a < natt) {
         // the attempt's four words with ONE 16-byte LDS read (four 4-byte reads at a lane stride of 16 bytes are
-        // 4-way bank conflicts); the compiler barrier keeps it behind the volatile in-place regeneration above,
+        // 4-way bank conflicts); the compiler barrier keeps it behind the volatile regeneration above,
         // and the LDS operations of one wave execute in program order
         asm volatile("" ::: "memory");
-        typedef unsigned u4 __attribute__((ext_vector_type(4)));
-        const u4 raw = *reinterpret_cast<const u4*>(const_cast<const uint32_t*>(lds[wave]) + 4 * a);
-        const uint32_t w0 = mt_temper(raw.x), w2 = mt_temper(raw.z);
-        // numpy: u = (a 2^26 + b) / 2^53 with a = w >> 5, b = w' >> 6, then x = 2 u - 1.  Every step of that is exact in
-        // float64 (53-bit integers, powers of two, |x| < 1 with 52 fractional bits), so x = a 2^-26 + (b 2^-52 - 1) in
-        // two fused multiply-adds is the same number
-        bool exact = true;
-        if (F32) {
-          // float32 form, fast path.  x = (2 a + 1 - 2^27) 2^-27 + (b 2^-25 - 1) 2^-27: the second term is uniform in
-          // [-2^-27, 2^-27) -- below the float32 rounding of x wherever |x| > 1/16 -- and has ZERO MEAN, so it is left out: one
-          // conversion of an odd 28-bit integer, no bias (dropping the always-positive b 2^-52 instead shifts every deviate by
-          // -2^-27, and 10^8 of those add up coherently at the field's origin: 6e-5 of the rms at 512^3), and the second word of
-          // each uniform is not even tempered here.  r2 = x1^2 + x2^2 is then good to ~2e-7.  Whether the attempt is accepted
-          // (0 < r2 < 1 IN FLOAT64, numpy's rounding: it decides which cell every later deviate belongs to) is certain unless r2
-          // lies within 1e-6 of 1 or underflows; and f = sqrt(-2 ln r2 / r2) keeps the float32 accuracy of its inputs unless
-          // ln r2 -> 0.  Both exceptions are the band r2 > 1 - 2^-8 (0.3 % of the attempts): those lanes, and the ones with
-          // r2 < 2^-9, take the float64 path below, which costs the wave its ~60 float64-rate instructions and the other two
-          // temperings only in the iterations where some lane needs it (one in four) instead of always.
-          const float x1f = (float)((int)((w0 >> 4) | 1u) - (1 << 27)) * 0x1p-27f;
-          const float x2f = (float)((int)((w2 >> 4) | 1u) - (1 << 27)) * 0x1p-27f;
-          const float r2f = fmaf(x1f, x1f, x2f * x2f);
-          // (below r2 = 2^-9 -- the 5-sigma deviates -- the left-out +-2^-27 would be more than 2.4e-7 of x: float64 path too)
-          exact = !(r2f <= 0.99609375f && r2f >= 0.001953125f) && r2f < 1.000001f;      // (beyond 1 + 1e-6: rejected for certain)
-          if (!exact) {
-            acc = r2f < 1.0f;
-            const float inv = __builtin_amdgcn_rcpf(r2f);
-            const float f = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(r2f) * inv);      // -2 ln 2 log2 r2 / r2
-            g0 = f * x2f;
-            g1 = f * x1f;
-          }
-        }
-        if (exact) {
-          const uint32_t w1 = mt_temper(raw.y), w3 = mt_temper(raw.w);
-          x1 = fma((double)(w0 >> 5), 0x1p-26, fma((double)(w1 >> 6), 0x1p-52, -1.0));
-          x2 = fma((double)(w2 >> 5), 0x1p-26, fma((double)(w3 >> 6), 0x1p-52, -1.0));
-          r2 = sum_of_squares(x1, x2);                          // no FMA: numpy's C code rounds both products
-          acc = (r2 < 1.0) && (r2 != 0.0);
-          if (F32 && acc) {
-            // log(r2) = log(r2f) + (r2 - r2f) / r2f: the hardware log2 (1 ulp of its result, also where it -> 0) of the
-            // rounded argument, plus the first-order term of the rounding (exact difference in float64)
-            const float r2f = (float)r2, inv = __builtin_amdgcn_rcpf(r2f);
-            const float lg = fmaf(__builtin_amdgcn_logf(r2f), 0.69314718056f, (float)(r2 - (double)r2f) * inv);
-            const float f = __builtin_amdgcn_sqrtf(-2.0f * lg * inv);
-            g0 = f * (float)x2;
-            g1 = f * (float)x1;
-          }
-        }
+        const uint32_t* wbase = const_cast<const uint32_t*>(lds[wave]) + (a < NATT ? (NWIN - 1) * WIN + 4 * a : 4 * (a - NATT));
+        const u4 raw = *reinterpret_cast<const u4*>(wbase);
+        acc = mt_polar_attempt<F32>(raw.x, raw.y, raw.z, raw.w, g0, g1, x1, x2, r2);
       }
       const unsigned long long ball = __ballot(acc);
       if (acc) {
@@ -289,6 +311,22 @@ __global__ __launch_bounds__(256) void mt_polar_kernel(const uint32_t* __restric
         }
       }
       running += (unsigned long long)__popcll(ball);
+    }
+  };
+  long long b = 0;
+  if (RF_MT_POLAR_PAIRS) {
+    for (; b + 2 <= nb; b += 2) {
+      mt_wave_regen(P, Q, lane);                             // block b     : P <- f(Q)
+      mt_wave_regen(Q, P, lane);                             // block b + 1 : Q <- f(P)
+      attempts(2 * NATT);
+    }
+  }
+  for (; b < nb; ++b) {                                      // (the odd block of a segment; every block when pairs are off)
+    mt_wave_regen(P, NWIN == 2 ? Q : P, lane);
+    attempts(NATT);
+    if (NWIN == 2) {                                         // the state moves back to Q for whatever follows
+      asm volatile("" ::: "memory");
+      for (int i = lane; i < MT_N; i += 64) Q[i] = P[i];
     }
   }
   if (lane == 0) counts[seg] = running - (unsigned long long)seg * cap;
