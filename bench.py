@@ -389,7 +389,15 @@ def main_multi(args, rank, world, local_rank, shape, power, spacing):
                      "kernel_ms_rank0_unpipelined_step": {"x": round(float(kern[0]), 4), "y": round(float(kern[1]), 4),
                                                    "exchange+z": round(float(kern[2]), 4),
                                                    "allreduce": round(float(kern[3]), 4)},
-                     "xgmi_egress_bytes_per_gpu": xgmi_bytes},
+                     "xgmi_egress_bytes_per_gpu": xgmi_bytes,
+                     # the exchange's own roofline: xGMI is point to point, one link per peer.  AMD's 153.6 GB/s per link is the sum of
+                     # both directions (7 links = 1075 GB/s aggregate), i.e. 76.8 GB/s per link and direction; the other reading is kept
+                     # beside it.  `achieved` = what every link must have carried per direction if the step time were all exchange.
+                     "xgmi": ({"links_used": world - 1, "bytes_per_link_per_direction": xgmi_bytes / (world - 1),
+                               "min_exchange_ms_at_76.8_GBs_per_direction": round(xgmi_bytes / (world - 1) / 76.8e9 * 1e3, 3),
+                               "min_exchange_ms_at_153.6_GBs_per_direction": round(xgmi_bytes / (world - 1) / 153.6e9 * 1e3, 3),
+                               "GBs_per_link_per_direction_if_step_were_all_exchange": round(xgmi_bytes / (world - 1) / (wall / args.steps) / 1e9, 1)}
+                              if world > 1 and xgmi_bytes else None)},
         "roofline": {"bound": "hbm", "kernel": "whole pipeline (5 sweeps) over %d GPUs" % world,
                      "achieved": round(5 * sweep * args.steps / wall / 1e9, 1), "peak": HBM_PEAK_GBS * world,
                      "unit": "GB/s", "frac": round(5 * sweep * args.steps / wall / 1e9 / (HBM_PEAK_GBS * world), 4),

@@ -230,21 +230,6 @@ void drop_graphs(rf_plan* p) {
   p->graphs.clear();
 }
 
-// EXPERIMENT (round 5, tools/xpad_probe.py): RF_XPAD_CELLS = complex cells of padding behind every x plane of W, applied to the x pass's
-// row stride and the y pass's plane stride only -- the z pass still reads dense rows, so the FIELD IS WRONG; what it answers is what
-// the strided passes would gain from a plane pitch that is not a power of two before every consumer of the dense field is changed
-long long xpad_cells() {
-  static const long long v = [] { const char* e = getenv("RF_XPAD_CELLS"); return e ? atoll(e) : 0LL; }();
-  return v;
-}
-
-// EXPERIMENT (round 5): RF_RSEG_PAD_CELLS = complex cells of padding between two source segments of the receive buffer R (the gathering z
-// pass reads nranks * chunks segments per row, each a power-of-two number of bytes after the previous one)
-long long rseg_pad_cells() {
-  static const long long v = [] { const char* e = getenv("RF_RSEG_PAD_CELLS"); return e ? atoll(e) : 0LL; }();
-  return v;
-}
-
 int ensure_k(rf_plan* p) {
   if (!p->K) RF_HIP(hipMalloc(&p->K, p->k_bytes));
   return 0;
@@ -435,7 +420,7 @@ int queue_x(rf_plan* p, const GenParams& gp, const void* kspace, void* W, hipStr
   // nx / rb contiguous chunks of rb * TC cells there
   const ColGeom gx = (W == p->X && W != nullptr)
                          ? xblock_x_geom(p->nx, p->ny, nzl, col_gen_tile_cols(p->f64, p->nx), xpose_row_block(p))
-                         : ColGeom{(long long)p->ny * nzl, 0, (long long)p->ny * nzl + xpad_cells()};
+                         : ColGeom{(long long)p->ny * nzl, 0, (long long)p->ny * nzl};
   if (timed) { RF_HIP(hipEventRecord(p->ev[5], sx)); p->repair_timed = fast; }   // overwritten by the launcher if it splits
   FastGenParams fgp = make_fast(p, gp.seed, gp.seed_dev != nullptr, gp.seed_dev);
   if (fast_noise && p->noise32_resident) {
@@ -488,7 +473,7 @@ int queue_z_slab(rf_plan* p, const void* R, void* W, double* stats_out, hipStrea
   const long long nrows = (long long)p->nxl * p->ny;
   const double scale = 1.0 / ((double)p->nx * (double)p->ny * (double)p->nz);
   const long long nzseg = p->nzl / slab_chunks(p);            // planes per received segment: nranks * chunks of them make a row
-  RF_HIP(launch_row_c2r_gather(p->f64, p->nzc, R, W, nrows, scale, (int)nzseg, nrows * nzseg + rseg_pad_cells(), p->tw_z, p->partials, s));
+  RF_HIP(launch_row_c2r_gather(p->f64, p->nzc, R, W, nrows, scale, (int)nzseg, nrows * nzseg, p->tw_z, p->partials, s));
   RF_HIP(launch_reduce_partials(p->partials, p->npartials, stats_out, p->partials + 2 * p->npartials, s));
   p->cur = W;
   p->real_valid = true;
@@ -653,12 +638,12 @@ int queue_yz(rf_plan* p, void* W, hipStream_t s, double* stats_out, bool timed) 
   const double scale = 1.0 / ((double)p->nx * (double)p->ny * (double)p->nz);
   const bool xp = p->X && xpose_ok(p);
   const long long rb = xpose_row_block(p), tc = col_tile_cols(p->f64, p->ny);
-  const ColGeom gy = xp ? xblock_y_geom(p->nx, p->ny, nzl, tc, rb) : ColGeom{nzl, (long long)p->ny * nzl + xpad_cells(), nzl};
+  const ColGeom gy = xp ? xblock_y_geom(p->nx, p->ny, nzl, tc, rb) : ColGeom{nzl, (long long)p->ny * nzl, nzl};
   long long B = yz_slab_planes(p);
   if (xp && B > 0 && (B % rb || (B & (B - 1)) || p->nx % B)) B = 0;      // a slab of X is whole x blocks, a power of two of them
   if (B <= 0) B = p->nx;
   const int nslab = (int)((p->nx + B - 1) / B);
-  const long long plane = ((long long)p->ny * nzl + xpad_cells()) * (long long)p->csize, tiles_per_plane = p->npartials / p->nx;
+  const long long plane = (long long)p->ny * nzl * (long long)p->csize, tiles_per_plane = p->npartials / p->nx;
   if (timed) {
     while ((int)p->slab_ev.size() < 2 * nslab) { hipEvent_t e; RF_HIP(hipEventCreate(&e)); p->slab_ev.push_back(e); }
     p->slab_timed = nslab;
@@ -925,7 +910,7 @@ int rf_plan_create(rf_plan** out, int nx, int ny, int nz, int dtype, int device,
   if ((e = hipStreamCreateWithFlags(&p->own_stream, hipStreamNonBlocking)) != hipSuccess)
     return cleanup(fail(2, std::string("hipStreamCreate: ") + hipGetErrorString(e)));
   p->stream = p->own_stream;
-  if ((e = hipMalloc(&p->W, p->w_bytes + (size_t)xpad_cells() * (size_t)nx * p->csize)) != hipSuccess || (nranks > 1 && (e = hipMalloc(&p->R, p->w_bytes + (size_t)rseg_pad_cells() * 1024 * p->csize)) != hipSuccess))
+  if ((e = hipMalloc(&p->W, p->w_bytes)) != hipSuccess || (nranks > 1 && (e = hipMalloc(&p->R, p->w_bytes)) != hipSuccess))
     return cleanup(fail(2, std::string("hipMalloc field buffer: ") + hipGetErrorString(e)));
   int rc = 0;
   if (dtype) {

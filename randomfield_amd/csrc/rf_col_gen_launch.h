@@ -55,6 +55,26 @@ hipError_t launch_pair(const IOA& ioa, const IOB& iob, long long ncols, const cp
   return hipGetLastError();
 }
 
+// pairs of adjacent tiles, whole-line stores (rf_kernels.h colpair_kernel): runs pairs b * pair_mul + pair_add, b in [0, npairs)
+#ifndef RF_X_PAIRS
+#define RF_X_PAIRS 1                   // the float32 generation pass of length 1024 (native generator or replayed deviates, whole grid or kz slab) on tile pairs
+#endif
+template <class C, class IO>
+hipError_t launch_onepair(const IO& io_in, long long ncols, const cplx<typename C::T>* tw, hipStream_t s, bool prepare_only,
+                          long long npairs, long long pair_mul = 1, long long pair_add = 0, int skip_period = 0) {
+  if (ncols % (2 * C::TC) || io_in.g.inner <= 0 || (io_in.g.inner & (io_in.g.inner - 1))) return hipErrorInvalidValue;
+  if (!prepare_only && (!io_in.g.rows_ok(C::N / C::RL, C::NPASS) || io_in.g.sub_shift > 0 || io_in.g.inner % (2 * C::TC))) return hipErrorInvalidValue;
+  const IO& io = io_in;
+  auto k = colpair_kernel<C, +1, IO>;
+  constexpr int lds_bytes = C::LDS_BYTES + IO::LDS_EXTRA;
+  static LdsAttrLatch latch;
+  if (hipError_t e = latch.ensure((const void*)k, lds_bytes); e != hipSuccess) return e;
+  if (prepare_only) return hipSuccess;
+  if (npairs <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k, dim3((unsigned)npairs), dim3(C::NT), lds_bytes, s, io, tw, npairs, pair_mul, pair_add, skip_period);
+  return hipGetLastError();
+}
+
 // the same through col2_kernel: a pass of length 2 C1::N as two C1 transforms per tile (rf_fft.h Col2); tw2 = the 2 C1::N-point table
 template <class C1, class IO>
 hipError_t launch_one2(const IO& io_in, long long ncols, const cplx<typename C1::T>* tw2, hipStream_t s, bool prepare_only,
@@ -137,15 +157,26 @@ hipError_t launch_fast_one(const FastGenParams& gp, CT* W, ColGeom g, long long 
   using IOF = typename IO1::fill_io;
   IOC ioc; ioc.base = base; ioc.g = g; ioc.gp = gp; ioc.kz0 = kz0; ioc.nzl = nzl; ioc.rec = nullptr; ioc.x0 = x0; ioc.x1 = x1; ioc.pot = pot;
   if constexpr (side) ioc.fixbuf = fixbuf;
+  // tile pairs with whole-line stores (ColPair): the 1024-point float32 pass, every tile of a kz row in a pair of its own row
+  constexpr bool pairs = RF_X_PAIRS && side && C::N == 1024 && sizeof(CT) == 8 && C::NPASS == 3 && (io_noise_src<IO0>::value == 0 || io_noise_src<IO0>::value == 2);
+  const bool use_pairs = pairs && split && x0 <= 0 && x1 >= C::N && tiles_per_iy % 2 == 0 && g.inner % (2 * C::TC) == 0 && g.sub_shift == 0 && RF_FIX_MERGED == 0;
   if (po) {
     hipError_t e = launch_one<C, IO0>(io0, ncols, tw, s, true);
+    if constexpr (pairs) {
+      if (e == hipSuccess) e = launch_onepair<C, IO0>(io0, ncols, tw, s, true, 0);
+      if (e == hipSuccess) e = launch_onepair<C, IOC>(ioc, ncols, tw, s, true, 0);
+    }
     if (e == hipSuccess && side) e = launch_one<C, IOC>(ioc, ncols, tw, s, true);
     if constexpr (side && (RF_FIX_MERGED == 3 || (RF_FIX_MERGED == 0 && RF_SRC2_PAIR_LAUNCH && io_noise_src<IO0>::value == 2)))
       if (e == hipSuccess) e = launch_pair<C, IOC, IO0>(ioc, io0, ncols, tw, s, true, 8, 1, 8, 2);
     return e != hipSuccess ? e : launch_one<C, IO1>(io1, ncols, tw, s, true);
   }
   if (!split) return launch_one<C, IO1>(io1, ncols, tw, s, false);
-  if (kz0 != 0) return launch_one<C, IO0>(io0, ncols, tw, s, false);   // only the slab that owns kz = 0 needs the repair
+  if (kz0 != 0) {                                                       // only the slab that owns kz = 0 needs the repair
+    if constexpr (pairs)
+      if (use_pairs && ntiles / 2 < (1LL << 31)) return launch_onepair<C, IO0>(io0, ncols, tw, s, false, ntiles / 2);
+    return launch_one<C, IO0>(io0, ncols, tw, s, false);
+  }
   // first the (few) tiles that hold slot kz = 0, with the repair; then every other tile without it
   hipError_t e = hipSuccess;
   if constexpr (side) {
@@ -170,6 +201,18 @@ hipError_t launch_fast_one(const FastGenParams& gp, CT* W, ColGeom g, long long 
     if (e == hipSuccess && na % 8 == 0 && tiles_per_iy >= 2 && tiles_per_iy < (1LL << 30) && ntiles < (1LL << 31) && na + nb < (1LL << 31)) {
       if (after_repair && (e = hipEventRecord(after_repair, s)) != hipSuccess) return e;       // (behind the side-buffer fill)
       return launch_pair<C, IOC, IO0>(ioc, io0, ncols, tw, s, false, na, tiles_per_iy, nb, (int)tiles_per_iy);
+    }
+  }
+  if constexpr (pairs) {
+    if (use_pairs) {
+      // the pair that holds the kz = 0 tile of every ky row (repair from the side buffer: only that tile's owning lanes take it), then all others
+      const long long ppi = tiles_per_iy / 2, npairs = ntiles / 2;
+      if (ppi >= (1LL << 30) || npairs >= (1LL << 31)) return hipErrorInvalidValue;
+      if (e == hipSuccess) e = launch_onepair<C, IOC>(ioc, ncols, tw, s, false, ncols / nzl, ppi, 0);
+      if (e != hipSuccess) return e;
+      if (after_repair && (e = hipEventRecord(after_repair, s)) != hipSuccess) return e;
+      if (ppi < 2) return hipSuccess;                    // (two tiles per ky row: the repair launch has covered everything)
+      return launch_onepair<C, IO0>(io0, ncols, tw, s, false, npairs - npairs / ppi, 1, 0, (int)ppi);
     }
   }
   if (e == hipSuccess) e = launch_one<C, IOC>(ioc, ncols, tw, s, false, ncols / nzl, tiles_per_iy, 0);

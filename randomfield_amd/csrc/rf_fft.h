@@ -824,6 +824,8 @@ struct ColFFT {
     pass_first(tid, tile, io, lds, none, false);
   }
   // pass 1: global -> R1 butterfly -> LDS (or straight back to global when N == R1)
+  // (FIXOK = false: the caller knows that this tile holds no kz = 0 slot -- the second tile of a ColPair -- and the repair code is left out)
+  template <bool FIXOK = true>
   RF_HD static void pass_first(int tid, long long tile, const IO& io, cx* lds, const PreRegs& pre, bool have_pre) {
     constexpr int R = C::R1, L = N / R;
     const int lp = tid % LPR, jl = tid / LPR;
@@ -843,7 +845,7 @@ struct ColFFT {
       if constexpr (SHARE) j = io.share_row(jl, L, 64 / LPR);
       if (j < L) {
         cx v[CPL][R];
-        constexpr bool PRE = (IO::FIX_MODE == 3);
+        constexpr bool PRE = (IO::FIX_MODE == 3) && FIXOK;
         if constexpr (SHARE) {
           V rows[R];
           io.template load_rows<R>(C0, cl, j, L, tid & 63, rows);
@@ -890,7 +892,7 @@ struct ColFFT {
 #pragma unroll
             for (int m = 0; m < R; ++m) v[0][m] = io.fix_value(Ccol, j, m * L);
           }
-        } else if (IO::FIX_MODE != 0 && io.needs_fix(Ccol)) {
+        } else if (FIXOK && IO::FIX_MODE != 0 && io.needs_fix(Ccol)) {
           if (C::NPASS == 1) {
 #pragma unroll
             for (int m = 0; m < R; ++m) v[0][m] = io.fix_value(Ccol, j, m * L);
@@ -1103,6 +1105,54 @@ struct Col2 {
 #if defined(__HIP_DEVICE_COMPILE__)
           __builtin_amdgcn_sched_barrier(0);       // one row pair at a time: hoisting all sixteen results in front of the stores spills
 #endif
+        }
+      }
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------
+// ColPair: TWO adjacent tiles per workgroup, one after the other, so that every 128-byte line of the output is written whole.  An
+// 8-column float32 tile row is 64 bytes -- half a line -- and the x pass's rows are a whole x plane (4 MiB) apart: a write-only sweep of
+// such half lines runs at 3.4 TB/s on MI355X where whole lines reach 5.35 TB/s, and two half-line writes to one line merge only
+// when they come from the same lane back to back.  So phase 0 transforms tile 2p and PARKS the last pass's
+// outputs (R V16 per thread: 32 registers) instead of storing them, phase 1 transforms tile 2p + 1, and its last pass stores, row by
+// row, the parked 16 bytes of tile 2p and its own 16 bytes of tile 2p + 1 -- 64 bytes apart in the same line -- from the same lane,
+// one after the other.  Same arithmetic per tile as ColFFT: the field is bit for bit the single-tile kernel's.  (Round 2 had this
+// form at 128 registers + spills and dropped it; with sigma shared between the rows +-ix the generation kernel needs 82.)
+// ---------------------------------------------------------------------------
+template <class C, int DIR, class IO>
+struct ColPair {
+  using F = ColFFT<C, DIR, IO>;
+  using T = typename C::T;
+  using cx = cplx<T>;
+  using V = V16<T>;
+  static constexpr int N = C::N, R = C::RL, L = N / R, CPL = C::CPL, LPR = C::LPR, BPI = C::BPI;
+  static_assert(C::NPASS >= 2, "ColPair parks the outputs of a last pass through LDS");
+  struct Park { V out[C::ITL][R]; };
+  RF_HD static void last_park(int tid, const cx* tw, cx* lds, Park& pk) {
+    const int lp = tid % LPR, jl = tid / LPR;
+#pragma unroll
+    for (int it = 0; it < C::ITL; ++it) {
+      const int j = it * BPI + jl;
+      if (j < L) F::last_butterfly(j, lp, tw, lds, pk.out[it]);
+    }
+  }
+  // phase 1, last pass: row by row the parked vector of tile `tile_a` and this phase's vector of tile tile_a + 1
+  RF_HD static void last_store(int tid, long long tile_a, const IO& io, const cx* tw, cx* lds, const Park& pk) {
+    const int lp = tid % LPR, jl = tid / LPR;
+    const long long C0a = tile_a * C::TC, C0b = C0a + C::TC;
+    const int cl = lp * CPL;
+#pragma unroll
+    for (int it = 0; it < C::ITL; ++it) {
+      const int j = it * BPI + jl;
+      if (j < L) {
+        V b[R];
+        F::last_butterfly(j, lp, tw, lds, b);
+#pragma unroll
+        for (int m = 0; m < R; ++m) {
+          io.store(C0a, cl, j, m * L, pk.out[it][m]);
+          io.store(C0b, cl, j, m * L, b[m]);
         }
       }
     }

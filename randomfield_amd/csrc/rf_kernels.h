@@ -187,6 +187,71 @@ __global__ __launch_bounds__(C1::NT, (IO::FIX_MODE != 0 ? 2 : col_min_waves<C1, 
   col2_body<C1, DIR, IO>(io, tw2, tile, rf_smem);
 }
 
+// two adjacent tiles per workgroup, whole-line stores (rf_fft.h ColPair): pair p = tiles 2p and 2p + 1
+// one phase of a pair: the passes of tile 2 pair + PHASE up to its last butterfly; phase 0 parks, phase 1 stores both tiles
+template <class C, int DIR, class IO, int PHASE>
+__device__ __forceinline__ void colpair_phase(IO& io, const cplx<typename C::T>* ltw, long long pair, cplx<typename C::T>* lds,
+                                              typename ColFFT<C, DIR, IO>::TwRegs& twr, typename ColPair<C, DIR, IO>::Park& pk) {
+  using X = ColPair<C, DIR, IO>;
+  using F = typename X::F;
+  const int tid = threadIdx.x;
+  const long long tile = 2 * pair + PHASE;
+  if (PHASE == 1) __syncthreads();                   // the tile in LDS is free again
+  // (the two phases run the same passes on the same LDS addresses: an opaque copy of the thread index per phase keeps the optimiser
+  // from carrying the first phase's addresses and twiddles through the second next to the parked registers -- see col2_body)
+  unsigned tu = (unsigned)tid;
+  asm volatile("" : "+v"(tu));
+  const int t = (int)tu;
+  // (the second tile of a pair has an odd index: it never holds the slot kz = 0, so its pass is built without the repair)
+  typename F::PreRegs pre;
+  if constexpr (F::PRELOAD) F::preload(t, tile, io, pre);
+  F::template pass_first<PHASE == 0>(t, tile, io, lds, pre, F::PRELOAD);
+  if (PHASE == 0) F::tw_stage(tid, lds, twr);
+  if (C::NPASS == 3) {
+    typename F::Regs r;
+    __syncthreads();
+    F::pass_mid_read(t, ltw, lds, r);
+    __syncthreads();
+    F::pass_mid_write(t, lds, r);
+  }
+  __syncthreads();
+  if (PHASE == 0) X::last_park(t, ltw, lds, pk);
+  else X::last_store(t, 2 * pair, io, ltw, lds, pk);
+}
+
+template <class C, int DIR, class IO>
+__device__ __forceinline__ void colpair_body(IO& io, const cplx<typename C::T>* __restrict__ tw, long long pair, char* rf_smem) {
+  using X = ColPair<C, DIR, IO>;
+  using F = typename X::F;
+  using cx = cplx<typename C::T>;
+  cx* lds = reinterpret_cast<cx*>(rf_smem);
+  const int tid = threadIdx.x;
+  io.bind_seed();
+  typename F::TwRegs twr;
+  typename X::Park pk;
+  if (IO::LDS_EXTRA > 0) {
+    io.prologue(tid, C::NT, F::lds_io(lds));
+    __syncthreads();
+  }
+  F::tw_fetch(tid, tw, twr);
+  const cx* ltw = F::lds_tw(lds);
+  colpair_phase<C, DIR, IO, 0>(io, ltw, pair, lds, twr, pk);
+  colpair_phase<C, DIR, IO, 1>(io, ltw, pair, lds, twr, pk);
+}
+
+// pairs b * pair_mul + pair_add, b in [0, npairs); skip_period > 0: all pairs except those = 0 mod skip_period
+template <class C, int DIR, class IO>
+__global__ __launch_bounds__(C::NT, (col_min_waves<C, IO>())) void colpair_kernel(IO io, const cplx<typename C::T>* __restrict__ tw,
+                                                                               long long npairs, long long pair_mul, long long pair_add, int skip_period) {
+  extern __shared__ __attribute__((aligned(16))) char rf_smem[];
+  long long pair = xcd_tile(blockIdx.x, npairs) * pair_mul + pair_add;
+  if (skip_period > 0) {
+    const unsigned t = (unsigned)pair;
+    pair = (long long)(t + t / (unsigned)(skip_period - 1) + 1u);
+  }
+  colpair_body<C, DIR, IO>(io, tw, pair, rf_smem);
+}
+
 // EXPERIMENT (RF_Z_XLANE = 1): the exchange between the middle and the last radix-8 stage of the z pass
 // through the wave's cross-lane network instead of the LDS row image.  With M / 8 = 64 a wave owns a row in both stages: stage-2
 // thread j = 8a + b leaves elements i = 64a + b + 8m (m = 0..7), stage-3 thread j' = b + 8p wants i = j' + 64m' -- element p of
