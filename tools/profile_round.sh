@@ -1,11 +1,14 @@
 #!/bin/bash
-# usage (on the GPU box, from the repo root): bash tools/profile_round.sh <tag>
+# usage (on the GPU box, from the repo root): bash tools/profile_round.sh <tag> [main|cfg|all]
 # bench line + rocprofv3 kernel stats + the two PMC passes (separate runs) + SQ counters -> gpurun_out/prof_<tag>/
+# (main = the bench command's passes, cfg = the per-configuration sets: two gpurun calls fit the call's time limit comfortably)
 set -e
 tag=${1:-x}
+part=${2:-all}
 out=gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
+if [ "$part" != "cfg" ]; then
 python3 bench.py --steps 20 --warmup 5 > $out/bench.json
 rocprofv3 --kernel-trace --stats -d $out/stats -o stats --output-format csv -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs > $out/bench_stats_run.json
 rocprofv3 --pmc FETCH_SIZE -d $out/fetch -o fetch --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs > /dev/null
@@ -20,6 +23,8 @@ nslab=$(python3 -c "import json;print(json.load(open('$out/bench.json'))['pipeli
 python3 tools/make_traffic.py $(find $out/fetch -name "*counter_collection.csv") $(find $out/write -name "*counter_collection.csv") $out/traffic.json "$tag" $nslab > $out/traffic.txt
 cp $(find $out/stats -name "*kernel_stats.csv") $out/kernel_stats.csv
 rm -rf $out/fetch $out/write $out/sqa $out/sqb $out/stats
+fi
+if [ "$part" = "main" ]; then ls $out; exit 0; fi
 # every other BASELINE configuration / path: kernel stats, FETCH_SIZE / WRITE_SIZE and the SQ sets per configuration (tools/profile_cfg.sh)
 for c in ref refone 512 2048 f64 f64ln rank0 rank3; do
   bash tools/profile_cfg.sh $out $c $c 3
