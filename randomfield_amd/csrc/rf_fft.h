@@ -1550,14 +1550,40 @@ struct RowC2R {
 
   RF_HD static cx* lds_at(cx* lds, int rl, int i) { return lds + (long long)rl * C::RS + pad16(i); }
   RF_HD static cx* lds_tw(cx* lds) { return lds + C::TILE_BYTES / (int)sizeof(cx); }
-  // The twiddle table (needed by pass 1 already: the untangle) goes global -> registers (tw_fetch), then the row data
+  // The twiddles in LDS: NOT the plain table exp(2 pi i q / 2M) the kernel gets, but three tables cut from it, each in the order its
+  // pass reads it, 2M entries in all (round 5).  Read from the plain table, the middle pass's w_(R1 R2)^(c m) sit 16 m entries apart
+  // -- 128 m bytes: a 4- or 8-way bank conflict per read -- and the last pass's w_M^(m j) 2 m entries apart (2- to 8-way); on the
+  // z pass of 1024^3 float32 40 % of the LDS-array cycles were conflict cycles (SQ_LDS_BANK_CONFLICT 1.08e7 of SQ_LDS_IDX_ACTIVE
+  // 2.70e7 per launch, profiles/r05_a_pmc_sq_*), two thirds of them from these reads.
+  //   U [k]            = t_k = tw[k], k < M                       : the untangle (consecutive lanes, consecutive k)
+  //   LT[(m-1) LL + j] = tw[2 m j],   1 <= m < RL, j < LL = M / RL : the last pass (consecutive lanes, consecutive j)
+  //   MT[(m-1) R1 + c] = tw[2 m c M / (R1 R2)], 1 <= m < R2, c < R1 : the middle pass (lane j reads entry c = j mod R1: broadcast)
+  static constexpr int LL = M / C::RL;
+  static constexpr int TW_LT = M, TW_MT = M + (C::NPASS >= 2 ? (C::RL - 1) * LL : 0);
+  static constexpr int TW_END = TW_MT + (C::NPASS == 3 ? (C::R2 - 1) * C::R1 : 0);
+  static_assert(TW_END <= 2 * M, "the three tables fit the space of the plain one");
+#ifndef RF_Z_TW_TABLES
+#define RF_Z_TW_TABLES 1                               // 0: the plain table in LDS, as in rounds 1 - 4 (A/B builds)
+#endif
+  RF_HD static int tw_source(int e) {                  // entry e of the LDS image <- entry tw_source(e) of the plain table
+    if (!RF_Z_TW_TABLES) return e;
+    if (e < TW_LT) return e;
+    if (e < TW_MT) { const int r = e - TW_LT; return 2 * (r / LL + 1) * (r % LL); }
+    if (e < TW_END) { const int r = e - TW_MT; return 2 * (r / C::R1 + 1) * (r % C::R1) * (M / (C::R1 * cmax(C::R2, 1))); }
+    return 0;
+  }
+  RF_HD static cx tw_last(const cx* ltw, int m, int j) { return RF_Z_TW_TABLES ? ltw[TW_LT + (m - 1) * LL + j] : ltw[2 * m * j]; }
+  RF_HD static cx tw_mid(const cx* ltw, int m, int j) {
+    return RF_Z_TW_TABLES ? ltw[TW_MT + (m - 1) * C::R1 + (j % C::R1)] : ltw[2 * stockham_tw_index(j, m, C::R1, cmax(C::R2, 1), M)];
+  }
+  // The table (needed by pass 1 already: the untangle) goes global -> registers (tw_fetch), then the row data
   // (pass_first_load), then registers -> LDS (tw_stage) and a barrier: both trips to memory are in flight together, and the
   // older one -- the small table -- is the one that is waited for first (loads retire in order).
   static constexpr int TWPT = ceil_div(2 * M, NT);
   struct TwRegs { cx v[TWPT]; };
   RF_HD static void tw_fetch(int tid, const cx* tw, TwRegs& t) {
 #pragma unroll
-    for (int k = 0; k < TWPT; ++k) t.v[k] = tw[(tid + k * NT) & (2 * M - 1)];       // (M is a power of two: no branch, no undefined slot)
+    for (int k = 0; k < TWPT; ++k) t.v[k] = tw[tw_source((tid + k * NT) & (2 * M - 1))];       // (M is a power of two: no branch, no undefined slot)
   }
   RF_HD static void tw_stage(int tid, cx* lds, const TwRegs& t) {
     cx* l = lds_tw(lds);
@@ -1675,7 +1701,7 @@ struct RowC2R {
 #pragma unroll
         for (int m = 0; m < R; ++m) {
           cx x = (L % 8 == 0) ? rd[m * (L + L / 8)] : *lds_at(lds, rl, j + m * L);
-          if (m > 0) x = cmul(x, tw[2 * stockham_tw_index(j, m, Ns, R, M)]);
+          if (m > 0) x = cmul(x, tw_mid(tw, m, j));
           r.v[it][m] = x;
         }
         DFT<R, DIR>::run(r.v[it]);
@@ -1719,7 +1745,7 @@ struct RowC2R {
 #pragma unroll
         for (int m = 0; m < R; ++m) {
           cx x = (L % 8 == 0) ? rd[m * (L + L / 8)] : *lds_at(lds, rl, j + m * L);
-          if (m > 0) x = cmul(x, tw[2 * m * j]);
+          if (m > 0) x = cmul(x, tw_last(tw, m, j));
           v[m] = x;
         }
         DFT<R, DIR>::run(v);

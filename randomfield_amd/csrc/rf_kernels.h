@@ -316,7 +316,7 @@ __device__ __forceinline__ void row_c2r_body(IO& io, const cplx<typename C::T>* 
         xlane_transpose8(r.v[it], tid & 63);       // -> the inputs of stage-3 thread j
         cx v[8];
 #pragma unroll
-        for (int m = 0; m < 8; ++m) v[m] = m > 0 ? cmul(r.v[it][m], ltw[2 * m * j]) : r.v[it][0];
+        for (int m = 0; m < 8; ++m) v[m] = m > 0 ? cmul(r.v[it][m], F::tw_last(ltw, m, j)) : r.v[it][0];
         DFT<8, +1>::run(v);
         if (tile * C::NRT + rl < nrows) {
 #pragma unroll
