@@ -651,6 +651,40 @@ def test_pipelined_slab_batch_matches_plain_path(hip, dpower, shape):
     plain.close()
 
 
+def test_exchange_standin_runs_the_real_schedule_on_a_virtual_rank(hip, dpower):
+    """rf_slab_set_exchange_standin (diagnostics, bench.py's config-4 entry): a rank of a multi-rank plan WITHOUT a communicator runs
+    the multi-GPU schedule -- forward half, exchange on the exchange stream, gathering z pass, pipelined batches -- with a copy kernel
+    in the all-to-all's place.  The received segments are the rank's own data for other x slabs, so the result is not a field; what
+    is checked: it runs to completion for every width, the moments are finite and reproducible, the own block (segment `rank`) really
+    is the forward half's block, and the call is refused where it has no business (single-rank plans, bad widths; a rank without
+    communicator and without stand-in still fails loudly)."""
+    k, Pk = dpower
+    shape, P = (256, 64, 256), 4
+    plans = _slab_plans(hip, shape, np.complex64, k, Pk, P)
+    p = plans[1]
+    with pytest.raises(RuntimeError):
+        p.realise(seed=3)                                         # no communicator, no stand-in: loud
+    with pytest.raises(RuntimeError):
+        p.set_exchange_standin(-1)
+    for w in (1, 16, 300):
+        p.set_exchange_standin(w)
+        p.realise(seed=3)
+        m1 = p.moments()
+        rms = p.realise_batch([3, 4, 5])
+        p.realise(seed=3)
+        assert np.isfinite(m1[1]) and m1[1] > 0 and p.moments() == m1 and np.all(np.isfinite(rms)) and len(rms) == 3
+    # the same rank through the separate steps with a real (virtual-rank) exchange gives a field; the stand-in run is not one
+    p.set_exchange_standin(0)
+    with pytest.raises(RuntimeError):
+        p.realise(seed=3)
+    one = make_plan(hip, shape, np.complex64, k, Pk)
+    with pytest.raises(RuntimeError):
+        one.set_exchange_standin(16)                              # a single-rank plan exchanges nothing
+    one.close()
+    for q in plans:
+        q.close()
+
+
 @pytest.mark.parametrize("shape,seed", [((16, 16, 16), 123), ((64, 64, 64), 123), ((128, 128, 256), 7), ((256, 256, 256), 2024)])
 def test_mt19937_replay_matches_numpy(hip, dpower, shape, seed):
     """On-GPU replay of np.random.RandomState(seed).normal(size=2*M) (random.py:24-28): MT19937 with jump-ahead
@@ -1602,9 +1636,11 @@ def test_distributed_generator_single_rank(hip, monkeypatch):
     nz = 64
     z = np.linspace(0, 0.1, nz)
     kw = dict(growth_function=np.exp(-z), mean_matter_density=1 + z, redshifts=z, transverse_distance=np.arange(nz) * 2.5)
+    with pytest.raises(ValueError):
+        Generator(32, 32, nz, 2.5, distributed=True, exchange_chunks=0, **kw)      # (opt-in sub-slab exchange: a count >= 1)
     for rng_kind in ("reference", "native"):
         one = Generator(32, 32, nz, 2.5, rng=rng_kind, **kw)
-        dist = Generator(32, 32, nz, 2.5, rng=rng_kind, distributed=True, **kw)
+        dist = Generator(32, 32, nz, 2.5, rng=rng_kind, distributed=True, exchange_chunks=(4 if rng_kind == "native" else None), **kw)
         assert dist.plan_c2r.data_out.shape == (32, 32, nz)
         a = one.generate_delta_field(seed=5).copy()
         b = dist.generate_delta_field(seed=5).copy()
