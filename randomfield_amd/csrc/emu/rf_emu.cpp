@@ -536,7 +536,7 @@ int c2r_lognormal_impl(int nx, int ny, int nz, const cplx<T>* kspace, const doub
         if (C::NPASS == 3) { for (int t = 0; t < C::NT; ++t) F::pass_mid_read(t, ltw, lds.data(), regs[t]);                        \
                              for (int t = 0; t < C::NT; ++t) F::pass_mid_write(t, lds.data(), regs[t]); }                          \
         if (C::NPASS >= 2) for (int t = 0; t < C::NT; ++t) F::pass_last(t, tile, ios[t], ltw, lds.data());                          \
-        double a = 0; for (int t = 0; t < C::NT; ++t) a += ios[t].acc;                                                              \
+        double a = 0; for (int t = 0; t < C::NT; ++t) a += ios[t].weighted_sum();                                                              \
         S += a;                                                                                                                     \
       } break; }
       RF_COL_SIZES(X)

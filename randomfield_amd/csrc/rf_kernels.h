@@ -57,7 +57,7 @@ __device__ __forceinline__ void col_body(IO& io, const cplx<typename C::T>* __re
     F::pass_last(tid, tile, io, ltw, lds);
   }
   if constexpr (IO::HAS_FINISH) {            // (AccColIO: the workgroup's sum of w |Y|^2 -> partials[tile])
-    double a = io.acc;
+    double a = io.weighted_sum();
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off);
     __syncthreads();                         // the LDS tile is no longer read
