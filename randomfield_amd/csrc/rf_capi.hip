@@ -1,5 +1,6 @@
-// rf_capi.hip -- the C-ABI of include/randomfield_hip.h: plan object, device
-// buffers, stream/graph orchestration of the HIP kernels.
+// rf_capi.hip -- the C-ABI of include/randomfield_hip.h: plan object, device buffers, stream / graph orchestration of the HIP kernels
+// (plans, inputs, realisations, transforms, host <-> device, timing; the replay of numpy's stream: rf_capi_mt.hip; the communicator
+// and the slab pipeline step by step: rf_capi_slab.hip; shared helpers: rf_plan.h).
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 #include <cstdio>
@@ -11,14 +12,12 @@
 
 #include <rccl/rccl.h>
 
-#include "../../include/randomfield_hip.h"
-#include "../../include/randomfield_hip_diag.h"
-#include "rf_host.h"
-#include "rf_launch.h"
+#include "rf_plan.h"
 
 using namespace rf;
+using namespace rfc;
 
-namespace {
+namespace rfc {
 
 thread_local std::string g_err;
 
@@ -27,34 +26,6 @@ int fail(int code, const std::string& msg) {
   return code;
 }
 
-#define RF_HIP(expr)                                                                              \
-  do {                                                                                            \
-    hipError_t e_ = (expr);                                                                       \
-    if (e_ != hipSuccess)                                                                         \
-      return fail(2, std::string(#expr) + " failed: " + hipGetErrorString(e_) + " (" __FILE__ ":" + \
-                         std::to_string(__LINE__) + ")");                                         \
-  } while (0)
-
-#define RF_REQUIRE(cond, msg) \
-  do {                        \
-    if (!(cond)) return fail(1, msg); \
-  } while (0)
-
-// RCCL entry points, resolved lazily with dlopen so that single-GPU use never depends on librccl
-// being loadable (types and enums come from <rccl/rccl.h>, no link-time dependency).
-struct Rccl {
-  void* lib = nullptr;
-  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
-  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
-  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
-  ncclResult_t (*GroupStart)() = nullptr;
-  ncclResult_t (*GroupEnd)() = nullptr;
-  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
-  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
-  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
-  const char* (*GetErrorString)(ncclResult_t) = nullptr;
-};
 Rccl g_rccl;
 
 int load_rccl() {
@@ -85,142 +56,6 @@ int load_rccl() {
   return 0;
 }
 
-#define RF_NCCL(expr)                                                                                   \
-  do {                                                                                                  \
-    ncclResult_t r_ = (expr);                                                                           \
-    if (r_ != ncclSuccess)                                                                              \
-      return fail(5, std::string(#expr) + " failed: " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "?")); \
-  } while (0)
-
-}  // namespace
-
-struct rf_plan {
-  int nx = 0, ny = 0, nz = 0, nzc = 0, f64 = 0, device = 0, nranks = 1, rank = 0;
-  int nxl = 0, nzl = 0, kz0 = 0;          // this rank's x-slab height, kz-slab width and first kz plane
-  void* R = nullptr;                      // receive buffer of the all-to-all (slab-path plans only)
-  void *W2 = nullptr, *R2 = nullptr;      // second buffer pair of pipelined slab batches
-  hipStream_t comm_stream = nullptr;      // exchange stream of pipelined slab batches
-  hipEvent_t pev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // fwd[2], exch[2], z[2]
-  bool force_slab = false;                // single-rank plan routed through the slab pipeline (tests)
-  int standin_wg = 0;                     // rf_slab_set_exchange_standin: workgroups of the copy kernel that stands in for the all-to-all of a rank without a communicator
-  // RF_FLAG_EXCHANGE_CHUNKS: the rank's kz slab as `xchunks` sub-slabs of nzl / xchunks planes, each generated, x- and y-transformed
-  // and SENT on its own, so that the exchange of sub-slab c runs under the forward passes of sub-slab c + 1 (queue_c2r).  Layout:
-  // W = [chunk][nx][ny][nzl / xchunks]; R = [source rank][chunk][nxl][ny][nzl / xchunks], which is what the gathering z pass reads
-  // anyway with nranks * xchunks segments per row
-  int xchunks = 1;
-  std::vector<hipEvent_t> chunk_ev;       // forward half of chunk c queued (no timing)
-  bool replicate = false;                 // multi-rank plan without an exchange: every rank generates all of k space (see queue_x)
-  ncclComm_t comm = nullptr;
-  size_t csize = 8;                       // bytes per complex element
-  hipStream_t own_stream = nullptr, stream = nullptr;
-  void* W = nullptr;                      // [nx][ny][nz] real == [nx][ny][nz/2] complex (packed Nyquist)
-  void* K = nullptr;                      // lazy: API-layout k-space [nx][ny][nz/2+1]
-  // lazy: the x pass's TRANSPOSED intermediate [kz tile][ny][nx][tile width]: the x pass stores whole
-  // contiguous tiles there and the y pass goes X -> W out of place.  xposed = the plan may use it (RF_FLAG_TRANSPOSED_INTERMEDIATE).
-  void* X = nullptr;
-  bool xposed = false;
-  // y and z passes slab by slab of x planes: -1 = automatic (slabs of about the Infinity Cache's size),
-  // 0 = whole-grid passes, > 0 = this many x planes per slab (RF_FLAG_YZ_SLAB_PLANES)
-  int yz_slab = -1;
-  hipStream_t aux_stream = nullptr;       // rf_realise_batch_reference: the stream the MT19937 replays run on
-  hipEvent_t bev[2] = {nullptr, nullptr}; // ... replay finished / generation pass has read the runs
-  std::vector<hipEvent_t> slab_ev;        // timed runs: after y(i), after z(i)
-  int slab_timed = 0;                     // slabs of the last timed run (0: whole-grid passes, ev[2] / ev[3] apply)
-  int yz_merge = 1;                       // rf_set_merged_yz: 0 never, 1 untimed calls (default), 2 timed calls too (events per launch)
-  int slab_merged = 0;                    // slabs of the last timed run that used merged launches: slab_ev = after y(0), after every merged launch, after the last z
-  void* P = nullptr;                      // lazy: saved potential, API layout (= P_base + an offset chosen by ensure_p)
-  void* P_base = nullptr;                 // the allocation P lives in
-  size_t w_bytes = 0, k_bytes = 0, p_bytes = 0;      // field buffer, k-space side array, potential array (padded rows)
-  int ppitch = 0;                         // cells per row of the potential array: nzl + 1, rounded up to even on float32 plans
-  void *tw_x = nullptr, *tw_y = nullptr, *tw_z = nullptr;
-  double *kx2 = nullptr, *ky2 = nullptr, *kz2 = nullptr;
-  double *xt = nullptr, *st = nullptr, *sl = nullptr;
-  int* bin = nullptr;
-  int nt = 0, nbins = 0;
-  double x0 = 0, inv_dx = 0;
-  bool have_kgrid = false, have_power = false;
-  // fast float32 native generation: float copies of the k^2 tables + per-bin sigma records
-  FastRec* frec = nullptr;
-  int fnbins = 0;
-  float fdkx = 0, fdky = 0, fdkz = 0, fu_scale = 0, fu_off = 0;
-  bool have_fast = false, exact_gen = false;
-  std::vector<double> h_kx2, h_ky2, h_kz2;   // host copies (k range of the grid for the fast records)
-  SigmaTableHost h_tab;
-  double* noise = nullptr;
-  size_t noise_cap = 0;
-  bool noise_resident = false;            // the device noise buffer holds a full set of deviates
-  // float32 deviates (rf_noise_mt19937_ex(single = 1)) stay where the one-pass replay writes them: mt_scratch, every
-  // segment's accepted pairs from slot seg * seg_cap, located through mt_offsets (FastGenParams::seg_*).  Only one of
-  // the two forms (float64 in cell order / float32 in segment order) is valid at a time.
-  bool noise32_resident = false;
-  unsigned long long seg_cap = 0;
-  int nseg = 0;
-  void* mt_rowtab = nullptr;           // float32 form: where each row (ix, iy) of the stream starts in the runs (rf_core.h RowLoc, 8 B x nx ny)
-  int* mt_flags = nullptr;             // device word: bit 0 = a row spans more than two segments (mt_rowtab_kernel)
-  void* fixbuf = nullptr;              // nx * ny complex: the repaired kz = 0 slots of the fast generation pass (fix_fill_kernel)
-  // MT19937 replay (rf_noise_mt19937): jump-polynomial bit positions per tree level, scratch
-  uint32_t* mt_pos = nullptr;          // set-bit positions of the jump polynomials, widened to 32 bits (scalar loads)
-  std::vector<int> mt_npos;
-  int mt_stride = 0, mt_bps = 0, mt_radix = 2;   // positions per polynomial (padded), blocks of 624 words per segment, tree radix
-  int* mt_npos_dev = nullptr;
-  uint32_t* mt_states = nullptr;
-  unsigned long long *mt_counts = nullptr, *mt_offsets = nullptr;
-  size_t mt_states_cap = 0, mt_seg_cap = 0;
-  void* mt_scratch = nullptr;          // one-pass replay: every segment's accepted pairs, densely from slot seg * (attempts per segment)
-  size_t mt_scratch_bytes = 0;
-  // distributed replay (rf_mt_share_*): this rank replays segments [sh_first, sh_first + sh_nloc) of the one stream
-  void *mt_send = nullptr, *mt_recv = nullptr;   // pairs packed by destination rank / stream of this rank as received (float32 mode)
-  size_t mt_send_bytes = 0, mt_recv_bytes = 0;
-  long long* mt_sbase = nullptr;                 // device, [nranks]: see mt_share_pack_kernel
-  unsigned long long* mt_first = nullptr;        // device: first stream cell of every local segment
-  size_t mt_first_cap = 0;
-  int sh_state = 0;                              // 0 idle, 1 replayed (begin), 2 packed, 3 exchanged
-  int sh_single = 0, sh_first = 0, sh_nloc = 0;
-  unsigned long long sh_total = 0;
-  std::vector<unsigned long long> sh_sendoff, sh_sendcnt, sh_recvoff, sh_recvcnt;      // pairs, per peer
-  double* partials = nullptr;
-  long long npartials = 0;
-  double* stats = nullptr;                // [2 * stats_cap] (sum, sumsq) per realisation
-  int stats_cap = 0;
-  uint64_t* seeds_dev = nullptr;
-  int seeds_cap = 0;
-  // the caller's seed array may be a temporary: it is copied into one of two plan-owned pinned staging slots before
-  // the asynchronous upload (a slot is reused only after the upload that last read it has completed)
-  uint64_t* seeds_pin[2] = {nullptr, nullptr};
-  hipEvent_t seeds_ev[2] = {nullptr, nullptr};
-  int seeds_pin_cap = 0, seeds_turn = 0;
-  bool resident_fast = false;             // the current call draws from the device-resident deviates (RF_NOISE_RESIDENT)
-  bool emit_potential = false;            // the current call transforms emit_pscale * delta(k) / k^2 instead of delta(k) (rf_realise_scaled_potential)
-  double emit_pscale = 0.0;
-  const double* zscale = nullptr;         // the current call's z pass multiplies plane z by zscale[z] (device table: ztab)
-  void* pot_target = nullptr;             // non-null while rf_realise_potential queues its x pass: where delta(k)/k^2 goes
-  double* coll_scratch = nullptr;         // 2 doubles on the device for host-side all-reduces (never aliases `stats`)
-  void* br_tmp = nullptr;                 // rf_realise_batch_reference: [start states n x 624][accepted totals n][flags n], kept between calls
-  int br_cap = 0;                         // (allocating and freeing them cost a device synchronisation per call: one-seed batches are the Generator's call)
-  double* ztab = nullptr;                 // 2 * nz doubles for lognormal / affine tables
-  // fused lognormal realisations (rf_realise_lognormal): [growth nz][density nz][A nz][B nz][sigma 8] and the y pass's Parseval partials
-  double* lntab = nullptr;
-  double* ypart = nullptr;
-  long long nypart = 0;
-  bool ln_tables = false, ln_density = false;
-  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // start, after x, y, z, reduce; [5] = after the kz = 0 repair launch
-  bool repair_timed = false;
-  bool aux_valid = false;              // the k buffer's memory currently holds an auxiliary REAL field (lensing potential)
-  bool unpacked = false;               // c2c plan: W is the full [nx][ny][nz] complex array, only rf_*_c / rf_execute_c2c apply
-  // non-power-of-two grid (rf_generic.h): the transforms run on API-layout arrays, K -> G -> W; no fused generation,
-  // no graphs, one rank.  gax / gay factor nx / ny, gaz factors nz/2 (packed plans) or nz (c2c plans)
-  bool generic = false;
-  void* G = nullptr;                   // lazy scratch [nx][ny][nz/2+1] complex
-  GenericAxis gax, gay, gaz;
-  bool timed = false;
-  struct BatchGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };
-  std::map<int, BatchGraph> graphs;       // captured batch graphs, keyed by the number of realisations
-  bool real_valid = false, k_valid = false, stats_valid = false;
-  void* cur = nullptr;                    // buffer holding the current real-space field
-  int stats_slot = 0;                     // which (sum, sumsq) pair of `stats` belongs to the current field                    // x-planes per y/z slab (0 = whole grid in one launch pair)
-};
-
-namespace {
 
 void drop_graphs(rf_plan* p) {
   for (auto& kv : p->graphs) {
@@ -403,7 +238,7 @@ int slab_chunks(const rf_plan* p) {
 size_t chunk_bytes(const rf_plan* p) { return p->w_bytes / (size_t)slab_chunks(p); }
 
 // (kz0c, nzlc >= 0: a sub-slab of this rank's planes instead of all of them -- W then points at the sub-slab's own region)
-int queue_x(rf_plan* p, const GenParams& gp, const void* kspace, void* W, hipStream_t sx, bool timed = false, int kz0c = -1, int nzlc = -1) {
+int queue_x(rf_plan* p, const GenParams& gp, const void* kspace, void* W, hipStream_t sx, bool timed, int kz0c, int nzlc) {
   // resident deviates (the numpy stream replayed by rf_noise_mt19937) take the fast float32 sigma path too; host-supplied
   // deviates (RF_NOISE_EXTERNAL, the parity mode) keep the exact reference dtype chain
   // (float32 copies of the deviates exist for this path only, and it can store the potential too; float64 ones cannot)
@@ -841,7 +676,7 @@ int shape_check(int nx, int ny, int nz, int f64, std::string* why, int nranks = 
   return 0;
 }
 
-}  // namespace
+}  // namespace rfc
 
 extern "C" {
 
@@ -1213,7 +1048,8 @@ int rf_execute_c2r(rf_plan* p) {
   return queue_c2r(p, make_gen(p, 0, RF_NOISE_NATIVE, false), p->K);
 }
 
-namespace {
+}  // extern "C"
+namespace rfc {
 // multi-rank forward transform, x-slab half: z pass on the local rows, in place, then the rows cut into the P send blocks
 // [nxl][ny][nzl] of R (block g = the kz planes of rank g) -- the reverse of what the gathering z pass reads
 int queue_r2c_slab_rows(rf_plan* p, hipStream_t s) {
@@ -1238,7 +1074,8 @@ int queue_r2c_slab_cols(rf_plan* p, hipStream_t s) {
   p->aux_valid = false;
   return 0;
 }
-}  // namespace
+}  // namespace rfc
+extern "C" {
 
 int rf_execute_r2c(rf_plan* p) {
   RF_REQUIRE(p, "null plan");
@@ -1346,11 +1183,13 @@ int rf_realise_scaled_potential(rf_plan* p, uint64_t seed, int mode, double scal
   return 0;
 }
 
+}  // extern "C"
+namespace rfc {
 // generate_delta_field(save_potential=True) (generate.py:191-219): the field as rf_realise, plus delta(k) / k^2 in the
 // plan's potential buffer.  With the native generator (or resident float32 deviates) the potential is a second store
 // stream of the generation pass; every other case runs the unfused sequence generate -> save_potential -> c2r.
 // whole = false stops after the y pass (the slab pipeline's forward half, rf_slab_forward_ex)
-static int potential_forward(rf_plan* p, uint64_t seed, int mode, const double* noise_host, bool whole) {
+int potential_forward(rf_plan* p, uint64_t seed, int mode, const double* noise_host, bool whole) {
   RF_REQUIRE(p->have_kgrid && p->have_power, "rf_set_kgrid and rf_set_power must be called first");
   RF_REQUIRE(mode == RF_NOISE_NATIVE || mode == RF_NOISE_EXTERNAL || mode == RF_NOISE_RESIDENT, "invalid noise mode");
   RF_REQUIRE(!(p->replicate && p->nranks > 1), "replicated-generation plans keep no k-space potential: clear RF_FLAG_REPLICATED_GENERATION");
@@ -1375,6 +1214,8 @@ static int potential_forward(rf_plan* p, uint64_t seed, int mode, const double* 
   p->resident_fast = false;
   return rc;
 }
+}  // namespace rfc
+extern "C" {
 
 int rf_realise_potential(rf_plan* p, uint64_t seed, int mode, const double* noise_host) {
   RF_REQUIRE(p, "null plan");
@@ -1850,749 +1691,6 @@ int rf_yz_slabs(rf_plan* p, int* nslab, int* planes) {
   if (p->X && xpose_ok(p) && B > 0 && (B % xpose_row_block(p) || (B & (B - 1)) || p->nx % B)) B = 0;
   *planes = B > 0 ? (int)B : p->nxl;
   *nslab = B > 0 ? (int)((p->nx + B - 1) / B) : 1;
-  return 0;
-}
-
-int rf_mt_set_jump(rf_plan* p, int npolys, const uint16_t* pos, const int* npos, int stride, int blocks_per_segment, int radix) {
-  RF_REQUIRE(p && pos && npos, "null argument");
-  RF_REQUIRE(!p->unpacked, "this call does not apply to an unpacked c2c plan");
-  RF_REQUIRE(npolys >= 1 && stride >= 1 && blocks_per_segment >= 1 && radix >= 2 && npolys % (radix - 1) == 0, "invalid jump table");
-  RF_HIP(hipSetDevice(p->device));
-  RF_HIP(hipStreamSynchronize(p->stream));
-  if (p->mt_pos) RF_HIP(hipFree(p->mt_pos));
-  if (p->mt_npos_dev) RF_HIP(hipFree(p->mt_npos_dev));
-  p->mt_pos = nullptr;
-  p->mt_npos_dev = nullptr;
-  // device rows (rf_k_mt.hip mt_jump_kernel): four lists, one per class c = position mod 4, each padded to a multiple of 8 entries;
-  // an entry is the byte offset 4 (position - c) of an aligned 16-byte read; the padding points into the block of zero words
-  // behind the 33-block window (33 * 624 words); four padded counts per polynomial
-  const uint32_t null_off = 4u * 33u * 624u;
-  const int wstride = ((stride + 7) / 8 + 4) * 8;
-  std::vector<uint32_t> wide((size_t)npolys * wstride, null_off);
-  std::vector<int> counts(4 * (size_t)npolys);
-  for (int l = 0; l < npolys; ++l) {
-    int n[4] = {0, 0, 0, 0};
-    for (int j = 0; j < npos[l]; ++j) ++n[pos[(size_t)l * stride + j] & 3];
-    int off[4], padded[4];
-    for (int c = 0, o = 0; c < 4; ++c) { padded[c] = (n[c] + 7) & ~7; off[c] = o; o += padded[c]; }
-    RF_REQUIRE(off[3] + padded[3] <= wstride, "jump table row too long");
-    int k[4] = {0, 0, 0, 0};
-    for (int j = 0; j < npos[l]; ++j) {
-      const uint32_t q = pos[(size_t)l * stride + j];
-      const int c = (int)(q & 3u);
-      wide[(size_t)l * wstride + off[c] + k[c]++] = 4u * (q - (uint32_t)c);
-    }
-    for (int c = 0; c < 4; ++c) counts[4 * l + c] = padded[c];
-  }
-  RF_HIP(hipMalloc((void**)&p->mt_pos, wide.size() * sizeof(uint32_t)));
-  RF_HIP(hipMemcpy(p->mt_pos, wide.data(), wide.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-  RF_HIP(hipMalloc((void**)&p->mt_npos_dev, counts.size() * sizeof(int)));
-  RF_HIP(hipMemcpy(p->mt_npos_dev, counts.data(), counts.size() * sizeof(int), hipMemcpyHostToDevice));
-  p->mt_npos.assign(npos, npos + npolys);
-  p->mt_stride = wstride;
-  p->mt_bps = blocks_per_segment;
-  p->mt_radix = radix;
-  return 0;
-}
-
-int rf_noise_mt19937(rf_plan* p, const uint32_t* state624, unsigned long long* accepted) {
-  return rf_noise_mt19937_ex(p, state624, accepted, 0);
-}
-
-namespace {
-// sizes of one replay of RandomState(seed).normal for this plan's grid (rf_k_mt.hip)
-struct MtGeom {
-  unsigned long long ncells, attempts, cap;
-  long long total_blocks;
-  int nseg, stages;
-  size_t need;          // bytes of the runs: nseg * cap pairs
-};
-int mt_geom(rf_plan* p, int single, MtGeom& g) {
-  g.ncells = (unsigned long long)p->nx * p->ny * (p->nzc + 1);
-  // polar attempts to generate: acceptance pi/4, margin of 10 sigma + 1024 (mt19937.attempts_needed)
-  const double pa = 0.78539816339744830962;
-  g.attempts = (unsigned long long)std::ceil((double)g.ncells / pa + 10.0 * std::sqrt((double)g.ncells * (1 - pa)) / pa + 1024.0);
-  g.total_blocks = (long long)((4 * g.attempts + 623) / 624);
-  g.nseg = (int)((g.total_blocks + p->mt_bps - 1) / p->mt_bps);
-  // stages of the radix-R jump tree: stage t needs the R - 1 polynomials t^(m R^t L), rows t (R - 1) .. of the table
-  const int R = p->mt_radix;
-  g.stages = 0;
-  long long reach = 1;
-  while (reach < g.nseg) { reach *= R; ++g.stages; }
-  RF_REQUIRE(g.stages * (R - 1) <= (int)p->mt_npos.size(), "grid too large for the uploaded jump table");
-  g.cap = (unsigned long long)p->mt_bps * (624 / 4);
-  g.need = (size_t)g.nseg * g.cap * (single ? 2 * sizeof(float) : 2 * sizeof(double));
-  return 0;
-}
-int mt_ensure_buffers(rf_plan* p, const MtGeom& g) {
-  const size_t nstates = (size_t)g.nseg;
-  if (p->mt_states_cap < nstates) {
-    if (p->mt_states) RF_HIP(hipFree(p->mt_states));
-    p->mt_states = nullptr;
-    RF_HIP(hipMalloc((void**)&p->mt_states, nstates * 624 * sizeof(uint32_t)));
-    p->mt_states_cap = nstates;
-  }
-  if (p->mt_seg_cap < (size_t)g.nseg + 1) {
-    if (p->mt_counts) RF_HIP(hipFree(p->mt_counts));
-    if (p->mt_offsets) RF_HIP(hipFree(p->mt_offsets));
-    p->mt_counts = p->mt_offsets = nullptr;
-    RF_HIP(hipMalloc((void**)&p->mt_counts, ((size_t)g.nseg + 1) * sizeof(unsigned long long)));
-    RF_HIP(hipMalloc((void**)&p->mt_offsets, ((size_t)g.nseg + 1) * sizeof(unsigned long long)));
-    p->mt_seg_cap = (size_t)g.nseg + 1;
-  }
-  if (!p->mt_rowtab) RF_HIP(hipMalloc(&p->mt_rowtab, (size_t)p->nx * p->ny * sizeof(RowLoc)));
-  if (!p->mt_flags) RF_HIP(hipMalloc((void**)&p->mt_flags, sizeof(int)));
-  if (p->mt_scratch_bytes < g.need) {
-    if (p->mt_scratch) RF_HIP(hipFree(p->mt_scratch));
-    p->mt_scratch = nullptr; p->mt_scratch_bytes = 0;
-    RF_HIP(hipMalloc(&p->mt_scratch, g.need));
-    p->mt_scratch_bytes = g.need;
-  }
-  return 0;
-}
-// the replay itself on stream s, from the start state in p->mt_states[0 .. 624): jump tree, ONE generation pass, scan (and the
-// move into cell order for float64 deviates).  No host synchronisation.
-int mt_queue(rf_plan* p, const MtGeom& g, int single, hipStream_t s) {
-  const int R = p->mt_radix;
-  // jump tree: stage t turns the start states of segments [0, R^t) into those of [R^t, R^(t+1))
-  long long dist = 1;
-  for (int t = 0; t < g.stages; ++t, dist *= R) {
-    const int nsrc = (int)(dist < g.nseg ? dist : g.nseg);
-    RF_HIP(launch_mt_jump(p->mt_states, p->mt_pos + (size_t)t * (R - 1) * p->mt_stride, p->mt_npos_dev + 4 * t * (R - 1), p->mt_stride, nsrc,
-                          dist, R - 1, g.nseg, s));
-  }
-  // ONE generation pass: every segment writes its accepted pairs densely into its own run of the scratch array
-  // (capacity = its attempts) and counts them; a scan of the counts gives each run its first cell, and a copy kernel
-  // moves the runs into place.  (Round 1 generated every block twice -- a count pass, then a fill pass that knew the
-  // offsets: 2.5 + 3.3 ms against 3.3 + 1.x ms for fill + move.)  A kz-slab rank replays the WHOLE stream (where a
-  // deviate goes depends on every earlier acceptance) and keeps the deviates of its own planes while moving.
-  RF_HIP(launch_mt_polar(single != 0, p->mt_states, g.nseg, p->mt_bps, g.total_blocks, p->mt_counts, p->mt_scratch, g.cap, s));
-  RF_HIP(launch_mt_scan(p->mt_counts, p->mt_offsets, g.nseg, s));
-  // float64 deviates are moved into cell order (and cut to this rank's planes); float32 ones stay in the segments' runs:
-  // the generation pass finds cell c through the scan (slack_cell), which saves the 1.7 ms copy per 1024^3
-  if (single) {
-    RF_HIP(hipMemsetAsync(p->mt_flags, 0, sizeof(int), s));
-    RF_HIP(launch_mt_rowtab(p->mt_offsets, g.nseg, p->mt_rowtab, p->nx, p->ny, (int)p->nzc + 1, p->mt_flags, s));
-  }
-  if (!single)
-    RF_HIP(launch_mt_compact(false, p->mt_scratch, p->mt_counts, p->mt_offsets, g.nseg, g.cap, p->noise, g.ncells, (int)p->nzc + 1,
-                             (int)p->nzl + 1, p->kz0, s));
-  return 0;
-}
-}  // namespace
-
-int rf_noise_mt19937_ex(rf_plan* p, const uint32_t* state624, unsigned long long* accepted, int single) {
-  RF_REQUIRE(p && state624, "null argument");
-  // `single` is a request: plans without the fast float32 generation pass (float64, generic shapes, exact-generation
-  // flag, tables too dense for the per-bin records) read float64 deviates and get them
-  if (single && (p->f64 || p->generic || !p->have_fast || p->exact_gen)) single = 0;
-  RF_REQUIRE(!p->unpacked, "this call does not apply to an unpacked c2c plan");
-  RF_REQUIRE(p->mt_pos && !p->mt_npos.empty(), "rf_mt_set_jump must be called first");
-  RF_HIP(hipSetDevice(p->device));
-  if (!single)
-    if (int rc = ensure_noise(p)) return rc;
-  MtGeom g;
-  if (int rc = mt_geom(p, single, g)) return rc;
-  // the float32 form locates a row's pairs through a table that allows ONE segment boundary per row: segments (cap attempts,
-  // ~0.785 cap pairs) must be longer than a row by a wide margin, or the float64 form (moved into cell order) serves
-  if (single && g.cap < 4ull * (unsigned long long)(p->nzc + 1)) {
-    single = 0;
-    if (int rc = ensure_noise(p)) return rc;
-    if (int rc = mt_geom(p, single, g)) return rc;
-  }
-  if (int rc = mt_ensure_buffers(p, g)) return rc;
-  hipStream_t s = p->stream;
-  RF_HIP(hipMemcpyAsync(p->mt_states, state624, 624 * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-  if (int rc = mt_queue(p, g, single, s)) return rc;
-  const int nseg = g.nseg;
-  unsigned long long total = 0;
-  int flags = 0;
-  p->noise_resident = false;
-  p->noise32_resident = false;
-  RF_HIP(hipMemcpyAsync(&total, p->mt_offsets + nseg, sizeof(total), hipMemcpyDeviceToHost, s));
-  if (single) RF_HIP(hipMemcpyAsync(&flags, p->mt_flags, sizeof(flags), hipMemcpyDeviceToHost, s));
-  RF_HIP(hipStreamSynchronize(s));
-  p->nseg = nseg;
-  p->seg_cap = g.cap;
-  if (accepted) *accepted = total;
-  RF_REQUIRE(total >= g.ncells, "MT19937 replay: not enough accepted polar attempts (increase the margin)");
-  RF_REQUIRE(!(flags & 1), "MT19937 replay: a segment holds fewer deviate pairs than a row of the grid has cells (segment length too short for the float32 form)");
-  p->noise_resident = !single;
-  p->noise32_resident = single != 0;
-  if (!single) {
-    // the runs are dead once the compaction has moved them into p->noise (the stream is idle here).  They are 1.27x the noise
-    // buffer -- 11 GB at 1024^3, the difference between fitting and not fitting a 2048^3 float64 plan with a saved potential
-    // into 288 GB -- so they are given back when the device is getting full; otherwise they stay for the next seed (allocating
-    // and releasing 11 GB costs ~0.5 s per call, a hundred times the replay).  (float32 deviates live IN the runs and keep them.)
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < total_b / 3) {
-      RF_HIP(hipFree(p->mt_scratch));
-      p->mt_scratch = nullptr;
-      p->mt_scratch_bytes = 0;
-    }
-  }
-  return 0;
-}
-
-/* ---- one stream, P ranks: the replay of RandomState(seed).normal shared between the ranks of a kz-slab job -----------------
- * rf_noise_mt19937_ex on a multi-rank plan replays the WHOLE stream on every rank (where a deviate goes depends on every
- * earlier acceptance).  Here rank r replays only segments [r nseg / P, (r + 1) nseg / P): (1) rf_mt_share_begin jumps to its first
- * segment (one jump per radix-16 digit), grows the local tree, runs the generation pass and returns its per-segment counts; (2) the
- * host gathers all counts (a few thousand integers) and hands them to rf_mt_share_pack, which scans them -- now every rank knows
- * which cells every rank holds -- and packs the local pairs by destination (kz slab); (3) ONE all-to-all of deviates, 8 B per
- * cell in float32 mode: the same volume as the field's exchange (rf_mt_share_exchange over RCCL, or rf_mt_share_exchange_local
- * between virtual ranks on one device); (4) rf_mt_share_finish leaves them as the plan's resident float64 deviates, the form
- * rf_realise(RF_NOISE_RESIDENT) and the other consumers already read on multi-rank plans.  Per rank: 1/P of the replay's time
- * and of its scratch.  float64 mode moves the exact deviates (16 B per cell) and gives bit for bit what the replicated
- * replay gives; float32 mode (complex64 plans) rounds the Box-Muller factor as rf_noise_mt19937_ex(single = 1) does. */
-namespace {
-inline int sh_seg_begin(int r, int nseg, int nranks) { return (int)((long long)r * nseg / nranks); }
-}
-int rf_mt_share_segments(rf_plan* p, int* nseg_total, int* seg_first, int* seg_count) {
-  RF_REQUIRE(p, "null plan");
-  RF_REQUIRE(!p->unpacked && !p->generic, "the distributed replay serves packed plans on the tiled kernels");
-  RF_REQUIRE(p->mt_pos && !p->mt_npos.empty(), "rf_mt_set_jump must be called first");
-  MtGeom g;
-  if (int rc = mt_geom(p, 1, g)) return rc;
-  const int a = sh_seg_begin(p->rank, g.nseg, p->nranks), b = sh_seg_begin(p->rank + 1, g.nseg, p->nranks);
-  if (nseg_total) *nseg_total = g.nseg;
-  if (seg_first) *seg_first = a;
-  if (seg_count) *seg_count = b - a;
-  return 0;
-}
-
-int rf_mt_share_begin(rf_plan* p, const uint32_t* state624, int single, unsigned long long* counts_out) {
-  RF_REQUIRE(p && state624 && counts_out, "null argument");
-  RF_REQUIRE(!p->unpacked && !p->generic, "the distributed replay serves packed plans on the tiled kernels");
-  RF_REQUIRE(!p->replicate, "replicated-generation plans draw native deviates only");
-  RF_REQUIRE(p->mt_pos && !p->mt_npos.empty(), "rf_mt_set_jump must be called first");
-  RF_REQUIRE(p->nranks >= 1 && p->nranks <= 64, "unsupported number of ranks");
-  if (single && p->f64) single = 0;                      // float64 cells: keep the exact deviates
-  RF_HIP(hipSetDevice(p->device));
-  p->sh_state = 0;
-  if (int rc = ensure_noise(p)) return rc;
-  MtGeom g;
-  if (int rc = mt_geom(p, single, g)) return rc;
-  const int first = sh_seg_begin(p->rank, g.nseg, p->nranks), nloc = sh_seg_begin(p->rank + 1, g.nseg, p->nranks) - first;
-  RF_REQUIRE(nloc >= 1, "more ranks than segments: use rf_noise_mt19937_ex on this grid");
-  MtGeom gl = g;
-  gl.nseg = nloc + 8;                                     // + slots for the jump to the first segment
-  gl.need = (size_t)nloc * g.cap * (single ? 2 * sizeof(float) : 2 * sizeof(double));
-  if (int rc = mt_ensure_buffers(p, gl)) return rc;
-  hipStream_t s = p->stream;
-  const int R = p->mt_radix;
-  // the start state of segment `first`: one jump per non-zero radix-R digit of `first` (digit d of weight R^t: polynomial
-  // t (R - 1) + d - 1 of the table), hopping through the spare slots behind the local states
-  int slot = nloc;
-  RF_HIP(hipMemcpyAsync(p->mt_states + (size_t)slot * 624, state624, 624 * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-  {
-    int rest = first;
-    for (int t = 0; rest > 0; ++t, rest /= R) {
-      const int d = rest % R;
-      if (d == 0) continue;
-      RF_REQUIRE(t < g.stages && slot + 1 < nloc + 8, "segment index beyond the uploaded jump table");
-      const int row = t * (R - 1) + d - 1;
-      RF_HIP(launch_mt_jump(p->mt_states + (size_t)slot * 624, p->mt_pos + (size_t)row * p->mt_stride, p->mt_npos_dev + 4 * row, p->mt_stride,
-                            1, 1, 1, 2, s));
-      ++slot;
-    }
-  }
-  RF_HIP(hipMemcpyAsync(p->mt_states, p->mt_states + (size_t)slot * 624, 624 * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
-  // the local tree and the generation pass over the local segments (mt_queue with a shifted origin)
-  long long dist = 1;
-  for (int t = 0; dist < nloc; ++t, dist *= R) {
-    const int nsrc = (int)(dist < nloc ? dist : nloc);
-    RF_HIP(launch_mt_jump(p->mt_states, p->mt_pos + (size_t)t * (R - 1) * p->mt_stride, p->mt_npos_dev + 4 * t * (R - 1), p->mt_stride, nsrc,
-                          dist, R - 1, nloc, s));
-  }
-  RF_HIP(launch_mt_polar(single != 0, p->mt_states, nloc, p->mt_bps, g.total_blocks - (long long)first * p->mt_bps, p->mt_counts, p->mt_scratch, g.cap, s));
-  RF_HIP(hipMemcpyAsync(counts_out, p->mt_counts, (size_t)nloc * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-  RF_HIP(hipStreamSynchronize(s));
-  p->sh_single = single; p->sh_first = first; p->sh_nloc = nloc;
-  p->noise_resident = false;                              // (p->noise is about to be overwritten)
-  p->noise32_resident = false;                            // (the runs in mt_scratch are this rank's share only)
-  p->sh_state = 1;
-  return 0;
-}
-
-// every rank's per-segment counts, in segment order, on every rank: an integer sum over the communicator of arrays that are zero
-// outside the rank's own range (a few thousand values; also the first collective after the local replays)
-int rf_mt_share_gather(rf_plan* p, unsigned long long* counts_all) {
-  RF_REQUIRE(p && counts_all, "null argument");
-  RF_REQUIRE(p->sh_state == 1, "rf_mt_share_begin must be called first");
-  RF_REQUIRE(p->nranks == 1 || p->comm != nullptr, "rf_comm_init has not been called on this multi-rank plan");
-  RF_HIP(hipSetDevice(p->device));
-  MtGeom g;
-  if (int rc = mt_geom(p, p->sh_single, g)) return rc;
-  if (p->comm_stream) RF_HIP(hipStreamSynchronize(p->comm_stream));          // (the communicator is used from one stream at a time)
-  unsigned long long* tmp = nullptr;
-  RF_HIP(hipMalloc((void**)&tmp, (size_t)g.nseg * sizeof(unsigned long long)));
-  hipStream_t s = p->stream;
-  hipError_t e = hipMemsetAsync(tmp, 0, (size_t)g.nseg * sizeof(unsigned long long), s);
-  if (e == hipSuccess) e = hipMemcpyAsync(tmp + p->sh_first, p->mt_counts, (size_t)p->sh_nloc * sizeof(unsigned long long), hipMemcpyDeviceToDevice, s);
-  if (e == hipSuccess && p->comm && g_rccl.AllReduce(tmp, tmp, (size_t)g.nseg, ncclUint64, ncclSum, p->comm, s) != ncclSuccess) e = hipErrorUnknown;
-  if (e == hipSuccess) e = hipMemcpyAsync(counts_all, tmp, (size_t)g.nseg * sizeof(unsigned long long), hipMemcpyDeviceToHost, s);
-  if (e == hipSuccess) e = hipStreamSynchronize(s);
-  (void)hipFree(tmp);
-  RF_HIP(e);
-  return 0;
-}
-
-int rf_mt_share_pack(rf_plan* p, const unsigned long long* counts_all) {
-  RF_REQUIRE(p && counts_all, "null argument");
-  RF_REQUIRE(p->sh_state == 1, "rf_mt_share_begin must be called first");
-  RF_HIP(hipSetDevice(p->device));
-  MtGeom g;
-  if (int rc = mt_geom(p, p->sh_single, g)) return rc;
-  const int P = p->nranks, nzl = (int)p->nzl, nzh = (int)p->nzc + 1;
-  std::vector<unsigned long long> off((size_t)g.nseg + 1);
-  off[0] = 0;
-  for (int i = 0; i < g.nseg; ++i) {
-    RF_REQUIRE(counts_all[i] <= g.cap, "a segment cannot hold more pairs than attempts: the gathered counts are corrupt");
-    off[i + 1] = off[i] + counts_all[i];
-  }
-  RF_REQUIRE(off[g.nseg] >= g.ncells, "MT19937 replay: not enough accepted polar attempts (increase the margin)");
-  p->sh_total = off[g.nseg];
-  // first cell of every rank's share, and the index in "stream q" (rows of nzl + 1 pairs: q's planes, then the Nyquist plane) of
-  // the first stream-q cell at or behind stream cell c
-  std::vector<unsigned long long> cb((size_t)P + 1);
-  for (int r = 0; r <= P; ++r) {
-    const unsigned long long c = off[sh_seg_begin(r, g.nseg, P)];
-    cb[r] = c < g.ncells ? c : g.ncells;
-  }
-  cb[P] = g.ncells;
-  auto fq = [&](int q, unsigned long long c) -> unsigned long long {
-    const unsigned long long col = c / (unsigned)nzh;
-    long long k = (long long)(c - col * (unsigned)nzh) - (long long)q * nzl;
-    k = k < 0 ? 0 : (k > nzl ? nzl : k);
-    return col * (unsigned)(nzl + 1) + (unsigned long long)k;
-  };
-  const int me = p->rank;
-  p->sh_sendoff.assign(P + 1, 0); p->sh_sendcnt.assign(P, 0); p->sh_recvoff.assign(P, 0); p->sh_recvcnt.assign(P, 0);
-  std::vector<long long> sbase(P);
-  for (int q = 0; q < P; ++q) {
-    p->sh_sendcnt[q] = fq(q, cb[me + 1]) - fq(q, cb[me]);
-    p->sh_sendoff[q + 1] = p->sh_sendoff[q] + p->sh_sendcnt[q];
-    sbase[q] = (long long)p->sh_sendoff[q] - (long long)fq(q, cb[me]);
-    p->sh_recvoff[q] = fq(me, cb[q]);                     // (q = the sending rank here)
-    p->sh_recvcnt[q] = fq(me, cb[q + 1]) - fq(me, cb[q]);
-  }
-  const size_t es = p->sh_single ? 2 * sizeof(float) : 2 * sizeof(double);
-  const size_t send_bytes = (size_t)(p->sh_sendoff[P] > 0 ? p->sh_sendoff[P] : 1) * es;
-  const size_t recv_pairs = (size_t)p->nx * p->ny * (nzl + 1);
-  if (p->mt_send_bytes < send_bytes) {
-    if (p->mt_send) RF_HIP(hipFree(p->mt_send));
-    p->mt_send = nullptr; p->mt_send_bytes = 0;
-    const size_t want = send_bytes + send_bytes / 64;    // (the shares differ from seed to seed by the counts' binomial noise)
-    RF_HIP(hipMalloc(&p->mt_send, want));
-    p->mt_send_bytes = want;
-  }
-  if (p->sh_single && p->mt_recv_bytes < recv_pairs * es) {
-    if (p->mt_recv) RF_HIP(hipFree(p->mt_recv));
-    p->mt_recv = nullptr; p->mt_recv_bytes = 0;
-    RF_HIP(hipMalloc(&p->mt_recv, recv_pairs * es));
-    p->mt_recv_bytes = recv_pairs * es;
-  }
-  if (!p->mt_sbase) RF_HIP(hipMalloc((void**)&p->mt_sbase, 64 * sizeof(long long)));
-  if (p->mt_first_cap < (size_t)p->sh_nloc) {
-    if (p->mt_first) RF_HIP(hipFree(p->mt_first));
-    p->mt_first = nullptr; p->mt_first_cap = 0;
-    RF_HIP(hipMalloc((void**)&p->mt_first, (size_t)p->sh_nloc * sizeof(unsigned long long)));
-    p->mt_first_cap = (size_t)p->sh_nloc;
-  }
-  hipStream_t s = p->stream;
-  RF_HIP(hipMemcpyAsync(p->mt_sbase, sbase.data(), (size_t)P * sizeof(long long), hipMemcpyHostToDevice, s));
-  RF_HIP(hipMemcpyAsync(p->mt_first, off.data() + p->sh_first, (size_t)p->sh_nloc * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
-  RF_HIP(launch_mt_share_pack(p->sh_single != 0, p->mt_scratch, p->mt_counts, p->mt_first, p->sh_nloc, g.cap, p->mt_send, g.ncells, nzh, nzl, P,
-                              p->mt_sbase, s));
-  RF_HIP(hipStreamSynchronize(s));                        // (sbase / off are host temporaries)
-  p->sh_state = 2;
-  return 0;
-}
-
-namespace {
-// where rank p's stream arrives: the resident deviates themselves (float64) or the float32 staging buffer
-inline char* sh_recv_base(rf_plan* p) { return p->sh_single ? (char*)p->mt_recv : (char*)p->noise; }
-}
-
-int rf_mt_share_exchange(rf_plan* p) {
-  RF_REQUIRE(p, "null plan");
-  RF_REQUIRE(p->sh_state == 2, "rf_mt_share_pack must be called first");
-  RF_REQUIRE(p->nranks == 1 || p->comm != nullptr, "rf_comm_init has not been called on this multi-rank plan");
-  RF_HIP(hipSetDevice(p->device));
-  const size_t es = p->sh_single ? 2 * sizeof(float) : 2 * sizeof(double);
-  hipStream_t s = p->stream;
-  const int me = p->rank;
-  RF_HIP(hipMemcpyAsync(sh_recv_base(p) + p->sh_recvoff[me] * es, (const char*)p->mt_send + p->sh_sendoff[me] * es, p->sh_sendcnt[me] * es,
-                        hipMemcpyDeviceToDevice, s));
-  if (p->nranks > 1) {
-    RF_NCCL(g_rccl.GroupStart());
-    for (int h = 0; h < p->nranks; ++h) {
-      if (h == me) continue;
-      if (p->sh_sendcnt[h]) RF_NCCL(g_rccl.Send((const char*)p->mt_send + p->sh_sendoff[h] * es, p->sh_sendcnt[h] * es, ncclUint8, h, p->comm, s));
-      if (p->sh_recvcnt[h]) RF_NCCL(g_rccl.Recv(sh_recv_base(p) + p->sh_recvoff[h] * es, p->sh_recvcnt[h] * es, ncclUint8, h, p->comm, s));
-    }
-    RF_NCCL(g_rccl.GroupEnd());
-  }
-  p->sh_state = 3;
-  return 0;
-}
-
-int rf_mt_share_exchange_local(rf_plan** plans, int n) {
-  RF_REQUIRE(plans && n >= 1, "null argument");
-  for (int g = 0; g < n; ++g) {
-    RF_REQUIRE(plans[g] && plans[g]->nranks == n && plans[g]->rank == g, "plans must be ranks 0..n-1 of one n-rank job");
-    RF_REQUIRE(plans[g]->device == plans[0]->device, "virtual ranks must live on one device");
-    RF_REQUIRE(plans[g]->sh_state == 2 && plans[g]->sh_single == plans[0]->sh_single, "rf_mt_share_pack must have run on every plan (same mode)");
-    RF_HIP(hipStreamSynchronize(plans[g]->stream));
-  }
-  const size_t es = plans[0]->sh_single ? 2 * sizeof(float) : 2 * sizeof(double);
-  for (int g = 0; g < n; ++g)        // sender g, receiver h
-    for (int h = 0; h < n; ++h) {
-      RF_REQUIRE(plans[g]->sh_sendcnt[h] == plans[h]->sh_recvcnt[g], "send / receive counts disagree");
-      if (plans[g]->sh_sendcnt[h])
-        RF_HIP(hipMemcpy(sh_recv_base(plans[h]) + plans[h]->sh_recvoff[g] * es, (const char*)plans[g]->mt_send + plans[g]->sh_sendoff[h] * es,
-                         plans[g]->sh_sendcnt[h] * es, hipMemcpyDeviceToDevice));
-    }
-  RF_HIP(hipDeviceSynchronize());       // (see rf_slab_exchange_local)
-  for (int g = 0; g < n; ++g) plans[g]->sh_state = 3;
-  return 0;
-}
-
-int rf_mt_share_finish(rf_plan* p, unsigned long long* accepted) {
-  RF_REQUIRE(p, "null plan");
-  RF_REQUIRE(p->sh_state == 3, "the exchange must have run first");
-  RF_HIP(hipSetDevice(p->device));
-  if (p->sh_single)
-    RF_HIP(launch_mt_share_widen(p->mt_recv, p->noise, (long long)p->nx * p->ny * (p->nzl + 1), p->stream));
-  RF_HIP(hipStreamSynchronize(p->stream));
-  p->noise_resident = true;
-  p->noise32_resident = false;
-  p->sh_state = 0;
-  if (accepted) *accepted = p->sh_total;
-  return 0;
-}
-
-// Same-seed realisations back to back (random.py:24-28 for n seeds): the replay of seed i + 1 (VALU / LDS-bound, second stream)
-// runs under the y and z passes of seed i (HBM-bound); ONE set of runs -- the replay of seed i + 1 starts when the generation
-// pass of seed i has read them, the generation pass of seed i + 1 when the replay has finished.  complex64 plans with the fast
-// generation path (float32 pairs).  states: n x 624 words (mt19937.seed_state); rms_out: n, optional.
-int rf_realise_batch_reference(rf_plan* p, const uint32_t* states, int n, double* rms_out) {
-  RF_REQUIRE(p && states, "null argument");
-  RF_REQUIRE(!p->unpacked, "this call does not apply to an unpacked c2c plan");
-  RF_REQUIRE(n >= 1, "need at least one seed");
-  RF_REQUIRE(p->have_kgrid && p->have_power, "rf_set_kgrid and rf_set_power must be called first");
-  RF_REQUIRE(p->mt_pos && !p->mt_npos.empty(), "rf_mt_set_jump must be called first");
-  RF_REQUIRE(p->nranks == 1 && !p->force_slab && !p->generic && !p->f64 && p->have_fast && !p->exact_gen,
-             "rf_realise_batch_reference is for single-GPU complex64 plans on the fast generation path; loop rf_noise_mt19937 + rf_realise otherwise");
-  RF_HIP(hipSetDevice(p->device));
-  MtGeom g;
-  if (int rc = mt_geom(p, 1, g)) return rc;
-  RF_REQUIRE(g.cap >= 4ull * (unsigned long long)(p->nzc + 1), "the replay's segments are too short for the float32 form on this grid: loop rf_noise_mt19937 + rf_realise");
-  if (int rc = mt_ensure_buffers(p, g)) return rc;
-  if (int rc = ensure_x(p)) return rc;
-  RF_HIP(hipStreamSynchronize(p->stream));
-  if (p->stats_cap < n) {
-    drop_graphs(p);
-    if (p->stats) RF_HIP(hipFree(p->stats));
-    p->stats = nullptr;
-    RF_HIP(hipMalloc((void**)&p->stats, 2 * (size_t)(n + 64) * sizeof(double)));
-    p->stats_cap = n + 64;
-  }
-  if (!p->aux_stream) {
-    RF_HIP(hipStreamCreateWithFlags(&p->aux_stream, hipStreamNonBlocking));
-    for (auto& e : p->bev) RF_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  }
-  // all start states and the per-seed accepted totals live on the device for the length of the batch (the plan keeps the block)
-  if (p->br_cap < n) {
-    if (p->br_tmp) RF_HIP(hipFree(p->br_tmp));
-    p->br_tmp = nullptr; p->br_cap = 0;
-    const int cap = n > 16 ? n : 16;
-    RF_HIP(hipMalloc(&p->br_tmp, (size_t)cap * (624 * sizeof(uint32_t) + sizeof(unsigned long long) + sizeof(int) + 4)));
-    p->br_cap = cap;
-  }
-  uint32_t* dstates = (uint32_t*)p->br_tmp;
-  unsigned long long* dtotals = (unsigned long long*)((char*)p->br_tmp + (size_t)p->br_cap * 624 * sizeof(uint32_t));
-  int* dflags = (int*)(dtotals + p->br_cap);
-  RF_HIP(hipMemcpy(dstates, states, (size_t)n * 624 * sizeof(uint32_t), hipMemcpyHostToDevice));
-  hipStream_t S = p->stream, R = p->aux_stream;
-  // whatever deviates were resident are about to be overwritten; the plan claims the new ones (and a field) only once every
-  // replay of the batch has been checked
-  p->noise_resident = false;
-  p->noise32_resident = false;
-  p->real_valid = false;
-  p->stats_valid = false;
-  p->nseg = g.nseg;
-  p->seg_cap = g.cap;
-  // both streams are drained before any return from here on
-  auto drain = [&](int rc) { (void)hipStreamSynchronize(R); (void)hipStreamSynchronize(S); return rc; };
-  auto replay = [&](int i) -> int {
-    RF_HIP(hipMemcpyAsync(p->mt_states, dstates + (size_t)i * 624, 624 * sizeof(uint32_t), hipMemcpyDeviceToDevice, R));
-    if (int r = mt_queue(p, g, 1, R)) return r;
-    RF_HIP(hipMemcpyAsync(dtotals + i, p->mt_offsets + g.nseg, sizeof(unsigned long long), hipMemcpyDeviceToDevice, R));
-    RF_HIP(hipMemcpyAsync(dflags + i, p->mt_flags, sizeof(int), hipMemcpyDeviceToDevice, R));
-    RF_HIP(hipEventRecord(p->bev[0], R));
-    return 0;
-  };
-  auto issue = [&]() -> int {
-    RF_HIP(hipEventRecord(p->ev[0], S));
-    RF_HIP(hipEventRecord(p->bev[1], S));
-    RF_HIP(hipStreamWaitEvent(R, p->bev[1], 0));          // (whatever ran on the main stream before the batch has finished with the runs)
-    if (int rc = replay(0)) return rc;
-    for (int i = 0; i < n; ++i) {
-      RF_HIP(hipStreamWaitEvent(S, p->bev[0], 0));        // the runs of seed i are complete
-      p->resident_fast = true;
-      p->noise32_resident = true;                         // (queue_x selects the float32-pair kernel by it; cleared again on failure)
-      const bool xp = p->X && xpose_ok(p);
-      const int rc = queue_x(p, make_gen(p, 0, RF_NOISE_RESIDENT, false), nullptr, xp ? p->X : p->W, S, false);
-      p->resident_fast = false;
-      if (rc) return rc;
-      RF_HIP(hipEventRecord(p->bev[1], S));               // the generation pass of seed i has read the runs
-      if (i + 1 < n) {
-        RF_HIP(hipStreamWaitEvent(R, p->bev[1], 0));
-        if (int rc2 = replay(i + 1)) return rc2;
-      }
-      if (int rc3 = queue_yz(p, p->W, S, p->stats + 2 * i, false)) return rc3;
-    }
-    RF_HIP(hipEventRecord(p->ev[4], S));
-    return 0;
-  };
-  std::vector<unsigned long long> totals((size_t)n);
-  std::vector<int> flags((size_t)n);
-  std::vector<double> st(2 * (size_t)n);
-  int rc = issue();
-  if (!rc) {
-    hipError_t e = hipStreamSynchronize(R);
-    if (e == hipSuccess) e = hipMemcpyAsync(st.data(), p->stats, st.size() * sizeof(double), hipMemcpyDeviceToHost, S);
-    if (e == hipSuccess) e = hipStreamSynchronize(S);
-    if (e == hipSuccess) e = hipMemcpy(totals.data(), dtotals, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(flags.data(), dflags, (size_t)n * sizeof(int), hipMemcpyDeviceToHost);
-    if (e != hipSuccess) rc = fail(2, std::string("rf_realise_batch_reference: ") + hipGetErrorString(e));
-  }
-  if (!rc)
-    for (int i = 0; i < n && !rc; ++i) {
-      if (totals[i] < g.ncells) rc = fail(1, "MT19937 replay: not enough accepted polar attempts (increase the margin)");
-      else if (flags[i] & 1) rc = fail(1, "MT19937 replay: a segment holds fewer deviate pairs than a row of the grid has cells");
-    }
-  if (rc) {
-    p->noise32_resident = false;
-    return drain(rc);
-  }
-  p->noise32_resident = true;                             // the last seed's deviates, as float32 pairs in the runs
-  p->cur = p->W; p->timed = false; p->real_valid = true; p->stats_valid = true; p->stats_slot = n - 1; p->k_valid = false;
-  if (rms_out) {
-    const double cnt = (double)p->nx * p->ny * p->nz;
-    for (int i = 0; i < n; ++i) {
-      const double m = st[2 * i] / cnt, v = st[2 * i + 1] / cnt - m * m;
-      rms_out[i] = v > 0 ? std::sqrt(v) : 0.0;
-    }
-  }
-  return 0;
-}
-
-int rf_can_batch_reference(rf_plan* p) {
-  if (!p || p->unpacked || p->nranks != 1 || p->force_slab || p->generic || p->f64 || !p->have_fast || p->exact_gen || !p->have_kgrid ||
-      !p->have_power || !p->mt_pos || p->mt_npos.empty())
-    return 0;
-  MtGeom g;
-  if (mt_geom(p, 1, g)) return 0;
-  return g.cap >= 4ull * (unsigned long long)(p->nzc + 1) ? 1 : 0;
-}
-
-int rf_download_noise(rf_plan* p, double* host, unsigned long long first, unsigned long long count) {
-  RF_REQUIRE(p && host, "null argument");
-  RF_REQUIRE(!p->unpacked, "this call does not apply to an unpacked c2c plan");
-  RF_REQUIRE(p->noise_resident, "no float64 deviates resident on the device");
-  RF_REQUIRE(first + count <= 2ull * p->nx * p->ny * (p->nzl + 1), "range outside the noise buffer");
-  RF_HIP(hipSetDevice(p->device));
-  RF_HIP(hipMemcpyAsync(host, p->noise + first, count * sizeof(double), hipMemcpyDeviceToHost, p->stream));
-  RF_HIP(hipStreamSynchronize(p->stream));
-  return 0;
-}
-
-int rf_comm_unique_id(void* id128) {
-  RF_REQUIRE(id128, "null argument");
-  if (int rc = load_rccl()) return rc;
-  ncclUniqueId id;
-  RF_NCCL(g_rccl.GetUniqueId(&id));
-  memcpy(id128, &id, sizeof(id));
-  return 0;
-}
-
-int rf_comm_init(rf_plan* p, const void* id128) {
-  RF_REQUIRE(p && id128, "null argument");
-  RF_REQUIRE(!p->unpacked, "this call does not apply to an unpacked c2c plan");
-  RF_REQUIRE(p->comm == nullptr, "communicator already initialised");
-  if (int rc = load_rccl()) return rc;
-  RF_HIP(hipSetDevice(p->device));
-  // RCCL inspects hipGetLastError(): make sure no stale (non-sticky) error of an earlier call is pending
-  {
-    hipError_t stale = hipGetLastError();
-    if (stale != hipSuccess && getenv("RANDOMFIELD_DEBUG"))
-      fprintf(stderr, "rf_comm_init: cleared stale HIP error: %s\n", hipGetErrorString(stale));
-  }
-  ncclUniqueId id;
-  memcpy(&id, id128, sizeof(id));
-  RF_NCCL(g_rccl.CommInitRank(&p->comm, p->nranks, id, p->rank));
-  // one tiny collective now: a broken communicator should fail here, not inside a timed region
-  RF_HIP(hipMemsetAsync(p->coll_scratch, 0, 2 * sizeof(double), p->stream));
-  RF_NCCL(g_rccl.AllReduce(p->coll_scratch, p->coll_scratch, 2, ncclFloat64, ncclSum, p->comm, p->stream));
-  RF_HIP(hipStreamSynchronize(p->stream));
-  return 0;
-}
-
-// ranks of the plan's RCCL communicator as RCCL itself counts them (ncclCommCount); 0 = no communicator (rf_comm_init has not run)
-int rf_comm_size(rf_plan* p, int* nranks) {
-  RF_REQUIRE(p && nranks, "null argument");
-  *nranks = 0;
-  if (!p->comm) return 0;
-  RF_NCCL(g_rccl.CommCount(p->comm, nranks));
-  return 0;
-}
-
-int rf_comm_allreduce_f64(rf_plan* p, double* inout, int n, int op) {
-  RF_REQUIRE(p && inout, "null argument");
-  RF_REQUIRE(!p->unpacked, "this call does not apply to an unpacked c2c plan");
-  RF_REQUIRE(n >= 1 && n <= 2, "n must be 1 or 2");
-  RF_REQUIRE(op == 0 || op == 1, "op must be 0 (sum) or 1 (max)");
-  RF_HIP(hipSetDevice(p->device));
-  if (!p->comm) { RF_HIP(hipStreamSynchronize(p->stream)); return 0; }     // a one-rank communicator still runs the collective
-  if (p->comm_stream) RF_HIP(hipStreamSynchronize(p->comm_stream));          // (the communicator is used from one stream at a time)
-  double* d = p->coll_scratch;            // its own two doubles: `stats` holds the moments of up to stats_cap realisations
-  RF_HIP(hipMemcpyAsync(d, inout, n * sizeof(double), hipMemcpyHostToDevice, p->stream));
-  RF_NCCL(g_rccl.AllReduce(d, d, n, ncclFloat64, op == 0 ? ncclSum : ncclMax, p->comm, p->stream));
-  RF_HIP(hipMemcpyAsync(inout, d, n * sizeof(double), hipMemcpyDeviceToHost, p->stream));
-  RF_HIP(hipStreamSynchronize(p->stream));
-  return 0;
-}
-
-/* ---- slab pipeline in separate steps (tests / custom exchanges) ------------------------------- */
-int rf_slab_forward(rf_plan* p, uint64_t seed, int mode, const double* noise_host) {
-  RF_REQUIRE(p, "null plan");
-  RF_REQUIRE(!p->unpacked, "this call does not apply to an unpacked c2c plan");
-  RF_REQUIRE(p->nranks > 1, "rf_slab_* are for multi-rank plans");
-  RF_REQUIRE(p->have_kgrid && p->have_power, "rf_set_kgrid and rf_set_power must be called first");
-  RF_HIP(hipSetDevice(p->device));
-  if (int rc = upload_noise(p, mode, noise_host)) return rc;
-  p->resident_fast = (mode == RF_NOISE_RESIDENT);
-  const int rc = queue_xy(p, make_gen(p, seed, mode, false), nullptr, p->W, p->stream, false);
-  p->resident_fast = false;
-  if (rc) return rc;
-  RF_HIP(hipStreamSynchronize(p->stream));
-  return 0;
-}
-
-// the forward half with the other two sources of rf_realise_potential / rf_execute_c2r
-int rf_slab_forward_ex(rf_plan* p, uint64_t seed, int mode, const double* noise_host, int source) {
-  RF_REQUIRE(p, "null plan");
-  RF_REQUIRE(!p->unpacked, "this call does not apply to an unpacked c2c plan");
-  RF_REQUIRE(p->nranks > 1, "rf_slab_* are for multi-rank plans");
-  RF_REQUIRE(source == RF_SLAB_GENERATE || source == RF_SLAB_GENERATE_SAVE_POTENTIAL || source == RF_SLAB_FROM_KSPACE, "invalid source");
-  if (source == RF_SLAB_GENERATE) return rf_slab_forward(p, seed, mode, noise_host);
-  RF_HIP(hipSetDevice(p->device));
-  if (source == RF_SLAB_GENERATE_SAVE_POTENTIAL) {
-    if (int rc = potential_forward(p, seed, mode, noise_host, false)) return rc;
-  } else {
-    RF_REQUIRE(p->K && p->k_valid, "no k-space data: call rf_generate, rf_load_potential or rf_upload_k first");
-    if (int rc = queue_xy(p, make_gen(p, 0, RF_NOISE_NATIVE, false), p->K, p->W, p->stream, false)) return rc;
-  }
-  RF_HIP(hipStreamSynchronize(p->stream));
-  return 0;
-}
-
-int rf_slab_exchange_local(rf_plan** plans, int n) {
-  RF_REQUIRE(plans && n >= 1, "null argument");
-  for (int g = 0; g < n; ++g) {
-    RF_REQUIRE(plans[g] && plans[g]->nranks == n && plans[g]->rank == g, "plans must be ranks 0..n-1 of one n-rank job");
-    RF_REQUIRE(plans[g]->device == plans[0]->device, "virtual ranks must live on one device");
-    RF_HIP(hipStreamSynchronize(plans[g]->stream));
-  }
-  const rf_plan* p0 = plans[0];
-  const int C = slab_chunks(p0);
-  for (int g = 0; g < n; ++g) RF_REQUIRE(slab_chunks(plans[g]) == C, "every rank must use the same number of exchange chunks");
-  const size_t blk = (size_t)p0->nxl * p0->ny * p0->nzl * p0->csize / (size_t)C, cb = p0->w_bytes / (size_t)C;
-  for (int g = 0; g < n; ++g)        // sender g, receiver h: block h of sub-slab c of W_g -> segment (g, c) of R_h
-    for (int h = 0; h < n; ++h)
-      for (int c = 0; c < C; ++c)
-        RF_HIP(hipMemcpy((char*)plans[h]->R + ((size_t)g * C + c) * blk, (char*)plans[g]->W + (size_t)c * cb + (size_t)h * blk, blk, hipMemcpyDeviceToDevice));
-  // a device-to-device hipMemcpy may return before the copy has run (it is only ordered on the null stream), and the
-  // plans' streams do not synchronise with the null stream: without this the gathering z pass of a large grid read
-  // blocks that had not arrived yet (caught by the full-size config-4 test; small grids happened to win the race)
-  RF_HIP(hipDeviceSynchronize());
-  return 0;
-}
-
-// the multi-rank forward transform in separate steps (virtual ranks): rows on the x slab, rf_slab_exchange_local_reverse, columns
-int rf_slab_r2c_rows(rf_plan* p) {
-  RF_REQUIRE(p, "null plan");
-  RF_REQUIRE(!p->unpacked && !p->generic, "this call applies to packed plans on the tiled kernels");
-  RF_REQUIRE(p->nranks > 1, "rf_slab_* are for multi-rank plans");
-  RF_REQUIRE(p->real_valid && p->cur == p->W, "no real-space field on the device: call rf_upload_real (or a c2r) first");
-  RF_HIP(hipSetDevice(p->device));
-  if (int rc = queue_r2c_slab_rows(p, p->stream)) return rc;
-  p->real_valid = false;
-  RF_HIP(hipStreamSynchronize(p->stream));
-  return 0;
-}
-int rf_slab_exchange_local_reverse(rf_plan** plans, int n) {
-  RF_REQUIRE(plans && n >= 1, "null argument");
-  for (int g = 0; g < n; ++g) {
-    RF_REQUIRE(plans[g] && plans[g]->nranks == n && plans[g]->rank == g, "plans must be ranks 0..n-1 of one n-rank job");
-    RF_REQUIRE(plans[g]->device == plans[0]->device, "virtual ranks must live on one device");
-    RF_HIP(hipStreamSynchronize(plans[g]->stream));
-  }
-  const rf_plan* p0 = plans[0];
-  const size_t blk = (size_t)p0->nxl * p0->ny * p0->nzl * p0->csize;
-  for (int h = 0; h < n; ++h)        // sender h (x slab), receiver g (kz slab): block g of R_h -> block h of W_g
-    for (int g = 0; g < n; ++g)
-      RF_HIP(hipMemcpy((char*)plans[g]->W + h * blk, (const char*)plans[h]->R + g * blk, blk, hipMemcpyDeviceToDevice));
-  RF_HIP(hipDeviceSynchronize());       // (see rf_slab_exchange_local)
-  return 0;
-}
-int rf_slab_r2c_cols(rf_plan* p) {
-  RF_REQUIRE(p, "null plan");
-  RF_REQUIRE(!p->unpacked && !p->generic, "this call applies to packed plans on the tiled kernels");
-  RF_REQUIRE(p->nranks > 1, "rf_slab_* are for multi-rank plans");
-  RF_HIP(hipSetDevice(p->device));
-  if (int rc = ensure_k(p)) return rc;
-  if (int rc = queue_r2c_slab_cols(p, p->stream)) return rc;
-  RF_HIP(hipStreamSynchronize(p->stream));
-  return 0;
-}
-
-int rf_slab_backward(rf_plan* p) {
-  RF_REQUIRE(p, "null plan");
-  RF_REQUIRE(!p->unpacked, "this call does not apply to an unpacked c2c plan");
-  RF_REQUIRE(p->nranks > 1, "rf_slab_* are for multi-rank plans");
-  RF_HIP(hipSetDevice(p->device));
-  if (int rc = queue_z_slab(p, p->R, p->W, p->stats, p->stream)) return rc;
-  p->stats_slot = 0;
-  RF_HIP(hipStreamSynchronize(p->stream));
-  return 0;
-}
-
-// A rank of an n-rank job WITHOUT a communicator (a virtual rank): `workgroups` > 0 lets rf_realise / rf_realise_batch run the real
-// schedule of a multi-GPU rank -- forward half, exchange on the exchange stream under the next forward half, gathering z pass -- with
-// the all-to-all replaced by a copy kernel of that many 256-thread workgroups that reads the blocks the rank would send and writes
-// the segments it would receive (RCCL's footprint in local HBM and on the compute units, without the links).  0 = off.
-int rf_slab_set_exchange_standin(rf_plan* p, int workgroups) {
-  RF_REQUIRE(p, "null plan");
-  RF_REQUIRE(!p->unpacked && !p->generic, "this call applies to packed plans on the tiled kernels");
-  RF_REQUIRE(p->nranks > 1 && p->comm == nullptr, "the exchange stand-in is for a rank of a multi-rank plan without a communicator");
-  RF_REQUIRE(workgroups >= 0 && workgroups <= 4096, "workgroups must be in [0, 4096]");
-  RF_HIP(hipSetDevice(p->device));
-  RF_HIP(hipStreamSynchronize(p->stream));
-  p->standin_wg = workgroups;
-  return 0;
-}
-
-int rf_slab_stats(rf_plan* p, double* sum, double* sumsq) {
-  RF_REQUIRE(p && sum && sumsq, "null argument");
-  RF_REQUIRE(!p->unpacked, "this call does not apply to an unpacked c2c plan");
-  double st[2];
-  RF_HIP(hipMemcpyAsync(st, p->stats, sizeof(st), hipMemcpyDeviceToHost, p->stream));
-  RF_HIP(hipStreamSynchronize(p->stream));
-  *sum = st[0]; *sumsq = st[1];
   return 0;
 }
 

@@ -10,7 +10,7 @@ src=$root/randomfield_amd/csrc
 out=/tmp/rf_variant_$name
 mkdir -p $out $root/tools/bin
 objs=""
-for f in rf_k_col_plain rf_k_col_gen rf_k_col_gen64 rf_k_row rf_k_row_c2c rf_k_yz rf_k_misc rf_k_mt rf_k_generic rf_capi; do
+for f in rf_k_col_plain rf_k_col_gen rf_k_col_gen64 rf_k_row rf_k_row_c2c rf_k_yz rf_k_misc rf_k_mt rf_k_generic rf_capi rf_capi_mt rf_capi_slab; do
   fl=""; [[ $f == rf_k_col_gen || $f == rf_k_mt ]] && fl="-mllvm -amdgpu-sched-strategy=max-ilp"       # (the Makefile's per-file flag)
   if [[ " $files " == *" $f "* ]]; then
     hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-slp-vectorize -Wno-unused-function -Wno-unused-variable $fl $extra -I$src -c $src/$f.hip -o $out/$f.o &
