@@ -43,7 +43,7 @@ enum { RF_LAYOUT_DENSE = 0, RF_LAYOUT_PADDED = 1 };
  * this repository returned the constant 1 while the surface grew from ~20 to 70 entry points; 5.0 is the first version that means
  * something: the consumer surface below + the diagnostics of randomfield_hip_diag.h.) */
 #define RF_ABI_MAJOR 5
-#define RF_ABI_MINOR 1
+#define RF_ABI_MINOR 2
 #define RF_ABI_VERSION ((RF_ABI_MAJOR << 16) | RF_ABI_MINOR)
 int rf_version(void);                            /* (major << 16) | minor */
 /* bit mask of the groups of entry points this build exports (each bit: every function of the group is present and works as this

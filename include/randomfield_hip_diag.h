@@ -62,6 +62,9 @@ int rf_slab_r2c_cols(rf_plan* plan);
  * measures: how much the overlapped passes lose to the exchange's local traffic (bench.py other_configs).  The
  * received segments hold the rank's own data for other x slabs, so the result is not a field.  0 = off. */
 int rf_slab_set_exchange_standin(rf_plan* plan, int workgroups);
+/* ... with the two directions of that traffic taken apart: the copy kernel reads read_percent and writes write_percent of every block
+ * (100 / 100 = the call above; 100 / 0: the send side's reads alone; 0 / 100: the receive side's writes alone; 50 / 50: half the volume) */
+int rf_slab_set_exchange_standin_ex(rf_plan* plan, int workgroups, int read_percent, int write_percent);
 /* rf_mt_share_exchange (randomfield_hip.h) between n virtual ranks living on one device */
 int rf_mt_share_exchange_local(rf_plan** plans, int n);
 

@@ -26,7 +26,7 @@ _c_dp = ctypes.POINTER(ctypes.c_double)
 
 # the ABI this binding was written against (include/randomfield_hip.h RF_ABI_MAJOR / RF_ABI_MINOR): load() refuses a library of
 # another major version or an older minor one
-ABI_MAJOR, ABI_MINOR = 5, 1
+ABI_MAJOR, ABI_MINOR = 5, 2
 FEATURES = {"realise": 1 << 0, "r2c": 1 << 1, "c2c": 1 << 2, "lognormal": 1 << 3, "potential": 1 << 4, "lensing": 1 << 5,
             "mt19937": 1 << 6, "mt19937_shared": 1 << 7, "multi_rank": 1 << 8, "generic_shapes": 1 << 9, "exchange_chunks": 1 << 10,
             "diagnostics": 1 << 11}
@@ -113,6 +113,7 @@ DIAG_SIGNATURES = {
     "rf_slab_exchange_local_reverse": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int]),
     "rf_slab_stats": (ctypes.c_int, [ctypes.c_void_p, _c_dp, _c_dp]),
     "rf_slab_set_exchange_standin": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "rf_slab_set_exchange_standin_ex": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
 }
 
 _lib = None
@@ -318,6 +319,10 @@ class DevicePlan(object):
         """Diagnostics (virtual rank of a multi-rank plan, no communicator): realise / realise_batch run the multi-GPU schedule with
         the all-to-all replaced by a copy kernel of ``workgroups`` workgroups (rf_slab_set_exchange_standin); 0 = off."""
         check(self._lib.rf_slab_set_exchange_standin(self._h, int(workgroups)), "rf_slab_set_exchange_standin")
+
+    def set_exchange_standin_ex(self, workgroups, read_percent=100, write_percent=100):
+        """The stand-in with the two directions of its traffic taken apart (rf_slab_set_exchange_standin_ex)."""
+        check(self._lib.rf_slab_set_exchange_standin_ex(self._h, int(workgroups), int(read_percent), int(write_percent)), "rf_slab_set_exchange_standin_ex")
 
     def set_stream(self, hip_stream):
         check(self._lib.rf_plan_set_stream(self._h, ctypes.c_void_p(hip_stream or 0)), "rf_plan_set_stream")

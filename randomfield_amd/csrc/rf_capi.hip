@@ -339,7 +339,7 @@ int queue_exchange_rccl(rf_plan* p, const void* W, void* R, hipStream_t s, int c
       const void* sp[16]; void* dp[16];
       int nb = 0;
       for (int h = 0; h < p->nranks; ++h) if (h != p->rank) { sp[nb] = src(c, h); dp[nb] = dst(c, h); ++nb; }
-      RF_HIP(launch_exchange_standin(sp, dp, nb, blk, p->standin_wg, s));
+      RF_HIP(launch_exchange_standin(sp, dp, nb, blk, p->standin_wg, p->standin_read_pct, p->standin_write_pct, (unsigned*)p->coll_scratch, s));
     }
     return 0;
   }

@@ -179,6 +179,17 @@ int rf_slab_set_exchange_standin(rf_plan* p, int workgroups) {
   RF_HIP(hipSetDevice(p->device));
   RF_HIP(hipStreamSynchronize(p->stream));
   p->standin_wg = workgroups;
+  p->standin_read_pct = p->standin_write_pct = 100;
+  return 0;
+}
+
+// the same with the two directions of the exchange's local traffic taken apart: the copy kernel reads read_percent and writes
+// write_percent of every block (100 / 100 = rf_slab_set_exchange_standin)
+int rf_slab_set_exchange_standin_ex(rf_plan* p, int workgroups, int read_percent, int write_percent) {
+  RF_REQUIRE(read_percent >= 0 && read_percent <= 100 && write_percent >= 0 && write_percent <= 100, "percentages must be in [0, 100]");
+  if (int rc = rf_slab_set_exchange_standin(p, workgroups)) return rc;
+  p->standin_read_pct = read_percent;
+  p->standin_write_pct = write_percent;
   return 0;
 }
 

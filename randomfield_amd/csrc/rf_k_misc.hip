@@ -12,23 +12,42 @@ namespace {
 // channels on the compute units (one 256-thread workgroup per channel) and in local HBM (every block read once, every block written
 // once), without the links.  Eight 16-byte loads in flight per thread, then eight stores; grid-stride over the blocks in turn.
 struct StandinBlocks { const char* src[16]; char* dst[16]; };
-__global__ __launch_bounds__(256) void exchange_standin_kernel(StandinBlocks blk, int nblk, unsigned long long bytes) {
+// read_pct / write_pct (0 .. 100): the share of every block that is read / written -- 100 / 100 is the copy; other values take the two
+// directions of the exchange's local traffic apart (reads without their writes, writes of a constant without reads, half of both ...)
+__global__ __launch_bounds__(256) void exchange_standin_kernel(StandinBlocks blk, int nblk, unsigned long long bytes, int read_pct, int write_pct,
+                                                               unsigned* __restrict__ sink) {
   typedef unsigned u4 __attribute__((ext_vector_type(4)));
   typedef __attribute__((address_space(1))) u4 gu4;
   const unsigned long long nvec = bytes / 16, stride = (unsigned long long)gridDim.x * 256;
+  const unsigned long long nr = nvec / 100 * (unsigned)read_pct, nw = nvec / 100 * (unsigned)write_pct;
+  const bool copy = read_pct == 100 && write_pct == 100;
+  u4 acc = {0u, 0u, 0u, 0u};
   for (int b = 0; b < nblk; ++b) {
     const gu4* s = (const gu4*)blk.src[b];
     gu4* d = (gu4*)blk.dst[b];
     unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
-    for (; i + 7 * stride < nvec; i += 8 * stride) {
-      u4 v[8];
+    if (copy) {
+      for (; i + 7 * stride < nvec; i += 8 * stride) {
+        u4 v[8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) v[k] = __builtin_nontemporal_load(s + i + k * stride);
+        for (int k = 0; k < 8; ++k) v[k] = __builtin_nontemporal_load(s + i + k * stride);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) __builtin_nontemporal_store(v[k], d + i + k * stride);
+        for (int k = 0; k < 8; ++k) __builtin_nontemporal_store(v[k], d + i + k * stride);
+      }
+      for (; i < nvec; i += stride) d[i] = s[i];
+    } else {
+      for (unsigned long long j = i; j + 7 * stride < nr; j += 8 * stride) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc ^= __builtin_nontemporal_load(s + j + k * stride);
+      }
+      const u4 c = {(unsigned)b, 1u, 2u, 3u};
+      for (unsigned long long j = i; j + 7 * stride < nw; j += 8 * stride) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) __builtin_nontemporal_store(c, d + j + k * stride);
+      }
     }
-    for (; i < nvec; i += stride) d[i] = s[i];
   }
+  if (!copy && (acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9e3779b9u && sink) *sink = acc.x;      // (keeps the reads alive; practically never taken)
 }
 
 template <typename T>
@@ -385,12 +404,13 @@ __global__ __launch_bounds__(256) void lensing_rows_kernel(const T* __restrict__
 
 }  // namespace
 
-hipError_t launch_exchange_standin(const void* const* src, void* const* dst, int nblk, size_t bytes, int workgroups, hipStream_t s) {
-  if (nblk < 0 || nblk > 16 || workgroups < 1 || bytes % 16) return hipErrorInvalidValue;
+hipError_t launch_exchange_standin(const void* const* src, void* const* dst, int nblk, size_t bytes, int workgroups, int read_pct, int write_pct,
+                                   unsigned* sink, hipStream_t s) {
+  if (nblk < 0 || nblk > 16 || workgroups < 1 || bytes % 16 || read_pct < 0 || read_pct > 100 || write_pct < 0 || write_pct > 100) return hipErrorInvalidValue;
   if (nblk == 0) return hipSuccess;
   StandinBlocks blk;
   for (int b = 0; b < 16; ++b) { blk.src[b] = b < nblk ? (const char*)src[b] : nullptr; blk.dst[b] = b < nblk ? (char*)dst[b] : nullptr; }
-  hipLaunchKernelGGL(exchange_standin_kernel, dim3((unsigned)workgroups), dim3(256), 0, s, blk, nblk, (unsigned long long)bytes);
+  hipLaunchKernelGGL(exchange_standin_kernel, dim3((unsigned)workgroups), dim3(256), 0, s, blk, nblk, (unsigned long long)bytes, read_pct, write_pct, sink);
   return hipGetLastError();
 }
 

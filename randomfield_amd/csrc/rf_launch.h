@@ -110,7 +110,9 @@ long long row_c2r_tiles(int f64, int M, long long nrows);
 
 // stand-in for the all-to-all of a kz-slab rank without a communicator (diagnostics): nblk <= 16 blocks of `bytes` bytes (a multiple of
 // 16) copied src[b] -> dst[b] by `workgroups` 256-thread workgroups
-hipError_t launch_exchange_standin(const void* const* src, void* const* dst, int nblk, size_t bytes, int workgroups, hipStream_t s);
+// (read_pct / write_pct: the share of every block that is read / written; 100 / 100 = the copy; sink: a device word nobody reads)
+hipError_t launch_exchange_standin(const void* const* src, void* const* dst, int nblk, size_t bytes, int workgroups, int read_pct, int write_pct,
+                                   unsigned* sink, hipStream_t s);
 // rows K,T,R,S into an API-layout k array [nx][ny][nz/2+1]
 hipError_t launch_gen_kspace(int f64, void* K, const GenParams& gp, hipStream_t s);
 // stats[0] = sum of partials[2i], stats[1] = sum of partials[2i+1]  (two levels through `scratch`, 512 doubles)

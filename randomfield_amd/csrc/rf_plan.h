@@ -73,6 +73,7 @@ struct rf_plan {
   hipStream_t comm_stream = nullptr;      // exchange stream of pipelined slab batches
   hipEvent_t pev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // fwd[2], exch[2], z[2]
   bool force_slab = false;                // single-rank plan routed through the slab pipeline (tests)
+  int standin_read_pct = 100, standin_write_pct = 100;   // ... and the share of the blocks it reads / writes (rf_slab_set_exchange_standin_ex)
   int standin_wg = 0;                     // rf_slab_set_exchange_standin: workgroups of the copy kernel that stands in for the all-to-all of a rank without a communicator
   // RF_FLAG_EXCHANGE_CHUNKS: the rank's kz slab as `xchunks` sub-slabs of nzl / xchunks planes, each generated, x- and y-transformed
   // and SENT on its own, so that the exchange of sub-slab c runs under the forward passes of sub-slab c + 1 (queue_c2r).  Layout:
