@@ -330,6 +330,29 @@ def main_multi(args, rank, world, local_rank, shape, power, spacing):
     plan.realise(seed=999)                             # eager single step: per-phase event times
     plan.sync()
     kern = np.array(plan.kernel_ms())                  # x, y, exchange+z, all-reduce
+    # exchange mode: the rank's kz slab as ONE block per peer, or as 4 sub-slabs (RF_FLAG_EXCHANGE_CHUNKS: 28 smaller sends in the same
+    # single group per realisation; the gathering z pass reads 4 x shorter segments, which one GPU's virtual ranks found 5 - 9 % faster,
+    # DESIGN.md section 5).  Neither layout has run over real links: both are timed on a few realisations and the faster one runs.
+    # (after the eager step above: single calls keep the plain one-stream sequence; the batch keeps ONE grouped exchange per realisation
+    # on the exchange stream whatever the layout)
+    chunks = 1
+    if world > 1 and mode == "exchange" and os.environ.get("RANDOMFIELD_EXCHANGE_CHUNKS", "auto") == "auto":
+        for c in (1, 4):
+            try:
+                plan.set_exchange_chunks(c)
+            except RuntimeError:
+                continue
+            plan.realise_batch(np.arange(7200, 7202, dtype=np.uint64), want_rms=False)
+            plan.sync()
+            dplan.barrier()
+            t0 = time.perf_counter()
+            plan.realise_batch(np.arange(7300, 7303, dtype=np.uint64), want_rms=False)
+            plan.sync()
+            dplan.barrier()
+            calib["exchange, %d sub-slab%s" % (c, "" if c == 1 else "s")] = float(dplan.allreduce([(time.perf_counter() - t0) / 3], op="max")[0]) * 1e3
+        best = min((k for k in calib if k.startswith("exchange, ")), key=calib.get, default=None)
+        chunks = 4 if best and best.startswith("exchange, 4") else 1
+        plan.set_exchange_chunks(chunks)
     plan.realise_batch(np.arange(1000, 1000 + max(args.warmup, 1), dtype=np.uint64), want_rms=False)
     plan.sync()
     dplan.barrier()
@@ -376,7 +399,7 @@ def main_multi(args, rank, world, local_rank, shape, power, spacing):
                                   "kz-slab generation + ONE RCCL all-to-all per realisation, overlapped with the next "
                                   "realisation's generation" if mode == "exchange" else
                                   "replicated generation: every rank generates all of k space and keeps its x slab, no all-to-all"),
-                   "grid": [nx, ny, nz], "rms_last": round(std, 6), "multi_gpu_mode": mode, "rccl_ranks": rccl_ranks,
+                   "grid": [nx, ny, nz], "rms_last": round(std, 6), "multi_gpu_mode": mode, "exchange_sub_slabs": chunks, "rccl_ranks": rccl_ranks,
                    "launcher": "bench.py's own child ranks" if os.environ.get("RANDOMFIELD_LAUNCH_NONCE", "").startswith("bench-") else "external (torch.distributed.run)",
                    "mode_calibration_ms_per_step": {k: round(v, 3) for k, v in calib.items()}},
         "single_gpu_equivalent": {"ms_per_step": round(t_single_max, 4), "ms_per_step_fastest_rank": round(t_single_min, 4),
