@@ -260,7 +260,7 @@ def other_configs(power, spacing, device, only=None):
         ent = {"forward_plus_backward_ms": round(f_ms + b_ms, 3),
                "standin_bytes_read": 7.0 / 8.0 * sweep2048 / 8.0, "standin_bytes_written": 7.0 / 8.0 * sweep2048 / 8.0}
         nreal = 8
-        for w in (16, 32):
+        for w in (16, 32, 128):                    # (16 / 32 = RCCL's channel footprint; 128 = a copy that is not its own bottleneck: the asymptote)
             p.set_exchange_standin(w)
             p.realise_batch(np.arange(3, dtype=np.uint64), want_rms=False)
             p.sync()
