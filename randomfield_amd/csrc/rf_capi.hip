@@ -488,8 +488,11 @@ int queue_yz(rf_plan* p, void* W, hipStream_t s, double* stats_out, bool timed) 
   // that rf_kernel_ms still means what it says
   // (rf_set_merged_yz(2) merges timed calls too, with an event behind every launch: rf_merged_yz_ms)
   static const bool merge_env = [] { const char* e = getenv("RANDOMFIELD_MERGE_YZ"); return !e || atoi(e) != 0; }();
-  if (merge_env && (timed ? p->yz_merge >= 2 : p->yz_merge >= 1) && !xp && !p->zscale && nslab > 1 && p->nx % B == 0 &&
-      yz_merged_fits(p->f64, p->ny, (int)p->nzc, gy, B * p->ny, B * nzl)) {
+  // (the last slab may be smaller -- a slab size that does not divide nx: RF_FLAG_YZ_SLAB_PLANES -- as long as both sizes fit the kernel)
+  const long long Blast = p->nx - (long long)(nslab - 1) * B;
+  if (merge_env && (timed ? p->yz_merge >= 2 : p->yz_merge >= 1) && !xp && !p->zscale && nslab > 1 &&
+      yz_merged_fits(p->f64, p->ny, (int)p->nzc, gy, B * p->ny, B * nzl) &&
+      (Blast == B || yz_merged_fits(p->f64, p->ny, (int)p->nzc, gy, B * p->ny, Blast * nzl))) {
     if (timed) {
       while ((int)p->slab_ev.size() < nslab + 1) { hipEvent_t e; RF_HIP(hipEventCreate(&e)); p->slab_ev.push_back(e); }
       p->slab_merged = nslab;
@@ -500,10 +503,11 @@ int queue_yz(rf_plan* p, void* W, hipStream_t s, double* stats_out, bool timed) 
     for (int i = 0; i < nslab; ++i) {
       char* Ws = (char*)W + (long long)i * B * plane;
       double* part = p->partials + 2 * (long long)i * B * tiles_per_plane;
+      const long long nb = i + 1 < nslab ? B : Blast, nb_next = i + 2 < nslab ? B : Blast;       // planes of slab i / of slab i + 1
       if (i + 1 < nslab)
-        RF_HIP(launch_yz_merged(p->f64, p->ny, (int)p->nzc, Ws, B * p->ny, scale, p->tw_z, part, Ws + B * plane, gy, B * nzl, p->tw_y, s));
+        RF_HIP(launch_yz_merged(p->f64, p->ny, (int)p->nzc, Ws, nb * p->ny, scale, p->tw_z, part, Ws + B * plane, gy, nb_next * nzl, p->tw_y, s));
       else
-        RF_HIP(launch_row_c2r(p->f64, (int)p->nzc, Ws, B * p->ny, scale, p->tw_z, part, s));
+        RF_HIP(launch_row_c2r(p->f64, (int)p->nzc, Ws, nb * p->ny, scale, p->tw_z, part, s));
       if (timed) RF_HIP(hipEventRecord(p->slab_ev[i + 1], s));
     }
     if (timed) { RF_HIP(hipEventRecord(p->ev[2], s)); RF_HIP(hipEventRecord(p->ev[3], s)); }
