@@ -2071,6 +2071,15 @@ def test_merged_yz_launches_give_the_same_field(hip, dpower):
     plan.set_merged_yz(0)
     plan.realise_batch(np.array([78], np.uint64), want_rms=False)          # (the captured graphs were dropped with the mode)
     assert np.array_equal(plan.download_real(), other)
+    # a slab size that does not divide nx: five slabs of 48 planes and one of 16, merged launches with a smaller last slab
+    plan.set_merged_yz(1)
+    plan.set_yz_slab_planes(48)
+    assert plan.yz_slabs() == (6, 48)
+    plan.realise_batch(np.array([78, 77], np.uint64), want_rms=False)
+    assert np.array_equal(plan.download_real(), ref) and plan.moments() == m0
+    plan.set_merged_yz(2)
+    plan.realise(seed=77)
+    assert np.array_equal(plan.download_real(), ref) and plan.merged_yz_ms()[1] == 5
     plan.close()
     # a FRESH plan whose first timed call is already merged: rf_kernel_ms must read the merged form's events only (the per-pass
     # event pairs of the one-launch-per-pass form were created for this plan but never recorded)
