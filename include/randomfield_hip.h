@@ -43,7 +43,7 @@ enum { RF_LAYOUT_DENSE = 0, RF_LAYOUT_PADDED = 1 };
  * this repository returned the constant 1 while the surface grew from ~20 to 70 entry points; 5.0 is the first version that means
  * something: the consumer surface below + the diagnostics of randomfield_hip_diag.h.) */
 #define RF_ABI_MAJOR 5
-#define RF_ABI_MINOR 2
+#define RF_ABI_MINOR 3
 #define RF_ABI_VERSION ((RF_ABI_MAJOR << 16) | RF_ABI_MINOR)
 int rf_version(void);                            /* (major << 16) | minor */
 /* bit mask of the groups of entry points this build exports (each bit: every function of the group is present and works as this
@@ -62,6 +62,7 @@ enum {
   RF_FEATURE_MULTI_RANK = 1 << 8,          /* nranks > 1 plans, rf_comm_*: kz slabs + one RCCL all-to-all (librccl is dlopen'ed by rf_comm_*) */
   RF_FEATURE_GENERIC_SHAPES = 1 << 9,      /* every even shape up to 8192 (complex64) / 4096 (complex128) per axis: rf_shape_supported(_dtype) == 2 */
   RF_FEATURE_EXCHANGE_CHUNKS = 1 << 10,    /* RF_FLAG_EXCHANGE_CHUNKS */
+  RF_FEATURE_DIRECT_EXCHANGE = 1 << 12,    /* rf_comm_enable_direct: the y pass stores into the peers' receive buffers (IPC-mapped), no all-to-all kernels */
   RF_FEATURE_DIAGNOSTICS = 1 << 11         /* the entry points of randomfield_hip_diag.h (timing per kernel, launch structure, virtual ranks) */
 };
 unsigned rf_abi_features(void);
@@ -269,6 +270,17 @@ int rf_elapsed_ms(rf_plan* plan, float* ms);
  * (torch.distributed / a file / MPI ...).  No-op requirement for nranks == 1. */
 int rf_comm_unique_id(void* id128);
 int rf_comm_init(rf_plan* plan, const void* id128);
+/* COLLECTIVE (every rank of the communicator calls it with the same `enable`).  The exchange WITHOUT send / receive kernels: the y pass
+ * of every rank stores its output tiles straight into the receive buffer of the rank that owns their x planes -- the buffers are
+ * mapped into the peers' address spaces once, here (hipIpcGetMemHandle / one ncclAllGather / hipIpcOpenMemHandle) -- and one tiny
+ * all-reduce per realisation is the barrier between the peers' stores and the z pass.  Local HBM traffic is then what the passes
+ * alone move (the grouped ncclSend / ncclRecv exchange reads every block and writes every segment once more: DESIGN.md section 5).
+ * The mapping is proved with markers stored from a kernel before it is used.  *enabled = 1: all ranks switched; 0: some rank could
+ * not (no IPC between these devices, a grid whose y-pass tiles straddle x planes ...) and ALL ranks keep the RCCL exchange -- that is
+ * not an error (return value 0).  Same fields either way, bit for bit.  enable = 0 switches back.  (No reference counterpart: the
+ * reference has no distributed code) */
+int rf_comm_enable_direct(rf_plan* plan, int enable, int* enabled);
+int rf_comm_direct_enabled(rf_plan* plan, int* enabled);
 /* ranks of the plan's communicator as RCCL counts them (ncclCommCount); 0 before rf_comm_init.  What a benchmark line states
  * as "did RCCL see N ranks" (the reference has no distributed code: SURVEY.md section 8e). */
 int rf_comm_size(rf_plan* plan, int* nranks);

@@ -65,6 +65,16 @@ int rf_slab_set_exchange_standin(rf_plan* plan, int workgroups);
 /* ... with the two directions of that traffic taken apart: the copy kernel reads read_percent and writes write_percent of every block
  * (100 / 100 = the call above; 100 / 0: the send side's reads alone; 0 / 100: the receive side's writes alone; 50 / 50: half the volume) */
 int rf_slab_set_exchange_standin_ex(rf_plan* plan, int workgroups, int read_percent, int write_percent);
+/* rf_comm_enable_direct (randomfield_hip.h) between n virtual ranks living on one device: every plan's y pass (rf_slab_forward) then
+ * stores into the receive buffers of the others -- plain device pointers here, IPC mappings on a real job -- and rf_slab_exchange_local
+ * is not called at all: forward on every rank, then backward on every rank.  enable = 0 unlinks.  Same fields, bit for bit. */
+int rf_slab_link_direct(rf_plan** plans, int n, int enable);
+/* ONE virtual rank through the schedule of the direct exchange (the counterpart of rf_slab_set_exchange_standin): rf_realise /
+ * rf_realise_batch run x pass, storing y pass, gathering z pass with the stores of block h going to segment h of the rank's OWN
+ * receive buffers -- pattern and volume of the real stores, without the links; the result is not a field (rf_download_real refuses).
+ * overlap = 1: in batches the storing y pass runs on the exchange stream beside the x / z passes of the neighbouring realisations (what a
+ * real job does, where that pass is link-bound); 0: everything on one stream.  on = 0 switches the stand-in off. */
+int rf_slab_set_direct_standin(rf_plan* plan, int on, int overlap);
 /* rf_mt_share_exchange (randomfield_hip.h) between n virtual ranks living on one device */
 int rf_mt_share_exchange_local(rf_plan** plans, int n);
 

@@ -26,10 +26,10 @@ _c_dp = ctypes.POINTER(ctypes.c_double)
 
 # the ABI this binding was written against (include/randomfield_hip.h RF_ABI_MAJOR / RF_ABI_MINOR): load() refuses a library of
 # another major version or an older minor one
-ABI_MAJOR, ABI_MINOR = 5, 2
+ABI_MAJOR, ABI_MINOR = 5, 3
 FEATURES = {"realise": 1 << 0, "r2c": 1 << 1, "c2c": 1 << 2, "lognormal": 1 << 3, "potential": 1 << 4, "lensing": 1 << 5,
             "mt19937": 1 << 6, "mt19937_shared": 1 << 7, "multi_rank": 1 << 8, "generic_shapes": 1 << 9, "exchange_chunks": 1 << 10,
-            "diagnostics": 1 << 11}
+            "diagnostics": 1 << 11, "direct_exchange": 1 << 12}
 
 # name -> (restype, argtypes); every symbol of include/randomfield_hip.h (the consumer surface) ...
 SIGNATURES = {
@@ -95,6 +95,8 @@ SIGNATURES = {
     "rf_comm_init": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "rf_comm_size": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]),
     "rf_comm_allreduce_f64": (ctypes.c_int, [ctypes.c_void_p, _c_dp, ctypes.c_int, ctypes.c_int]),
+    "rf_comm_enable_direct": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
+    "rf_comm_direct_enabled": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]),
 }
 # ... and of include/randomfield_hip_diag.h (per-kernel timing, launch structure, virtual ranks: tests, bench.py, tools)
 DIAG_SIGNATURES = {
@@ -114,6 +116,8 @@ DIAG_SIGNATURES = {
     "rf_slab_stats": (ctypes.c_int, [ctypes.c_void_p, _c_dp, _c_dp]),
     "rf_slab_set_exchange_standin": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "rf_slab_set_exchange_standin_ex": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "rf_slab_link_direct": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int]),
+    "rf_slab_set_direct_standin": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
 }
 
 _lib = None
@@ -673,6 +677,32 @@ class DevicePlan(object):
 
     def barrier(self):
         self.allreduce([0.0])
+
+    def enable_direct_exchange(self, on=True):
+        """COLLECTIVE over the plan's communicator (rf_comm_enable_direct): switch the exchange between the y and z passes to the
+        direct form -- every rank's y pass stores its output tiles straight into the (IPC-mapped) receive buffers of the ranks
+        that own their x planes, one tiny all-reduce per realisation as the barrier -- if EVERY rank can; returns whether the job
+        now runs that way (False: all ranks keep the grouped ncclSend / ncclRecv exchange).  Same fields either way."""
+        got = ctypes.c_int(0)
+        check(self._lib.rf_comm_enable_direct(self._h, 1 if on else 0, ctypes.byref(got)), "rf_comm_enable_direct")
+        return bool(got.value)
+
+    def direct_exchange_enabled(self):
+        got = ctypes.c_int(0)
+        check(self._lib.rf_comm_direct_enabled(self._h, ctypes.byref(got)), "rf_comm_direct_enabled")
+        return bool(got.value)
+
+    @staticmethod
+    def slab_link_direct(plans, on=True):
+        """Diagnostics: the direct exchange between virtual ranks on one device (rf_slab_link_direct) -- ``slab_forward`` on every
+        plan then stores into the others' receive buffers and ``slab_exchange_local`` is not called."""
+        arr = (ctypes.c_void_p * len(plans))(*[p._h.value for p in plans])
+        check(load().rf_slab_link_direct(arr, len(plans), 1 if on else 0), "rf_slab_link_direct")
+
+    def set_direct_standin(self, on=True, overlap=True):
+        """Diagnostics: one virtual rank through the schedule of the direct exchange, its stores landing in its own receive
+        buffers (rf_slab_set_direct_standin); not a field."""
+        check(self._lib.rf_slab_set_direct_standin(self._h, 1 if on else 0, 1 if overlap else 0), "rf_slab_set_direct_standin")
 
     def slab_forward(self, seed=0, noise=None, source="generate"):
         """Forward half of the slab pipeline on this rank's kz planes.  ``source``: 'generate' (rows K..S fused into the

@@ -50,6 +50,7 @@ int load_rccl() {
   RF_SYM(Send, "ncclSend")
   RF_SYM(Recv, "ncclRecv")
   RF_SYM(AllReduce, "ncclAllReduce")
+  RF_SYM(AllGather, "ncclAllGather")
   RF_SYM(GetErrorString, "ncclGetErrorString")
 #undef RF_SYM
   g_rccl.lib = h;
@@ -272,6 +273,76 @@ int queue_x(rf_plan* p, const GenParams& gp, const void* kspace, void* W, hipStr
   return 0;
 }
 
+// Does this plan exchange by storing its y pass's output straight into the peers' receive buffers (rf_plan.h `direct`)?
+bool direct_active(const rf_plan* p) {
+  return p->direct && (p->nranks > 1 || p->force_slab) && !p->replicate && !p->generic && !p->unpacked;
+}
+
+// The device table of destination bases the storing y pass reads (rf_fft.h DirectColIO): for receive buffer b, sub-slab c and
+// destination rank h, cell `off` of block h of the local sub-slab lands at  R_h + (rank * C + c) * blk_c + off  =  tab + h * blk_c + off.
+int rebuild_peer_tab(rf_plan* p) {
+  const int C = slab_chunks(p), P = p->nranks;
+  RF_REQUIRE((int)p->peer_R[0].size() == P && (int)p->peer_R[1].size() == P, "direct exchange: the peers' receive buffers are not known");
+  RF_REQUIRE(col_direct_supported(p->f64, p->ny, p->nzl / C),
+             "direct exchange: a y-pass tile would straddle two x planes (nz / (2 ranks chunks) is narrower than the tile)");
+  const long long blk_c = (long long)p->nxl * p->ny * (p->nzl / C) * (long long)p->csize;
+  std::vector<void*> h_tab((size_t)2 * C * P);
+  for (int b = 0; b < 2; ++b)
+    for (int c = 0; c < C; ++c)
+      for (int h = 0; h < P; ++h)
+        h_tab[((size_t)b * C + c) * P + h] = p->peer_R[b][h] ? (char*)p->peer_R[b][h] + ((long long)p->rank * C + c - h) * blk_c : nullptr;
+  RF_HIP(hipStreamSynchronize(p->stream));
+  if (p->comm_stream) RF_HIP(hipStreamSynchronize(p->comm_stream));
+  if (p->peer_tab) RF_HIP(hipFree(p->peer_tab));
+  p->peer_tab = nullptr;
+  RF_HIP(hipMalloc((void**)&p->peer_tab, h_tab.size() * sizeof(void*)));
+  RF_HIP(hipMemcpy(p->peer_tab, h_tab.data(), h_tab.size() * sizeof(void*), hipMemcpyHostToDevice));
+  p->peer_tab_chunks = C;
+  return 0;
+}
+
+// the barrier between the peers' stores into a receive buffer and its readers (and, the other way, between the readers of a receive
+// buffer and the next stores into it): a 2-double all-reduce on its own scratch words.  Virtual ranks (no communicator) are ordered
+// by the host that drives them.
+int direct_barrier(rf_plan* p, hipStream_t s) {
+  if (p->nranks > 1 && p->comm) RF_NCCL(g_rccl.AllReduce(p->coll_scratch + 2, p->coll_scratch + 2, 2, ncclFloat64, ncclSum, p->comm, s));
+  return 0;
+}
+
+// the y pass of sub-slab c (the whole kz slab when the plan does not chunk) out of W into the peers' receive buffers number `rbuf`
+int queue_y_direct(rf_plan* p, const void* W, int rbuf, hipStream_t s, int c) {
+  const int C = slab_chunks(p);
+  RF_REQUIRE(p->peer_tab && p->peer_tab_chunks == C && c >= 0 && c < C, "direct exchange: the destination table does not match the plan's exchange chunks");
+  RF_REQUIRE(p->peer_R[rbuf][p->rank] != nullptr, "direct exchange: the second receive buffer does not exist");
+  const long long nzc_ = p->nzl / C;
+  const ColGeom gy{nzc_, (long long)p->ny * nzc_, nzc_};
+  int shift = 0;
+  while ((1 << shift) < p->nxl) ++shift;
+  RF_HIP(launch_col_direct(p->f64, p->ny, (const char*)W + (size_t)c * chunk_bytes(p), gy, p->peer_tab + ((size_t)rbuf * C + c) * p->nranks, shift,
+                           (long long)p->nx * nzc_, p->tw_y, s));
+  return 0;
+}
+
+// The forward half of a plan in direct mode: sub-slab by sub-slab the x pass on stream A and the storing y pass on stream Y (Y == A: one
+// stream; Y != A: the stores of sub-slab c -- link-bound on a real job -- run beside the x pass of sub-slab c + 1).  The caller has
+// put the barrier that frees the receive buffers in front of it on Y.  `timed` (Y == A only): ev[5] / ev[1] / ev[2] as queue_xy.
+int direct_forward(rf_plan* p, const GenParams& gp, const void* kspace, void* W, int rbuf, hipStream_t A, hipStream_t Y, bool timed) {
+  const int C = slab_chunks(p);
+  const long long nzc_ = p->nzl / C;
+  if (Y != A)
+    while ((int)p->chunk_ev.size() < C + 1) { hipEvent_t e; RF_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); p->chunk_ev.push_back(e); }
+  for (int c = 0; c < C; ++c) {
+    if (C == 1) { if (int rc = queue_x(p, gp, kspace, W, A, timed)) return rc; }
+    else if (int rc = queue_x(p, gp, kspace, (char*)W + (size_t)c * chunk_bytes(p), A, false, p->kz0 + c * (int)nzc_, (int)nzc_)) return rc;
+    if (timed && C == 1) RF_HIP(hipEventRecord(p->ev[1], A));
+    if (Y != A) { RF_HIP(hipEventRecord(p->chunk_ev[c], A)); RF_HIP(hipStreamWaitEvent(Y, p->chunk_ev[c], 0)); }
+    if (int rc = queue_y_direct(p, W, rbuf, Y, c)) return rc;
+  }
+  if (timed && C > 1) { RF_HIP(hipEventRecord(p->ev[5], A)); p->repair_timed = false; RF_HIP(hipEventRecord(p->ev[1], A)); }
+  if (timed) RF_HIP(hipEventRecord(p->ev[2], A));          // (Y != A: the stores are still running on Y -- the x passes' end stands for both, as in the chunked rccl path)
+  return 0;
+}
+
 // x pass (generation or API k-space fused into its load) + y pass of buffer W on stream s.
 // Records ev[1] (after x) and ev[2] (after y) when `timed`.
 // the forward half of ONE sub-slab c of a plan that exchanges in chunks: x pass + y pass on its nzl / xchunks planes (region c of W)
@@ -285,7 +356,9 @@ int queue_xy_chunk(rf_plan* p, const GenParams& gp, const void* kspace, void* W,
   return 0;
 }
 
-int queue_xy(rf_plan* p, const GenParams& gp, const void* kspace, void* W, hipStream_t s, bool timed) {
+// (a plan in direct mode: the y pass stores into the peers' receive buffers `rbuf`, and what follows is the z pass, not an exchange)
+int queue_xy(rf_plan* p, const GenParams& gp, const void* kspace, void* W, hipStream_t s, bool timed, int rbuf) {
+  if (direct_active(p)) return direct_forward(p, gp, kspace, W, rbuf, s, s, timed);
   if (slab_chunks(p) > 1) {
     for (int c = 0; c < slab_chunks(p); ++c)
       if (int rc = queue_xy_chunk(p, gp, kspace, W, s, c)) return rc;
@@ -343,19 +416,88 @@ int queue_exchange_rccl(rf_plan* p, const void* W, void* R, hipStream_t s, int c
     }
     return 0;
   }
+  // (a failing send / receive must not leave the group open on this communicator: the first error is kept, the group is always closed)
   RF_NCCL(g_rccl.GroupStart());
-  for (int c = c0; c < c1; ++c)
-    for (int h = 0; h < p->nranks; ++h) {
+  ncclResult_t first = ncclSuccess;
+  const char* what = "";
+  for (int c = c0; c < c1 && first == ncclSuccess; ++c)
+    for (int h = 0; h < p->nranks && first == ncclSuccess; ++h) {
       if (h == p->rank) continue;
-      RF_NCCL(g_rccl.Send(src(c, h), blk, ncclUint8, h, p->comm, s));
-      RF_NCCL(g_rccl.Recv(dst(c, h), blk, ncclUint8, h, p->comm, s));
+      if ((first = g_rccl.Send(src(c, h), blk, ncclUint8, h, p->comm, s)) != ncclSuccess) { what = "ncclSend"; break; }
+      if ((first = g_rccl.Recv(dst(c, h), blk, ncclUint8, h, p->comm, s)) != ncclSuccess) { what = "ncclRecv"; break; }
     }
-  RF_NCCL(g_rccl.GroupEnd());
+  const ncclResult_t end = g_rccl.GroupEnd();
+  if (first != ncclSuccess) return fail(5, std::string(what) + " inside the grouped exchange failed: " + g_rccl.GetErrorString(first));
+  RF_NCCL(end);
   return 0;
 }
 
 int ensure_comm_stream(rf_plan* p) {
   if (!p->comm_stream) RF_HIP(hipStreamCreateWithFlags(&p->comm_stream, hipStreamNonBlocking));
+  return 0;
+}
+
+// second (send, receive) buffer pair, exchange stream and events of the pipelined batches
+int ensure_batch_buffers(rf_plan* p) {
+  if (!p->W2) {
+    RF_HIP(hipMalloc(&p->W2, p->w_bytes));
+    RF_HIP(hipMalloc(&p->R2, p->w_bytes));
+    if (int rc = ensure_comm_stream(p)) return rc;
+    for (auto& e : p->pev) RF_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  return 0;
+}
+
+// Pipelined batch of a plan in direct mode.  The y pass of realisation i stores into the PEERS' receive buffers i % 2 -- it is the
+// exchange, and on a real job it runs at the speed of the links -- so it goes to the exchange stream Y, where it runs beside the z pass of
+// realisation i - 1 and the x pass of realisation i + 1 on the compute stream A; B(i), a tiny all-reduce on Y, tells every rank that
+// all y(i) and all z(i - 1) are done:
+//   A:  x(0) | x(1)          z(0) | x(2)          z(1) | ...
+//   Y:  B(-1) y(0) B(0)    | y(1)   B(1)        | y(2)   B(2)        | ...
+// y(i) waits for x(i) (event) and follows B(i - 1) on Y: no peer still reads its receive buffer i % 2 (z(i - 2) is inside B(i - 1));
+// z(i) waits for B(i): every peer's stores of realisation i have landed; x(i + 2), which overwrites the send buffer y(i) read, follows
+// z(i) on A.  The local HBM traffic is that of the passes alone: no send-side reads, no receive-side writes by copy kernels.
+// (direct_overlap = 0: everything on A in the order x(i) y(i) z(i - 1) B(i).)
+int slab_batch_direct(rf_plan* p, const uint64_t* seeds, int n) {
+  RF_REQUIRE(p->nranks == 1 || p->comm || p->direct_standin, "virtual ranks linked for the direct exchange run step by step (rf_slab_forward, rf_slab_backward)");
+  void* Wb[2] = {p->W, p->W2};
+  void* Rb[2] = {p->R, p->R2};
+  hipEvent_t *ev_fwd = p->pev, *ev_bar = p->pev + 2, *ev_z = p->pev + 4;
+  const bool two = p->direct_overlap != 0;
+  hipStream_t A = p->stream, Y = two ? p->comm_stream : p->stream;
+  RF_HIP(hipEventRecord(p->ev[0], A));
+  if (two) { RF_HIP(hipEventRecord(ev_z[1], A)); RF_HIP(hipStreamWaitEvent(Y, ev_z[1], 0)); }     // whatever the plan's stream did before
+  if (int rc = direct_barrier(p, Y)) return rc;                   // B(-1): nobody is still reading (or sending from) a receive buffer
+  for (int i = 0; i <= n; ++i) {
+    const int b = i & 1, pb = (i - 1) & 1;
+    if (i < n) {
+      // (sub-slab by sub-slab when the plan chunks: x(c) on A, the stores of sub-slab c on Y behind an event)
+      if (int rc = direct_forward(p, make_gen(p, seeds[i], RF_NOISE_NATIVE, false), nullptr, Wb[b], b, A, Y, false)) return rc;
+      (void)ev_fwd;
+    }
+    if (i >= 1) {
+      if (two) RF_HIP(hipStreamWaitEvent(A, ev_bar[pb], 0));
+      if (int rc = queue_z_slab(p, Rb[pb], Wb[pb], p->stats + 2 * (i - 1), A)) return rc;
+      if (two) RF_HIP(hipEventRecord(ev_z[pb], A));
+    }
+    if (i < n) {
+      if (two && i >= 1) RF_HIP(hipStreamWaitEvent(Y, ev_z[pb], 0));
+      if (int rc = direct_barrier(p, Y)) return rc;               // B(i)
+      if (two) RF_HIP(hipEventRecord(ev_bar[b], Y));
+    }
+  }
+  if (p->nranks > 1 && p->comm) {                                 // the moments of all n realisations: one all-reduce, on the stream that drives the communicator
+    const int lb = (n - 1) & 1;
+    if (two) RF_HIP(hipStreamWaitEvent(Y, ev_z[lb], 0));
+    RF_NCCL(g_rccl.AllReduce(p->stats, p->stats, 2 * (size_t)n, ncclFloat64, ncclSum, p->comm, Y));
+    if (two) { RF_HIP(hipEventRecord(ev_bar[lb], Y)); RF_HIP(hipStreamWaitEvent(A, ev_bar[lb], 0)); }
+  }
+  RF_HIP(hipEventRecord(p->ev[4], A));
+  p->cur = Wb[(n - 1) & 1];
+  p->stats_slot = n - 1;
+  p->timed = false;
+  p->real_valid = !p->direct_standin;
+  p->stats_valid = true;
   return 0;
 }
 
@@ -390,12 +532,7 @@ int slab_batch(rf_plan* p, const uint64_t* seeds, int n) {
     p->stats_valid = true;
     return 0;
   }
-  if (!p->W2) {
-    RF_HIP(hipMalloc(&p->W2, p->w_bytes));
-    RF_HIP(hipMalloc(&p->R2, p->w_bytes));
-    if (int rc = ensure_comm_stream(p)) return rc;
-    for (auto& e : p->pev) RF_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  }
+  if (int rc = ensure_batch_buffers(p)) return rc;
   if (p->stats_cap < n) {
     RF_HIP(hipStreamSynchronize(p->stream));
     drop_graphs(p);
@@ -404,6 +541,7 @@ int slab_batch(rf_plan* p, const uint64_t* seeds, int n) {
     RF_HIP(hipMalloc((void**)&p->stats, 2 * (size_t)(n + 64) * sizeof(double)));
     p->stats_cap = n + 64;
   }
+  if (direct_active(p)) return slab_batch_direct(p, seeds, n);
   void* Wb[2] = {p->W, p->W2};
   void* Rb[2] = {p->R, p->R2};
   hipEvent_t *ev_fwd = p->pev, *ev_exch = p->pev + 2, *ev_z = p->pev + 4;
@@ -439,7 +577,7 @@ int slab_batch(rf_plan* p, const uint64_t* seeds, int n) {
   p->cur = Wb[(n - 1) & 1];
   p->stats_slot = n - 1;
   p->timed = false;
-  p->real_valid = true;
+  p->real_valid = !(p->nranks > 1 && !p->comm);        // (a stand-in exchange leaves this rank's own data in the segments: not a field)
   p->stats_valid = true;
   return 0;
 }
@@ -593,6 +731,35 @@ int queue_c2r(rf_plan* p, const GenParams& gp, const void* kspace) {
     p->stats_valid = true;
     return 0;
   }
+  if (direct_active(p)) {
+    // ONE realisation of a plan in direct mode: the storing y pass is the exchange.  Unchunked: x, B, y, B, z on the plan's stream.  In
+    // sub-slabs: the stores of sub-slab c go to the exchange stream and run beside the x pass of sub-slab c + 1.  The barrier in front
+    // keeps the stores away from a peer that still reads (or, in the forward transform's reverse exchange, sends from) its receive
+    // buffer; the one behind tells every rank that all stores have landed.  The communicator is driven from ONE stream per call.
+    RF_REQUIRE(p->nranks == 1 || p->comm || p->direct_standin, "virtual ranks linked for the direct exchange run step by step (rf_slab_forward, rf_slab_backward)");
+    const int C = slab_chunks(p);
+    const bool two = p->direct_overlap != 0 && C > 1;
+    if (int rc = ensure_comm_stream(p)) return rc;
+    while ((int)p->chunk_ev.size() < C + 1) { hipEvent_t e; RF_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); p->chunk_ev.push_back(e); }
+    hipStream_t A = p->stream, Y = two ? p->comm_stream : p->stream;
+    if (two) { RF_HIP(hipEventRecord(p->chunk_ev[C], A)); RF_HIP(hipStreamWaitEvent(Y, p->chunk_ev[C], 0)); }
+    if (int rc = direct_barrier(p, Y)) return rc;
+    if (int rc = direct_forward(p, gp, kspace, p->W, 0, A, Y, p->timed)) return rc;
+    if (int rc = direct_barrier(p, Y)) return rc;
+    if (two) { RF_HIP(hipEventRecord(p->chunk_ev[C], Y)); RF_HIP(hipStreamWaitEvent(A, p->chunk_ev[C], 0)); }
+    if (int rc = queue_z_slab(p, p->R, p->W, p->stats, A)) return rc;
+    if (p->timed) RF_HIP(hipEventRecord(p->ev[3], A));
+    if (p->nranks > 1 && p->comm) {
+      if (two) { RF_HIP(hipEventRecord(p->chunk_ev[C], A)); RF_HIP(hipStreamWaitEvent(Y, p->chunk_ev[C], 0)); }
+      RF_NCCL(g_rccl.AllReduce(p->stats, p->stats, 2, ncclFloat64, ncclSum, p->comm, Y));
+      if (two) { RF_HIP(hipEventRecord(p->chunk_ev[C], Y)); RF_HIP(hipStreamWaitEvent(A, p->chunk_ev[C], 0)); }
+    }
+    if (p->timed) RF_HIP(hipEventRecord(p->ev[4], A));
+    p->stats_slot = 0;
+    p->stats_valid = true;
+    if (p->direct_standin) p->real_valid = false;       // (the stores went to this rank's own buffers: no field came out)
+    return 0;
+  }
   if (slab_chunks(p) > 1) {
     // ONE realisation, exchange overlapped with its own forward half: sub-slab c is generated and x / y-transformed on the plan's
     // stream, its grouped send / receive goes to the exchange stream behind an event, the forward half of sub-slab c + 1 follows
@@ -625,6 +792,7 @@ int queue_c2r(rf_plan* p, const GenParams& gp, const void* kspace) {
     if (p->timed) RF_HIP(hipEventRecord(p->ev[4], A));
     p->stats_slot = 0;
     p->stats_valid = true;
+    if (p->nranks > 1 && !p->comm) p->real_valid = false;       // (stand-in exchange: not a field)
     return 0;
   }
   if (int rc = queue_xy(p, gp, kspace, p->W, p->stream, p->timed)) return rc;
@@ -650,6 +818,7 @@ int queue_c2r(rf_plan* p, const GenParams& gp, const void* kspace) {
     if (p->timed) RF_HIP(hipEventRecord(p->ev[4], p->stream));
     p->stats_slot = 0;
     p->stats_valid = true;
+    if (p->nranks > 1 && !p->comm) p->real_valid = false;       // (stand-in exchange: not a field)
     return 0;
   }
   return fail(1, "queue_c2r: unreachable");
@@ -689,7 +858,7 @@ int rf_version(void) { return RF_ABI_VERSION; }
 unsigned rf_abi_features(void) {
   return RF_FEATURE_REALISE | RF_FEATURE_R2C | RF_FEATURE_C2C | RF_FEATURE_LOGNORMAL | RF_FEATURE_POTENTIAL | RF_FEATURE_LENSING |
          RF_FEATURE_MT19937 | RF_FEATURE_MT19937_SHARED | RF_FEATURE_MULTI_RANK | RF_FEATURE_GENERIC_SHAPES | RF_FEATURE_EXCHANGE_CHUNKS |
-         RF_FEATURE_DIAGNOSTICS;
+         RF_FEATURE_DIRECT_EXCHANGE | RF_FEATURE_DIAGNOSTICS;
 }
 
 const char* rf_last_error(void) { return g_err.c_str(); }
@@ -767,7 +936,8 @@ int rf_plan_create(rf_plan** out, int nx, int ny, int nz, int dtype, int device,
   p->stats_cap = 64;
   if ((e = hipMalloc((void**)&p->partials, (2 * p->npartials + 512) * sizeof(double))) != hipSuccess ||
       (e = hipMalloc((void**)&p->stats, 2 * p->stats_cap * sizeof(double))) != hipSuccess ||
-      (e = hipMalloc((void**)&p->coll_scratch, 2 * sizeof(double))) != hipSuccess ||
+      (e = hipMalloc((void**)&p->coll_scratch, 4 * sizeof(double))) != hipSuccess ||      // [0..1] host-side all-reduces, [2..3] the direct exchange's barriers
+     
       (e = hipMalloc((void**)&p->kx2, nx * sizeof(double))) != hipSuccess ||
       (e = hipMalloc((void**)&p->ky2, ny * sizeof(double))) != hipSuccess ||
       (e = hipMalloc((void**)&p->kz2, (p->nzc + 1) * sizeof(double))) != hipSuccess ||
@@ -784,6 +954,7 @@ int rf_plan_create(rf_plan** out, int nx, int ny, int nz, int dtype, int device,
         (e = launch_col_fastgen(dtype, nx, p->W, gx, (long long)ny * nzl, fp0, 0, (int)nzl, p->tw_x, p->stream, true)) != hipSuccess ||
         (e = launch_col_plain(dtype, ny, +1, p->W, gy, (long long)nx * nzl, p->tw_y, p->stream, true)) != hipSuccess ||
         (e = launch_col_xpose(dtype, ny, p->W, gy, p->W, gy, (long long)nx * nzl, p->tw_y, p->stream, true)) != hipSuccess ||
+        (e = launch_col_direct(dtype, ny, p->W, gy, nullptr, 0, (long long)nx * nzl, p->tw_y, p->stream, true)) != hipSuccess ||
         (e = launch_col_plain_acc(dtype, ny, p->W, gy, (long long)nx * nzl, 0, (int)nzl, nullptr, p->tw_y, p->stream, true)) != hipSuccess ||
         (e = launch_row_c2r_lognormal(dtype, (int)nzc, p->W, (long long)p->nxl * ny, 1.0, nullptr, nullptr, p->tw_z, p->partials, p->stream, true)) != hipSuccess ||
         (yz_merged_supported(dtype, ny, (int)nzc) && (e = launch_yz_merged(dtype, ny, (int)nzc, p->W, 8, 1.0, p->tw_z, p->partials, p->W, ColGeom{p->nzl, (long long)ny * p->nzl, p->nzl}, 8, p->tw_y, p->stream, true)) != hipSuccess) ||
@@ -901,7 +1072,8 @@ int rf_plan_destroy(rf_plan* p) {
   if (p->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(p->comm);
   if (p->comm_stream) { (void)hipStreamSynchronize(p->comm_stream); (void)hipStreamDestroy(p->comm_stream); }
   for (auto& e : p->pev) if (e) (void)hipEventDestroy(e);
-  void* bufs[] = {p->W, p->R, p->W2, p->R2, p->K, p->P_base, p->G, p->tw_x, p->tw_y, p->tw_z, p->kx2, p->ky2, p->kz2, p->xt, p->st, p->sl, p->bin,
+  for (void* m : p->ipc_open) (void)hipIpcCloseMemHandle(m);
+  void* bufs[] = {p->peer_tab, p->W, p->R, p->W2, p->R2, p->K, p->P_base, p->G, p->tw_x, p->tw_y, p->tw_z, p->kx2, p->ky2, p->kz2, p->xt, p->st, p->sl, p->bin,
                   p->X, p->lntab, p->ypart, p->noise, p->mt_scratch, p->mt_send, p->mt_recv, p->mt_sbase, p->mt_first, p->mt_pos, p->mt_npos_dev, p->mt_states, p->mt_counts, p->mt_offsets, p->mt_rowtab, p->mt_flags, p->br_tmp, p->fixbuf, p->partials, p->stats, p->seeds_dev, p->ztab, p->frec, p->coll_scratch};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -943,9 +1115,12 @@ int rf_plan_set_flag(rf_plan* p, int flag, int value) {
     RF_REQUIRE(C == 1 || (nzc_ % 2 == 0 && ((long long)p->ny * nzc_) % col_tile_cols(p->f64, p->nx) == 0 &&
                           ((long long)p->ny * nzc_) % col_gen_tile_cols(p->f64, p->nx) == 0 && ((long long)p->nx * nzc_) % col_tile_cols(p->f64, p->ny) == 0),
                "too many exchange chunks for this grid: a sub-slab must hold an even number of planes and whole tiles of the x and y passes");
+    RF_REQUIRE(!p->direct || col_direct_supported(p->f64, p->ny, nzc_),
+               "too many exchange chunks for the direct exchange: a y-pass tile would straddle two x planes");
     p->xchunks = C;
     drop_graphs(p);
     p->real_valid = false;                       // (the buffers' layout between the passes changes; nothing resident survives it)
+    if (p->direct) return rebuild_peer_tab(p);
     return 0;
   }
   if (flag == RF_FLAG_YZ_SLAB_PLANES) {          // -1 automatic, 0 whole-grid passes, > 0 x planes per slab

@@ -31,7 +31,8 @@ int rf_comm_init(rf_plan* p, const void* id128) {
   memcpy(&id, id128, sizeof(id));
   RF_NCCL(g_rccl.CommInitRank(&p->comm, p->nranks, id, p->rank));
   // one tiny collective now: a broken communicator should fail here, not inside a timed region
-  RF_HIP(hipMemsetAsync(p->coll_scratch, 0, 2 * sizeof(double), p->stream));
+  RF_HIP(hipMemsetAsync(p->coll_scratch, 0, 4 * sizeof(double), p->stream));
+  p->standin_wg = 0;                       // (a stand-in exchange is a thing of ranks without a communicator)
   RF_NCCL(g_rccl.AllReduce(p->coll_scratch, p->coll_scratch, 2, ncclFloat64, ncclSum, p->comm, p->stream));
   RF_HIP(hipStreamSynchronize(p->stream));
   return 0;
@@ -153,6 +154,181 @@ int rf_slab_r2c_cols(rf_plan* p) {
   if (int rc = ensure_k(p)) return rc;
   if (int rc = queue_r2c_slab_cols(p, p->stream)) return rc;
   RF_HIP(hipStreamSynchronize(p->stream));
+  return 0;
+}
+
+/* ---- the direct exchange: the y pass stores into the peers' receive buffers ------------------- */
+namespace {
+// forget the peers (a failed set-up, or switching the mode off): unmap what this process mapped
+int direct_reset(rf_plan* p) {
+  RF_HIP(hipStreamSynchronize(p->stream));
+  if (p->comm_stream) RF_HIP(hipStreamSynchronize(p->comm_stream));
+  p->direct = false;
+  for (void* m : p->ipc_open) (void)hipIpcCloseMemHandle(m);
+  p->ipc_open.clear();
+  p->peer_R[0].clear(); p->peer_R[1].clear();
+  if (p->peer_tab) { RF_HIP(hipFree(p->peer_tab)); p->peer_tab = nullptr; }
+  p->peer_tab_chunks = 0;
+  return 0;
+}
+bool direct_shape_ok(const rf_plan* p) {
+  return !p->unpacked && !p->generic && col_direct_supported(p->f64, p->ny, p->nzl / slab_chunks(p));
+}
+// min over the communicator's ranks of a flag (1 = fine here), on the plan's stream
+int agree(rf_plan* p, bool mine, bool* all) {
+  double v[2] = {mine ? 1.0 : 0.0, 0.0};
+  RF_HIP(hipMemcpyAsync(p->coll_scratch, v, sizeof(v), hipMemcpyHostToDevice, p->stream));
+  RF_NCCL(g_rccl.AllReduce(p->coll_scratch, p->coll_scratch, 2, ncclFloat64, ncclMin, p->comm, p->stream));
+  RF_HIP(hipMemcpyAsync(v, p->coll_scratch, sizeof(v), hipMemcpyDeviceToHost, p->stream));
+  RF_HIP(hipStreamSynchronize(p->stream));
+  *all = v[0] > 0.5;
+  return 0;
+}
+}  // namespace
+
+// COLLECTIVE over the plan's communicator.  enable != 0: every rank publishes the IPC handles of its two receive buffers (one
+// ncclAllGather), maps its peers' buffers (hipIpcOpenMemHandle, peer access enabled lazily), proves the mapping with a marker that every
+// rank stores into every peer's buffer from a kernel and every rank then finds in its own, and only if ALL ranks succeeded switches
+// the plan to the direct exchange: *enabled = 1.  Any failure anywhere (no IPC between these devices, a shape whose y-pass tiles
+// straddle x planes ...) leaves every rank on the grouped ncclSend / ncclRecv exchange, *enabled = 0, return value 0 -- never a
+// job where some ranks store directly and others wait in a receive.  enable == 0: back to the RCCL exchange (also collective).
+int rf_comm_enable_direct(rf_plan* p, int enable, int* enabled) {
+  RF_REQUIRE(p && enabled, "null argument");
+  *enabled = 0;
+  RF_REQUIRE(!p->unpacked, "this call does not apply to an unpacked c2c plan");
+  RF_REQUIRE(p->nranks > 1 ? p->comm != nullptr : p->force_slab, "rf_comm_enable_direct needs rf_comm_init first (or, on one rank, RF_FLAG_FORCE_SLAB_PATH)");
+  RF_HIP(hipSetDevice(p->device));
+  drop_graphs(p);
+  if (!enable) return direct_reset(p);
+  if (p->direct) { *enabled = 1; return 0; }
+  if (int rc = direct_reset(p)) return rc;
+  const int P = p->nranks;
+  bool ok = direct_shape_ok(p) && !p->replicate;
+  if (ok && ensure_batch_buffers(p) != 0) ok = false;
+  if (P == 1) {                                  // the forced slab path of a single rank: its own buffers are all there is
+    if (!ok) return 0;
+    p->peer_R[0].assign(1, p->R); p->peer_R[1].assign(1, p->R2);
+    if (int rc = rebuild_peer_tab(p)) return rc;
+    p->direct = true; *enabled = 1;
+    return 0;
+  }
+  // 1. handles of R and R2, gathered from every rank: [P][2 handles + ok flag], 192 bytes per rank
+  constexpr size_t REC = 192;
+  static_assert(2 * sizeof(hipIpcMemHandle_t) + 8 <= REC, "record too small for two IPC handles");
+  std::vector<unsigned char> rec(REC * P, 0);
+  unsigned char* mine = rec.data() + REC * p->rank;
+  hipIpcMemHandle_t hd[2];
+  if (ok && (hipIpcGetMemHandle(&hd[0], p->R) != hipSuccess || hipIpcGetMemHandle(&hd[1], p->R2) != hipSuccess)) { ok = false; (void)hipGetLastError(); }
+  if (ok) { memcpy(mine, hd, sizeof(hd)); mine[2 * sizeof(hipIpcMemHandle_t)] = 1; }
+  unsigned char* dev = nullptr;
+  RF_HIP(hipMalloc((void**)&dev, REC * P));
+  auto done = [&](int rc) { (void)hipFree(dev); return rc; };
+  if (hipMemcpyAsync(dev + REC * p->rank, mine, REC, hipMemcpyHostToDevice, p->stream) != hipSuccess) return done(fail(2, "hipMemcpyAsync of the IPC handles failed"));
+  if (g_rccl.AllGather(dev + REC * p->rank, dev, REC, ncclUint8, p->comm, p->stream) != ncclSuccess) return done(fail(5, "ncclAllGather of the IPC handles failed"));
+  if (hipMemcpyAsync(rec.data(), dev, REC * P, hipMemcpyDeviceToHost, p->stream) != hipSuccess || hipStreamSynchronize(p->stream) != hipSuccess)
+    return done(fail(2, "reading back the gathered IPC handles failed"));
+  for (int h = 0; h < P; ++h) ok = ok && rec[REC * h + 2 * sizeof(hipIpcMemHandle_t)] == 1;
+  // 2. map the peers' buffers
+  std::vector<void*> R0(P, nullptr), R1(P, nullptr);
+  if (ok) {
+    R0[p->rank] = p->R; R1[p->rank] = p->R2;
+    for (int h = 0; h < P && ok; ++h) {
+      if (h == p->rank) continue;
+      hipIpcMemHandle_t ph[2];
+      memcpy(ph, rec.data() + REC * h, sizeof(ph));
+      for (int b = 0; b < 2 && ok; ++b) {
+        void* m = nullptr;
+        if (hipIpcOpenMemHandle(&m, ph[b], hipIpcMemLazyEnablePeerAccess) != hipSuccess || !m) { ok = false; (void)hipGetLastError(); break; }
+        p->ipc_open.push_back(m);
+        (b ? R1 : R0)[h] = m;
+      }
+    }
+  }
+  bool all = false;
+  if (int rc = agree(p, ok, &all)) return done(rc);
+  if (!all) { (void)hipFree(dev); return direct_reset(p); }
+  // 3. prove it: rank g stores the marker (tag + g) into slot g of every rank's two buffers, from a kernel, as the y pass will;
+  //    behind a barrier every rank must find all P markers in its own buffers (which are scratch between realisations)
+  p->peer_R[0] = R0; p->peer_R[1] = R1;
+  void** tabs = nullptr;
+  if (hipMalloc((void**)&tabs, 2 * P * sizeof(void*)) != hipSuccess) return done(fail(2, "hipMalloc failed"));
+  std::vector<void*> both(R0); both.insert(both.end(), R1.begin(), R1.end());
+  const unsigned long long tag = 0x5246444952000000ull;          // "RFDIR"
+  bool good = hipMemsetAsync(p->R, 0, 8 * P, p->stream) == hipSuccess && hipMemsetAsync(p->R2, 0, 8 * P, p->stream) == hipSuccess &&
+              hipMemcpyAsync(tabs, both.data(), 2 * P * sizeof(void*), hipMemcpyHostToDevice, p->stream) == hipSuccess;
+  if (int rc = direct_barrier(p, p->stream)) { (void)hipFree(tabs); return done(rc); }          // every rank has cleared its slots
+  good = good && launch_peer_mark(tabs, 2 * P, p->rank, tag + (unsigned)p->rank, p->stream) == hipSuccess;
+  if (int rc = direct_barrier(p, p->stream)) { (void)hipFree(tabs); return done(rc); }          // every rank's markers are on their way ... and have landed
+  std::vector<unsigned long long> got(2 * P, 0);
+  good = good && hipMemcpyAsync(got.data(), p->R, 8 * P, hipMemcpyDeviceToHost, p->stream) == hipSuccess &&
+         hipMemcpyAsync(got.data() + P, p->R2, 8 * P, hipMemcpyDeviceToHost, p->stream) == hipSuccess && hipStreamSynchronize(p->stream) == hipSuccess;
+  for (int g = 0; g < P && good; ++g) good = got[g] == tag + (unsigned)g && got[P + g] == tag + (unsigned)g;
+  (void)hipFree(tabs);
+  (void)hipGetLastError();
+  if (int rc = agree(p, good, &all)) return done(rc);
+  (void)hipFree(dev);
+  if (!all) return direct_reset(p);
+  if (int rc = rebuild_peer_tab(p)) { (void)direct_reset(p); return rc; }
+  p->direct = true;
+  *enabled = 1;
+  return 0;
+}
+
+int rf_comm_direct_enabled(rf_plan* p, int* enabled) {
+  RF_REQUIRE(p && enabled, "null argument");
+  *enabled = p->direct ? 1 : 0;
+  return 0;
+}
+
+// the same between n virtual ranks living on one device (their buffers are plain device pointers to one another); enable = 0 unlinks
+int rf_slab_link_direct(rf_plan** plans, int n, int enable) {
+  RF_REQUIRE(plans && n >= 1, "null argument");
+  for (int g = 0; g < n; ++g) {
+    RF_REQUIRE(plans[g] && plans[g]->nranks == n && plans[g]->rank == g, "plans must be ranks 0..n-1 of one n-rank job");
+    RF_REQUIRE(plans[g]->device == plans[0]->device && plans[g]->comm == nullptr, "virtual ranks live on one device and have no communicator");
+    RF_REQUIRE(!enable || (direct_shape_ok(plans[g]) && !plans[g]->replicate), "this plan's y-pass tiles would straddle x planes (or it replicates its generation): no direct exchange");
+  }
+  RF_HIP(hipSetDevice(plans[0]->device));
+  for (int g = 0; g < n; ++g) {
+    if (int rc = direct_reset(plans[g])) return rc;
+    if (enable) if (int rc = ensure_batch_buffers(plans[g])) return rc;
+  }
+  if (!enable) return 0;
+  for (int g = 0; g < n; ++g) {
+    rf_plan* p = plans[g];
+    p->peer_R[0].resize(n); p->peer_R[1].resize(n);
+    for (int h = 0; h < n; ++h) { p->peer_R[0][h] = plans[h]->R; p->peer_R[1][h] = plans[h]->R2; }
+    if (int rc = rebuild_peer_tab(p)) return rc;
+    p->direct = true;
+    p->standin_wg = 0;
+  }
+  return 0;
+}
+
+// ONE virtual rank through the schedule of the direct mode (the counterpart of rf_slab_set_exchange_standin): its y pass stores block h
+// into segment h of its OWN receive buffers -- the store pattern and volume of the real thing, minus the links; the result is not a field.
+// overlap: the batch's storing y pass on the exchange stream beside the neighbouring realisations' x / z passes (1) or everything on one stream (0)
+int rf_slab_set_direct_standin(rf_plan* p, int on, int overlap) {
+  RF_REQUIRE(p, "null plan");
+  RF_REQUIRE(!p->unpacked && !p->generic, "this call applies to packed plans on the tiled kernels");
+  RF_REQUIRE(p->nranks > 1 && p->comm == nullptr, "the direct stand-in is for a rank of a multi-rank plan without a communicator");
+  RF_HIP(hipSetDevice(p->device));
+  if (int rc = direct_reset(p)) return rc;
+  p->direct_standin = false;
+  if (!on) return 0;
+  RF_REQUIRE(direct_shape_ok(p) && !p->replicate, "this plan's y-pass tiles would straddle x planes (or it replicates its generation): no direct exchange");
+  if (int rc = ensure_batch_buffers(p)) return rc;
+  const long long blk = (long long)p->nxl * p->ny * p->nzl * (long long)p->csize;
+  p->peer_R[0].resize(p->nranks); p->peer_R[1].resize(p->nranks);
+  for (int h = 0; h < p->nranks; ++h) {
+    p->peer_R[0][h] = (char*)p->R + (long long)(h - p->rank) * blk;
+    p->peer_R[1][h] = (char*)p->R2 + (long long)(h - p->rank) * blk;
+  }
+  if (int rc = rebuild_peer_tab(p)) return rc;
+  p->direct = true;
+  p->direct_standin = true;
+  p->direct_overlap = overlap ? 1 : 0;
+  p->standin_wg = 0;
   return 0;
 }
 

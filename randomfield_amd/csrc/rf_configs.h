@@ -52,6 +52,9 @@ struct PairSel1024 { using type = ColCfg<float, 512, 8, 8, 8, 8, 256>; };
 #ifndef RF_Y_COL2_1024
 #define RF_Y_COL2_1024 1               // (rf_k_col_plain.hip launch_col_plain, rf_k_yz.hip: the in-place float32 pass of length 1024 in that form)
 #endif
+#ifndef RF_COL2_2048
+#define RF_COL2_2048 1                 // length-2048 float32 in-place / direct passes as two 1024-point transforms per tile (Col2); 0 = the whole-column kernels
+#endif
 #define RF_COL_SIZES(X) X(8) X(16) X(32) X(64) X(128) X(256) X(512) X(1024) X(2048)
 
 // ---- contiguous (z) pass: M = nz / 2 ----------------------------------------

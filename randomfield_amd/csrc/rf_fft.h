@@ -1048,6 +1048,33 @@ template <typename T> struct Pair2ColIO {
   static constexpr bool HAS_FINISH = false;
 };
 
+// ---------------------------------------------------------------------------
+// The y pass of a kz-slab rank that IS the exchange ("direct" mode): it reads the rank's array [nx][ny][nzl] and
+// stores every output tile straight into the receive buffer of the rank that owns the tile's x plane -- no send buffer, no copy
+// kernels, no local traffic beyond what the pass moves anyway.  A tile (all ny rows of TC kz columns of ONE ix) has exactly one
+// destination h = ix / nxl, and the destination's layout [source][nxl][ny][nzl] is the local one shifted by a per-destination base:
+//   cell (ix, iy, kz) of rank g   local:  ((ix * ny) + iy) * nzl + kz  =  h * blk + off
+//                                 remote: R_h + g * blk + off                               (blk = nxl * ny * nzl cells)
+// so tab[h] = R_h + (g - h) * blk and the store geometry is the load geometry.  `tab` lives in device memory (one scalar load per
+// tile); R_h is a peer-mapped pointer (hipIpcOpenMemHandle) on a real job and a plain device pointer between virtual ranks.
+// bind_tile() is called once per workgroup, before the passes.
+// ---------------------------------------------------------------------------
+template <typename T, bool WIDE = false> struct DirectColIO : PlainColIO<T, WIDE> {
+  cplx<T>* out = nullptr;
+  cplx<T>* const* tab = nullptr;
+  int dest_shift = 0;            // log2(x planes per destination rank)
+  RF_HD void bind_tile(long long C0) { out = tab[(C0 >> this->g.inner_shift()) >> dest_shift]; }
+  RF_HD void store(long long C0, int cl, int rb, int ro, const V16<T>& v) const { v16_store<T>(this->g.template at<WIDE>(out, C0, cl, rb, ro), v); }
+};
+// ... and the same for the passes that run as two half-length transforms per tile (Col2)
+template <typename T> struct Pair2DirectColIO : Pair2ColIO<T> {
+  cplx<T>* out = nullptr;
+  cplx<T>* const* tab = nullptr;
+  int dest_shift = 0;
+  RF_HD void bind_tile(long long C0) { out = tab[(C0 >> this->g.inner_shift()) >> dest_shift]; }
+  RF_HD void store(long long C0, int cl, int rb, int ro, const V16<T>& v) const { v16_store<T>(this->g.template at<false>(out, C0, cl, rb, ro), v); }
+};
+
 // exp(DIR * 2 pi i m / 16), m in [0, 8)
 template <int DIR, typename T> RF_HD cplx<T> w16_half(int m) {
   const T c1 = (T)0.92387953251128675613, s1 = (T)0.38268343236508977173, r = (T)0.70710678118654752440;

@@ -134,9 +134,6 @@ int col_tile_cols(int f64, int N) {
 
 hipError_t launch_col_plain(int f64, int N, int dir, void* base, ColGeom g, long long ncols, const void* tw,
                             hipStream_t s, bool po) {
-#ifndef RF_COL2_2048
-#define RF_COL2_2048 1                 // length-2048 float32 passes as two 1024-point transforms per tile (Col2); 0 = the whole-column kernels
-#endif
   if (RF_COL2_2048 && N == 2048 && !f64) {
     // (the radix-8-first 1024-point configuration: with 32 parked registers the 16-first one would not fit 128 VGPRs)
     using C1 = GenSel<float, 1024>::type;

@@ -50,6 +50,13 @@ __global__ __launch_bounds__(256) void exchange_standin_kernel(StandinBlocks blk
   if (!copy && (acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9e3779b9u && sink) *sink = acc.x;      // (keeps the reads alive; practically never taken)
 }
 
+// rf_comm_enable_direct's proof that the peers' receive buffers are really mapped: thread t stores `value` into word `slot` of bases[t]
+// -- a store from a kernel through the mapped pointer, which is what the storing y pass will do
+__global__ __launch_bounds__(64) void peer_mark_kernel(void* const* __restrict__ bases, int n, int slot, unsigned long long value) {
+  const int t = threadIdx.x;
+  if (t < n && bases[t]) reinterpret_cast<unsigned long long*>(bases[t])[slot] = value;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void gen_kspace_kernel(cplx<T>* __restrict__ K, GenParams gp) {
   const int nzh = gp.zpitch;            // this rank's planes + the Nyquist plane (nz/2 + 1 on one rank)
@@ -411,6 +418,12 @@ hipError_t launch_exchange_standin(const void* const* src, void* const* dst, int
   StandinBlocks blk;
   for (int b = 0; b < 16; ++b) { blk.src[b] = b < nblk ? (const char*)src[b] : nullptr; blk.dst[b] = b < nblk ? (char*)dst[b] : nullptr; }
   hipLaunchKernelGGL(exchange_standin_kernel, dim3((unsigned)workgroups), dim3(256), 0, s, blk, nblk, (unsigned long long)bytes, read_pct, write_pct, sink);
+  return hipGetLastError();
+}
+
+hipError_t launch_peer_mark(void* const* bases_dev, int n, int slot, unsigned long long value, hipStream_t s) {
+  if (n < 1 || n > 64 || slot < 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(peer_mark_kernel, dim3(1), dim3(64), 0, s, bases_dev, n, slot, value);
   return hipGetLastError();
 }
 

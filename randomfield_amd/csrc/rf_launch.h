@@ -45,6 +45,12 @@ hipError_t launch_col_plain(int f64, int N, int dir, void* base, ColGeom g, long
 // when the x pass left a transposed intermediate: DESIGN.md section 3.8)
 hipError_t launch_col_xpose(int f64, int N, const void* src, ColGeom gs, void* dst, ColGeom gd, long long ncols, const void* tw,
                             hipStream_t s, bool prepare_only = false);
+// the inverse pass out of place with every output tile stored through tab[ix >> dest_shift] instead of `src`'s own base (device table of
+// per-destination base pointers; ix = the tile's index of the slow column axis: rf_fft.h DirectColIO) -- the y pass of a kz-slab rank
+// writing straight into the receive buffers of the exchange
+bool col_direct_supported(int f64, int N, long long inner);
+hipError_t launch_col_direct(int f64, int N, const void* src, ColGeom g, void* const* tab, int dest_shift, long long ncols, const void* tw,
+                             hipStream_t s, bool prepare_only = false);
 int col_gen_tile_cols(int f64, int N);   // tile width of the generation-fused x pass of length N
 int col_gen_row_block(int f64, int N, int want);   // x rows per block of the transposed intermediate: `want`, or N when the pass cannot block
 // x pass of c2r fused with generation (kspace == nullptr) or reading an API-layout k array
@@ -113,6 +119,8 @@ long long row_c2r_tiles(int f64, int M, long long nrows);
 // (read_pct / write_pct: the share of every block that is read / written; 100 / 100 = the copy; sink: a device word nobody reads)
 hipError_t launch_exchange_standin(const void* const* src, void* const* dst, int nblk, size_t bytes, int workgroups, int read_pct, int write_pct,
                                    unsigned* sink, hipStream_t s);
+// word `slot` of each of the n <= 64 buffers bases_dev[t] (device table; null entries skipped) := value, stored from a kernel
+hipError_t launch_peer_mark(void* const* bases_dev, int n, int slot, unsigned long long value, hipStream_t s);
 // rows K,T,R,S into an API-layout k array [nx][ny][nz/2+1]
 hipError_t launch_gen_kspace(int f64, void* K, const GenParams& gp, hipStream_t s);
 // stats[0] = sum of partials[2i], stats[1] = sum of partials[2i+1]  (two levels through `scratch`, 512 doubles)

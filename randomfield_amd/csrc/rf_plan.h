@@ -51,6 +51,7 @@ struct Rccl {
   ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 extern Rccl g_rccl;
@@ -82,6 +83,16 @@ struct rf_plan {
   int xchunks = 1;
   std::vector<hipEvent_t> chunk_ev;       // forward half of chunk c queued (no timing)
   bool replicate = false;                 // multi-rank plan without an exchange: every rank generates all of k space (see queue_x)
+  // "direct" exchange: the y pass stores its output tiles straight into the receive buffers of the ranks that own
+  // their x planes (rf_fft.h DirectColIO) -- peer-mapped pointers between processes (rf_comm_enable_direct), plain device pointers between
+  // virtual ranks (rf_slab_link_direct) -- and one tiny all-reduce per realisation is the barrier between the peers' stores and the z pass
+  bool direct = false;
+  std::vector<void*> peer_R[2];           // host: every rank's R and R2 as THIS process addresses them ([rank] = its own)
+  void** peer_tab = nullptr;              // device: [2 buffers][chunks][nranks] destination bases, shifted as DirectColIO wants them
+  int peer_tab_chunks = 0;                // ... built for this many exchange chunks
+  std::vector<void*> ipc_open;            // peer mappings this process opened (closed at destroy)
+  bool direct_standin = false;            // rf_slab_set_direct_standin: the stores land in this rank's own buffers (no field comes out)
+  int direct_overlap = 1;                 // batches: 1 = the storing y pass on the exchange stream beside the neighbours' x / z passes, 0 = everything on one stream
   ncclComm_t comm = nullptr;
   size_t csize = 8;                       // bytes per complex element
   hipStream_t own_stream = nullptr, stream = nullptr;
@@ -203,7 +214,10 @@ int slab_chunks(const rf_plan* p);
 GenParams make_gen(rf_plan* p, uint64_t seed, int mode, bool seed_from_dev);
 int upload_noise(rf_plan* p, int mode, const double* noise_host);
 int queue_x(rf_plan* p, const GenParams& gp, const void* kspace, void* W, hipStream_t sx, bool timed = false, int kz0c = -1, int nzlc = -1);
-int queue_xy(rf_plan* p, const GenParams& gp, const void* kspace, void* W, hipStream_t s, bool timed);
+int queue_xy(rf_plan* p, const GenParams& gp, const void* kspace, void* W, hipStream_t s, bool timed, int rbuf = 0);
+int ensure_batch_buffers(rf_plan* p);
+int rebuild_peer_tab(rf_plan* p);
+int direct_barrier(rf_plan* p, hipStream_t s);
 int queue_yz(rf_plan* p, void* W, hipStream_t s, double* stats_out, bool timed);
 int queue_z_slab(rf_plan* p, const void* R, void* W, double* stats_out, hipStream_t s);
 int queue_r2c_slab_rows(rf_plan* p, hipStream_t s);

@@ -129,6 +129,12 @@ class Generator(object):
         them): k space is split by kz planes, the field by x planes, and every method works on this rank's
         ``nx / WORLD_SIZE`` planes of the field (``data_out`` has that many; see :mod:`randomfield_amd.slab`).  All ranks
         must make the same calls with the same arguments; ``seed=None`` is agreed between the ranks.
+    exchange : {None, 'auto', 'direct', 'rccl'}, optional
+        ``distributed=True``: how the blocks move between the y and z passes -- 'direct': every rank's y pass stores its output
+        straight into the IPC-mapped receive buffers of its peers (no send / receive kernels, no extra sweep of local memory);
+        'rccl': one grouped ncclSend / ncclRecv all-to-all; 'auto' (default, also ``RANDOMFIELD_EXCHANGE``): direct if every
+        rank can, else rccl.  The fields are identical.  ``exchange_chunks`` (or ``RANDOMFIELD_EXCHANGE_CHUNKS``: 'auto' = 1, or
+        a power of two) cuts the rank's kz slab into sub-slabs that travel while the next one is being generated.
     store_potential : bool, optional
         hip backend: ``generate_delta_field(save_potential=True)`` normally does not write delta(k)/k**2 to memory when it can be
         formed again on demand from the seed (``rng='native'``) or from the replayed deviates still on the device (complex64,
@@ -139,7 +145,7 @@ class Generator(object):
     def __init__(self, nx, ny, nz, grid_spacing_Mpc_h, num_plot_sections=4, cosmology=None, power=None,
                  verbose=False, *, backend=None, dtype=np.complex64, rng="reference", growth_function=None,
                  mean_matter_density=None, redshifts=None, transverse_distance=None, curvature_K=0.0, distributed=False,
-                 store_potential=False, exchange_chunks=None):
+                 store_potential=False, exchange_chunks=None, exchange=None):
         self.backend = transform.resolve_backend(backend)
         self.distributed = bool(distributed)
         self.store_potential = bool(store_potential)
@@ -154,15 +160,15 @@ class Generator(object):
             from . import slab
             if nx % 2 or ny % 2 or nz % 2:
                 raise ValueError("All shape dimensions must be even.")
-            self.plan_c2r = slab.SlabHostPlan(slab.DistributedPlan(nx, ny, nz, dtype), dtype)
+            self.plan_c2r = slab.SlabHostPlan(slab.DistributedPlan(nx, ny, nz, dtype, exchange=exchange), dtype)
             # every call here is ONE realisation.  Its all-to-all can be cut into sub-slabs that travel while the next sub-slab is
             # still being generated and transformed (RF_FLAG_EXCHANGE_CHUNKS) -- OPT-IN (`exchange_chunks=` or the environment
             # variable RANDOMFIELD_EXCHANGE_CHUNKS): the two-stream schedule is verified with virtual ranks and the forced slab
             # path on one GPU only; the default stays the plain forward -> exchange -> backward sequence on one stream until a
             # multi-GPU run has shown the same field and a gain
-            chunks = exchange_chunks if exchange_chunks is not None else int(os.environ.get("RANDOMFIELD_EXCHANGE_CHUNKS", "1") or 1)
-            if chunks < 1:
-                raise ValueError("exchange_chunks must be >= 1.")
+            chunks = slab.exchange_chunks_setting(exchange_chunks)      # (one parser for bench.py and this class)
+            if chunks == "auto":
+                chunks = 1
             if self.plan_c2r.device.nranks > 1 and chunks > 1:
                 self.plan_c2r.device.set_exchange_chunks(chunks)
             # generate.py:79-80: the forward plan over the same memory (here: this rank's window of the field in, its kz planes out)

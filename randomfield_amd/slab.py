@@ -20,7 +20,7 @@ import time
 
 import numpy as np
 
-__all__ = ["slab_layout", "exchange_blocks", "gather_rows", "side_array_planes", "split_side_array",
+__all__ = ["slab_layout", "exchange_blocks", "direct_store_bases", "exchange_chunks_setting", "exchange_mode_setting", "gather_rows", "side_array_planes", "split_side_array",
            "assemble_side_array", "shared_replay_layout", "shared_replay_pack", "exchange_unique_id", "launch_nonce", "init_process_group", "DistributedPlan", "SlabHostPlan", "SlabHostReversePlan", "Deadline"]
 
 
@@ -40,6 +40,46 @@ def exchange_blocks(local_k, nranks):
     nx = local_k.shape[0]
     nxl = nx // nranks
     return [local_k[h * nxl:(h + 1) * nxl] for h in range(nranks)]
+
+
+def direct_store_bases(nx, ny, nz, nranks, rank, chunks=1):
+    """The arithmetic of the DIRECT exchange (rf_capi.hip rebuild_peer_tab, rf_fft.h DirectColIO): rank ``rank``'s y pass stores every
+    output tile straight into the receive buffer of the rank h = ix // nxl that owns the tile's x plane.  The receive layout is
+    [source rank][chunk][nxl][ny][nzl / chunks] -- what the gathering z pass reads -- and a cell's offset inside its block is the same on
+    both sides, so the store address is the LOCAL cell offset plus a per-(chunk, destination) base.  Returns ``base[c][h]`` in cells,
+    relative to the start of rank h's receive buffer (it may be negative: the local offset of block h starts at h * blk):
+    cell ``off`` of sub-slab c's local array [nx][ny][nzl / chunks] goes to  receive_h[base[c][h] + off]."""
+    lay = slab_layout(nx, ny, nz, nranks, rank)
+    if lay["nzl"] % chunks:
+        raise ValueError("the number of exchange chunks must divide nz / (2 ranks)")
+    blk = lay["nxl"] * ny * (lay["nzl"] // chunks)
+    return [[(rank * chunks + c - h) * blk for h in range(nranks)] for c in range(chunks)]
+
+
+def exchange_chunks_setting(explicit=None):
+    """ONE parser for ``RANDOMFIELD_EXCHANGE_CHUNKS`` (bench.py, Generator): ``'auto'`` or an integer >= 1; ``explicit`` (an argument
+    of the caller) wins over the environment.  Returns 'auto' or the integer; anything else raises ValueError with the variable's name."""
+    raw = explicit if explicit is not None else os.environ.get("RANDOMFIELD_EXCHANGE_CHUNKS", "auto")
+    if raw is None or (isinstance(raw, str) and raw.strip().lower() in ("", "auto")):
+        return "auto"
+    try:
+        n = int(raw)
+    except (TypeError, ValueError):
+        raise ValueError("RANDOMFIELD_EXCHANGE_CHUNKS / exchange_chunks must be 'auto' or an integer >= 1, got %r" % (raw,))
+    if n < 1:
+        raise ValueError("RANDOMFIELD_EXCHANGE_CHUNKS / exchange_chunks must be >= 1, got %d" % n)
+    return n
+
+
+def exchange_mode_setting(explicit=None):
+    """``RANDOMFIELD_EXCHANGE``: how a multi-rank plan moves its blocks between the y and z passes -- 'direct' (the y pass stores into
+    the peers' IPC-mapped receive buffers; an error if some rank cannot), 'rccl' (grouped ncclSend / ncclRecv) or 'auto' (direct if
+    EVERY rank can, else rccl: the default)."""
+    raw = explicit if explicit is not None else os.environ.get("RANDOMFIELD_EXCHANGE", "auto")
+    mode = str(raw).strip().lower() or "auto"
+    if mode not in ("auto", "direct", "rccl"):
+        raise ValueError("RANDOMFIELD_EXCHANGE / exchange must be 'auto', 'direct' or 'rccl', got %r" % (raw,))
+    return mode
 
 
 def gather_rows(recv_blocks):
@@ -276,8 +316,9 @@ class DistributedPlan(object):
     ``plan.set_replicated_generation(True)`` switches to the communication-free mode (every rank generates all
     of k space and keeps its x slab; native generator only) -- see DESIGN.md section 5."""
 
-    def __init__(self, nx, ny, nz, dtype=np.complex64, device=None, rank=None, world=None):
+    def __init__(self, nx, ny, nz, dtype=np.complex64, device=None, rank=None, world=None, exchange=None):
         from . import _hip
+        mode = exchange_mode_setting(exchange)
         self.rank = int(os.environ.get("RANK", "0")) if rank is None else rank
         self.world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else world
         local_rank = int(os.environ.get("LOCAL_RANK", str(self.rank)))
@@ -292,11 +333,29 @@ class DistributedPlan(object):
             with self.deadline("RCCL communicator init"):
                 self.plan.comm_init(uid)      # collective: every rank calls it; ends with a tiny all-reduce
                 self.plan.barrier()
+            # the exchange without send / receive kernels, if every rank can map its peers' receive buffers (collective; all ranks
+            # get the same answer): DESIGN.md section 5.  ``exchange`` / RANDOMFIELD_EXCHANGE = 'rccl' keeps the grouped send / receive.
+            self.exchange = "rccl"
+            if mode != "rccl":
+                with self.deadline("direct exchange set-up"):
+                    try:
+                        got = self.plan.enable_direct_exchange(True)
+                    except RuntimeError:
+                        if mode == "direct":
+                            raise
+                        got = False
+                if got:
+                    self.exchange = "direct"
+                elif mode == "direct":
+                    raise RuntimeError("exchange='direct' was asked for, but not every rank could map its peers' receive buffers "
+                                       "(or the grid's y-pass tiles straddle x planes)")
             if self.rank == 0:
                 try:
                     os.remove(self._path)
                 except OSError:
                     pass
+        else:
+            self.exchange = "none"
 
     def deadline(self, what, seconds=None):
         """``with dist.deadline("first exchange"): ...`` -- a watchdog around a step every rank must reach (:class:`Deadline`)."""

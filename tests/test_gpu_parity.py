@@ -2124,3 +2124,147 @@ def test_one_call_same_seed_path_equals_the_two_calls(hip, dpower, shape):
     gen = Generator(nx, ny, nz, SPACING, backend="hip")
     d = gen.generate_delta_field(seed=321, save_potential=True)
     assert np.array_equal(d, two) and gen.potential is not None
+
+
+# ---- the direct exchange: the y pass stores into the peers' receive buffers -------------------------------
+def _slab_run_direct(hip, plans, **forward):
+    """forward on every (linked) virtual rank -- its y pass stores into the others' receive buffers --, then backward on every rank:
+    no exchange step at all"""
+    for p in plans:
+        p.slab_forward(**forward)
+    for p in plans:
+        p.slab_backward()
+    return np.concatenate([p.download_real() for p in plans], axis=0)
+
+
+@pytest.mark.parametrize("shape,dtype,nranks,chunks", [((64, 512, 128), np.complex64, 2, 1), ((64, 256, 256), np.complex64, 4, 2), ((64, 64, 512), np.complex64, 8, 1),
+                                                       ((32, 16, 128), np.complex128, 2, 2), ((32, 1024, 128), np.complex64, 4, 1), ((16, 2048, 128), np.complex64, 2, 2),
+                                                       ((1024, 512, 64), np.complex64, 2, 1), ((16, 1024, 64), np.complex128, 2, 1)])
+def test_direct_exchange_between_virtual_ranks_is_bit_identical(hip, dpower, shape, dtype, nranks, chunks):
+    """rf_slab_link_direct: the y pass of every virtual rank stores its tiles straight into the receive buffers of the ranks that own
+    their x planes (the layout the gathering z pass reads), instead of writing them in place for an all-to-all to move.  Same
+    arithmetic per tile, same cells in the same places: the field is that of the copy-exchange path bit for bit -- native generator,
+    host deviates through the exact chain, uploaded k space, the fused potential store; whole slabs and sub-slabs; every y-pass
+    kernel family (whole-column, two half-length transforms at 1024 and 2048, float64)."""
+    k, Pk = dpower
+    nx, ny, nz = shape
+    plans = _slab_plans(hip, shape, dtype, k, Pk, nranks)
+    noise = cpu_ref.reference_noise(5, nx * ny * (nz // 2 + 1))
+    for p in plans:
+        p.set_exchange_chunks(chunks)
+    want = {"native": _slab_run(hip, plans, seed=11), "host noise": _slab_run(hip, plans, noise=noise),
+            "potential": _slab_run(hip, plans, seed=11, source="potential")}
+    for p in plans:
+        p.generate(seed=12)
+    want["k space"] = _slab_run(hip, plans, source="kspace")
+    stats_want = [p.slab_stats() for p in plans]
+    hip.DevicePlan.slab_link_direct(plans)
+    got = {"native": _slab_run_direct(hip, plans, seed=11), "host noise": _slab_run_direct(hip, plans, noise=noise),
+           "potential": _slab_run_direct(hip, plans, seed=11, source="potential")}
+    for p in plans:
+        p.generate(seed=12)
+    got["k space"] = _slab_run_direct(hip, plans, source="kspace")
+    for key in want:
+        assert np.array_equal(got[key], want[key]), key
+    assert [p.slab_stats() for p in plans] == stats_want
+    assert want["native"].std() > 0 and not np.array_equal(want["native"], want["host noise"])
+    # linked virtual ranks have no barrier of their own: the whole-call entry points refuse them
+    with pytest.raises(RuntimeError):
+        plans[0].realise(seed=1)
+    # switching the sub-slab count while linked rebuilds the destination table; unlinking restores the copy-exchange path
+    if chunks == 1 and shape == (64, 512, 128):
+        for p in plans:
+            p.set_exchange_chunks(2)
+        a = _slab_run_direct(hip, plans, seed=11)
+        hip.DevicePlan.slab_link_direct(plans, False)
+        assert np.array_equal(_slab_run(hip, plans, seed=11), a)
+        for p in plans:
+            p.set_exchange_chunks(1)
+    hip.DevicePlan.slab_link_direct(plans, False)
+    assert np.array_equal(_slab_run(hip, plans, seed=11), want["native"])
+    for p in plans:
+        p.close()
+
+
+def test_direct_exchange_on_one_rank_through_the_whole_call_paths(hip, dpower):
+    """rf_comm_enable_direct on a single rank routed through the slab pipeline: rf_realise, rf_realise_potential + the Newtonian
+    potential and the pipelined batch run the direct mode's own schedules (storing y pass, barriers, both receive buffers, one and two
+    streams, whole slab and sub-slabs) and must give the plain single-GPU plan's fields."""
+    k, Pk = dpower
+    shape = (256, 128, 256)
+    plain = make_plan(hip, shape, np.complex64, k, Pk)
+    slab = make_plan(hip, shape, np.complex64, k, Pk)
+    with pytest.raises(RuntimeError):
+        slab.enable_direct_exchange()                        # neither a communicator nor the forced slab path
+    slab.set_force_slab_path(True)
+    assert slab.enable_direct_exchange() and slab.direct_exchange_enabled()
+    rms_ref = plain.realise_batch([5, 6, 7, 8])
+    last = plain.download_real()
+    std = plain.moments()[1]
+    for chunks in (1, 4, 1):
+        slab.set_exchange_chunks(chunks)
+        for seed in (3, 4):
+            plain.realise(seed=seed)
+            slab.realise(seed=seed)
+            assert np.max(np.abs(slab.download_real() - plain.download_real())) <= 1e-6 * std
+            assert abs(slab.moments()[1] - plain.moments()[1]) <= 1e-6 * std
+            assert len(slab.kernel_ms()) == 5
+        plain.realise_potential(seed=9)
+        slab.realise_potential(seed=9)
+        assert np.max(np.abs(slab.download_real() - plain.download_real())) <= 1e-6 * std
+        plain.load_potential(-1.5)
+        slab.load_potential(-1.5)
+        plain.execute_c2r()
+        slab.execute_c2r()
+        a, b = plain.download_real(), slab.download_real()
+        assert np.max(np.abs(a - b)) <= 2e-6 * a.std()
+        for n in (1, 2, 4):
+            assert np.allclose(slab.realise_batch([5, 6, 7, 8][:n]), rms_ref[:n], rtol=1e-6, atol=0)
+        assert np.max(np.abs(slab.download_real() - last)) <= 1e-6 * std
+    assert not slab.enable_direct_exchange(False) and not slab.direct_exchange_enabled()
+    slab.realise(seed=3)
+    plain.realise(seed=3)
+    assert np.max(np.abs(slab.download_real() - plain.download_real())) <= 1e-6 * std
+    slab.close()
+    plain.close()
+
+
+def test_direct_exchange_refuses_tiles_that_straddle_x_planes(hip, dpower):
+    """A y-pass tile has ONE destination only if it lies inside one x plane: kz slabs narrower than the tile keep the copy exchange."""
+    k, Pk = dpower
+    plans = _slab_plans(hip, (64, 32, 64), np.complex64, k, Pk, 4)          # 8 kz planes per rank, 32-column tiles
+    with pytest.raises(RuntimeError):
+        hip.DevicePlan.slab_link_direct(plans)
+    with pytest.raises(RuntimeError):
+        plans[0].set_direct_standin(True)
+    ref = _slab_run(hip, plans, seed=2)                                      # ... and still works
+    assert np.isfinite(ref).all() and ref.std() > 0
+    for p in plans:
+        p.close()
+
+
+def test_direct_standin_runs_the_direct_schedule_on_a_virtual_rank(hip, dpower):
+    """rf_slab_set_direct_standin (diagnostics, bench.py's config-4 entry): one rank of a multi-rank plan without a communicator through
+    the direct mode's schedules, its stores landing in its own receive buffers.  Not a field (the download refuses); finite,
+    reproducible moments; the same moments whether the batch's storing pass runs on the exchange stream or on the plan's."""
+    k, Pk = dpower
+    shape, P = (256, 64, 256), 4
+    plans = _slab_plans(hip, shape, np.complex64, k, Pk, P)
+    p = plans[2]
+    seen = []
+    for overlap in (True, False):
+        p.set_direct_standin(True, overlap=overlap)
+        p.realise(seed=3)
+        m1 = p.moments()
+        with pytest.raises(RuntimeError):
+            p.download_real()
+        rms = p.realise_batch([3, 4, 5])
+        p.realise(seed=3)
+        assert np.isfinite(m1[1]) and m1[1] > 0 and p.moments() == m1 and np.all(np.isfinite(rms)) and len(rms) == 3
+        seen.append(tuple(rms))
+    assert seen[0] == seen[1]
+    p.set_direct_standin(False)
+    with pytest.raises(RuntimeError):
+        p.realise(seed=3)                                    # back to "no communicator, no stand-in": loud
+    for q in plans:
+        q.close()
