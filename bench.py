@@ -280,6 +280,23 @@ def other_configs(power, spacing, device, only=None):
                                         "standin_alone_ms": round(seq - f_ms - b_ms, 3),
                                         "standin_alone_GBs_each_way": round(7.0 / 8.0 * sweep2048 / 8.0 / max(seq - f_ms - b_ms, 1e-3) / 1e6, 1)}
         p.set_exchange_standin(0)
+        # ... and through the schedule of the DIRECT exchange (rf_slab_set_direct_standin): the y pass stores block h into segment h of the
+        # rank's own receive buffers -- the store pattern and volume of the real thing (7/8 of them would cross the links) --, no copy
+        # kernel at all: what the scattered-destination, out-of-place y pass costs on this side of the links
+        for overlap in (False, True):
+            p.set_direct_standin(True, overlap=overlap)
+            p.realise_batch(np.arange(3, dtype=np.uint64), want_rms=False)
+            p.sync()
+            ts = []
+            for k in range(3):
+                t0 = time.perf_counter()
+                p.realise_batch(np.arange(100 * k, 100 * k + nreal, dtype=np.uint64), want_rms=False)
+                p.sync()
+                ts.append((time.perf_counter() - t0) / nreal * 1e3)
+            t_p = float(np.median(ts))
+            ent["direct exchange stand-in, %s" % ("storing y pass on the exchange stream" if overlap else "one stream")] = {
+                "pipelined_ms_per_realisation": round(t_p, 3), "slowdown_vs_forward_plus_backward": round(t_p / (f_ms + b_ms), 4)}
+        p.set_direct_standin(False)
         standin["rank %d" % r] = ent
         p.close()
     out["2048^3 / 8 kz slabs, per-rank compute on this GPU (virtual ranks, no exchange)"] = per_rank
@@ -293,7 +310,7 @@ def main_multi(args, rank, world, local_rank, shape, power, spacing):
     through RCCL (randomfield_amd/slab.py)."""
     from randomfield_amd import powertools, slab
     nx, ny, nz = shape
-    dplan = slab.DistributedPlan(nx, ny, nz, np.complex64, device=local_rank, rank=rank, world=world)
+    dplan = slab.DistributedPlan(nx, ny, nz, np.complex64, device=local_rank, rank=rank, world=world, exchange="rccl")      # (the modes are calibrated below)
     plan = dplan.plan
     if world == 1:        # --force-multi on one GPU (tests): the slab pipeline with a one-rank communicator, the exchange = a copy
         from randomfield_amd import _hip
@@ -301,60 +318,88 @@ def main_multi(args, rank, world, local_rank, shape, power, spacing):
         plan.comm_init(_hip.DevicePlan.comm_unique_id())
     plan.set_kgrid(*powertools.ksq_axes(nx, ny, nz, spacing))
     plan.set_power(*powertools.sigma_table(power, (nx, ny, nz), spacing))
-    # Two ways to run the slab decomposition: "exchange" = kz slabs + ONE RCCL all-to-all, pipelined
-    # behind the next realisation's generation; "replicate" = no all-to-all, every rank generates all of k space and keeps
-    # its x slab (P-fold redundant x-pass arithmetic).  xGMI is point to point, so which one is faster depends on how many
-    # links the job spans (2 GPUs share ONE link): measure both on a few realisations and take the faster.
-    mode = os.environ.get("RANDOMFIELD_MULTI_MODE", "auto")
-    calib = {}
+    # Three ways to run the slab decomposition, all giving the same field:
+    #   "direct"    kz slabs; the y pass of every rank stores its output straight into the IPC-mapped receive buffers of its peers, one
+    #               tiny all-reduce per realisation as the barrier -- no send / receive kernels, no extra sweep of local memory;
+    #   "rccl"      kz slabs + ONE grouped ncclSend / ncclRecv all-to-all per realisation, pipelined behind the next realisation's generation;
+    #   "replicate" no exchange: every rank generates all of k space and keeps its x slab (P-fold redundant x-pass arithmetic).
+    # xGMI is point to point, so which is fastest depends on how many links the job spans (2 GPUs share ONE link) and on what the links
+    # deliver: every candidate is timed on a few realisations and the fastest one runs.  A candidate must first reproduce the rccl mode's
+    # rms on the same seeds (they are all-reduced: every rank sees the same numbers and takes the same decision).
+    mode = os.environ.get("RANDOMFIELD_MULTI_MODE", "auto")            # auto | direct | rccl (= exchange) | replicate
+    if mode == "exchange":
+        mode = "rccl"
+    calib, rejected = {}, {}
     with dplan.deadline("first exchange"):            # a rank that died leaves the others blocked in the grouped send / receive: bounded
         plan.realise(seed=998)
         plan.sync()
         dplan.barrier()
-    if world > 1 and mode == "auto":
-        for m in ("exchange", "replicate"):
-            try:
-                plan.set_replicated_generation(m == "replicate")
-            except RuntimeError:          # shape without a replicated-generation instantiation: the exchange mode it is
+
+    def set_mode(m):
+        """switch the plan (collectively); False when this job cannot run that way"""
+        try:
+            if m == "replicate":
+                plan.enable_direct_exchange(False)
+                plan.set_replicated_generation(True)
+                return True
+            if world > 1:
+                plan.set_replicated_generation(False)
+            return plan.enable_direct_exchange(True) if m == "direct" else not plan.enable_direct_exchange(False)
+        except RuntimeError:              # a shape without that instantiation
+            return False
+
+    def trial(label, reference_rms=None):
+        """two realisations with their rms (warm-up + the equality check), then three timed ones: ms per realisation, max over ranks"""
+        rms = plan.realise_batch(np.arange(7000, 7002, dtype=np.uint64), want_rms=True)
+        plan.sync()
+        dplan.barrier()
+        if reference_rms is not None and not np.allclose(rms, reference_rms, rtol=1e-6, atol=0):
+            rejected[label] = "rms %r differs from the rccl exchange's %r on the same seeds" % ([float(v) for v in rms], [float(v) for v in reference_rms])
+            return rms
+        t0 = time.perf_counter()
+        plan.realise_batch(np.arange(7100, 7103, dtype=np.uint64), want_rms=False)
+        plan.sync()
+        dplan.barrier()
+        calib[label] = float(dplan.allreduce([(time.perf_counter() - t0) / 3], op="max")[0]) * 1e3
+        return rms
+
+    rms_rccl = None
+    if mode == "auto":                                # (one rank through --force-multi: the two kz-slab modes, the exchange = the own block)
+        for m in ("rccl", "direct", "replicate") if world > 1 else ("rccl", "direct"):
+            if not set_mode(m):
+                rejected[m] = "not available for this job (shape, or a rank could not map its peers' receive buffers)"
                 continue
-            plan.realise_batch(np.arange(7000, 7002, dtype=np.uint64), want_rms=False)
-            plan.sync()
-            dplan.barrier()
-            t0 = time.perf_counter()
-            plan.realise_batch(np.arange(7100, 7103, dtype=np.uint64), want_rms=False)
-            plan.sync()
-            dplan.barrier()
-            calib[m] = float(dplan.allreduce([(time.perf_counter() - t0) / 3], op="max")[0]) * 1e3
+            r = trial(m, rms_rccl)
+            if m == "rccl":
+                rms_rccl = r
         mode = min(calib, key=calib.get)
-    elif mode not in ("exchange", "replicate"):
-        mode = "exchange"
-    if world > 1:
-        plan.set_replicated_generation(mode == "replicate")
+    elif mode not in ("direct", "rccl", "replicate"):
+        mode = "rccl"
+    if not set_mode(mode):
+        raise RuntimeError("RANDOMFIELD_MULTI_MODE=%s is not available for this job" % mode)
     plan.realise(seed=999)                             # eager single step: per-phase event times
     plan.sync()
     kern = np.array(plan.kernel_ms())                  # x, y, exchange+z, all-reduce
-    # exchange mode: the rank's kz slab as ONE block per peer, or as 4 sub-slabs (RF_FLAG_EXCHANGE_CHUNKS: 28 smaller sends in the same
-    # single group per realisation; the gathering z pass reads 4 x shorter segments, which one GPU's virtual ranks found 5 - 9 % faster,
-    # DESIGN.md section 5).  Neither layout has run over real links: both are timed on a few realisations and the faster one runs.
-    # (after the eager step above: single calls keep the plain one-stream sequence; the batch keeps ONE grouped exchange per realisation
-    # on the exchange stream whatever the layout)
-    chunks = 1
-    if world > 1 and mode == "exchange" and os.environ.get("RANDOMFIELD_EXCHANGE_CHUNKS", "auto") == "auto":
-        for c in (1, 4):
-            try:
-                plan.set_exchange_chunks(c)
-            except RuntimeError:
-                continue
-            plan.realise_batch(np.arange(7200, 7202, dtype=np.uint64), want_rms=False)
-            plan.sync()
-            dplan.barrier()
-            t0 = time.perf_counter()
-            plan.realise_batch(np.arange(7300, 7303, dtype=np.uint64), want_rms=False)
-            plan.sync()
-            dplan.barrier()
-            calib["exchange, %d sub-slab%s" % (c, "" if c == 1 else "s")] = float(dplan.allreduce([(time.perf_counter() - t0) / 3], op="max")[0]) * 1e3
-        best = min((k for k in calib if k.startswith("exchange, ")), key=calib.get, default=None)
-        chunks = 4 if best and best.startswith("exchange, 4") else 1
+    # kz-slab modes: the rank's kz slab as ONE block per peer, or as 4 sub-slabs (RF_FLAG_EXCHANGE_CHUNKS; the gathering z pass then reads
+    # 4 x shorter segments, which one GPU's virtual ranks found 5 - 9 % faster, DESIGN.md section 5).  RANDOMFIELD_EXCHANGE_CHUNKS = an
+    # integer is honoured as given; 'auto' (default) times both layouts and keeps 4 only if it is faster AND reproduces the rms of 1.
+    from randomfield_amd.slab import exchange_chunks_setting
+    chunks, want_chunks = 1, exchange_chunks_setting()
+    if mode in ("direct", "rccl"):
+        if want_chunks == "auto":
+            rms1 = None
+            for c in (1, 4):
+                try:
+                    plan.set_exchange_chunks(c)
+                except RuntimeError:
+                    continue
+                r = trial("%s, %d sub-slab%s" % (mode, c, "" if c == 1 else "s"), rms1)
+                if c == 1:
+                    rms1 = r
+            best = min((k for k in calib if k.startswith(mode + ", ")), key=calib.get, default=None)
+            chunks = 4 if best and best.startswith(mode + ", 4") else 1
+        else:
+            chunks = int(want_chunks)
         plan.set_exchange_chunks(chunks)
     plan.realise_batch(np.arange(1000, 1000 + max(args.warmup, 1), dtype=np.uint64), want_rms=False)
     plan.sync()
@@ -387,9 +432,29 @@ def main_multi(args, rank, world, local_rank, shape, power, spacing):
     single.close()
     t_single_max = float(dplan.allreduce([t_single], op="max")[0])
     t_single_min = -float(dplan.allreduce([-t_single], op="max")[0])
+    # a labelled comparator, NOT this job: every GPU its own realisation of the WHOLE grid, no exchange (what a user with an ensemble
+    # of independent realisations gets from the node; it needs the whole grid to fit one GPU)
+    t_full = float("inf")
+    if world > 1:
+        try:
+            full = _hip.DevicePlan(nx, ny, nz, np.complex64, device=local_rank)
+            full.set_kgrid(*powertools.ksq_axes(nx, ny, nz, spacing))
+            full.set_power(*powertools.sigma_table(power, (nx, ny, nz), spacing))
+            full.realise_batch_prepare(1)
+            full.realise_batch(np.array([1], dtype=np.uint64), want_rms=False)
+            full.sync()
+            t0 = time.perf_counter()
+            for i in range(3):
+                full.realise_batch(np.array([2 + i], dtype=np.uint64), want_rms=False)
+            full.sync()
+            t_full = (time.perf_counter() - t0) / 3
+            full.close()
+        except RuntimeError:
+            pass                                      # (the whole grid does not fit one GPU: no such comparator)
+        t_full = float(dplan.allreduce([min(t_full, 1e9)], op="max")[0])
     cells = float(nx) * ny * nz
     sweep = 8.0 * nx * ny * (nz // 2 + 1)
-    xgmi_bytes = (world - 1) / world * sweep / world if mode == "exchange" else 0.0     # all-to-all egress per GPU
+    xgmi_bytes = (world - 1) / world * sweep / world if mode in ("direct", "rccl") else 0.0     # egress per GPU of the exchange
     out = {
         "metric": "Mcells/s for N^3 delta(x) realisation",
         "value": round(cells * args.steps / wall / 1e6, 1), "unit": "Mcells/s",
@@ -399,17 +464,23 @@ def main_multi(args, rank, world, local_rank, shape, power, spacing):
         "config": {"workload": "%dx%dx%d float32 delta(x) realisations, x-slab decomposition over %d GPUs (%s), "
                                "native Philox4x32-7 RNG, shipped 500-row P(k)"
                                % (nx, ny, nz, world,
-                                  "kz-slab generation + ONE RCCL all-to-all per realisation, overlapped with the next "
-                                  "realisation's generation" if mode == "exchange" else
-                                  "replicated generation: every rank generates all of k space and keeps its x slab, no all-to-all"),
+                                  {"rccl": "kz-slab generation + ONE RCCL all-to-all per realisation, overlapped with the next realisation's generation",
+                                   "direct": "kz-slab generation; the y pass stores into the peers' IPC-mapped receive buffers (the exchange), "
+                                             "one tiny all-reduce per realisation as the barrier",
+                                   "replicate": "replicated generation: every rank generates all of k space and keeps its x slab, no all-to-all"}[mode]),
                    "grid": [nx, ny, nz], "rms_last": round(std, 6), "multi_gpu_mode": mode, "exchange_sub_slabs": chunks, "rccl_ranks": rccl_ranks,
                    "launcher": "bench.py's own child ranks" if os.environ.get("RANDOMFIELD_LAUNCH_NONCE", "").startswith("bench-") else "external (torch.distributed.run)",
-                   "mode_calibration_ms_per_step": {k: round(v, 3) for k, v in calib.items()}},
+                   "mode_calibration_ms_per_step": {k: round(v, 3) for k, v in calib.items()},
+                   "modes_rejected": rejected},
         "single_gpu_equivalent": {"ms_per_step": round(t_single_max, 4), "ms_per_step_fastest_rank": round(t_single_min, 4),
                                   "grid": [e, e, e], "Mcells_s": round(float(e) ** 3 / t_single_max / 1e3, 1),
                                   "speedup_of_this_job": round(cells * args.steps / wall / (float(e) ** 3 / (t_single_max * 1e-3)), 3),
                                   "note": "every rank alone on its own GPU in this same job (%d^3, %d realisations from one hipGraph, "
-                                          "as `--gpus 1`); slowest rank quoted" % (e, args.steps)},
+                                          "as `--gpus 1`); slowest rank quoted" % (e, args.steps),
+                                  # NOT config 4 and not `value`: N independent realisations of the whole grid, one per GPU, no exchange
+                                  "ensemble_Mcells_s": (round(world * cells / t_full / 1e6, 1) if world > 1 and t_full < 1e8 else None),
+                                  "ensemble_note": "comparator only: every GPU generates its OWN %dx%dx%d realisation (no slab decomposition, no "
+                                                   "exchange; slowest rank): what an ensemble of independent realisations gets from the node" % (nx, ny, nz)},
         "pipeline": {"algorithmic_GBs": round(5 * sweep * args.steps / wall / 1e9, 1),
                      "frac_of_hbm_peak": round(5 * sweep * args.steps / wall / 1e9 / (HBM_PEAK_GBS * world), 4),
                      "kernel_ms_rank0_unpipelined_step": {"x": round(float(kern[0]), 4), "y": round(float(kern[1]), 4),

@@ -367,3 +367,121 @@ def test_deadline_names_the_missing_rank_and_exits(tmp_path):
             del os.environ["TMPDIR"]
         else:
             os.environ["TMPDIR"] = old
+
+
+def _direct_worker(rank, world, port, shape, chunks, out_dir):
+    """The DIRECT exchange between processes (rf_comm_enable_direct), modelled on the CPU: every rank's receive buffer lives in a
+    shared-memory segment (the stand-in for a hipMalloc'ed buffer + hipIpcGetMemHandle), its NAME is the handle that one all-gather
+    hands to every rank, every rank maps its peers' segments (hipIpcOpenMemHandle), proves the mapping with markers, and then its
+    "y pass" stores every output tile at  local cell offset + slab.direct_store_bases()[chunk][destination]  in the destination's
+    buffer -- the arithmetic of rf_capi.hip rebuild_peer_tab.  One barrier, then the gathering z pass reads [source][chunk][nxl][ny][nzl/C]."""
+    import torch.distributed as dist
+    from multiprocessing import shared_memory
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from oracle import cpu_ref
+    from randomfield_amd import slab
+    d, r, w, lr = slab.init_process_group()
+    nx, ny, nz = shape
+    lay = slab.slab_layout(nx, ny, nz, world, rank)
+    nxl, nzl, nzc = lay["nxl"], lay["nzl"], nz // 2
+    nzs = nzl // chunks
+    cells = nx * ny * nzl                                     # == nxl * ny * nzc: the receive buffer is as large as the local array
+    # 1. the receive buffer and its handle
+    seg = shared_memory.SharedMemory(create=True, size=cells * 16)
+    mine_R = np.ndarray((cells,), np.complex128, buffer=seg.buf)
+    mine_R[:] = np.nan
+    handles = [None] * world
+    dist.all_gather_object(handles, seg.name)
+    # 2. map the peers' buffers
+    peers, views = [], []
+    for h in range(world):
+        if h == rank:
+            peers.append(seg)
+            views.append(mine_R)
+        else:
+            s = shared_memory.SharedMemory(name=handles[h])
+            peers.append(s)
+            views.append(np.ndarray((cells,), np.complex128, buffer=s.buf))
+    # 3. prove it: marker (1000 + me) into slot `me` of every buffer, barrier, every rank finds all markers in its own
+    for h in range(world):
+        views[h][rank] = 1000 + rank
+    dist.barrier()
+    assert [mine_R[g].real for g in range(world)] == [1000 + g for g in range(world)]
+    dist.barrier()
+    mine_R[:] = np.nan
+    dist.barrier()
+    # the rank's kz slab after the x and y passes, sub-slab by sub-slab: local array [chunk][nx][ny][nzl / C]
+    pw = np.load(os.path.join(ROOT, "tests", "golden", "default_power.npz"))
+    noise = cpu_ref.reference_noise(11, nx * ny * (nz // 2 + 1))
+    full_k = cpu_ref.generate_kspace(nx, ny, nz, 2.5, pw["k"], pw["Pk"], noise=noise, dtype=np.complex128)
+    packed = full_k[:, :, :nzc].copy()
+    packed[:, :, 0] = full_k[:, :, 0] + 1j * full_k[:, :, nzc]
+    base = slab.direct_store_bases(nx, ny, nz, world, rank, chunks)
+    for c in range(chunks):
+        kz0 = lay["kz0"] + c * nzs
+        sub = np.fft.ifft(np.fft.ifft(packed[:, :, kz0:kz0 + nzs], axis=0), axis=1) * (nx * ny)      # [nx][ny][nzs], x and y passes
+        # THE stores of the y pass: a tile = all ny rows of some kz columns of ONE ix; destination h = ix // nxl
+        for ix in range(nx):
+            h = ix // nxl
+            off = (ix * ny + np.arange(ny)[:, None]) * nzs + np.arange(nzs)[None, :]               # local cell offsets of the plane's rows
+            views[h][base[c][h] + off] = sub[ix]
+    dist.barrier()                                            # the tiny all-reduce: every rank's stores have landed
+    assert not np.isnan(mine_R).any()                         # every cell of the receive buffer was written exactly by its owner
+    rows = mine_R.reshape(world, chunks, nxl, ny, nzs).transpose(2, 3, 0, 1, 4).reshape(nxl, ny, nzc)
+    half = np.empty((nxl, ny, nzc + 1), np.complex128)
+    half[:, :, :nzc] = rows
+    half[:, :, 0] = rows[:, :, 0].real
+    half[:, :, nzc] = rows[:, :, 0].imag
+    delta = np.fft.irfft(half, n=nz, axis=2) / (nx * ny)
+    np.save(os.path.join(out_dir, "direct%d.npy" % rank), delta)
+    dist.barrier()                                            # nobody unmaps while a peer still reads
+    del views, mine_R
+    for h, s in enumerate(peers):
+        s.close()
+    dist.barrier()
+    seg.unlink()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,shape,chunks", [(2, (8, 8, 16), 1), (2, (8, 4, 32), 2), (4, (16, 8, 64), 2)])
+def test_direct_exchange_processes(tmp_path, world, shape, chunks):
+    """The hand-off of the direct exchange between PROCESSES: handles gathered, peers' buffers mapped, markers, stores at
+    local offset + per-destination base, one barrier -- and every rank's x slab of the field comes out."""
+    pytest.importorskip("torch")
+    import torch.multiprocessing as mp
+    from oracle import cpu_ref
+    mp.spawn(_direct_worker, args=(world, _free_port(), shape, chunks, str(tmp_path)), nprocs=world, join=True)
+    nx, ny, nz = shape
+    pw = np.load(os.path.join(ROOT, "tests", "golden", "default_power.npz"))
+    noise = cpu_ref.reference_noise(11, nx * ny * (nz // 2 + 1))
+    ref, rms = cpu_ref.generate_delta_field(nx, ny, nz, 2.5, pw["k"], pw["Pk"], noise=noise, dtype=np.complex128)
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), "direct%d.npy" % r))
+        x0 = r * (nx // world)
+        assert np.allclose(got, ref[x0:x0 + nx // world], rtol=0, atol=1e-12 * rms)
+
+
+def test_direct_store_bases_and_settings(monkeypatch):
+    from randomfield_amd import slab
+    # rank g, destination h, chunk c: base = (g C + c - h) * block cells; a cell of block h lands in segment (g, c) of rank h
+    b = slab.direct_store_bases(16, 8, 64, 4, 2, chunks=2)
+    blk = 4 * 8 * 4
+    assert b[1][3] == (2 * 2 + 1 - 3) * blk and b[0][0] == 4 * blk and len(b) == 2 and len(b[0]) == 4
+    for raw, want in ((None, "auto"), ("auto", "auto"), ("", "auto"), ("4", 4), (2, 2)):
+        monkeypatch.delenv("RANDOMFIELD_EXCHANGE_CHUNKS", raising=False)
+        if isinstance(raw, str):
+            monkeypatch.setenv("RANDOMFIELD_EXCHANGE_CHUNKS", raw)
+            assert slab.exchange_chunks_setting() == want
+        else:
+            assert slab.exchange_chunks_setting(raw) == want
+    monkeypatch.setenv("RANDOMFIELD_EXCHANGE_CHUNKS", "many")
+    with pytest.raises(ValueError):
+        slab.exchange_chunks_setting()
+    with pytest.raises(ValueError):
+        slab.exchange_chunks_setting(0)
+    assert slab.exchange_chunks_setting(8) == 8                  # (an explicit argument wins over the environment)
+    monkeypatch.setenv("RANDOMFIELD_EXCHANGE", "RCCL")
+    assert slab.exchange_mode_setting() == "rccl" and slab.exchange_mode_setting("direct") == "direct"
+    with pytest.raises(ValueError):
+        slab.exchange_mode_setting("nvlink")

@@ -969,6 +969,20 @@ def test_config4_shapes_with_virtual_ranks(hip, dpower):
         for x in planes:
             if r * nxl <= x < (r + 1) * nxl:
                 assert np.array_equal(p.download_real(x0=x - r * nxl, x1=x - r * nxl + 1), unchunked[(r, x)]), "plane %d of rank %d, chunked" % (x, r)
+    # ... and with the DIRECT exchange (rf_slab_link_direct): every rank's y pass stores its 2048-point tiles straight into the receive
+    # buffers of the eight x-slab owners, nothing is copied afterwards -- whole slabs, then 4 sub-slabs: not one bit differs
+    for chunks in (1, 4):
+        hip.DevicePlan.slab_link_direct(plans, False)
+        for p in plans:
+            p.set_exchange_chunks(chunks)
+        hip.DevicePlan.slab_link_direct(plans)
+        for p in plans:
+            p.slab_forward(seed=4)
+        for r, p in enumerate(plans):
+            p.slab_backward()
+            for x in planes:
+                if r * nxl <= x < (r + 1) * nxl:
+                    assert np.array_equal(p.download_real(x0=x - r * nxl, x1=x - r * nxl + 1), unchunked[(r, x)]), "plane %d of rank %d, direct, %d sub-slabs" % (x, r, chunks)
     for p in plans:
         p.close()
 
@@ -1882,6 +1896,10 @@ def test_bench_multi_gpu_code_path_with_one_rank(hip):
     # what RCCL itself says the communicator spans, and the N = 1 equivalent timed in the same job
     assert line["config"]["rccl_ranks"] == 1 and line["config"]["launcher"].startswith("external")
     assert line["single_gpu_equivalent"]["grid"] == [256, 256, 256] and line["single_gpu_equivalent"]["ms_per_step"] > 0
+    # both kz-slab modes were calibrated (the direct one reproduced the rccl mode's rms, or it would be listed as rejected) and one runs
+    cal = line["config"]["mode_calibration_ms_per_step"]
+    assert cal["rccl"] > 0 and cal["direct"] > 0 and line["config"]["modes_rejected"] == {}
+    assert line["config"]["multi_gpu_mode"] in ("rccl", "direct") and line["config"]["exchange_sub_slabs"] in (1, 4)
 
 
 def test_two_distributed_plans_in_a_row(hip, dpower, monkeypatch, tmp_path):
