@@ -208,6 +208,24 @@ def other_configs(power, spacing, device, only=None):
                     1024, t, 20 * (1 + 2 / 1024), **passes(dev, 1024, 8, x_sweeps=2.0 if rng == "reference" else 1.0))
             dev.close()
             del gen
+    # what a drop-in user of the reference API sees: generate_delta_field(seed) RETURNS a numpy array (generate.py:184-189,230).  PCIe-inclusive
+    # wall time per call, field delivered into the plan's host buffer -- slab by slab behind the z pass (rf_set_host_sink: the default of
+    # download=True) against the realisation followed by the download.  Never `value`: the bench line is device-resident.
+    host = {}
+    for rng in ("native", "reference"):
+        gen = Generator(1024, 1024, 1024, spacing, power=power, rng=rng)
+        dev = gen.plan_c2r.device
+        t_sink = _timed(lambda: gen.generate_delta_field(seed=next(seeds), save_potential=False), dev.sync, reps=3, warm=2)
+
+        def serial():
+            gen.generate_delta_field(seed=next(seeds), save_potential=False, download=False)
+            gen.download_field()
+        t_serial = _timed(serial, dev.sync, reps=3, warm=1)
+        host["rng='%s'" % rng] = {"ms_delivered_behind_the_z_pass": round(t_sink * 1e3, 2), "ms_realisation_then_download": round(t_serial * 1e3, 2),
+                                  "GBs_over_pcie": round(4.0 * 1024 ** 3 / t_sink / 1e9, 1)}
+        dev.close()
+        del gen
+    out["1024^3 f32 Generator.generate_delta_field(seed) -> numpy array on the host (PCIe-inclusive; not the bench line)"] = host
     # the float64 configurations in a process of their own: where the allocator puts a 17 GB plan after the plans above have come
     # and gone costs its strided passes 3 - 5 % (and after IT has been freed, later plans' store streams 20 %: tools/frag_probe.py)
     # -- a fresh process is what a user of that configuration has

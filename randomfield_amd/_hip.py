@@ -84,6 +84,8 @@ SIGNATURES = {
     "rf_upload_real": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
     "rf_download_real": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "rf_device_ptr": (ctypes.c_int, [ctypes.c_void_p, _c_void_pp, _c_void_pp]),
+    "rf_set_host_sink": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
+    "rf_host_sink_delivered": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]),
     "rf_sync": (ctypes.c_int, [ctypes.c_void_p]),
     "rf_elapsed_ms": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]),
     "rf_set_z_tables": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.c_int]),
@@ -645,6 +647,24 @@ class DevicePlan(object):
                                          LAYOUT_PADDED if padded else LAYOUT_DENSE, int(x0), int(x1)),
               "rf_download_real")
         return out
+
+    def arm_host_sink(self, out, padded=False):
+        """The NEXT realisation of this (single-GPU, tiled) plan delivers its field into ``out`` -- (nx, ny, nz [+ 2 if padded]) of the
+        plan's real dtype, C-contiguous -- slab by slab behind its z pass and returns when the field is there (rf_set_host_sink); the
+        buffer is pinned on first use.  Returns False when the plan or the host cannot (multi-rank / generic plans, registration refused):
+        nothing is armed then.  ``host_sink_delivered()`` tells afterwards whether the call delivered."""
+        nzp = self.nz + 2 if padded else self.nz
+        if out.shape != (self.nx, self.ny, nzp) or out.dtype != self.real_dtype or not out.flags.c_contiguous:
+            raise ValueError("arm_host_sink: out has the wrong shape, dtype or layout")
+        if self.nranks != 1 or not self.tiled:
+            return False
+        rc = self._lib.rf_set_host_sink(self._h, out.ctypes.data_as(ctypes.c_void_p), LAYOUT_PADDED if padded else LAYOUT_DENSE)
+        return rc == 0
+
+    def host_sink_delivered(self):
+        got = ctypes.c_int(0)
+        check(self._lib.rf_host_sink_delivered(self._h, ctypes.byref(got)), "rf_host_sink_delivered")
+        return bool(got.value)
 
     def device_ptrs(self):
         a, b = ctypes.c_void_p(), ctypes.c_void_p()

@@ -591,7 +591,7 @@ int yz_slab_planes(const rf_plan* p) {
   const long long plane = (long long)p->ny * p->nzl * (long long)p->csize;
   long long B = p->yz_slab;
   if (B < 0) {
-    if (p->f64) return 0;      // float64 passes: within 1 % of the whole-grid launches at every slab size measured (9.32-9.53 against 9.41 ms)
+    if (p->f64 && !p->sink_host) return 0;      // float64 passes: within 1 % of the whole-grid launches at every slab size measured (9.32-9.53 against 9.41 ms); slabs anyway when a host sink wants them one by one
     static const long long target = [] { const char* e = getenv("RF_YZ_SLAB_MB"); return (e && atoll(e) > 0 ? atoll(e) : 256LL) << 20; }();
     B = 1;
     while (2 * B * plane <= target) B *= 2;
@@ -606,8 +606,34 @@ int yz_slab_planes(const rf_plan* p) {
 // y and z passes of a single-rank plan + the moments into stats_out[0..1], slab by slab when yz_slab_planes() says so.  The x
 // pass has left its output either in W (plain layout: both passes in place) or in the blocked intermediate X (y pass in place
 // on X, z pass gathering X -> W).
+// host sink (rf_set_host_sink): planes [x0, x0 + nb) of the field have just been finished by the z pass queued on s -- their copy to
+// the armed host buffer goes to dl_stream behind an event
+int sink_slab(rf_plan* p, const void* W, long long x0, long long nb, int slab, hipStream_t s) {
+  while ((int)p->sink_ev.size() <= slab) { hipEvent_t e; RF_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); p->sink_ev.push_back(e); }
+  RF_HIP(hipEventRecord(p->sink_ev[slab], s));
+  RF_HIP(hipStreamWaitEvent(p->dl_stream, p->sink_ev[slab], 0));
+  const size_t rsize = p->csize / 2, width = (size_t)p->nz * rsize;
+  const size_t hpitch = p->sink_layout == RF_LAYOUT_PADDED ? (size_t)(p->nz + 2) * rsize : width;
+  RF_HIP(hipMemcpy2DAsync((char*)p->sink_host + (size_t)x0 * p->ny * hpitch, hpitch, (const char*)W + (size_t)x0 * p->ny * width, width, width,
+                          (size_t)nb * p->ny, hipMemcpyDeviceToHost, p->dl_stream));
+  return 0;
+}
+// ... and after the last slab: the call that was armed returns with the field on the host (one shot)
+int sink_finish(rf_plan* p) {
+  RF_HIP(hipStreamSynchronize(p->dl_stream));
+  p->sink_host = nullptr;
+  p->sink_delivered = true;
+  return 0;
+}
+
 int queue_yz(rf_plan* p, void* W, hipStream_t s, double* stats_out, bool timed) {
   const long long nzl = p->nzl;
+  bool sink = p->sink_host != nullptr && !p->zscale;
+  if (sink) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(s, &cap);
+    sink = cap == hipStreamCaptureStatusNone;      // (a captured batch keeps its fields on the device)
+  }
   const double scale = 1.0 / ((double)p->nx * (double)p->ny * (double)p->nz);
   const bool xp = p->X && xpose_ok(p);
   const long long rb = xpose_row_block(p), tc = col_tile_cols(p->f64, p->ny);
@@ -647,10 +673,12 @@ int queue_yz(rf_plan* p, void* W, hipStream_t s, double* stats_out, bool timed) 
       else
         RF_HIP(launch_row_c2r(p->f64, (int)p->nzc, Ws, nb * p->ny, scale, p->tw_z, part, s));
       if (timed) RF_HIP(hipEventRecord(p->slab_ev[i + 1], s));
+      if (sink) if (int rc = sink_slab(p, W, (long long)i * B, nb, i, s)) return rc;
     }
     if (timed) { RF_HIP(hipEventRecord(p->ev[2], s)); RF_HIP(hipEventRecord(p->ev[3], s)); }
     RF_HIP(launch_reduce_partials(p->partials, p->npartials, stats_out, p->partials + 2 * p->npartials, s));
     if (timed) RF_HIP(hipEventRecord(p->ev[4], s));
+    if (sink) return sink_finish(p);
     return 0;
   }
   for (int i = 0; i < nslab; ++i) {
@@ -665,10 +693,12 @@ int queue_yz(rf_plan* p, void* W, hipStream_t s, double* stats_out, bool timed) 
     else if (p->zscale) RF_HIP(launch_row_c2r_zscale(p->f64, (int)p->nzc, Ws, nb * p->ny, scale, p->zscale, p->tw_z, part, s));
     else RF_HIP(launch_row_c2r(p->f64, (int)p->nzc, Ws, nb * p->ny, scale, p->tw_z, part, s));
     if (timed) RF_HIP(hipEventRecord(p->slab_ev[2 * i + 1], s));
+    if (sink) if (int rc = sink_slab(p, W, x0, nb, i, s)) return rc;
   }
   if (timed) { RF_HIP(hipEventRecord(p->ev[2], s)); RF_HIP(hipEventRecord(p->ev[3], s)); }   // (rf_kernel_ms sums the slab events)
   RF_HIP(launch_reduce_partials(p->partials, p->npartials, stats_out, p->partials + 2 * p->npartials, s));
   if (timed) RF_HIP(hipEventRecord(p->ev[4], s));
+  if (sink) return sink_finish(p);
   return 0;
 }
 
@@ -1073,6 +1103,9 @@ int rf_plan_destroy(rf_plan* p) {
   if (p->comm_stream) { (void)hipStreamSynchronize(p->comm_stream); (void)hipStreamDestroy(p->comm_stream); }
   for (auto& e : p->pev) if (e) (void)hipEventDestroy(e);
   for (void* m : p->ipc_open) (void)hipIpcCloseMemHandle(m);
+  if (p->dl_stream) { (void)hipStreamSynchronize(p->dl_stream); (void)hipStreamDestroy(p->dl_stream); }
+  for (auto& e : p->sink_ev) (void)hipEventDestroy(e);
+  if (p->sink_registered) (void)hipHostUnregister(p->sink_registered);
   void* bufs[] = {p->peer_tab, p->W, p->R, p->W2, p->R2, p->K, p->P_base, p->G, p->tw_x, p->tw_y, p->tw_z, p->kx2, p->ky2, p->kz2, p->xt, p->st, p->sl, p->bin,
                   p->X, p->lntab, p->ypart, p->noise, p->mt_scratch, p->mt_send, p->mt_recv, p->mt_sbase, p->mt_first, p->mt_pos, p->mt_npos_dev, p->mt_states, p->mt_counts, p->mt_offsets, p->mt_rowtab, p->mt_flags, p->br_tmp, p->fixbuf, p->partials, p->stats, p->seeds_dev, p->ztab, p->frec, p->coll_scratch};
   for (void* b : bufs)
@@ -1771,6 +1804,43 @@ int rf_download_real(rf_plan* p, void* host, int layout, int x0, int x1) {
   const char* src = (const char*)p->cur + (size_t)x0 * p->ny * width;
   RF_HIP(hipMemcpy2DAsync(host, hpitch, src, width, width, (size_t)(x1 - x0) * p->ny, hipMemcpyDeviceToHost, p->stream));
   RF_HIP(hipStreamSynchronize(p->stream));
+  return 0;
+}
+
+// generate.py:184-189,230: the reference's calls RETURN a host array, and at 1024^3 the device -> host copy (75 ms over PCIe) is 15 x the
+// realisation.  Armed with a host buffer, the NEXT realisation of a single-GPU plan (rf_realise, rf_realise_potential,
+// rf_realise_batch_reference, rf_realise_lognormal ...: everything whose y / z passes run slab by slab on the plan's stream) queues the
+// copy of every slab of x planes behind that slab's z pass, on a stream of its own, and returns when the whole field is in `host`
+// (layout as rf_download_real): the copy starts ~1.5 ms into a 1024^3 realisation instead of after it.  The host range is pinned
+// (hipHostRegister) on first use and stays pinned while the same buffer is armed again.  One shot: rf_host_sink_delivered says whether the
+// armed call delivered (then rf_download_real is not needed) and disarms.  host = NULL disarms.
+int rf_set_host_sink(rf_plan* p, void* host, int layout) {
+  RF_REQUIRE(p, "null plan");
+  RF_REQUIRE(!p->unpacked && !p->generic && p->nranks == 1 && !p->force_slab, "a host sink serves single-GPU packed plans on the tiled kernels");
+  RF_REQUIRE(layout == RF_LAYOUT_DENSE || layout == RF_LAYOUT_PADDED, "invalid layout");
+  RF_HIP(hipSetDevice(p->device));
+  p->sink_delivered = false;
+  if (!host) { p->sink_host = nullptr; return 0; }
+  const size_t rsize = p->csize / 2, bytes = (size_t)p->nx * p->ny * (size_t)(layout == RF_LAYOUT_PADDED ? p->nz + 2 : p->nz) * rsize;
+  if (p->sink_registered != host || p->sink_registered_bytes < bytes) {
+    if (p->sink_registered) { (void)hipHostUnregister(p->sink_registered); p->sink_registered = nullptr; p->sink_registered_bytes = 0; }
+    const hipError_t e = hipHostRegister(host, bytes, hipHostRegisterDefault);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(2, std::string("hipHostRegister of the host sink failed: ") + hipGetErrorString(e)); }
+    p->sink_registered = host; p->sink_registered_bytes = bytes;
+  }
+  if (!p->dl_stream) RF_HIP(hipStreamCreateWithFlags(&p->dl_stream, hipStreamNonBlocking));
+  drop_graphs(p);                                  // (a float64 plan's launch structure follows the sink: slabs)
+  p->sink_host = host;
+  p->sink_layout = layout;
+  return 0;
+}
+
+int rf_host_sink_delivered(rf_plan* p, int* delivered) {
+  RF_REQUIRE(p && delivered, "null argument");
+  *delivered = p->sink_delivered ? 1 : 0;
+  if (p->sink_host && !p->sink_delivered) drop_graphs(p);
+  p->sink_host = nullptr;
+  p->sink_delivered = false;
   return 0;
 }
 

@@ -286,6 +286,10 @@ class Generator(object):
             # per call otherwise); the plan itself remembers what it was last given, whoever gave it
             dev.set_power(log10_k, sigma, if_changed=True)
             realised = False
+            # generate.py:184-189,230 returns a HOST array, and the device -> host copy is 15 x the realisation at 1024^3: armed with
+            # the plan's host buffer, the realisation below delivers slab by slab behind its z pass (rf_set_host_sink)
+            sink = bool(download) and not self.distributed and dev.arm_host_sink(self.plan_c2r.data_out_padded, padded=True)
+            self._sink_armed = sink
             if self.rng == "reference":
                 # RandomState(seed).normal (random.py:24): MT19937 + polar method replayed on the GPU from the seed's
                 # 624-word start state -- integer seeds, array seeds (init_by_array) and None alike; no host deviates
@@ -333,7 +337,8 @@ class Generator(object):
                 self.potential = None
             mean, std = dev.moments()
             self.delta_field_rms = self.plan_c2r.data_out.dtype.type(std)
-            self._field_on_host = False
+            self._field_on_host = bool(sink and dev.host_sink_delivered())
+            self._sink_armed = False
             delta = self.download_field() if download else None
 
         if self.verbose:
@@ -344,8 +349,8 @@ class Generator(object):
         """One fused realisation on the device.  Native generator on a single-GPU tiled plan: replayed from a captured
         one-realisation hipGraph (rf_realise_batch with one seed, read from device memory) -- the call is ~35 kernel launches, and
         their launch gaps are 5 % of a 1024^3 realisation when issued one by one; everything else issues them eagerly."""
-        if noise is None and not self.distributed and dev.tiled and dev.nranks == 1:
-            dev.realise_batch(np.array([dseed], np.uint64), want_rms=False)
+        if noise is None and not self.distributed and dev.tiled and dev.nranks == 1 and not getattr(self, "_sink_armed", False):
+            dev.realise_batch(np.array([dseed], np.uint64), want_rms=False)       # (a captured graph keeps its field on the device: not with a host sink)
         else:
             dev.realise(dseed, noise)
 

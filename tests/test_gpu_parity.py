@@ -2286,3 +2286,44 @@ def test_direct_standin_runs_the_direct_schedule_on_a_virtual_rank(hip, dpower):
         p.realise(seed=3)                                    # back to "no communicator, no stand-in": loud
     for q in plans:
         q.close()
+
+
+@pytest.mark.parametrize("shape,dtype", [((256, 1024, 1024), np.complex64), ((64, 64, 64), np.complex64), ((128, 512, 1024), np.complex128)])
+def test_host_sink_delivers_the_field_slab_by_slab(hip, dpower, shape, dtype):
+    """rf_set_host_sink (generate.py:184-189,230: the reference's calls return host arrays): the realisation's own z pass hands every
+    finished slab of x planes to a device -> host copy on a second stream.  The host array must be exactly what rf_download_real
+    delivers afterwards -- eager native call, the same-seed one-call path, the stored-potential call, float64 (slabs forced by the
+    sink) and a grid without slabs -- and the sink is one shot."""
+    from randomfield_amd import Generator
+    k, Pk = dpower
+    plan = make_plan(hip, shape, dtype, k, Pk)
+    rt = np.float32 if dtype == np.complex64 else np.float64
+    host = np.full(shape[:2] + (shape[2] + 2,), np.nan, rt)
+    assert plan.arm_host_sink(host, padded=True)
+    plan.realise(seed=5)
+    assert plan.host_sink_delivered()
+    want = plan.download_real()
+    assert np.array_equal(host[:, :, :shape[2]], want) and np.isnan(host[:, :, shape[2]:]).all()
+    host[:] = np.nan
+    plan.realise(seed=6)                                     # one shot: nothing armed now
+    assert not plan.host_sink_delivered() and np.isnan(host).all()
+    dense = np.empty(shape, rt)
+    assert plan.arm_host_sink(dense)                         # another buffer (re-registered), dense rows
+    plan.realise_potential(seed=7)
+    assert plan.host_sink_delivered() and np.array_equal(dense, plan.download_real())
+    plan.realise_batch(np.array([8, 9], np.uint64), want_rms=False)        # graph batches are unaffected afterwards
+    plan.realise(seed=9)
+    ref9 = plan.download_real()
+    plan.close()
+    if dtype == np.complex64:
+        for rng in ("native", "reference"):
+            gen = Generator(*shape, SPACING, rng=rng)
+            a = gen.generate_delta_field(seed=11, save_potential=False).copy()
+            rms_a = gen.delta_field_rms
+            assert gen._field_on_host
+            gen.generate_delta_field(seed=11, save_potential=False, download=False)
+            b = gen.download_field()
+            assert np.array_equal(a, b) and gen.delta_field_rms == rms_a and a.std() > 0
+            c = gen.generate_delta_field(seed=11, save_potential=True)      # the default call
+            assert np.array_equal(c, a)
+            gen.plan_c2r.device.close()
