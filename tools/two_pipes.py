@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Two independent 1024^3 float32 pipelines (two plans, two streams) on one GPU: 2 x K graph-replayed realisations one plan after the
-other against both at once.  Does the vector-bound generation pass of one overlap the y / z passes of the other?  usage: two_pipes.py [K]"""
+other against both at once.  Does the vector-bound generation pass of one overlap the y / z passes of the other?  usage: two_pipes.py [K] [variant.so]"""
 import os
 import sys
 import time
@@ -11,6 +11,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from randomfield_amd import _hip, powertools   # noqa: E402
 
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+if len(sys.argv) > 2 and sys.argv[2] != "-":
+    _hip.LIB_PATH = os.path.abspath(sys.argv[2])           # a variant build of the library (tools/bin/lib_*.so)
 n = 1024
 power = powertools.load_default_power()
 plans = []
