@@ -678,7 +678,7 @@ def main():
     nslab, slab_planes = plan.yz_slabs()
     launches = [1, nslab, nslab]
     traffic, traffic_source, pass_traffic = None, None, {}
-    keys = [["FastGenColIOT<0, 0,", "FastGenColIOT<0, 1,", "FastGenColIOT<0, 3,", "fix_fill_kernel"], ["PlainColIO", "XposeColIO", "Pair2ColIO"], ["row_c2r_kernel"]]
+    keys = [["FastGenColIOT<0,", "FastGenColIOT<1,", "FastGenColIOT<3,", "fix_fill_kernel"], ["PlainColIO", "XposeColIO", "Pair2ColIO"], ["row_c2r_kernel"]]
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
     except Exception as e:                               # no committed profile: say so instead of a silent null

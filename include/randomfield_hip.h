@@ -260,10 +260,10 @@ int rf_lensing_potential(rf_plan* plan, const double* cot_z, int nz, double spac
 int rf_download_aux(rf_plan* plan, void* host, int x0, int x1);   /* planes [x0, x1) of the auxiliary field, dense */
 
 /* generate.py:184-189,230 (the reference's calls return HOST arrays): arm a host buffer (layout and size as rf_download_real's, all nx
- * planes) and the NEXT realisation of a single-GPU plan on the tiled kernels delivers its field there slab by slab -- the device -> host
- * copy of each slab of x planes is queued behind that slab's z pass on a stream of its own -- and returns when the field is complete
- * on the host.  The buffer is pinned on first use (hipHostRegister) and stays pinned while it is armed again.  One shot;
- * rf_host_sink_delivered reports whether the armed call delivered (else use rf_download_real) and disarms.  host = NULL disarms. */
+ * planes; ordinary pageable memory) and the NEXT realisation of a single-GPU plan on the tiled kernels delivers its field there slab by
+ * slab -- the device -> host copy of each slab of x planes runs as soon as that slab's z pass has finished, while the GPU works on
+ * the following slabs -- and returns when the field is complete on the host.  One shot; rf_host_sink_delivered reports whether the
+ * armed call delivered (else use rf_download_real) and disarms.  host = NULL disarms. */
 int rf_set_host_sink(rf_plan* plan, void* host, int layout);
 int rf_host_sink_delivered(rf_plan* plan, int* delivered);
 

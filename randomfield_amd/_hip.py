@@ -270,6 +270,7 @@ class DevicePlan(object):
         if getattr(self, "_h", None) is not None and self._h.value:
             self._lib.rf_plan_destroy(self._h)
             self._h = ctypes.c_void_p()
+        self._sink_keepalive = None
 
     def __del__(self):
         try:
@@ -650,15 +651,16 @@ class DevicePlan(object):
 
     def arm_host_sink(self, out, padded=False):
         """The NEXT realisation of this (single-GPU, tiled) plan delivers its field into ``out`` -- (nx, ny, nz [+ 2 if padded]) of the
-        plan's real dtype, C-contiguous -- slab by slab behind its z pass and returns when the field is there (rf_set_host_sink); the
-        buffer is pinned on first use.  Returns False when the plan or the host cannot (multi-rank / generic plans, registration refused):
-        nothing is armed then.  ``host_sink_delivered()`` tells afterwards whether the call delivered."""
+        plan's real dtype, C-contiguous -- slab by slab behind its z pass and returns when the field is there (rf_set_host_sink).
+        Returns False when the plan cannot (multi-rank / generic plans): nothing is armed then.  ``host_sink_delivered()`` tells afterwards whether the call delivered."""
         nzp = self.nz + 2 if padded else self.nz
         if out.shape != (self.nx, self.ny, nzp) or out.dtype != self.real_dtype or not out.flags.c_contiguous:
             raise ValueError("arm_host_sink: out has the wrong shape, dtype or layout")
         if self.nranks != 1 or not self.tiled:
             return False
         rc = self._lib.rf_set_host_sink(self._h, out.ctypes.data_as(ctypes.c_void_p), LAYOUT_PADDED if padded else LAYOUT_DENSE)
+        if rc == 0:
+            self._sink_keepalive = out           # (the armed call writes into it: it must live until then)
         return rc == 0
 
     def host_sink_delivered(self):

@@ -387,7 +387,7 @@ int realise_fast_impl(int nx, int ny, int nz, const GenHost& h, uint64_t seed, d
   if constexpr (sizeof(T) == 4) {
     if (nx == 2048 && ((long long)ny * nzc) % 8 == 0) {      // the library's x pass at this length: Col2 over the 1024-point configuration
       using C1 = GenSel<float, 1024>::type;
-      using IO2 = FastGenColIOT<0, 3, 0, 0, 0, 2>;
+      using IO2 = FastGenColIOT<3, 0, 0, 0, 2>;
       IO2 io2;
       io2.base = W; io2.g = io.g; io2.kz0 = 0; io2.nzl = (int)nzc; io2.rec = nullptr; io2.gp = io.gp; io2.pot = nullptr;
       typename IO2::fill_io iof;

@@ -75,17 +75,11 @@ int ensure_k(rf_plan* p) {
 // that pass is bimodal -- 5.2 or 5.75 ms for the whole default call at 1024^3 -- and tools/pot_offset.py shows what decides it:
 // NOT the virtual addresses (45 plans at identical virtual addresses of both arrays and 15 offsets of the potential inside its
 // allocation, 256 B ... 4 MiB: either mode at every offset, the same offset in both modes) but the physical pages the driver
-// happens to back them with, which user space neither sees nor chooses.  RF_POT_OFFSET (bytes) moves the array inside a slightly
-// larger allocation for that measurement; the product uses offset 0.
+// happens to back them with, which user space neither sees nor chooses: the array sits at offset 0 of its allocation.
 int ensure_p(rf_plan* p) {
   if (p->P) return 0;
-  size_t off = 0, window = 0;
-  if (const char* e = getenv("RF_POT_OFFSET")) { off = (size_t)atoll(e) & ~(size_t)255; window = 8u << 20; }
-  if (off >= window) off = 0;
-  RF_HIP(hipMalloc(&p->P_base, p->p_bytes + window));
-  p->P = (char*)p->P_base + off;
-  if (getenv("RANDOMFIELD_DEBUG"))
-    fprintf(stderr, "ensure_p: W %p P_base %p offset %zu (P - W) mod 4 MiB = %zu\n", p->W, p->P_base, off, ((size_t)p->P - (size_t)p->W) % (4u << 20));
+  RF_HIP(hipMalloc(&p->P_base, p->p_bytes));
+  p->P = p->P_base;
   return 0;
 }
 
@@ -97,10 +91,7 @@ int ensure_g(rf_plan* p) {
 // May the plan hand the x pass's output to the y and z passes through the blocked intermediate X (rf_fft.h xblock_*_geom)?
 // Single-rank tiled plans whose x and y passes use tiles of the same width, whose kz runs are whole tiles and whose z pass
 // can gather (whole workgroups per x block and iy, whole segments per thread group).
-#ifndef RF_XP_ROWBLOCK
-#define RF_XP_ROWBLOCK 64
-#endif
-int xpose_row_block(const rf_plan* p) { return col_gen_row_block(p->f64, p->nx, RF_XP_ROWBLOCK); }
+int xpose_row_block(const rf_plan* p) { return col_gen_row_block(p->f64, p->nx, 64); }      // x rows per block of the transposed intermediate
 bool xpose_ok(const rf_plan* p) {
   if (!p->xposed || p->generic || p->unpacked || p->nranks > 1 || p->force_slab) return false;
   const int tcx = col_gen_tile_cols(p->f64, p->nx), tcy = col_tile_cols(p->f64, p->ny);
@@ -592,7 +583,7 @@ int yz_slab_planes(const rf_plan* p) {
   long long B = p->yz_slab;
   if (B < 0) {
     if (p->f64 && !p->sink_host) return 0;      // float64 passes: within 1 % of the whole-grid launches at every slab size measured (9.32-9.53 against 9.41 ms); slabs anyway when a host sink wants them one by one
-    static const long long target = [] { const char* e = getenv("RF_YZ_SLAB_MB"); return (e && atoll(e) > 0 ? atoll(e) : 256LL) << 20; }();
+    const long long target = 256LL << 20;              // the Infinity Cache (RF_FLAG_YZ_SLAB_PLANES sets another slab size per plan)
     B = 1;
     while (2 * B * plane <= target) B *= 2;
   }
@@ -606,21 +597,27 @@ int yz_slab_planes(const rf_plan* p) {
 // y and z passes of a single-rank plan + the moments into stats_out[0..1], slab by slab when yz_slab_planes() says so.  The x
 // pass has left its output either in W (plain layout: both passes in place) or in the blocked intermediate X (y pass in place
 // on X, z pass gathering X -> W).
-// host sink (rf_set_host_sink): planes [x0, x0 + nb) of the field have just been finished by the z pass queued on s -- their copy to
-// the armed host buffer goes to dl_stream behind an event
-int sink_slab(rf_plan* p, const void* W, long long x0, long long nb, int slab, hipStream_t s) {
+// Host sink (rf_set_host_sink).  The z pass of a slab of x planes has been queued on s: mark that point with an event ...
+int sink_mark(rf_plan* p, int slab, hipStream_t s) {
   while ((int)p->sink_ev.size() <= slab) { hipEvent_t e; RF_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); p->sink_ev.push_back(e); }
   RF_HIP(hipEventRecord(p->sink_ev[slab], s));
+  return 0;
+}
+// ... and, once the launches of the NEXT slab are queued too (the GPU has work while the host waits here), copy planes [x0, x0 + nb)
+// to the armed host buffer: an ordinary device -> host copy into pageable memory on dl_stream behind the slab's event -- it returns
+// when the rows are in the caller's memory.  (The host buffer is deliberately NOT registered with hipHostRegister: round 6 first
+// built it that way, and later device -> host copies of the same process then aborted now and then inside the runtime.)
+int sink_copy(rf_plan* p, const void* W, long long x0, long long nb, int slab) {
   RF_HIP(hipStreamWaitEvent(p->dl_stream, p->sink_ev[slab], 0));
   const size_t rsize = p->csize / 2, width = (size_t)p->nz * rsize;
   const size_t hpitch = p->sink_layout == RF_LAYOUT_PADDED ? (size_t)(p->nz + 2) * rsize : width;
   RF_HIP(hipMemcpy2DAsync((char*)p->sink_host + (size_t)x0 * p->ny * hpitch, hpitch, (const char*)W + (size_t)x0 * p->ny * width, width, width,
                           (size_t)nb * p->ny, hipMemcpyDeviceToHost, p->dl_stream));
+  RF_HIP(hipStreamSynchronize(p->dl_stream));
   return 0;
 }
-// ... and after the last slab: the call that was armed returns with the field on the host (one shot)
+// ... after the last slab: the armed call returns with the field on the host (one shot)
 int sink_finish(rf_plan* p) {
-  RF_HIP(hipStreamSynchronize(p->dl_stream));
   p->sink_host = nullptr;
   p->sink_delivered = true;
   return 0;
@@ -651,10 +648,9 @@ int queue_yz(rf_plan* p, void* W, hipStream_t s, double* stats_out, bool timed) 
   // launch (the next slab's y tiles fill the CUs the draining z pass leaves idle); timed calls keep one launch per pass and slab, so
   // that rf_kernel_ms still means what it says
   // (rf_set_merged_yz(2) merges timed calls too, with an event behind every launch: rf_merged_yz_ms)
-  static const bool merge_env = [] { const char* e = getenv("RANDOMFIELD_MERGE_YZ"); return !e || atoi(e) != 0; }();
   // (the last slab may be smaller -- a slab size that does not divide nx: RF_FLAG_YZ_SLAB_PLANES -- as long as both sizes fit the kernel)
   const long long Blast = p->nx - (long long)(nslab - 1) * B;
-  if (merge_env && (timed ? p->yz_merge >= 2 : p->yz_merge >= 1) && !xp && !p->zscale && nslab > 1 &&
+  if ((timed ? p->yz_merge >= 2 : p->yz_merge >= 1) && !xp && !p->zscale && nslab > 1 &&
       yz_merged_fits(p->f64, p->ny, (int)p->nzc, gy, B * p->ny, B * nzl) &&
       (Blast == B || yz_merged_fits(p->f64, p->ny, (int)p->nzc, gy, B * p->ny, Blast * nzl))) {
     if (timed) {
@@ -673,12 +669,18 @@ int queue_yz(rf_plan* p, void* W, hipStream_t s, double* stats_out, bool timed) 
       else
         RF_HIP(launch_row_c2r(p->f64, (int)p->nzc, Ws, nb * p->ny, scale, p->tw_z, part, s));
       if (timed) RF_HIP(hipEventRecord(p->slab_ev[i + 1], s));
-      if (sink) if (int rc = sink_slab(p, W, (long long)i * B, nb, i, s)) return rc;
+      if (sink) {
+        if (int rc = sink_mark(p, i, s)) return rc;
+        if (i > 0) if (int rc = sink_copy(p, W, (long long)(i - 1) * B, B, i - 1)) return rc;       // (slab i - 1, while the GPU runs slab i)
+      }
     }
     if (timed) { RF_HIP(hipEventRecord(p->ev[2], s)); RF_HIP(hipEventRecord(p->ev[3], s)); }
     RF_HIP(launch_reduce_partials(p->partials, p->npartials, stats_out, p->partials + 2 * p->npartials, s));
     if (timed) RF_HIP(hipEventRecord(p->ev[4], s));
-    if (sink) return sink_finish(p);
+    if (sink) {
+      if (int rc = sink_copy(p, W, (long long)(nslab - 1) * B, Blast, nslab - 1)) return rc;
+      return sink_finish(p);
+    }
     return 0;
   }
   for (int i = 0; i < nslab; ++i) {
@@ -693,12 +695,19 @@ int queue_yz(rf_plan* p, void* W, hipStream_t s, double* stats_out, bool timed) 
     else if (p->zscale) RF_HIP(launch_row_c2r_zscale(p->f64, (int)p->nzc, Ws, nb * p->ny, scale, p->zscale, p->tw_z, part, s));
     else RF_HIP(launch_row_c2r(p->f64, (int)p->nzc, Ws, nb * p->ny, scale, p->tw_z, part, s));
     if (timed) RF_HIP(hipEventRecord(p->slab_ev[2 * i + 1], s));
-    if (sink) if (int rc = sink_slab(p, W, x0, nb, i, s)) return rc;
+    if (sink) {
+      if (int rc = sink_mark(p, i, s)) return rc;
+      if (i > 0) if (int rc = sink_copy(p, W, x0 - B, B, i - 1)) return rc;                          // (slab i - 1, while the GPU runs slab i)
+    }
   }
   if (timed) { RF_HIP(hipEventRecord(p->ev[2], s)); RF_HIP(hipEventRecord(p->ev[3], s)); }   // (rf_kernel_ms sums the slab events)
   RF_HIP(launch_reduce_partials(p->partials, p->npartials, stats_out, p->partials + 2 * p->npartials, s));
   if (timed) RF_HIP(hipEventRecord(p->ev[4], s));
-  if (sink) return sink_finish(p);
+  if (sink) {
+    const long long xl = (long long)(nslab - 1) * B;
+    if (int rc = sink_copy(p, W, xl, p->nx - xl, nslab - 1)) return rc;
+    return sink_finish(p);
+  }
   return 0;
 }
 
@@ -1105,7 +1114,6 @@ int rf_plan_destroy(rf_plan* p) {
   for (void* m : p->ipc_open) (void)hipIpcCloseMemHandle(m);
   if (p->dl_stream) { (void)hipStreamSynchronize(p->dl_stream); (void)hipStreamDestroy(p->dl_stream); }
   for (auto& e : p->sink_ev) (void)hipEventDestroy(e);
-  if (p->sink_registered) (void)hipHostUnregister(p->sink_registered);
   void* bufs[] = {p->peer_tab, p->W, p->R, p->W2, p->R2, p->K, p->P_base, p->G, p->tw_x, p->tw_y, p->tw_z, p->kx2, p->ky2, p->kz2, p->xt, p->st, p->sl, p->bin,
                   p->X, p->lntab, p->ypart, p->noise, p->mt_scratch, p->mt_send, p->mt_recv, p->mt_sbase, p->mt_first, p->mt_pos, p->mt_npos_dev, p->mt_states, p->mt_counts, p->mt_offsets, p->mt_rowtab, p->mt_flags, p->br_tmp, p->fixbuf, p->partials, p->stats, p->seeds_dev, p->ztab, p->frec, p->coll_scratch};
   for (void* b : bufs)
@@ -1809,36 +1817,29 @@ int rf_download_real(rf_plan* p, void* host, int layout, int x0, int x1) {
 
 // generate.py:184-189,230: the reference's calls RETURN a host array, and at 1024^3 the device -> host copy (75 ms over PCIe) is 15 x the
 // realisation.  Armed with a host buffer, the NEXT realisation of a single-GPU plan (rf_realise, rf_realise_potential,
-// rf_realise_batch_reference, rf_realise_lognormal ...: everything whose y / z passes run slab by slab on the plan's stream) queues the
-// copy of every slab of x planes behind that slab's z pass, on a stream of its own, and returns when the whole field is in `host`
-// (layout as rf_download_real): the copy starts ~1.5 ms into a 1024^3 realisation instead of after it.  The host range is pinned
-// (hipHostRegister) on first use and stays pinned while the same buffer is armed again.  One shot: rf_host_sink_delivered says whether the
-// armed call delivered (then rf_download_real is not needed) and disarms.  host = NULL disarms.
+// rf_realise_batch_reference ...: everything whose y / z passes run slab by slab on the plan's stream) copies every slab of x planes to
+// the host as soon as its z pass has finished, while the GPU runs the following slabs, and returns when the whole field is in `host`
+// (layout as rf_download_real): the copy starts ~1.5 ms into a 1024^3 realisation instead of after it.  Ordinary pageable memory.
+// One shot: rf_host_sink_delivered says whether the armed call delivered (then rf_download_real is not needed) and disarms.
+// host = NULL disarms.
 int rf_set_host_sink(rf_plan* p, void* host, int layout) {
   RF_REQUIRE(p, "null plan");
   RF_REQUIRE(!p->unpacked && !p->generic && p->nranks == 1 && !p->force_slab, "a host sink serves single-GPU packed plans on the tiled kernels");
   RF_REQUIRE(layout == RF_LAYOUT_DENSE || layout == RF_LAYOUT_PADDED, "invalid layout");
   RF_HIP(hipSetDevice(p->device));
+  RF_HIP(hipStreamSynchronize(p->stream));
   p->sink_delivered = false;
-  if (!host) { p->sink_host = nullptr; return 0; }
-  const size_t rsize = p->csize / 2, bytes = (size_t)p->nx * p->ny * (size_t)(layout == RF_LAYOUT_PADDED ? p->nz + 2 : p->nz) * rsize;
-  if (p->sink_registered != host || p->sink_registered_bytes < bytes) {
-    if (p->sink_registered) { (void)hipHostUnregister(p->sink_registered); p->sink_registered = nullptr; p->sink_registered_bytes = 0; }
-    const hipError_t e = hipHostRegister(host, bytes, hipHostRegisterDefault);
-    if (e != hipSuccess) { (void)hipGetLastError(); return fail(2, std::string("hipHostRegister of the host sink failed: ") + hipGetErrorString(e)); }
-    p->sink_registered = host; p->sink_registered_bytes = bytes;
-  }
-  if (!p->dl_stream) RF_HIP(hipStreamCreateWithFlags(&p->dl_stream, hipStreamNonBlocking));
-  drop_graphs(p);                                  // (a float64 plan's launch structure follows the sink: slabs)
+  if (p->f64 && (p->sink_host == nullptr) != (host == nullptr)) drop_graphs(p);      // (a float64 plan runs its y / z passes slab by slab only for a sink)
   p->sink_host = host;
   p->sink_layout = layout;
+  if (host && !p->dl_stream) RF_HIP(hipStreamCreateWithFlags(&p->dl_stream, hipStreamNonBlocking));
   return 0;
 }
 
 int rf_host_sink_delivered(rf_plan* p, int* delivered) {
   RF_REQUIRE(p && delivered, "null argument");
   *delivered = p->sink_delivered ? 1 : 0;
-  if (p->sink_host && !p->sink_delivered) drop_graphs(p);
+  if (p->sink_host && p->f64) { RF_HIP(hipStreamSynchronize(p->stream)); drop_graphs(p); }
   p->sink_host = nullptr;
   p->sink_delivered = false;
   return 0;

@@ -5,18 +5,9 @@
 #include "rf_kernels.h"
 #include "rf_launch.h"
 
-#ifndef RF_COL2_2048
-#define RF_COL2_2048 1                 // length-2048 float32 passes as two 1024-point transforms per tile (Col2); 0 = the whole-column kernels
-#endif
-#ifndef RF_FIX_MERGED
-#define RF_FIX_MERGED 0                // 1 = the tiles that hold kz = 0 run inside ONE launch of the FIX = 3 kernel over all tiles (a uniform branch: 8 loads
-#endif                                 // from the side buffer); 0 = as a launch of their own in front of the FIX = 0 kernel's (measured: DESIGN.md 3.2)
-#ifndef RF_SRC2_PAIR_LAUNCH
-#define RF_SRC2_PAIR_LAUNCH 0          // 1 = the deviate-reading generation pass runs its kz = 0 tiles in the main launch's grid (col_pair_kernel):
-#endif                                 // measured, 9.25 - 9.28 against 9.25 - 9.43 ms per one-call same-seed realisation -- inside the noise; off
-#ifndef RF_COL2_F64_1024
-#define RF_COL2_F64_1024 1             // the float64 generation pass of length 1024 as two 512-point transforms per tile (Col2): two workgroups per CU
-#endif
+// (Launch structure of the kz = 0 repair, settled by measurement -- DESIGN_HISTORY.md: the tiles that hold slot kz = 0 run as a launch of
+// their own in FRONT of the lean kernel's launch over all other tiles.  One launch of the repairing kernel over all tiles, the lean
+// kernel over all tiles followed by the kz = 0 tiles again, and both kinds of tile in one grid were each measured and are gone.)
 
 namespace rf {
 namespace {
@@ -39,26 +30,8 @@ hipError_t launch_one(const IO& io_in, long long ncols, const cplx<typename C::T
   return hipGetLastError();
 }
 
-// two kinds of tile in one grid (rf_kernels.h col_pair_kernel): workgroups [0, na) = ioa on tiles b * mul_a, then nb workgroups = iob on
-// every tile except those = 0 mod skip_b
-template <class C, class IOA, class IOB>
-hipError_t launch_pair(const IOA& ioa, const IOB& iob, long long ncols, const cplx<typename C::T>* tw, hipStream_t s, bool prepare_only,
-                       long long na, long long mul_a, long long nb, int skip_b) {
-  if (ncols % C::TC || iob.g.inner <= 0 || (iob.g.inner & (iob.g.inner - 1))) return hipErrorInvalidValue;
-  if (!prepare_only && (!iob.g.rows_ok(C::N / C::RL, C::NPASS) || (iob.g.sub_shift > 0 && (1 << iob.g.sub_shift) < C::TC))) return hipErrorInvalidValue;
-  auto k = col_pair_kernel<C, +1, IOA, IOB>;
-  constexpr int la = C::LDS_BYTES + IOA::LDS_EXTRA, lb = C::LDS_BYTES + IOB::LDS_EXTRA, lds_bytes = la > lb ? la : lb;
-  static LdsAttrLatch latch;
-  if (hipError_t e = latch.ensure((const void*)k, lds_bytes); e != hipSuccess) return e;
-  if (prepare_only) return hipSuccess;
-  hipLaunchKernelGGL(k, dim3((unsigned)(na + nb)), dim3(C::NT), lds_bytes, s, ioa, iob, tw, na, mul_a, nb, skip_b);
-  return hipGetLastError();
-}
-
 // pairs of adjacent tiles, whole-line stores (rf_kernels.h colpair_kernel): runs pairs b * pair_mul + pair_add, b in [0, npairs)
-#ifndef RF_X_PAIRS
-#define RF_X_PAIRS 1                   // the float32 generation pass of length 1024 (native generator or replayed deviates, whole grid or kz slab) on tile pairs
-#endif
+// (the float32 generation pass of length 1024 -- native generator or replayed deviates, whole grid or kz slab -- runs on tile pairs)
 template <class C, class IO>
 hipError_t launch_onepair(const IO& io_in, long long ncols, const cplx<typename C::T>* tw, hipStream_t s, bool prepare_only,
                           long long npairs, long long pair_mul = 1, long long pair_add = 0, int skip_period = 0) {
@@ -124,10 +97,6 @@ hipError_t launch_fast_one2(const FastGenParams& gp, cplx<typename C1::T>* W, Co
   if (!fixbuf) return hipErrorInvalidValue;
   IOF iof; iof.base = W; iof.g = g; iof.gp = gp; iof.kz0 = kz0; iof.nzl = nzl; iof.rec = nullptr; iof.pot = nullptr;
   hipError_t e = launch_fix_fill(iof, fixbuf, s);
-  if (RF_FIX_MERGED == 1) {
-    if (e == hipSuccess && after_repair) e = hipEventRecord(after_repair, s);
-    return e != hipSuccess ? e : launch_one2<C1, IOC>(ioc, ncols, tw2, s, false);
-  }
   if (e == hipSuccess) e = launch_one2<C1, IOC>(ioc, ncols, tw2, s, false, ncols / nzl, tiles_per_iy, 0);
   if (e != hipSuccess || tiles_per_iy >= (1LL << 30) || ntiles >= (1LL << 31)) return e != hipSuccess ? e : hipErrorInvalidValue;
   if (after_repair && (e = hipEventRecord(after_repair, s)) != hipSuccess) return e;
@@ -158,8 +127,8 @@ hipError_t launch_fast_one(const FastGenParams& gp, CT* W, ColGeom g, long long 
   IOC ioc; ioc.base = base; ioc.g = g; ioc.gp = gp; ioc.kz0 = kz0; ioc.nzl = nzl; ioc.rec = nullptr; ioc.x0 = x0; ioc.x1 = x1; ioc.pot = pot;
   if constexpr (side) ioc.fixbuf = fixbuf;
   // tile pairs with whole-line stores (ColPair): the 1024-point float32 pass, every tile of a kz row in a pair of its own row
-  constexpr bool pairs = RF_X_PAIRS && side && C::N == 1024 && sizeof(CT) == 8 && C::NPASS == 3 && (io_noise_src<IO0>::value == 0 || io_noise_src<IO0>::value == 2);
-  const bool use_pairs = pairs && split && x0 <= 0 && x1 >= C::N && tiles_per_iy % 2 == 0 && g.inner % (2 * C::TC) == 0 && g.sub_shift == 0 && RF_FIX_MERGED == 0;
+  constexpr bool pairs = side && C::N == 1024 && sizeof(CT) == 8 && C::NPASS == 3 && (io_noise_src<IO0>::value == 0 || io_noise_src<IO0>::value == 2);
+  const bool use_pairs = pairs && split && x0 <= 0 && x1 >= C::N && tiles_per_iy % 2 == 0 && g.inner % (2 * C::TC) == 0 && g.sub_shift == 0;
   if (po) {
     hipError_t e = launch_one<C, IO0>(io0, ncols, tw, s, true);
     if constexpr (pairs) {
@@ -167,8 +136,6 @@ hipError_t launch_fast_one(const FastGenParams& gp, CT* W, ColGeom g, long long 
       if (e == hipSuccess) e = launch_onepair<C, IOC>(ioc, ncols, tw, s, true, 0);
     }
     if (e == hipSuccess && side) e = launch_one<C, IOC>(ioc, ncols, tw, s, true);
-    if constexpr (side && (RF_FIX_MERGED == 3 || (RF_FIX_MERGED == 0 && RF_SRC2_PAIR_LAUNCH && io_noise_src<IO0>::value == 2)))
-      if (e == hipSuccess) e = launch_pair<C, IOC, IO0>(ioc, io0, ncols, tw, s, true, 8, 1, 8, 2);
     return e != hipSuccess ? e : launch_one<C, IO1>(io1, ncols, tw, s, true);
   }
   if (!split) return launch_one<C, IO1>(io1, ncols, tw, s, false);
@@ -183,25 +150,6 @@ hipError_t launch_fast_one(const FastGenParams& gp, CT* W, ColGeom g, long long 
     if (!fixbuf) return hipErrorInvalidValue;
     IOF iof; iof.base = base; iof.g = g; iof.gp = gp; iof.kz0 = kz0; iof.nzl = nzl; iof.rec = nullptr; iof.x0 = x0; iof.x1 = x1; iof.pot = pot;
     e = launch_fix_fill(iof, fixbuf, s);
-    if (RF_FIX_MERGED == 1) {
-      if (e == hipSuccess && after_repair) e = hipEventRecord(after_repair, s);
-      return e != hipSuccess ? e : launch_one<C, IOC>(ioc, ncols, tw, s, false);
-    }
-    if (RF_FIX_MERGED == 2) {        // experiment: the lean kernel over ALL tiles (64 per ky row, no skipping), then the kz = 0 tiles again with the repair
-      if (e == hipSuccess) e = launch_one<C, IO0>(io0, ncols, tw, s, false);
-      if (e == hipSuccess && after_repair) e = hipEventRecord(after_repair, s);
-      return e != hipSuccess ? e : launch_one<C, IOC>(ioc, ncols, tw, s, false, ncols / nzl, tiles_per_iy, 0);
-    }
-  }
-  // the kz = 0 tiles (repair from the side buffer) and all the others in ONE grid (rf_kernels.h col_pair_kernel): experiments only
-  // (RF_FIX_MERGED = 3: every generation pass; RF_SRC2_PAIR_LAUNCH: the pass that reads the replayed deviates) -- no gain measured
-  constexpr bool pair_launch = side && (RF_FIX_MERGED == 3 || (RF_FIX_MERGED == 0 && RF_SRC2_PAIR_LAUNCH && io_noise_src<IO0>::value == 2));
-  if constexpr (pair_launch) {
-    const long long na = ncols / nzl, nb = ntiles - ntiles / tiles_per_iy;
-    if (e == hipSuccess && na % 8 == 0 && tiles_per_iy >= 2 && tiles_per_iy < (1LL << 30) && ntiles < (1LL << 31) && na + nb < (1LL << 31)) {
-      if (after_repair && (e = hipEventRecord(after_repair, s)) != hipSuccess) return e;       // (behind the side-buffer fill)
-      return launch_pair<C, IOC, IO0>(ioc, io0, ncols, tw, s, false, na, tiles_per_iy, nb, (int)tiles_per_iy);
-    }
   }
   if constexpr (pairs) {
     if (use_pairs) {

@@ -177,10 +177,8 @@ RF_HD uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
 // two v_mad_u64_u32 + two v_bitop3 per lane-load: 7 instead of 10 rounds is -6 % of its instructions (measured -1.3 % of a
 // 1024^3 realisation).  The test-side restatement of the stream uses the same count; both are pinned by Random123's
 // published known-answer vectors for 7 and 10 rounds (tests/test_oracle_golden.py).
-#ifndef RF_PHILOX_ROUNDS
-#define RF_PHILOX_ROUNDS 7
-#endif
-template <int ROUNDS = RF_PHILOX_ROUNDS>
+constexpr int PHILOX_ROUNDS = 7;          // the native stream's definition (CHANGES.md): Philox4x32-7
+template <int ROUNDS = PHILOX_ROUNDS>
 RF_HD PhiloxOut philox4x32(uint64_t ctr_lo, uint64_t ctr_hi, uint64_t key) {
   uint32_t c0 = (uint32_t)ctr_lo, c1 = (uint32_t)(ctr_lo >> 32);
   uint32_t c2 = (uint32_t)ctr_hi, c3 = (uint32_t)(ctr_hi >> 32);
@@ -199,7 +197,7 @@ RF_HD PhiloxOut philox4x32(uint64_t ctr_lo, uint64_t ctr_hi, uint64_t key) {
   PhiloxOut o; o.w[0] = c0; o.w[1] = c1; o.w[2] = c2; o.w[3] = c3;
   return o;
 }
-RF_HD PhiloxOut philox_native(uint64_t ctr_lo, uint64_t ctr_hi, uint64_t key) { return philox4x32<RF_PHILOX_ROUNDS>(ctr_lo, ctr_hi, key); }
+RF_HD PhiloxOut philox_native(uint64_t ctr_lo, uint64_t ctr_hi, uint64_t key) { return philox4x32<PHILOX_ROUNDS>(ctr_lo, ctr_hi, key); }
 
 // Box-Muller from two 32-bit words: u = (w + 0.5) / 2^32 in (0, 1).
 template <typename T> struct BoxMuller;
@@ -487,28 +485,21 @@ RF_HD uint64_t fast_pair_counter(const FastGenParams& g, int ix, int iy, int kz)
   return (((uint64_t)ix * (uint64_t)g.ny + (uint64_t)iy) * (uint64_t)(g.nz / 2) + (uint64_t)kz) >> 1;
 }
 
-// AB: development-only ablation mask (1: no Philox, 2: no sigma lookup, 4: no Box-Muller); 0 in the product.
 // The two packed cells kz, kz + 1 of one column from ONE Philox call: k^2 = kxy + kz2a / kz2b.
-template <int AB = 0>
 RF_HD void fast_gen_pair_at(const FastGenParams& g, const FastRec* rec, uint64_t seed, uint64_t ctr, float k2a,
                             float k2b, cplx<float>& c0, cplx<float>& c1) {
-  PhiloxOut o;
-  if (AB & 1) { o.w[0] = (uint32_t)ctr; o.w[1] = (uint32_t)ctr * 3u; o.w[2] = (uint32_t)ctr * 5u; o.w[3] = (uint32_t)ctr * 7u; }
-  else if (AB & 8) o = philox4x32<7>(ctr, 0, seed);   // timing experiment only
-  else o = philox_native(ctr, 0, seed);
+  const PhiloxOut o = philox_native(ctr, 0, seed);
   float g0, g1;
-  const float s0 = (AB & 2) ? k2a : fast_sigma(g, rec, k2a);
-  const float s1 = (AB & 2) ? k2b : fast_sigma(g, rec, k2b);
-  if (AB & 4) { g0 = s0 * (float)o.w[0]; g1 = s0 * (float)o.w[1]; } else BoxMuller<float>::run_scaled(o.w[0], o.w[1], s0, g0, g1);
+  const float s0 = fast_sigma(g, rec, k2a), s1 = fast_sigma(g, rec, k2b);
+  BoxMuller<float>::run_scaled(o.w[0], o.w[1], s0, g0, g1);
   c0 = mk<float>(g0, g1);
-  if (AB & 4) { g0 = s1 * (float)o.w[2]; g1 = s1 * (float)o.w[3]; } else BoxMuller<float>::run_scaled(o.w[2], o.w[3], s1, g0, g1);
+  BoxMuller<float>::run_scaled(o.w[2], o.w[3], s1, g0, g1);
   c1 = mk<float>(g0, g1);
 }
-template <int AB = 0>
 RF_HD void fast_gen_pair(const FastGenParams& g, const FastRec* rec, uint64_t seed, int ix, int iy, int kz,
                          cplx<float>& c0, cplx<float>& c1) {
   const float kxy = fast_kxy2(g, ix, iy);
-  fast_gen_pair_at<AB>(g, rec, seed, fast_pair_counter(g, ix, iy, kz), fast_k2(g, kxy, kz), fast_k2(g, kxy, kz + 1), c0, c1);
+  fast_gen_pair_at(g, rec, seed, fast_pair_counter(g, ix, iy, kz), fast_k2(g, kxy, kz), fast_k2(g, kxy, kz + 1), c0, c1);
 }
 
 // One packed cell with native noise index ci (float64 plans: one complex128 per lane, so the two cells of a Philox

@@ -145,10 +145,7 @@ struct ColGeom {
   bool rows_ok(int L, int npass) const { return row_shift >= 30 || (npass >= 2 && L % (1 << row_shift) == 0); }
   template <bool WIDE, typename E> RF_HD E* at(E* base, long long C0, int cl, int rb, int ro) const {
     E* ub = base + uniform_part(C0, ro);
-#ifndef RF_FORCE_WIDE
-#define RF_FORCE_WIDE 0
-#endif
-    if (WIDE || RF_FORCE_WIDE) return ub + lane_part_wide(cl, rb);
+    if (WIDE) return ub + lane_part_wide(cl, rb);
     return reinterpret_cast<E*>((size_t)ub + (size_t)(lane_part(cl, rb) * (uint32_t)sizeof(E)));
   }
 };
@@ -283,10 +280,7 @@ inline ColGeom xblock_y_geom(long long nx, long long ny, long long nzl, long lon
 template <class IO> inline void set_xpose_order(IO& io, long long nhi, long long tiles_per_run) {
   io.nhi_shift = 63 - __builtin_clzll((unsigned long long)nhi);
   io.tpr_shift = 63 - __builtin_clzll((unsigned long long)tiles_per_run);
-#ifndef RF_XP_GROUP
-#define RF_XP_GROUP 0
-#endif
-  io.grp_shift = io.tpr_shift < RF_XP_GROUP ? io.tpr_shift : RF_XP_GROUP;
+  io.grp_shift = 0;                 // (kz tiles of one ix dispatched in groups of 2^grp_shift: measured, no gain -- DESIGN_HISTORY.md)
 }
 
 // x pass fused with generation (rows K,T,R,S): load() synthesises the packed
@@ -370,7 +364,7 @@ template <typename T, bool WIDE = false> struct GenColIO {
 // 1e-5 * rms parity tolerance) and the pass is HBM-bound (12.9 GB) instead of latency-bound on table lookups.
 // XS: 1 = row r of the pass is mode ix = r; 2 = the pass is one HALF of a transform of twice its length (Col2 below: rows of the
 // even / odd modes ix = 2 r + xp, xp = the phase set_phase() selects) -- native generation without the potential store only.
-template <int AB = 0, int FIX = 1, int SLAB = 0, int POT = 0, int SRC = 0, int XS = 1>
+template <int FIX = 1, int SLAB = 0, int POT = 0, int SRC = 0, int XS = 1>
 struct FastGenColIOT {
   static_assert(XS == 1 || (XS == 2 && SLAB == 0 && POT != 1 && SRC != 1), "half-transform rows: native generation or float32 deviate pairs, no potential store");
   static constexpr int NOISE_SRC = SRC;      // (0 native, 1 float64 deviates, 2 float32 pairs in the replay's runs)
@@ -386,16 +380,9 @@ struct FastGenColIOT {
   RF_HD int nzl_shift() const { return 31 - __builtin_clz((unsigned)nzl); }
   const FastRec* rec;      // set by prologue(): LDS copy of the sigma records (or the global one)
   static constexpr int LDS_EXTRA = FAST_LDS_BINS * (int)sizeof(FastRec);
-  // keep the compiler from interleaving all R generation bodies of a butterfly (register blow-up);
-  // RF_FENCE_EVERY = 0 disables it, k > 0 fences after every k-th row (timing experiments)
-#ifndef RF_FENCE_EVERY
-#define RF_FENCE_EVERY 0
-#endif
-  RF_HD static void sched_fence(int m = 0) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    if (RF_FENCE_EVERY > 0 && (m % (RF_FENCE_EVERY > 0 ? RF_FENCE_EVERY : 1)) == (RF_FENCE_EVERY > 0 ? RF_FENCE_EVERY - 1 : 0)) __builtin_amdgcn_sched_barrier(0);
-#endif
-  }
+  // (a scheduling fence between the R generation bodies of a butterfly was measured every 1, 2 and 4 rows: no gain with the max-ILP
+  // strategy this file is compiled with; the hook stays because ColFFT calls it on every IO)
+  RF_HD static void sched_fence(int = 0) {}
   // stage the sigma records in LDS (every thread copies its share; the kernel barriers afterwards)
   // (the host only selects this kernel when nbins <= FAST_LDS_BINS, so `rec` is always an LDS pointer
   // and the lookups compile to ds_read_b128, not flat loads)
@@ -425,7 +412,7 @@ struct FastGenColIOT {
     const float kxy = fmaf(kx, kx, ky * ky);                                           // == fast_kxy2(gp, rb + ro, iy)
     const float k2a = fast_k2(gp, kxy, kz), k2b = fast_k2(gp, kxy, kz + 1);
     if (SRC == 0) {
-      fast_gen_pair_at<AB>(gp, rec, seed, ctr_l + ctr_u, k2a, k2b, v.c[0], v.c[1]);
+      fast_gen_pair_at(gp, rec, seed, ctr_l + ctr_u, k2a, k2b, v.c[0], v.c[1]);
     } else if (SRC == 1) {
       // cells (ix, iy, kz) and (ix, iy, kz + 1) are adjacent in the reference's order: 4 doubles, 32 contiguous bytes
       const int nzp = gp.zpitch;
@@ -440,11 +427,9 @@ struct FastGenColIOT {
       // and kz + 1 are neighbours unless a segment ends between them
       RowLoc e;
       if (raw) { e.off = 0; e.seg_n = 0; }
-      else if (AB & 64) { e.off = (uint32_t)(iy * gp.nx + rb + ro); e.seg_n = (uint32_t)(gp.nz / 2 + 1); }      // (ablation builds only)
       else e = load_rowloc((gp.rowtab + rot) + (uint32_t)(iy * gp.nx + rbt));
       cplx<float> ga, gb;
       if (raw) { ga = raw->c[0]; gb = raw->c[1]; }                                       // (loaded by preload() at the top of the kernel)
-      else if (AB & 16) { ga = mk<float>((float)e.off, (float)e.seg_n); gb = mk<float>((float)kz, (float)e.off); }
       else { ga = load_pair_global(row_pair(gp, e, kz)); gb = load_pair_global(row_pair(gp, e, kz + 1)); }
       const float sa = fast_sigma(gp, rec, k2a), sb = fast_sigma(gp, rec, k2b);
       v.c[0] = mk<float>(sa * ga.x, sa * ga.y);
@@ -478,13 +463,10 @@ struct FastGenColIOT {
   // The values are bit for bit those of the unshared kernel: kx enters through its square.  Butterfly 0 (rows m L, mirror R - m, row
   // R/2 L its own mirror) and butterfly L/2 (its own mirror image) take no partner: they source from themselves.  XS = 2, odd phase
   // (rows of the modes 2 r + 1): the mirror of row r is N1 - 1 - r, i.e. butterfly L - 1 - j, and no butterfly is its own partner.
-#ifndef RF_SIGMA_SHARE
-#define RF_SIGMA_SHARE 1
-#endif
   // (measured on MI355X, profiles/r05_ab/r05_c_*: the whole-column kernels gain -- x pass of 1024^3 1.186 -> 1.15 ms, 1131 instead of 1198
   // vector instructions per wave -- the two-phase Col2 form, whose register budget is full with the parked half, loses 4 %: 10.87 -> 11.29 ms
-  // per 2048^3; so XS = 1 only, RF_SIGMA_SHARE = 2 includes the Col2 form)
-  static constexpr bool SIGMA_SHARE = RF_SIGMA_SHARE && SRC == 0 && SLAB == 0 && (AB == 0) && (XS == 1 || RF_SIGMA_SHARE >= 2);
+  // per 2048^3; so XS = 1 only)
+  static constexpr bool SIGMA_SHARE = SRC == 0 && SLAB == 0 && XS == 1;
   // butterfly (row base) of slot jl = tid / LPR when there are S slots per wave: the first S/2 slots of a wave take q = (S/2) w + s, the
   // others its partner
   RF_HD int share_row(int jl, int L, int S) const {
@@ -559,12 +541,9 @@ struct FastGenColIOT {
     for (int m = 0; m < R; ++m) out[m] = load(C0, cl, j, m * L);      // (the emulator has no lanes: the same values row by row)
 #endif
   }
-#ifndef RF_SRC2_PRELOAD
-#define RF_SRC2_PRELOAD 1
-#endif
   // SRC = 2: the memory half of load() -- the row's table entry, then its two deviate pairs -- for the kernel to issue before it
   // stages any table (col_kernel): three dependent round trips (records, row table, pairs) become two that overlap the staging
-  static constexpr bool HAS_PRELOAD = (SRC == 2 && RF_SRC2_PRELOAD != 0);
+  static constexpr bool HAS_PRELOAD = (SRC == 2);
   RF_HD V16<float> preload(long long C0, int cl, int rb, int ro) const {
     V16<float> v;
     const long long C = C0 + cl;
@@ -582,8 +561,8 @@ struct FastGenColIOT {
   RF_HD long long remap_tile(long long t) const { return t; }
   static constexpr bool HAS_FINISH = false;
   static constexpr int FIX_MODE = FIX;
-  template <int F2> using with_fix = FastGenColIOT<AB, F2, SLAB, POT, SRC, XS>;
-  using fill_io = FastGenColIOT<AB, 1, SLAB, POT, SRC, 1>;      // the IO whose fix_value() fix_fill_kernel evaluates (mode index = row)
+  template <int F2> using with_fix = FastGenColIOT<F2, SLAB, POT, SRC, XS>;
+  using fill_io = FastGenColIOT<1, SLAB, POT, SRC, 1>;      // the IO whose fix_value() fix_fill_kernel evaluates (mode index = row)
   const cplx<float>* fixbuf = nullptr;                          // FIX = 3: [ny][nx] repaired slots kz = 0, left by fix_fill_kernel
   RF_HD bool needs_fix(long long C) const { return FIX != 0 && kz0 + (int)((unsigned)C & (unsigned)(nzl - 1)) == 0; }
   // FIX = 3: the repaired slot of mode (XS (rb + ro) + xp, iy) from the side buffer (lane part + uniform part, as load())
@@ -613,11 +592,10 @@ struct FastGenColIOT {
   RF_HD void store(long long C0, int cl, int rb, int ro, const V16<float>& v) const {
     // x0, x1 are multiples of the last pass's row stride L (the launcher checks it) and rb < L: the test is uniform
     if (SLAB && (ro < x0 || ro >= x1)) return;
-    if ((AB & 32) && v.c[0].x != 12345.678f) return;                                    // (ablation builds only: no stores)
     v16_store<float>(g.at<false>(base, C0, cl, rb, ro), v);
   }
 };
-using FastGenColIO = FastGenColIOT<0, 1>;   // (emulator)
+using FastGenColIO = FastGenColIOT<1>;   // (emulator)
 
 // The same fast generation for float64 plans (native generator only: parity / reference-noise mode keeps the exact
 // float64 chain of GenColIO).  The deviates and sigma are formed in float32 -- hardware log / sin / cos, LDS
@@ -1221,29 +1199,23 @@ struct RowCfg {
 // real [nrows][2M] on output (same memory).  Accumulates sum / sum of squares.
 // streaming (non-temporal) access to one complex element: the z pass touches every byte exactly once, so there is
 // nothing to keep in the caches (a read+write sweep with the hint ran 6 % faster than without, tools/xbench.hip)
-#ifndef RF_Z_NT
-#define RF_Z_NT 1
-#endif
 template <typename T> RF_HD cplx<T> stream_load(const cplx<T>* p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  if (RF_Z_NT) {
-    typedef T vt __attribute__((ext_vector_type(2)));
-    const vt v = __builtin_nontemporal_load(reinterpret_cast<const vt*>(p));
-    return mk<T>(v.x, v.y);
-  }
-#endif
+  typedef T vt __attribute__((ext_vector_type(2)));
+  const vt v = __builtin_nontemporal_load(reinterpret_cast<const vt*>(p));
+  return mk<T>(v.x, v.y);
+#else
   return *p;
+#endif
 }
 template <typename T> RF_HD void stream_store(cplx<T>* p, cplx<T> z) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  if (RF_Z_NT) {
-    typedef T vt __attribute__((ext_vector_type(2)));
-    vt v; v.x = z.x; v.y = z.y;
-    __builtin_nontemporal_store(v, reinterpret_cast<vt*>(p));
-    return;
-  }
-#endif
+  typedef T vt __attribute__((ext_vector_type(2)));
+  vt v; v.x = z.x; v.y = z.y;
+  __builtin_nontemporal_store(v, reinterpret_cast<vt*>(p));
+#else
   *p = z;
+#endif
 }
 
 // Per-thread (sum, sum of squares) of the values a thread stores in the z pass.  float32 fields: FOUR float32 accumulators (the real and
@@ -1404,10 +1376,7 @@ RF_HD double exp_finish(double f, double tj, int k) {
   // exp(c f) - 1 = f (c + f (c^2/2 + f (c^3/6 + f c^4/24))): |c f| <= ln2/128, so the first dropped term (c f)^5/120 is <= 3.9e-14 of
   // the result -- the fused map is checked against the reference's chain to 1e-12, its tolerance is 1e-11 (rounds 3 - 4 carried the
   // fifth-order term too: one more float64 fma per element, 2 x 10^9 of them per 1024^3 field)
-#ifndef RF_EXP_DEGREE5
-#define RF_EXP_DEGREE5 0
-#endif
-  double q = RF_EXP_DEGREE5 ? __builtin_fma(f, 0x1.5d87fe78a6731p-40 /* c^5/120 */, 0x1.3b2ab6fba4e77p-31 /* c^4/24 */) : 0x1.3b2ab6fba4e77p-31 /* c^4/24 */;
+  double q = 0x1.3b2ab6fba4e77p-31 /* c^4/24 */;
   q = __builtin_fma(f, q, 0x1.c6b08d704a0c0p-23 /* c^3/6 */);
   q = __builtin_fma(f, q, 0x1.ebfbdff82c58fp-15 /* c^2/2 */);
   q = __builtin_fma(f, q, 0x1.62e42fefa39efp-7 /* c */);
@@ -1453,10 +1422,6 @@ template <typename T, int SPARE = 0> struct LognormalRowIO {
 #else
     const double* tb = (SPARE && etab) ? etab : rf_exp2_tab;        // (the emulator has no staging step)
     if (!(SPARE && etab)) return exp_scaled64<1>(d * Ap[z], tb) * Bp[z];
-#endif
-#ifdef RF_LN_AB                    // (ablation builds only: bit 0 = uniform table entries, bit 1 = no gather)
-    if (RF_LN_AB & 1) z = 0;
-    if (RF_LN_AB & 2) tb = nullptr;
 #endif
     return exp_scaled64<ESTRIDE>(d * Ap[z], tb) * Bp[z];
   }
@@ -1599,19 +1564,15 @@ struct RowC2R {
   static constexpr int TW_LT = M, TW_MT = M + (C::NPASS >= 2 ? (C::RL - 1) * LL : 0);
   static constexpr int TW_END = TW_MT + (C::NPASS == 3 ? (C::R2 - 1) * C::R1 : 0);
   static_assert(TW_END <= 2 * M, "the three tables fit the space of the plain one");
-#ifndef RF_Z_TW_TABLES
-#define RF_Z_TW_TABLES 1                               // 0: the plain table in LDS, as in rounds 1 - 4 (A/B builds)
-#endif
   RF_HD static int tw_source(int e) {                  // entry e of the LDS image <- entry tw_source(e) of the plain table
-    if (!RF_Z_TW_TABLES) return e;
     if (e < TW_LT) return e;
     if (e < TW_MT) { const int r = e - TW_LT; return 2 * (r / LL + 1) * (r % LL); }
     if (e < TW_END) { const int r = e - TW_MT; return 2 * (r / C::R1 + 1) * (r % C::R1) * (M / (C::R1 * cmax(C::R2, 1))); }
     return 0;
   }
-  RF_HD static cx tw_last(const cx* ltw, int m, int j) { return RF_Z_TW_TABLES ? ltw[TW_LT + (m - 1) * LL + j] : ltw[2 * m * j]; }
+  RF_HD static cx tw_last(const cx* ltw, int m, int j) { return ltw[TW_LT + (m - 1) * LL + j]; }
   RF_HD static cx tw_mid(const cx* ltw, int m, int j) {
-    return RF_Z_TW_TABLES ? ltw[TW_MT + (m - 1) * C::R1 + (j % C::R1)] : ltw[2 * stockham_tw_index(j, m, C::R1, cmax(C::R2, 1), M)];
+    return ltw[TW_MT + (m - 1) * C::R1 + (j % C::R1)];
   }
   // The table (needed by pass 1 already: the untangle) goes global -> registers (tw_fetch), then the row data
   // (pass_first_load), then registers -> LDS (tw_stage) and a barrier: both trips to memory are in flight together, and the

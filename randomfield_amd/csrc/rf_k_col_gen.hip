@@ -39,19 +39,19 @@ hipError_t launch_col_fastgen(int f64, int N, void* W, ColGeom g, long long ncol
     if (gp.emit_potential && (slab || pot || gp.noise)) return hipErrorInvalidValue;
     if (gp.noise32 || po)                      // ... of the replayed deviates (float32 pairs in the replay's runs)
       switch (N) {
-#define X(NN) case NN: { hipError_t e = launch_fast_one<typename GenSel<float, NN>::type, FastGenColIOT<0, 0, 0, 2, 2>, FastGenColIOT<0, 1, 0, 2, 2>, cplx<float>>(gp, (cplx<float>*)W, g, ncols, kz0, nzl, (const cplx<float>*)tw, s, po, after_repair, x0, x1, (cplx<float>*)fixbuf); if (!po || e != hipSuccess) return e; break; }
+#define X(NN) case NN: { hipError_t e = launch_fast_one<typename GenSel<float, NN>::type, FastGenColIOT<0, 0, 2, 2>, FastGenColIOT<1, 0, 2, 2>, cplx<float>>(gp, (cplx<float>*)W, g, ncols, kz0, nzl, (const cplx<float>*)tw, s, po, after_repair, x0, x1, (cplx<float>*)fixbuf); if (!po || e != hipSuccess) return e; break; }
         RF_COL_SIZES(X)
 #undef X
         default: return hipErrorInvalidValue;
       }
     if (RF_COL2_2048 && N == 2048) {
       using C1 = GenSel<float, 1024>::type;
-      hipError_t e = launch_fast_one2<C1, FastGenColIOT<0, 0, 0, 2, 0, 2>, FastGenColIOT<0, 1, 0, 2, 0, 2>>(
+      hipError_t e = launch_fast_one2<C1, FastGenColIOT<0, 0, 2, 0, 2>, FastGenColIOT<1, 0, 2, 0, 2>>(
           gp, (cplx<float>*)W, g, ncols, kz0, nzl, (const cplx<float>*)tw, s, po, after_repair, (cplx<float>*)fixbuf);
       if (!po || e != hipSuccess) return e;
     }
     switch (N) {
-#define X(NN) case NN: { hipError_t e = launch_fast_one<typename GenSel<float, NN>::type, FastGenColIOT<0, 0, 0, 2>, FastGenColIOT<0, 1, 0, 2>, cplx<float>>(gp, (cplx<float>*)W, g, ncols, kz0, nzl, (const cplx<float>*)tw, s, po, after_repair, x0, x1, (cplx<float>*)fixbuf); if (!po || e != hipSuccess) return e; break; }
+#define X(NN) case NN: { hipError_t e = launch_fast_one<typename GenSel<float, NN>::type, FastGenColIOT<0, 0, 2>, FastGenColIOT<1, 0, 2>, cplx<float>>(gp, (cplx<float>*)W, g, ncols, kz0, nzl, (const cplx<float>*)tw, s, po, after_repair, x0, x1, (cplx<float>*)fixbuf); if (!po || e != hipSuccess) return e; break; }
       RF_COL_SIZES(X)
 #undef X
       default: return hipErrorInvalidValue;
@@ -60,36 +60,25 @@ hipError_t launch_col_fastgen(int f64, int N, void* W, ColGeom g, long long ncol
   if (gp.noise || po) {                        // resident float64 deviates (rng='reference') through the fast float32 sigma path
     if (gp.noise && (slab || pot)) return hipErrorInvalidValue;
     switch (N) {
-#define X(NN) case NN: { hipError_t e = launch_fast_one<typename GenSel<float, NN>::type, FastGenColIOT<0, 0, 0, 0, 1>, FastGenColIOT<0, 1, 0, 0, 1>, cplx<float>>(gp, (cplx<float>*)W, g, ncols, kz0, nzl, (const cplx<float>*)tw, s, po, after_repair, x0, x1, (cplx<float>*)fixbuf); if (!po || e != hipSuccess) return e; break; }
+#define X(NN) case NN: { hipError_t e = launch_fast_one<typename GenSel<float, NN>::type, FastGenColIOT<0, 0, 0, 1>, FastGenColIOT<1, 0, 0, 1>, cplx<float>>(gp, (cplx<float>*)W, g, ncols, kz0, nzl, (const cplx<float>*)tw, s, po, after_repair, x0, x1, (cplx<float>*)fixbuf); if (!po || e != hipSuccess) return e; break; }
       RF_COL_SIZES(X)
 #undef X
       default: return hipErrorInvalidValue;
     }
   }
-#ifndef RF_SRC2_AB
-#define RF_SRC2_AB 0                   // ablation mask of the deviate-reading kernel (16: no pair loads, 32: no stores, 64: no table loads); 0 in the product
-#endif
   if (gp.noise32 || po) {                      // resident float32 deviates, without / with the potential store
     if (gp.noise32 && slab) return hipErrorInvalidValue;
-#ifndef RF_SRC2_COL2_1024
-#define RF_SRC2_COL2_1024 0            // EXPERIMENT (measured, not adopted: 2.69 against 2.47 ms per 1024^3): the deviate-reading pass of length 1024 as two
-                                       // 512-point transforms per tile (256 threads, 44 KB: three workgroups per CU), as the in-place y pass runs
-#endif
-    if (RF_SRC2_COL2_1024 && N == 1024 && (!pot || po)) {
-      hipError_t e = launch_fast_one2<PairSel1024::type, FastGenColIOT<RF_SRC2_AB, 0, 0, 0, 2, 2>, FastGenColIOT<RF_SRC2_AB, 1, 0, 0, 2, 2>>(
-          gp, (cplx<float>*)W, g, ncols, kz0, nzl, (const cplx<float>*)tw, s, po, after_repair, (cplx<float>*)fixbuf);
-      if (!po || e != hipSuccess) return e;
-    }
+    // (the same pass as two 512-point transforms per tile, as the in-place y pass runs: measured 2.69 against 2.47 ms per 1024^3, not kept)
     if (!pot || po)
       switch (N) {
-#define X(NN) case NN: { hipError_t e = launch_fast_one<typename GenSel<float, NN>::type, FastGenColIOT<RF_SRC2_AB, 0, 0, 0, 2>, FastGenColIOT<RF_SRC2_AB, 1, 0, 0, 2>, cplx<float>>(gp, (cplx<float>*)W, g, ncols, kz0, nzl, (const cplx<float>*)tw, s, po, after_repair, x0, x1, (cplx<float>*)fixbuf); if (!po || e != hipSuccess) return e; break; }
+#define X(NN) case NN: { hipError_t e = launch_fast_one<typename GenSel<float, NN>::type, FastGenColIOT<0, 0, 0, 2>, FastGenColIOT<1, 0, 0, 2>, cplx<float>>(gp, (cplx<float>*)W, g, ncols, kz0, nzl, (const cplx<float>*)tw, s, po, after_repair, x0, x1, (cplx<float>*)fixbuf); if (!po || e != hipSuccess) return e; break; }
         RF_COL_SIZES(X)
 #undef X
         default: return hipErrorInvalidValue;
       }
     if (pot || po)
       switch (N) {
-#define X(NN) case NN: { hipError_t e = launch_fast_one<typename GenSel<float, NN>::type, FastGenColIOT<0, 0, 0, 1, 2>, FastGenColIOT<0, 1, 0, 1, 2>, cplx<float>>(gp, (cplx<float>*)W, g, ncols, kz0, nzl, (const cplx<float>*)tw, s, po, after_repair, x0, x1, (cplx<float>*)fixbuf, (cplx<float>*)pot); if (!po || e != hipSuccess) return e; break; }
+#define X(NN) case NN: { hipError_t e = launch_fast_one<typename GenSel<float, NN>::type, FastGenColIOT<0, 0, 1, 2>, FastGenColIOT<1, 0, 1, 2>, cplx<float>>(gp, (cplx<float>*)W, g, ncols, kz0, nzl, (const cplx<float>*)tw, s, po, after_repair, x0, x1, (cplx<float>*)fixbuf, (cplx<float>*)pot); if (!po || e != hipSuccess) return e; break; }
         RF_COL_SIZES(X)
 #undef X
         default: return hipErrorInvalidValue;
@@ -98,7 +87,7 @@ hipError_t launch_col_fastgen(int f64, int N, void* W, ColGeom g, long long ncol
   if (pot || po) {                             // generation + potential store (save_potential=True), whole grid
     if (slab && pot) return hipErrorInvalidValue;
     switch (N) {
-#define X(NN) case NN: { hipError_t e = launch_fast_one<typename GenSel<float, NN>::type, FastGenColIOT<0, 0, 0, 1>, FastGenColIOT<0, 1, 0, 1>, cplx<float>>(gp, (cplx<float>*)W, g, ncols, kz0, nzl, (const cplx<float>*)tw, s, po, after_repair, x0, x1, (cplx<float>*)fixbuf, (cplx<float>*)pot); if (!po || e != hipSuccess) return e; break; }
+#define X(NN) case NN: { hipError_t e = launch_fast_one<typename GenSel<float, NN>::type, FastGenColIOT<0, 0, 1>, FastGenColIOT<1, 0, 1>, cplx<float>>(gp, (cplx<float>*)W, g, ncols, kz0, nzl, (const cplx<float>*)tw, s, po, after_repair, x0, x1, (cplx<float>*)fixbuf, (cplx<float>*)pot); if (!po || e != hipSuccess) return e; break; }
       RF_COL_SIZES(X)
 #undef X
       default: return hipErrorInvalidValue;
@@ -106,23 +95,20 @@ hipError_t launch_col_fastgen(int f64, int N, void* W, ColGeom g, long long ncol
   }
   if (slab || po) {
     switch (N) {
-#define X(NN) case NN: { hipError_t e = launch_fast_one<typename GenSel<float, NN>::type, FastGenColIOT<0, 0, 1>, FastGenColIOT<0, 1, 1>, cplx<float>>(gp, (cplx<float>*)W, g, ncols, kz0, nzl, (const cplx<float>*)tw, s, po, after_repair, x0, x1, (cplx<float>*)fixbuf); if (!po || e != hipSuccess) return e; break; }
+#define X(NN) case NN: { hipError_t e = launch_fast_one<typename GenSel<float, NN>::type, FastGenColIOT<0, 1>, FastGenColIOT<1, 1>, cplx<float>>(gp, (cplx<float>*)W, g, ncols, kz0, nzl, (const cplx<float>*)tw, s, po, after_repair, x0, x1, (cplx<float>*)fixbuf); if (!po || e != hipSuccess) return e; break; }
       RF_COL_SIZES(X)
 #undef X
       default: return hipErrorInvalidValue;
     }
   }
-#ifndef RF_GEN_AB
-#define RF_GEN_AB 0                    // ablation mask of the benchmarked kernel (rf_core.h fast_gen_pair_at); 0 in the product
-#endif
   if (RF_COL2_2048 && N == 2048 && (!slab || po)) {
     using C1 = GenSel<float, 1024>::type;
-    hipError_t e = launch_fast_one2<C1, FastGenColIOT<RF_GEN_AB, 0, 0, 0, 0, 2>, FastGenColIOT<RF_GEN_AB, 1, 0, 0, 0, 2>>(
+    hipError_t e = launch_fast_one2<C1, FastGenColIOT<0, 0, 0, 0, 2>, FastGenColIOT<1, 0, 0, 0, 2>>(
         gp, (cplx<float>*)W, g, ncols, kz0, nzl, (const cplx<float>*)tw, s, po, after_repair, (cplx<float>*)fixbuf);
     if (!po || e != hipSuccess) return e;
   }
   switch (N) {
-#define X(NN) case NN: return launch_fast_one<typename GenSel<float, NN>::type, FastGenColIOT<RF_GEN_AB, 0, 0>, FastGenColIOT<RF_GEN_AB, 1, 0>, cplx<float>>(gp, (cplx<float>*)W, g, ncols, kz0, nzl, (const cplx<float>*)tw, s, po, after_repair, x0, x1, (cplx<float>*)fixbuf);
+#define X(NN) case NN: return launch_fast_one<typename GenSel<float, NN>::type, FastGenColIOT<0, 0>, FastGenColIOT<1, 0>, cplx<float>>(gp, (cplx<float>*)W, g, ncols, kz0, nzl, (const cplx<float>*)tw, s, po, after_repair, x0, x1, (cplx<float>*)fixbuf);
     RF_COL_SIZES(X)
 #undef X
     default: return hipErrorInvalidValue;
@@ -155,7 +141,7 @@ int col_gen_row_block(int f64, int N, int want) {
 bool col_fastgen_supported(int f64, int N) {
   switch (N) {
 #define X(NN) case NN: return f64 ? GenSel<double, NN>::type::LDS_BYTES + FastGenColIO64<1, 0>::LDS_EXTRA <= 160 * 1024 \
-                                  : GenSel<float, NN>::type::LDS_BYTES + FastGenColIOT<0, 1, 0>::LDS_EXTRA <= 160 * 1024;
+                                  : GenSel<float, NN>::type::LDS_BYTES + FastGenColIOT<1, 0>::LDS_EXTRA <= 160 * 1024;
     RF_COL_SIZES(X)
 #undef X
     default: return false;

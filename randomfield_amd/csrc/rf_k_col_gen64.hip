@@ -11,7 +11,7 @@ hipError_t launch_col_fastgen64(int N, void* W, ColGeom g, long long ncols, cons
   if (gp.noise || (gp.noise32 && !po)) return hipErrorInvalidValue;     // resident deviates: the exact kernel serves float64 plans
   if (gp.emit_potential || po) {               // POT = 2: the pass transforms pscale * delta(k) / k^2 (rf_realise_scaled_potential)
     if (gp.emit_potential && (slab || pot)) return hipErrorInvalidValue;
-    if (RF_COL2_F64_1024 && N == 1024) {
+    if (N == 1024) {                   // (as two 512-point transforms per tile, Col2: two workgroups per CU -- DESIGN.md 3.10)
       using C1 = GenSel<double, 512>::type;
       hipError_t e = launch_fast_one2<C1, FastGenColIO64<0, 0, 2, 2>, FastGenColIO64<1, 0, 2, 2>>(
           gp, (cplx<double>*)W, g, ncols, kz0, nzl, (const cplx<double>*)tw, s, po, after_repair, (cplx<double>*)fixbuf);
@@ -33,7 +33,7 @@ hipError_t launch_col_fastgen64(int N, void* W, ColGeom g, long long ncols, cons
       default: return hipErrorInvalidValue;
     }
   }
-  if (RF_COL2_F64_1024 && N == 1024 && (!slab || po)) {
+  if (N == 1024 && (!slab || po)) {
     using C1 = GenSel<double, 512>::type;
     hipError_t e = launch_fast_one2<C1, FastGenColIO64<0, 0, 0, 2>, FastGenColIO64<1, 0, 0, 2>>(
         gp, (cplx<double>*)W, g, ncols, kz0, nzl, (const cplx<double>*)tw, s, po, after_repair, (cplx<double>*)fixbuf);

@@ -76,13 +76,7 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
 // (and classes') partial XORs meet in LDS, indexed by output word, in the space the position table occupied.
 // History of one jump on a CU: 0.19 ms with one word per lane and 10 waves, 0.14 ms with ds_read2st64_b32 and 15 waves, 0.087 ms
 // with ds_read_b64, see DESIGN.md section 3.6 for the 16-byte form.
-#ifndef RF_MT_JUMP_GROUPS
-#define RF_MT_JUMP_GROUPS 4
-#endif
-#ifndef RF_MT_JUMP_UNROLL
-#define RF_MT_JUMP_UNROLL 2        // chunks of 8 reads in flight per lane
-#endif
-constexpr int MT_JUMP_LANES = 160, MT_JUMP_USED = MT_N / 4 + 1, MT_JUMP_GROUPS = RF_MT_JUMP_GROUPS, MT_JUMP_THREADS = MT_JUMP_LANES * MT_JUMP_GROUPS;
+constexpr int MT_JUMP_LANES = 160, MT_JUMP_USED = MT_N / 4 + 1, MT_JUMP_GROUPS = 4, MT_JUMP_THREADS = MT_JUMP_LANES * MT_JUMP_GROUPS;
 constexpr int MT_ZERO_WORDS = 4 * MT_JUMP_LANES;                         // zero block behind the window: the padding position of every class
 constexpr int MT_PART_WORDS = 4 * MT_JUMP_LANES;                          // per (group, class): output words 0 .. 623 (+ slack)
 constexpr int MT_JUMP_POS_BYTES = MT_POS_MAX * (int)sizeof(uint32_t);
@@ -138,7 +132,7 @@ __global__ __launch_bounds__(MT_JUMP_THREADS) void mt_jump_kernel(const uint32_t
       const int n = c == 0 ? n0 : (c == 1 ? n1 : (c == 2 ? n2 : n3));
       const u4* lp = reinterpret_cast<const u4*>(lpos + off);         // (off is a multiple of 8 words)
       u4 a = {0u, 0u, 0u, 0u};
-#pragma unroll RF_MT_JUMP_UNROLL
+#pragma unroll 2                           // (chunks of 8 reads in flight per lane; 1 and 4 measured: no difference)
       for (int j = 2 * grp; j < (n >> 2); j += 2 * MT_JUMP_GROUPS) {  // a chunk of 8 positions = two broadcast reads
         const u4 q0 = lp[j], q1 = lp[j + 1];
 #define RF_MT_QUAD(o) (*reinterpret_cast<const u4*>(__builtin_assume_aligned(wb + (o), 16)))
@@ -202,9 +196,6 @@ __global__ __launch_bounds__(MT_JUMP_THREADS) void mt_jump_kernel(const uint32_t
 //   integers by TwoSum / fused-multiply-add residuals, log1p by its series, float64 only for |d| < 2^-11: no acceptance differed over
 //   4e7 modelled attempts, and the replay took exactly as long (3.74 - 3.78 against 3.73 - 3.77 ms per 1024^3, profiles/r05_ab/
 //   r05_d_mt_ab.log): the pass is bound by the latency chain of its in-order LDS regeneration, not by those instructions.  Removed.)
-#ifndef RF_MT_POLAR_PAIRS
-#define RF_MT_POLAR_PAIRS 1            // 0: one block per round (three wave iterations of 156 attempts), as in rounds 1 - 4
-#endif
 typedef __attribute__((address_space(3))) uint32_t mt_lds_u32;
 
 // the next 624 words: nw <- f(od) (od == nw: in place)
@@ -267,7 +258,7 @@ template <bool F32>
 __global__ __launch_bounds__(256) void mt_polar_kernel(const uint32_t* __restrict__ states, int blocks_per_segment,
                                                        long long total_blocks, int nseg, unsigned long long* __restrict__ counts,
                                                        double* __restrict__ runs, unsigned long long cap) {
-  constexpr int NWIN = RF_MT_POLAR_PAIRS ? 2 : 1, WIN = MT_N + 16, NATT = MT_N / 4;
+  constexpr int NWIN = 2, WIN = MT_N + 16, NATT = MT_N / 4;
   __shared__ __attribute__((aligned(16))) uint32_t lds[4][NWIN * WIN];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long long seg = (long long)blockIdx.x * 4 + wave;
@@ -314,12 +305,10 @@ __global__ __launch_bounds__(256) void mt_polar_kernel(const uint32_t* __restric
     }
   };
   long long b = 0;
-  if (RF_MT_POLAR_PAIRS) {
-    for (; b + 2 <= nb; b += 2) {
-      mt_wave_regen(P, Q, lane);                             // block b     : P <- f(Q)
-      mt_wave_regen(Q, P, lane);                             // block b + 1 : Q <- f(P)
-      attempts(2 * NATT);
-    }
+  for (; b + 2 <= nb; b += 2) {
+    mt_wave_regen(P, Q, lane);                               // block b     : P <- f(Q)
+    mt_wave_regen(Q, P, lane);                               // block b + 1 : Q <- f(P)
+    attempts(2 * NATT);
   }
   for (; b < nb; ++b) {                                      // (the odd block of a segment; every block when pairs are off)
     mt_wave_regen(P, NWIN == 2 ? Q : P, lane);

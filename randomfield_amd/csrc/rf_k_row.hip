@@ -2,9 +2,6 @@
 #include "rf_kernels.h"
 #include "rf_launch.h"
 
-#ifndef RF_LN_SPARE
-#define RF_LN_SPARE 1       // the float64 lognormal epilogue's exp table in the tile's spare LDS slots (0: read from global memory)
-#endif
 
 namespace rf {
 namespace {
@@ -76,7 +73,7 @@ hipError_t launch_lognormal_t(int M, cplx<T>* W, long long nrows, double scale, 
                               const cplx<T>* tw, double* partials, hipStream_t s, bool po) {
   // float64 rows of >= 512 complex: the exp table in the tile's spare LDS slots (rf_fft.h LognormalRowIO)
   switch (M) {
-#define X(MM) case MM: { constexpr int SP = (RF_LN_SPARE && sizeof(T) == 8 && MM >= 512) ? 1 : 0;                       \
+#define X(MM) case MM: { constexpr int SP = (sizeof(T) == 8 && MM >= 512) ? 1 : 0;                       \
     LognormalRowIO<T, SP> io; io.base = W; io.scale = (T)scale; io.M_of = M; io.Ap = Ap; io.Bp = Bp;                     \
     return launch_one<typename RowSel<T, MM>::type, LognormalRowIO<T, SP>>(io, nrows, tw, partials, s, po); }
     RF_ROW_SIZES(X)

@@ -33,7 +33,7 @@ __global__ __launch_bounds__((CR::NT > YB::NT ? CR::NT : YB::NT)) void yz_merged
   extern __shared__ __attribute__((aligned(16))) char rf_smem[];
   if (blockIdx.x < nz_tiles) {
     if (CR::NT < YB::NT && threadIdx.x >= CR::NT) return;
-    const long long tile = RF_Z_REVERSE ? (long long)nz_tiles - 1 - blockIdx.x : (long long)blockIdx.x;
+    const long long tile = (long long)nz_tiles - 1 - blockIdx.x;          // (rows last to first, as row_c2r_kernel)
     row_c2r_body<CR, RIO>(rio, twz, nrows, partials, tile, rf_smem);
   } else {
     if (YB::NT < CR::NT && threadIdx.x >= YB::NT) return;

@@ -23,7 +23,7 @@ constexpr int col_min_waves() {
   return w < 1 ? 1 : (w > 4 ? 4 : w);
 }
 
-// one tile of a strided pass (the body of col_kernel; col_pair_kernel runs two kinds of it in one grid)
+// one tile of a strided pass (the body of col_kernel)
 template <class C, int DIR, class IO>
 __device__ __forceinline__ void col_body(IO& io, const cplx<typename C::T>* __restrict__ tw, long long tile, char* rf_smem) {
   using F = ColFFT<C, DIR, IO>;
@@ -78,22 +78,6 @@ __global__ __launch_bounds__(C::NT, (col_min_waves<C, IO>())) void col_kernel(IO
   col_body<C, DIR, IO>(io, tw, io.remap_tile(tile), rf_smem);                     // (remap: identity except for XposeColIO)
 }
 
-// Two kinds of tile of the same pass in ONE grid: workgroups [0, na) run IO `ioa` on the tiles b * mul_a (the generation pass's kz = 0
-// tiles with the Hermitian repair from the side buffer), the others IO `iob` on all tiles except those = 0 mod skip_b.  The kz = 0
-// launch on its own is two rounds of workgroups -- latency, not throughput (0.03 - 0.05 ms per 1024^3 realisation); in front of the
-// main tiles in one grid it costs its share of the throughput.  Each kind keeps its own code: a uniform branch on the workgroup index.
-template <class C, int DIR, class IOA, class IOB>
-__global__ __launch_bounds__(C::NT, (col_min_waves<C, IOB>())) void col_pair_kernel(IOA ioa, IOB iob, const cplx<typename C::T>* __restrict__ tw,
-                                                                                 long long na, long long mul_a, long long nb, int skip_b) {
-  extern __shared__ __attribute__((aligned(16))) char rf_smem[];
-  if ((long long)blockIdx.x < na) {
-    col_body<C, DIR, IOA>(ioa, tw, (long long)blockIdx.x * mul_a, rf_smem);
-  } else {
-    const unsigned t = (unsigned)xcd_tile((long long)blockIdx.x - na, nb);       // (na is a multiple of 8: xcd_tile's assumption holds)
-    col_body<C, DIR, IOB>(iob, tw, (long long)(t + t / (unsigned)(skip_b - 1) + 1u), rf_smem);
-  }
-}
-
 // The repaired slots kz = 0 of every mode (ix, iy) -- (plane kz = 0) + i (plane kz = nz/2), each Hermitian-symmetrised
 // (transform.py:141-158; rf_core.h fast_fix_kz0) -- into the side buffer out[iy * nx + ix] that the FIX = 3 launch of the generation
 // pass reads.  IOF = the pass's IO with FIX = 1 and rows = modes (fill_io): the SAME fix_value() the pass itself would evaluate,
@@ -146,11 +130,10 @@ __device__ __forceinline__ void col2_body(IO& io, const cplx<typename C1::T>* __
     // instructions on sign-correct divisions and un-folded LDS addresses)
     unsigned tu = (unsigned)tid;
     asm volatile("" : "+v"(tu));
-#ifndef RF_COL2_MASK_PHASES
-#define RF_COL2_MASK_PHASES 0          // bit p: phase p of a FLOAT32 pass sees the masked index.  None: at 122 registers next to the 32 parked ones the folded
-#endif                                 // addresses cost 12 - 60 bytes of scratch per thread and the 2048^3 x pass runs 9 % SLOWER (12.4 -> 13.6 ms); the float64
-                                       // generation pass (104 registers) takes the mask in both phases: 2.63 -> 2.47 ms per 1024^3
-    constexpr int mask_phases = sizeof(typename C1::T) == 8 ? 3 : (RF_COL2_MASK_PHASES & 3);
+    // float32 passes see the unmasked index in both phases: at 122 registers next to the 32 parked ones the folded addresses cost 12 - 60
+    // bytes of scratch per thread and the 2048^3 x pass runs 9 % SLOWER (12.4 -> 13.6 ms); the float64 generation pass (104 registers)
+    // takes the mask in both phases: 2.63 -> 2.47 ms per 1024^3
+    constexpr int mask_phases = sizeof(typename C1::T) == 8 ? 3 : 0;
     const int t = ((mask_phases >> phase) & 1) ? (int)(tu & (unsigned)(C1::NT - 1)) : (int)tu;
     static_assert((C1::NT & (C1::NT - 1)) == 0, "the thread count of a Col2 pass is a power of two");
     if constexpr (F::PRELOAD) {                      // (IOs that read memory in pass 1: this phase's loads go out first)
@@ -252,32 +235,6 @@ __global__ __launch_bounds__(C::NT, (col_min_waves<C, IO>())) void colpair_kerne
   colpair_body<C, DIR, IO>(io, tw, pair, rf_smem);
 }
 
-// EXPERIMENT (RF_Z_XLANE = 1): the exchange between the middle and the last radix-8 stage of the z pass
-// through the wave's cross-lane network instead of the LDS row image.  With M / 8 = 64 a wave owns a row in both stages: stage-2
-// thread j = 8a + b leaves elements i = 64a + b + 8m (m = 0..7), stage-3 thread j' = b + 8p wants i = j' + 64m' -- element p of
-// lane b + 8m': an 8 x 8 transpose between the register index and lane bits 3..5, done as three butterfly exchanges
-// (__shfl_xor by 8, 16, 32: ds_bpermute / DPP), 24 32-bit exchanges per thread instead of 8 ds_write_b64 + 8 ds_read_b64 and
-// two barriers.
-#ifndef RF_Z_XLANE
-#define RF_Z_XLANE 0
-#endif
-template <typename T>
-__device__ __forceinline__ void xlane_transpose8(cplx<T>* v, int lane) {
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const bool hi = (lane >> (3 + k)) & 1;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      if (e & (1 << k)) continue;
-      const int f = e | (1 << k);
-      // lanes with the bit clear keep v[e] and trade v[f] for the partner's v[e]; lanes with it set keep v[f] and trade v[e]
-      const T sx = hi ? v[e].x : v[f].x, sy = hi ? v[e].y : v[f].y;
-      const T rx = __shfl_xor(sx, 8 << k), ry = __shfl_xor(sy, 8 << k);
-      if (hi) { v[e].x = rx; v[e].y = ry; } else { v[f].x = rx; v[f].y = ry; }
-    }
-  }
-}
-
 // one tile of the z pass (the body of row_c2r_kernel; yz_merged_kernel runs it for its z tiles): c2r rows + the workgroup's
 // (sum, sum of squares) into partials[2 tile]
 template <class C, class IO>
@@ -305,36 +262,17 @@ __device__ __forceinline__ void row_c2r_body(IO& io, const cplx<typename C::T>* 
     __syncthreads();
     F::pass_first(tid, tile, nrows, io, ltw, lds, r);
   }
-  constexpr bool xlane = RF_Z_XLANE && C::NPASS == 3 && C::R2 == 8 && C::RL == 8 && C::M / 8 == 64 && sizeof(typename C::T) == 4 && C::NT % 64 == 0;
-  if constexpr (xlane) {
+  // (the exchange between the middle and the last radix-8 stage through the wave's cross-lane network instead of the LDS row image was
+  // measured in round 3 -- 24 ds_bpermute per thread against 8 + 8 LDS accesses and two barriers -- and lost: DESIGN_HISTORY.md)
+  if (C::NPASS == 3) {
     __syncthreads();
-    F::pass_mid_read(tid, ltw, lds, r);            // stage 2: LDS -> registers -> DFT8 (r.v[it][m])
-#pragma unroll
-    for (int it = 0; it < C::IT2; ++it) {
-      const int w = it * C::NT + tid, rl = w / 64, j = w % 64;
-      if (rl < C::NRT) {
-        xlane_transpose8(r.v[it], tid & 63);       // -> the inputs of stage-3 thread j
-        cx v[8];
-#pragma unroll
-        for (int m = 0; m < 8; ++m) v[m] = m > 0 ? cmul(r.v[it][m], F::tw_last(ltw, m, j)) : r.v[it][0];
-        DFT<8, +1>::run(v);
-        if (tile * C::NRT + rl < nrows) {
-#pragma unroll
-          for (int m = 0; m < 8; ++m) io.template store2<C::NRT>(tile, rl, j, m * 64, v[m], r.mom);
-        }
-      }
-    }
-  } else {
-    if (C::NPASS == 3) {
-      __syncthreads();
-      F::pass_mid_read(tid, ltw, lds, r);
-      __syncthreads();
-      F::pass_mid_write(tid, lds, r);
-    }
-    if (C::NPASS >= 2) {
-      __syncthreads();
-      F::pass_last(tid, tile, nrows, io, ltw, lds, r);
-    }
+    F::pass_mid_read(tid, ltw, lds, r);
+    __syncthreads();
+    F::pass_mid_write(tid, lds, r);
+  }
+  if (C::NPASS >= 2) {
+    __syncthreads();
+    F::pass_last(tid, tile, nrows, io, ltw, lds, r);
   }
   // workgroup reduction of the moments: wave shuffle, then one slot per wave in LDS
   double s1 = r.mom.sum(), s2 = r.mom.sumsq();
@@ -363,12 +301,9 @@ __device__ __forceinline__ void row_c2r_body(IO& io, const cplx<typename C::T>* 
 // bytes of scratch per thread) the passes WITH an epilogue (LognormalRowIO, ScaleZRowIO: row_io_pre) gain -- the fused lognormal z pass
 // 4.00 -> 3.70 ms per 1024^3 float64 on MI355X, profiles/r05_ab/r05_b_ln_*.log -- while the plain pass, which already sits at the copy
 // ceiling, loses 4 % (3.18 -> 3.32 ms) and keeps its registers.  (Rows of 1024 complex128: 184 bytes of scratch at three waves; left alone.)
-#ifndef RF_ROW64_EPILOGUE_WAVES
-#define RF_ROW64_EPILOGUE_WAVES 3
-#endif
 template <class C, class IO>
 constexpr int row_min_waves() {
-  return (sizeof(typename C::T) == 8 && C::M == 512 && row_io_pre<IO, C::RL>::value) ? RF_ROW64_EPILOGUE_WAVES : 1;
+  return (sizeof(typename C::T) == 8 && C::M == 512 && row_io_pre<IO, C::RL>::value) ? 3 : 1;
 }
 template <class C, class IO>
 __global__ __launch_bounds__(C::NT, (row_min_waves<C, IO>())) void row_c2r_kernel(IO io, const cplx<typename C::T>* __restrict__ tw,
@@ -376,10 +311,7 @@ __global__ __launch_bounds__(C::NT, (row_min_waves<C, IO>())) void row_c2r_kerne
   extern __shared__ __attribute__((aligned(16))) char rf_smem[];
   // last rows first: the pass before this one wrote the array front to back, so its end is what the 256 MiB Infinity
   // Cache still holds (measured: DESIGN.md section 3.8)
-#ifndef RF_Z_REVERSE
-#define RF_Z_REVERSE 1
-#endif
-  const long long tile = RF_Z_REVERSE ? (long long)gridDim.x - 1 - blockIdx.x : (long long)blockIdx.x;
+  const long long tile = (long long)gridDim.x - 1 - blockIdx.x;
   row_c2r_body<C, IO>(io, tw, nrows, partials, tile, rf_smem);
 }
 

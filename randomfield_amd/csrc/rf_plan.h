@@ -106,12 +106,11 @@ struct rf_plan {
   // 0 = whole-grid passes, > 0 = this many x planes per slab (RF_FLAG_YZ_SLAB_PLANES)
   int yz_slab = -1;
   // rf_set_host_sink: the NEXT single-rank realisation delivers its field to host memory slab by slab, each slab's device -> host copy
-  // queued on dl_stream behind that slab's z pass (generate.py:184-189,230 returns a host array: the copy is 15 x the realisation)
+  // on dl_stream behind that slab's z pass while the GPU runs the next slab (generate.py:184-189,230 returns a host array: the copy is
+  // 15 x the realisation)
   void* sink_host = nullptr;              // armed destination (one shot), RF_LAYOUT_DENSE / RF_LAYOUT_PADDED rows
   int sink_layout = 0;
   bool sink_delivered = false;            // the last armed call has delivered
-  void* sink_registered = nullptr;        // host range currently pinned by hipHostRegister (kept across calls: the plan's own host buffer)
-  size_t sink_registered_bytes = 0;
   hipStream_t dl_stream = nullptr;
   std::vector<hipEvent_t> sink_ev;
   hipStream_t aux_stream = nullptr;       // rf_realise_batch_reference: the stream the MT19937 replays run on

@@ -2288,6 +2288,13 @@ def test_direct_standin_runs_the_direct_schedule_on_a_virtual_rank(hip, dpower):
         q.close()
 
 
+def _unaligned(shape, rt):
+    """a C-contiguous array of that shape that does NOT start on a page boundary"""
+    raw = np.empty(int(np.prod(shape)) + 1024 + 16, rt)
+    off = ((-raw.ctypes.data) % 4096) // raw.itemsize + 16
+    return raw[off:off + int(np.prod(shape))].reshape(shape)
+
+
 @pytest.mark.parametrize("shape,dtype", [((256, 1024, 1024), np.complex64), ((64, 64, 64), np.complex64), ((128, 512, 1024), np.complex128)])
 def test_host_sink_delivers_the_field_slab_by_slab(hip, dpower, shape, dtype):
     """rf_set_host_sink (generate.py:184-189,230: the reference's calls return host arrays): the realisation's own z pass hands every
@@ -2307,8 +2314,8 @@ def test_host_sink_delivers_the_field_slab_by_slab(hip, dpower, shape, dtype):
     host[:] = np.nan
     plan.realise(seed=6)                                     # one shot: nothing armed now
     assert not plan.host_sink_delivered() and np.isnan(host).all()
-    dense = np.empty(shape, rt)
-    assert plan.arm_host_sink(dense)                         # another buffer (re-registered), dense rows
+    dense = _unaligned(shape, rt)
+    assert plan.arm_host_sink(dense)                         # another buffer, dense rows, any alignment
     plan.realise_potential(seed=7)
     assert plan.host_sink_delivered() and np.array_equal(dense, plan.download_real())
     plan.realise_batch(np.array([8, 9], np.uint64), want_rms=False)        # graph batches are unaffected afterwards
