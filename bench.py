@@ -227,7 +227,7 @@ def other_configs(power, spacing, device, only=None):
         del gen
     out["1024^3 f32 Generator.generate_delta_field(seed) -> numpy array on the host (PCIe-inclusive; not the bench line)"] = host
     # the float64 configurations in a process of their own: where the allocator puts a 17 GB plan after the plans above have come
-    # and gone costs its strided passes 3 - 5 % (and after IT has been freed, later plans' store streams 20 %: tools/frag_probe.py)
+    # and gone costs its strided passes 3 - 5 % (and after IT has been freed, later plans' store streams 20 %: DESIGN_HISTORY.md)
     # -- a fresh process is what a user of that configuration has
     import subprocess
     try:
@@ -524,6 +524,128 @@ def main_multi(args, rank, world, local_rank, shape, power, spacing):
         print(json.dumps(out))
 
 
+def build_line(shape, steps, warmup, gpus, wall, gpu_ms, std, kern, merged_ms, merged_n, nslab, slab_planes, traffic_path=None):
+    """The N = 1 JSON line from the measured numbers -- no GPU call in here, so that tests/test_bench_contract.py can run it with stubbed
+    timings: wall = seconds of the `steps` timed realisations, gpu_ms = the same by HIP events, std = rms of the last field,
+    kern = [x main kernel, y, z, reduce, x launch over the kz = 0 tiles] in ms (eager realisations), merged_ms / merged_n = mean
+    duration and launches per realisation of the merged z + y launch (None / 0 where the shape has none), nslab / slab_planes = how
+    the y / z passes are launched."""
+    nx, ny, nz = shape
+    cells = float(nx) * ny * nz
+    sweep = 8.0 * nx * ny * (nz // 2 + 1)           # bytes of one sweep of the packed complex64 array
+    # kern = [x main kernel, y, z, reduce, x launch over the kz = 0 tiles]; the x pass writes one sweep, of which the
+    # main kernel writes all tiles but one per ky row
+    names = ["x pass (generation + FFT, write only; its three launches: the side buffer of repaired kz = 0 slots, the kz = 0 tiles, all others)",
+             "y pass (FFT in place)", "z pass (c2r + moments, in place)"]
+    # the x pass is three launches (side-buffer fill, the tiles that hold slot kz = 0, then all others): the PASS is what gets compared
+    pass_ms = np.array([kern[0] + kern[4], kern[1], kern[2]])
+    alg = [sweep, 2 * sweep, 2 * sweep]
+    dom = int(np.argmax(pass_ms))
+    achieved = alg[dom] / (pass_ms[dom] * 1e-3) / 1e9          # = bytes per launch / mean launch duration (both divided by the launches)
+    # HBM bytes per launch of that kernel from the committed rocprofv3 --pmc passes (profiles/), if they
+    # were taken on this grid; bench.py itself cannot run the profiler
+    # (per LAUNCH, like `achieved`: the y and z passes are nslab launches each when they run slab by slab; the x pass is its
+    # two launches together)
+    launches = [1, nslab, nslab]
+    traffic, traffic_source, pass_traffic = None, None, {}
+    keys = [["FastGenColIOT<0,", "FastGenColIOT<1,", "FastGenColIOT<3,", "fix_fill_kernel"], ["PlainColIO", "XposeColIO", "Pair2ColIO"], ["row_c2r_kernel"]]
+    try:
+        tj = json.load(open(traffic_path or os.path.join(ROOT, "profiles", "traffic_latest.json")))
+    except Exception as e:                               # no committed profile: say so instead of a silent null
+        tj, traffic_source = None, "profiles/traffic_latest.json not readable (%s)" % e
+    if tj is not None:
+        if (nx, ny, nz) == tuple(tj.get("grid", (1024, 1024, 1024))) and gpus == 1:
+            for i, k in enumerate(("x", "y", "z")):
+                tot = sum(v["total"] for name, v in tj["kernels"].items() if any(key in name for key in keys[i]))
+                pass_traffic[k] = tot if tot > 0 else None
+            traffic = pass_traffic[("x", "y", "z")[dom]]
+            src = tj.get("source") or tj.get("note") or "profiles/traffic_latest.json"
+            traffic_source = ("NOT measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes committed as %s" % src if traffic
+                              else "no kernel of %s matched %r" % (src, keys[dom]))
+            if traffic and tj.get("yz_slabs") not in (None, nslab):
+                traffic_source += " (taken with %s y / z launches per realisation, this run has %d)" % (tj.get("yz_slabs"), nslab)
+        else:
+            traffic_source = "the committed PMC passes are for a %s grid on one GPU, not this run's" % (tj.get("grid", [1024, 1024, 1024]),)
+    out = {
+        "metric": "Mcells/s for N^3 delta(x) realisation",
+        "value": round(cells * steps / wall / 1e6, 1),
+        "unit": "Mcells/s",
+        "n_gpus": gpus, "steps": steps, "warmup": warmup,
+        "ms_per_step": round(wall / steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%dx%dx%d float32 delta(x) realisations back to back (hipGraph replay), "
+                               "native Philox4x32-7 RNG, shipped 500-row P(k), spacing 2.5 Mpc/h" % (nx, ny, nz),
+                   "grid": [nx, ny, nz], "rms_last": round(std, 6)},
+        "gpu_ms_per_step_events": round(gpu_ms / steps, 4),
+        "pipeline": {"algorithmic_GBs": round(5 * sweep * steps / wall / 1e9, 1),
+                     "frac_of_hbm_peak": round(5 * sweep * steps / wall / 1e9 / HBM_PEAK_GBS, 4),
+                     "kernel_ms": {"x": round(float(kern[0]), 4), "y": round(float(kern[1]), 4),
+                                   "z": round(float(kern[2]), 4), "reduce": round(float(kern[3]), 4),
+                                   "x_kz0_tiles": round(float(kern[4]), 4)},
+                     "kernel_ms_note": "HIP-event intervals around each pass of EAGER realisations in this process (they include the "
+                                       "launch gaps, and y / z are the sums over their %d launches of %d x planes): their sum is "
+                                       "larger than ms_per_step, which is the graph replay" % (nslab, slab_planes),
+                     "yz_slabs": nslab,
+                     "launches_per_realisation": {"x": 3, "y": nslab, "z": nslab, "reduce": 1},
+                     "traffic_bytes_per_launch": pass_traffic,
+                     "pass_frac_of_hbm_peak": {k: round(alg[i] / (pass_ms[i] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                                               for i, k in enumerate(("x", "y", "z"))}},
+        "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "traffic_source": traffic_source,
+                     "algorithmic_bytes_per_launch": alg[dom] / launches[dom], "avg_ms": round(float(pass_ms[dom]) / launches[dom], 5),
+                     "launches_per_realisation": launches[dom],
+                     "whole_pipeline_frac": round(5 * sweep * steps / wall / 1e9 / HBM_PEAK_GBS, 4)},
+    }
+    # An estimate of the bytes that really cross the HBM pins (DESIGN.md section 4): `achieved` / `frac` price ALGORITHMIC bytes, but when
+    # the y and z passes run slab by slab the slab goes from the y pass to the z pass through the 256 MiB Infinity Cache and the z pass
+    # overwrites it in place, so per realisation only the x pass's write (S), the y pass's read (S) and the z pass's result (S) reach
+    # HBM: 3 of the 5 sweeps.  No counter on this chip separates Infinity-Cache hits from HBM accesses (FETCH_SIZE / WRITE_SIZE are L2-side
+    # and count the hits: MI355X_MICROARCH.md), hence an estimate: it assumes a perfect hand-off (every line the y pass writes is still
+    # in the cache when the z pass reads it and is overwritten before it is evicted).
+    handoff = nslab > 1
+    hbm_per_pass = [sweep, sweep if handoff else 2 * sweep, sweep if handoff else 2 * sweep]
+    out["roofline"]["hbm_bytes_est"] = hbm_per_pass[dom] / launches[dom]
+    out["roofline"]["frac_hbm_est"] = round(hbm_per_pass[dom] / (pass_ms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    out["pipeline"]["hbm_bytes_est_per_realisation"] = float(sum(hbm_per_pass))
+    out["pipeline"]["frac_hbm_est"] = round(sum(hbm_per_pass) * steps / wall / 1e9 / HBM_PEAK_GBS, 4)
+    hbm_note = ("ESTIMATE, not a counter: algorithmic bytes minus what the slab hand-off keeps in the 256 MiB Infinity Cache (the z pass reads "
+                "what the y pass has just written, and overwrites it before it is evicted): x writes S, y reads S, z's result S = 3 of "
+                "the 5 sweeps per realisation reach HBM" if handoff else
+                "no slab hand-off on this grid (whole-grid passes): the estimate equals the algorithmic bytes")
+    out["roofline"]["hbm_bytes_est_note"] = hbm_note
+    if merged_ms:
+        # the kernel the timed region spends most of its time in: (nslab - 1) merged launches per realisation, each the z pass of one
+        # slab (read + write) and the y pass of the next (read + write): 4 sweeps of a slab
+        alg_m = 4 * sweep / nslab
+        ach_m = alg_m / (merged_ms * 1e-3) / 1e9
+        tm = None
+        if tj is not None and (nx, ny, nz) == tuple(tj.get("grid", (1024, 1024, 1024))):
+            tot = sum(v["total"] for name, v in tj["kernels"].items() if "yz_merged_kernel" in name)
+            tm = tot if tot > 0 else None
+        out["roofline"] = {"bound": "hbm", "kernel": "yz_merged_kernel: z pass (c2r + moments) of slab s + y pass (FFT in place) of slab s + 1 in one launch",
+                           "achieved": round(ach_m, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach_m / HBM_PEAK_GBS, 4),
+                           "traffic": tm,
+                           "traffic_source": (traffic_source if tm else "no yz_merged_kernel entry in profiles/traffic_latest.json"),
+                           "algorithmic_bytes_per_launch": alg_m, "avg_ms": round(merged_ms, 5), "launches_per_realisation": merged_n,
+                           "note": "HIP events behind every launch of eager realisations (rf_set_merged_yz(2)); the same passes one launch "
+                                   "each: pipeline.kernel_ms / pass_frac_of_hbm_peak",
+                           "unmerged_dominant_pass": {"kernel": names[dom], "frac": round(achieved / HBM_PEAK_GBS, 4),
+                                                      "avg_ms": round(float(pass_ms[dom]) / launches[dom], 5)},
+                           "whole_pipeline_frac": round(5 * sweep * steps / wall / 1e9 / HBM_PEAK_GBS, 4),
+                           # of the launch's four slab sweeps the y half's read and the z half's result cross the HBM pins
+                           "hbm_bytes_est": 2 * sweep / nslab,
+                           "frac_hbm_est": round(2 * sweep / nslab / (merged_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                           "hbm_bytes_est_note": hbm_note}
+        out["pipeline"]["launches_per_realisation"] = {"x": 3, "y": 1, "z + y merged": merged_n, "z": 1, "reduce": 1}
+    out["config"]["parity"] = ("native stream = this repo's own definition (no reference counterpart): the kernel instantiations "
+                               "of this run are value-checked against the oracle's float64 restatement at 1e-5 * rms in "
+                               "tests/test_gpu_parity.py::test_native_generation_bench_instantiations_against_oracle; the "
+                               "same-seed path (rng='reference') is in other_configs")
+    return out
+
+
 def launch_ranks(n):
     """`python bench.py --gpus N` outside any launcher: start N fresh ranks of this script (one per GPU, RANK = LOCAL_RANK = r)
     with the environment `torch.distributed.run` would give them, relay rank 0's standard output (the ONE JSON line) and
@@ -660,119 +782,8 @@ def main():
     gpu_ms = plan.elapsed_ms()
     mean, std = plan.moments()
 
-    cells = float(nx) * ny * nz
-    sweep = 8.0 * nx * ny * (nz // 2 + 1)           # bytes of one sweep of the packed complex64 array
-    # kern = [x main kernel, y, z, reduce, x launch over the kz = 0 tiles]; the x pass writes one sweep, of which the
-    # main kernel writes all tiles but one per ky row
-    names = ["x pass (generation + FFT, write only; its three launches: the side buffer of repaired kz = 0 slots, the kz = 0 tiles, all others)",
-             "y pass (FFT in place)", "z pass (c2r + moments, in place)"]
-    # the x pass is three launches (side-buffer fill, the tiles that hold slot kz = 0, then all others): the PASS is what gets compared
-    pass_ms = np.array([kern[0] + kern[4], kern[1], kern[2]])
-    alg = [sweep, 2 * sweep, 2 * sweep]
-    dom = int(np.argmax(pass_ms))
-    achieved = alg[dom] / (pass_ms[dom] * 1e-3) / 1e9          # = bytes per launch / mean launch duration (both divided by the launches)
-    # HBM bytes per launch of that kernel from the committed rocprofv3 --pmc passes (profiles/), if they
-    # were taken on this grid; bench.py itself cannot run the profiler
-    # (per LAUNCH, like `achieved`: the y and z passes are nslab launches each when they run slab by slab; the x pass is its
-    # two launches together)
     nslab, slab_planes = plan.yz_slabs()
-    launches = [1, nslab, nslab]
-    traffic, traffic_source, pass_traffic = None, None, {}
-    keys = [["FastGenColIOT<0,", "FastGenColIOT<1,", "FastGenColIOT<3,", "fix_fill_kernel"], ["PlainColIO", "XposeColIO", "Pair2ColIO"], ["row_c2r_kernel"]]
-    try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
-    except Exception as e:                               # no committed profile: say so instead of a silent null
-        tj, traffic_source = None, "profiles/traffic_latest.json not readable (%s)" % e
-    if tj is not None:
-        if (nx, ny, nz) == tuple(tj.get("grid", (1024, 1024, 1024))) and args.gpus == 1:
-            for i, k in enumerate(("x", "y", "z")):
-                tot = sum(v["total"] for name, v in tj["kernels"].items() if any(key in name for key in keys[i]))
-                pass_traffic[k] = tot if tot > 0 else None
-            traffic = pass_traffic[("x", "y", "z")[dom]]
-            src = tj.get("source") or tj.get("note") or "profiles/traffic_latest.json"
-            traffic_source = ("NOT measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes committed as %s" % src if traffic
-                              else "no kernel of %s matched %r" % (src, keys[dom]))
-            if traffic and tj.get("yz_slabs") not in (None, nslab):
-                traffic_source += " (taken with %s y / z launches per realisation, this run has %d)" % (tj.get("yz_slabs"), nslab)
-        else:
-            traffic_source = "the committed PMC passes are for a %s grid on one GPU, not this run's" % (tj.get("grid", [1024, 1024, 1024]),)
-    out = {
-        "metric": "Mcells/s for N^3 delta(x) realisation",
-        "value": round(cells * args.steps / wall / 1e6, 1),
-        "unit": "Mcells/s",
-        "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(wall / args.steps * 1e3, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%dx%dx%d float32 delta(x) realisations back to back (hipGraph replay), "
-                               "native Philox4x32-7 RNG, shipped 500-row P(k), spacing 2.5 Mpc/h" % (nx, ny, nz),
-                   "grid": [nx, ny, nz], "rms_last": round(std, 6)},
-        "gpu_ms_per_step_events": round(gpu_ms / args.steps, 4),
-        "pipeline": {"algorithmic_GBs": round(5 * sweep * args.steps / wall / 1e9, 1),
-                     "frac_of_hbm_peak": round(5 * sweep * args.steps / wall / 1e9 / HBM_PEAK_GBS, 4),
-                     "kernel_ms": {"x": round(float(kern[0]), 4), "y": round(float(kern[1]), 4),
-                                   "z": round(float(kern[2]), 4), "reduce": round(float(kern[3]), 4),
-                                   "x_kz0_tiles": round(float(kern[4]), 4)},
-                     "kernel_ms_note": "HIP-event intervals around each pass of EAGER realisations in this process (they include the "
-                                       "launch gaps, and y / z are the sums over their %d launches of %d x planes): their sum is "
-                                       "larger than ms_per_step, which is the graph replay" % (nslab, slab_planes),
-                     "yz_slabs": nslab,
-                     "launches_per_realisation": {"x": 3, "y": nslab, "z": nslab, "reduce": 1},
-                     "traffic_bytes_per_launch": pass_traffic,
-                     "pass_frac_of_hbm_peak": {k: round(alg[i] / (pass_ms[i] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-                                               for i, k in enumerate(("x", "y", "z"))}},
-        "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                     "traffic_source": traffic_source,
-                     "algorithmic_bytes_per_launch": alg[dom] / launches[dom], "avg_ms": round(float(pass_ms[dom]) / launches[dom], 5),
-                     "launches_per_realisation": launches[dom],
-                     "whole_pipeline_frac": round(5 * sweep * args.steps / wall / 1e9 / HBM_PEAK_GBS, 4)},
-    }
-    # An estimate of the bytes that really cross the HBM pins: `achieved` / `frac` price ALGORITHMIC bytes, but when
-    # the y and z passes run slab by slab the slab goes from the y pass to the z pass through the 256 MiB Infinity Cache and the z pass
-    # overwrites it in place, so per realisation only the x pass's write (S), the y pass's read (S) and the z pass's result (S) reach
-    # HBM: 3 of the 5 sweeps.  No counter on this chip separates Infinity-Cache hits from HBM accesses (FETCH_SIZE / WRITE_SIZE are L2-side
-    # and count the hits: MI355X_MICROARCH.md), hence an estimate: it assumes a perfect hand-off (every line the y pass writes is still
-    # in the cache when the z pass reads it and is overwritten before it is evicted).
-    handoff = nslab > 1
-    hbm_per_pass = [sweep, sweep if handoff else 2 * sweep, sweep if handoff else 2 * sweep]
-    out["roofline"]["hbm_bytes_est"] = hbm_per_pass[dom] / launches[dom]
-    out["roofline"]["frac_hbm_est"] = round(hbm_per_pass[dom] / (pass_ms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-    out["pipeline"]["hbm_bytes_est_per_realisation"] = float(sum(hbm_per_pass))
-    out["pipeline"]["frac_hbm_est"] = round(sum(hbm_per_pass) * args.steps / wall / 1e9 / HBM_PEAK_GBS, 4)
-    hbm_note = ("ESTIMATE, not a counter: algorithmic bytes minus what the slab hand-off keeps in the 256 MiB Infinity Cache (the z pass reads "
-                "what the y pass has just written, and overwrites it before it is evicted): x writes S, y reads S, z's result S = 3 of "
-                "the 5 sweeps per realisation reach HBM" if handoff else
-                "no slab hand-off on this grid (whole-grid passes): the estimate equals the algorithmic bytes")
-    out["roofline"]["hbm_bytes_est_note"] = hbm_note
-    if merged_ms:
-        # the kernel the timed region spends most of its time in: (nslab - 1) merged launches per realisation, each the z pass of one
-        # slab (read + write) and the y pass of the next (read + write): 4 sweeps of a slab
-        alg_m = 4 * sweep / nslab
-        ach_m = alg_m / (merged_ms * 1e-3) / 1e9
-        tm = None
-        if tj is not None and (nx, ny, nz) == tuple(tj.get("grid", (1024, 1024, 1024))):
-            tot = sum(v["total"] for name, v in tj["kernels"].items() if "yz_merged_kernel" in name)
-            tm = tot if tot > 0 else None
-        out["roofline"] = {"bound": "hbm", "kernel": "yz_merged_kernel: z pass (c2r + moments) of slab s + y pass (FFT in place) of slab s + 1 in one launch",
-                           "achieved": round(ach_m, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach_m / HBM_PEAK_GBS, 4),
-                           "traffic": tm,
-                           "traffic_source": (traffic_source if tm else "no yz_merged_kernel entry in profiles/traffic_latest.json"),
-                           "algorithmic_bytes_per_launch": alg_m, "avg_ms": round(merged_ms, 5), "launches_per_realisation": merged_n,
-                           "note": "HIP events behind every launch of eager realisations (rf_set_merged_yz(2)); the same passes one launch "
-                                   "each: pipeline.kernel_ms / pass_frac_of_hbm_peak",
-                           "unmerged_dominant_pass": {"kernel": names[dom], "frac": round(achieved / HBM_PEAK_GBS, 4),
-                                                      "avg_ms": round(float(pass_ms[dom]) / launches[dom], 5)},
-                           "whole_pipeline_frac": round(5 * sweep * args.steps / wall / 1e9 / HBM_PEAK_GBS, 4),
-                           # of the launch's four slab sweeps the y half's read and the z half's result cross the HBM pins
-                           "hbm_bytes_est": 2 * sweep / nslab,
-                           "frac_hbm_est": round(2 * sweep / nslab / (merged_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                           "hbm_bytes_est_note": hbm_note}
-        out["pipeline"]["launches_per_realisation"] = {"x": 3, "y": 1, "z + y merged": merged_n, "z": 1, "reduce": 1}
-    out["config"]["parity"] = ("native stream = this repo's own definition (no reference counterpart): the kernel instantiations "
-                               "of this run are value-checked against the oracle's float64 restatement at 1e-5 * rms in "
-                               "tests/test_gpu_parity.py::test_native_generation_bench_instantiations_against_oracle; the "
-                               "same-seed path (rng='reference') is in other_configs")
+    out = build_line((nx, ny, nz), args.steps, args.warmup, args.gpus, wall, gpu_ms, std, kern, merged_ms, merged_n, nslab, slab_planes)
     plan.close()
     if rank == 0 and args.gpus == 1 and not args.no_other_configs:
         out["other_configs"] = other_configs(power, spacing, local_rank)

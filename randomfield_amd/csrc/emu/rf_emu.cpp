@@ -75,6 +75,44 @@ void run_col2_pass(const IO& io_in, long long ncols, const cplx<typename C1::T>*
     }
   }
 }
+// tile pairs with whole-line stores (rf_kernels.h colpair_body, rf_fft_col.h ColPair): phase 0 transforms tile 2p and PARKS the last
+// pass's outputs, phase 1 transforms tile 2p + 1 (built without the kz = 0 repair: FIXOK = false) and stores both tiles row by row
+template <class C, int DIR, class IO>
+void run_colpair_pass(const IO& io_in, long long ncols, const cplx<typename C::T>* tw) {
+  using X = ColPair<C, DIR, IO>;
+  using F = typename X::F;
+  using cx = cplx<typename C::T>;
+  std::vector<cx> lds((size_t)(C::LDS_BYTES + IO::LDS_EXTRA) / sizeof(cx));
+  std::vector<typename F::Regs> regs(C::NT);
+  std::vector<typename F::TwRegs> twr(C::NT);
+  std::vector<typename F::PreRegs> pre(C::NT);
+  std::vector<typename X::Park> pk(C::NT);
+  std::vector<IO> ios(C::NT, io_in);
+  for (auto& io : ios) io.bind_seed();
+  const long long npairs = ncols / (2 * C::TC);
+  for (long long pair = 0; pair < npairs; ++pair) {
+    if (IO::LDS_EXTRA > 0) for (int t = 0; t < C::NT; ++t) ios[t].prologue(t, C::NT, F::lds_io(lds.data()));
+    for (int t = 0; t < C::NT; ++t) F::tw_fetch(t, tw, twr[t]);
+    const cx* ltw = F::lds_tw(lds.data());
+    for (int phase = 0; phase < 2; ++phase) {
+      const long long tile = 2 * pair + phase;
+      if (F::PRELOAD) for (int t = 0; t < C::NT; ++t) F::preload(t, tile, ios[t], pre[t]);
+      for (int t = 0; t < C::NT; ++t) {
+        if (phase == 0) F::template pass_first<true>(t, tile, ios[t], lds.data(), pre[t], F::PRELOAD);
+        else F::template pass_first<false>(t, tile, ios[t], lds.data(), pre[t], F::PRELOAD);
+      }
+      if (phase == 0) for (int t = 0; t < C::NT; ++t) F::tw_stage(t, lds.data(), twr[t]);
+      if (C::NPASS == 3) {
+        for (int t = 0; t < C::NT; ++t) F::pass_mid_read(t, ltw, lds.data(), regs[t]);
+        for (int t = 0; t < C::NT; ++t) F::pass_mid_write(t, lds.data(), regs[t]);
+      }
+      if (phase == 0) for (int t = 0; t < C::NT; ++t) X::last_park(t, ltw, lds.data(), pk[t]);
+      else for (int t = 0; t < C::NT; ++t) X::last_store(t, 2 * pair, ios[t], ltw, lds.data(), pk[t]);
+    }
+  }
+}
+int g_pairs = 1;           // (the product's rule: the float32 generation pass of length 1024 runs on tile pairs)
+
 // the product's rule (rf_k_col_plain.hip / rf_k_col_gen.hip): float32 in-place passes of length 2048 -- and, since round 4, of length
 // 1024 -- run through Col2 (two half-length transforms per tile)
 template <typename T, int DIR>
@@ -414,6 +452,21 @@ int realise_fast_impl(int nx, int ny, int nz, const GenHost& h, uint64_t seed, d
       x_done = true;
     }
   }
+  if constexpr (sizeof(T) == 4) {
+    using C = GenSel<float, 1024>::type;
+    if (!x_done && g_pairs && nx == 1024 && nzc > C::TC && nzc % (2 * C::TC) == 0) {      // float32, length 1024: tile pairs (ColPair), repair from the side buffer
+      using IOC = typename IO::template with_fix<3>;
+      IOC ioc;
+      ioc.base = W; ioc.g = io.g; ioc.kz0 = 0; ioc.nzl = (int)nzc; ioc.rec = nullptr; ioc.gp = io.gp; ioc.pot = nullptr;
+      typename IOC::fill_io iof;
+      iof.base = W; iof.g = io.g; iof.kz0 = 0; iof.nzl = (int)nzc; iof.rec = nullptr; iof.gp = io.gp; iof.pot = nullptr;
+      fill_fix_buffer(iof, fixbuf);
+      ioc.fixbuf = fixbuf.data();
+      auto tw = make_twiddles<float>(1024);
+      run_colpair_pass<C, +1, IOC>(ioc, (long long)ny * nzc, tw.data());
+      x_done = true;
+    }
+  }
   if (!x_done && (nx == 512 || nx == 1024)) {               // the long whole-column passes: FIX = 3 where the library splits
     using IOC = typename IO::template with_fix<3>;
     const int tc = tile_cols<T>(nx, true);
@@ -681,6 +734,17 @@ int emu_row_c2r_xgather(int f64, int M, int nx, int ny, int tc, int rb, const vo
 // 1 (default): c2r transforms hand x -> y through the transposed intermediate where the product would; 0: in place
 int emu_set_xposed(int on) { const int old = g_xposed; g_xposed = on; return old; }
 int emu_set_rowblock(int rb) { const int old = g_rowblock; g_rowblock = rb; return old; }
+// 1 (default): the float32 generation pass of length 1024 on tile pairs (ColPair), as the product; 0: one tile per workgroup (ColFFT)
+int emu_set_pairs(int on) { const int old = g_pairs; g_pairs = on; return old; }
+// FastGenColIOT::share_row (rf_fft_gen.h): the butterfly row of slot jl when L butterflies are dealt to slots of S per wave so that
+// the rows +-ix sit 32 lanes apart (the sigma exchange of the x pass); a host-side table for the bijection test
+// (xs2_phase < 0: the whole-column form XS = 1; 0 / 1: the even / odd phase of the two-half-transform form XS = 2)
+int emu_share_row(int jl, int L, int S, int xs2_phase) {
+  if (xs2_phase < 0) { FastGenColIOT<0> io; return io.share_row(jl, L, S); }
+  FastGenColIOT<0, 0, 0, 0, 2> io;
+  io.set_phase(xs2_phase);
+  return io.share_row(jl, L, S);
+}
 int emu_xpose_applies(int f64, int nx, int ny, int nz) { return f64 ? xpose_ok<double>(nx, ny, nz / 2) : xpose_ok<float>(nx, ny, nz / 2); }
 
 // full fused realisation: generation + x, y, z passes -> W (real [nx][ny][nz]) and (sum, sumsq)

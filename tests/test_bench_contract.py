@@ -1,18 +1,57 @@
-"""The bench line's contract, checked on the CPU against the line committed with the round's profiles (profiles/r05_c_bench.json =
-`python bench.py --steps 20 --warmup 5` at HEAD on an MI355X): the keys the driver and the review read, their units and their internal
-consistency.  (bench.py itself needs a GPU; this keeps a refactor from silently dropping or renaming a key.)"""
+"""The bench line's contract, checked on the CPU twice: (a) against what bench.py's own build_line() assembles from STUBBED timings --
+a change to bench.py that drops or renames a key, or breaks the arithmetic between the fields, fails here --, and (b) against the line
+committed with the round's profiles (`python bench.py` on an MI355X), which also carries cpu_baseline and other_configs (they need
+the GPU and the oracle).  The keys the driver and the review read, their units and their internal consistency."""
+import importlib.util
 import json
 import os
 
+import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LINE = os.path.join(ROOT, "profiles", "r05_c_bench.json")
+LINE = os.path.join(ROOT, "profiles", "r06_a_bench.json")
 
 
-@pytest.fixture(scope="module")
-def line():
-    return json.load(open(LINE))
+def _bench_module():
+    spec = importlib.util.spec_from_file_location("rf_bench_under_test", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _stub_line():
+    """build_line() on the numbers of a typical 1024^3 run: 20 steps in 77.2 ms, the merged launch at 0.170 ms"""
+    b = _bench_module()
+    return b.build_line((1024, 1024, 1024), 20, 5, 1, 0.0772, 77.0, 2.3137, np.array([1.05, 1.65, 1.33, 0.0186, 0.066]), 0.170, 15, 16, 64)
+
+
+@pytest.fixture(scope="module", params=["built from stubbed timings", "committed"])
+def line(request):
+    if request.param == "committed":
+        return json.load(open(LINE))
+    out = _stub_line()
+    # what main() adds after build_line(): stand-ins with the right shape (the real ones need a GPU and the oracle)
+    out["cpu_baseline"] = {"value": 32.5, "unit": "Mcells/s", "cores": 1, "kind": "port", "sample": "stub", "rms": 2.3137536}
+    out["speedup_vs_cpu_baseline"] = round(out["value"] / 32.5, 1)
+    return out
+
+
+def test_build_line_follows_its_inputs():
+    """the arithmetic of the line: value and ms_per_step from the wall clock, the roofline object from the merged launch's duration,
+    and -- for a shape without merged launches -- from the slowest pass"""
+    b = _bench_module()
+    out = _stub_line()
+    assert out["ms_per_step"] == pytest.approx(3.86, rel=1e-6) and out["value"] == pytest.approx(1024 ** 3 / 3.86e-3 / 1e6, rel=1e-4)
+    sweep = 8.0 * 1024 * 1024 * 513
+    r = out["roofline"]
+    assert "yz_merged_kernel" in r["kernel"] and r["launches_per_realisation"] == 15 and r["algorithmic_bytes_per_launch"] == 4 * sweep / 16
+    assert r["achieved"] == pytest.approx(4 * sweep / 16 / 0.170e-3 / 1e9, rel=1e-3)
+    assert r["unmerged_dominant_pass"]["kernel"].startswith("y pass") and out["pipeline"]["yz_slabs"] == 16
+    plain = b.build_line((512, 512, 512), 10, 2, 1, 0.0054, 5.3, 2.2, np.array([0.14, 0.17, 0.19, 0.01, 0.02]), None, 0, 2, 256)
+    assert plain["roofline"]["kernel"].startswith("z pass") and plain["roofline"]["launches_per_realisation"] == 2
+    assert plain["roofline"]["achieved"] == pytest.approx(2 * 8.0 * 512 * 512 * 257 / 0.19e-3 / 1e9, rel=1e-3)
+    assert plain["roofline"]["traffic"] is None and "1024" in plain["roofline"]["traffic_source"]      # (the committed PMC passes are 1024^3)
 
 
 def test_top_level_contract(line):
@@ -56,10 +95,11 @@ def test_cpu_baseline_object(line):
     assert abs(c["rms"] - 2.3137536) < 1e-6            # the reference's own rms for this workload
 
 
-def test_other_configs_carry_every_baseline_configuration(line):
+def test_other_configs_carry_every_baseline_configuration():
+    line = json.load(open(LINE))
     o = line["other_configs"]
     for needle in ("512^3 f32 single realisation", "rng='reference'", "1024^3 f64", "1024^3 f64 + lognormal", "2048^3 f32 on one GPU",
-                   "per-rank compute", "exchange stand-in"):
+                   "per-rank compute", "exchange stand-in", "numpy array on the host"):
         assert any(needle in k for k in o), needle
     for k, v in o.items():
         if isinstance(v, dict) and "ms" in v and "kernel_ms" in v:
@@ -71,3 +111,6 @@ def test_other_configs_carry_every_baseline_configuration(line):
         for w in ("16 workgroups", "32 workgroups"):
             assert e[w]["pipelined_ms_per_realisation"] > e["forward_plus_backward_ms"] > 0
             assert e[w]["slowdown_vs_forward_plus_backward"] == pytest.approx(e[w]["pipelined_ms_per_realisation"] / e["forward_plus_backward_ms"], rel=2e-3)
+        # the direct exchange's stand-in (no copy kernel at all): far below the copy stand-in's
+        for k in ("direct exchange stand-in, one stream", "direct exchange stand-in, storing y pass on the exchange stream"):
+            assert 0 < e[k]["pipelined_ms_per_realisation"] < e["128 workgroups"]["pipelined_ms_per_realisation"]

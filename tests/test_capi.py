@@ -55,6 +55,9 @@ def test_exports_every_declared_symbol():
     nm = subprocess.run(["nm", "-D", "--defined-only", _hip.LIB_PATH], stdout=subprocess.PIPE, check=True).stdout.decode()
     exported = sorted(set(re.findall(r"\sT\s+(rf_[a-z0-9_]+)$", nm, flags=re.M)))
     assert exported == sorted(declared + diag), set(exported) ^ set(declared + diag)
+    # ... and nothing else at all: the C++ helpers the translation units share (namespace rfc) are not an interface (rf_exports.map)
+    every = [line.split()[-1] for line in nm.splitlines() if line.strip()]
+    assert sorted(every) == exported, [n for n in every if n not in exported][:5]
     # the knobs and virtual-rank steps a consumer should not bind live in the diagnostics header only
     for name in ("rf_kernel_ms", "rf_set_merged_yz", "rf_merged_yz_ms", "rf_slab_exchange_local", "rf_slab_exchange_local_reverse",
                  "rf_mt_share_exchange_local", "rf_slab_forward", "rf_slab_backward", "rf_slab_set_exchange_standin"):

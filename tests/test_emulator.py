@@ -423,3 +423,45 @@ def test_fused_lognormal_pipeline(shape, dtype):
     want = cpu_ref.scale_z(cpu_ref.lognormal(delta.copy(), growth, sigma=rt(sig.value)), dens)
     assert np.all(out > 0) and np.max(np.abs(out - want) / want) <= (3e-6 if rt == np.float32 else 1e-12)
     assert abs(s1.value - out.astype(np.float64).sum()) <= 1e-6 * out.size * np.abs(out).max()
+
+
+def test_tile_pairs_give_the_single_tile_field(default_power):
+    """ColPair (rf_fft_col.h; the product's float32 generation pass of length 1024): two adjacent tiles per workgroup, the first tile's
+    last-pass outputs parked in registers, both tiles stored row by row from the same lane -- and the second tile's first pass built
+    without the kz = 0 repair.  Same arithmetic per tile as ColFFT: the emulated field through pairs is bit for bit the field through
+    single tiles (this file also runs under ASan / UBSan: the parked store's indexing is checked there)."""
+    nx, ny, nz = 1024, 8, 64
+    k, Pk = default_power["k"], default_power["Pk"]
+    xt, st = cpu_ref.sigma_table(k, Pk, nx, ny, nz, 2.5)
+    old = emu_util.lib().emu_set_pairs(1)
+    try:
+        pairs, s1, s2 = emu_util.realise_fast(nx, ny, nz, 2.5, xt, st, seed=23)
+        emu_util.lib().emu_set_pairs(0)
+        single, t1, t2 = emu_util.realise_fast(nx, ny, nz, 2.5, xt, st, seed=23)
+    finally:
+        emu_util.lib().emu_set_pairs(old)
+    assert np.array_equal(pairs, single) and (s1, s2) == (t1, t2) and pairs.std() > 0
+    noise = cpu_ref.native_noise(23, nx, ny, nz, np.complex64)
+    ref, rms = cpu_ref.generate_delta_field(nx, ny, nz, 2.5, k, Pk, noise=noise, double_fft=True)
+    assert np.max(np.abs(pairs - ref)) <= 3e-5 * rms
+
+
+@pytest.mark.parametrize("L,S", [(128, 16), (128, 32), (64, 16), (256, 16), (16, 16)])
+def test_sigma_share_row_mapping_is_a_bijection(L, S):
+    """FastGenColIOT::share_row: the L butterflies of the generation pass are dealt to the lanes so that butterfly q and its mirror
+    L - q (the rows -ix; butterfly 0 pairs with L/2, both their own mirrors) sit half a wave apart and can trade sigma values through
+    ds_bpermute.  Every butterfly must be taken exactly once, partners must be S/2 slots apart in the same wave -- for the
+    whole-column form (XS = 1) and for both phases of the two-half-transform form (odd phase: mirror L - 1 - q, nobody its own)."""
+    f = emu_util.lib().emu_share_row
+    h = S // 2
+    for phase in (-1, 0, 1):
+        rows = [f(jl, L, S, phase) for jl in range(L)]
+        assert sorted(rows) == list(range(L)), (phase, rows[:8])
+        for jl in range(L):
+            sl = jl % S
+            if sl < h:
+                q, partner = rows[jl], rows[jl + h]
+                if phase == 1:
+                    assert partner == L - 1 - q
+                else:
+                    assert partner == (L // 2 if q == 0 else L - q)

@@ -41,6 +41,11 @@ for shape in ((8, 8, 16), (16, 32, 64), (64, 16, 32)):
         emu_util.realise(nx, ny, nz, 2.5, xt, st, noise=noise, dtype=dt)
         emu_util.realise(nx, ny, nz, 2.5, xt, st, seed=3, dtype=dt)
     emu_util.realise_fast(nx, ny, nz, 2.5, xt, st, seed=3)
+# the float32 generation pass of length 1024 on tile pairs (ColPair: parked registers, paired stores) and as two half transforms at 2048
+for shape in ((1024, 8, 32), (2048, 8, 16)):
+    nx, ny, nz = shape
+    xt, st = cpu_ref.sigma_table(pw["k"], pw["Pk"], nx, ny, nz, 2.5)
+    emu_util.realise_fast(nx, ny, nz, 2.5, xt, st, seed=5)
 for shape in ((4, 6, 8), (40, 60, 80), (10, 14, 22), (2, 2, 2), (26, 34, 46)):        # the generic mixed-radix blocks
     for ct, rt in ((np.complex64, np.float32), (np.complex128, np.float64)):
         nx, ny, nz = shape
