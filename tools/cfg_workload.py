@@ -5,7 +5,8 @@
 
 cases: 512 | 1024 | ref (1024^3, rng='reference': MT19937 replay + generation pass reading the deviates) | refone | refbatch |
        f64 (1024^3 float64) | f64ln (config 5: float64 + lognormal, fused) | 2048 (2048^3 float32 on one GPU) |
-       rank0 / rank3 (per-rank compute of the 2048^3 / 8 job, virtual ranks: forward + backward halves)
+       rank0 / rank3 (per-rank compute of the 2048^3 / 8 job, virtual ranks: forward + backward halves) |
+       rank0direct / rank3direct (the same rank through the pipelined batch of the direct exchange, its stores into its own buffers)
 Prints one JSON line: wall ms per call (median) and the plan's per-pass event times where the call records them."""
 import json
 import os
@@ -98,6 +99,16 @@ elif case in ("rank0", "rank3"):
         fw.append(t1 - t0)
         bw.append(t2 - t1)
     res = {"case": case, "forward_ms": round(float(np.median(fw)) * 1e3, 3), "backward_ms": round(float(np.median(bw)) * 1e3, 3)}
+elif case in ("rank0direct", "rank3direct"):      # the same rank through the DIRECT exchange's schedule (rf_slab_set_direct_standin, one stream)
+    plan = make(2048, np.complex64, nranks=8, rank=int(case[4]))
+    plan.set_direct_standin(True, overlap=False)
+    plan.realise_batch(np.arange(2, dtype=np.uint64), want_rms=False)
+    plan.sync()
+    n = max(reps, 2) * 2
+    t0 = time.perf_counter()
+    plan.realise_batch(np.arange(10, 10 + n, dtype=np.uint64), want_rms=False)
+    plan.sync()
+    res = {"case": case, "ms": round((time.perf_counter() - t0) / n * 1e3, 3), "note": "per realisation of a pipelined batch; storing y pass = col2_direct_kernel"}
 else:
     sys.exit("unknown case %r" % case)
 print(json.dumps(res), flush=True)

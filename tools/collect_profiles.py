@@ -23,7 +23,8 @@ workloads = {"ref": "1024^3 float32, rng='reference' (MT19937 replay + deviate-r
              "refone": "1024^3 float32, rng='reference' as ONE device call (rf_realise_batch_reference with one seed: what Generator runs)",
              "512": "512^3 float32, one realisation (config 2)", "2048": "2048^3 float32 on one GPU (config 4's kernels at full length)",
              "f64": "1024^3 float64", "f64ln": "1024^3 float64 + lognormal, fused (config 5)",
-             "rank0": "rank 0 of 2048^3 / 8 (virtual ranks): forward + backward halves", "rank3": "rank 3 of 2048^3 / 8 (virtual ranks)"}
+             "rank0": "rank 0 of 2048^3 / 8 (virtual ranks): forward + backward halves", "rank3": "rank 3 of 2048^3 / 8 (virtual ranks)",
+             "rank3direct": "rank 3 of 2048^3 / 8 through the pipelined batch of the DIRECT exchange (its y pass stores into its own receive buffers)"}
 commit = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], text=True, cwd=root).strip()
 t = json.load(open(os.path.join(src, "traffic.json")))
 t["source"] = "profiles/traffic_latest.json (%s: profiles/%s_* and profiles/%s_cfg/) @ commit %s" % (tag, tag, tag, commit)
@@ -35,7 +36,7 @@ for name, what in workloads.items():
     tj = os.path.join(src, name + "_traffic.json")
     if os.path.exists(tj):
         c = json.load(open(tj))
-        t["configs"][name] = {"workload": what, "grid": [2048] * 3 if name in ("2048", "rank0", "rank3") else ([512] * 3 if name == "512" else [1024] * 3),
+        t["configs"][name] = {"workload": what, "grid": [2048] * 3 if name in ("2048", "rank0", "rank3", "rank3direct") else ([512] * 3 if name == "512" else [1024] * 3),
                               "run": json.load(open(os.path.join(src, name + "_run.json"))), "kernels": c["kernels"]}
 json.dump(t, open(os.path.join(dst, "traffic_latest.json"), "w"), indent=1)
 print("profiles/%s_*, profiles/%s_cfg/ (%d files), traffic_latest.json: %d kernels + %d configurations"

@@ -26,7 +26,7 @@ rm -rf $out/fetch $out/write $out/sqa $out/sqb $out/stats
 fi
 if [ "$part" = "main" ]; then ls $out; exit 0; fi
 # every other BASELINE configuration / path: kernel stats, FETCH_SIZE / WRITE_SIZE and the SQ sets per configuration (tools/profile_cfg.sh)
-for c in ref refone 512 2048 f64 f64ln rank0 rank3; do
+for c in ref refone 512 2048 f64 f64ln rank0 rank3 rank3direct; do
   bash tools/profile_cfg.sh $out $c $c 3
 done
 ls $out
