@@ -60,7 +60,7 @@ enum {
                                               random.py:24-28 replayed on the device */
   RF_FEATURE_MT19937_SHARED = 1 << 7,      /* rf_mt_share_*: that stream shared between kz-slab ranks */
   RF_FEATURE_MULTI_RANK = 1 << 8,          /* nranks > 1 plans, rf_comm_*: kz slabs + one RCCL all-to-all (librccl is dlopen'ed by rf_comm_*) */
-  RF_FEATURE_GENERIC_SHAPES = 1 << 9,      /* every even shape up to 8192 (complex64) / 4096 (complex128) per axis: rf_shape_supported(_dtype) == 2 */
+  RF_FEATURE_GENERIC_SHAPES = 1 << 9,      /* every even shape (axes of up to 8192 complex64 / 4096 complex128 points, or two factors that fit): rf_shape_supported(_dtype) == 2 */
   RF_FEATURE_EXCHANGE_CHUNKS = 1 << 10,    /* RF_FLAG_EXCHANGE_CHUNKS */
   RF_FEATURE_DIRECT_EXCHANGE = 1 << 12,    /* rf_comm_enable_direct: the y pass stores into the peers' receive buffers (IPC-mapped), no all-to-all kernels */
   RF_FEATURE_DIAGNOSTICS = 1 << 11         /* the entry points of randomfield_hip_diag.h (timing per kernel, launch structure, virtual ranks) */
@@ -69,11 +69,12 @@ unsigned rf_abi_features(void);
 const char* rf_last_error(void);
 int rf_device_count(int* count);
 /* is this grid shape supported by the HIP kernels?  1: tiled power-of-two kernels (nx, ny in 8..2048, nz in 16..2048);
- * 2: generic mixed-radix kernels (any other even nx, ny, nz up to 8192, or 4096 on RF_F64 plans -- the reference's own test shapes (4,6,8) and
- * (40,60,80), transform.py:172-177; single GPU, k space materialised); 0: unsupported */
+ * 2: generic mixed-radix kernels (any other even nx, ny, nz -- the reference's own test shapes (4,6,8) and (40,60,80), transform.py:172-177;
+ * single GPU, k space materialised.  An axis of up to 8192 points -- 4096 on RF_F64 plans -- is one pass; a longer one must split into two
+ * factors within that cap and takes two); 0: unsupported */
 int rf_shape_supported(int nx, int ny, int nz);
 /* the same for ONE dtype (RF_F32 / RF_F64): what rf_plan_create(nx, ny, nz, dtype, ...) on one rank will accept -- rf_shape_supported answers
- * for complex64 plans on the generic path (axes up to 8192), complex128 plans stop at 4096 */
+ * for complex64 plans on the generic path (one-pass axes up to 8192 points), complex128 lines hold 4096 */
 int rf_shape_supported_dtype(int nx, int ny, int nz, int dtype);
 
 /* ---- plan: replaces transform.Plan.__init__ / allocate (transform.py:10-43,170-276)
@@ -188,7 +189,7 @@ int rf_execute_r2c(rf_plan* plan);               /* real field -> k buffer, unno
 
 /* ---- unpacked complex-to-complex plans: Plan(packed=False) (transform.py:207-213,266-270; the reference's
  * tests/test_transform.py:180-298).  One device buffer [nx][ny][nz] complex, transformed in place.
- * Power-of-two axes in [8, 2048] run on the tiled kernels, any other even axes up to 8192 (RF_F32) / 4096 (RF_F64) on the generic ones.
+ * Power-of-two axes in [8, 2048] run on the tiled kernels, any other even axes on the generic ones (up to 8192 (RF_F32) / 4096 (RF_F64) points in one pass, longer ones split into two factors that fit).
  * Only rf_upload_c / rf_download_c / rf_execute_c2c,
  * rf_sync, rf_elapsed_ms, rf_plan_set_stream, rf_plan_nbytes, rf_device_ptr and rf_plan_destroy apply. */
 int rf_plan_create_c2c(rf_plan** plan, int nx, int ny, int nz, int dtype, int device);

@@ -184,7 +184,8 @@ def require_gpu():
 
 def shape_supported(nx, ny, nz, dtype=None):
     """Does the HIP path take this grid?  With a dtype (numpy complex64 / complex128, or RF_F32 / RF_F64) the answer is exactly what
-    rf_plan_create accepts for it on one rank (complex128 plans: generic axes up to 4096, complex64 up to 8192)."""
+    rf_plan_create accepts for it on one rank (generic axes: one LDS line of up to 8192 complex64 / 4096 complex128 points, or two
+    factors that fit)."""
     if dtype is None:
         return bool(load().rf_shape_supported(int(nx), int(ny), int(nz)))
     code = dtype if dtype in (RF_F32, RF_F64) else (RF_F64 if np.dtype(dtype) in (np.dtype(np.complex128), np.dtype(np.float64)) else RF_F32)

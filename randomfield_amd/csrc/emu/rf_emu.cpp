@@ -499,62 +499,103 @@ int realise_fast_impl(int nx, int ny, int nz, const GenHost& h, uint64_t seed, d
 // ---- non-power-of-two path (rf_generic.h): the same block functions the kernels run, one "thread" per block ----
 struct NoSync { void operator()() const {} };
 
+// The library's sequences (rf_generic.h generic_*_seq) with every launch replaced by a loop over its blocks, one "thread" each.
+// g_generic_cap: the longest line kept "in LDS" -- the library's cap is 8192 / 4096; tests lower it so that small grids take the
+// four-step form of the long axes.
+int g_generic_cap = 0;                  // 0: generic_max_axis(dtype)
+template <typename T> struct EmuGenericOps {
+  const cplx<T>*rx, *ry, *rz;
+  int nx, ny, nz, M;                    // M = row length of the contiguous complex transform's root table / 2 (packed) -- see callers
+  long long rows;
+  std::vector<cplx<T>> lds;
+  double s1 = 0, s2 = 0;
+  const cplx<T>* root(int which) const { return which == 0 ? rx : (which == 1 ? ry : rz); }
+  int axis(const void* src, void* dst, const GenericAxis& ax, long long stride, long long inner, long long outer, long long nlines, int which, int sign, double scale) {
+    const int TC = 3;                   // deliberately not dividing the line counts
+    lds.resize(2 * (size_t)ax.n * TC);
+    for (long long b = 0; b * TC < nlines; ++b)
+      generic_axis_block<T>((const cplx<T>*)src, (cplx<T>*)dst, ax, stride, inner, outer, nlines, TC, root(which), sign, (T)scale, lds.data(), b, 0, 1, NoSync());
+    return 0;
+  }
+  int lines(const void* src, void* dst, const GenericLines& L, int which) {
+    const int TC = 3;
+    lds.resize(2 * (size_t)L.ax.n * TC);
+    for (long long b = 0; b * TC < L.nlines(); ++b)
+      generic_lines_block<T>((const cplx<T>*)src, (cplx<T>*)dst, L, TC, root(which), lds.data(), b, 0, 1, NoSync());
+    return 0;
+  }
+  GenericAxis az;
+  int row_c2r(const void* G, void* W, double scale) {
+    const int TR = 2;
+    lds.resize(2 * (size_t)az.n * TR);
+    for (long long b = 0; b * TR < rows; ++b)
+      generic_row_c2r_block<T>((const cplx<T>*)G, (T*)W, az, rows, TR, rz, (T)scale, lds.data(), b, 0, 1, NoSync(), s1, s2);
+    return 0;
+  }
+  int row_r2c(const void* W, void* G) {
+    const int TR = 2;
+    lds.resize(2 * (size_t)az.n * TR);
+    for (long long b = 0; b * TR < rows; ++b) generic_row_r2c_block<T>((const T*)W, (cplx<T>*)G, az, rows, TR, rz, lds.data(), b, 0, 1, NoSync());
+    return 0;
+  }
+  int untangle(const void* G, void* Z) { for (long long i = 0; i < rows * M; ++i) generic_untangle_at<T>((const cplx<T>*)G, (cplx<T>*)Z, M, rz, i); return 0; }
+  int tangle(const void* Z, void* G) { for (long long i = 0; i < rows * (M + 1); ++i) generic_tangle_at<T>((const cplx<T>*)Z, (cplx<T>*)G, M, rz, i); return 0; }
+  int moments(const void* W) {
+    const T* w = (const T*)W;
+    for (long long i = 0; i < rows * 2 * M; ++i) { s1 += (double)w[i]; s2 += (double)w[i] * (double)w[i]; }
+    return 0;
+  }
+  int copy(void* dst, const void* src, size_t bytes) { memcpy(dst, src, bytes); return 0; }
+};
+// one axis: short (its line fits the cap) or split in two factors that do; false: neither
+inline bool emu_axis(long long n, int cap, GenericAxis& ax, GenericLong& lg) {
+  lg = GenericLong();
+  if (n <= cap) return generic_factor((int)n, ax);
+  return generic_split(n, cap, lg);
+}
+template <typename T> bool emu_dims(int nx, int ny, int nz, bool packed, GenericDims& d) {
+  const int cap = g_generic_cap > 0 ? g_generic_cap : generic_max_axis(sizeof(T) == 8);
+  d.nx = nx; d.ny = ny; d.nz = nz; d.csize = sizeof(cplx<T>);
+  if (packed && (nz & 1)) return false;
+  return emu_axis(nx, cap, d.ax, d.lx) && emu_axis(ny, cap, d.ay, d.ly) && emu_axis(packed ? nz / 2 : nz, cap, d.az, d.lz);
+}
+
 template <typename T>
 int generic_c2r_impl(int nx, int ny, int nz, const cplx<T>* K, T* W, double* s1, double* s2) {
-  GenericAxis ax, ay, az;
-  if (!generic_factor(nx, ax) || !generic_factor(ny, ay) || !generic_factor(nz / 2, az) || (nz & 1)) return -1;
+  GenericDims d;
+  if (!emu_dims<T>(nx, ny, nz, true, d)) return -1;
   const long long nzh = nz / 2 + 1;
   auto rx = make_twiddles<T>(nx), ry = make_twiddles<T>(ny), rz = make_twiddles<T>(nz);
-  std::vector<cplx<T>> G((size_t)nx * ny * nzh);
-  const int TC = 3, TR = 2;                                   // deliberately not dividing the line counts
-  std::vector<cplx<T>> lds(2 * (size_t)std::max(std::max(nx, ny), nz) * 4);
-  const long long lx = (long long)ny * nzh, ly = (long long)nx * nzh, lz = (long long)nx * ny;
-  for (long long b = 0; b * TC < lx; ++b)
-    generic_axis_block<T>(K, G.data(), ax, lx, lx, 0, lx, TC, rx.data(), +1, (T)1, lds.data(), b, 0, 1, NoSync());
-  for (long long b = 0; b * TC < ly; ++b)
-    generic_axis_block<T>(G.data(), G.data(), ay, nzh, nzh, ny * nzh, ly, TC, ry.data(), +1, (T)1, lds.data(), b, 0, 1, NoSync());
-  double a1 = 0, a2 = 0;
-  const T scale = (T)(1.0 / ((double)nx * ny * nz));
-  for (long long b = 0; b * TR < lz; ++b)
-    generic_row_c2r_block<T>(G.data(), W, az, lz, TR, rz.data(), scale, lds.data(), b, 0, 1, NoSync(), a1, a2);
-  if (s1) *s1 = a1;
-  if (s2) *s2 = a2;
-  return 0;
+  std::vector<cplx<T>> G((size_t)nx * ny * nzh), G2((size_t)nx * ny * nzh);
+  EmuGenericOps<T> ops{rx.data(), ry.data(), rz.data(), nx, ny, nz, nz / 2, (long long)nx * ny};
+  ops.az = d.az;
+  const int rc = generic_c2r_seq(ops, d, K, G.data(), G2.data(), W, 1.0 / ((double)nx * ny * nz));
+  if (s1) *s1 = ops.s1;
+  if (s2) *s2 = ops.s2;
+  return rc;
 }
 
 template <typename T>
 int generic_r2c_impl(int nx, int ny, int nz, const T* W, cplx<T>* K) {
-  GenericAxis ax, ay, az;
-  if (!generic_factor(nx, ax) || !generic_factor(ny, ay) || !generic_factor(nz / 2, az) || (nz & 1)) return -1;
+  GenericDims d;
+  if (!emu_dims<T>(nx, ny, nz, true, d)) return -1;
   const long long nzh = nz / 2 + 1;
   auto rx = make_twiddles<T>(nx), ry = make_twiddles<T>(ny), rz = make_twiddles<T>(nz);
-  const int TC = 3, TR = 2;
-  std::vector<cplx<T>> lds(2 * (size_t)std::max(std::max(nx, ny), nz) * 4);
-  const long long lx = (long long)ny * nzh, ly = (long long)nx * nzh, lz = (long long)nx * ny;
-  for (long long b = 0; b * TR < lz; ++b) generic_row_r2c_block<T>(W, K, az, lz, TR, rz.data(), lds.data(), b, 0, 1, NoSync());
-  for (long long b = 0; b * TC < ly; ++b)
-    generic_axis_block<T>(K, K, ay, nzh, nzh, ny * nzh, ly, TC, ry.data(), -1, (T)1, lds.data(), b, 0, 1, NoSync());
-  for (long long b = 0; b * TC < lx; ++b)
-    generic_axis_block<T>(K, K, ax, lx, lx, 0, lx, TC, rx.data(), -1, (T)1, lds.data(), b, 0, 1, NoSync());
-  return 0;
+  std::vector<cplx<T>> G((size_t)nx * ny * nzh), G2((size_t)nx * ny * nzh);
+  EmuGenericOps<T> ops{rx.data(), ry.data(), rz.data(), nx, ny, nz, nz / 2, (long long)nx * ny};
+  ops.az = d.az;
+  return generic_r2c_seq(ops, d, W, K, G.data(), G2.data());
 }
 
 template <typename T>
 int generic_c2c_impl(int nx, int ny, int nz, int dir, cplx<T>* D) {
-  GenericAxis ax, ay, az;
-  if (!generic_factor(nx, ax) || !generic_factor(ny, ay) || !generic_factor(nz, az)) return -1;
+  GenericDims d;
+  if (!emu_dims<T>(nx, ny, nz, false, d)) return -1;
   auto rx = make_twiddles<T>(nx), ry = make_twiddles<T>(ny), rz = make_twiddles<T>(nz);
-  const int TC = 3;
-  std::vector<cplx<T>> lds(2 * (size_t)std::max(std::max(nx, ny), nz) * 4);
-  const long long lx = (long long)ny * nz, ly = (long long)nx * nz, lz = (long long)nx * ny;
-  const T scale = dir > 0 ? (T)(1.0 / ((double)nx * ny * nz)) : (T)1;
-  for (long long b = 0; b * TC < lx; ++b)
-    generic_axis_block<T>(D, D, ax, lx, lx, 0, lx, TC, rx.data(), dir, (T)1, lds.data(), b, 0, 1, NoSync());
-  for (long long b = 0; b * TC < ly; ++b)
-    generic_axis_block<T>(D, D, ay, nz, nz, (long long)ny * nz, ly, TC, ry.data(), dir, (T)1, lds.data(), b, 0, 1, NoSync());
-  for (long long b = 0; b * TC < lz; ++b)
-    generic_axis_block<T>(D, D, az, 1, 1, nz, lz, TC, rz.data(), dir, scale, lds.data(), b, 0, 1, NoSync());
-  return 0;
+  std::vector<cplx<T>> G((size_t)nx * ny * nz);
+  EmuGenericOps<T> ops{rx.data(), ry.data(), rz.data(), nx, ny, nz, nz, (long long)nx * ny};
+  ops.az = d.az;
+  return generic_c2c_seq(ops, d, D, G.data(), dir, dir > 0 ? 1.0 / ((double)nx * ny * nz) : 1.0);
 }
 
 // rf_realise_lognormal on an uploaded k-space array: x pass, the accumulating y pass (AccColIO: one Parseval partial per tile),
@@ -734,6 +775,9 @@ int emu_row_c2r_xgather(int f64, int M, int nx, int ny, int tc, int rb, const vo
 // 1 (default): c2r transforms hand x -> y through the transposed intermediate where the product would; 0: in place
 int emu_set_xposed(int on) { const int old = g_xposed; g_xposed = on; return old; }
 int emu_set_rowblock(int rb) { const int old = g_rowblock; g_rowblock = rb; return old; }
+// the longest line the generic path keeps whole (0 = the library's cap, 8192 complex64 / 4096 complex128): longer axes take the four-step
+// form -- lowered by tests so that small grids exercise it
+int emu_set_generic_cap(int cap) { const int old = g_generic_cap; g_generic_cap = cap; return old; }
 // 1 (default): the float32 generation pass of length 1024 on tile pairs (ColPair), as the product; 0: one tile per workgroup (ColFFT)
 int emu_set_pairs(int on) { const int old = g_pairs; g_pairs = on; return old; }
 // FastGenColIOT::share_row (rf_fft_gen.h): the butterfly row of slot jl when L butterflies are dealt to slots of S per wave so that

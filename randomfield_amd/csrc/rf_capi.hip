@@ -102,13 +102,27 @@ int ensure_x(rf_plan* p) {
   return 0;
 }
 
-// any even shape with axes up to generic_max_axis(dtype) -- 8192 for complex64, 4096 for complex128: a whole line in LDS
-// (transform.py:172-177 asks for even axes, nothing more)
-bool generic_shape(int nx, int ny, int nz, int f64, GenericAxis& ax, GenericAxis& ay, GenericAxis& az_half) {
+// Any even shape (transform.py:172-177 asks for even axes, nothing more) whose axes either fit one line of the LDS
+// (generic_max_axis(dtype): 8192 for complex64, 4096 for complex128) or split into two factors that do (the four-step form of
+// rf_generic.h: up to cap^2).  packed: the contiguous axis is transformed at length nz / 2 (c2r / r2c plans), else at nz (c2c plans).
+bool generic_dims(int nx, int ny, int nz, int f64, bool packed, GenericDims& d) {
   if (nx < 2 || ny < 2 || nz < 2 || (nx & 1) || (ny & 1) || (nz & 1)) return false;
   const int cap = generic_max_axis(f64);
-  if (nx > cap || ny > cap || nz > cap) return false;
-  return generic_factor(nx, ax) && generic_factor(ny, ay) && generic_factor(nz / 2, az_half);
+  d = GenericDims();
+  d.nx = nx; d.ny = ny; d.nz = nz; d.csize = f64 ? 16 : 8;
+  auto one = [&](long long n, GenericAxis& ax, GenericLong& lg) {
+    lg = GenericLong();
+    if (n <= cap) return generic_factor((int)n, ax);
+    return generic_split(n, cap, lg);
+  };
+  // (a packed plan's root table of the contiguous axis has nz entries; nz itself must stay addressable: nz / 2 <= cap^2 is the limit that bites)
+  return one(nx, d.ax, d.lx) && one(ny, d.ay, d.ly) && one(packed ? nz / 2 : nz, d.az, d.lz);
+}
+bool generic_shape(int nx, int ny, int nz, int f64, GenericAxis& ax, GenericAxis& ay, GenericAxis& az_half) {
+  GenericDims d;
+  if (!generic_dims(nx, ny, nz, f64, true, d)) return false;
+  ax = d.ax; ay = d.ay; az_half = d.az;
+  return true;
 }
 
 GenParams make_gen(rf_plan* p, uint64_t seed, int mode, bool seed_from_dev) {
@@ -724,17 +738,48 @@ int queue_xyz(rf_plan* p, const GenParams& gp, const void* kspace, void* W, hipS
   return queue_yz(p, W, s, stats_out, timed);
 }
 
-// non-power-of-two grid: API-layout half spectrum K -> x pass into G -> y pass in G -> contiguous c2r pass into W,
-// (sum, sumsq) into stats_out
+// the launches behind the sequences of rf_generic.h (generic_c2r_seq / generic_r2c_seq / generic_c2c_seq) on the plan's stream
+struct HipGenericOps {
+  rf_plan* p;
+  hipStream_t s;
+  const void* root(int which) const { return which == 0 ? p->tw_x : (which == 1 ? p->tw_y : p->tw_z); }
+  int axis(const void* src, void* dst, const GenericAxis& ax, long long stride, long long inner, long long outer, long long nlines, int which, int sign, double scale) {
+    RF_HIP(launch_generic_axis(p->f64, src, dst, ax, stride, inner, outer, nlines, root(which), sign, scale, s));
+    return 0;
+  }
+  int lines(const void* src, void* dst, const GenericLines& L, int which) {
+    RF_HIP(launch_generic_lines(p->f64, src, dst, L, root(which), s));
+    return 0;
+  }
+  int row_c2r(const void* G, void* W, double scale) {
+    RF_HIP(launch_generic_row_c2r(p->f64, G, W, p->gdims.az, (long long)p->nx * p->ny, p->tw_z, scale, p->partials, s));
+    return 0;
+  }
+  int row_r2c(const void* W, void* G) {
+    RF_HIP(launch_generic_row_r2c(p->f64, W, G, p->gdims.az, (long long)p->nx * p->ny, p->tw_z, s));
+    return 0;
+  }
+  int untangle(const void* G, void* Z) { RF_HIP(launch_generic_untangle(p->f64, G, Z, (int)p->nzc, (long long)p->nx * p->ny, p->tw_z, s)); return 0; }
+  int tangle(const void* Z, void* G) { RF_HIP(launch_generic_tangle(p->f64, Z, G, (int)p->nzc, (long long)p->nx * p->ny, p->tw_z, s)); return 0; }
+  int moments(const void* W) { RF_HIP(launch_generic_moments(p->f64, W, (long long)p->nx * p->ny * p->nz, p->partials, p->npartials, s)); return 0; }
+  int copy(void* dst, const void* src, size_t bytes) { RF_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s)); return 0; }
+};
+bool generic_any_long(const rf_plan* p) { return p->gdims.lx.split() || p->gdims.ly.split() || p->gdims.lz.split(); }
+// the second scratch array, for plans with an axis in the four-step form
+int ensure_g2(rf_plan* p) {
+  if (!p->G2 && generic_any_long(p)) RF_HIP(hipMalloc(&p->G2, p->unpacked ? p->w_bytes : p->k_bytes));
+  return 0;
+}
+
+// non-power-of-two grid: API-layout half spectrum K -> x pass into G -> y pass -> contiguous c2r pass into W (rf_generic.h
+// generic_c2r_seq: axes too long for one line of the LDS take the four-step form through the scratch arrays), (sum, sumsq) into stats_out
 int generic_c2r(rf_plan* p, const void* K, double* stats_out) {
   if (int rc = ensure_g(p)) return rc;
-  const long long nzh = p->nzc + 1, lx = (long long)p->ny * nzh, ly = (long long)p->nx * nzh, lz = (long long)p->nx * p->ny;
-  hipStream_t s = p->stream;
-  RF_HIP(launch_generic_axis(p->f64, K, p->G, p->gax, lx, lx, 0, lx, p->tw_x, +1, 1.0, s));
-  RF_HIP(launch_generic_axis(p->f64, p->G, p->G, p->gay, nzh, nzh, (long long)p->ny * nzh, ly, p->tw_y, +1, 1.0, s));
+  if (int rc = ensure_g2(p)) return rc;
+  HipGenericOps ops{p, p->stream};
   const double scale = 1.0 / ((double)p->nx * (double)p->ny * (double)p->nz);
-  RF_HIP(launch_generic_row_c2r(p->f64, p->G, p->W, p->gaz, lz, p->tw_z, scale, p->partials, s));
-  RF_HIP(launch_reduce_partials(p->partials, p->npartials, stats_out, p->partials + 2 * p->npartials, s));
+  if (int rc = generic_c2r_seq(ops, p->gdims, K, p->G, p->G2, p->W, scale)) return rc;
+  RF_HIP(launch_reduce_partials(p->partials, p->npartials, stats_out, p->partials + 2 * p->npartials, p->stream));
   return 0;
 }
 
@@ -929,17 +974,17 @@ int rf_plan_create(rf_plan** out, int nx, int ny, int nz, int dtype, int device,
   RF_REQUIRE(dtype == RF_F32 || dtype == RF_F64, "dtype must be RF_F32 or RF_F64");
   std::string why;
   RF_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "invalid nranks/rank");
-  GenericAxis gax, gay, gaz;
+  GenericDims gd;
   bool generic = false;
   if (shape_check(nx, ny, nz, dtype, &why, nranks)) {
-    generic = nranks == 1 && generic_shape(nx, ny, nz, dtype == RF_F64, gax, gay, gaz);
+    generic = nranks == 1 && generic_dims(nx, ny, nz, dtype == RF_F64, true, gd);
     if (!generic)
-      return fail(1, "unsupported shape: " + why + (nranks == 1 ? std::string(" (and not an even shape with axes <= ") + (dtype == RF_F64 ? "4096, the cap of complex128 plans" : "8192, the cap of complex64 plans") + " either: rf_shape_supported_dtype)" : ""));
+      return fail(1, "unsupported shape: " + why + (nranks == 1 ? std::string(" (and not an even shape whose axes fit one line of the LDS -- ") + (dtype == RF_F64 ? "4096 points on complex128 plans" : "8192 points on complex64 plans") + " -- or split into two factors that do, either: rf_shape_supported_dtype)" : ""));
   }
   RF_HIP(hipSetDevice(device));
   rf_plan* p = new rf_plan();
   p->generic = generic;
-  if (generic) { p->gax = gax; p->gay = gay; p->gaz = gaz; }
+  if (generic) { p->gdims = gd; p->gax = gd.ax; p->gay = gd.ay; p->gaz = gd.az; }
   p->nx = nx; p->ny = ny; p->nz = nz; p->nzc = nz / 2; p->f64 = dtype; p->device = device;
   p->nranks = nranks; p->rank = rank;
   p->csize = dtype ? 16 : 8;
@@ -970,7 +1015,7 @@ int rf_plan_create(rf_plan** out, int nx, int ny, int nz, int dtype, int device,
     if (!rc) rc = upload_twiddles<float>(&p->tw_z, nz);
   }
   if (rc) return cleanup(rc);
-  p->npartials = generic ? generic_row_blocks(dtype, (int)p->nzc, (long long)nx * ny)
+  p->npartials = generic ? (gd.lz.split() ? 1024 : generic_row_blocks(dtype, (int)p->nzc, (long long)nx * ny))      // (long rows: the moments are a pass of their own, 1024 blocks)
                : nranks > 1 ? row_c2r_tiles(dtype, p->nzc, (long long)p->nxl * ny) : row_c2r_tiles(dtype, p->nzc, (long long)nx * ny);
   p->stats_cap = 64;
   if ((e = hipMalloc((void**)&p->partials, (2 * p->npartials + 512) * sizeof(double))) != hipSuccess ||
@@ -1021,15 +1066,13 @@ int rf_plan_create_c2c(rf_plan** out, int nx, int ny, int nz, int dtype, int dev
     const int tcx = col_tile_cols(dtype, nx), tcy = col_tile_cols(dtype, ny);
     generic = ((long long)ny * nz) % tcx || ((long long)nx * nz) % tcy;      // too few columns for a tile
   }
-  GenericAxis gax, gay, gaz;
-  const int gcap = generic_max_axis(dtype == RF_F64);
-  if (generic && !(nx >= 2 && ny >= 2 && nz >= 2 && !(nx & 1) && !(ny & 1) && !(nz & 1) && nx <= gcap && ny <= gcap && nz <= gcap &&
-                   generic_factor(nx, gax) && generic_factor(ny, gay) && generic_factor(nz, gaz)))
-    return fail(1, "unsupported shape for a c2c plan: nx, ny, nz must be even and at most 8192 (complex64) / 4096 (complex128)");
+  GenericDims gd;
+  if (generic && !generic_dims(nx, ny, nz, dtype == RF_F64, false, gd))
+    return fail(1, "unsupported shape for a c2c plan: nx, ny, nz must be even, and every axis must fit one line of the LDS (8192 points complex64 / 4096 complex128) or split into two factors that do");
   RF_HIP(hipSetDevice(device));
   rf_plan* p = new rf_plan();
   p->generic = generic;
-  if (generic) { p->gax = gax; p->gay = gay; p->gaz = gaz; }
+  if (generic) { p->gdims = gd; p->gax = gd.ax; p->gay = gd.ay; p->gaz = gd.az; }
   p->nx = nx; p->ny = ny; p->nz = nz; p->nzc = nz / 2; p->f64 = dtype; p->device = device;
   p->nranks = 1; p->rank = 0; p->csize = dtype ? 16 : 8; p->nxl = nx; p->nzl = p->nzc; p->kz0 = 0;
   p->unpacked = true;
@@ -1089,10 +1132,9 @@ int rf_execute_c2c(rf_plan* p, int direction) {
   const double scale = direction > 0 ? 1.0 / ((double)p->nx * (double)p->ny * (double)p->nz) : 1.0;
   RF_HIP(hipEventRecord(p->ev[0], p->stream));
   if (p->generic) {
-    const long long lx = (long long)p->ny * nz, ly = (long long)p->nx * nz, lz = (long long)p->nx * p->ny;
-    RF_HIP(launch_generic_axis(p->f64, p->W, p->W, p->gax, lx, lx, 0, lx, p->tw_x, direction, 1.0, p->stream));
-    RF_HIP(launch_generic_axis(p->f64, p->W, p->W, p->gay, nz, nz, (long long)p->ny * nz, ly, p->tw_y, direction, 1.0, p->stream));
-    RF_HIP(launch_generic_axis(p->f64, p->W, p->W, p->gaz, 1, 1, nz, lz, p->tw_z, direction, scale, p->stream));
+    if (generic_any_long(p) && !p->G) RF_HIP(hipMalloc(&p->G, p->w_bytes));        // scratch of the four-step form
+    HipGenericOps ops{p, p->stream};
+    if (int rc = generic_c2c_seq(ops, p->gdims, p->W, p->G, direction, scale)) return rc;
   } else {
     RF_HIP(launch_col_plain(p->f64, p->nx, direction, p->W, gx, (long long)p->ny * nz, p->tw_x, p->stream));
     RF_HIP(launch_col_plain(p->f64, p->ny, direction, p->W, gy, (long long)p->nx * nz, p->tw_y, p->stream));
@@ -1114,7 +1156,7 @@ int rf_plan_destroy(rf_plan* p) {
   for (void* m : p->ipc_open) (void)hipIpcCloseMemHandle(m);
   if (p->dl_stream) { (void)hipStreamSynchronize(p->dl_stream); (void)hipStreamDestroy(p->dl_stream); }
   for (auto& e : p->sink_ev) (void)hipEventDestroy(e);
-  void* bufs[] = {p->peer_tab, p->W, p->R, p->W2, p->R2, p->K, p->P_base, p->G, p->tw_x, p->tw_y, p->tw_z, p->kx2, p->ky2, p->kz2, p->xt, p->st, p->sl, p->bin,
+  void* bufs[] = {p->peer_tab, p->W, p->R, p->W2, p->R2, p->K, p->P_base, p->G, p->G2, p->tw_x, p->tw_y, p->tw_z, p->kx2, p->ky2, p->kz2, p->xt, p->st, p->sl, p->bin,
                   p->X, p->lntab, p->ypart, p->noise, p->mt_scratch, p->mt_send, p->mt_recv, p->mt_sbase, p->mt_first, p->mt_pos, p->mt_npos_dev, p->mt_states, p->mt_counts, p->mt_offsets, p->mt_rowtab, p->mt_flags, p->br_tmp, p->fixbuf, p->partials, p->stats, p->seeds_dev, p->ztab, p->frec, p->coll_scratch};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -1136,7 +1178,7 @@ int rf_plan_destroy(rf_plan* p) {
 
 int rf_plan_nbytes(rf_plan* p, size_t* nbytes) {
   RF_REQUIRE(p && nbytes, "null argument");
-  *nbytes = p->w_bytes * (1 + (p->R ? 1 : 0) + (p->W2 ? 2 : 0) + (p->X ? 1 : 0)) + (p->K ? p->k_bytes : 0) + (p->P ? p->p_bytes : 0) + (p->G ? p->k_bytes : 0) +
+  *nbytes = p->w_bytes * (1 + (p->R ? 1 : 0) + (p->W2 ? 2 : 0) + (p->X ? 1 : 0)) + (p->K ? p->k_bytes : 0) + (p->P ? p->p_bytes : 0) + ((p->G ? 1 : 0) + (p->G2 ? 1 : 0)) * (p->unpacked ? p->w_bytes : p->k_bytes) +
             p->noise_cap * sizeof(double) + p->mt_scratch_bytes;      // + resident deviates and the replay's scratch runs
   return 0;
 }
@@ -1318,11 +1360,10 @@ int rf_execute_r2c(rf_plan* p) {
   const long long nzc = p->nzc;
   const ColGeom gx{(long long)p->ny * nzc, 0, (long long)p->ny * nzc}, gy{nzc, (long long)p->ny * nzc, nzc};
   RF_HIP(hipEventRecord(p->ev[0], p->stream));
-  if (p->generic) {            // rows -> half spectrum in K, then the y and x forward passes in place
-    const long long nzh = nzc + 1, lx = (long long)p->ny * nzh, ly = (long long)p->nx * nzh;
-    RF_HIP(launch_generic_row_r2c(p->f64, p->W, p->K, p->gaz, (long long)p->nx * p->ny, p->tw_z, p->stream));
-    RF_HIP(launch_generic_axis(p->f64, p->K, p->K, p->gay, nzh, nzh, (long long)p->ny * nzh, ly, p->tw_y, -1, 1.0, p->stream));
-    RF_HIP(launch_generic_axis(p->f64, p->K, p->K, p->gax, lx, lx, 0, lx, p->tw_x, -1, 1.0, p->stream));
+  if (p->generic) {            // rows -> half spectrum in K, then the y and x forward passes (rf_generic.h generic_r2c_seq)
+    if (generic_any_long(p)) { if (int rc = ensure_g(p)) return rc; if (int rc = ensure_g2(p)) return rc; }
+    HipGenericOps ops{p, p->stream};
+    if (int rc = generic_r2c_seq(ops, p->gdims, p->W, p->K, p->G, p->G2)) return rc;
     RF_HIP(hipEventRecord(p->ev[4], p->stream));
     p->timed = false;
     p->k_valid = true;          // the real field in W is untouched on this path

@@ -191,6 +191,210 @@ RF_HD void generic_row_r2c_block(const T* W, cplx<T>* G, const GenericAxis& ax, 
   }
 }
 
+// ---------------------------------------------------------------------------
+// Axes LONGER than a line that fits the LDS (n > generic_max_axis): the four-step form through global memory.  With n = n1 n2,
+// j = j1 n2 + j2 and k = k1 + n1 k2:
+//     X[k1 + n1 k2] = sum_j2 w_n2^(j2 k2) * [ w_n^(j2 k1) * sum_j1 x[j1 n2 + j2] w_n1^(j1 k1) ]
+//   step 1: for every j2 the length-n1 transform over j1 (elements n2 apart), in place: Y[k1][j2] at position k1 n2 + j2;
+//   step 3: for every k1 the length-n2 transform over j2 (adjacent elements), its inputs multiplied by w_n^(j2 k1) on load, its outputs
+//           stored n1 apart from position k1: natural order -- into ANOTHER array (a line's stores land among other lines' inputs).
+// Both steps are "lines with sub-lines" (GenericLines) run by generic_lines_block, the generalisation of generic_axis_block: parent
+// line l0 starts at (l0 / inner) outer + l0 % inner; its sub-line q starts q * sub further on and has its own element stride.
+// Every even n <= cap^2 that splits into two factors <= cap is served (transform.py:172-177 accepts any even shape).
+// ---------------------------------------------------------------------------
+struct GenericLong {
+  int n = 0, n1 = 0, n2 = 0;            // n1 = 0: the axis is not split (its line fits the LDS)
+  GenericAxis a1, a2;
+  RF_HD bool split() const { return n1 > 0; }
+};
+// n = n1 n2 with both factors <= cap (and factorable): the most balanced split; false if there is none
+inline bool generic_split(long long n, int cap, GenericLong& lg) {
+  lg = GenericLong();
+  if (n < 4 || n > (long long)cap * cap || n > 0x7fffffffLL) return false;
+  lg.n = (int)n;
+  int best = 0;
+  for (long long d = 1; d * d <= n; ++d)
+    if (n % d == 0 && n / d <= cap && d <= cap) best = (int)d;           // largest divisor <= sqrt(n) whose cofactor fits
+  if (best < 2) return false;
+  lg.n1 = (int)(n / best); lg.n2 = best;                                  // n1 >= n2
+  return generic_factor(lg.n1, lg.a1) && generic_factor(lg.n2, lg.a2);
+}
+
+struct GenericLines {
+  GenericAxis ax;                       // the line's own transform
+  int rstep = 1;                        // root[] holds exp(2 pi i t / (ax.n * rstep))
+  long long stride_s = 1, inner_s = 1, outer_s = 0, sub_s = 0;      // source: parent line, element stride, sub-line offset
+  long long stride_d = 1, inner_d = 1, outer_d = 0, sub_d = 0;      // destination
+  long long nparent = 0;                // parent lines
+  int nsub = 1;                         // sub-lines per parent line; line index l = q * nparent + l0 (neighbouring l0 are neighbours in memory)
+  int tw_n = 0, tw_step = 1;            // > 0: element e of sub-line q is multiplied by root[((e q) mod tw_n) * tw_step] on load (conjugated for sign < 0)
+  int sign = +1;
+  double scale = 1.0;
+  RF_HD long long nlines() const { return nparent * nsub; }
+};
+// step 1 / step 3 of the four-step transform of the lines (S, inner, outer, nparent) of length lg.n; root_mul: the root table holds
+// exp(2 pi i t / (lg.n * root_mul)).  Step 3 stores through (Sd, inner_d, outer_d).
+inline GenericLines generic_long_step1(const GenericLong& lg, long long S, long long inner, long long outer, long long nparent, int root_mul, int sign) {
+  GenericLines L;
+  L.ax = lg.a1; L.rstep = lg.n2 * root_mul;
+  L.stride_s = L.stride_d = (long long)lg.n2 * S; L.inner_s = L.inner_d = inner; L.outer_s = L.outer_d = outer; L.sub_s = L.sub_d = S;
+  L.nparent = nparent; L.nsub = lg.n2; L.sign = sign;
+  return L;
+}
+inline GenericLines generic_long_step3(const GenericLong& lg, long long S, long long inner, long long outer, long long Sd, long long inner_d,
+                                       long long outer_d, long long nparent, int root_mul, int sign, double scale) {
+  GenericLines L;
+  L.ax = lg.a2; L.rstep = lg.n1 * root_mul;
+  L.stride_s = S; L.inner_s = inner; L.outer_s = outer; L.sub_s = (long long)lg.n2 * S;
+  L.stride_d = (long long)lg.n1 * Sd; L.inner_d = inner_d; L.outer_d = outer_d; L.sub_d = Sd;
+  L.nparent = nparent; L.nsub = lg.n1; L.tw_n = lg.n; L.tw_step = root_mul; L.sign = sign; L.scale = scale;
+  return L;
+}
+
+// block `blk` transforms lines [blk TC, blk TC + TC) of L; lds: 2 * L.ax.n * TC elements.  src == dst is allowed when the two
+// addressings are the same (step 1); step 3 needs another array.
+template <typename T, class Sync>
+RF_HD void generic_lines_block(const cplx<T>* src, cplx<T>* dst, const GenericLines& L, int TC, const cplx<T>* root, cplx<T>* lds,
+                               long long blk, int tid, int nth, Sync sync) {
+  const int n = L.ax.n, total = n * TC;
+  const long long l0b = blk * TC, nl = L.nlines();
+  cplx<T>*a = lds, *b = lds + total;
+  for (int idx = tid; idx < total; idx += nth) {
+    const int c = idx % TC, e = idx / TC;
+    const long long l = l0b + c;
+    cplx<T> v = mk<T>((T)0, (T)0);
+    if (l < nl) {
+      const long long q = l / L.nparent, l0 = l - q * L.nparent;
+      v = src[(l0 / L.inner_s) * L.outer_s + l0 % L.inner_s + q * L.sub_s + e * L.stride_s];
+      if (L.tw_n > 0) {
+        const long long t = ((long long)e * q) % L.tw_n;
+        cplx<T> w = root[t * L.tw_step];
+        if (L.sign < 0) w.y = -w.y;
+        v = mk<T>(v.x * w.x - v.y * w.y, v.x * w.y + v.y * w.x);
+      }
+    }
+    a[idx] = v;
+  }
+  sync();
+  const cplx<T>* r = generic_line_fft<T>(a, b, L.ax, TC, root, L.rstep, L.sign, tid, nth, sync);
+  const T scale = (T)L.scale;
+  for (int idx = tid; idx < total; idx += nth) {
+    const int c = idx % TC, e = idx / TC;
+    const long long l = l0b + c;
+    if (l < nl) {
+      const long long q = l / L.nparent, l0 = l - q * L.nparent;
+      const cplx<T> v = r[idx];
+      dst[(l0 / L.inner_d) * L.outer_d + l0 % L.inner_d + q * L.sub_d + e * L.stride_d] = mk<T>(v.x * scale, v.y * scale);
+    }
+  }
+}
+
+// The Hermitian (un)tangle of the packed transforms as passes of their own, for rows too long for generic_row_c2r_block /
+// generic_row_r2c_block (element idx of the grid-stride loop; root = exp(2 pi i t / nz), M = nz / 2):
+//   untangle: Z[row][k] = (X[k] + conj X[M-k]) + i w^k (X[k] - conj X[M-k]), k < M, from rows of M + 1 bins (imaginary parts of X[0], X[M] ignored)
+template <typename T>
+RF_HD void generic_untangle_at(const cplx<T>* G, cplx<T>* Z, int M, const cplx<T>* root, long long idx) {
+  const long long row = idx / M;
+  const int k = (int)(idx - row * M);
+  const cplx<T>* X = G + row * (long long)(M + 1);
+  cplx<T> z;
+  if (k == 0) {
+    z = mk<T>(X[0].x + X[M].x, X[0].x - X[M].x);
+  } else {
+    const cplx<T> p = X[k], q = X[M - k];
+    const T er = p.x + q.x, ei = p.y - q.y, orr = p.x - q.x, oi = p.y + q.y;
+    const cplx<T> w = root[k];
+    z = mk<T>(er - (w.x * oi + w.y * orr), ei + (w.x * orr - w.y * oi));
+  }
+  Z[idx] = z;
+}
+//   tangle: X[k] = (Z[k] + conj Z[M-k]) / 2 - (i / 2) conj(w)^k (Z[k] - conj Z[M-k]), k <= M, Z[M] = Z[0], into rows of M + 1 bins
+template <typename T>
+RF_HD void generic_tangle_at(const cplx<T>* Z, cplx<T>* G, int M, const cplx<T>* root, long long idx) {
+  const long long row = idx / (M + 1);
+  const int k = (int)(idx - row * (M + 1));
+  const cplx<T>* z = Z + row * (long long)M;
+  const cplx<T> p = z[k % M], q = z[(M - k) % M];
+  const T er = (T)0.5 * (p.x + q.x), ei = (T)0.5 * (p.y - q.y), orr = (T)0.5 * (p.x - q.x), oi = (T)0.5 * (p.y + q.y);
+  cplx<T> w = root[k];
+  w.y = -w.y;
+  G[idx] = mk<T>(er + (w.x * oi + w.y * orr), ei - (w.x * orr - w.y * oi));
+}
+
+// ---------------------------------------------------------------------------
+// The sequences of the three generic transforms, written ONCE for the library (Ops = kernel launches, rf_capi.hip) and for the CPU
+// emulator (Ops = loops over blocks, emu/rf_emu.cpp), so that the buffer choreography of the long axes is tested on the CPU too.
+// Ops provides (all return 0 or an error code; `which` = 0 / 1 / 2 selects the x / y / z root table):
+//   axis(src, dst, ax, stride, inner, outer, nlines, which, sign, scale)   one plain pass (generic_axis_block)
+//   lines(src, dst, L, which)                                              one pass of lines with sub-lines (generic_lines_block)
+//   row_c2r(G, W, scale) / row_r2c(W, G)                                   the fused contiguous passes of rows that fit the LDS
+//   untangle(G, Z) / tangle(Z, G) / moments(W)                             the pieces of the contiguous passes for long rows
+//   copy(dst, src, bytes)
+// ---------------------------------------------------------------------------
+struct GenericDims {
+  int nx = 0, ny = 0, nz = 0;
+  GenericAxis ax, ay, az;               // az factors nz / 2 (packed plans) or nz (c2c plans); unused where the long form applies
+  GenericLong lx, ly, lz;
+  size_t csize = 8;                     // bytes per complex element
+};
+// four-step pass of the lines (S, inner, outer, nparent) of a long axis: step 1 src -> tmp (tmp may be src), step 3 tmp -> dst (dst != tmp)
+template <class Ops>
+int generic_long_pass(Ops& ops, const void* src, void* tmp, void* dst, const GenericLong& lg, long long S, long long inner, long long outer,
+                      long long Sd, long long inner_d, long long outer_d, long long nparent, int which, int root_mul, int sign, double scale) {
+  if (int rc = ops.lines(src, tmp, generic_long_step1(lg, S, inner, outer, nparent, root_mul, sign), which)) return rc;
+  return ops.lines(tmp, dst, generic_long_step3(lg, S, inner, outer, Sd, inner_d, outer_d, nparent, root_mul, sign, scale), which);
+}
+// half spectrum K [nx][ny][nz/2+1] -> dense reals W [nx][ny][nz] (np.fft.irfftn with `scale`); G, G2: scratch arrays of K's size (G2 is
+// touched only when an axis is long); the (sum, sumsq) partials are left by row_c2r / moments
+template <class Ops>
+int generic_c2r_seq(Ops& ops, const GenericDims& d, const void* K, void* G, void* G2, void* W, double scale) {
+  const long long nzh = d.nz / 2 + 1, M = d.nz / 2;
+  const long long Lx = (long long)d.ny * nzh, Ly = (long long)d.nx * nzh, rows = (long long)d.nx * d.ny;
+  if (d.lx.split()) { if (int rc = generic_long_pass(ops, K, G2, G, d.lx, Lx, Lx, 0, Lx, Lx, 0, Lx, 0, 1, +1, 1.0)) return rc; }
+  else if (int rc = ops.axis(K, G, d.ax, Lx, Lx, 0, Lx, 0, +1, 1.0)) return rc;
+  void* cur = G;
+  if (d.ly.split()) { if (int rc = generic_long_pass(ops, G, G, G2, d.ly, nzh, nzh, (long long)d.ny * nzh, nzh, nzh, (long long)d.ny * nzh, Ly, 1, 1, +1, 1.0)) return rc; cur = G2; }
+  else if (int rc = ops.axis(G, G, d.ay, nzh, nzh, (long long)d.ny * nzh, Ly, 1, +1, 1.0)) return rc;
+  if (!d.lz.split()) return ops.row_c2r(cur, W, scale);
+  void* other = cur == G ? G2 : G;                       // rows of M complex: the untangled spectrum, then (step 1, in place) its first transform
+  if (int rc = ops.untangle(cur, other)) return rc;
+  if (int rc = generic_long_pass(ops, other, other, W, d.lz, 1, 1, M, 1, 1, M, rows, 2, 2, +1, scale)) return rc;     // W as rows of M complex = nz reals
+  return ops.moments(W);
+}
+// dense reals W -> half spectrum K (np.fft.rfftn); W is left untouched
+template <class Ops>
+int generic_r2c_seq(Ops& ops, const GenericDims& d, const void* W, void* K, void* G, void* G2) {
+  const long long nzh = d.nz / 2 + 1, M = d.nz / 2;
+  const long long Lx = (long long)d.ny * nzh, Ly = (long long)d.nx * nzh, rows = (long long)d.nx * d.ny;
+  if (d.lz.split()) {
+    if (int rc = generic_long_pass(ops, W, G, G2, d.lz, 1, 1, M, 1, 1, M, rows, 2, 2, -1, 1.0)) return rc;
+    if (int rc = ops.tangle(G2, K)) return rc;
+  } else if (int rc = ops.row_r2c(W, K)) return rc;
+  void* cur = K;
+  if (d.ly.split()) { if (int rc = generic_long_pass(ops, K, K, G, d.ly, nzh, nzh, (long long)d.ny * nzh, nzh, nzh, (long long)d.ny * nzh, Ly, 1, 1, -1, 1.0)) return rc; cur = G; }
+  else if (int rc = ops.axis(K, K, d.ay, nzh, nzh, (long long)d.ny * nzh, Ly, 1, -1, 1.0)) return rc;
+  if (d.lx.split()) {
+    void* dst = cur == K ? G : K;
+    if (int rc = generic_long_pass(ops, cur, cur, dst, d.lx, Lx, Lx, 0, Lx, Lx, 0, Lx, 0, 1, -1, 1.0)) return rc;
+    cur = dst;
+  } else if (int rc = ops.axis(cur, cur, d.ax, Lx, Lx, 0, Lx, 0, -1, 1.0)) return rc;
+  if (cur != K) return ops.copy(K, cur, (size_t)d.nx * d.ny * nzh * d.csize);
+  return 0;
+}
+// unpacked complex array D [nx][ny][nz] in place (np.fft.fftn / ifftn: sign -1 unscaled, +1 with `scale`); G: scratch of D's size,
+// touched only when an axis is long
+template <class Ops>
+int generic_c2c_seq(Ops& ops, const GenericDims& d, void* D, void* G, int sign, double scale) {
+  const long long nz = d.nz, Lx = (long long)d.ny * nz, Ly = (long long)d.nx * nz, rows = (long long)d.nx * d.ny;
+  const size_t bytes = (size_t)d.nx * d.ny * nz * d.csize;
+  if (d.lx.split()) { if (int rc = generic_long_pass(ops, D, D, G, d.lx, Lx, Lx, 0, Lx, Lx, 0, Lx, 0, 1, sign, 1.0)) return rc; if (int rc = ops.copy(D, G, bytes)) return rc; }
+  else if (int rc = ops.axis(D, D, d.ax, Lx, Lx, 0, Lx, 0, sign, 1.0)) return rc;
+  if (d.ly.split()) { if (int rc = generic_long_pass(ops, D, D, G, d.ly, nz, nz, (long long)d.ny * nz, nz, nz, (long long)d.ny * nz, Ly, 1, 1, sign, 1.0)) return rc; if (int rc = ops.copy(D, G, bytes)) return rc; }
+  else if (int rc = ops.axis(D, D, d.ay, nz, nz, (long long)d.ny * nz, Ly, 1, sign, 1.0)) return rc;
+  if (d.lz.split()) { if (int rc = generic_long_pass(ops, D, D, G, d.lz, 1, 1, nz, 1, 1, nz, rows, 2, 1, sign, scale)) return rc; return ops.copy(D, G, bytes); }
+  return ops.axis(D, D, d.az, 1, 1, nz, rows, 2, sign, scale);
+}
+
 // lines / rows per block so that the two LDS buffers stay within 64 KB (no function attribute needed); a single line longer than
 // that (n > 4096 complex64 / 2048 complex128) takes what it needs, up to GENERIC_LDS_MAX
 inline int generic_lines_per_block(int n, int elem_bytes, int want, long long budget = 65536) {

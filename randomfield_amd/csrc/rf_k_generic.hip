@@ -46,6 +46,60 @@ __global__ __launch_bounds__(256) void generic_row_r2c_kernel(const T* __restric
                            (int)threadIdx.x, (int)blockDim.x, BlockSync());
 }
 
+// lines with sub-lines (the two steps of the four-step transform of an axis too long for the LDS: rf_generic.h GenericLines)
+template <typename T>
+__global__ __launch_bounds__(256) void generic_lines_kernel(const cplx<T>* src, cplx<T>* dst, GenericLines L, int TC, const cplx<T>* __restrict__ root) {
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  generic_lines_block<T>(src, dst, L, TC, root, reinterpret_cast<cplx<T>*>(lds_raw), (long long)blockIdx.x, (int)threadIdx.x, (int)blockDim.x, BlockSync());
+}
+template <typename T>
+__global__ __launch_bounds__(256) void generic_untangle_kernel(const cplx<T>* __restrict__ G, cplx<T>* __restrict__ Z, int M, long long total,
+                                                              const cplx<T>* __restrict__ root) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) generic_untangle_at<T>(G, Z, M, root, i);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void generic_tangle_kernel(const cplx<T>* __restrict__ Z, cplx<T>* __restrict__ G, int M, long long total,
+                                                            const cplx<T>* __restrict__ root) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) generic_tangle_at<T>(Z, G, M, root, i);
+}
+// (sum, sum of squares) of n reals: block b leaves its share in partials[2b], partials[2b + 1] (fixed order inside a block: deterministic)
+template <typename T>
+__global__ __launch_bounds__(256) void generic_moments_kernel(const T* __restrict__ W, long long n, double* __restrict__ partials) {
+  __shared__ double red[2 * 4];
+  double s1 = 0.0, s2 = 0.0;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const double v = (double)W[i];
+    s1 += v; s2 += v * v;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_down(s1, off); s2 += __shfl_down(s2, off); }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) { red[2 * wave] = s1; red[2 * wave + 1] = s2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0.0, b = 0.0;
+    for (int w = 0; w < 4; ++w) { a += red[2 * w]; b += red[2 * w + 1]; }
+    partials[2 * (long long)blockIdx.x] = a;
+    partials[2 * (long long)blockIdx.x + 1] = b;
+  }
+}
+
+template <typename T>
+hipError_t lines_t(const void* src, void* dst, const GenericLines& L, const void* root, hipStream_t s) {
+  // sub-lines whose parents are neighbours in memory (inner > 1) go 16 to a block, as in axis_t
+  const int tc = generic_lines_per_block(L.ax.n, (int)sizeof(cplx<T>), L.inner_s > 1 ? 16 : 4);
+  const long long nblk = (L.nlines() + tc - 1) / tc;
+  if (nblk <= 0) return hipSuccess;
+  if (nblk > 0x7fffffffLL || L.nparent <= 0 || L.nsub <= 0) return hipErrorInvalidValue;
+  const size_t lds = 2 * (size_t)L.ax.n * tc * sizeof(cplx<T>);
+  if (lds > (size_t)GENERIC_LDS_MAX) return hipErrorInvalidValue;
+  static LdsAttrLatch latch;
+  if (lds > 65536)
+    if (hipError_t e = latch.ensure((const void*)generic_lines_kernel<T>, GENERIC_LDS_MAX); e != hipSuccess) return e;
+  hipLaunchKernelGGL(generic_lines_kernel<T>, dim3((unsigned)nblk), dim3(256), lds, s, (const cplx<T>*)src, (cplx<T>*)dst, L, tc, (const cplx<T>*)root);
+  return hipGetLastError();
+}
+
 template <typename T>
 hipError_t axis_t(const void* src, void* dst, const GenericAxis& ax, long long stride, long long inner, long long outer,
                   long long nlines, const void* root, int sign, double scale, hipStream_t s) {
@@ -72,6 +126,30 @@ hipError_t launch_generic_axis(int f64, const void* src, void* dst, const Generi
                                long long outer, long long nlines, const void* root, int sign, double scale, hipStream_t s) {
   return f64 ? axis_t<double>(src, dst, ax, stride, inner, outer, nlines, root, sign, scale, s)
              : axis_t<float>(src, dst, ax, stride, inner, outer, nlines, root, sign, scale, s);
+}
+
+hipError_t launch_generic_lines(int f64, const void* src, void* dst, const GenericLines& L, const void* root, hipStream_t s) {
+  return f64 ? lines_t<double>(src, dst, L, root, s) : lines_t<float>(src, dst, L, root, s);
+}
+hipError_t launch_generic_untangle(int f64, const void* G, void* Z, int M, long long nrows, const void* root, hipStream_t s) {
+  const long long total = nrows * M;
+  const unsigned grid = (unsigned)(total / 256 + 1 < 65536 ? total / 256 + 1 : 65536);
+  if (f64) hipLaunchKernelGGL(generic_untangle_kernel<double>, dim3(grid), dim3(256), 0, s, (const cplx<double>*)G, (cplx<double>*)Z, M, total, (const cplx<double>*)root);
+  else hipLaunchKernelGGL(generic_untangle_kernel<float>, dim3(grid), dim3(256), 0, s, (const cplx<float>*)G, (cplx<float>*)Z, M, total, (const cplx<float>*)root);
+  return hipGetLastError();
+}
+hipError_t launch_generic_tangle(int f64, const void* Z, void* G, int M, long long nrows, const void* root, hipStream_t s) {
+  const long long total = nrows * (M + 1);
+  const unsigned grid = (unsigned)(total / 256 + 1 < 65536 ? total / 256 + 1 : 65536);
+  if (f64) hipLaunchKernelGGL(generic_tangle_kernel<double>, dim3(grid), dim3(256), 0, s, (const cplx<double>*)Z, (cplx<double>*)G, M, total, (const cplx<double>*)root);
+  else hipLaunchKernelGGL(generic_tangle_kernel<float>, dim3(grid), dim3(256), 0, s, (const cplx<float>*)Z, (cplx<float>*)G, M, total, (const cplx<float>*)root);
+  return hipGetLastError();
+}
+hipError_t launch_generic_moments(int f64, const void* W, long long n, double* partials, long long nblocks, hipStream_t s) {
+  if (nblocks < 1 || nblocks > 0x7fffffffLL) return hipErrorInvalidValue;
+  if (f64) hipLaunchKernelGGL(generic_moments_kernel<double>, dim3((unsigned)nblocks), dim3(256), 0, s, (const double*)W, n, partials);
+  else hipLaunchKernelGGL(generic_moments_kernel<float>, dim3((unsigned)nblocks), dim3(256), 0, s, (const float*)W, n, partials);
+  return hipGetLastError();
 }
 
 long long generic_row_blocks(int f64, int M, long long nrows) {

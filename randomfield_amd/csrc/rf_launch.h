@@ -169,6 +169,12 @@ hipError_t launch_mt_share_widen(const void* recv, double* noise, long long npai
 // complex pass along one axis: line l starts at (l / inner) * outer + l % inner, elements `stride` apart; src == dst allowed
 hipError_t launch_generic_axis(int f64, const void* src, void* dst, const GenericAxis& ax, long long stride, long long inner,
                                long long outer, long long nlines, const void* root, int sign, double scale, hipStream_t s);
+// axes too long for the LDS (rf_generic.h GenericLong): one step of the four-step transform (lines with sub-lines); the Hermitian
+// (un)tangle of long rows as passes of their own; (sum, sum of squares) of a real array into nblocks partial pairs
+hipError_t launch_generic_lines(int f64, const void* src, void* dst, const GenericLines& L, const void* root, hipStream_t s);
+hipError_t launch_generic_untangle(int f64, const void* G, void* Z, int M, long long nrows, const void* root, hipStream_t s);
+hipError_t launch_generic_tangle(int f64, const void* Z, void* G, int M, long long nrows, const void* root, hipStream_t s);
+hipError_t launch_generic_moments(int f64, const void* W, long long n, double* partials, long long nblocks, hipStream_t s);
 // rows of nz/2+1 half-spectrum bins (G) <-> dense rows of nz reals (W); ax factors nz/2, root_nz has nz entries;
 // the c2r pass leaves (sum, sumsq) of block b in partials[2b], partials[2b+1]
 long long generic_row_blocks(int f64, int M, long long nrows);

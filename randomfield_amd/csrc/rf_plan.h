@@ -201,8 +201,10 @@ struct rf_plan {
   // non-power-of-two grid (rf_generic.h): the transforms run on API-layout arrays, K -> G -> W; no fused generation,
   // no graphs, one rank.  gax / gay factor nx / ny, gaz factors nz/2 (packed plans) or nz (c2c plans)
   bool generic = false;
-  void* G = nullptr;                   // lazy scratch [nx][ny][nz/2+1] complex
+  void* G = nullptr;                   // lazy scratch [nx][ny][nz/2+1] complex (c2c plans: [nx][ny][nz], for a long axis)
+  void* G2 = nullptr;                  // lazy second scratch: only when an axis is too long for one line (four-step form, rf_generic.h)
   rf::GenericAxis gax, gay, gaz;
+  rf::GenericDims gdims;               // the same + the split of the long axes, as the sequences of rf_generic.h take them
   bool timed = false;
   struct BatchGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };
   std::map<int, BatchGraph> graphs;       // captured batch graphs, keyed by the number of realisations

@@ -18,7 +18,7 @@ Backends.  The reference switches between pyFFTW and ``numpy.fft`` on the
   ``RuntimeError`` -- it never silently computes on the CPU.
 * ``backend='numpy'`` (explicit opt-in; or ``RANDOMFIELD_BACKEND=numpy``): the
   reference's own ``numpy.fft`` fallback, kept for hosts without a GPU and for shapes
-  the HIP kernels do not cover (an axis longer than 8192, or 4096 for complex128).  Power-of-two axes run on
+  the HIP kernels do not cover (an odd axis; an axis beyond 8192 points -- 4096 for complex128 -- with no two factors that fit).  Power-of-two axes run on
   the tiled kernels; any other even shape -- the reference's own test shapes (4, 6, 8)
   and (40, 60, 80) among them -- on the generic mixed-radix kernels.
 
@@ -274,13 +274,13 @@ class Plan(object):
             cdtype = lay.dtype_in if (inverse or not packed) else lay.dtype_out
             if np.dtype(cdtype) not in (np.dtype(np.complex64), np.dtype(np.complex128)):
                 raise RuntimeError("hip backend supports complex64 / complex128 only: {0}.".format(cdtype))
-            # power-of-two axes (8..2048; nz from 16) run on the tiled kernels, any other even shape with axes up to
-            # 8192 (complex64) / 4096 (complex128) on the generic mixed-radix kernels (csrc/rf_generic.h: a whole line
-            # of the axis in LDS); the library decides and refuses the rest
-            cap = 8192 if np.dtype(cdtype) == np.dtype(np.complex64) else 4096
-            if max(nx, ny, nz) > cap or (packed and not _hip.shape_supported(nx, ny, nz)):
+            # power-of-two axes (8..2048; nz from 16) run on the tiled kernels, any other even shape on the generic mixed-radix
+            # kernels (csrc/rf_generic.h): an axis of up to 8192 (complex64) / 4096 (complex128) points as one line in LDS, a longer
+            # one as two passes over factors that fit; the library decides and refuses the rest
+            if packed and not _hip.shape_supported(nx, ny, nz, cdtype):
                 raise RuntimeError(
-                    "hip backend: shape {0} is not supported (even axes up to 8192 for complex64, 4096 for complex128); "
+                    "hip backend: shape {0} is not supported (even axes that fit one line of the LDS -- 8192 points for complex64, "
+                    "4096 for complex128 -- or split into two factors that do); "
                     "use backend='numpy' explicitly for this shape.".format(tuple(shape)))
             # a reverse plan that shares our memory also shares our device plan (one device buffer, as the
             # reference's pair of plans shares one host buffer)

@@ -89,12 +89,14 @@ def test_shape_support_query_needs_no_gpu():
     assert lib.rf_shape_supported(4, 6, 8) == 2 and lib.rf_shape_supported(40, 60, 80) == 2
     assert lib.rf_shape_supported(16, 16, 18) == 2 and lib.rf_shape_supported(8, 8, 8) == 2
     assert lib.rf_shape_supported(4096, 16, 16) == 2 and lib.rf_shape_supported(8, 6000, 8192) == 2
-    assert not _hip.shape_supported(16384, 16, 16) and not _hip.shape_supported(5, 6, 8) and not _hip.shape_supported(4, 6, 7)
-    # the dtype-aware query is what rf_plan_create accepts: complex128 plans stop at 4096 on the generic path
-    assert lib.rf_shape_supported_dtype(8, 6000, 8192, _hip.RF_F32) == 2 and lib.rf_shape_supported_dtype(8, 6000, 8192, _hip.RF_F64) == 0
+    assert not _hip.shape_supported(16418, 16, 16) and not _hip.shape_supported(5, 6, 8) and not _hip.shape_supported(4, 6, 7)     # 16418 = 2 x 8209 (prime)
+    # longer axes split into two factors that each fit one line (the four-step form, rf_generic.h generic_split)
+    assert lib.rf_shape_supported(16384, 16, 16) == 2 and lib.rf_shape_supported(4, 6, 2 * 12000) == 2
+    # the dtype-aware query is what rf_plan_create accepts: a complex128 line holds 4096 points, so 2 x 6000 x 8192 ... nz / 2 = 4096 fits, 8192-point y lines split
+    assert lib.rf_shape_supported_dtype(8, 6000, 8192, _hip.RF_F32) == 2 and lib.rf_shape_supported_dtype(8, 8198, 8, _hip.RF_F64) == 0      # 8198 = 2 x 4099 (prime)
     assert lib.rf_shape_supported_dtype(4096, 4, 8, _hip.RF_F64) == 2 and lib.rf_shape_supported_dtype(1024, 1024, 1024, _hip.RF_F64) == 1
     assert lib.rf_shape_supported_dtype(16, 16, 16, 7) == 0
-    assert _hip.shape_supported(4096, 16, 16, np.complex128) and not _hip.shape_supported(8192, 16, 16, np.complex128)
+    assert _hip.shape_supported(4096, 16, 16, np.complex128) and _hip.shape_supported(8192, 16, 16, np.complex128) and not _hip.shape_supported(8198, 16, 16, np.complex128)
     assert _hip.shape_supported(8192, 16, 16, np.complex64)
 
 

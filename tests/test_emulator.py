@@ -465,3 +465,32 @@ def test_sigma_share_row_mapping_is_a_bijection(L, S):
                     assert partner == L - 1 - q
                 else:
                     assert partner == (L // 2 if q == 0 else L - q)
+
+
+@pytest.mark.parametrize("shape,cap", [((40, 60, 80), 16), ((36, 10, 24), 8), ((6, 100, 16), 12), ((4, 6, 192), 16), ((64, 8, 16), 8), ((8, 8, 128), 16)])
+def test_axes_too_long_for_one_line_take_the_four_step_form(shape, cap):
+    """Axes longer than a line the LDS holds (the library's cap: 8192 complex64 / 4096 complex128; lowered here so that small grids
+    qualify) run as a four-step transform through global memory -- n = n1 n2: sub-line transforms of length n1, twiddles on load,
+    sub-line transforms of length n2 stored in natural order -- with the SAME sequences and block functions as the library
+    (rf_generic.h generic_*_seq, generic_lines_block, generic_untangle_at / generic_tangle_at): c2r = np.fft.irfftn, r2c = rfftn,
+    c2c = fftn / ifftn, every axis long in turn, with line counts that do not divide the block sizes."""
+    rng = np.random.RandomState(7)
+    nx, ny, nz = shape
+    old = emu_util.lib().emu_set_generic_cap(cap)
+    try:
+        for ct, rt, tol in ((np.complex64, np.float32, 4e-6), (np.complex128, np.float64, 4e-14)):
+            ks = (rng.normal(size=(nx, ny, nz // 2 + 1)) + 1j * rng.normal(size=(nx, ny, nz // 2 + 1))).astype(ct)
+            out, s1, s2 = emu_util.generic_c2r(ks)
+            ref = np.fft.irfftn(ks.astype(np.complex128), s=shape, axes=(0, 1, 2))
+            assert np.max(np.abs(out - ref)) <= tol * ref.std()
+            assert abs(s1 - ref.sum()) <= 10 * tol * ref.std() * ref.size and abs(s2 - (ref ** 2).sum()) <= 10 * tol * (ref ** 2).sum()
+            f = rng.normal(size=shape).astype(rt)
+            spec = emu_util.generic_r2c(f)
+            ref = np.fft.rfftn(f.astype(np.float64))
+            assert np.max(np.abs(spec - ref)) <= tol * np.abs(ref).std() * 4
+            a = (rng.normal(size=shape) + 1j * rng.normal(size=shape)).astype(ct)
+            for inverse, fn in ((False, np.fft.fftn), (True, np.fft.ifftn)):
+                ref = fn(a.astype(np.complex128))
+                assert np.max(np.abs(emu_util.generic_c2c(a, inverse) - ref)) <= tol * np.abs(ref).std() * 4
+    finally:
+        emu_util.lib().emu_set_generic_cap(old)

@@ -442,9 +442,9 @@ def test_errors_are_loud(hip, dpower):
     with pytest.raises(RuntimeError):
         hip.DevicePlan(4, 6, 7)                                      # unsupported shape (odd axis): no silent CPU path
     with pytest.raises(RuntimeError):
-        hip.DevicePlan(16384, 16, 16)                                # axis longer than any kernel covers
+        hip.DevicePlan(16418, 16, 16)                                # 2 x 8209 (prime): neither one line of the LDS nor two factors that fit
     with pytest.raises(RuntimeError):
-        hip.DevicePlan(8192, 16, 16, np.complex128)                  # (complex128 lines: up to 4096)
+        hip.DevicePlan(8198, 16, 16, np.complex128)                  # (complex128 lines: up to 4096 points; 8198 = 2 x 4099)
     plan = hip.DevicePlan(16, 16, 16)
     with pytest.raises(RuntimeError):
         plan.realise(seed=1)                                         # tables not set
@@ -457,7 +457,7 @@ def test_errors_are_loud(hip, dpower):
     plan.close()
     from randomfield_amd.transform import Plan
     with pytest.raises(RuntimeError):
-        Plan(shape=(16384, 16, 16), dtype_in=np.complex64)           # hip backend refuses, does not fall back
+        Plan(shape=(16418, 16, 16), dtype_in=np.complex64)           # hip backend refuses, does not fall back
 
 
 def _virtual_rank_field(hip, shape, dtype, k, Pk, nranks, seed=None, noise=None, exact=False):
@@ -741,9 +741,9 @@ def test_unpacked_c2c_plan_against_numpy(hip, shape):
     src = small.data_in.copy()
     assert np.max(np.abs(small.execute() - np.fft.ifftn(src.astype(np.complex128)))) <= 1e-6
     with pytest.raises(RuntimeError):
-        transform.Plan((8, 8, 16384), dtype_in=np.complex64, packed=False, backend="hip")   # nz beyond every kernel
+        transform.Plan((8, 8, 16418), dtype_in=np.complex64, packed=False, backend="hip")   # nz = 2 x 8209 (prime): beyond every kernel
     with pytest.raises(RuntimeError):
-        transform.Plan((8, 8, 8192), dtype_in=np.complex128, packed=False, backend="hip")   # (complex128: 4096)
+        transform.Plan((8, 8, 8198), dtype_in=np.complex128, packed=False, backend="hip")   # (complex128 lines hold 4096 points; 8198 = 2 x 4099)
 
 
 @pytest.mark.parametrize("shape", [(8, 8, 16), (16, 8, 64), (8, 16, 256), (4 * 2, 8, 2048), (8, 8, 512), (8, 8, 1024)])
@@ -1458,11 +1458,16 @@ def test_generic_shape_plans(hip):
 
 
 @pytest.mark.parametrize("shape,ct", [((4096, 8, 16), np.complex64), ((8, 8192, 12), np.complex64), ((6, 8, 8192), np.complex64),
-                                      ((12, 6000, 8), np.complex64), ((4096, 4, 8), np.complex128), ((4, 6, 4096), np.complex128)])
+                                      ((12, 6000, 8), np.complex64), ((4096, 4, 8), np.complex128), ((4, 6, 4096), np.complex128),
+                                      # one axis too long for a line of the LDS: the four-step form (two passes of sub-lines)
+                                      ((16384, 4, 8), np.complex64), ((4, 24000, 8), np.complex64), ((4, 6, 40000), np.complex64),
+                                      ((6, 4, 32768), np.complex64), ((8192, 4, 8), np.complex128), ((4, 10000, 8), np.complex128),
+                                      ((4, 6, 16384), np.complex128), ((4100, 2, 8200), np.complex128)])      # (the last: two long axes at once)
 def test_axes_longer_than_2048(hip, dpower, shape, ct):
     """transform.py:172-177 accepts any even shape.  Axes beyond the tiled kernels' 2048 run on the generic mixed-radix kernels with
-    the whole line in LDS: up to 8192 complex64 / 4096 complex128 per axis (rf_generic.h).  Packed c2r against numpy's irfftn, the
-    r2c reverse plan, unpacked c2c both ways, and a Generator field against the oracle's realisation of the same deviates."""
+    the whole line in LDS: up to 8192 complex64 / 4096 complex128 points; longer axes as two passes over factors that fit (the
+    four-step form, rf_generic.h).  Packed c2r against numpy's irfftn, the r2c reverse plan, unpacked c2c both ways, and a
+    Generator field against the oracle's realisation of the same deviates."""
     from randomfield_amd.transform import Plan
     from randomfield_amd import Generator
     rng = np.random.RandomState(17)
@@ -1488,10 +1493,11 @@ def test_axes_longer_than_2048(hip, dpower, shape, ct):
         assert np.max(np.abs(c.execute() - ref)) <= 20 * tol * np.abs(ref).std()
         c.device.close()
     k, Pk = dpower                                   # (the shipped default power: what Generator() loads)
-    gen = Generator(nx, ny, nz, SPACING, backend="hip")
+    spacing = SPACING if max(shape) <= 16384 else 1.0          # (the default power table starts at k = 1e-4: longer boxes need smaller cells)
+    gen = Generator(nx, ny, nz, spacing, backend="hip")
     if ct == np.complex64:
         delta = gen.generate_delta_field(seed=4, save_potential=False)
-        want, rms = cpu_ref.generate_delta_field(nx, ny, nz, SPACING, k, Pk, seed=4, double_fft=True)
+        want, rms = cpu_ref.generate_delta_field(nx, ny, nz, spacing, k, Pk, seed=4, double_fft=True)
         assert delta.shape == shape and np.max(np.abs(delta - want)) <= TOL_F32 * rms
         assert abs(float(gen.delta_field_rms) - rms) <= TOL_F32 * rms
         gen.plan_c2r.device.close()
