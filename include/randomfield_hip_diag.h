@@ -69,6 +69,14 @@ int rf_slab_set_exchange_standin_ex(rf_plan* plan, int workgroups, int read_perc
  * stores into the receive buffers of the others -- plain device pointers here, IPC mappings on a real job -- and rf_slab_exchange_local
  * is not called at all: forward on every rank, then backward on every rank.  enable = 0 unlinks.  Same fields, bit for bit. */
 int rf_slab_link_direct(rf_plan** plans, int n, int enable);
+/* The same hand-off between ranks that live in DIFFERENT processes and have no communicator, the transport left to the caller (the
+ * two-process test on one GPU; a host with its own rendezvous): export writes this rank's record (two IPC handles + a flag; all zero when
+ * the plan cannot take part), import takes the records of all ranks in rank order, maps the peers' buffers and switches the storing y
+ * pass on (*enabled = 0 and nothing mapped when any record says no).  The barrier between the storing y pass and the z pass is the
+ * caller's: rf_slab_forward, rf_sync, barrier, rf_slab_backward. */
+#define RF_DIRECT_RECORD_BYTES 192
+int rf_slab_direct_export(rf_plan* plan, void* record, int nbytes);
+int rf_slab_direct_import(rf_plan* plan, const void* records, int nranks, int* enabled);
 /* ONE virtual rank through the schedule of the direct exchange (the counterpart of rf_slab_set_exchange_standin): rf_realise /
  * rf_realise_batch run x pass, storing y pass, gathering z pass with the stores of block h going to segment h of the rank's OWN
  * receive buffers -- pattern and volume of the real stores, without the links; the result is not a field (rf_download_real refuses).

@@ -18,6 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librandomfield_hip.so")
 
 RF_F32, RF_F64 = 0, 1
+DIRECT_RECORD_BYTES = 192                 # RF_DIRECT_RECORD_BYTES (randomfield_hip_diag.h)
 NOISE_NATIVE, NOISE_EXTERNAL, NOISE_RESIDENT = 0, 1, 2
 LAYOUT_DENSE, LAYOUT_PADDED = 0, 1
 
@@ -120,6 +121,8 @@ DIAG_SIGNATURES = {
     "rf_slab_set_exchange_standin_ex": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "rf_slab_link_direct": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int]),
     "rf_slab_set_direct_standin": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
+    "rf_slab_direct_export": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
+    "rf_slab_direct_import": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
 }
 
 _lib = None
@@ -721,6 +724,24 @@ class DevicePlan(object):
         plan then stores into the others' receive buffers and ``slab_exchange_local`` is not called."""
         arr = (ctypes.c_void_p * len(plans))(*[p._h.value for p in plans])
         check(load().rf_slab_link_direct(arr, len(plans), 1 if on else 0), "rf_slab_link_direct")
+
+    def slab_direct_export(self):
+        """Diagnostics: this rank's record for the direct exchange between processes without a communicator (two IPC handles + a
+        flag, rf_slab_direct_export) -- bytes to hand to every other rank by whatever transport the caller has."""
+        buf = (ctypes.c_ubyte * DIRECT_RECORD_BYTES)()
+        check(self._lib.rf_slab_direct_export(self._h, buf, DIRECT_RECORD_BYTES), "rf_slab_direct_export")
+        return bytes(buf)
+
+    def slab_direct_import(self, records):
+        """Diagnostics: map the receive buffers named by the records of ALL ranks (rank order) and switch the storing y pass on
+        (rf_slab_direct_import); False when some rank cannot take part.  The barrier between ``slab_forward`` and
+        ``slab_backward`` is the caller's (``sync()`` + its own barrier)."""
+        blob = b"".join(records)
+        if len(blob) != DIRECT_RECORD_BYTES * len(records):
+            raise ValueError("every record is {0} bytes".format(DIRECT_RECORD_BYTES))
+        on = ctypes.c_int(0)
+        check(self._lib.rf_slab_direct_import(self._h, blob, len(records), ctypes.byref(on)), "rf_slab_direct_import")
+        return bool(on.value)
 
     def set_direct_standin(self, on=True, overlap=True):
         """Diagnostics: one virtual rank through the schedule of the direct exchange, its stores landing in its own receive

@@ -174,6 +174,39 @@ int direct_reset(rf_plan* p) {
 bool direct_shape_ok(const rf_plan* p) {
   return !p->unpacked && !p->generic && col_direct_supported(p->f64, p->ny, p->nzl / slab_chunks(p));
 }
+// What a rank tells the others about its two receive buffers: [2 IPC handles][ok flag], RF_DIRECT_RECORD_BYTES per rank
+constexpr size_t DIRECT_REC = 192;
+static_assert(2 * sizeof(hipIpcMemHandle_t) + 8 <= DIRECT_REC, "record too small for two IPC handles");
+// this rank's record (all zero = "not here": shape without a storing y pass, no buffers, no handles)
+bool direct_fill_record(rf_plan* p, unsigned char* mine) {
+  memset(mine, 0, DIRECT_REC);
+  if (!(direct_shape_ok(p) && !p->replicate) || ensure_batch_buffers(p) != 0) return false;
+  hipIpcMemHandle_t hd[2];
+  if (hipIpcGetMemHandle(&hd[0], p->R) != hipSuccess || hipIpcGetMemHandle(&hd[1], p->R2) != hipSuccess) { (void)hipGetLastError(); return false; }
+  memcpy(mine, hd, sizeof(hd));
+  mine[2 * sizeof(hipIpcMemHandle_t)] = 1;
+  return true;
+}
+// map the two buffers of every peer named in rec[P][DIRECT_REC]; false (and nothing left mapped beyond p->ipc_open, which direct_reset closes) on any failure
+bool direct_map_peers(rf_plan* p, const unsigned char* rec, std::vector<void*>& R0, std::vector<void*>& R1) {
+  const int P = p->nranks;
+  for (int h = 0; h < P; ++h)
+    if (rec[DIRECT_REC * h + 2 * sizeof(hipIpcMemHandle_t)] != 1) return false;
+  R0.assign(P, nullptr); R1.assign(P, nullptr);
+  R0[p->rank] = p->R; R1[p->rank] = p->R2;
+  for (int h = 0; h < P; ++h) {
+    if (h == p->rank) continue;
+    hipIpcMemHandle_t ph[2];
+    memcpy(ph, rec + DIRECT_REC * h, sizeof(ph));
+    for (int b = 0; b < 2; ++b) {
+      void* m = nullptr;
+      if (hipIpcOpenMemHandle(&m, ph[b], hipIpcMemLazyEnablePeerAccess) != hipSuccess || !m) { (void)hipGetLastError(); return false; }
+      p->ipc_open.push_back(m);
+      (b ? R1 : R0)[h] = m;
+    }
+  }
+  return true;
+}
 // min over the communicator's ranks of a flag (1 = fine here), on the plan's stream
 int agree(rf_plan* p, bool mine, bool* all) {
   double v[2] = {mine ? 1.0 : 0.0, 0.0};
@@ -212,14 +245,11 @@ int rf_comm_enable_direct(rf_plan* p, int enable, int* enabled) {
     p->direct = true; *enabled = 1;
     return 0;
   }
-  // 1. handles of R and R2, gathered from every rank: [P][2 handles + ok flag], 192 bytes per rank
-  constexpr size_t REC = 192;
-  static_assert(2 * sizeof(hipIpcMemHandle_t) + 8 <= REC, "record too small for two IPC handles");
+  // 1. handles of R and R2, gathered from every rank
+  constexpr size_t REC = DIRECT_REC;
   std::vector<unsigned char> rec(REC * P, 0);
   unsigned char* mine = rec.data() + REC * p->rank;
-  hipIpcMemHandle_t hd[2];
-  if (ok && (hipIpcGetMemHandle(&hd[0], p->R) != hipSuccess || hipIpcGetMemHandle(&hd[1], p->R2) != hipSuccess)) { ok = false; (void)hipGetLastError(); }
-  if (ok) { memcpy(mine, hd, sizeof(hd)); mine[2 * sizeof(hipIpcMemHandle_t)] = 1; }
+  ok = ok && direct_fill_record(p, mine);
   unsigned char* dev = nullptr;
   RF_HIP(hipMalloc((void**)&dev, REC * P));
   auto done = [&](int rc) { (void)hipFree(dev); return rc; };
@@ -227,23 +257,9 @@ int rf_comm_enable_direct(rf_plan* p, int enable, int* enabled) {
   if (g_rccl.AllGather(dev + REC * p->rank, dev, REC, ncclUint8, p->comm, p->stream) != ncclSuccess) return done(fail(5, "ncclAllGather of the IPC handles failed"));
   if (hipMemcpyAsync(rec.data(), dev, REC * P, hipMemcpyDeviceToHost, p->stream) != hipSuccess || hipStreamSynchronize(p->stream) != hipSuccess)
     return done(fail(2, "reading back the gathered IPC handles failed"));
-  for (int h = 0; h < P; ++h) ok = ok && rec[REC * h + 2 * sizeof(hipIpcMemHandle_t)] == 1;
   // 2. map the peers' buffers
-  std::vector<void*> R0(P, nullptr), R1(P, nullptr);
-  if (ok) {
-    R0[p->rank] = p->R; R1[p->rank] = p->R2;
-    for (int h = 0; h < P && ok; ++h) {
-      if (h == p->rank) continue;
-      hipIpcMemHandle_t ph[2];
-      memcpy(ph, rec.data() + REC * h, sizeof(ph));
-      for (int b = 0; b < 2 && ok; ++b) {
-        void* m = nullptr;
-        if (hipIpcOpenMemHandle(&m, ph[b], hipIpcMemLazyEnablePeerAccess) != hipSuccess || !m) { ok = false; (void)hipGetLastError(); break; }
-        p->ipc_open.push_back(m);
-        (b ? R1 : R0)[h] = m;
-      }
-    }
-  }
+  std::vector<void*> R0, R1;
+  ok = ok && direct_map_peers(p, rec.data(), R0, R1);
   bool all = false;
   if (int rc = agree(p, ok, &all)) return done(rc);
   if (!all) { (void)hipFree(dev); return direct_reset(p); }
@@ -302,6 +318,37 @@ int rf_slab_link_direct(rf_plan** plans, int n, int enable) {
     p->direct = true;
     p->standin_wg = 0;
   }
+  return 0;
+}
+
+// The IPC hand-off of rf_comm_enable_direct with the TRANSPORT LEFT TO THE CALLER: ranks of one job that live in different processes
+// and have no communicator (a test's two processes on one GPU, a host framework with its own rendezvous).  export: this rank's record
+// (RF_DIRECT_RECORD_BYTES; all zero when the plan cannot take part); import: the records of all ranks, in rank order -- maps the
+// peers' buffers and switches the storing y pass on (*enabled = 0 and nothing mapped when any rank's record says no).  The barriers
+// between the storing y pass and the z pass are the caller's too: rf_slab_forward, rf_sync, the caller's barrier, rf_slab_backward.
+int rf_slab_direct_export(rf_plan* p, void* record, int nbytes) {
+  RF_REQUIRE(p && record, "null argument");
+  RF_REQUIRE(nbytes == (int)DIRECT_REC, "record size: RF_DIRECT_RECORD_BYTES");
+  RF_REQUIRE(!p->unpacked && p->nranks > 1 && p->comm == nullptr, "rf_slab_direct_export applies to a rank of a multi-rank plan without a communicator");
+  RF_HIP(hipSetDevice(p->device));
+  direct_fill_record(p, (unsigned char*)record);
+  return 0;
+}
+int rf_slab_direct_import(rf_plan* p, const void* records, int nranks, int* enabled) {
+  RF_REQUIRE(p && records && enabled, "null argument");
+  *enabled = 0;
+  RF_REQUIRE(!p->unpacked && p->nranks > 1 && p->comm == nullptr && nranks == p->nranks, "rf_slab_direct_import: records of all ranks of this communicator-less plan");
+  RF_HIP(hipSetDevice(p->device));
+  drop_graphs(p);
+  if (int rc = direct_reset(p)) return rc;
+  if (!(direct_shape_ok(p) && !p->replicate) || ensure_batch_buffers(p) != 0) return 0;
+  std::vector<void*> R0, R1;
+  if (!direct_map_peers(p, (const unsigned char*)records, R0, R1)) return direct_reset(p);
+  p->peer_R[0] = R0; p->peer_R[1] = R1;
+  if (int rc = rebuild_peer_tab(p)) { (void)direct_reset(p); return rc; }
+  p->direct = true;
+  p->standin_wg = 0;
+  *enabled = 1;
   return 0;
 }
 

@@ -7,6 +7,8 @@ path to max|d_gpu - d_cpu| <= 1e-5 * rms(d) on the same noise; in practice the
 difference is ~1e-6 * rms (float32 FFT rounding).  k-space cells agree to the
 last ulp of log10f (5e-7 relative).  float64 plans: 1e-12.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -2208,6 +2210,47 @@ def test_direct_exchange_between_virtual_ranks_is_bit_identical(hip, dpower, sha
     assert np.array_equal(_slab_run(hip, plans, seed=11), want["native"])
     for p in plans:
         p.close()
+
+
+@pytest.mark.parametrize("shape,kind,chunks", [((64, 512, 128), "c64", 1), ((32, 1024, 256), "c64", 2), ((32, 16, 128), "c128", 1)])
+def test_direct_exchange_between_processes_through_ipc_handles(hip, dpower, tmp_path, shape, kind, chunks):
+    """The IPC hand-off with REAL processes: two ranks of one job, each a process of its own on this GPU, swap the records of
+    rf_slab_direct_export through files, map each other's receive buffers (hipIpcOpenMemHandle) and run the storing y pass into the
+    other PROCESS's memory (tests/direct_ipc_worker.py).  The assembled field must be, bit for bit and twice in a row, the field of the
+    same two ranks living in one process with the exchange done by device copies.
+    (The transport of the records and the barrier are the caller's here; rf_comm_enable_direct does the same over RCCL, which refuses
+    two ranks on one device.)"""
+    import subprocess
+    import sys
+    k, Pk = dpower
+    nx, ny, nz = shape
+    world = 2
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "direct_ipc_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), str(tmp_path), kind] + [str(v) for v in shape] + [str(chunks)],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    outs = []
+    try:
+        for pr in procs:
+            outs.append(pr.communicate(timeout=400)[0].decode(errors="replace"))
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    assert [pr.returncode for pr in procs] == [0] * world, "\n".join(outs)
+    assert all((tmp_path / "on_{0}".format(r)).read_bytes() == b"1" for r in range(world))
+    got = np.concatenate([np.load(tmp_path / "field_{0}.npy".format(r)) for r in range(world)], axis=1)       # [seed][x][y][z]
+    ct = np.complex64 if kind == "c64" else np.complex128
+    plans = _slab_plans(hip, shape, ct, k, Pk, world)        # the same two ranks as virtual ranks of THIS process, exchange by device copies
+    for p in plans:
+        p.set_exchange_chunks(chunks)
+    for i, seed in enumerate((11, 12)):
+        want = _slab_run(hip, plans, seed=seed)
+        assert want.std() > 0 and np.array_equal(got[i], want), (i, seed)
+    for p in plans:
+        p.close()
+    stats = np.sum([np.frombuffer((tmp_path / "stats_{0}".format(r)).read_bytes(), dtype=np.float64) for r in range(world)], axis=0)
+    last = got[-1].astype(np.float64)                       # the ranks' local (sum, sum of squares) of the last realisation add up to the field's
+    assert abs(stats[0] - last.sum()) <= 1e-6 * np.sqrt(last.size) * last.std() and abs(stats[1] - (last ** 2).sum()) <= 1e-9 * (last ** 2).sum()
 
 
 def test_direct_exchange_on_one_rank_through_the_whole_call_paths(hip, dpower):
