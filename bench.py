@@ -387,7 +387,8 @@ def main_multi(args, rank, world, local_rank, shape, power, spacing):
             if not set_mode(m):
                 rejected[m] = "not available for this job (shape, or a rank could not map its peers' receive buffers)"
                 continue
-            r = trial(m, rms_rccl)
+            with dplan.deadline("calibration of the %s mode" % m):      # (a hang names its mode and ends the job instead of blocking until the driver's limit)
+                r = trial(m, rms_rccl)
             if m == "rccl":
                 rms_rccl = r
         mode = min(calib, key=calib.get)

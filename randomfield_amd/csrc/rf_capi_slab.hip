@@ -174,9 +174,9 @@ int direct_reset(rf_plan* p) {
 bool direct_shape_ok(const rf_plan* p) {
   return !p->unpacked && !p->generic && col_direct_supported(p->f64, p->ny, p->nzl / slab_chunks(p));
 }
-// What a rank tells the others about its two receive buffers: [2 IPC handles][ok flag], RF_DIRECT_RECORD_BYTES per rank
+// What a rank tells the others about its two receive buffers: [2 IPC handles][ok flag, 8 bytes][PCI bus id of its device, 32 bytes], RF_DIRECT_RECORD_BYTES per rank
 constexpr size_t DIRECT_REC = 192;
-static_assert(2 * sizeof(hipIpcMemHandle_t) + 8 <= DIRECT_REC, "record too small for two IPC handles");
+static_assert(2 * sizeof(hipIpcMemHandle_t) + 8 + 32 <= DIRECT_REC, "record too small for two IPC handles, the flag and the PCI bus id");
 // this rank's record (all zero = "not here": shape without a storing y pass, no buffers, no handles)
 bool direct_fill_record(rf_plan* p, unsigned char* mine) {
   memset(mine, 0, DIRECT_REC);
@@ -185,6 +185,9 @@ bool direct_fill_record(rf_plan* p, unsigned char* mine) {
   if (hipIpcGetMemHandle(&hd[0], p->R) != hipSuccess || hipIpcGetMemHandle(&hd[1], p->R2) != hipSuccess) { (void)hipGetLastError(); return false; }
   memcpy(mine, hd, sizeof(hd));
   mine[2 * sizeof(hipIpcMemHandle_t)] = 1;
+  // where the buffers live, so that a peer can ask the runtime BEFORE it maps them whether its device reaches this one at all
+  char* bus = (char*)mine + 2 * sizeof(hipIpcMemHandle_t) + 8;
+  if (hipDeviceGetPCIBusId(bus, 32, p->device) != hipSuccess) { (void)hipGetLastError(); bus[0] = 0; }
   return true;
 }
 // map the two buffers of every peer named in rec[P][DIRECT_REC]; false (and nothing left mapped beyond p->ipc_open, which direct_reset closes) on any failure
@@ -198,6 +201,17 @@ bool direct_map_peers(rf_plan* p, const unsigned char* rec, std::vector<void*>& 
     if (h == p->rank) continue;
     hipIpcMemHandle_t ph[2];
     memcpy(ph, rec + DIRECT_REC * h, sizeof(ph));
+    // a peer on another device this process can see: no peer access between the two, no direct exchange (a store through such a
+    // mapping would fault, not fail).  A device this process cannot see (masked by HIP_VISIBLE_DEVICES) is left to hipIpcOpenMemHandle.
+    char bus[32];
+    memcpy(bus, rec + DIRECT_REC * h + 2 * sizeof(hipIpcMemHandle_t) + 8, sizeof(bus));
+    bus[31] = 0;
+    int pdev = -1, can = 0;
+    if (bus[0] && hipDeviceGetByPCIBusId(&pdev, bus) == hipSuccess && pdev >= 0 && pdev != p->device) {
+      if (hipDeviceCanAccessPeer(&can, p->device, pdev) != hipSuccess || !can) { (void)hipGetLastError(); return false; }
+    } else {
+      (void)hipGetLastError();
+    }
     for (int b = 0; b < 2; ++b) {
       void* m = nullptr;
       if (hipIpcOpenMemHandle(&m, ph[b], hipIpcMemLazyEnablePeerAccess) != hipSuccess || !m) { (void)hipGetLastError(); return false; }
