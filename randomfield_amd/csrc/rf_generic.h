@@ -43,31 +43,156 @@ inline bool generic_factor(int n, GenericAxis& ax) {
   return ax.nf <= GENERIC_MAX_FACTORS;
 }
 
+// Division by a run-time constant that is the same for all threads: q = (a * m) >> 32 with m = floor(2^32 / d) + 1 is exact whenever
+// a * d < 2^32 (the error term a * (m d - 2^32) / (d 2^32) stays below 1 / d).  Here a < n * TC <= 2^17 and d <= 2^13.  A 32-bit
+// integer division costs ~40 instructions on this hardware, and the loops below need three to five per element.
+struct FastDiv {
+  uint32_t d, m;
+  RF_HD explicit FastDiv(uint32_t dd) : d(dd), m(dd > 1 ? (uint32_t)(0x100000000ull / dd) + 1u : 0u) {}
+  RF_HD uint32_t div(uint32_t a) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return d > 1 ? __umulhi(a, m) : a;
+#else
+    return d > 1 ? (uint32_t)(((uint64_t)a * m) >> 32) : a;
+#endif
+  }
+  RF_HD void divmod(uint32_t a, uint32_t& q, uint32_t& r) const { q = div(a); r = a - q * d; }
+};
+
+// How a block's threads walk the n * TC elements of its LDS image (element e of line c at [e * TC + c]): thread tid takes
+// idx = tid, tid + nth, ...  When nth is a multiple of TC (every kernel launch) a thread stays on ONE line c = tid % TC and its e
+// advances by nth / TC: no division per element; otherwise (the emulator's single thread) c and e come from idx.
+struct GenericWalk {
+  int TC, total, nth, c0, e0, estep;
+  bool fixed;
+  FastDiv dtc;
+  RF_HD GenericWalk(int n, int TC_, int tid, int nth_) : TC(TC_), total(n * TC_), nth(nth_), c0(0), e0(0), estep(0), fixed(nth_ % TC_ == 0), dtc((uint32_t)TC_) {
+    if (fixed) { c0 = tid % TC; e0 = tid / TC; estep = nth / TC; }
+  }
+  RF_HD void at(int idx, int i, int& c, int& e) const {
+    if (fixed) { c = c0; e = e0 + i * estep; }
+    else { uint32_t q, r; dtc.divmod((uint32_t)idx, q, r); c = (int)r; e = (int)q; }
+  }
+};
+
 // One Stockham stage of radix R on TC interleaved lines (element e of line c at [e * TC + c]): output o of a line is
 //   out[o] = sum_r in[j + r n/R] * exp(sign 2 pi i r (k / (Ns R) + u / R)),   o = jhi Ns R + u Ns + k,  j = jhi Ns + k
 // (Ns = product of the radices already applied).  `root` holds exp(+2 pi i t / (n * rstep)), t in [0, n * rstep).
+//
+// Any radix: every OUTPUT is a dot product of length R (R table reads and R LDS reads per element).
 template <typename T>
-RF_HD void generic_stage(const cplx<T>* in, cplx<T>* out, int n, int TC, int R, int Ns, const cplx<T>* root, int rstep,
-                         int sign, int tid, int nth) {
-  const int m = n / R, unit = n / (Ns * R), total = n * TC;
-  for (int idx = tid; idx < total; idx += nth) {
-    const int c = idx % TC, o = idx / TC;
-    const int k = o % Ns, u = (o / Ns) % R, jhi = o / (Ns * R);
-    const int j = jhi * Ns + k;
-    int q = k * unit + u * m;                      // < n / R + n
+RF_HD void generic_stage_any(const cplx<T>* in, cplx<T>* out, int n, int TC, int R, int Ns, const cplx<T>* root, int rstep,
+                             int sign, int tid, int nth) {
+  const int m = n / R, unit = n / (Ns * R);
+  const GenericWalk walk(n, TC, tid, nth);
+  const FastDiv dNs((uint32_t)Ns), dR((uint32_t)R);
+  const T sg = sign < 0 ? (T)-1 : (T)1;
+  int i = 0;
+  for (int idx = tid; idx < walk.total; idx += nth, ++i) {
+    int c, o;
+    walk.at(idx, i, c, o);
+    uint32_t t, k, jhi, u;
+    dNs.divmod((uint32_t)o, t, k);                 // k = o % Ns, t = o / Ns
+    dR.divmod(t, jhi, u);                          // u = t % R,  jhi = t / R
+    const int j = (int)jhi * Ns + (int)k;
+    int q = (int)k * unit + (int)u * m;            // < n / R + n
     if (q >= n) q -= n;
     T sr = (T)0, si = (T)0;
     int ri = 0;
+    const cplx<T>* pin = in + j * TC + c;
+    const int mstep = m * TC;
     for (int r = 0; r < R; ++r) {
-      const cplx<T> v = in[(j + r * m) * TC + c];
+      const cplx<T> v = pin[r * mstep];
       cplx<T> w = root[ri * rstep];
-      if (sign < 0) w.y = -w.y;
+      w.y *= sg;
       sr += v.x * w.x - v.y * w.y;
       si += v.x * w.y + v.y * w.x;
       ri += q;
       if (ri >= n) ri -= n;
     }
     out[o * TC + c] = mk<T>(sr, si);
+  }
+}
+
+// Radices 2, 3, 4, 5 (all but the large prime factors of an axis): one thread per BUTTERFLY -- R inputs, their R - 1 twiddles
+// w^(r k) (one table read each; none in the first stage, where k = 0), the R-point transform in registers, R outputs.  Per element one
+// LDS read, one LDS write and at most one table read, where the form above has R of each.  sg = +1 / -1: the sign of the exponent.
+template <typename T> RF_HD cplx<T> gmul(const cplx<T>& a, const cplx<T>& w, T sg) {
+  const T wy = w.y * sg;
+  return mk<T>(a.x * w.x - a.y * wy, a.x * wy + a.y * w.x);
+}
+template <typename T> RF_HD cplx<T> gadd(const cplx<T>& a, const cplx<T>& b) { return mk<T>(a.x + b.x, a.y + b.y); }
+template <typename T> RF_HD cplx<T> gsub(const cplx<T>& a, const cplx<T>& b) { return mk<T>(a.x - b.x, a.y - b.y); }
+// a + sg * i * b   and   a - sg * i * b
+template <typename T> RF_HD cplx<T> gadd_i(const cplx<T>& a, const cplx<T>& b, T sg) { return mk<T>(a.x - sg * b.y, a.y + sg * b.x); }
+template <typename T> RF_HD cplx<T> gsub_i(const cplx<T>& a, const cplx<T>& b, T sg) { return mk<T>(a.x + sg * b.y, a.y - sg * b.x); }
+
+template <typename T, int R> RF_HD void generic_dft(cplx<T>* y, T sg) {
+  if (R == 2) {
+    const cplx<T> a = y[0], b = y[1];
+    y[0] = gadd(a, b); y[1] = gsub(a, b);
+  } else if (R == 4) {
+    const cplx<T> a = gadd(y[0], y[2]), b = gsub(y[0], y[2]), c = gadd(y[1], y[3]), d = gsub(y[1], y[3]);
+    y[0] = gadd(a, c); y[2] = gsub(a, c);
+    y[1] = gadd_i(b, d, sg); y[3] = gsub_i(b, d, sg);
+  } else if (R == 3) {
+    const T h = (T)0.86602540378443864676;        // sin(2 pi / 3)
+    const cplx<T> t1 = gadd(y[1], y[2]), d = gsub(y[1], y[2]);
+    const cplx<T> t2 = mk<T>(y[0].x - (T)0.5 * t1.x, y[0].y - (T)0.5 * t1.y), t3 = mk<T>(h * d.x, h * d.y);
+    y[0] = gadd(y[0], t1);
+    y[1] = gadd_i(t2, t3, sg); y[2] = gsub_i(t2, t3, sg);
+  } else {                                         // R == 5
+    const T c1 = (T)0.30901699437494742410, c2 = (T)-0.80901699437494742410;       // cos(2 pi / 5), cos(4 pi / 5)
+    const T s1 = (T)0.95105651629515357212, s2 = (T)0.58778525229247312917;        // sin(2 pi / 5), sin(4 pi / 5)
+    const cplx<T> a1 = gadd(y[1], y[4]), a2 = gadd(y[2], y[3]), b1 = gsub(y[1], y[4]), b2 = gsub(y[2], y[3]);
+    const cplx<T> p1 = mk<T>(y[0].x + c1 * a1.x + c2 * a2.x, y[0].y + c1 * a1.y + c2 * a2.y);
+    const cplx<T> p2 = mk<T>(y[0].x + c2 * a1.x + c1 * a2.x, y[0].y + c2 * a1.y + c1 * a2.y);
+    const cplx<T> q1 = mk<T>(s1 * b1.x + s2 * b2.x, s1 * b1.y + s2 * b2.y);
+    const cplx<T> q2 = mk<T>(s2 * b1.x - s1 * b2.x, s2 * b1.y - s1 * b2.y);
+    y[0] = mk<T>(y[0].x + a1.x + a2.x, y[0].y + a1.y + a2.y);
+    y[1] = gadd_i(p1, q1, sg); y[4] = gsub_i(p1, q1, sg);
+    y[2] = gadd_i(p2, q2, sg); y[3] = gsub_i(p2, q2, sg);
+  }
+}
+
+template <typename T, int R>
+RF_HD void generic_stage_r(const cplx<T>* in, cplx<T>* out, int n, int TC, int Ns, const cplx<T>* root, int rstep, int sign, int tid, int nth) {
+  const int m = n / R, unit = n / (Ns * R);
+  const GenericWalk walk(m, TC, tid, nth);         // the m * TC butterflies: butterfly j of line c
+  const FastDiv dNs((uint32_t)Ns);
+  const T sg = sign < 0 ? (T)-1 : (T)1;
+  const int mstep = m * TC, ostep = Ns * TC;
+  int i = 0;
+  for (int idx = tid; idx < walk.total; idx += nth, ++i) {
+    int c, j;
+    walk.at(idx, i, c, j);
+    uint32_t jhi, k;
+    dNs.divmod((uint32_t)j, jhi, k);
+    cplx<T> y[R];
+    const cplx<T>* pin = in + j * TC + c;
+#pragma unroll
+    for (int r = 0; r < R; ++r) y[r] = pin[r * mstep];
+    if (Ns > 1) {
+      const int q = (int)k * unit * rstep;         // r * k * unit < n for r < R
+#pragma unroll
+      for (int r = 1; r < R; ++r) y[r] = gmul(y[r], root[r * q], sg);
+    }
+    generic_dft<T, R>(y, sg);
+    cplx<T>* po = out + ((int)jhi * Ns * R + (int)k) * TC + c;
+#pragma unroll
+    for (int u = 0; u < R; ++u) po[u * ostep] = y[u];
+  }
+}
+
+template <typename T>
+RF_HD void generic_stage(const cplx<T>* in, cplx<T>* out, int n, int TC, int R, int Ns, const cplx<T>* root, int rstep,
+                         int sign, int tid, int nth) {
+  switch (R) {
+    case 2: generic_stage_r<T, 2>(in, out, n, TC, Ns, root, rstep, sign, tid, nth); break;
+    case 3: generic_stage_r<T, 3>(in, out, n, TC, Ns, root, rstep, sign, tid, nth); break;
+    case 4: generic_stage_r<T, 4>(in, out, n, TC, Ns, root, rstep, sign, tid, nth); break;
+    case 5: generic_stage_r<T, 5>(in, out, n, TC, Ns, root, rstep, sign, tid, nth); break;
+    default: generic_stage_any<T>(in, out, n, TC, R, Ns, root, rstep, sign, tid, nth);
   }
 }
 
@@ -95,21 +220,29 @@ RF_HD void generic_axis_block(const cplx<T>* src, cplx<T>* dst, const GenericAxi
   const int n = ax.n, total = n * TC;
   const long long l0 = blk * TC;
   cplx<T>*a = lds, *b = lds + total;
-  for (int idx = tid; idx < total; idx += nth) {
-    const int c = idx % TC, e = idx / TC;
+  const GenericWalk walk(n, TC, tid, nth);
+  // (a thread that stays on one line forms that line's base once: the 64-bit division is ~100 instructions)
+  const long long lf = l0 + walk.c0;
+  const long long basef = walk.fixed && lf < nlines ? (lf / inner) * outer + lf % inner : 0;
+  int i = 0;
+  for (int idx = tid; idx < total; idx += nth, ++i) {
+    int c, e;
+    walk.at(idx, i, c, e);
     const long long l = l0 + c;
     cplx<T> v = mk<T>((T)0, (T)0);
-    if (l < nlines) v = src[(l / inner) * outer + l % inner + e * stride];
+    if (l < nlines) v = src[(walk.fixed ? basef : (l / inner) * outer + l % inner) + e * stride];
     a[idx] = v;
   }
   sync();
   const cplx<T>* r = generic_line_fft<T>(a, b, ax, TC, root, 1, sign, tid, nth, sync);
-  for (int idx = tid; idx < total; idx += nth) {
-    const int c = idx % TC, e = idx / TC;
+  i = 0;
+  for (int idx = tid; idx < total; idx += nth, ++i) {
+    int c, e;
+    walk.at(idx, i, c, e);
     const long long l = l0 + c;
     if (l < nlines) {
       const cplx<T> v = r[idx];
-      dst[(l / inner) * outer + l % inner + e * stride] = mk<T>(v.x * scale, v.y * scale);
+      dst[(walk.fixed ? basef : (l / inner) * outer + l % inner) + e * stride] = mk<T>(v.x * scale, v.y * scale);
     }
   }
 }
@@ -125,8 +258,11 @@ RF_HD void generic_row_c2r_block(const cplx<T>* G, T* W, const GenericAxis& ax, 
   const int M = ax.n, total = M * TR;
   const long long r0 = blk * TR;
   cplx<T>*a = lds, *b = lds + total;
+  const FastDiv dM((uint32_t)M);
   for (int idx = tid; idx < total; idx += nth) {
-    const int k = idx % M, c = idx / M;             // consecutive threads walk along a row
+    uint32_t cq, kr;
+    dM.divmod((uint32_t)idx, cq, kr);
+    const int k = (int)kr, c = (int)cq;             // consecutive threads walk along a row
     cplx<T> z = mk<T>((T)0, (T)0);
     if (r0 + c < nrows) {
       const cplx<T>* X = G + (r0 + c) * (long long)(M + 1);
@@ -145,7 +281,9 @@ RF_HD void generic_row_c2r_block(const cplx<T>* G, T* W, const GenericAxis& ax, 
   sync();
   const cplx<T>* r = generic_line_fft<T>(a, b, ax, TR, root, 2, +1, tid, nth, sync);
   for (int idx = tid; idx < total; idx += nth) {
-    const int m = idx % M, c = idx / M;
+    uint32_t cq, mr;
+    dM.divmod((uint32_t)idx, cq, mr);
+    const int m = (int)mr, c = (int)cq;
     if (r0 + c < nrows) {
       const cplx<T> v = r[m * TR + c];
       const T x0 = v.x * scale, x1 = v.y * scale;
@@ -166,8 +304,11 @@ RF_HD void generic_row_r2c_block(const T* W, cplx<T>* G, const GenericAxis& ax, 
   const int M = ax.n, total = M * TR;
   const long long r0 = blk * TR;
   cplx<T>*a = lds, *b = lds + total;
+  const FastDiv dM((uint32_t)M), dM1((uint32_t)(M + 1));
   for (int idx = tid; idx < total; idx += nth) {
-    const int m = idx % M, c = idx / M;
+    uint32_t cq, mr;
+    dM.divmod((uint32_t)idx, cq, mr);
+    const int m = (int)mr, c = (int)cq;
     cplx<T> z = mk<T>((T)0, (T)0);
     if (r0 + c < nrows) {
       const T* in = W + (r0 + c) * (long long)(2 * M) + 2 * m;
@@ -179,9 +320,11 @@ RF_HD void generic_row_r2c_block(const T* W, cplx<T>* G, const GenericAxis& ax, 
   const cplx<T>* r = generic_line_fft<T>(a, b, ax, TR, root, 2, -1, tid, nth, sync);
   const int totalo = (M + 1) * TR;
   for (int idx = tid; idx < totalo; idx += nth) {
-    const int k = idx % (M + 1), c = idx / (M + 1);
+    uint32_t cq, kr;
+    dM1.divmod((uint32_t)idx, cq, kr);
+    const int k = (int)kr, c = (int)cq;
     if (r0 + c < nrows) {
-      const cplx<T> p = r[(k % M) * TR + c], q = r[((M - k) % M) * TR + c];
+      const cplx<T> p = r[(k == M ? 0 : k) * TR + c], q = r[(k == 0 ? 0 : M - k) * TR + c];
       const T er = (T)0.5 * (p.x + q.x), ei = (T)0.5 * (p.y - q.y), orr = (T)0.5 * (p.x - q.x), oi = (T)0.5 * (p.y + q.y);
       cplx<T> w = root[k];
       w.y = -w.y;
@@ -259,13 +402,30 @@ RF_HD void generic_lines_block(const cplx<T>* src, cplx<T>* dst, const GenericLi
   const int n = L.ax.n, total = n * TC;
   const long long l0b = blk * TC, nl = L.nlines();
   cplx<T>*a = lds, *b = lds + total;
-  for (int idx = tid; idx < total; idx += nth) {
-    const int c = idx % TC, e = idx / TC;
+  const GenericWalk walk(n, TC, tid, nth);
+  // (a thread that stays on one line forms that line's sub-line index and bases once)
+  long long qf = 0, bsf = 0, bdf = 0;
+  if (walk.fixed && l0b + walk.c0 < nl) {
+    const long long l = l0b + walk.c0;
+    qf = l / L.nparent;
+    const long long l0 = l - qf * L.nparent;
+    bsf = (l0 / L.inner_s) * L.outer_s + l0 % L.inner_s + qf * L.sub_s;
+    bdf = (l0 / L.inner_d) * L.outer_d + l0 % L.inner_d + qf * L.sub_d;
+  }
+  int i = 0;
+  for (int idx = tid; idx < total; idx += nth, ++i) {
+    int c, e;
+    walk.at(idx, i, c, e);
     const long long l = l0b + c;
     cplx<T> v = mk<T>((T)0, (T)0);
     if (l < nl) {
-      const long long q = l / L.nparent, l0 = l - q * L.nparent;
-      v = src[(l0 / L.inner_s) * L.outer_s + l0 % L.inner_s + q * L.sub_s + e * L.stride_s];
+      long long q = qf, bs = bsf;
+      if (!walk.fixed) {
+        q = l / L.nparent;
+        const long long l0 = l - q * L.nparent;
+        bs = (l0 / L.inner_s) * L.outer_s + l0 % L.inner_s + q * L.sub_s;
+      }
+      v = src[bs + e * L.stride_s];
       if (L.tw_n > 0) {
         const long long t = ((long long)e * q) % L.tw_n;
         cplx<T> w = root[t * L.tw_step];
@@ -278,13 +438,19 @@ RF_HD void generic_lines_block(const cplx<T>* src, cplx<T>* dst, const GenericLi
   sync();
   const cplx<T>* r = generic_line_fft<T>(a, b, L.ax, TC, root, L.rstep, L.sign, tid, nth, sync);
   const T scale = (T)L.scale;
-  for (int idx = tid; idx < total; idx += nth) {
-    const int c = idx % TC, e = idx / TC;
+  i = 0;
+  for (int idx = tid; idx < total; idx += nth, ++i) {
+    int c, e;
+    walk.at(idx, i, c, e);
     const long long l = l0b + c;
     if (l < nl) {
-      const long long q = l / L.nparent, l0 = l - q * L.nparent;
+      long long bd = bdf;
+      if (!walk.fixed) {
+        const long long q = l / L.nparent, l0 = l - q * L.nparent;
+        bd = (l0 / L.inner_d) * L.outer_d + l0 % L.inner_d + q * L.sub_d;
+      }
       const cplx<T> v = r[idx];
-      dst[(l0 / L.inner_d) * L.outer_d + l0 % L.inner_d + q * L.sub_d + e * L.stride_d] = mk<T>(v.x * scale, v.y * scale);
+      dst[bd + e * L.stride_d] = mk<T>(v.x * scale, v.y * scale);
     }
   }
 }

@@ -8,7 +8,7 @@ namespace {
 struct BlockSync { __device__ void operator()() const { __syncthreads(); } };
 
 template <typename T>
-__global__ __launch_bounds__(256) void generic_axis_kernel(const cplx<T>* src, cplx<T>* dst, GenericAxis ax, long long stride,
+__global__ __launch_bounds__(1024) void generic_axis_kernel(const cplx<T>* src, cplx<T>* dst, GenericAxis ax, long long stride,
                                                           long long inner, long long outer, long long nlines, int TC,
                                                           const cplx<T>* __restrict__ root, int sign, T scale) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void generic_row_r2c_kernel(const T* __restric
 
 // lines with sub-lines (the two steps of the four-step transform of an axis too long for the LDS: rf_generic.h GenericLines)
 template <typename T>
-__global__ __launch_bounds__(256) void generic_lines_kernel(const cplx<T>* src, cplx<T>* dst, GenericLines L, int TC, const cplx<T>* __restrict__ root) {
+__global__ __launch_bounds__(1024) void generic_lines_kernel(const cplx<T>* src, cplx<T>* dst, GenericLines L, int TC, const cplx<T>* __restrict__ root) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
   generic_lines_block<T>(src, dst, L, TC, root, reinterpret_cast<cplx<T>*>(lds_raw), (long long)blockIdx.x, (int)threadIdx.x, (int)blockDim.x, BlockSync());
 }
@@ -84,19 +84,41 @@ __global__ __launch_bounds__(256) void generic_moments_kernel(const T* __restric
   }
 }
 
+// Lines per workgroup, threads and LDS bytes of a strided pass over lines of n elements of `es` bytes.  Neighbouring lines are
+// neighbours in memory, so tc lines give segments of tc * es bytes: 16 lines when two workgroups of them still share a CU's LDS, else
+// whatever keeps the segments at 64 bytes or more (one workgroup per CU then); enough threads for 16 waves per CU either way -- the
+// stages are chains of dependent LDS and table reads with a barrier between them, and latency is all that bounds them.
+struct StridedShape { int tc, threads; size_t lds; };
+inline StridedShape strided_shape(int n, int es, bool neighbours) {
+  auto lds = [&](int tc) { return 2 * (size_t)n * tc * es; };
+  int tc = neighbours ? 16 : 4;
+  while (tc > 1 && lds(tc) > (size_t)GENERIC_LDS_MAX / 2) tc >>= 1;
+  const int seg = 64 / es;                                             // lines per 64-byte segment
+  if (neighbours && tc < seg) {
+    int t2 = seg;
+    while (t2 > tc && lds(t2) > (size_t)GENERIC_LDS_MAX) t2 >>= 1;
+    tc = t2;
+  }
+  const int per_cu = (int)((size_t)(GENERIC_LDS_MAX + 256) / (lds(tc) > 0 ? lds(tc) : 1));
+  int threads = 256;
+  while (threads < 1024 && per_cu * threads < 1024 && (long long)n * tc >= 4LL * threads) threads <<= 1;
+  return {tc, threads, lds(tc)};
+}
+
 template <typename T>
 hipError_t lines_t(const void* src, void* dst, const GenericLines& L, const void* root, hipStream_t s) {
   // sub-lines whose parents are neighbours in memory (inner > 1) go 16 to a block, as in axis_t
-  const int tc = generic_lines_per_block(L.ax.n, (int)sizeof(cplx<T>), L.inner_s > 1 ? 16 : 4);
+  const StridedShape sh = strided_shape(L.ax.n, (int)sizeof(cplx<T>), L.inner_s > 1);
+  const int tc = sh.tc;
   const long long nblk = (L.nlines() + tc - 1) / tc;
   if (nblk <= 0) return hipSuccess;
   if (nblk > 0x7fffffffLL || L.nparent <= 0 || L.nsub <= 0) return hipErrorInvalidValue;
-  const size_t lds = 2 * (size_t)L.ax.n * tc * sizeof(cplx<T>);
+  const size_t lds = sh.lds;
   if (lds > (size_t)GENERIC_LDS_MAX) return hipErrorInvalidValue;
   static LdsAttrLatch latch;
   if (lds > 65536)
     if (hipError_t e = latch.ensure((const void*)generic_lines_kernel<T>, GENERIC_LDS_MAX); e != hipSuccess) return e;
-  hipLaunchKernelGGL(generic_lines_kernel<T>, dim3((unsigned)nblk), dim3(256), lds, s, (const cplx<T>*)src, (cplx<T>*)dst, L, tc, (const cplx<T>*)root);
+  hipLaunchKernelGGL(generic_lines_kernel<T>, dim3((unsigned)nblk), dim3(sh.threads), lds, s, (const cplx<T>*)src, (cplx<T>*)dst, L, tc, (const cplx<T>*)root);
   return hipGetLastError();
 }
 
@@ -104,16 +126,17 @@ template <typename T>
 hipError_t axis_t(const void* src, void* dst, const GenericAxis& ax, long long stride, long long inner, long long outer,
                   long long nlines, const void* root, int sign, double scale, hipStream_t s) {
   // lines that are neighbours in memory (inner > 1) are transformed 16 at a time: 128-byte (float32) segments
-  const int tc = generic_lines_per_block(ax.n, (int)sizeof(cplx<T>), inner > 1 ? 16 : 4);
+  const StridedShape sh = strided_shape(ax.n, (int)sizeof(cplx<T>), inner > 1);
+  const int tc = sh.tc;
   const long long nblk = (nlines + tc - 1) / tc;
   if (nblk <= 0) return hipSuccess;
   if (nblk > 0x7fffffffLL) return hipErrorInvalidValue;
-  const size_t lds = 2 * (size_t)ax.n * tc * sizeof(cplx<T>);
+  const size_t lds = sh.lds;
   if (lds > (size_t)GENERIC_LDS_MAX) return hipErrorInvalidValue;
   static LdsAttrLatch latch;
   if (lds > 65536)
     if (hipError_t e = latch.ensure((const void*)generic_axis_kernel<T>, GENERIC_LDS_MAX); e != hipSuccess) return e;
-  hipLaunchKernelGGL(generic_axis_kernel<T>, dim3((unsigned)nblk), dim3(256), lds, s, (const cplx<T>*)src, (cplx<T>*)dst, ax, stride,
+  hipLaunchKernelGGL(generic_axis_kernel<T>, dim3((unsigned)nblk), dim3(sh.threads), lds, s, (const cplx<T>*)src, (cplx<T>*)dst, ax, stride,
                      inner, outer, nlines, tc, (const cplx<T>*)root, sign, (T)scale);
   return hipGetLastError();
 }
