@@ -1015,7 +1015,7 @@ int rf_plan_create(rf_plan** out, int nx, int ny, int nz, int dtype, int device,
     if (!rc) rc = upload_twiddles<float>(&p->tw_z, nz);
   }
   if (rc) return cleanup(rc);
-  p->npartials = generic ? (gd.lz.split() ? 1024 : generic_row_blocks(dtype, (int)p->nzc, (long long)nx * ny))      // (long rows: the moments are a pass of their own, 1024 blocks)
+  p->npartials = generic ? (gd.lz.split() ? 1024 : generic_row_blocks(dtype, gd.az, (long long)nx * ny))      // (long rows: the moments are a pass of their own, 1024 blocks)
                : nranks > 1 ? row_c2r_tiles(dtype, p->nzc, (long long)p->nxl * ny) : row_c2r_tiles(dtype, p->nzc, (long long)nx * ny);
   p->stats_cap = 64;
   if ((e = hipMalloc((void**)&p->partials, (2 * p->npartials + 512) * sizeof(double))) != hipSuccess ||

@@ -26,7 +26,15 @@ struct GenericAxis {
   int n;                                // line length
   int nf;                               // number of radices
   int f[GENERIC_MAX_FACTORS];           // their product is n
+  // derived by generic_factor (the kernels read these as uniform values from their argument block):
+  int smooth;                           // all radices among 2, 3, 4, 5: the in-place form (see generic_stage_inplace)
+  int w[GENERIC_MAX_FACTORS];           // Ns of stage s = f[0] ... f[s-1]
+  unsigned fm[GENERIC_MAX_FACTORS];     // multiply-high reciprocals of f[s] and of w[s] (FastDiv)
+  unsigned wm[GENERIC_MAX_FACTORS];
 };
+
+// reciprocal for division by multiply-high (FastDiv below): floor(2^32 / d) + 1, d >= 2
+inline unsigned generic_magic(unsigned d) { return d > 1 ? 0xFFFFFFFFu / d + 1u : 0u; }
 
 // radices of n: 4s first (fewest stages), then 2, then the odd primes in increasing order
 inline bool generic_factor(int n, GenericAxis& ax) {
@@ -40,7 +48,18 @@ inline bool generic_factor(int n, GenericAxis& ax) {
   for (int p = 3; p * p <= m; p += 2)
     while (m % p == 0) push(p);
   if (m > 1) push(m);
-  return ax.nf <= GENERIC_MAX_FACTORS;
+  if (ax.nf > GENERIC_MAX_FACTORS) return false;
+  ax.smooth = 1;
+  int Ns = 1;
+  for (int s = 0; s < GENERIC_MAX_FACTORS; ++s) {
+    if (s >= ax.nf) { ax.f[s] = 1; ax.w[s] = n; ax.fm[s] = 0; ax.wm[s] = generic_magic((unsigned)n); continue; }
+    if (ax.f[s] > 5) ax.smooth = 0;
+    ax.w[s] = Ns;
+    ax.fm[s] = generic_magic((unsigned)ax.f[s]);
+    ax.wm[s] = generic_magic((unsigned)Ns);
+    Ns *= ax.f[s];
+  }
+  return true;
 }
 
 // Division by a run-time constant that is the same for all threads: q = (a * m) >> 32 with m = floor(2^32 / d) + 1 is exact whenever
@@ -48,7 +67,8 @@ inline bool generic_factor(int n, GenericAxis& ax) {
 // integer division costs ~40 instructions on this hardware, and the loops below need three to five per element.
 struct FastDiv {
   uint32_t d, m;
-  RF_HD explicit FastDiv(uint32_t dd) : d(dd), m(dd > 1 ? (uint32_t)(0x100000000ull / dd) + 1u : 0u) {}
+  RF_HD explicit FastDiv(uint32_t dd) : d(dd), m(dd > 1 ? 0xFFFFFFFFu / dd + 1u : 0u) {}
+  RF_HD FastDiv(uint32_t dd, uint32_t mm) : d(dd), m(mm) {}                        // (reciprocal formed on the host: generic_magic)
   RF_HD uint32_t div(uint32_t a) const {
 #if defined(__HIP_DEVICE_COMPILE__)
     return d > 1 ? __umulhi(a, m) : a;
@@ -156,10 +176,10 @@ template <typename T, int R> RF_HD void generic_dft(cplx<T>* y, T sg) {
 }
 
 template <typename T, int R>
-RF_HD void generic_stage_r(const cplx<T>* in, cplx<T>* out, int n, int TC, int Ns, const cplx<T>* root, int rstep, int sign, int tid, int nth) {
-  const int m = n / R, unit = n / (Ns * R);
+RF_HD void generic_stage_r(const cplx<T>* in, cplx<T>* out, int n, int TC, int Ns, unsigned Nsm, const cplx<T>* root, int rstep, int sign, int tid, int nth) {
+  const FastDiv dNs((uint32_t)Ns, Nsm);
+  const int m = n / R, unit = (int)dNs.div((uint32_t)m);
   const GenericWalk walk(m, TC, tid, nth);         // the m * TC butterflies: butterfly j of line c
-  const FastDiv dNs((uint32_t)Ns);
   const T sg = sign < 0 ? (T)-1 : (T)1;
   const int mstep = m * TC, ostep = Ns * TC;
   int i = 0;
@@ -184,25 +204,92 @@ RF_HD void generic_stage_r(const cplx<T>* in, cplx<T>* out, int n, int TC, int N
   }
 }
 
+// ---- axes whose radices are all among 2, 3, 4, 5 ("smooth": every power-of-two times 3^a 5^b length): IN PLACE, one buffer.
+// Decimation in time on a line stored in digit-reversed order: stage s (radix R, Ns = product of the radices before it) finds the R
+// sub-transforms of length Ns it combines in the R consecutive runs of Ns positions of one block of Ns R, and leaves the block's
+// transform in those same positions -- butterflies touch disjoint positions, so a stage needs no second buffer and the line needs
+// half the LDS (twice the lines per workgroup, or two workgroups per CU).  The digit reversal costs nothing: it is the position an
+// element is WRITTEN to when the line is loaded (generic_pos).  Same butterflies on the same values as the two-buffer form.
+RF_HD bool generic_smooth(const GenericAxis& ax) { return ax.smooth != 0; }
+// buffers of n * TC elements a line transform of this axis needs in LDS
+RF_HD int generic_bufs(const GenericAxis& ax) { return generic_smooth(ax) ? 1 : 2; }
+
+// where element e of a line goes when the line is loaded: e = d_(nf-1) + f_(nf-1) (d_(nf-2) + f_(nf-2) (...)), the digit of the LAST
+// radix least significant, lands at sum_s d_s Ns_s; the identity for an axis that is not smooth (two-buffer form, natural order)
+RF_HD int generic_pos(const GenericAxis& ax, int e) {
+  if (!ax.smooth) return e;
+  uint32_t j = (uint32_t)e;
+  int p = 0;
+  for (int s = ax.nf - 1; s >= 0; --s) {
+    uint32_t q, r;
+    FastDiv((uint32_t)ax.f[s], ax.fm[s]).divmod(j, q, r);
+    p += (int)r * ax.w[s];
+    j = q;
+  }
+  return p;
+}
+
+template <typename T, int R>
+RF_HD void generic_stage_inplace(cplx<T>* a, int n, int TC, int Ns, unsigned Nsm, const cplx<T>* root, int rstep, int sign, int tid, int nth) {
+  const FastDiv dNs((uint32_t)Ns, Nsm);
+  const int m = n / R, unit = (int)dNs.div((uint32_t)m);
+  const GenericWalk walk(m, TC, tid, nth);         // the m * TC butterflies
+  const T sg = sign < 0 ? (T)-1 : (T)1;
+  const int step = Ns * TC;
+  int i = 0;
+  for (int idx = tid; idx < walk.total; idx += nth, ++i) {
+    int c, bf;
+    walk.at(idx, i, c, bf);
+    uint32_t jhi, k;
+    dNs.divmod((uint32_t)bf, jhi, k);
+    cplx<T>* p = a + ((int)jhi * Ns * R + (int)k) * TC + c;
+    cplx<T> y[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) y[r] = p[r * step];
+    if (Ns > 1) {
+      const int q = (int)k * unit * rstep;         // r * k * unit < n for r < R
+#pragma unroll
+      for (int r = 1; r < R; ++r) y[r] = gmul(y[r], root[r * q], sg);
+    }
+    generic_dft<T, R>(y, sg);
+#pragma unroll
+    for (int u = 0; u < R; ++u) p[u * step] = y[u];
+  }
+}
+
 template <typename T>
-RF_HD void generic_stage(const cplx<T>* in, cplx<T>* out, int n, int TC, int R, int Ns, const cplx<T>* root, int rstep,
+RF_HD void generic_stage(const cplx<T>* in, cplx<T>* out, int n, int TC, int R, int Ns, unsigned Nsm, const cplx<T>* root, int rstep,
                          int sign, int tid, int nth) {
   switch (R) {
-    case 2: generic_stage_r<T, 2>(in, out, n, TC, Ns, root, rstep, sign, tid, nth); break;
-    case 3: generic_stage_r<T, 3>(in, out, n, TC, Ns, root, rstep, sign, tid, nth); break;
-    case 4: generic_stage_r<T, 4>(in, out, n, TC, Ns, root, rstep, sign, tid, nth); break;
-    case 5: generic_stage_r<T, 5>(in, out, n, TC, Ns, root, rstep, sign, tid, nth); break;
+    case 2: generic_stage_r<T, 2>(in, out, n, TC, Ns, Nsm, root, rstep, sign, tid, nth); break;
+    case 3: generic_stage_r<T, 3>(in, out, n, TC, Ns, Nsm, root, rstep, sign, tid, nth); break;
+    case 4: generic_stage_r<T, 4>(in, out, n, TC, Ns, Nsm, root, rstep, sign, tid, nth); break;
+    case 5: generic_stage_r<T, 5>(in, out, n, TC, Ns, Nsm, root, rstep, sign, tid, nth); break;
     default: generic_stage_any<T>(in, out, n, TC, R, Ns, root, rstep, sign, tid, nth);
   }
 }
 
-// all stages; returns the buffer that holds the result (a or b)
+// all stages; returns the buffer that holds the result (a or b).  The caller has written element e of line c to
+// a[generic_pos(ax, e) * TC + c]; a smooth axis is transformed in place (b is not touched and may be null).
 template <typename T, class Sync>
 RF_HD cplx<T>* generic_line_fft(cplx<T>* a, cplx<T>* b, const GenericAxis& ax, int TC, const cplx<T>* root, int rstep,
                                 int sign, int tid, int nth, Sync sync) {
   int Ns = 1;
+  if (generic_smooth(ax)) {
+    for (int s = 0; s < ax.nf; ++s) {
+      switch (ax.f[s]) {
+        case 2: generic_stage_inplace<T, 2>(a, ax.n, TC, Ns, ax.wm[s], root, rstep, sign, tid, nth); break;
+        case 3: generic_stage_inplace<T, 3>(a, ax.n, TC, Ns, ax.wm[s], root, rstep, sign, tid, nth); break;
+        case 4: generic_stage_inplace<T, 4>(a, ax.n, TC, Ns, ax.wm[s], root, rstep, sign, tid, nth); break;
+        default: generic_stage_inplace<T, 5>(a, ax.n, TC, Ns, ax.wm[s], root, rstep, sign, tid, nth);
+      }
+      sync();
+      Ns *= ax.f[s];
+    }
+    return a;
+  }
   for (int s = 0; s < ax.nf; ++s) {
-    generic_stage<T>(a, b, ax.n, TC, ax.f[s], Ns, root, rstep, sign, tid, nth);
+    generic_stage<T>(a, b, ax.n, TC, ax.f[s], Ns, ax.wm[s], root, rstep, sign, tid, nth);
     sync();
     Ns *= ax.f[s];
     cplx<T>* t = a; a = b; b = t;
@@ -212,7 +299,7 @@ RF_HD cplx<T>* generic_line_fft(cplx<T>* a, cplx<T>* b, const GenericAxis& ax, i
 
 // Strided (or contiguous) complex pass: block `blk` transforms lines [blk TC, blk TC + TC) of length ax.n;
 // line l starts at (l / inner) * outer + l % inner and its elements are `stride` apart.  src == dst is allowed
-// (a block reads all of its lines before it writes any).  lds: 2 * ax.n * TC elements.
+// (a block reads all of its lines before it writes any).  lds: generic_bufs(ax) * ax.n * TC elements.
 template <typename T, class Sync>
 RF_HD void generic_axis_block(const cplx<T>* src, cplx<T>* dst, const GenericAxis& ax, long long stride, long long inner,
                               long long outer, long long nlines, int TC, const cplx<T>* root, int sign, T scale,
@@ -231,7 +318,7 @@ RF_HD void generic_axis_block(const cplx<T>* src, cplx<T>* dst, const GenericAxi
     const long long l = l0 + c;
     cplx<T> v = mk<T>((T)0, (T)0);
     if (l < nlines) v = src[(walk.fixed ? basef : (l / inner) * outer + l % inner) + e * stride];
-    a[idx] = v;
+    a[generic_pos(ax, e) * TC + c] = v;
   }
   sync();
   const cplx<T>* r = generic_line_fft<T>(a, b, ax, TC, root, 1, sign, tid, nth, sync);
@@ -251,7 +338,7 @@ RF_HD void generic_axis_block(const cplx<T>* src, cplx<T>* dst, const GenericAxi
 // With w = exp(2 pi i / nz):  z[m] = x[2m] + i x[2m+1] = IDFT_M( (X[k] + conj X[M-k]) + i w^k (X[k] - conj X[M-k]) ),
 // the imaginary parts of X[0] and X[M] being ignored.  `ax` factors M; root = exp(2 pi i t / nz), t in [0, nz).
 // Block `blk` owns rows [blk TR, blk TR + TR); the calling thread's share of (sum, sum of squares) of the outputs
-// (after `scale`) is added to s1, s2.  lds: 2 * M * TR elements.
+// (after `scale`) is added to s1, s2.  lds: generic_bufs(ax) * M * TR elements.
 template <typename T, class Sync>
 RF_HD void generic_row_c2r_block(const cplx<T>* G, T* W, const GenericAxis& ax, long long nrows, int TR, const cplx<T>* root,
                                  T scale, cplx<T>* lds, long long blk, int tid, int nth, Sync sync, double& s1, double& s2) {
@@ -276,7 +363,7 @@ RF_HD void generic_row_c2r_block(const cplx<T>* G, T* W, const GenericAxis& ax, 
         z = mk<T>(er - (w.x * oi + w.y * orr), ei + (w.x * orr - w.y * oi));
       }
     }
-    a[k * TR + c] = z;
+    a[generic_pos(ax, k) * TR + c] = z;
   }
   sync();
   const cplx<T>* r = generic_line_fft<T>(a, b, ax, TR, root, 2, +1, tid, nth, sync);
@@ -314,7 +401,7 @@ RF_HD void generic_row_r2c_block(const T* W, cplx<T>* G, const GenericAxis& ax, 
       const T* in = W + (r0 + c) * (long long)(2 * M) + 2 * m;
       z = mk<T>(in[0], in[1]);
     }
-    a[m * TR + c] = z;
+    a[generic_pos(ax, m) * TR + c] = z;
   }
   sync();
   const cplx<T>* r = generic_line_fft<T>(a, b, ax, TR, root, 2, -1, tid, nth, sync);
@@ -394,7 +481,7 @@ inline GenericLines generic_long_step3(const GenericLong& lg, long long S, long 
   return L;
 }
 
-// block `blk` transforms lines [blk TC, blk TC + TC) of L; lds: 2 * L.ax.n * TC elements.  src == dst is allowed when the two
+// block `blk` transforms lines [blk TC, blk TC + TC) of L; lds: generic_bufs(L.ax) * L.ax.n * TC elements.  src == dst is allowed when the two
 // addressings are the same (step 1); step 3 needs another array.
 template <typename T, class Sync>
 RF_HD void generic_lines_block(const cplx<T>* src, cplx<T>* dst, const GenericLines& L, int TC, const cplx<T>* root, cplx<T>* lds,
@@ -433,7 +520,7 @@ RF_HD void generic_lines_block(const cplx<T>* src, cplx<T>* dst, const GenericLi
         v = mk<T>(v.x * w.x - v.y * w.y, v.x * w.y + v.y * w.x);
       }
     }
-    a[idx] = v;
+    a[generic_pos(L.ax, e) * TC + c] = v;
   }
   sync();
   const cplx<T>* r = generic_line_fft<T>(a, b, L.ax, TC, root, L.rstep, L.sign, tid, nth, sync);
@@ -563,9 +650,9 @@ int generic_c2c_seq(Ops& ops, const GenericDims& d, void* D, void* G, int sign, 
 
 // lines / rows per block so that the two LDS buffers stay within 64 KB (no function attribute needed); a single line longer than
 // that (n > 4096 complex64 / 2048 complex128) takes what it needs, up to GENERIC_LDS_MAX
-inline int generic_lines_per_block(int n, int elem_bytes, int want, long long budget = 65536) {
+inline int generic_lines_per_block(int n, int elem_bytes, int want, long long budget = 65536, int bufs = 2) {
   int tc = want;
-  while (tc > 1 && 2LL * n * tc * elem_bytes > budget) tc >>= 1;
+  while (tc > 1 && (long long)bufs * n * tc * elem_bytes > budget) tc >>= 1;
   return tc;
 }
 

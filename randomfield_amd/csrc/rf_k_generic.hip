@@ -89,8 +89,9 @@ __global__ __launch_bounds__(256) void generic_moments_kernel(const T* __restric
 // whatever keeps the segments at 64 bytes or more (one workgroup per CU then); enough threads for 16 waves per CU either way -- the
 // stages are chains of dependent LDS and table reads with a barrier between them, and latency is all that bounds them.
 struct StridedShape { int tc, threads; size_t lds; };
-inline StridedShape strided_shape(int n, int es, bool neighbours) {
-  auto lds = [&](int tc) { return 2 * (size_t)n * tc * es; };
+inline StridedShape strided_shape(const GenericAxis& ax, int es, bool neighbours) {
+  const int n = ax.n, bufs = generic_bufs(ax);
+  auto lds = [&](int tc) { return (size_t)bufs * n * tc * es; };
   int tc = neighbours ? 16 : 4;
   while (tc > 1 && lds(tc) > (size_t)GENERIC_LDS_MAX / 2) tc >>= 1;
   const int seg = 64 / es;                                             // lines per 64-byte segment
@@ -108,7 +109,7 @@ inline StridedShape strided_shape(int n, int es, bool neighbours) {
 template <typename T>
 hipError_t lines_t(const void* src, void* dst, const GenericLines& L, const void* root, hipStream_t s) {
   // sub-lines whose parents are neighbours in memory (inner > 1) go 16 to a block, as in axis_t
-  const StridedShape sh = strided_shape(L.ax.n, (int)sizeof(cplx<T>), L.inner_s > 1);
+  const StridedShape sh = strided_shape(L.ax, (int)sizeof(cplx<T>), L.inner_s > 1);
   const int tc = sh.tc;
   const long long nblk = (L.nlines() + tc - 1) / tc;
   if (nblk <= 0) return hipSuccess;
@@ -126,7 +127,7 @@ template <typename T>
 hipError_t axis_t(const void* src, void* dst, const GenericAxis& ax, long long stride, long long inner, long long outer,
                   long long nlines, const void* root, int sign, double scale, hipStream_t s) {
   // lines that are neighbours in memory (inner > 1) are transformed 16 at a time: 128-byte (float32) segments
-  const StridedShape sh = strided_shape(ax.n, (int)sizeof(cplx<T>), inner > 1);
+  const StridedShape sh = strided_shape(ax, (int)sizeof(cplx<T>), inner > 1);
   const int tc = sh.tc;
   const long long nblk = (nlines + tc - 1) / tc;
   if (nblk <= 0) return hipSuccess;
@@ -141,7 +142,7 @@ hipError_t axis_t(const void* src, void* dst, const GenericAxis& ax, long long s
   return hipGetLastError();
 }
 
-template <typename T> int rows_per_block(int M) { return generic_lines_per_block(M, (int)sizeof(cplx<T>), 8, 49152); }   // + the reduction's static LDS
+template <typename T> int rows_per_block(const GenericAxis& ax) { return generic_lines_per_block(ax.n, (int)sizeof(cplx<T>), 8, 49152, generic_bufs(ax)); }   // + the reduction's static LDS
 
 }  // namespace
 
@@ -175,18 +176,18 @@ hipError_t launch_generic_moments(int f64, const void* W, long long n, double* p
   return hipGetLastError();
 }
 
-long long generic_row_blocks(int f64, int M, long long nrows) {
-  const int tr = f64 ? rows_per_block<double>(M) : rows_per_block<float>(M);
+long long generic_row_blocks(int f64, const GenericAxis& ax, long long nrows) {
+  const int tr = f64 ? rows_per_block<double>(ax) : rows_per_block<float>(ax);
   return (nrows + tr - 1) / tr;
 }
 
 hipError_t launch_generic_row_c2r(int f64, const void* G, void* W, const GenericAxis& ax, long long nrows, const void* root,
                                   double scale, double* partials, hipStream_t s) {
-  const long long nblk = generic_row_blocks(f64, ax.n, nrows);
+  const long long nblk = generic_row_blocks(f64, ax, nrows);
   if (nblk <= 0 || nblk > 0x7fffffffLL) return hipErrorInvalidValue;
   if (f64) {
-    const int tr = rows_per_block<double>(ax.n);
-    const size_t lds = 2 * (size_t)ax.n * tr * sizeof(cplx<double>);
+    const int tr = rows_per_block<double>(ax);
+    const size_t lds = (size_t)generic_bufs(ax) * ax.n * tr * sizeof(cplx<double>);
     if (lds > (size_t)GENERIC_LDS_MAX) return hipErrorInvalidValue;
     static LdsAttrLatch latch;
     if (lds > 49152)
@@ -194,8 +195,8 @@ hipError_t launch_generic_row_c2r(int f64, const void* G, void* W, const Generic
     hipLaunchKernelGGL(generic_row_c2r_kernel<double>, dim3((unsigned)nblk), dim3(256), lds, s,
                        (const cplx<double>*)G, (double*)W, ax, nrows, tr, (const cplx<double>*)root, scale, partials);
   } else {
-    const int tr = rows_per_block<float>(ax.n);
-    const size_t lds = 2 * (size_t)ax.n * tr * sizeof(cplx<float>);
+    const int tr = rows_per_block<float>(ax);
+    const size_t lds = (size_t)generic_bufs(ax) * ax.n * tr * sizeof(cplx<float>);
     if (lds > (size_t)GENERIC_LDS_MAX) return hipErrorInvalidValue;
     static LdsAttrLatch latch;
     if (lds > 49152)
@@ -208,11 +209,11 @@ hipError_t launch_generic_row_c2r(int f64, const void* G, void* W, const Generic
 
 hipError_t launch_generic_row_r2c(int f64, const void* W, void* G, const GenericAxis& ax, long long nrows, const void* root,
                                   hipStream_t s) {
-  const long long nblk = generic_row_blocks(f64, ax.n, nrows);
+  const long long nblk = generic_row_blocks(f64, ax, nrows);
   if (nblk <= 0 || nblk > 0x7fffffffLL) return hipErrorInvalidValue;
   if (f64) {
-    const int tr = rows_per_block<double>(ax.n);
-    const size_t lds = 2 * (size_t)ax.n * tr * sizeof(cplx<double>);
+    const int tr = rows_per_block<double>(ax);
+    const size_t lds = (size_t)generic_bufs(ax) * ax.n * tr * sizeof(cplx<double>);
     if (lds > (size_t)GENERIC_LDS_MAX) return hipErrorInvalidValue;
     static LdsAttrLatch latch;
     if (lds > 49152)
@@ -220,8 +221,8 @@ hipError_t launch_generic_row_r2c(int f64, const void* W, void* G, const Generic
     hipLaunchKernelGGL(generic_row_r2c_kernel<double>, dim3((unsigned)nblk), dim3(256), lds, s,
                        (const double*)W, (cplx<double>*)G, ax, nrows, tr, (const cplx<double>*)root);
   } else {
-    const int tr = rows_per_block<float>(ax.n);
-    const size_t lds = 2 * (size_t)ax.n * tr * sizeof(cplx<float>);
+    const int tr = rows_per_block<float>(ax);
+    const size_t lds = (size_t)generic_bufs(ax) * ax.n * tr * sizeof(cplx<float>);
     if (lds > (size_t)GENERIC_LDS_MAX) return hipErrorInvalidValue;
     static LdsAttrLatch latch;
     if (lds > 49152)

@@ -177,7 +177,7 @@ hipError_t launch_generic_tangle(int f64, const void* Z, void* G, int M, long lo
 hipError_t launch_generic_moments(int f64, const void* W, long long n, double* partials, long long nblocks, hipStream_t s);
 // rows of nz/2+1 half-spectrum bins (G) <-> dense rows of nz reals (W); ax factors nz/2, root_nz has nz entries;
 // the c2r pass leaves (sum, sumsq) of block b in partials[2b], partials[2b+1]
-long long generic_row_blocks(int f64, int M, long long nrows);
+long long generic_row_blocks(int f64, const GenericAxis& ax, long long nrows);
 hipError_t launch_generic_row_c2r(int f64, const void* G, void* W, const GenericAxis& ax, long long nrows, const void* root_nz,
                                   double scale, double* partials, hipStream_t s);
 hipError_t launch_generic_row_r2c(int f64, const void* W, void* G, const GenericAxis& ax, long long nrows, const void* root_nz,
