@@ -527,14 +527,14 @@ template <typename T> struct EmuGenericOps {
   GenericAxis az;
   int row_c2r(const void* G, void* W, double scale) {
     const int TR = 2;
-    lds.resize(2 * (size_t)az.n * TR);
+    lds.resize(2 * (size_t)az.n * generic_row_pitch(TR));
     for (long long b = 0; b * TR < rows; ++b)
       generic_row_c2r_block<T>((const cplx<T>*)G, (T*)W, az, rows, TR, rz, (T)scale, lds.data(), b, 0, 1, NoSync(), s1, s2);
     return 0;
   }
   int row_r2c(const void* W, void* G) {
     const int TR = 2;
-    lds.resize(2 * (size_t)az.n * TR);
+    lds.resize(2 * (size_t)az.n * generic_row_pitch(TR));
     for (long long b = 0; b * TR < rows; ++b) generic_row_r2c_block<T>((const T*)W, (cplx<T>*)G, az, rows, TR, rz, lds.data(), b, 0, 1, NoSync());
     return 0;
   }

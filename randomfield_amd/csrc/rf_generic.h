@@ -101,7 +101,7 @@ struct GenericWalk {
 //
 // Any radix: every OUTPUT is a dot product of length R (R table reads and R LDS reads per element).
 template <typename T>
-RF_HD void generic_stage_any(const cplx<T>* in, cplx<T>* out, int n, int TC, int R, int Ns, const cplx<T>* root, int rstep,
+RF_HD void generic_stage_any(const cplx<T>* in, cplx<T>* out, int n, int TC, int P, int R, int Ns, const cplx<T>* root, int rstep,
                              int sign, int tid, int nth) {
   const int m = n / R, unit = n / (Ns * R);
   const GenericWalk walk(n, TC, tid, nth);
@@ -119,8 +119,8 @@ RF_HD void generic_stage_any(const cplx<T>* in, cplx<T>* out, int n, int TC, int
     if (q >= n) q -= n;
     T sr = (T)0, si = (T)0;
     int ri = 0;
-    const cplx<T>* pin = in + j * TC + c;
-    const int mstep = m * TC;
+    const cplx<T>* pin = in + j * P + c;
+    const int mstep = m * P;
     for (int r = 0; r < R; ++r) {
       const cplx<T> v = pin[r * mstep];
       cplx<T> w = root[ri * rstep];
@@ -130,7 +130,7 @@ RF_HD void generic_stage_any(const cplx<T>* in, cplx<T>* out, int n, int TC, int
       ri += q;
       if (ri >= n) ri -= n;
     }
-    out[o * TC + c] = mk<T>(sr, si);
+    out[o * P + c] = mk<T>(sr, si);
   }
 }
 
@@ -176,12 +176,12 @@ template <typename T, int R> RF_HD void generic_dft(cplx<T>* y, T sg) {
 }
 
 template <typename T, int R>
-RF_HD void generic_stage_r(const cplx<T>* in, cplx<T>* out, int n, int TC, int Ns, unsigned Nsm, const cplx<T>* root, int rstep, int sign, int tid, int nth) {
+RF_HD void generic_stage_r(const cplx<T>* in, cplx<T>* out, int n, int TC, int P, int Ns, unsigned Nsm, const cplx<T>* root, int rstep, int sign, int tid, int nth) {
   const FastDiv dNs((uint32_t)Ns, Nsm);
   const int m = n / R, unit = (int)dNs.div((uint32_t)m);
   const GenericWalk walk(m, TC, tid, nth);         // the m * TC butterflies: butterfly j of line c
   const T sg = sign < 0 ? (T)-1 : (T)1;
-  const int mstep = m * TC, ostep = Ns * TC;
+  const int mstep = m * P, ostep = Ns * P;
   int i = 0;
   for (int idx = tid; idx < walk.total; idx += nth, ++i) {
     int c, j;
@@ -189,7 +189,7 @@ RF_HD void generic_stage_r(const cplx<T>* in, cplx<T>* out, int n, int TC, int N
     uint32_t jhi, k;
     dNs.divmod((uint32_t)j, jhi, k);
     cplx<T> y[R];
-    const cplx<T>* pin = in + j * TC + c;
+    const cplx<T>* pin = in + j * P + c;
 #pragma unroll
     for (int r = 0; r < R; ++r) y[r] = pin[r * mstep];
     if (Ns > 1) {
@@ -198,7 +198,7 @@ RF_HD void generic_stage_r(const cplx<T>* in, cplx<T>* out, int n, int TC, int N
       for (int r = 1; r < R; ++r) y[r] = gmul(y[r], root[r * q], sg);
     }
     generic_dft<T, R>(y, sg);
-    cplx<T>* po = out + ((int)jhi * Ns * R + (int)k) * TC + c;
+    cplx<T>* po = out + ((int)jhi * Ns * R + (int)k) * P + c;
 #pragma unroll
     for (int u = 0; u < R; ++u) po[u * ostep] = y[u];
   }
@@ -230,19 +230,19 @@ RF_HD int generic_pos(const GenericAxis& ax, int e) {
 }
 
 template <typename T, int R>
-RF_HD void generic_stage_inplace(cplx<T>* a, int n, int TC, int Ns, unsigned Nsm, const cplx<T>* root, int rstep, int sign, int tid, int nth) {
+RF_HD void generic_stage_inplace(cplx<T>* a, int n, int TC, int P, int Ns, unsigned Nsm, const cplx<T>* root, int rstep, int sign, int tid, int nth) {
   const FastDiv dNs((uint32_t)Ns, Nsm);
   const int m = n / R, unit = (int)dNs.div((uint32_t)m);
   const GenericWalk walk(m, TC, tid, nth);         // the m * TC butterflies
   const T sg = sign < 0 ? (T)-1 : (T)1;
-  const int step = Ns * TC;
+  const int step = Ns * P;
   int i = 0;
   for (int idx = tid; idx < walk.total; idx += nth, ++i) {
     int c, bf;
     walk.at(idx, i, c, bf);
     uint32_t jhi, k;
     dNs.divmod((uint32_t)bf, jhi, k);
-    cplx<T>* p = a + ((int)jhi * Ns * R + (int)k) * TC + c;
+    cplx<T>* p = a + ((int)jhi * Ns * R + (int)k) * P + c;
     cplx<T> y[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) y[r] = p[r * step];
@@ -258,30 +258,31 @@ RF_HD void generic_stage_inplace(cplx<T>* a, int n, int TC, int Ns, unsigned Nsm
 }
 
 template <typename T>
-RF_HD void generic_stage(const cplx<T>* in, cplx<T>* out, int n, int TC, int R, int Ns, unsigned Nsm, const cplx<T>* root, int rstep,
+RF_HD void generic_stage(const cplx<T>* in, cplx<T>* out, int n, int TC, int P, int R, int Ns, unsigned Nsm, const cplx<T>* root, int rstep,
                          int sign, int tid, int nth) {
   switch (R) {
-    case 2: generic_stage_r<T, 2>(in, out, n, TC, Ns, Nsm, root, rstep, sign, tid, nth); break;
-    case 3: generic_stage_r<T, 3>(in, out, n, TC, Ns, Nsm, root, rstep, sign, tid, nth); break;
-    case 4: generic_stage_r<T, 4>(in, out, n, TC, Ns, Nsm, root, rstep, sign, tid, nth); break;
-    case 5: generic_stage_r<T, 5>(in, out, n, TC, Ns, Nsm, root, rstep, sign, tid, nth); break;
-    default: generic_stage_any<T>(in, out, n, TC, R, Ns, root, rstep, sign, tid, nth);
+    case 2: generic_stage_r<T, 2>(in, out, n, TC, P, Ns, Nsm, root, rstep, sign, tid, nth); break;
+    case 3: generic_stage_r<T, 3>(in, out, n, TC, P, Ns, Nsm, root, rstep, sign, tid, nth); break;
+    case 4: generic_stage_r<T, 4>(in, out, n, TC, P, Ns, Nsm, root, rstep, sign, tid, nth); break;
+    case 5: generic_stage_r<T, 5>(in, out, n, TC, P, Ns, Nsm, root, rstep, sign, tid, nth); break;
+    default: generic_stage_any<T>(in, out, n, TC, P, R, Ns, root, rstep, sign, tid, nth);
   }
 }
 
 // all stages; returns the buffer that holds the result (a or b).  The caller has written element e of line c to
-// a[generic_pos(ax, e) * TC + c]; a smooth axis is transformed in place (b is not touched and may be null).
+// a[generic_pos(ax, e) * P + c] -- P >= TC is the pitch of the LDS image (TC where the threads walk along c, TC + 1 where they walk along
+// e: an odd pitch keeps those walks off the same banks); a smooth axis is transformed in place (b is not touched and may be null).
 template <typename T, class Sync>
-RF_HD cplx<T>* generic_line_fft(cplx<T>* a, cplx<T>* b, const GenericAxis& ax, int TC, const cplx<T>* root, int rstep,
+RF_HD cplx<T>* generic_line_fft(cplx<T>* a, cplx<T>* b, const GenericAxis& ax, int TC, int P, const cplx<T>* root, int rstep,
                                 int sign, int tid, int nth, Sync sync) {
   int Ns = 1;
   if (generic_smooth(ax)) {
     for (int s = 0; s < ax.nf; ++s) {
       switch (ax.f[s]) {
-        case 2: generic_stage_inplace<T, 2>(a, ax.n, TC, Ns, ax.wm[s], root, rstep, sign, tid, nth); break;
-        case 3: generic_stage_inplace<T, 3>(a, ax.n, TC, Ns, ax.wm[s], root, rstep, sign, tid, nth); break;
-        case 4: generic_stage_inplace<T, 4>(a, ax.n, TC, Ns, ax.wm[s], root, rstep, sign, tid, nth); break;
-        default: generic_stage_inplace<T, 5>(a, ax.n, TC, Ns, ax.wm[s], root, rstep, sign, tid, nth);
+        case 2: generic_stage_inplace<T, 2>(a, ax.n, TC, P, Ns, ax.wm[s], root, rstep, sign, tid, nth); break;
+        case 3: generic_stage_inplace<T, 3>(a, ax.n, TC, P, Ns, ax.wm[s], root, rstep, sign, tid, nth); break;
+        case 4: generic_stage_inplace<T, 4>(a, ax.n, TC, P, Ns, ax.wm[s], root, rstep, sign, tid, nth); break;
+        default: generic_stage_inplace<T, 5>(a, ax.n, TC, P, Ns, ax.wm[s], root, rstep, sign, tid, nth);
       }
       sync();
       Ns *= ax.f[s];
@@ -289,7 +290,7 @@ RF_HD cplx<T>* generic_line_fft(cplx<T>* a, cplx<T>* b, const GenericAxis& ax, i
     return a;
   }
   for (int s = 0; s < ax.nf; ++s) {
-    generic_stage<T>(a, b, ax.n, TC, ax.f[s], Ns, ax.wm[s], root, rstep, sign, tid, nth);
+    generic_stage<T>(a, b, ax.n, TC, P, ax.f[s], Ns, ax.wm[s], root, rstep, sign, tid, nth);
     sync();
     Ns *= ax.f[s];
     cplx<T>* t = a; a = b; b = t;
@@ -321,7 +322,7 @@ RF_HD void generic_axis_block(const cplx<T>* src, cplx<T>* dst, const GenericAxi
     a[generic_pos(ax, e) * TC + c] = v;
   }
   sync();
-  const cplx<T>* r = generic_line_fft<T>(a, b, ax, TC, root, 1, sign, tid, nth, sync);
+  const cplx<T>* r = generic_line_fft<T>(a, b, ax, TC, TC, root, 1, sign, tid, nth, sync);
   i = 0;
   for (int idx = tid; idx < total; idx += nth, ++i) {
     int c, e;
@@ -334,17 +335,23 @@ RF_HD void generic_axis_block(const cplx<T>* src, cplx<T>* dst, const GenericAxi
   }
 }
 
+// Pitch of the LDS image of the contiguous passes (element e of row c at [e * pitch + c]).  Their threads walk ALONG a row on load and
+// store (that is what keeps the global accesses whole lines), i.e. with a stride of `pitch` elements in LDS: at pitch TR = 8 that is
+// 64 bytes and eight lanes share a bank (three quarters of the pass's LDS cycles were conflict cycles: SQ_LDS_BANK_CONFLICT 9.9e8 of
+// SQ_LDS_IDX_ACTIVE 1.3e9 at 1000^3); the odd pitch TR + 1 spreads both that walk and the stages' walk along c over all banks.
+RF_HD int generic_row_pitch(int TR) { return TR > 1 ? TR + 1 : TR; }
+
 // Contiguous pass of the packed inverse transform: rows of M + 1 = nz/2 + 1 half-spectrum bins -> nz reals.
 // With w = exp(2 pi i / nz):  z[m] = x[2m] + i x[2m+1] = IDFT_M( (X[k] + conj X[M-k]) + i w^k (X[k] - conj X[M-k]) ),
 // the imaginary parts of X[0] and X[M] being ignored.  `ax` factors M; root = exp(2 pi i t / nz), t in [0, nz).
 // Block `blk` owns rows [blk TR, blk TR + TR); the calling thread's share of (sum, sum of squares) of the outputs
-// (after `scale`) is added to s1, s2.  lds: generic_bufs(ax) * M * TR elements.
+// (after `scale`) is added to s1, s2.  lds: generic_bufs(ax) * M * generic_row_pitch(TR) elements.
 template <typename T, class Sync>
 RF_HD void generic_row_c2r_block(const cplx<T>* G, T* W, const GenericAxis& ax, long long nrows, int TR, const cplx<T>* root,
                                  T scale, cplx<T>* lds, long long blk, int tid, int nth, Sync sync, double& s1, double& s2) {
-  const int M = ax.n, total = M * TR;
+  const int M = ax.n, total = M * TR, P = generic_row_pitch(TR);
   const long long r0 = blk * TR;
-  cplx<T>*a = lds, *b = lds + total;
+  cplx<T>*a = lds, *b = lds + M * P;
   const FastDiv dM((uint32_t)M);
   for (int idx = tid; idx < total; idx += nth) {
     uint32_t cq, kr;
@@ -363,16 +370,16 @@ RF_HD void generic_row_c2r_block(const cplx<T>* G, T* W, const GenericAxis& ax, 
         z = mk<T>(er - (w.x * oi + w.y * orr), ei + (w.x * orr - w.y * oi));
       }
     }
-    a[generic_pos(ax, k) * TR + c] = z;
+    a[generic_pos(ax, k) * P + c] = z;
   }
   sync();
-  const cplx<T>* r = generic_line_fft<T>(a, b, ax, TR, root, 2, +1, tid, nth, sync);
+  const cplx<T>* r = generic_line_fft<T>(a, b, ax, TR, P, root, 2, +1, tid, nth, sync);
   for (int idx = tid; idx < total; idx += nth) {
     uint32_t cq, mr;
     dM.divmod((uint32_t)idx, cq, mr);
     const int m = (int)mr, c = (int)cq;
     if (r0 + c < nrows) {
-      const cplx<T> v = r[m * TR + c];
+      const cplx<T> v = r[m * P + c];
       const T x0 = v.x * scale, x1 = v.y * scale;
       T* out = W + (r0 + c) * (long long)(2 * M) + 2 * m;
       out[0] = x0;
@@ -388,9 +395,9 @@ RF_HD void generic_row_c2r_block(const cplx<T>* G, T* W, const GenericAxis& ax, 
 template <typename T, class Sync>
 RF_HD void generic_row_r2c_block(const T* W, cplx<T>* G, const GenericAxis& ax, long long nrows, int TR, const cplx<T>* root,
                                  cplx<T>* lds, long long blk, int tid, int nth, Sync sync) {
-  const int M = ax.n, total = M * TR;
+  const int M = ax.n, total = M * TR, P = generic_row_pitch(TR);
   const long long r0 = blk * TR;
-  cplx<T>*a = lds, *b = lds + total;
+  cplx<T>*a = lds, *b = lds + M * P;
   const FastDiv dM((uint32_t)M), dM1((uint32_t)(M + 1));
   for (int idx = tid; idx < total; idx += nth) {
     uint32_t cq, mr;
@@ -401,17 +408,17 @@ RF_HD void generic_row_r2c_block(const T* W, cplx<T>* G, const GenericAxis& ax, 
       const T* in = W + (r0 + c) * (long long)(2 * M) + 2 * m;
       z = mk<T>(in[0], in[1]);
     }
-    a[generic_pos(ax, m) * TR + c] = z;
+    a[generic_pos(ax, m) * P + c] = z;
   }
   sync();
-  const cplx<T>* r = generic_line_fft<T>(a, b, ax, TR, root, 2, -1, tid, nth, sync);
+  const cplx<T>* r = generic_line_fft<T>(a, b, ax, TR, P, root, 2, -1, tid, nth, sync);
   const int totalo = (M + 1) * TR;
   for (int idx = tid; idx < totalo; idx += nth) {
     uint32_t cq, kr;
     dM1.divmod((uint32_t)idx, cq, kr);
     const int k = (int)kr, c = (int)cq;
     if (r0 + c < nrows) {
-      const cplx<T> p = r[(k == M ? 0 : k) * TR + c], q = r[(k == 0 ? 0 : M - k) * TR + c];
+      const cplx<T> p = r[(k == M ? 0 : k) * P + c], q = r[(k == 0 ? 0 : M - k) * P + c];
       const T er = (T)0.5 * (p.x + q.x), ei = (T)0.5 * (p.y - q.y), orr = (T)0.5 * (p.x - q.x), oi = (T)0.5 * (p.y + q.y);
       cplx<T> w = root[k];
       w.y = -w.y;
@@ -523,7 +530,7 @@ RF_HD void generic_lines_block(const cplx<T>* src, cplx<T>* dst, const GenericLi
     a[generic_pos(L.ax, e) * TC + c] = v;
   }
   sync();
-  const cplx<T>* r = generic_line_fft<T>(a, b, L.ax, TC, root, L.rstep, L.sign, tid, nth, sync);
+  const cplx<T>* r = generic_line_fft<T>(a, b, L.ax, TC, TC, root, L.rstep, L.sign, tid, nth, sync);
   const T scale = (T)L.scale;
   i = 0;
   for (int idx = tid; idx < total; idx += nth, ++i) {
@@ -650,9 +657,9 @@ int generic_c2c_seq(Ops& ops, const GenericDims& d, void* D, void* G, int sign, 
 
 // lines / rows per block so that the two LDS buffers stay within 64 KB (no function attribute needed); a single line longer than
 // that (n > 4096 complex64 / 2048 complex128) takes what it needs, up to GENERIC_LDS_MAX
-inline int generic_lines_per_block(int n, int elem_bytes, int want, long long budget = 65536, int bufs = 2) {
+inline int generic_lines_per_block(int n, int elem_bytes, int want, long long budget = 65536, int bufs = 2, bool row_pitch = false) {
   int tc = want;
-  while (tc > 1 && (long long)bufs * n * tc * elem_bytes > budget) tc >>= 1;
+  while (tc > 1 && (long long)bufs * n * (row_pitch ? generic_row_pitch(tc) : tc) * elem_bytes > budget) tc >>= 1;
   return tc;
 }
 

@@ -85,21 +85,15 @@ __global__ __launch_bounds__(256) void generic_moments_kernel(const T* __restric
 }
 
 // Lines per workgroup, threads and LDS bytes of a strided pass over lines of n elements of `es` bytes.  Neighbouring lines are
-// neighbours in memory, so tc lines give segments of tc * es bytes: 16 lines when two workgroups of them still share a CU's LDS, else
-// whatever keeps the segments at 64 bytes or more (one workgroup per CU then); enough threads for 16 waves per CU either way -- the
-// stages are chains of dependent LDS and table reads with a barrier between them, and latency is all that bounds them.
+// neighbours in memory, so tc lines give segments of tc * es bytes: the widest tile up to 16 lines that fits a CU's LDS (128-byte
+// segments with one workgroup per CU beat 64-byte ones with two: 1000^3 14.6 against 16.3 ms); enough threads for 16 waves per CU --
+// the stages are chains of dependent LDS and table reads with a barrier between them, and latency is what bounds them.
 struct StridedShape { int tc, threads; size_t lds; };
 inline StridedShape strided_shape(const GenericAxis& ax, int es, bool neighbours) {
   const int n = ax.n, bufs = generic_bufs(ax);
   auto lds = [&](int tc) { return (size_t)bufs * n * tc * es; };
   int tc = neighbours ? 16 : 4;
-  while (tc > 1 && lds(tc) > (size_t)GENERIC_LDS_MAX / 2) tc >>= 1;
-  const int seg = 64 / es;                                             // lines per 64-byte segment
-  if (neighbours && tc < seg) {
-    int t2 = seg;
-    while (t2 > tc && lds(t2) > (size_t)GENERIC_LDS_MAX) t2 >>= 1;
-    tc = t2;
-  }
+  while (tc > 1 && lds(tc) > (size_t)GENERIC_LDS_MAX) tc >>= 1;
   const int per_cu = (int)((size_t)(GENERIC_LDS_MAX + 256) / (lds(tc) > 0 ? lds(tc) : 1));
   int threads = 256;
   while (threads < 1024 && per_cu * threads < 1024 && (long long)n * tc >= 4LL * threads) threads <<= 1;
@@ -142,7 +136,7 @@ hipError_t axis_t(const void* src, void* dst, const GenericAxis& ax, long long s
   return hipGetLastError();
 }
 
-template <typename T> int rows_per_block(const GenericAxis& ax) { return generic_lines_per_block(ax.n, (int)sizeof(cplx<T>), 8, 49152, generic_bufs(ax)); }   // + the reduction's static LDS
+template <typename T> int rows_per_block(const GenericAxis& ax) { return generic_lines_per_block(ax.n, (int)sizeof(cplx<T>), 8, 49152, generic_bufs(ax), true); }   // + the reduction's static LDS
 
 }  // namespace
 
@@ -187,7 +181,7 @@ hipError_t launch_generic_row_c2r(int f64, const void* G, void* W, const Generic
   if (nblk <= 0 || nblk > 0x7fffffffLL) return hipErrorInvalidValue;
   if (f64) {
     const int tr = rows_per_block<double>(ax);
-    const size_t lds = (size_t)generic_bufs(ax) * ax.n * tr * sizeof(cplx<double>);
+    const size_t lds = (size_t)generic_bufs(ax) * ax.n * generic_row_pitch(tr) * sizeof(cplx<double>);
     if (lds > (size_t)GENERIC_LDS_MAX) return hipErrorInvalidValue;
     static LdsAttrLatch latch;
     if (lds > 49152)
@@ -196,7 +190,7 @@ hipError_t launch_generic_row_c2r(int f64, const void* G, void* W, const Generic
                        (const cplx<double>*)G, (double*)W, ax, nrows, tr, (const cplx<double>*)root, scale, partials);
   } else {
     const int tr = rows_per_block<float>(ax);
-    const size_t lds = (size_t)generic_bufs(ax) * ax.n * tr * sizeof(cplx<float>);
+    const size_t lds = (size_t)generic_bufs(ax) * ax.n * generic_row_pitch(tr) * sizeof(cplx<float>);
     if (lds > (size_t)GENERIC_LDS_MAX) return hipErrorInvalidValue;
     static LdsAttrLatch latch;
     if (lds > 49152)
@@ -213,7 +207,7 @@ hipError_t launch_generic_row_r2c(int f64, const void* W, void* G, const Generic
   if (nblk <= 0 || nblk > 0x7fffffffLL) return hipErrorInvalidValue;
   if (f64) {
     const int tr = rows_per_block<double>(ax);
-    const size_t lds = (size_t)generic_bufs(ax) * ax.n * tr * sizeof(cplx<double>);
+    const size_t lds = (size_t)generic_bufs(ax) * ax.n * generic_row_pitch(tr) * sizeof(cplx<double>);
     if (lds > (size_t)GENERIC_LDS_MAX) return hipErrorInvalidValue;
     static LdsAttrLatch latch;
     if (lds > 49152)
@@ -222,7 +216,7 @@ hipError_t launch_generic_row_r2c(int f64, const void* W, void* G, const Generic
                        (const double*)W, (cplx<double>*)G, ax, nrows, tr, (const cplx<double>*)root);
   } else {
     const int tr = rows_per_block<float>(ax);
-    const size_t lds = (size_t)generic_bufs(ax) * ax.n * tr * sizeof(cplx<float>);
+    const size_t lds = (size_t)generic_bufs(ax) * ax.n * generic_row_pitch(tr) * sizeof(cplx<float>);
     if (lds > (size_t)GENERIC_LDS_MAX) return hipErrorInvalidValue;
     static LdsAttrLatch latch;
     if (lds > 49152)

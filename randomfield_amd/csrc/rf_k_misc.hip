@@ -57,16 +57,22 @@ __global__ __launch_bounds__(64) void peer_mark_kernel(void* const* __restrict__
   if (t < n && bases[t]) reinterpret_cast<unsigned long long*>(bases[t])[slot] = value;
 }
 
+// Rows (ix, iy) of the half spectrum: blockDim.x threads walk along kz, blockDim.y rows per workgroup (short rows share a wave); a
+// row's indices are formed once per row with 32-bit divisions -- the flat form paid four 64-bit divisions per cell, more than the
+// cell's own arithmetic.
 template <typename T>
-__global__ __launch_bounds__(256) void gen_kspace_kernel(cplx<T>* __restrict__ K, GenParams gp) {
+__global__ __launch_bounds__(256) void gen_kspace_kernel(cplx<T>* __restrict__ K, GenParams gp, unsigned nrows) {
   const int nzh = gp.zpitch;            // this rank's planes + the Nyquist plane (nz/2 + 1 on one rank)
-  const long long total = (long long)gp.nx * gp.ny * nzh;
   const uint64_t seed = gp.seed_dev ? *gp.seed_dev : gp.seed;
-  for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += (long long)gridDim.x * blockDim.x) {
-    const int sl = (int)(c % nzh), iz = sl == nzh - 1 ? gp.nz / 2 : gp.zoff + sl;
-    const long long col = c / nzh;
-    const int iy = (int)(col % gp.ny), ix = (int)(col / gp.ny);
-    K[c] = gen_cell<T>(gp, seed, ix, iy, iz);
+  for (unsigned long long r0 = (unsigned long long)blockIdx.x * blockDim.y; r0 < nrows; r0 += (unsigned long long)gridDim.x * blockDim.y) {
+    const unsigned long long rr = r0 + threadIdx.y;
+    if (rr >= nrows) continue;
+    const unsigned row = (unsigned)rr, ix = row / (unsigned)gp.ny, iy = row - ix * (unsigned)gp.ny;
+    cplx<T>* Kr = K + (long long)row * nzh;
+    for (int sl = threadIdx.x; sl < nzh; sl += blockDim.x) {
+      const int iz = sl == nzh - 1 ? gp.nz / 2 : gp.zoff + sl;
+      Kr[sl] = gen_cell<T>(gp, seed, (int)ix, (int)iy, iz);
+    }
   }
 }
 
@@ -428,9 +434,16 @@ hipError_t launch_peer_mark(void* const* bases_dev, int n, int slot, unsigned lo
 }
 
 hipError_t launch_gen_kspace(int f64, void* K, const GenParams& gp, hipStream_t s) {
-  const long long total = (long long)gp.nx * gp.ny * gp.zpitch;
-  if (f64) hipLaunchKernelGGL(gen_kspace_kernel<double>, dim3(grid_for(total, 256)), dim3(256), 0, s, (cplx<double>*)K, gp);
-  else hipLaunchKernelGGL(gen_kspace_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, s, (cplx<float>*)K, gp);
+  const long long nrows = (long long)gp.nx * gp.ny;
+  if (nrows <= 0 || nrows > 0x7fffffffLL) return hipErrorInvalidValue;
+  // 256 threads: tx along a row (the power of two that covers it, up to 256), ty rows per workgroup; many rows: a grid-stride loop
+  int tx = 1;
+  while (tx < 256 && tx < gp.zpitch) tx <<= 1;
+  const int ty = 256 / tx;
+  const long long nblk = (nrows + ty - 1) / ty;
+  const unsigned grid = (unsigned)(nblk < (1LL << 22) ? nblk : (1LL << 22));
+  if (f64) hipLaunchKernelGGL(gen_kspace_kernel<double>, dim3(grid), dim3(tx, ty), 0, s, (cplx<double>*)K, gp, (unsigned)nrows);
+  else hipLaunchKernelGGL(gen_kspace_kernel<float>, dim3(grid), dim3(tx, ty), 0, s, (cplx<float>*)K, gp, (unsigned)nrows);
   return hipGetLastError();
 }
 
