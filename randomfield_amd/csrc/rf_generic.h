@@ -313,13 +313,33 @@ RF_HD void generic_axis_block(const cplx<T>* src, cplx<T>* dst, const GenericAxi
   const long long lf = l0 + walk.c0;
   const long long basef = walk.fixed && lf < nlines ? (lf / inner) * outer + lf % inner : 0;
   int i = 0;
-  for (int idx = tid; idx < total; idx += nth, ++i) {
-    int c, e;
-    walk.at(idx, i, c, e);
-    const long long l = l0 + c;
-    cplx<T> v = mk<T>((T)0, (T)0);
-    if (l < nlines) v = src[(walk.fixed ? basef : (l / inner) * outer + l % inner) + e * stride];
-    a[generic_pos(ax, e) * TC + c] = v;
+  if (walk.fixed) {
+    // four loads in flight per thread before the first is used (the loop below, left to the compiler, waits for each load in turn:
+    // the position of the LDS write is a run-time loop over the radices)
+    const bool live = lf < nlines;
+    for (int e = walk.e0; e < n; e += 4 * walk.estep) {
+      cplx<T> v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int ee = e + u * walk.estep;
+        v[u] = mk<T>((T)0, (T)0);
+        if (live && ee < n) v[u] = src[basef + ee * stride];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int ee = e + u * walk.estep;
+        if (ee < n) a[generic_pos(ax, ee) * TC + walk.c0] = v[u];
+      }
+    }
+  } else {
+    for (int idx = tid; idx < total; idx += nth, ++i) {
+      int c, e;
+      walk.at(idx, i, c, e);
+      const long long l = l0 + c;
+      cplx<T> v = mk<T>((T)0, (T)0);
+      if (l < nlines) v = src[(l / inner) * outer + l % inner + e * stride];
+      a[generic_pos(ax, e) * TC + c] = v;
+    }
   }
   sync();
   const cplx<T>* r = generic_line_fft<T>(a, b, ax, TC, TC, root, 1, sign, tid, nth, sync);
@@ -353,24 +373,37 @@ RF_HD void generic_row_c2r_block(const cplx<T>* G, T* W, const GenericAxis& ax, 
   const long long r0 = blk * TR;
   cplx<T>*a = lds, *b = lds + M * P;
   const FastDiv dM((uint32_t)M);
-  for (int idx = tid; idx < total; idx += nth) {
-    uint32_t cq, kr;
-    dM.divmod((uint32_t)idx, cq, kr);
-    const int k = (int)kr, c = (int)cq;             // consecutive threads walk along a row
-    cplx<T> z = mk<T>((T)0, (T)0);
-    if (r0 + c < nrows) {
-      const cplx<T>* X = G + (r0 + c) * (long long)(M + 1);
-      if (k == 0) {
-        z = mk<T>(X[0].x + X[M].x, X[0].x - X[M].x);
+  // four elements per trip, their loads issued before the first is used (see generic_axis_block)
+  for (int idx0 = tid; idx0 < total; idx0 += 4 * nth) {
+    cplx<T> pv[4], qv[4], wv[4];
+    int kk[4], cc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = idx0 + u * nth;
+      uint32_t cq = 0, kr = 0;
+      if (idx < total) dM.divmod((uint32_t)idx, cq, kr);
+      kk[u] = (int)kr; cc[u] = (int)cq;             // consecutive threads walk along a row
+      pv[u] = qv[u] = wv[u] = mk<T>((T)0, (T)0);
+      if (idx < total && r0 + cc[u] < nrows) {
+        const cplx<T>* X = G + (r0 + cc[u]) * (long long)(M + 1);
+        pv[u] = X[kk[u]]; qv[u] = X[M - kk[u]];     // conj X[M-k] = (q.x, -q.y); k = 0 reads X[0] and X[M]
+        wv[u] = root[kk[u]];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (idx0 + u * nth >= total) continue;
+      const cplx<T> p = pv[u], q = qv[u], w = wv[u];
+      cplx<T> z;
+      if (kk[u] == 0) {
+        z = mk<T>(p.x + q.x, p.x - q.x);
       } else {
-        const cplx<T> p = X[k], q = X[M - k];       // conj X[M-k] = (q.x, -q.y)
         const T er = p.x + q.x, ei = p.y - q.y, orr = p.x - q.x, oi = p.y + q.y;
-        const cplx<T> w = root[k];
         // e + i w o
         z = mk<T>(er - (w.x * oi + w.y * orr), ei + (w.x * orr - w.y * oi));
       }
+      a[generic_pos(ax, kk[u]) * P + cc[u]] = z;
     }
-    a[generic_pos(ax, k) * P + c] = z;
   }
   sync();
   const cplx<T>* r = generic_line_fft<T>(a, b, ax, TR, P, root, 2, +1, tid, nth, sync);
