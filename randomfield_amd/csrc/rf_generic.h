@@ -298,17 +298,32 @@ RF_HD cplx<T>* generic_line_fft(cplx<T>* a, cplx<T>* b, const GenericAxis& ax, i
   return a;
 }
 
+// The stages' twiddles from LDS instead of the root table in global memory: tw[t] = root[t * rstep], t < n, staged behind the line
+// image(s) by the block functions when the launcher found room for it (`tw_lds`).  A butterfly waits for its R - 1 twiddles before
+// it can start, and with two butterflies per thread and stage there is nothing else to overlap a cache hit's latency with.
+template <typename T>
+RF_HD const cplx<T>* generic_stage_table(int tw_lds, cplx<T>* lds_tw, const cplx<T>* root, int n, int& rstep, int tid, int nth) {
+  if (!tw_lds) return root;
+  for (int t = tid; t < n; t += nth) lds_tw[t] = root[t * rstep];
+  rstep = 1;
+  return lds_tw;                                   // (the caller's barrier before the first stage covers these writes)
+}
+// elements of LDS a block function needs: the line image(s) of pitch P and, with tw_lds, the stage table
+RF_HD long long generic_lds_elems(const GenericAxis& ax, int P, int tw_lds) { return (long long)generic_bufs(ax) * ax.n * P + (tw_lds ? ax.n : 0); }
+
 // Strided (or contiguous) complex pass: block `blk` transforms lines [blk TC, blk TC + TC) of length ax.n;
 // line l starts at (l / inner) * outer + l % inner and its elements are `stride` apart.  src == dst is allowed
 // (a block reads all of its lines before it writes any).  lds: generic_bufs(ax) * ax.n * TC elements.
 template <typename T, class Sync>
 RF_HD void generic_axis_block(const cplx<T>* src, cplx<T>* dst, const GenericAxis& ax, long long stride, long long inner,
                               long long outer, long long nlines, int TC, const cplx<T>* root, int sign, T scale,
-                              cplx<T>* lds, long long blk, int tid, int nth, Sync sync) {
+                              cplx<T>* lds, long long blk, int tid, int nth, Sync sync, int tw_lds = 0) {
   const int n = ax.n, total = n * TC;
   const long long l0 = blk * TC;
   cplx<T>*a = lds, *b = lds + total;
   const GenericWalk walk(n, TC, tid, nth);
+  int rs = 1;
+  const cplx<T>* rt = generic_stage_table<T>(tw_lds, lds + generic_bufs(ax) * total, root, n, rs, tid, nth);
   // (a thread that stays on one line forms that line's base once: the 64-bit division is ~100 instructions)
   const long long lf = l0 + walk.c0;
   const long long basef = walk.fixed && lf < nlines ? (lf / inner) * outer + lf % inner : 0;
@@ -342,7 +357,7 @@ RF_HD void generic_axis_block(const cplx<T>* src, cplx<T>* dst, const GenericAxi
     }
   }
   sync();
-  const cplx<T>* r = generic_line_fft<T>(a, b, ax, TC, TC, root, 1, sign, tid, nth, sync);
+  const cplx<T>* r = generic_line_fft<T>(a, b, ax, TC, TC, rt, rs, sign, tid, nth, sync);
   i = 0;
   for (int idx = tid; idx < total; idx += nth, ++i) {
     int c, e;
@@ -368,10 +383,12 @@ RF_HD int generic_row_pitch(int TR) { return TR > 1 ? TR + 1 : TR; }
 // (after `scale`) is added to s1, s2.  lds: generic_bufs(ax) * M * generic_row_pitch(TR) elements.
 template <typename T, class Sync>
 RF_HD void generic_row_c2r_block(const cplx<T>* G, T* W, const GenericAxis& ax, long long nrows, int TR, const cplx<T>* root,
-                                 T scale, cplx<T>* lds, long long blk, int tid, int nth, Sync sync, double& s1, double& s2) {
+                                 T scale, cplx<T>* lds, long long blk, int tid, int nth, Sync sync, double& s1, double& s2, int tw_lds = 0) {
   const int M = ax.n, total = M * TR, P = generic_row_pitch(TR);
   const long long r0 = blk * TR;
   cplx<T>*a = lds, *b = lds + M * P;
+  int rs = 2;
+  const cplx<T>* rt = generic_stage_table<T>(tw_lds, lds + generic_bufs(ax) * M * P, root, M, rs, tid, nth);
   const FastDiv dM((uint32_t)M);
   // four elements per trip, their loads issued before the first is used (see generic_axis_block)
   for (int idx0 = tid; idx0 < total; idx0 += 4 * nth) {
@@ -406,7 +423,7 @@ RF_HD void generic_row_c2r_block(const cplx<T>* G, T* W, const GenericAxis& ax, 
     }
   }
   sync();
-  const cplx<T>* r = generic_line_fft<T>(a, b, ax, TR, P, root, 2, +1, tid, nth, sync);
+  const cplx<T>* r = generic_line_fft<T>(a, b, ax, TR, P, rt, rs, +1, tid, nth, sync);
   for (int idx = tid; idx < total; idx += nth) {
     uint32_t cq, mr;
     dM.divmod((uint32_t)idx, cq, mr);
@@ -427,10 +444,12 @@ RF_HD void generic_row_c2r_block(const cplx<T>* G, T* W, const GenericAxis& ax, 
 //   Z = DFT_M(x[2m] + i x[2m+1]);  X[k] = (Z[k] + conj Z[M-k]) / 2 - (i / 2) conj(w)^k (Z[k] - conj Z[M-k]),  Z[M] = Z[0].
 template <typename T, class Sync>
 RF_HD void generic_row_r2c_block(const T* W, cplx<T>* G, const GenericAxis& ax, long long nrows, int TR, const cplx<T>* root,
-                                 cplx<T>* lds, long long blk, int tid, int nth, Sync sync) {
+                                 cplx<T>* lds, long long blk, int tid, int nth, Sync sync, int tw_lds = 0) {
   const int M = ax.n, total = M * TR, P = generic_row_pitch(TR);
   const long long r0 = blk * TR;
   cplx<T>*a = lds, *b = lds + M * P;
+  int rs = 2;
+  const cplx<T>* rt = generic_stage_table<T>(tw_lds, lds + generic_bufs(ax) * M * P, root, M, rs, tid, nth);
   const FastDiv dM((uint32_t)M), dM1((uint32_t)(M + 1));
   for (int idx = tid; idx < total; idx += nth) {
     uint32_t cq, mr;
@@ -444,7 +463,7 @@ RF_HD void generic_row_r2c_block(const T* W, cplx<T>* G, const GenericAxis& ax, 
     a[generic_pos(ax, m) * P + c] = z;
   }
   sync();
-  const cplx<T>* r = generic_line_fft<T>(a, b, ax, TR, P, root, 2, -1, tid, nth, sync);
+  const cplx<T>* r = generic_line_fft<T>(a, b, ax, TR, P, rt, rs, -1, tid, nth, sync);
   const int totalo = (M + 1) * TR;
   for (int idx = tid; idx < totalo; idx += nth) {
     uint32_t cq, kr;
@@ -525,11 +544,13 @@ inline GenericLines generic_long_step3(const GenericLong& lg, long long S, long 
 // addressings are the same (step 1); step 3 needs another array.
 template <typename T, class Sync>
 RF_HD void generic_lines_block(const cplx<T>* src, cplx<T>* dst, const GenericLines& L, int TC, const cplx<T>* root, cplx<T>* lds,
-                               long long blk, int tid, int nth, Sync sync) {
+                               long long blk, int tid, int nth, Sync sync, int tw_lds = 0) {
   const int n = L.ax.n, total = n * TC;
   const long long l0b = blk * TC, nl = L.nlines();
   cplx<T>*a = lds, *b = lds + total;
   const GenericWalk walk(n, TC, tid, nth);
+  int rs = L.rstep;
+  const cplx<T>* rt = generic_stage_table<T>(tw_lds, lds + generic_bufs(L.ax) * total, root, n, rs, tid, nth);
   // (a thread that stays on one line forms that line's sub-line index and bases once)
   long long qf = 0, bsf = 0, bdf = 0;
   if (walk.fixed && l0b + walk.c0 < nl) {
@@ -563,7 +584,7 @@ RF_HD void generic_lines_block(const cplx<T>* src, cplx<T>* dst, const GenericLi
     a[generic_pos(L.ax, e) * TC + c] = v;
   }
   sync();
-  const cplx<T>* r = generic_line_fft<T>(a, b, L.ax, TC, TC, root, L.rstep, L.sign, tid, nth, sync);
+  const cplx<T>* r = generic_line_fft<T>(a, b, L.ax, TC, TC, rt, rs, L.sign, tid, nth, sync);
   const T scale = (T)L.scale;
   i = 0;
   for (int idx = tid; idx < total; idx += nth, ++i) {
@@ -692,7 +713,7 @@ int generic_c2c_seq(Ops& ops, const GenericDims& d, void* D, void* G, int sign, 
 // that (n > 4096 complex64 / 2048 complex128) takes what it needs, up to GENERIC_LDS_MAX
 inline int generic_lines_per_block(int n, int elem_bytes, int want, long long budget = 65536, int bufs = 2, bool row_pitch = false) {
   int tc = want;
-  while (tc > 1 && (long long)bufs * n * (row_pitch ? generic_row_pitch(tc) : tc) * elem_bytes > budget) tc >>= 1;
+  while (tc > 1 && ((long long)bufs * n * (row_pitch ? generic_row_pitch(tc) : tc) + n) * elem_bytes > budget) tc >>= 1;     // (+ n: the stage table)
   return tc;
 }
 

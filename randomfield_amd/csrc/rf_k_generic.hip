@@ -10,21 +10,21 @@ struct BlockSync { __device__ void operator()() const { __syncthreads(); } };
 template <typename T>
 __global__ __launch_bounds__(1024) void generic_axis_kernel(const cplx<T>* src, cplx<T>* dst, GenericAxis ax, long long stride,
                                                           long long inner, long long outer, long long nlines, int TC,
-                                                          const cplx<T>* __restrict__ root, int sign, T scale) {
+                                                          const cplx<T>* __restrict__ root, int sign, T scale, int tw_lds) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
   generic_axis_block<T>(src, dst, ax, stride, inner, outer, nlines, TC, root, sign, scale, reinterpret_cast<cplx<T>*>(lds_raw),
-                        (long long)blockIdx.x, (int)threadIdx.x, (int)blockDim.x, BlockSync());
+                        (long long)blockIdx.x, (int)threadIdx.x, (int)blockDim.x, BlockSync(), tw_lds);
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void generic_row_c2r_kernel(const cplx<T>* __restrict__ G, T* __restrict__ W, GenericAxis ax,
                                                              long long nrows, int TR, const cplx<T>* __restrict__ root, T scale,
-                                                             double* __restrict__ partials) {
+                                                             double* __restrict__ partials, int tw_lds) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
   __shared__ double red[2 * 4];
   double s1 = 0.0, s2 = 0.0;
   generic_row_c2r_block<T>(G, W, ax, nrows, TR, root, scale, reinterpret_cast<cplx<T>*>(lds_raw), (long long)blockIdx.x,
-                           (int)threadIdx.x, (int)blockDim.x, BlockSync(), s1, s2);
+                           (int)threadIdx.x, (int)blockDim.x, BlockSync(), s1, s2, tw_lds);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_down(s1, off); s2 += __shfl_down(s2, off); }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -40,17 +40,17 @@ __global__ __launch_bounds__(256) void generic_row_c2r_kernel(const cplx<T>* __r
 
 template <typename T>
 __global__ __launch_bounds__(256) void generic_row_r2c_kernel(const T* __restrict__ W, cplx<T>* __restrict__ G, GenericAxis ax,
-                                                             long long nrows, int TR, const cplx<T>* __restrict__ root) {
+                                                             long long nrows, int TR, const cplx<T>* __restrict__ root, int tw_lds) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
   generic_row_r2c_block<T>(W, G, ax, nrows, TR, root, reinterpret_cast<cplx<T>*>(lds_raw), (long long)blockIdx.x,
-                           (int)threadIdx.x, (int)blockDim.x, BlockSync());
+                           (int)threadIdx.x, (int)blockDim.x, BlockSync(), tw_lds);
 }
 
 // lines with sub-lines (the two steps of the four-step transform of an axis too long for the LDS: rf_generic.h GenericLines)
 template <typename T>
-__global__ __launch_bounds__(1024) void generic_lines_kernel(const cplx<T>* src, cplx<T>* dst, GenericLines L, int TC, const cplx<T>* __restrict__ root) {
+__global__ __launch_bounds__(1024) void generic_lines_kernel(const cplx<T>* src, cplx<T>* dst, GenericLines L, int TC, const cplx<T>* __restrict__ root, int tw_lds) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
-  generic_lines_block<T>(src, dst, L, TC, root, reinterpret_cast<cplx<T>*>(lds_raw), (long long)blockIdx.x, (int)threadIdx.x, (int)blockDim.x, BlockSync());
+  generic_lines_block<T>(src, dst, L, TC, root, reinterpret_cast<cplx<T>*>(lds_raw), (long long)blockIdx.x, (int)threadIdx.x, (int)blockDim.x, BlockSync(), tw_lds);
 }
 template <typename T>
 __global__ __launch_bounds__(256) void generic_untangle_kernel(const cplx<T>* __restrict__ G, cplx<T>* __restrict__ Z, int M, long long total,
@@ -88,16 +88,17 @@ __global__ __launch_bounds__(256) void generic_moments_kernel(const T* __restric
 // neighbours in memory, so tc lines give segments of tc * es bytes: the widest tile up to 16 lines that fits a CU's LDS (128-byte
 // segments with one workgroup per CU beat 64-byte ones with two: 1000^3 14.6 against 16.3 ms); enough threads for 16 waves per CU --
 // the stages are chains of dependent LDS and table reads with a barrier between them, and latency is what bounds them.
-struct StridedShape { int tc, threads; size_t lds; };
+struct StridedShape { int tc, threads; size_t lds; int tw_lds; };
 inline StridedShape strided_shape(const GenericAxis& ax, int es, bool neighbours) {
   const int n = ax.n, bufs = generic_bufs(ax);
-  auto lds = [&](int tc) { return (size_t)bufs * n * tc * es; };
+  auto lds = [&](int tc) { return ((size_t)bufs * n * tc + n) * es; };            // (+ n: the stage table, generic_stage_table)
   int tc = neighbours ? 16 : 4;
   while (tc > 1 && lds(tc) > (size_t)GENERIC_LDS_MAX) tc >>= 1;
+  if (lds(tc) > (size_t)GENERIC_LDS_MAX) return {1, 256, (size_t)bufs * n * es, 0};   // the longest lines that are not smooth: no room for the table
   const int per_cu = (int)((size_t)(GENERIC_LDS_MAX + 256) / (lds(tc) > 0 ? lds(tc) : 1));
   int threads = 256;
   while (threads < 1024 && per_cu * threads < 1024 && (long long)n * tc >= 4LL * threads) threads <<= 1;
-  return {tc, threads, lds(tc)};
+  return {tc, threads, lds(tc), 1};
 }
 
 template <typename T>
@@ -113,7 +114,7 @@ hipError_t lines_t(const void* src, void* dst, const GenericLines& L, const void
   static LdsAttrLatch latch;
   if (lds > 65536)
     if (hipError_t e = latch.ensure((const void*)generic_lines_kernel<T>, GENERIC_LDS_MAX); e != hipSuccess) return e;
-  hipLaunchKernelGGL(generic_lines_kernel<T>, dim3((unsigned)nblk), dim3(sh.threads), lds, s, (const cplx<T>*)src, (cplx<T>*)dst, L, tc, (const cplx<T>*)root);
+  hipLaunchKernelGGL(generic_lines_kernel<T>, dim3((unsigned)nblk), dim3(sh.threads), lds, s, (const cplx<T>*)src, (cplx<T>*)dst, L, tc, (const cplx<T>*)root, sh.tw_lds);
   return hipGetLastError();
 }
 
@@ -132,7 +133,7 @@ hipError_t axis_t(const void* src, void* dst, const GenericAxis& ax, long long s
   if (lds > 65536)
     if (hipError_t e = latch.ensure((const void*)generic_axis_kernel<T>, GENERIC_LDS_MAX); e != hipSuccess) return e;
   hipLaunchKernelGGL(generic_axis_kernel<T>, dim3((unsigned)nblk), dim3(sh.threads), lds, s, (const cplx<T>*)src, (cplx<T>*)dst, ax, stride,
-                     inner, outer, nlines, tc, (const cplx<T>*)root, sign, (T)scale);
+                     inner, outer, nlines, tc, (const cplx<T>*)root, sign, (T)scale, sh.tw_lds);
   return hipGetLastError();
 }
 
@@ -175,56 +176,50 @@ long long generic_row_blocks(int f64, const GenericAxis& ax, long long nrows) {
   return (nrows + tr - 1) / tr;
 }
 
+namespace {
+// rows per workgroup, LDS bytes and whether the stage table fits behind the line image(s)
+struct RowShape { int tr; size_t lds; int tw_lds; };
+template <typename T> RowShape row_shape(const GenericAxis& ax) {
+  const int tr = rows_per_block<T>(ax);
+  const size_t base = (size_t)generic_bufs(ax) * ax.n * generic_row_pitch(tr) * sizeof(cplx<T>), with = base + (size_t)ax.n * sizeof(cplx<T>);
+  const int tw = with <= (size_t)GENERIC_LDS_MAX ? 1 : 0;
+  return {tr, tw ? with : base, tw};
+}
+template <typename T>
+hipError_t row_c2r_t(const void* G, void* W, const GenericAxis& ax, long long nrows, const void* root, double scale, double* partials, long long nblk, hipStream_t s) {
+  const RowShape sh = row_shape<T>(ax);
+  if (sh.lds > (size_t)GENERIC_LDS_MAX) return hipErrorInvalidValue;
+  static LdsAttrLatch latch;
+  if (sh.lds > 49152)
+    if (hipError_t e = latch.ensure((const void*)generic_row_c2r_kernel<T>, GENERIC_LDS_MAX); e != hipSuccess) return e;
+  hipLaunchKernelGGL(generic_row_c2r_kernel<T>, dim3((unsigned)nblk), dim3(256), sh.lds, s, (const cplx<T>*)G, (T*)W, ax, nrows, sh.tr, (const cplx<T>*)root, (T)scale,
+                     partials, sh.tw_lds);
+  return hipGetLastError();
+}
+template <typename T>
+hipError_t row_r2c_t(const void* W, void* G, const GenericAxis& ax, long long nrows, const void* root, long long nblk, hipStream_t s) {
+  const RowShape sh = row_shape<T>(ax);
+  if (sh.lds > (size_t)GENERIC_LDS_MAX) return hipErrorInvalidValue;
+  static LdsAttrLatch latch;
+  if (sh.lds > 49152)
+    if (hipError_t e = latch.ensure((const void*)generic_row_r2c_kernel<T>, GENERIC_LDS_MAX); e != hipSuccess) return e;
+  hipLaunchKernelGGL(generic_row_r2c_kernel<T>, dim3((unsigned)nblk), dim3(256), sh.lds, s, (const T*)W, (cplx<T>*)G, ax, nrows, sh.tr, (const cplx<T>*)root, sh.tw_lds);
+  return hipGetLastError();
+}
+}  // namespace
+
 hipError_t launch_generic_row_c2r(int f64, const void* G, void* W, const GenericAxis& ax, long long nrows, const void* root,
                                   double scale, double* partials, hipStream_t s) {
   const long long nblk = generic_row_blocks(f64, ax, nrows);
   if (nblk <= 0 || nblk > 0x7fffffffLL) return hipErrorInvalidValue;
-  if (f64) {
-    const int tr = rows_per_block<double>(ax);
-    const size_t lds = (size_t)generic_bufs(ax) * ax.n * generic_row_pitch(tr) * sizeof(cplx<double>);
-    if (lds > (size_t)GENERIC_LDS_MAX) return hipErrorInvalidValue;
-    static LdsAttrLatch latch;
-    if (lds > 49152)
-      if (hipError_t e = latch.ensure((const void*)generic_row_c2r_kernel<double>, GENERIC_LDS_MAX); e != hipSuccess) return e;
-    hipLaunchKernelGGL(generic_row_c2r_kernel<double>, dim3((unsigned)nblk), dim3(256), lds, s,
-                       (const cplx<double>*)G, (double*)W, ax, nrows, tr, (const cplx<double>*)root, scale, partials);
-  } else {
-    const int tr = rows_per_block<float>(ax);
-    const size_t lds = (size_t)generic_bufs(ax) * ax.n * generic_row_pitch(tr) * sizeof(cplx<float>);
-    if (lds > (size_t)GENERIC_LDS_MAX) return hipErrorInvalidValue;
-    static LdsAttrLatch latch;
-    if (lds > 49152)
-      if (hipError_t e = latch.ensure((const void*)generic_row_c2r_kernel<float>, GENERIC_LDS_MAX); e != hipSuccess) return e;
-    hipLaunchKernelGGL(generic_row_c2r_kernel<float>, dim3((unsigned)nblk), dim3(256), lds, s,
-                       (const cplx<float>*)G, (float*)W, ax, nrows, tr, (const cplx<float>*)root, (float)scale, partials);
-  }
-  return hipGetLastError();
+  return f64 ? row_c2r_t<double>(G, W, ax, nrows, root, scale, partials, nblk, s) : row_c2r_t<float>(G, W, ax, nrows, root, scale, partials, nblk, s);
 }
 
 hipError_t launch_generic_row_r2c(int f64, const void* W, void* G, const GenericAxis& ax, long long nrows, const void* root,
                                   hipStream_t s) {
   const long long nblk = generic_row_blocks(f64, ax, nrows);
   if (nblk <= 0 || nblk > 0x7fffffffLL) return hipErrorInvalidValue;
-  if (f64) {
-    const int tr = rows_per_block<double>(ax);
-    const size_t lds = (size_t)generic_bufs(ax) * ax.n * generic_row_pitch(tr) * sizeof(cplx<double>);
-    if (lds > (size_t)GENERIC_LDS_MAX) return hipErrorInvalidValue;
-    static LdsAttrLatch latch;
-    if (lds > 49152)
-      if (hipError_t e = latch.ensure((const void*)generic_row_r2c_kernel<double>, GENERIC_LDS_MAX); e != hipSuccess) return e;
-    hipLaunchKernelGGL(generic_row_r2c_kernel<double>, dim3((unsigned)nblk), dim3(256), lds, s,
-                       (const double*)W, (cplx<double>*)G, ax, nrows, tr, (const cplx<double>*)root);
-  } else {
-    const int tr = rows_per_block<float>(ax);
-    const size_t lds = (size_t)generic_bufs(ax) * ax.n * generic_row_pitch(tr) * sizeof(cplx<float>);
-    if (lds > (size_t)GENERIC_LDS_MAX) return hipErrorInvalidValue;
-    static LdsAttrLatch latch;
-    if (lds > 49152)
-      if (hipError_t e = latch.ensure((const void*)generic_row_r2c_kernel<float>, GENERIC_LDS_MAX); e != hipSuccess) return e;
-    hipLaunchKernelGGL(generic_row_r2c_kernel<float>, dim3((unsigned)nblk), dim3(256), lds, s,
-                       (const float*)W, (cplx<float>*)G, ax, nrows, tr, (const cplx<float>*)root);
-  }
-  return hipGetLastError();
+  return f64 ? row_r2c_t<double>(W, G, ax, nrows, root, nblk, s) : row_r2c_t<float>(W, G, ax, nrows, root, nblk, s);
 }
 
 }  // namespace rf
