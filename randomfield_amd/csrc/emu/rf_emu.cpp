@@ -789,6 +789,25 @@ int emu_share_row(int jl, int L, int S, int xs2_phase) {
   io.set_phase(xs2_phase);
   return io.share_row(jl, L, S);
 }
+// generic_pos (rf_generic.h): where element e of a line of n goes in the LDS image of the in-place transform; out[e] = position,
+// returns 1 when the axis is smooth (radices 2..5), 0 when the positions are the identity (two-buffer form), -1 when n does not factor
+int emu_generic_positions(int n, int* out) {
+  GenericAxis ax;
+  if (!generic_factor(n, ax)) return -1;
+  for (int e = 0; e < n; ++e) out[e] = generic_pos(ax, e);
+  return generic_smooth(ax) ? 1 : 0;
+}
+// FastDiv (rf_generic.h): the first a < amax at which a / d or a % d by multiply-high differs from the machine's division; -1 if none
+long long emu_fastdiv_first_error(unsigned d, unsigned amax) {
+  const FastDiv fd(d, generic_magic(d));
+  const FastDiv fd2(d);
+  for (unsigned a = 0; a < amax; ++a) {
+    uint32_t q, r;
+    fd.divmod(a, q, r);
+    if (q != a / d || r != a % d || fd2.div(a) != a / d) return (long long)a;
+  }
+  return -1;
+}
 int emu_xpose_applies(int f64, int nx, int ny, int nz) { return f64 ? xpose_ok<double>(nx, ny, nz / 2) : xpose_ok<float>(nx, ny, nz / 2); }
 
 // full fused realisation: generation + x, y, z passes -> W (real [nx][ny][nz]) and (sum, sumsq)

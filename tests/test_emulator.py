@@ -467,6 +467,26 @@ def test_sigma_share_row_mapping_is_a_bijection(L, S):
                     assert partner == (L // 2 if q == 0 else L - q)
 
 
+def test_generic_in_place_positions_and_fast_division():
+    """rf_generic.h: an axis whose radices are all among 2..5 is transformed in place on a line stored in digit-reversed order --
+    generic_pos must be a permutation of [0, n) for such n (and the identity otherwise); and the divisions of the stage loops are
+    multiply-high by a host-formed reciprocal (FastDiv), exact for every numerator the loops can produce (a < n * TC <= 2**17,
+    a * d < 2**32)."""
+    import ctypes
+    lib = emu_util.lib()
+    lib.emu_fastdiv_first_error.restype = ctypes.c_longlong
+    for n in (2, 4, 6, 8, 10, 12, 60, 96, 100, 250, 500, 768, 960, 1000, 1024, 3000, 4096, 6000, 8192):
+        out = (ctypes.c_int * n)()
+        assert lib.emu_generic_positions(n, out) == 1, n
+        assert sorted(out) == list(range(n)), n
+    for n in (14, 22, 26, 1019 * 2, 7 * 64):
+        out = (ctypes.c_int * n)()
+        assert lib.emu_generic_positions(n, out) == 0 and list(out) == list(range(n)), n
+    for d in (1, 2, 3, 4, 5, 7, 8, 9, 16, 25, 125, 241, 500, 683, 1000, 1024, 4095, 4096, 4097, 8191, 8192):
+        amax = min(1 << 17, (1 << 32) // d)
+        assert lib.emu_fastdiv_first_error(d, amax) == -1, d
+
+
 @pytest.mark.parametrize("shape,cap", [((40, 60, 80), 16), ((36, 10, 24), 8), ((6, 100, 16), 12), ((4, 6, 192), 16), ((64, 8, 16), 8), ((8, 8, 128), 16)])
 def test_axes_too_long_for_one_line_take_the_four_step_form(shape, cap):
     """Axes longer than a line the LDS holds (the library's cap: 8192 complex64 / 4096 complex128; lowered here so that small grids
