@@ -432,6 +432,25 @@ def main_multi(args, rank, world, local_rank, shape, power, spacing):
     wall = time.perf_counter() - t0
     wall = float(dplan.allreduce([wall], op="max")[0])
     mean, std = plan.moments()
+    # After the timed region: the last timed realisation once more through the OTHER kz-slab exchange (direct <-> rccl).  The two must give
+    # the same field (the same cells in the same places), so the same rms to the last bits the all-reduce order leaves: evidence on the
+    # line itself that the mode that was timed moved every tile to where it belongs on this host.
+    cross = None
+    if mode in ("direct", "rccl"):
+        other = "rccl" if mode == "direct" else "direct"
+        try:
+            if set_mode(other):
+                with dplan.deadline("cross-check through the %s exchange" % other):
+                    r = plan.realise_batch(np.array([123 + args.steps - 1], dtype=np.uint64), want_rms=True)
+                    plan.sync()
+                    dplan.barrier()
+                cross = {"other_mode": other, "rms_timed_mode": float(std), "rms_other_mode": float(r[0]),
+                         "agree": bool(np.isclose(float(r[0]), float(std), rtol=1e-6, atol=0))}
+            else:
+                cross = {"other_mode": other, "agree": None, "note": "the other mode is not available for this job"}
+        finally:
+            set_mode(mode)
+            plan.set_exchange_chunks(chunks)
     rccl_ranks = plan.comm_size()                      # what RCCL itself says the communicator spans (ncclCommCount)
     # the N = 1 equivalent in the SAME job: every rank times the per-GPU cube (edge^3, what `--gpus 1` runs: `steps` realisations
     # replayed from one hipGraph) alone on its own GPU, no communicator involved; slowest and fastest rank reported
@@ -490,7 +509,7 @@ def main_multi(args, rank, world, local_rank, shape, power, spacing):
                    "grid": [nx, ny, nz], "rms_last": round(std, 6), "multi_gpu_mode": mode, "exchange_sub_slabs": chunks, "rccl_ranks": rccl_ranks,
                    "launcher": "bench.py's own child ranks" if os.environ.get("RANDOMFIELD_LAUNCH_NONCE", "").startswith("bench-") else "external (torch.distributed.run)",
                    "mode_calibration_ms_per_step": {k: round(v, 3) for k, v in calib.items()},
-                   "modes_rejected": rejected},
+                   "modes_rejected": rejected, "exchange_cross_check": cross},
         "single_gpu_equivalent": {"ms_per_step": round(t_single_max, 4), "ms_per_step_fastest_rank": round(t_single_min, 4),
                                   "grid": [e, e, e], "Mcells_s": round(float(e) ** 3 / t_single_max / 1e3, 1),
                                   "speedup_of_this_job": round(cells * args.steps / wall / (float(e) ** 3 / (t_single_max * 1e-3)), 3),

@@ -1908,6 +1908,10 @@ def test_bench_multi_gpu_code_path_with_one_rank(hip):
     cal = line["config"]["mode_calibration_ms_per_step"]
     assert cal["rccl"] > 0 and cal["direct"] > 0 and line["config"]["modes_rejected"] == {}
     assert line["config"]["multi_gpu_mode"] in ("rccl", "direct") and line["config"]["exchange_sub_slabs"] in (1, 4)
+    # ... and the last timed realisation went through the other exchange once more after the timed region: same rms
+    cross = line["config"]["exchange_cross_check"]
+    assert cross["agree"] is True and cross["other_mode"] != line["config"]["multi_gpu_mode"]
+    assert abs(cross["rms_timed_mode"] - line["config"]["rms_last"]) < 1e-5
 
 
 def test_two_distributed_plans_in_a_row(hip, dpower, monkeypatch, tmp_path):
