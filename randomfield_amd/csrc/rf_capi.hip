@@ -110,13 +110,16 @@ bool generic_dims(int nx, int ny, int nz, int f64, bool packed, GenericDims& d) 
   const int cap = generic_max_axis(f64);
   d = GenericDims();
   d.nx = nx; d.ny = ny; d.nz = nz; d.csize = f64 ? 16 : 8;
-  auto one = [&](long long n, GenericAxis& ax, GenericLong& lg) {
+  auto one = [&](long long n, GenericAxis& ax, GenericLong& lg, bool strided) {
     lg = GenericLong();
-    if (n <= cap) return generic_factor((int)n, ax);
-    return generic_split(n, cap, lg);
+    if (n > cap) return generic_split(n, cap, lg);
+    if (!generic_factor((int)n, ax)) return false;
+    // a strided line that fits, but only one or two to a workgroup: the four-step form if the length splits (rf_generic.h)
+    if (strided && generic_prefers_split(ax, (int)d.csize) && !generic_split(n, cap, lg)) lg = GenericLong();
+    return true;
   };
   // (a packed plan's root table of the contiguous axis has nz entries; nz itself must stay addressable: nz / 2 <= cap^2 is the limit that bites)
-  return one(nx, d.ax, d.lx) && one(ny, d.ay, d.ly) && one(packed ? nz / 2 : nz, d.az, d.lz);
+  return one(nx, d.ax, d.lx, true) && one(ny, d.ay, d.ly, true) && one(packed ? nz / 2 : nz, d.az, d.lz, false);
 }
 bool generic_shape(int nx, int ny, int nz, int f64, GenericAxis& ax, GenericAxis& ay, GenericAxis& az_half) {
   GenericDims d;

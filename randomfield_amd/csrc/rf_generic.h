@@ -645,6 +645,20 @@ RF_HD void generic_tangle_at(const cplx<T>* Z, cplx<T>* G, int M, const cplx<T>*
 //   untangle(G, Z) / tangle(Z, G) / moments(W)                             the pieces of the contiguous passes for long rows
 //   copy(dst, src, bytes)
 // ---------------------------------------------------------------------------
+// Lines of a strided pass that go into one workgroup together (neighbours in memory: tc lines = segments of tc elements): the widest
+// tile up to 16 whose image(s) and stage table fit a CU's LDS (rf_k_generic.hip strided_shape launches exactly this).  Below 4 lines
+// the segments are 16 bytes of complex64 and a pass moves a fraction of what the memory system can: generic_prefers_split.
+inline int generic_strided_tile(const GenericAxis& ax, int elem_bytes) {
+  auto lds = [&](int tc) { return ((long long)generic_bufs(ax) * ax.n * tc + ax.n) * elem_bytes; };
+  int tc = 16;
+  while (tc > 1 && lds(tc) > (long long)GENERIC_LDS_MAX) tc >>= 1;
+  return tc;
+}
+// A strided axis that fits one line of the LDS but only one or two lines per workgroup is faster in the four-step form, whose factors
+// go 16 lines to a workgroup (measured, 1000-cell transverse planes: 4096 points 0.49 -> 0.40 ms, 8192 points 0.36 -> 0.27 ms per
+// realisation; 2000 points -- 4 lines -- 1.25 against 1.54: stays one pass).  Contiguous axes never: their lines ARE the segments.
+inline bool generic_prefers_split(const GenericAxis& ax, int elem_bytes) { return generic_strided_tile(ax, elem_bytes) < 4; }
+
 struct GenericDims {
   int nx = 0, ny = 0, nz = 0;
   GenericAxis ax, ay, az;               // az factors nz / 2 (packed plans) or nz (c2c plans); unused where the long form applies

@@ -92,7 +92,7 @@ struct StridedShape { int tc, threads; size_t lds; int tw_lds; };
 inline StridedShape strided_shape(const GenericAxis& ax, int es, bool neighbours) {
   const int n = ax.n, bufs = generic_bufs(ax);
   auto lds = [&](int tc) { return ((size_t)bufs * n * tc + n) * es; };            // (+ n: the stage table, generic_stage_table)
-  int tc = neighbours ? 16 : 4;
+  int tc = neighbours ? generic_strided_tile(ax, es) : 4;
   while (tc > 1 && lds(tc) > (size_t)GENERIC_LDS_MAX) tc >>= 1;
   if (lds(tc) > (size_t)GENERIC_LDS_MAX) return {1, 256, (size_t)bufs * n * es, 0};   // the longest lines that are not smooth: no room for the table
   const int per_cu = (int)((size_t)(GENERIC_LDS_MAX + 256) / (lds(tc) > 0 ? lds(tc) : 1));

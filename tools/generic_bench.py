@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Timing of the generic (non-power-of-two) path: realisations on grids such as 1000^3 against the tiled 1024^3.
-usage: generic_bench.py [edge ...]"""
+usage: generic_bench.py [--lib variant.so] [edge | NXxNYxNZ ...]"""
 import os
 import sys
 import time
@@ -34,6 +34,9 @@ def run(shape, ct=np.complex64, reps=3):
 
 
 if __name__ == "__main__":
-    edges = [int(a) for a in sys.argv[1:]] or [500, 512, 1000, 1024]
-    for e in edges:
-        run((e, e, e))
+    args = sys.argv[1:]
+    if args and args[0] == "--lib":
+        _hip.LIB_PATH = os.path.abspath(args[1])
+        args = args[2:]
+    for a in args or ["500", "512", "1000", "1024"]:
+        run(tuple(int(v) for v in a.split("x")) if "x" in a else (int(a),) * 3)
