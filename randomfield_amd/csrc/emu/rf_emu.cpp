@@ -503,6 +503,8 @@ struct NoSync { void operator()() const {} };
 // g_generic_cap: the longest line kept "in LDS" -- the library's cap is 8192 / 4096; tests lower it so that small grids take the
 // four-step form of the long axes.
 int g_generic_cap = 0;                  // 0: generic_max_axis(dtype)
+int g_generic_tile = 3;                 // lines per block of the strided passes: 3 = deliberately not dividing the line counts (the walk by
+                                        // index); 1 = the kernels' walk, a thread staying on one line (GenericWalk::fixed)
 template <typename T> struct EmuGenericOps {
   const cplx<T>*rx, *ry, *rz;
   int nx, ny, nz, M;                    // M = row length of the contiguous complex transform's root table / 2 (packed) -- see callers
@@ -511,14 +513,14 @@ template <typename T> struct EmuGenericOps {
   double s1 = 0, s2 = 0;
   const cplx<T>* root(int which) const { return which == 0 ? rx : (which == 1 ? ry : rz); }
   int axis(const void* src, void* dst, const GenericAxis& ax, long long stride, long long inner, long long outer, long long nlines, int which, int sign, double scale) {
-    const int TC = 3;                   // deliberately not dividing the line counts
+    const int TC = g_generic_tile;
     lds.resize(2 * (size_t)ax.n * TC + ax.n);
     for (long long b = 0; b * TC < nlines; ++b)
       generic_axis_block<T>((const cplx<T>*)src, (cplx<T>*)dst, ax, stride, inner, outer, nlines, TC, root(which), sign, (T)scale, lds.data(), b, 0, 1, NoSync(), 1);
     return 0;
   }
   int lines(const void* src, void* dst, const GenericLines& L, int which) {
-    const int TC = 3;
+    const int TC = g_generic_tile;
     lds.resize(2 * (size_t)L.ax.n * TC + L.ax.n);
     for (long long b = 0; b * TC < L.nlines(); ++b)
       generic_lines_block<T>((const cplx<T>*)src, (cplx<T>*)dst, L, TC, root(which), lds.data(), b, 0, 1, NoSync(), 1);
@@ -778,6 +780,7 @@ int emu_set_rowblock(int rb) { const int old = g_rowblock; g_rowblock = rb; retu
 // the longest line the generic path keeps whole (0 = the library's cap, 8192 complex64 / 4096 complex128): longer axes take the four-step
 // form -- lowered by tests so that small grids exercise it
 int emu_set_generic_cap(int cap) { const int old = g_generic_cap; g_generic_cap = cap; return old; }
+int emu_set_generic_tile(int tc) { const int old = g_generic_tile; g_generic_tile = tc > 0 ? tc : 3; return old; }
 // 1 (default): the float32 generation pass of length 1024 on tile pairs (ColPair), as the product; 0: one tile per workgroup (ColFFT)
 int emu_set_pairs(int on) { const int old = g_pairs; g_pairs = on; return old; }
 // FastGenColIOT::share_row (rf_fft_gen.h): the butterfly row of slot jl when L butterflies are dealt to slots of S per wave so that

@@ -561,27 +561,59 @@ RF_HD void generic_lines_block(const cplx<T>* src, cplx<T>* dst, const GenericLi
     bdf = (l0 / L.inner_d) * L.outer_d + l0 % L.inner_d + qf * L.sub_d;
   }
   int i = 0;
-  for (int idx = tid; idx < total; idx += nth, ++i) {
-    int c, e;
-    walk.at(idx, i, c, e);
-    const long long l = l0b + c;
-    cplx<T> v = mk<T>((T)0, (T)0);
-    if (l < nl) {
-      long long q = qf, bs = bsf;
-      if (!walk.fixed) {
-        q = l / L.nparent;
-        const long long l0 = l - q * L.nparent;
-        bs = (l0 / L.inner_s) * L.outer_s + l0 % L.inner_s + q * L.sub_s;
+  if (walk.fixed) {
+    // four loads (and their twiddles) in flight per thread; the twiddle index (e q) mod tw_n advances by (estep q) mod tw_n per
+    // element -- one 64-bit modulo per thread instead of one per element
+    const bool live = l0b + walk.c0 < nl;
+    const bool twid = L.tw_n > 0;
+    long long t = twid ? ((long long)walk.e0 * qf) % L.tw_n : 0;
+    const long long dt = twid ? ((long long)walk.estep * qf) % L.tw_n : 0;
+    for (int e = walk.e0; e < n; e += 4 * walk.estep) {
+      cplx<T> v[4], w[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int ee = e + u * walk.estep;
+        v[u] = mk<T>((T)0, (T)0);
+        w[u] = mk<T>((T)1, (T)0);
+        if (live && ee < n) {
+          v[u] = src[bsf + ee * L.stride_s];
+          if (twid) w[u] = root[t * L.tw_step];
+        }
+        t += dt;
+        if (t >= L.tw_n) t -= L.tw_n;
       }
-      v = src[bs + e * L.stride_s];
-      if (L.tw_n > 0) {
-        const long long t = ((long long)e * q) % L.tw_n;
-        cplx<T> w = root[t * L.tw_step];
-        if (L.sign < 0) w.y = -w.y;
-        v = mk<T>(v.x * w.x - v.y * w.y, v.x * w.y + v.y * w.x);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int ee = e + u * walk.estep;
+        if (ee >= n) continue;
+        cplx<T> x = v[u];
+        if (twid) {
+          cplx<T> ww = w[u];
+          if (L.sign < 0) ww.y = -ww.y;
+          x = mk<T>(x.x * ww.x - x.y * ww.y, x.x * ww.y + x.y * ww.x);
+        }
+        a[generic_pos(L.ax, ee) * TC + walk.c0] = x;
       }
     }
-    a[generic_pos(L.ax, e) * TC + c] = v;
+  } else {
+    for (int idx = tid; idx < total; idx += nth, ++i) {
+      int c, e;
+      walk.at(idx, i, c, e);
+      const long long l = l0b + c;
+      cplx<T> v = mk<T>((T)0, (T)0);
+      if (l < nl) {
+        const long long q = l / L.nparent, l0 = l - q * L.nparent;
+        const long long bs = (l0 / L.inner_s) * L.outer_s + l0 % L.inner_s + q * L.sub_s;
+        v = src[bs + e * L.stride_s];
+        if (L.tw_n > 0) {
+          const long long t = ((long long)e * q) % L.tw_n;
+          cplx<T> w = root[t * L.tw_step];
+          if (L.sign < 0) w.y = -w.y;
+          v = mk<T>(v.x * w.x - v.y * w.y, v.x * w.y + v.y * w.x);
+        }
+      }
+      a[generic_pos(L.ax, e) * TC + c] = v;
+    }
   }
   sync();
   const cplx<T>* r = generic_line_fft<T>(a, b, L.ax, TC, TC, rt, rs, L.sign, tid, nth, sync);

@@ -254,7 +254,8 @@ def test_generic_mixed_radix_transforms_against_numpy(shape):
     block sizes are part of the case."""
     rng = np.random.RandomState(5)
     nx, ny, nz = shape
-    for ct, rt, tol in ((np.complex64, np.float32, 3e-6), (np.complex128, np.float64, 3e-14)):
+    for tile, (ct, rt, tol) in [(t, c) for t in (3, 1) for c in ((np.complex64, np.float32, 3e-6), (np.complex128, np.float64, 3e-14))]:
+        emu_util.lib().emu_set_generic_tile(tile)            # 1: a thread stays on one line (the kernels' walk), 3: walks by index
         ks = (rng.normal(size=(nx, ny, nz // 2 + 1)) + 1j * rng.normal(size=(nx, ny, nz // 2 + 1))).astype(ct)
         out, s1, s2 = emu_util.generic_c2r(ks)
         ref = np.fft.irfftn(ks.astype(np.complex128), s=shape, axes=(0, 1, 2))
@@ -268,6 +269,7 @@ def test_generic_mixed_radix_transforms_against_numpy(shape):
         for inverse, fn in ((False, np.fft.fftn), (True, np.fft.ifftn)):
             ref = fn(a.astype(np.complex128))
             assert np.max(np.abs(emu_util.generic_c2c(a, inverse) - ref)) <= tol * np.abs(ref).std() * 4
+    emu_util.lib().emu_set_generic_tile(3)
 
 
 @pytest.mark.parametrize("name", ["stages_4x6x8_c64.npz", "stages_6x4x12_c64.npz", "stages_4x6x8_c128.npz"])
@@ -498,7 +500,10 @@ def test_axes_too_long_for_one_line_take_the_four_step_form(shape, cap):
     nx, ny, nz = shape
     old = emu_util.lib().emu_set_generic_cap(cap)
     try:
-        for ct, rt, tol in ((np.complex64, np.float32, 4e-6), (np.complex128, np.float64, 4e-14)):
+        # (tile 3: lines per block that divide nothing, threads walking by index; tile 1: the kernels' own walk -- a thread stays on
+        # one line, loads four elements per trip and advances the twiddle index instead of reducing e q mod n per element)
+        for tile, (ct, rt, tol) in [(t, c) for t in (3, 1) for c in ((np.complex64, np.float32, 4e-6), (np.complex128, np.float64, 4e-14))]:
+            emu_util.lib().emu_set_generic_tile(tile)
             ks = (rng.normal(size=(nx, ny, nz // 2 + 1)) + 1j * rng.normal(size=(nx, ny, nz // 2 + 1))).astype(ct)
             out, s1, s2 = emu_util.generic_c2r(ks)
             ref = np.fft.irfftn(ks.astype(np.complex128), s=shape, axes=(0, 1, 2))
@@ -514,3 +519,4 @@ def test_axes_too_long_for_one_line_take_the_four_step_form(shape, cap):
                 assert np.max(np.abs(emu_util.generic_c2c(a, inverse) - ref)) <= tol * np.abs(ref).std() * 4
     finally:
         emu_util.lib().emu_set_generic_cap(old)
+        emu_util.lib().emu_set_generic_tile(3)
