@@ -1388,12 +1388,14 @@ def test_generic_shapes_against_oracle(hip, dpower, shape):
         plan.close()
 
 
-def test_generic_shape_generator_api(hip, dpower):
-    """The drop-in Generator at the reference's (40, 60, 80): default call (save_potential=True, the reference's
+@pytest.mark.parametrize("shape", [(40, 60, 80), (16384, 4, 8), (4, 9000, 8), (4, 6, 16400)])
+def test_generic_shape_generator_api(hip, dpower, shape):
+    """The drop-in Generator at the reference's (40, 60, 80) -- and on grids with one axis in the four-step form (x, y, and the
+    contiguous axis of the packed plan: nz / 2 = 8200 points): default call (save_potential=True, the reference's
     stream replayed on the GPU), Newtonian potential, density and lensing against this repo's numpy backend, which
     is pinned to the reference on the CPU."""
     from randomfield_amd import Generator
-    nx, ny, nz = 40, 60, 80
+    nx, ny, nz = shape
     z = np.linspace(0, 0.1, nz)
     kw = dict(growth_function=np.exp(-z), mean_matter_density=1 + z, redshifts=z,
               transverse_distance=np.arange(nz) * 2.5)
