@@ -514,14 +514,14 @@ template <typename T> struct EmuGenericOps {
   const cplx<T>* root(int which) const { return which == 0 ? rx : (which == 1 ? ry : rz); }
   int axis(const void* src, void* dst, const GenericAxis& ax, long long stride, long long inner, long long outer, long long nlines, int which, int sign, double scale) {
     const int TC = g_generic_tile;
-    lds.resize(2 * (size_t)ax.n * TC + ax.n);
+    lds.resize(2 * (size_t)ax.n * TC + 2 * ax.n + 4);
     for (long long b = 0; b * TC < nlines; ++b)
       generic_axis_block<T>((const cplx<T>*)src, (cplx<T>*)dst, ax, stride, inner, outer, nlines, TC, root(which), sign, (T)scale, lds.data(), b, 0, 1, NoSync(), 1);
     return 0;
   }
   int lines(const void* src, void* dst, const GenericLines& L, int which) {
     const int TC = g_generic_tile;
-    lds.resize(2 * (size_t)L.ax.n * TC + L.ax.n);
+    lds.resize(2 * (size_t)L.ax.n * TC + 2 * L.ax.n + 4);
     for (long long b = 0; b * TC < L.nlines(); ++b)
       generic_lines_block<T>((const cplx<T>*)src, (cplx<T>*)dst, L, TC, root(which), lds.data(), b, 0, 1, NoSync(), 1);
     return 0;
@@ -529,14 +529,14 @@ template <typename T> struct EmuGenericOps {
   GenericAxis az;
   int row_c2r(const void* G, void* W, double scale) {
     const int TR = 2;
-    lds.resize(2 * (size_t)az.n * generic_row_pitch(TR) + az.n);
+    lds.resize(2 * (size_t)az.n * generic_row_pitch(TR) + 2 * az.n + 4);
     for (long long b = 0; b * TR < rows; ++b)
       generic_row_c2r_block<T>((const cplx<T>*)G, (T*)W, az, rows, TR, rz, (T)scale, lds.data(), b, 0, 1, NoSync(), s1, s2, 1);
     return 0;
   }
   int row_r2c(const void* W, void* G) {
     const int TR = 2;
-    lds.resize(2 * (size_t)az.n * generic_row_pitch(TR) + az.n);
+    lds.resize(2 * (size_t)az.n * generic_row_pitch(TR) + 2 * az.n + 4);
     for (long long b = 0; b * TR < rows; ++b) generic_row_r2c_block<T>((const T*)W, (cplx<T>*)G, az, rows, TR, rz, lds.data(), b, 0, 1, NoSync(), 1);
     return 0;
   }

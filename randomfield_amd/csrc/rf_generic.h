@@ -45,6 +45,9 @@ inline bool generic_factor(int n, GenericAxis& ax) {
   auto push = [&](int r) { if (ax.nf < GENERIC_MAX_FACTORS) ax.f[ax.nf] = r; ++ax.nf; m /= r; };
   while (m % 4 == 0) push(4);
   while (m % 2 == 0) push(2);
+  // a 4 and the lone 2 behind it as ONE radix-8 stage (a radix-2 stage costs as much index arithmetic per butterfly as a radix-4 one,
+  // for half the elements)
+  if (ax.nf >= 2 && ax.nf <= GENERIC_MAX_FACTORS && ax.f[ax.nf - 1] == 2 && ax.f[ax.nf - 2] == 4) { ax.f[ax.nf - 2] = 8; --ax.nf; }
   for (int p = 3; p * p <= m; p += 2)
     while (m % p == 0) push(p);
   if (m > 1) push(m);
@@ -53,7 +56,7 @@ inline bool generic_factor(int n, GenericAxis& ax) {
   int Ns = 1;
   for (int s = 0; s < GENERIC_MAX_FACTORS; ++s) {
     if (s >= ax.nf) { ax.f[s] = 1; ax.w[s] = n; ax.fm[s] = 0; ax.wm[s] = generic_magic((unsigned)n); continue; }
-    if (ax.f[s] > 5) ax.smooth = 0;
+    if (ax.f[s] > 5 && ax.f[s] != 8) ax.smooth = 0;
     ax.w[s] = Ns;
     ax.fm[s] = generic_magic((unsigned)ax.f[s]);
     ax.wm[s] = generic_magic((unsigned)Ns);
@@ -134,7 +137,7 @@ RF_HD void generic_stage_any(const cplx<T>* in, cplx<T>* out, int n, int TC, int
   }
 }
 
-// Radices 2, 3, 4, 5 (all but the large prime factors of an axis): one thread per BUTTERFLY -- R inputs, their R - 1 twiddles
+// Radices 2, 3, 4, 5, 8 (all but the large prime factors of an axis): one thread per BUTTERFLY -- R inputs, their R - 1 twiddles
 // w^(r k) (one table read each; none in the first stage, where k = 0), the R-point transform in registers, R outputs.  Per element one
 // LDS read, one LDS write and at most one table read, where the form above has R of each.  sg = +1 / -1: the sign of the exponent.
 template <typename T> RF_HD cplx<T> gmul(const cplx<T>& a, const cplx<T>& w, T sg) {
@@ -161,6 +164,19 @@ template <typename T, int R> RF_HD void generic_dft(cplx<T>* y, T sg) {
     const cplx<T> t2 = mk<T>(y[0].x - (T)0.5 * t1.x, y[0].y - (T)0.5 * t1.y), t3 = mk<T>(h * d.x, h * d.y);
     y[0] = gadd(y[0], t1);
     y[1] = gadd_i(t2, t3, sg); y[2] = gsub_i(t2, t3, sg);
+  } else if (R == 8) {
+    // even / odd halves through the 4-point transform, then X[k] = a[k] + w8^k b[k], X[k + 4] = a[k] - w8^k b[k], w8 = exp(sg 2 pi i / 8)
+    const T h = (T)0.70710678118654752440;
+    cplx<T> a[4] = {y[0], y[2], y[4], y[6]}, b[4] = {y[1], y[3], y[5], y[7]};
+    generic_dft<T, 4>(a, sg);
+    generic_dft<T, 4>(b, sg);
+    const cplx<T> b1 = mk<T>(h * (b[1].x - sg * b[1].y), h * (b[1].y + sg * b[1].x));          // w8   b[1]
+    const cplx<T> b2 = mk<T>(-sg * b[2].y, sg * b[2].x);                                          // w8^2 b[2] = sg i b[2]
+    const cplx<T> b3 = mk<T>(h * (-b[3].x - sg * b[3].y), h * (-b[3].y + sg * b[3].x));        // w8^3 b[3]
+    y[0] = gadd(a[0], b[0]); y[4] = gsub(a[0], b[0]);
+    y[1] = gadd(a[1], b1);   y[5] = gsub(a[1], b1);
+    y[2] = gadd(a[2], b2);   y[6] = gsub(a[2], b2);
+    y[3] = gadd(a[3], b3);   y[7] = gsub(a[3], b3);
   } else {                                         // R == 5
     const T c1 = (T)0.30901699437494742410, c2 = (T)-0.80901699437494742410;       // cos(2 pi / 5), cos(4 pi / 5)
     const T s1 = (T)0.95105651629515357212, s2 = (T)0.58778525229247312917;        // sin(2 pi / 5), sin(4 pi / 5)
@@ -204,7 +220,7 @@ RF_HD void generic_stage_r(const cplx<T>* in, cplx<T>* out, int n, int TC, int P
   }
 }
 
-// ---- axes whose radices are all among 2, 3, 4, 5 ("smooth": every power-of-two times 3^a 5^b length): IN PLACE, one buffer.
+// ---- axes whose radices are all among 2, 3, 4, 5, 8 ("smooth": every power-of-two times 3^a 5^b length): IN PLACE, one buffer.
 // Decimation in time on a line stored in digit-reversed order: stage s (radix R, Ns = product of the radices before it) finds the R
 // sub-transforms of length Ns it combines in the R consecutive runs of Ns positions of one block of Ns R, and leaves the block's
 // transform in those same positions -- butterflies touch disjoint positions, so a stage needs no second buffer and the line needs
@@ -265,6 +281,7 @@ RF_HD void generic_stage(const cplx<T>* in, cplx<T>* out, int n, int TC, int P, 
     case 3: generic_stage_r<T, 3>(in, out, n, TC, P, Ns, Nsm, root, rstep, sign, tid, nth); break;
     case 4: generic_stage_r<T, 4>(in, out, n, TC, P, Ns, Nsm, root, rstep, sign, tid, nth); break;
     case 5: generic_stage_r<T, 5>(in, out, n, TC, P, Ns, Nsm, root, rstep, sign, tid, nth); break;
+    case 8: generic_stage_r<T, 8>(in, out, n, TC, P, Ns, Nsm, root, rstep, sign, tid, nth); break;
     default: generic_stage_any<T>(in, out, n, TC, P, R, Ns, root, rstep, sign, tid, nth);
   }
 }
@@ -282,6 +299,7 @@ RF_HD cplx<T>* generic_line_fft(cplx<T>* a, cplx<T>* b, const GenericAxis& ax, i
         case 2: generic_stage_inplace<T, 2>(a, ax.n, TC, P, Ns, ax.wm[s], root, rstep, sign, tid, nth); break;
         case 3: generic_stage_inplace<T, 3>(a, ax.n, TC, P, Ns, ax.wm[s], root, rstep, sign, tid, nth); break;
         case 4: generic_stage_inplace<T, 4>(a, ax.n, TC, P, Ns, ax.wm[s], root, rstep, sign, tid, nth); break;
+        case 8: generic_stage_inplace<T, 8>(a, ax.n, TC, P, Ns, ax.wm[s], root, rstep, sign, tid, nth); break;
         default: generic_stage_inplace<T, 5>(a, ax.n, TC, P, Ns, ax.wm[s], root, rstep, sign, tid, nth);
       }
       sync();
@@ -308,8 +326,20 @@ RF_HD const cplx<T>* generic_stage_table(int tw_lds, cplx<T>* lds_tw, const cplx
   rstep = 1;
   return lds_tw;                                   // (the caller's barrier before the first stage covers these writes)
 }
-// elements of LDS a block function needs: the line image(s) of pitch P and, with tw_lds, the stage table
-RF_HD long long generic_lds_elems(const GenericAxis& ax, int P, int tw_lds) { return (long long)generic_bufs(ax) * ax.n * P + (tw_lds ? ax.n : 0); }
+// ... and, behind the stage table, generic_pos as a table of n 16-bit entries (smooth axes; `tw_lds` switches both on): the digit
+// reversal is ~5 instructions per radix and element when computed, one LDS read when looked up.  The caller puts a barrier between
+// this and the first use.  nullptr: compute.
+template <typename T>
+RF_HD const uint16_t* generic_pos_table(int tw_lds, cplx<T>* behind_stage_table, const GenericAxis& ax, int tid, int nth) {
+  if (!tw_lds || !ax.smooth) return nullptr;
+  uint16_t* pt = reinterpret_cast<uint16_t*>(behind_stage_table);
+  for (int t = tid; t < ax.n; t += nth) pt[t] = (uint16_t)generic_pos(ax, t);
+  return pt;
+}
+// bytes of LDS behind the line image(s) when tw_lds is on: the stage table and the position table
+inline size_t generic_extra_bytes(const GenericAxis& ax, int elem_bytes) {
+  return (size_t)ax.n * elem_bytes + (ax.smooth ? (((size_t)ax.n * 2 + 15) & ~(size_t)15) : 0);
+}
 
 // Strided (or contiguous) complex pass: block `blk` transforms lines [blk TC, blk TC + TC) of length ax.n;
 // line l starts at (l / inner) * outer + l % inner and its elements are `stride` apart.  src == dst is allowed
@@ -324,6 +354,8 @@ RF_HD void generic_axis_block(const cplx<T>* src, cplx<T>* dst, const GenericAxi
   const GenericWalk walk(n, TC, tid, nth);
   int rs = 1;
   const cplx<T>* rt = generic_stage_table<T>(tw_lds, lds + generic_bufs(ax) * total, root, n, rs, tid, nth);
+  const uint16_t* ptab = generic_pos_table<T>(tw_lds, lds + generic_bufs(ax) * total + n, ax, tid, nth);
+  if (ptab) sync();
   // (a thread that stays on one line forms that line's base once: the 64-bit division is ~100 instructions)
   const long long lf = l0 + walk.c0;
   const long long basef = walk.fixed && lf < nlines ? (lf / inner) * outer + lf % inner : 0;
@@ -343,7 +375,7 @@ RF_HD void generic_axis_block(const cplx<T>* src, cplx<T>* dst, const GenericAxi
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int ee = e + u * walk.estep;
-        if (ee < n) a[generic_pos(ax, ee) * TC + walk.c0] = v[u];
+        if (ee < n) a[(ptab ? (int)ptab[ee] : generic_pos(ax, ee)) * TC + walk.c0] = v[u];
       }
     }
   } else {
@@ -353,19 +385,32 @@ RF_HD void generic_axis_block(const cplx<T>* src, cplx<T>* dst, const GenericAxi
       const long long l = l0 + c;
       cplx<T> v = mk<T>((T)0, (T)0);
       if (l < nlines) v = src[(l / inner) * outer + l % inner + e * stride];
-      a[generic_pos(ax, e) * TC + c] = v;
+      a[(ptab ? (int)ptab[e] : generic_pos(ax, e)) * TC + c] = v;
     }
   }
   sync();
   const cplx<T>* r = generic_line_fft<T>(a, b, ax, TC, TC, rt, rs, sign, tid, nth, sync);
-  i = 0;
-  for (int idx = tid; idx < total; idx += nth, ++i) {
-    int c, e;
-    walk.at(idx, i, c, e);
-    const long long l = l0 + c;
-    if (l < nlines) {
-      const cplx<T> v = r[idx];
-      dst[(walk.fixed ? basef : (l / inner) * outer + l % inner) + e * stride] = mk<T>(v.x * scale, v.y * scale);
+  if (walk.fixed) {
+    if (lf < nlines) {
+      cplx<T>* pd = dst + basef + walk.e0 * stride;
+      const long long step = walk.estep * stride;
+      const cplx<T>* pr = r + walk.e0 * TC + walk.c0;
+      const int rstepl = walk.estep * TC;
+      for (int e = walk.e0; e < n; e += walk.estep, pd += step, pr += rstepl) {
+        const cplx<T> v = *pr;
+        *pd = mk<T>(v.x * scale, v.y * scale);
+      }
+    }
+  } else {
+    i = 0;
+    for (int idx = tid; idx < total; idx += nth, ++i) {
+      int c, e;
+      walk.at(idx, i, c, e);
+      const long long l = l0 + c;
+      if (l < nlines) {
+        const cplx<T> v = r[idx];
+        dst[(l / inner) * outer + l % inner + e * stride] = mk<T>(v.x * scale, v.y * scale);
+      }
     }
   }
 }
@@ -389,6 +434,8 @@ RF_HD void generic_row_c2r_block(const cplx<T>* G, T* W, const GenericAxis& ax, 
   cplx<T>*a = lds, *b = lds + M * P;
   int rs = 2;
   const cplx<T>* rt = generic_stage_table<T>(tw_lds, lds + generic_bufs(ax) * M * P, root, M, rs, tid, nth);
+  const uint16_t* ptab = generic_pos_table<T>(tw_lds, lds + generic_bufs(ax) * M * P + M, ax, tid, nth);
+  if (ptab) sync();
   const FastDiv dM((uint32_t)M);
   // four elements per trip, their loads issued before the first is used (see generic_axis_block)
   for (int idx0 = tid; idx0 < total; idx0 += 4 * nth) {
@@ -419,7 +466,7 @@ RF_HD void generic_row_c2r_block(const cplx<T>* G, T* W, const GenericAxis& ax, 
         // e + i w o
         z = mk<T>(er - (w.x * oi + w.y * orr), ei + (w.x * orr - w.y * oi));
       }
-      a[generic_pos(ax, kk[u]) * P + cc[u]] = z;
+      a[(ptab ? (int)ptab[kk[u]] : generic_pos(ax, kk[u])) * P + cc[u]] = z;
     }
   }
   sync();
@@ -450,6 +497,8 @@ RF_HD void generic_row_r2c_block(const T* W, cplx<T>* G, const GenericAxis& ax, 
   cplx<T>*a = lds, *b = lds + M * P;
   int rs = 2;
   const cplx<T>* rt = generic_stage_table<T>(tw_lds, lds + generic_bufs(ax) * M * P, root, M, rs, tid, nth);
+  const uint16_t* ptab = generic_pos_table<T>(tw_lds, lds + generic_bufs(ax) * M * P + M, ax, tid, nth);
+  if (ptab) sync();
   const FastDiv dM((uint32_t)M), dM1((uint32_t)(M + 1));
   for (int idx = tid; idx < total; idx += nth) {
     uint32_t cq, mr;
@@ -460,7 +509,7 @@ RF_HD void generic_row_r2c_block(const T* W, cplx<T>* G, const GenericAxis& ax, 
       const T* in = W + (r0 + c) * (long long)(2 * M) + 2 * m;
       z = mk<T>(in[0], in[1]);
     }
-    a[generic_pos(ax, m) * P + c] = z;
+    a[(ptab ? (int)ptab[m] : generic_pos(ax, m)) * P + c] = z;
   }
   sync();
   const cplx<T>* r = generic_line_fft<T>(a, b, ax, TR, P, rt, rs, -1, tid, nth, sync);
@@ -551,6 +600,8 @@ RF_HD void generic_lines_block(const cplx<T>* src, cplx<T>* dst, const GenericLi
   const GenericWalk walk(n, TC, tid, nth);
   int rs = L.rstep;
   const cplx<T>* rt = generic_stage_table<T>(tw_lds, lds + generic_bufs(L.ax) * total, root, n, rs, tid, nth);
+  const uint16_t* ptab = generic_pos_table<T>(tw_lds, lds + generic_bufs(L.ax) * total + n, L.ax, tid, nth);
+  if (ptab) sync();
   // (a thread that stays on one line forms that line's sub-line index and bases once)
   long long qf = 0, bsf = 0, bdf = 0;
   if (walk.fixed && l0b + walk.c0 < nl) {
@@ -592,7 +643,7 @@ RF_HD void generic_lines_block(const cplx<T>* src, cplx<T>* dst, const GenericLi
           if (L.sign < 0) ww.y = -ww.y;
           x = mk<T>(x.x * ww.x - x.y * ww.y, x.x * ww.y + x.y * ww.x);
         }
-        a[generic_pos(L.ax, ee) * TC + walk.c0] = x;
+        a[(ptab ? (int)ptab[ee] : generic_pos(L.ax, ee)) * TC + walk.c0] = x;
       }
     }
   } else {
@@ -612,7 +663,7 @@ RF_HD void generic_lines_block(const cplx<T>* src, cplx<T>* dst, const GenericLi
           v = mk<T>(v.x * w.x - v.y * w.y, v.x * w.y + v.y * w.x);
         }
       }
-      a[generic_pos(L.ax, e) * TC + c] = v;
+      a[(ptab ? (int)ptab[e] : generic_pos(L.ax, e)) * TC + c] = v;
     }
   }
   sync();
@@ -681,7 +732,7 @@ RF_HD void generic_tangle_at(const cplx<T>* Z, cplx<T>* G, int M, const cplx<T>*
 // tile up to 16 whose image(s) and stage table fit a CU's LDS (rf_k_generic.hip strided_shape launches exactly this).  Below 4 lines
 // the segments are 16 bytes of complex64 and a pass moves a fraction of what the memory system can: generic_prefers_split.
 inline int generic_strided_tile(const GenericAxis& ax, int elem_bytes) {
-  auto lds = [&](int tc) { return ((long long)generic_bufs(ax) * ax.n * tc + ax.n) * elem_bytes; };
+  auto lds = [&](int tc) { return (long long)generic_bufs(ax) * ax.n * tc * elem_bytes + (long long)generic_extra_bytes(ax, elem_bytes); };
   int tc = 16;
   while (tc > 1 && lds(tc) > (long long)GENERIC_LDS_MAX) tc >>= 1;
   return tc;
@@ -759,7 +810,7 @@ int generic_c2c_seq(Ops& ops, const GenericDims& d, void* D, void* G, int sign, 
 // that (n > 4096 complex64 / 2048 complex128) takes what it needs, up to GENERIC_LDS_MAX
 inline int generic_lines_per_block(int n, int elem_bytes, int want, long long budget = 65536, int bufs = 2, bool row_pitch = false) {
   int tc = want;
-  while (tc > 1 && ((long long)bufs * n * (row_pitch ? generic_row_pitch(tc) : tc) + n) * elem_bytes > budget) tc >>= 1;     // (+ n: the stage table)
+  while (tc > 1 && ((long long)bufs * n * (row_pitch ? generic_row_pitch(tc) : tc) + n) * elem_bytes + 2LL * n + 16 > budget) tc >>= 1;     // (+ the stage and position tables)
   return tc;
 }
 

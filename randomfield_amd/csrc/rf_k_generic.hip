@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void generic_moments_kernel(const T* __restric
 struct StridedShape { int tc, threads; size_t lds; int tw_lds; };
 inline StridedShape strided_shape(const GenericAxis& ax, int es, bool neighbours) {
   const int n = ax.n, bufs = generic_bufs(ax);
-  auto lds = [&](int tc) { return ((size_t)bufs * n * tc + n) * es; };            // (+ n: the stage table, generic_stage_table)
+  auto lds = [&](int tc) { return (size_t)bufs * n * tc * es + generic_extra_bytes(ax, es); };      // (+ the stage and position tables)
   int tc = neighbours ? generic_strided_tile(ax, es) : 4;
   while (tc > 1 && lds(tc) > (size_t)GENERIC_LDS_MAX) tc >>= 1;
   if (lds(tc) > (size_t)GENERIC_LDS_MAX) return {1, 256, (size_t)bufs * n * es, 0};   // the longest lines that are not smooth: no room for the table
@@ -181,7 +181,7 @@ namespace {
 struct RowShape { int tr; size_t lds; int tw_lds; };
 template <typename T> RowShape row_shape(const GenericAxis& ax) {
   const int tr = rows_per_block<T>(ax);
-  const size_t base = (size_t)generic_bufs(ax) * ax.n * generic_row_pitch(tr) * sizeof(cplx<T>), with = base + (size_t)ax.n * sizeof(cplx<T>);
+  const size_t base = (size_t)generic_bufs(ax) * ax.n * generic_row_pitch(tr) * sizeof(cplx<T>), with = base + generic_extra_bytes(ax, (int)sizeof(cplx<T>));
   const int tw = with <= (size_t)GENERIC_LDS_MAX ? 1 : 0;
   return {tr, tw ? with : base, tw};
 }
