@@ -239,6 +239,12 @@ def other_configs(power, spacing, device, only=None):
         for v in sub.values():
             v["note_process"] = "measured in the bench process (child process failed: %s)" % e
         out.update(sub)
+    # a grid that is NOT a power of two (transform.py:172-177 accepts any even shape): the generic mixed-radix kernels;
+    # k space is materialised there -- 7 sweeps of the half spectrum instead of 5 -- and no roofline claim is made for the path
+    plan = plan_for(1000, np.complex64)
+    t = _timed(lambda: plan.realise(seed=next(seeds)), plan.sync, reps=3, warm=1)
+    out["1000^3 f32, not a power of two (generic kernels)"] = entry(1000, t, 28 * (1 + 2 / 1000), tiled=bool(plan.tiled))
+    plan.close()
     # config 4's grid on ONE GPU (34 GB): its per-GPU kernels at full axis length -- the length-2048 strided passes run as two
     # 1024-point transforms per tile; the 8-GPU job itself is `bench.py --gpus 8`
     plan = plan_for(2048, np.complex64)
