@@ -445,7 +445,9 @@ def main_multi(args, rank, world, local_rank, shape, power, spacing):
     if mode in ("direct", "rccl"):
         other = "rccl" if mode == "direct" else "direct"
         try:
-            if set_mode(other):
+            if other not in calib:          # (only a mode that came through its calibration a moment ago: nothing here may cost the line)
+                cross = {"other_mode": other, "agree": None, "note": "the other mode was not calibrated in this job (rejected, or the mode was forced)"}
+            elif set_mode(other):
                 with dplan.deadline("cross-check through the %s exchange" % other):
                     r = plan.realise_batch(np.array([123 + args.steps - 1], dtype=np.uint64), want_rms=True)
                     plan.sync()
